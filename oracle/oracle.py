@@ -1,0 +1,165 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes loaders for the CPU checkers.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (crackle_amd/) never does.
+
+Two checkers share one calling convention:
+  * ``ref``    — oracle/_ref/libcrackle_ref.so: the reference's own header-only C++
+                 compiled in place by ``make -C oracle ref`` (binary travels to the
+                 GPU box; sources do not).
+  * ``port``   — oracle/libckl_oracle.so: this repo's plain-C restatement
+                 (oracle/ckl_oracle.c), pinned byte-for-byte against ``ref`` and the
+                 committed golden fixtures.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_REF_SO = os.path.join(HERE, "_ref", "libcrackle_ref.so")
+_PORT_SO = os.path.join(HERE, "libckl_oracle.so")
+
+
+def build(which=("oracle", "ref")):
+  for target in which:
+    subprocess.run(["make", "-s", "-C", HERE, target], check=True)
+
+
+class _Checker:
+  def __init__(self, path, prefix, kind):
+    self.path = path
+    self.kind = kind
+    self.lib = C.CDLL(path)
+    self.prefix = prefix
+    L = self.lib
+    f = getattr(L, prefix + "compress")
+    f.restype = C.c_int
+    f.argtypes = [
+      C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+      C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_uint64,
+      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+    ]
+    self._compress = f
+    f = getattr(L, prefix + "decompress")
+    f.restype = C.c_int
+    f.argtypes = [
+      C.c_char_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64,
+      C.c_int, C.c_uint64,
+    ]
+    self._decompress = f
+    f = getattr(L, prefix + "free")
+    f.restype = None
+    f.argtypes = [C.c_void_p]
+    self._free = f
+    f = getattr(L, prefix + "last_error")
+    f.restype = C.c_char_p
+    self._err = f
+    f = getattr(L, prefix + "connected_components")
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                  C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    self._cc = f
+    f = getattr(L, prefix + "slice_vcg")
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_void_p]
+    self._vcg = f
+    f = getattr(L, prefix + "crc32c")
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_char_p, C.c_uint64]
+    self._crc = f
+
+  # -- reference-shaped surface (fastcrackle.compress/decompress semantics) --
+  def compress(self, labels, allow_pins=False, fortran_order=None, markov_model_order=0,
+               optimize_pins=False, auto_bgcolor=True, manual_bgcolor=0, parallel=1):
+    """labels: any-order ndarray; converted like crackle/codec.py:723-724."""
+    if fortran_order is None:
+      fortran_order = bool(labels.flags.f_contiguous)
+    labels = np.asfortranarray(labels)
+    shape = list(labels.shape) + [1] * (3 - labels.ndim)
+    out = C.c_void_p()
+    n = C.c_uint64()
+    rc = self._compress(
+      labels.ctypes.data, labels.dtype.itemsize, int(labels.dtype.kind == "i"),
+      shape[0], shape[1], shape[2], int(bool(allow_pins)), int(fortran_order),
+      int(markov_model_order), int(optimize_pins), int(auto_bgcolor),
+      int(manual_bgcolor), int(parallel), C.byref(out), C.byref(n))
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    try:
+      return C.string_at(out.value, n.value)
+    finally:
+      self._free(out)
+
+  def decompress(self, binary, z_start=0, z_end=-1, parallel=1, label=None):
+    """Returns the 1-D array fastcrackle.decompress would (x fastest for F streams)."""
+    binary = bytes(binary)
+    fmt = int.from_bytes(binary[5:7], "little")
+    dw = 1 << (fmt & 3)
+    sx = int.from_bytes(binary[7:11], "little")
+    sy = int.from_bytes(binary[11:15], "little")
+    sz = int.from_bytes(binary[15:19], "little")
+    zs = max(z_start, 0)
+    ze = sz if z_end == -1 else min(max(z_end, 0), sz)
+    dtype = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[dw]
+    if label is not None:
+      dtype = np.uint8
+    out = np.zeros(sx * sy * max(ze - zs, 0), dtype=dtype)
+    rc = self._decompress(binary, len(binary), out.ctypes.data, z_start, z_end,
+                          int(parallel), int(label is not None), int(label or 0))
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    return out
+
+  def connected_components(self, labels):
+    labels = np.asfortranarray(labels)
+    sx, sy, sz = labels.shape
+    cc = np.zeros(sx * sy * sz, dtype=np.uint32)
+    per = np.zeros(sz, dtype=np.uint64)
+    N = C.c_uint64()
+    rc = self._cc(labels.ctypes.data, labels.dtype.itemsize, sx, sy, sz,
+                  cc.ctypes.data, per.ctypes.data, C.byref(N))
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    return cc.reshape((sx, sy, sz), order="F"), per, N.value
+
+  def slice_vcg(self, binary, z):
+    binary = bytes(binary)
+    sx = int.from_bytes(binary[7:11], "little")
+    sy = int.from_bytes(binary[11:15], "little")
+    out = np.zeros(sx * sy, dtype=np.uint8)
+    rc = self._vcg(binary, len(binary), z, out.ctypes.data)
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    return out.reshape((sx, sy), order="F")
+
+  def crc32c(self, data):
+    data = bytes(data)
+    return int(self._crc(data, len(data)))
+
+
+_cache = {}
+
+
+def ref():
+  """The compiled reference (None if oracle/_ref was never built)."""
+  if "ref" not in _cache:
+    _cache["ref"] = (
+      _Checker(_REF_SO, "ckl_ref_", "reference") if os.path.exists(_REF_SO) else None
+    )
+  return _cache["ref"]
+
+
+def port():
+  """This repo's plain-C restatement (built on demand)."""
+  if "port" not in _cache:
+    if not os.path.exists(_PORT_SO):
+      build(("oracle",))
+    _cache["port"] = _Checker(_PORT_SO, "ckl_oracle_", "port")
+  return _cache["port"]
+
+
+def best():
+  """Strongest available checker: the compiled reference, else the restatement."""
+  return ref() or port()
