@@ -1,0 +1,52 @@
+/* TEST INFRASTRUCTURE ONLY — plain-C CPU restatement of the crackle
+ * compress()/decompress() path (seung-lab/crackle, src/crackle.hpp).
+ *
+ * This is the parity checker ("oracle") for the HIP product in crackle_amd/.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  Parity status: PINNED — byte-identical to the compiled reference
+ * (oracle/_ref) over the golden grid in tests/golden/ (see tests/gen_golden.py)
+ * and to the reference's known-answer vectors.
+ */
+#ifndef CKL_ORACLE_H
+#define CKL_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ckl_oracle_last_error(void);
+void ckl_oracle_free(void* p);
+
+/* mirrors crackle::compress<LABEL> (src/crackle.hpp:220-257); labels x-fastest */
+int ckl_oracle_compress(
+	const void* labels, int dtype_bytes, int is_signed,
+	int64_t sx, int64_t sy, int64_t sz,
+	int allow_pins, int fortran_order, uint64_t markov_order,
+	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
+	uint64_t parallel, unsigned char** out, uint64_t* out_len);
+
+/* mirrors crackle::decompress<LABEL,OUT> (src/crackle.hpp:503-663) */
+int ckl_oracle_decompress(
+	const unsigned char* buf, uint64_t n, void* out,
+	int64_t z_start, int64_t z_end, uint64_t parallel,
+	int has_label, uint64_t label);
+
+/* mirrors crackle::cc3d::connected_components (src/cc3d.hpp:371-400) */
+int ckl_oracle_connected_components(
+	const void* labels, int dtype_bytes,
+	int64_t sx, int64_t sy, int64_t sz,
+	uint32_t* cc_out, uint64_t* per_slice, uint64_t* N);
+
+/* mirrors crackle::crack_code_to_vcg (src/crackle.hpp:414-425) for slice z */
+int ckl_oracle_slice_vcg(
+	const unsigned char* buf, uint64_t n, int64_t z, uint8_t* vcg_out);
+
+/* mirrors crackle::crc::crc32c (src/crc.hpp:51-57) */
+uint32_t ckl_oracle_crc32c(const uint8_t* data, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
