@@ -1,0 +1,110 @@
+"""Pins the oracle (oracle/ckl_oracle.c) to the reference: known-answer vectors from
+SURVEY.md Appendix C, the committed golden fixtures (bytes produced by the reference
+itself, tests/gen_golden.py), and — where oracle/_ref exists — the live reference."""
+import numpy as np
+import pytest
+
+import golden_cases
+from util import golden, manifest, label_format, flat_1d, sha
+
+SMALL = golden_cases.small_cases()
+LARGE = golden_cases.large_cases()
+
+KAT = {
+  # SURVEY.md Appendix C (reference output, whole files)
+  "kat_4x4": "63726b6c0180000400000004000000010000001f0d000000000000002a0b00000018a101dc"
+             "02000000000000000007020001040000000101010132330beabcfb79c99303a6",
+  "kat_4x4_m1": "63726b6c0180020400000004000000010000001f0d00000000000000e70a000000a00b4401"
+                "02000000000000000007020001f7960104000000010101010204eabcfb79c99303a6",
+  "kat_ones_300": "63726b6c0182002c0100002c010000020000001f13000000000000005c0600000006000000dbd808fb"
+                  "01000000000000000101000000010000000000020000000000020000000000c7c4bfbff75103d8f75103d8",
+}
+
+
+def test_crc32c_check_value(port):
+  assert port.crc32c(b"123456789") == 0xE3069283
+  assert port.crc32c(b"") == 0
+
+
+@pytest.mark.parametrize("name", sorted(KAT))
+def test_known_answer_vectors(port, name):
+  arr, kw = SMALL[name]
+  assert port.compress(arr, **kw).hex() == KAT[name]
+  assert golden()[name].hex() == KAT[name]
+
+
+def test_kat_c_order_header(port):
+  b = port.compress(SMALL["kat_4x4_c"][0])
+  f = port.compress(SMALL["kat_4x4"][0])
+  assert b[5] == 0x00 and f[5] == 0x80 and b[28] == 0x8D
+  assert b[29:] == f[29:]
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_golden_small(port, name):
+  arr, kw = SMALL[name]
+  want = golden()[name]
+  if label_format(want) == 0 or arr.size == 0:
+    assert port.compress(arr, parallel=2, **kw) == want
+  # TODO(pins encode restatement): pin-format streams are only decoded by the port
+  if arr.size:
+    got = port.decompress(want, parallel=2)
+    assert np.array_equal(got, flat_1d(arr))
+
+
+@pytest.mark.parametrize("name", sorted(LARGE))
+def test_golden_large(port, name):
+  thunk, kw = LARGE[name]
+  arr = thunk()
+  m = manifest()[name]
+  assert sha(np.asfortranarray(arr).tobytes(order="F")) == m["input_sha256"], "generator drifted"
+  if kw.get("allow_pins"):
+    pytest.skip("pin encode not restated yet")
+  b = port.compress(arr, parallel=4, **kw)
+  assert len(b) == m["length"] and sha(b) == m["sha256"]
+  assert np.array_equal(port.decompress(b, parallel=4), flat_1d(arr))
+
+
+def test_z_range_and_label(port):
+  arr, kw = SMALL["c0_voronoi_u8"]
+  b = golden()["c0_voronoi_u8"]
+  full = flat_1d(arr).reshape(arr.shape, order="F")
+  got = port.decompress(b, 3, 9).reshape((64, 64, 6), order="F")
+  assert np.array_equal(got, full[:, :, 3:9])
+  lbl = int(full[10, 10, 5])
+  got = port.decompress(b, 0, -1, label=lbl).reshape(arr.shape, order="F")
+  assert np.array_equal(got.astype(bool), full == lbl)
+  # pins stream, range + label
+  bp = golden()["c0_voronoi_u8_pins"]
+  assert label_format(bp) == 2
+  got = port.decompress(bp, 5, 12).reshape((64, 64, 7), order="F")
+  assert np.array_equal(got, full[:, :, 5:12])
+
+
+def test_header_corruption_detected(port):
+  b = bytearray(golden()["kat_4x4"])
+  b[8] ^= 0x10
+  with pytest.raises(RuntimeError):
+    port.decompress(bytes(b))
+
+
+def test_slice_crc_mismatch_reported(port):
+  b = bytearray(golden()["c0_voronoi_u8"])
+  b[-1] ^= 0xFF
+  with pytest.raises(RuntimeError, match="crc"):
+    port.decompress(bytes(b))
+
+
+def test_live_reference_agrees(port, ref):
+  if ref is None:
+    pytest.skip("oracle/_ref not built (reference sources absent)")
+  for name in ("c0_voronoi_u8_m5", "rand_64x63x3_m3", "noise_2000", "checker_16"):
+    arr, kw = SMALL[name]
+    assert ref.compress(arr, **kw) == golden()[name] == port.compress(arr, **kw)
+    assert np.array_equal(ref.decompress(golden()[name]), port.decompress(golden()[name]))
+  b = golden()["c0_voronoi_u8"]
+  assert np.array_equal(ref.slice_vcg(b, 3), port.slice_vcg(b, 3))
+  arr = SMALL["c0_voronoi_u8"][0]
+  cr, pr, nr = ref.connected_components(arr)
+  cp, pp, np_ = port.connected_components(arr)
+  assert nr == np_ and np.array_equal(cr, cp) and np.array_equal(pr, pp)
