@@ -1,0 +1,13 @@
+"""crackle_amd — MI355X-native encode/decode path of the crackle segmentation codec.
+
+Drop-in for the reference's ``crackle.compress`` / ``crackle.decompress`` /
+``crackle.decompress_range`` / ``crackle.header`` (same .ckl bitstream, bit-exact),
+computed by hand-written HIP kernels behind the C-ABI in include/crackle_amd.h.
+"""
+from .headers import CrackleHeader, FormatError, LabelFormat, CrackFormat
+from .codec import compress, decompress, decompress_range, header, labels, num_labels, contains
+
+__all__ = [
+  "CrackleHeader", "FormatError", "LabelFormat", "CrackFormat",
+  "compress", "decompress", "decompress_range", "header", "labels", "num_labels", "contains",
+]

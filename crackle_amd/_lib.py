@@ -1,0 +1,92 @@
+"""ctypes binding of libcrackle_amd.so (the C-ABI in include/crackle_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing, loading it
+raises, and every compute entry point fails with CKL_ERR_NO_DEVICE when no HIP
+device is usable.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcrackle_amd.so")
+
+CKL_OK, CKL_ERR_FORMAT, CKL_ERR_RUNTIME, CKL_ERR_ARG, CKL_ERR_NO_DEVICE, CKL_ERR_CRC = range(6)
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class HeaderInfo(C.Structure):
+  _fields_ = [
+    ("format_version", C.c_uint32), ("label_format", C.c_uint32), ("crack_format", C.c_uint32),
+    ("is_signed", C.c_uint32), ("data_width", C.c_uint32), ("stored_data_width", C.c_uint32),
+    ("sx", C.c_uint32), ("sy", C.c_uint32), ("sz", C.c_uint32),
+    ("fortran_order", C.c_uint32), ("markov_model_order", C.c_uint32), ("is_sorted", C.c_uint32),
+    ("num_label_bytes", C.c_uint64), ("header_bytes", C.c_uint64),
+  ]
+
+
+class EncodeOverrides(C.Structure):
+  _fields_ = [
+    ("force_crack_format", C.c_int32), ("force_label_format", C.c_int32),
+    ("force_stored_width", C.c_int32), ("has_model", C.c_int32),
+    ("model", C.c_void_p),
+  ]
+
+
+EXPORTS = {
+  # name: (restype, argtypes) — one entry per declaration in include/crackle_amd.h
+  "ckl_last_error": (C.c_char_p, []),
+  "ckl_abi_version": (C.c_int, []),
+  "ckl_device_count": (C.c_int, []),
+  "ckl_header_info_from_bytes": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(HeaderInfo)]),
+  "ckl_compress": (C.c_int, [
+    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+    C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int64,
+    C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+  "ckl_free": (None, [C.c_void_p]),
+  "ckl_decompress": (C.c_int, [
+    C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
+    C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_int]),
+  "ckl_decoder_create": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+  "ckl_decoder_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]),
+  "ckl_decoder_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+  "ckl_decoder_destroy": (None, [C.c_void_p]),
+  "ckl_encoder_create": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+  "ckl_encoder_run": (C.c_int, [
+    C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+    C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int64,
+    C.POINTER(EncodeOverrides), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+  "ckl_encoder_stats": (C.c_int, [
+    C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+  "ckl_encoder_markov_stats": (C.c_int, [
+    C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_void_p]),
+  "ckl_encoder_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+  "ckl_encoder_destroy": (None, [C.c_void_p]),
+  "ckl_zstack": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+  "ckl_crc32c": (C.c_uint32, [C.c_char_p, C.c_uint64]),
+}
+
+_lib = None
+
+
+def lib():
+  """Loads libcrackle_amd.so, failing loudly when it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP extension first "
+        "(python -m crackle_amd.build, or __graft_entry__.build()). "
+        "crackle_amd has no CPU fallback."
+      )
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+      f = getattr(L, name)   # AttributeError here = ABI drift: fail loudly
+      f.restype = res
+      f.argtypes = args
+    _lib = L
+  return _lib
+
+
+def last_error() -> str:
+  return lib().ckl_last_error().decode("utf-8", "replace")

@@ -1,0 +1,58 @@
+"""Builds crackle_amd/libcrackle_amd.so (HIP kernels + C-ABI) for gfx950 with hipcc.
+
+  python -m crackle_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is built in-tree so that it travels
+with the repository snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcrackle_amd.so")
+SOURCES = ["ckl_common.hip", "ckl_decode.hip", "ckl_encode.hip", "ckl_zstack.hip"]
+HEADERS = ["ckl_common.hpp", "ckl_device.hpp", "ckl_ccl.hpp", os.path.join("..", "..", "include", "crackle_amd.h")]
+ARCH = os.environ.get("CKL_OFFLOAD_ARCH", "gfx950")
+
+
+def _hipcc():
+  for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+    if c and (os.path.sep not in c or os.path.exists(c)):
+      return c
+  return "hipcc"
+
+
+def _stale(target, deps):
+  if not os.path.exists(target):
+    return True
+  t = os.path.getmtime(target)
+  return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+  srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+  hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+  objdir = os.path.join(HERE, "build")
+  os.makedirs(objdir, exist_ok=True)
+  objs = []
+  flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+  for s in srcs:
+    o = os.path.join(objdir, os.path.basename(s) + ".o")
+    objs.append(o)
+    if force or _stale(o, [s] + hdrs):
+      cmd = [_hipcc(), *flags, "-c", s, "-o", o]
+      if verbose:
+        print(" ".join(cmd), flush=True)
+      subprocess.run(cmd, check=True)
+  if force or _stale(LIB, objs):
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+    if verbose:
+      print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+  return LIB
+
+
+if __name__ == "__main__":
+  build(force="--force" in sys.argv)

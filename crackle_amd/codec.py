@@ -1,0 +1,193 @@
+"""crackle.compress / crackle.decompress on an MI355X.
+
+Mirrors the reference's Python surface for this path
+(/root/reference/crackle/codec.py:616-733): same names, arguments, return types and
+error behaviour, with one addition — ``device`` selects the HIP device ordinal.
+All compute goes through the C-ABI of libcrackle_amd.so; there is no CPU fallback.
+"""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .headers import CrackleHeader, FormatError, LabelFormat
+
+
+def _raise(rc: int):
+  msg = _lib.last_error()
+  if rc == _lib.CKL_ERR_FORMAT:
+    raise FormatError(msg)
+  if rc == _lib.CKL_ERR_ARG:
+    raise ValueError(msg)
+  raise RuntimeError(msg)
+
+
+def header(binary: bytes) -> CrackleHeader:
+  """Decode the header from a Crackle bytestream (codec.py:13-15)."""
+  return CrackleHeader.frombytes(binary)
+
+
+def _label_section(binary: bytes, head: CrackleHeader):
+  """(number of stored unique labels, their byte offset) of the label section
+  (codec.py:17-50, 82-96)."""
+  off = head.header_bytes + head.grid_index_bytes
+  if head.label_format != LabelFormat.FLAT:
+    off += head.stored_data_width
+  n = int.from_bytes(binary[off:off + 8], "little")
+  return n, off + 8
+
+
+def num_labels(binary: bytes) -> int:
+  """Number of unique labels in the stream (codec.py:82-96; pin streams count the
+  background color too)."""
+  head = header(binary)
+  if head.voxels() == 0:
+    return 0
+  n, _ = _label_section(binary, head)
+  if head.label_format != LabelFormat.FLAT:
+    n += 1
+  return n
+
+
+def labels(binary: bytes) -> np.ndarray:
+  """Unique labels of the stream (codec.py:17-50)."""
+  head = header(binary)
+  if head.voxels() == 0:
+    return np.zeros((0,), dtype=head.dtype)
+  n, off = _label_section(binary, head)
+  uniq = np.frombuffer(binary, dtype=head.stored_dtype, offset=off, count=n)
+  if head.label_format != LabelFormat.FLAT:
+    base = head.header_bytes + head.grid_index_bytes
+    bg = np.frombuffer(binary, dtype=head.stored_dtype, offset=base, count=1)
+    uniq = np.sort(np.concatenate((bg, uniq)))
+  return uniq.astype(head.dtype, copy=False)
+
+
+def contains(binary: bytes, label: int) -> bool:
+  """codec.py:98-132 (sorted search on the unique label list)."""
+  head = header(binary)
+  if head.voxels() == 0:
+    return False
+  u = labels(binary)
+  if label < 0 or label > np.iinfo(u.dtype).max:
+    return False
+  i = np.searchsorted(u, u.dtype.type(label))
+  return bool(i < u.size and u[i] == label)
+
+
+def compress(
+  labels: np.ndarray,
+  allow_pins: int = 0,
+  markov_model_order: int = 0,
+  bgcolor: Optional[int] = None,
+  parallel: int = 0,
+  device: int = 0,
+) -> bytes:
+  """Compress the 3D labels array into a Crackle bytestream (codec.py:689-733).
+
+  ``parallel`` is accepted for signature compatibility; the device schedules all
+  z-slices itself."""
+  if np.issubdtype(labels.dtype, np.signedinteger):
+    raise TypeError("Signed integer data types are not currently supported.")
+  if labels.dtype.kind not in "ub" or labels.dtype.itemsize not in (1, 2, 4, 8):
+    raise TypeError(f"Unsupported data type: {labels.dtype}")
+  if labels.ndim > 3:
+    raise ValueError("labels must have at most 3 dimensions")
+
+  f_order = bool(labels.flags.f_contiguous)
+  labels = np.asfortranarray(labels)
+  shape = list(labels.shape) + [1] * (3 - labels.ndim)   # fastcrackle.cpp:141-147
+  optimize_pins = (allow_pins == 2)
+  auto_bgcolor = (bgcolor is None)
+  manual_bgcolor = 0 if bgcolor is None else int(bgcolor)
+
+  out = C.c_void_p()
+  n = C.c_uint64()
+  rc = _lib.lib().ckl_compress(
+    labels.ctypes.data, _lib.MEM_HOST, labels.dtype.itemsize, 0,
+    shape[0], shape[1], shape[2],
+    int(bool(allow_pins)), int(f_order), int(markov_model_order),
+    int(optimize_pins), int(auto_bgcolor), manual_bgcolor,
+    int(device), C.byref(out), C.byref(n),
+  )
+  if rc != _lib.CKL_OK:
+    _raise(rc)
+  try:
+    return C.string_at(out.value, n.value)
+  finally:
+    _lib.lib().ckl_free(out)
+
+
+def _device_decompress(binary: bytes, z_start: int, z_end: int, label: Optional[int], device: int, head: CrackleHeader) -> np.ndarray:
+  """fastcrackle.decompress equivalent (fastcrackle.cpp:40-128): 1-D array."""
+  zs = max(z_start, 0)
+  ze = head.sz if z_end == -1 else min(max(z_end, 0), head.sz)
+  voxels = head.sx * head.sy * max(ze - zs, 0)
+  dtype = np.uint8 if label is not None else head.dtype
+  arr = np.empty((voxels,), dtype=dtype)
+  rc = _lib.lib().ckl_decompress(
+    binary, len(binary), arr.ctypes.data, arr.nbytes, _lib.MEM_HOST,
+    z_start, z_end, int(label is not None), int(label or 0), int(device),
+  )
+  if rc != _lib.CKL_OK:
+    _raise(rc)
+  return arr
+
+
+def decompress_range(
+  binary: bytes,
+  z_start: Optional[int],
+  z_end: Optional[int],
+  parallel: int = 0,
+  label: Optional[int] = None,
+  device: int = 0,
+) -> np.ndarray:
+  """Decompress a z-range of a Crackle binary into a numpy array (codec.py:632-687)."""
+  binary = bytes(binary)
+  head = CrackleHeader.frombytes(binary)
+  sx, sy, sz = head.sx, head.sy, head.sz
+  z_start = 0 if z_start is None else int(z_start)
+  z_end = sz if z_end is None else int(z_end)
+  order = "F" if head.fortran_order else "C"
+  shape = (sx, sy, z_end - z_start)
+
+  if sx * sy * sz == 0:
+    out = np.zeros((0,), dtype=head.dtype)
+  elif label is not None and not contains(binary, label):
+    out = np.zeros(shape, order=order, dtype=head.dtype)
+  elif label is None and num_labels(binary) == 1:
+    single = labels(binary)[0]
+    out = np.zeros(shape, order=order, dtype=head.dtype) if single == 0 else np.full(shape, single, order=order, dtype=head.dtype)
+  else:
+    out = _device_decompress(binary, z_start, z_end, label, device, head)
+
+  out = out.reshape(shape, order=order)
+  if label is not None:
+    return out.view(bool)
+  if head.signed:
+    out = out.view({1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[head.data_width])
+  return out
+
+
+def decompress(
+  binary: bytes,
+  label: Optional[int] = None,
+  parallel: int = 0,
+  crop: bool = False,
+  device: int = 0,
+) -> np.ndarray:
+  """Decompress a Crackle binary into a numpy array (codec.py:616-630).
+  With ``label``, returns the boolean image of that label."""
+  if label is None:
+    return decompress_range(binary, None, None, parallel, device=device)
+  # binary-image mode: the reference restricts the decode to the label's z-range
+  # (codec.py:588-614); the full-range decode gives the same image
+  img = decompress_range(binary, None, None, parallel, label=label, device=device)
+  if not crop:
+    return img
+  nz = np.flatnonzero(img.any(axis=(0, 1)))
+  if nz.size == 0:
+    head = CrackleHeader.frombytes(binary)
+    return np.zeros([0, 0, 0], dtype=bool, order="F" if head.fortran_order else "C")
+  return img[:, :, nz[0]:nz[-1] + 1]

@@ -1,0 +1,993 @@
+// Decode path: .ckl bytes resident in HBM -> label volume in HBM.
+// Replaces crackle::decompress<LABEL,OUT> (src/crackle.hpp:503-663) and the
+// per-slice functions it calls:
+//   read_boc_index / packed_codepoints_to_symbols   src/crackcodes.hpp:283-316, 523-603
+//   markov::decode_codepoints / codepoints_to_symbols src/markov.hpp:268-323, crackcodes.hpp:606-676
+//   decode_(im)permissible_crack_code (rasteriser)   src/crackcodes.hpp:706-876
+//   cc3d::color_connectivity_graph + relabel         src/cc3d.hpp:114-254   (ckl_ccl.hpp)
+//   crc32c of the component image                    src/crackle.hpp:599-611
+//   labels::decode_flat / decode_condensed_pins      src/labels.hpp:453-617
+//   the paint loop                                   src/crackle.hpp:617-656
+//
+// Kernels (block = 256 threads):
+//   k_decode_cracks   one workgroup per slice: BOC index, 2-bit unpack + mod-4
+//                     prefix sum (undo the difference code), control-pair detection,
+//                     symbol compaction and position prefix sums (block scans), a
+//                     short serial pass over the control symbols only (branch stack),
+//                     then parallel rasterisation of every move into two bit planes.
+//   k_ccl_*           see ckl_ccl.hpp
+//   k_label_map_*     component -> label tables (flat keys / pins)
+//   k_paint           out[p] = label_map[cc(p)] fused with the crc32c of the
+//                     component image (never materialised in memory)
+#include "ckl_common.hpp"
+#include "ckl_ccl.hpp"
+
+#include <algorithm>
+#include <memory>
+
+namespace ckl {
+
+using namespace dev;
+
+// ------------------------------------------------------------------------------
+// crack code -> crack planes
+// ------------------------------------------------------------------------------
+enum : uint8_t { SYM_U = 0, SYM_R = 1, SYM_D = 2, SYM_L = 3, SYM_B = 4, SYM_T = 5 };
+
+struct CrackArgs {
+	const uint8_t* stream;
+	const uint64_t* code_off;    // [nslices] byte offset of each slice's crack code
+	const uint32_t* code_len;    // [nslices]
+	const uint64_t* cbase;       // [nslices] base index into the per-code scratch arrays
+	const uint32_t* ccap;        // [nslices] capacity (codes) of this slice's scratch
+	const uint64_t* nbase;       // [nslices] base index into `nodes`
+	const uint32_t* ncap;        // [nslices]
+	int sx, sy;
+	int xw, yw;
+	int markov_order;
+	const uint8_t* model;        // [4^order][4] rank -> symbol
+	uint8_t* ucode;              // unpacked difference codes (markov only)
+	uint8_t* sym_kind;
+	uint32_t* sym_pos;           // exclusive prefix sum of move displacements (mod 2^32)
+	uint32_t* sym_seg;           // number of 't' symbols before the symbol
+	uint32_t* ctl_sym;           // symbol index of every control symbol, in order
+	uint32_t* seg_off;           // per segment: vertex offset to add to sym_pos
+	uint32_t* stack;
+	uint32_t* nodes;
+	uint32_t* planeV;
+	uint32_t* planeH;
+	uint32_t row_words;
+	uint64_t plane_words;
+	uint32_t* slice_err;         // [nslices] sticky error bits
+};
+
+enum : uint32_t {
+	ERR_BOC = 1u,          // beginning-of-chain index malformed
+	ERR_RANGE = 2u,        // a move left the vertex grid
+	ERR_CAPACITY = 4u,     // scratch capacity exceeded (cannot happen for well-formed sizes)
+	ERR_NCOMP = 8u,        // component count differs from the label section
+	ERR_CRC = 16u,         // crc32c of the component image differs from the stored one
+};
+
+__device__ __forceinline__ uint32_t rd_le_dev(const uint8_t* p, int w) {
+	uint32_t v = 0;
+	for (int i = 0; i < w; i++) v |= static_cast<uint32_t>(p[i]) << (8 * i);
+	return v;
+}
+
+__global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
+	__shared__ uint32_t s_scan[4 * kWaves];
+	__shared__ int32_t s_scanmax[kWaves];
+	__shared__ uint32_t s_last_move[kBlock];
+	__shared__ uint32_t s_last_ctrl[kBlock];
+	__shared__ uint32_t s_nnodes, s_ncodes, s_nsyms, s_nctl, s_valid_segs, s_err;
+
+	const uint32_t zi = blockIdx.x;
+	const int tid = threadIdx.x;
+	const uint8_t* code = a.stream + a.code_off[zi];
+	const uint32_t code_len = a.code_len[zi];
+	const uint64_t cb = a.cbase[zi];
+	const uint32_t cap = a.ccap[zi];
+	uint32_t* nodes = a.nodes + a.nbase[zi];
+	const uint32_t ncap = a.ncap[zi];
+	const uint32_t sxe = a.sx + 1, sye = a.sy + 1;
+	const uint32_t nverts = sxe * sye;
+
+	// ---- phase A: beginning-of-chain index (crackcodes.hpp:283-316), serial ----
+	if (tid == 0) {
+		uint32_t err = 0, nn = 0, ncodes = 0;
+		uint32_t index_end = 0;
+		if (code_len < 4u + a.yw) {
+			err |= ERR_BOC;
+		}
+		else {
+			const uint32_t index_size = rd_le_dev(code, 4);
+			index_end = 4u + index_size;
+			if (index_size < static_cast<uint32_t>(a.yw) || index_end > code_len || index_end < 4u) {
+				err |= ERR_BOC;
+				index_end = code_len;
+			}
+			else {
+				uint32_t idx = 4;
+				const uint32_t num_y = rd_le_dev(code + idx, a.yw);
+				idx += a.yw;
+				uint32_t y = 0;
+				for (uint32_t yi = 0; yi < num_y && !err; yi++) {
+					if (idx + a.yw + a.xw > index_end) { err |= ERR_BOC; break; }
+					y += rd_le_dev(code + idx, a.yw); idx += a.yw;
+					const uint32_t num_x = rd_le_dev(code + idx, a.xw); idx += a.xw;
+					uint32_t x = 0;
+					for (uint32_t xi = 0; xi < num_x; xi++) {
+						if (idx + a.xw > index_end) { err |= ERR_BOC; break; }
+						x += rd_le_dev(code + idx, a.xw); idx += a.xw;
+						if (x >= sxe || y >= sye || nn >= ncap) { err |= ERR_BOC; break; }
+						nodes[nn++] = x + sxe * y;
+					}
+				}
+			}
+			// ---- markov bitstream -> unpacked difference codes (markov.hpp:268-313), serial ----
+			const uint32_t nbytes = code_len - index_end;
+			if (a.markov_order == 0) {
+				ncodes = nbytes * 4u;
+			}
+			else if (nbytes > 0) {
+				const uint8_t* s = code + index_end;
+				uint8_t* uc = a.ucode + cb;
+				const int shift = 2 * (a.markov_order - 1);
+				uint32_t m = 0;
+				const uint32_t start = s[0] & 3u;
+				uc[m++] = static_cast<uint8_t>(start);
+				uint32_t ctx = start << shift;
+				int pos = 2;
+				for (uint32_t i = 0; i < nbytes; i++) {
+					uint32_t byte = s[i];
+					if (i + 1 < nbytes) byte |= static_cast<uint32_t>(s[i + 1]) << 8;
+					while (pos < 8) {
+						const uint32_t cp = (byte >> pos) & 7u;
+						uint32_t rank;
+						if ((cp & 1u) == 0) { rank = 0; pos += 1; }
+						else if ((cp & 2u) == 0) { rank = 1; pos += 2; }
+						else if ((cp & 4u) == 0) { rank = 2; pos += 3; }
+						else { rank = 3; pos += 3; }
+						const uint32_t v = a.model[ctx * 4u + rank];
+						if (m < cap) uc[m++] = static_cast<uint8_t>(v);
+						else err |= ERR_CAPACITY;
+						ctx = (ctx >> 2) + (v << shift);
+					}
+					pos -= 8;
+				}
+				ncodes = m;
+			}
+		}
+		if (ncodes > cap) { ncodes = cap; err |= ERR_CAPACITY; }
+		s_nnodes = nn;
+		s_ncodes = ncodes;
+		s_err = err;
+	}
+	__syncthreads();
+	const uint32_t n_codes = s_ncodes;
+	const uint32_t n_nodes = s_nnodes;
+	const uint32_t index_end = 4u + (code_len >= 4u ? rd_le_dev(code, 4) : 0u);
+	const uint8_t* packed = code + index_end;          // only dereferenced when n_codes > 0 (then index_end <= code_len)
+	const uint8_t* ucode = a.ucode + cb;
+
+	uint8_t* sym_kind = a.sym_kind + cb;
+	uint32_t* sym_pos = a.sym_pos + cb;
+	uint32_t* sym_seg = a.sym_seg + cb;
+	uint32_t* ctl_sym = a.ctl_sym + cb;
+
+	// ---- phase B: codes -> symbols, tiled block scans with carries -------------------
+	// (crackcodes.hpp:547-598 / SURVEY.md Appendix D6)
+	// Every code position g in [0, n_codes] is visited; position g finalises the
+	// symbol of code g-1 (a move becomes 'b'/'t' when code g is its exact reverse).
+	uint32_t carry_sum = 0;          // running mod-4 sum of difference codes
+	uint32_t carry_move = 0xFF;      // move of code g0-1 (0xFF: none)
+	uint32_t carry_ctrl = 0;         // was code g0-1 the second half of a control pair
+	int32_t carry_lf = -1;           // last position whose `reverse-of-previous` test was false
+	uint32_t carry_nsym = 0, carry_nt = 0, carry_nctl = 0, carry_pos = 0;
+	constexpr uint32_t kPer = 16;
+	constexpr uint32_t kTile = kBlock * kPer;
+
+	if (n_nodes > 0 && n_codes > 0) {
+		for (uint32_t tile = 0; tile <= n_codes; tile += kTile) {
+			const uint32_t g0 = tile + tid * kPer;
+			// -- load 16 difference codes
+			uint32_t dc[kPer];
+			uint32_t tsum = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < kPer; k++) {
+				const uint32_t g = g0 + k;
+				uint32_t c = 0;
+				if (g < n_codes) {
+					c = a.markov_order ? ucode[g] : ((packed[g >> 2] >> (2 * (g & 3))) & 3u);
+				}
+				tsum = (tsum + c) & 3u;
+				dc[k] = tsum;   // inclusive local sum mod 4
+			}
+			uint32_t v1[1] = { tsum }, t1[1];
+			block_excl_add<1>(v1, t1, s_scan);
+			const uint32_t base_sum = (carry_sum + v1[0]) & 3u;
+			uint32_t mv[kPer];
+#pragma unroll
+			for (uint32_t k = 0; k < kPer; k++) mv[k] = (dc[k] + base_sum) & 3u;
+			s_last_move[tid] = mv[kPer - 1];
+			__syncthreads();
+			const uint32_t prev_move = tid ? s_last_move[tid - 1] : carry_move;
+			const uint32_t tile_last_move = s_last_move[kBlock - 1];
+
+			// -- r[g]: code g is the exact reverse of code g-1; runs of r alternate ctrl/move
+			uint32_t rmask = 0;
+			int32_t lf = INT32_MIN;
+#pragma unroll
+			for (uint32_t k = 0; k < kPer; k++) {
+				const uint32_t g = g0 + k;
+				const uint32_t pm = k ? mv[k - 1] : prev_move;
+				const bool r = (g > 0) && (g < n_codes) && (pm != 0xFF) && ((mv[k] ^ pm) == 2u);
+				if (r) rmask |= (1u << k);
+				else lf = static_cast<int32_t>(g);
+			}
+			int32_t lf_tot;
+			int32_t lf_in = block_excl_max(lf, lf_tot, s_scanmax);
+			if (lf_in < carry_lf) lf_in = carry_lf;
+			uint32_t cmask = 0;   // ctrl flags of my 16 codes
+			{
+				int32_t cur = lf_in;
+#pragma unroll
+				for (uint32_t k = 0; k < kPer; k++) {
+					const int32_t g = static_cast<int32_t>(g0 + k);
+					if (rmask & (1u << k)) { if ((g - cur) & 1) cmask |= (1u << k); }
+					else cur = g;
+				}
+			}
+			s_last_ctrl[tid] = (cmask >> (kPer - 1)) & 1u;
+			__syncthreads();
+			const uint32_t prev_ctrl = tid ? s_last_ctrl[tid - 1] : carry_ctrl;
+			const uint32_t tile_last_ctrl = s_last_ctrl[kBlock - 1];
+
+			// -- events: position g emits the symbol of code g-1 unless g-1 was a control half
+			uint32_t kinds = 0;        // 3 bits per event slot k
+			uint32_t emask = 0;
+			uint32_t n_ev = 0, n_t = 0, n_ctl = 0, dpos = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < kPer; k++) {
+				const uint32_t g = g0 + k;
+				const uint32_t pm = k ? mv[k - 1] : prev_move;
+				const uint32_t pc = k ? ((cmask >> (k - 1)) & 1u) : prev_ctrl;
+				if (g >= 1 && g <= n_codes && !pc && pm != 0xFF) {
+					uint32_t kind;
+					if (g < n_codes && (cmask & (1u << k))) kind = (mv[k] == 0u || mv[k] == 3u) ? SYM_T : SYM_B;
+					else kind = pm;
+					emask |= (1u << k);
+					kinds |= 0;  // placeholder to keep the compiler from merging branches oddly
+					n_ev++;
+					if (kind == SYM_T) n_t++;
+					if (kind >= SYM_B) n_ctl++;
+					else dpos += (kind == SYM_R) ? 1u : (kind == SYM_L) ? 0xFFFFFFFFu : (kind == SYM_D) ? sxe : (0u - sxe);
+				}
+			}
+			uint32_t v4[4] = { n_ev, n_t, n_ctl, dpos }, t4[4];
+			block_excl_add<4>(v4, t4, s_scan);
+			uint32_t o_sym = carry_nsym + v4[0], o_t = carry_nt + v4[1], o_ctl = carry_nctl + v4[2], o_pos = carry_pos + v4[3];
+#pragma unroll
+			for (uint32_t k = 0; k < kPer; k++) {
+				if (!(emask & (1u << k))) continue;
+				const uint32_t g = g0 + k;
+				const uint32_t pm = k ? mv[k - 1] : prev_move;
+				uint32_t kind;
+				if (g < n_codes && (cmask & (1u << k))) kind = (mv[k] == 0u || mv[k] == 3u) ? SYM_T : SYM_B;
+				else kind = pm;
+				if (o_sym < cap) {
+					sym_kind[o_sym] = static_cast<uint8_t>(kind);
+					sym_pos[o_sym] = o_pos;
+					sym_seg[o_sym] = o_t;
+					if (kind >= SYM_B && o_ctl < cap) ctl_sym[o_ctl] = o_sym;
+				}
+				o_sym++;
+				if (kind == SYM_T) o_t++;
+				if (kind >= SYM_B) o_ctl++;
+				else o_pos += (kind == SYM_R) ? 1u : (kind == SYM_L) ? 0xFFFFFFFFu : (kind == SYM_D) ? sxe : (0u - sxe);
+			}
+			(void)kinds;
+			// -- carries to the next tile (uniform across the block)
+			carry_sum = (carry_sum + t1[0]) & 3u;
+			carry_move = (tile + kTile <= n_codes) ? tile_last_move : 0xFF;
+			carry_ctrl = tile_last_ctrl;
+			if (lf_tot > carry_lf) carry_lf = lf_tot;
+			carry_nsym += t4[0]; carry_nt += t4[1]; carry_nctl += t4[2]; carry_pos += t4[3];
+			__syncthreads();
+		}
+	}
+	if (tid == 0) {
+		s_nsyms = carry_nsym < cap ? carry_nsym : cap;
+		s_nctl = carry_nctl < cap ? carry_nctl : cap;
+		if (carry_nsym > cap) s_err |= ERR_CAPACITY;
+	}
+	__syncthreads();
+	const uint32_t n_syms = s_nsyms, n_ctl = s_nctl;
+
+	// ---- phase C: serial pass over the control symbols only ('b' push / 't' pop) -----
+	// (crackcodes.hpp:771-781, 849-859: the rasteriser's revisit stack; chain
+	// segmentation by branches_taken, crackcodes.hpp:549-598)
+	uint32_t* seg_off = a.seg_off + cb;
+	uint32_t* stack = a.stack + cb;
+	if (tid == 0) {
+		uint32_t valid = 0;
+		if (n_nodes > 0 && n_syms > 0) {
+			uint32_t off = nodes[0];
+			uint32_t chain = 0, sp = 0;
+			seg_off[0] = off;
+			valid = 1;
+			for (uint32_t k = 0; k < n_ctl; k++) {
+				const uint32_t s = ctl_sym[k];
+				const uint32_t kind = sym_kind[s];
+				const uint32_t pos = sym_pos[s];
+				if (kind == SYM_B) {
+					stack[sp++] = off + pos;      // sp <= number of 'b' <= n_ctl <= cap
+				}
+				else {
+					if (sp > 0) {
+						off = stack[--sp] - pos;
+					}
+					else {
+						chain++;
+						if (chain >= n_nodes) break;   // trailing pad codes are ignored
+						off = nodes[chain] - pos;
+					}
+					const uint32_t seg = sym_seg[s] + 1u;
+					if (seg < cap) { seg_off[seg] = off; valid = seg + 1u; }
+				}
+			}
+		}
+		s_valid_segs = valid;
+	}
+	__syncthreads();
+	const uint32_t valid_segs = s_valid_segs;
+
+	// ---- phase D: rasterise every move into the crack planes (crackcodes.hpp:706-862) ----
+	uint32_t* pv = a.planeV + zi * a.plane_words;
+	uint32_t* ph = a.planeH + zi * a.plane_words;
+	uint32_t err = 0;
+	const uint32_t sx = a.sx, sy = a.sy;
+	for (uint32_t s = tid; s < n_syms; s += kBlock) {
+		const uint32_t kind = sym_kind[s];
+		if (kind >= SYM_B) continue;
+		const uint32_t seg = sym_seg[s];
+		if (seg >= valid_segs) continue;
+		const uint32_t t = seg_off[seg] + sym_pos[s];
+		if (t >= nverts) { err |= ERR_RANGE; continue; }
+		const uint32_t y = t / sxe;
+		const uint32_t x = t - y * sxe;
+		// vertical moves cross planeV, horizontal moves cross planeH
+		if (kind == SYM_D) {          // edge (x,y)-(x,y+1): between pixels (x-1,y) | (x,y)
+			if (x >= 1 && x < sx && y < sy) atomicOr(pv + static_cast<uint64_t>(y) * a.row_words + (x >> 5), 1u << (x & 31));
+			else if (y >= sy) err |= ERR_RANGE;
+		}
+		else if (kind == SYM_U) {     // edge (x,y-1)-(x,y)
+			if (x >= 1 && x < sx && y >= 1) atomicOr(pv + static_cast<uint64_t>(y - 1) * a.row_words + (x >> 5), 1u << (x & 31));
+			else if (y < 1) err |= ERR_RANGE;
+		}
+		else if (kind == SYM_R) {     // edge (x,y)-(x+1,y): between pixels (x,y-1) | (x,y)
+			if (y >= 1 && y < sy && x < sx) atomicOr(ph + static_cast<uint64_t>(y) * a.row_words + (x >> 5), 1u << (x & 31));
+			else if (x >= sx) err |= ERR_RANGE;
+		}
+		else {                        // SYM_L: edge (x-1,y)-(x,y)
+			if (y >= 1 && y < sy && x >= 1) atomicOr(ph + static_cast<uint64_t>(y) * a.row_words + ((x - 1) >> 5), 1u << ((x - 1) & 31));
+			else if (x < 1) err |= ERR_RANGE;
+		}
+	}
+	if (err) atomicOr(&s_err, err);
+	__syncthreads();
+	if (tid == 0 && s_err) atomicOr(a.slice_err + zi, s_err);
+}
+
+// ------------------------------------------------------------------------------
+// component -> label tables
+// ------------------------------------------------------------------------------
+// flat (labels.hpp:453-506): label_map[i] = uniq[key[i]] for the components of the
+// decoded slices; i counts from the first component of slice z_start.
+__global__ void __launch_bounds__(kBlock) k_label_map_flat(
+	const uint8_t* __restrict__ keys, int key_width, const uint8_t* __restrict__ uniq, int stored_width,
+	uint64_t num_unique, uint32_t is_signed, uint64_t n, uint64_t* __restrict__ label_map
+) {
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (i >= n) return;
+	uint64_t key = 0;
+	for (int b = 0; b < key_width; b++) key |= static_cast<uint64_t>(keys[i * key_width + b]) << (8 * b);
+	uint64_t v = 0;
+	if (key < num_unique) {
+		for (int b = 0; b < stored_width; b++) v |= static_cast<uint64_t>(uniq[key * stored_width + b]) << (8 * b);
+		if (is_signed && stored_width < 8 && (v >> (8 * stored_width - 1))) v |= ~0ull << (8 * stored_width);
+	}
+	label_map[i] = v;
+}
+__global__ void __launch_bounds__(kBlock) k_fill_u64(uint64_t* p, uint64_t v, uint64_t n) {
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+// condensed pins, single-component lists (labels.hpp:578-593): ids are global component ids
+__global__ void __launch_bounds__(kBlock) k_label_map_ccids(
+	const uint64_t* __restrict__ ids, const uint64_t* __restrict__ labels, uint64_t n,
+	uint64_t left, uint64_t right, uint64_t* __restrict__ label_map
+) {
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t id = ids[i];
+	if (id >= left && id < right) label_map[id - left] = labels[i];
+}
+// condensed pins proper (labels.hpp:600-614): a pin at (loc, z0..z0+depth) labels the
+// component of pixel loc in every slice it pierces.  One thread per (pin, slice) pair.
+__global__ void __launch_bounds__(kBlock) k_label_map_pins(
+	const uint64_t* __restrict__ pin_index, const uint64_t* __restrict__ pin_depth, const uint64_t* __restrict__ pin_label,
+	const uint64_t* __restrict__ pin_work_off, uint64_t n_pins, uint64_t total_work,
+	const uint32_t* __restrict__ L, const uint32_t* __restrict__ R, uint64_t sxy,
+	int64_t z_start, int64_t z_end, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ ncomp,
+	uint64_t* __restrict__ label_map
+) {
+	const uint64_t w = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (w >= total_work) return;
+	// binary search the pin owning work item w
+	uint64_t lo = 0, hi = n_pins;
+	while (lo + 1 < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (pin_work_off[mid] <= w) lo = mid; else hi = mid;
+	}
+	const uint64_t j = lo;
+	const int64_t pin_z = static_cast<int64_t>(pin_index[j] / sxy);
+	const uint64_t loc = pin_index[j] - static_cast<uint64_t>(pin_z) * sxy;
+	int64_t zs = pin_z > z_start ? pin_z : z_start;
+	const int64_t z = zs + static_cast<int64_t>(w - pin_work_off[j]);
+	int64_t ze = pin_z + static_cast<int64_t>(pin_depth[j]) + 1;
+	if (ze > z_end) ze = z_end;
+	if (z >= ze) return;
+	const uint64_t zi = static_cast<uint64_t>(z - z_start);
+	const uint32_t root = L[zi * sxy + loc];
+	const uint32_t cc = R[zi * sxy + root];
+	if (cc < ncomp[zi]) label_map[comp_off[zi] + cc] = pin_label[j];
+}
+
+// ------------------------------------------------------------------------------
+// paint + crc32c of the component image
+// ------------------------------------------------------------------------------
+struct PaintArgs {
+	const uint32_t* L;
+	const uint32_t* R;
+	const uint64_t* label_map;
+	const uint64_t* comp_off;     // [nslices] first label_map entry of each slice
+	const uint32_t* ncomp;        // [nslices] computed component counts
+	const uint32_t* crc_stride_tab;  // [4][256] multiply by x^(32*256)
+	const uint32_t* crc_lane_pow;    // [256] x^(32*(256-j))
+	const uint32_t* crc_tile_pow;    // [tiles] x^(32*kCrcTile*(tiles-1-t))
+	uint32_t* crc_acc;            // [nslices]
+	uint32_t* slice_err;
+	void* out;
+	uint64_t sxy;
+	uint32_t sx, sy;
+	uint32_t tiles;               // crc tiles per slice
+	uint32_t pad;                 // virtual zero words in front of each slice
+	uint32_t nslices;
+	uint32_t fortran_order;
+	uint32_t has_label;
+	uint64_t label;
+};
+
+template <typename OUT>
+__global__ void __launch_bounds__(kBlock) k_paint(PaintArgs a) {
+	__shared__ uint32_t s_tab[1024];
+	__shared__ uint32_t s_red[kWaves];
+	const uint32_t zi = blockIdx.y;
+	const uint32_t t = blockIdx.x;
+	for (int i = threadIdx.x; i < 1024; i += kBlock) s_tab[i] = a.crc_stride_tab[i];
+	__syncthreads();
+	const uint32_t* Lz = a.L + zi * a.sxy;
+	const uint32_t* Rz = a.R + zi * a.sxy;
+	const uint64_t* lm = a.label_map + a.comp_off[zi];
+	const uint32_t nc = a.ncomp[zi];
+	OUT* out = reinterpret_cast<OUT*>(a.out);
+	uint32_t acc = 0;
+	uint32_t bad = 0;
+#pragma unroll
+	for (int i = 0; i < kCrcRows; i++) {
+		const uint64_t kp = static_cast<uint64_t>(t) * kCrcTile + i * kBlock + threadIdx.x;
+		uint32_t word = 0;
+		if (kp >= a.pad) {
+			const uint64_t p = kp - a.pad;   // < sxy by construction of tiles/pad
+			const uint32_t cc = Rz[Lz[p]];
+			word = cc;
+			uint64_t v = 0;
+			if (cc < nc) v = lm[cc]; else bad = 1;
+			if (a.has_label) v = (v == a.label);
+			if (a.fortran_order) {
+				out[static_cast<uint64_t>(zi) * a.sxy + p] = static_cast<OUT>(v);
+			}
+			else {
+				const uint32_t y = static_cast<uint32_t>(p / a.sx);
+				const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * a.sx);
+				out[zi + static_cast<uint64_t>(a.nslices) * (y + static_cast<uint64_t>(a.sy) * x)] = static_cast<OUT>(v);
+			}
+		}
+		acc = crc_stride_step(s_tab, acc) ^ word;
+	}
+	uint32_t val = gf_mul(acc, a.crc_lane_pow[threadIdx.x]);
+	val = block_xor(val, s_red);
+	if (threadIdx.x == 0) {
+		atomicXor(a.crc_acc + zi, gf_mul(val, a.crc_tile_pow[t]));
+	}
+	if (bad) atomicOr(a.slice_err + zi, ERR_NCOMP);
+}
+
+// compares the accumulated raw crc with the stored per-slice crc32c and the computed
+// component counts with the label section; grid = ceil(nslices / 256)
+__global__ void __launch_bounds__(kBlock) k_check(
+	const uint32_t* __restrict__ crc_acc, const uint32_t* __restrict__ crc_expect_raw,
+	const uint32_t* __restrict__ ncomp, const uint32_t* __restrict__ ncomp_expect,
+	uint32_t check_crc, uint32_t check_ncomp, uint32_t nslices, uint32_t* __restrict__ slice_err
+) {
+	const uint32_t zi = blockIdx.x * kBlock + threadIdx.x;
+	if (zi >= nslices) return;
+	uint32_t e = 0;
+	if (check_crc && crc_acc[zi] != crc_expect_raw[zi]) e |= ERR_CRC;
+	if (check_ncomp && ncomp[zi] != ncomp_expect[zi]) e |= ERR_NCOMP;
+	if (e) atomicOr(slice_err + zi, e);
+}
+
+}  // namespace ckl
+
+// ------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------
+using namespace ckl;
+
+struct ckl_decoder {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+	float pipeline_ms = 0.f, dominant_ms = 0.f;
+
+	Header head;
+	std::vector<uint8_t> host_stream;   // only the parts the host parses are kept: header+z-index+labels
+	uint64_t n_bytes = 0;
+	int64_t z_start = 0, z_end = 0;
+	uint32_t nslices = 0;
+	uint64_t sxy = 0;
+
+	// device residents
+	DevBuf<uint8_t> d_stream;
+	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off;
+	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap;
+	DevBuf<uint8_t> d_model, d_ucode, d_sym_kind;
+	DevBuf<uint32_t> d_sym_pos, d_sym_seg, d_ctl_sym, d_seg_off, d_stack, d_nodes;
+	DevBuf<uint32_t> d_planes;          // V then H
+	DevBuf<uint32_t> d_L, d_R, d_tile_count, d_ncomp, d_ncomp_expect;
+	DevBuf<uint32_t> d_crc_tab, d_crc_lane_pow, d_crc_tile_pow, d_crc_acc, d_crc_expect, d_slice_err;
+	DevBuf<uint64_t> d_label_map;
+	DevBuf<uint64_t> d_pin_index, d_pin_depth, d_pin_label, d_pin_work_off, d_ccl_id, d_ccl_label;
+
+	// label section layout
+	uint64_t total_comp = 0;            // components in [z_start, z_end)
+	uint64_t comp_left = 0;             // global id of the first component of z_start
+	uint64_t keys_offset = 0, uniq_offset = 0, num_unique = 0;
+	int key_width = 1;
+	uint64_t bgcolor = 0;
+	uint64_t n_pins = 0, pin_total_work = 0, n_ccl = 0;
+
+	uint32_t row_words = 0;
+	uint64_t plane_words = 0;
+	uint32_t ccl_tiles = 0, crc_tiles = 0, crc_pad = 0;
+	bool check_crc = true;
+
+	~ckl_decoder() {
+		if (ev0) (void)hipEventDestroy(ev0);
+		if (ev1) (void)hipEventDestroy(ev1);
+		if (evk0) (void)hipEventDestroy(evk0);
+		if (evk1) (void)hipEventDestroy(evk1);
+		if (stream) (void)hipStreamDestroy(stream);
+	}
+};
+
+namespace {
+
+template <typename T>
+void upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t s) {
+	d.ensure(h.size());
+	if (!h.empty()) CKL_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+uint64_t read_stored(const Header& h, const uint8_t* lb, uint64_t offset) {
+	const int w = h.stored_data_width;
+	uint64_t v = rd_le(lb + offset, w);
+	if (h.is_signed && w < 8 && (v >> (8 * w - 1))) v |= ~0ull << (8 * w);
+	return v;
+}
+
+void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end) {
+	if (n < Header::kBytesV0) throw Error(CKL_ERR_FORMAT, "crackle: Input too small to be a valid stream. Bytes: " + std::to_string(n));
+	d.head = Header::parse(buf, n);
+	const Header& h = d.head;
+	// range clamp (crackle.hpp:527-537)
+	int64_t zs = z_start, ze = z_end;
+	zs = std::max<int64_t>(std::min<int64_t>(zs, static_cast<int64_t>(h.sz) - 1), 0);
+	ze = ze < 0 ? static_cast<int64_t>(h.sz) : ze;
+	ze = std::max<int64_t>(std::min<int64_t>(ze, static_cast<int64_t>(h.sz)), 0);
+	if (zs >= ze) throw Error(CKL_ERR_RUNTIME, "crackle: Invalid range: " + std::to_string(zs) + " - " + std::to_string(ze));
+	d.z_start = zs; d.z_end = ze;
+	d.nslices = static_cast<uint32_t>(ze - zs);
+	d.sxy = static_cast<uint64_t>(h.sx) * h.sy;
+	d.n_bytes = n;
+	if (d.sxy == 0) return;
+	if (d.sxy >= (1ull << 31)) throw Error(CKL_ERR_ARG, "crackle_amd: slices of 2^31 or more pixels are not supported");
+
+	const uint64_t hb = h.header_bytes(), gib = h.grid_index_bytes();
+	const uint64_t tail = h.format_version == 0 ? 0 : 4ull * (static_cast<uint64_t>(h.sz) + 1);
+	if (hb + gib + h.num_label_bytes + h.markov_model_bytes() + tail > n) {
+		throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_code_offsets: Unable to read past end of buffer.");
+	}
+	// z-index (crackle.hpp:262-313)
+	if (h.format_version > 0) {
+		const uint32_t stored = static_cast<uint32_t>(rd_le(buf + hb + 4ull * h.sz, 4));
+		const uint32_t computed = crc32c(buf + hb, 4ull * h.sz);
+		if (stored != computed) {
+			throw Error(CKL_ERR_CRC, "crackle: grid index crc32c did not match. stored: " + std::to_string(stored) + " computed: " + std::to_string(computed));
+		}
+	}
+	std::vector<uint64_t> z_index(static_cast<size_t>(h.sz) + 1);
+	z_index[0] = hb + gib + h.num_label_bytes + h.markov_model_bytes();
+	for (uint64_t z = 0; z < h.sz; z++) z_index[z + 1] = z_index[z] + rd_le(buf + hb + 4 * z, 4);
+	if (z_index[h.sz] + tail > n) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
+
+	hipStream_t s = d.stream;
+	// the whole stream goes to HBM once
+	d.d_stream.ensure(n + 16);
+	CKL_HIP(hipMemcpyAsync(d.d_stream.p, buf, n, hipMemcpyHostToDevice, s));
+
+	// per-slice descriptors and scratch layout
+	const int xw = byte_width(static_cast<uint64_t>(h.sx) + 1), yw = byte_width(static_cast<uint64_t>(h.sy) + 1);
+	std::vector<uint64_t> code_off(d.nslices), cbase(d.nslices), nbase(d.nslices);
+	std::vector<uint32_t> code_len(d.nslices), ccap(d.nslices), ncap(d.nslices);
+	uint64_t ctot = 0, ntot = 0;
+	for (uint32_t zi = 0; zi < d.nslices; zi++) {
+		const uint64_t z = static_cast<uint64_t>(zs) + zi;
+		const uint64_t len = z_index[z + 1] - z_index[z];
+		if (len > 0xFFFFFFF0ull / 8) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack code of a slice is too large");
+		code_off[zi] = z_index[z];
+		code_len[zi] = static_cast<uint32_t>(len);
+		uint64_t index_size = len >= 4 ? rd_le(buf + z_index[z], 4) : 0;
+		uint64_t payload = (len >= 4 + index_size) ? len - 4 - index_size : 0;
+		// codes: 4 per byte (plain) or at most 8 per byte (+1 raw) for the markov bitstream
+		uint64_t cap = (h.markov_model_order ? payload * 8 + 1 : payload * 4) + 2;
+		uint64_t nodes_cap = std::min<uint64_t>(index_size, len) / xw + 1;
+		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cap); ctot += cap;
+		nbase[zi] = ntot; ncap[zi] = static_cast<uint32_t>(nodes_cap); ntot += nodes_cap;
+	}
+	(void)yw;
+	upload(d.d_code_off, code_off, s);
+	upload(d.d_code_len, code_len, s);
+	upload(d.d_cbase, cbase, s);
+	upload(d.d_ccap, ccap, s);
+	upload(d.d_nbase, nbase, s);
+	upload(d.d_ncap, ncap, s);
+	if (h.markov_model_order) d.d_ucode.ensure(ctot);
+	d.d_sym_kind.ensure(ctot);
+	d.d_sym_pos.ensure(ctot);
+	d.d_sym_seg.ensure(ctot);
+	d.d_ctl_sym.ensure(ctot);
+	d.d_seg_off.ensure(ctot);
+	d.d_stack.ensure(ctot);
+	d.d_nodes.ensure(ntot);
+
+	if (h.markov_model_order) {
+		std::vector<uint8_t> model = markov_model_from_stored(buf + hb + gib + h.num_label_bytes, h.markov_model_bytes(), h.markov_model_order);
+		upload(d.d_model, model, s);
+	}
+
+	// planes, CCL arrays
+	d.row_words = (h.sx + 31) / 32;
+	d.plane_words = static_cast<uint64_t>(d.row_words) * h.sy;
+	d.d_planes.ensure(2 * d.plane_words * d.nslices);
+	d.d_L.ensure(d.sxy * d.nslices);
+	d.d_R.ensure(d.sxy * d.nslices);
+	d.ccl_tiles = static_cast<uint32_t>((d.sxy + kCclTile - 1) / kCclTile);
+	d.d_tile_count.ensure(static_cast<size_t>(d.ccl_tiles) * d.nslices);
+	d.d_ncomp.ensure(d.nslices);
+	d.d_slice_err.ensure(d.nslices);
+	d.d_crc_acc.ensure(d.nslices);
+
+	// crc machinery: multiply-by-x^(32*256) tables, per-lane and per-tile powers
+	d.crc_tiles = static_cast<uint32_t>((d.sxy + kCrcTile - 1) / kCrcTile);
+	d.crc_pad = static_cast<uint32_t>(static_cast<uint64_t>(d.crc_tiles) * kCrcTile - d.sxy);
+	{
+		std::vector<uint32_t> tab(1024), lane_pow(kBlock), tile_pow(d.crc_tiles);
+		const uint32_t M = gf_xpow(32ull * kBlock);
+		for (int k = 0; k < 4; k++)
+			for (uint32_t b = 0; b < 256; b++) tab[k * 256 + b] = gf_mul(b << (8 * k), M);
+		for (int j = 0; j < kBlock; j++) lane_pow[j] = gf_xpow(32ull * (kBlock - j));
+		const uint32_t T = gf_xpow(32ull * kCrcTile);
+		uint32_t acc = 0x80000000u;   // x^0
+		for (uint32_t t = d.crc_tiles; t-- > 0;) { tile_pow[t] = acc; acc = gf_mul(acc, T); }
+		upload(d.d_crc_tab, tab, s);
+		upload(d.d_crc_lane_pow, lane_pow, s);
+		upload(d.d_crc_tile_pow, tile_pow, s);
+	}
+	d.check_crc = h.format_version > 0;
+	if (d.check_crc) {
+		// stored = ~(x^(32 n) * 0xFFFFFFFF ^ raw)  =>  raw = ~stored ^ init_term
+		const uint32_t init_term = gf_mul(0xFFFFFFFFu, gf_xpow(32ull * d.sxy));
+		std::vector<uint32_t> expect(d.nslices);
+		const uint8_t* crcs = buf + n - 4ull * h.sz;
+		for (uint32_t zi = 0; zi < d.nslices; zi++) {
+			const uint32_t stored = static_cast<uint32_t>(rd_le(crcs + 4ull * (zs + zi), 4));
+			expect[zi] = (~stored) ^ init_term;
+		}
+		upload(d.d_crc_expect, expect, s);
+	}
+
+	// label section layout (labels.hpp:424-451, 453-617), parsed once
+	const uint8_t* lb = buf + hb + gib;
+	const uint64_t nlb = h.num_label_bytes;
+	const int sw = h.stored_data_width;
+	const int component_width = byte_width(d.sxy);
+	uint64_t offset;
+	if (h.label_format == FLAT) {
+		if (nlb < 8) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+		d.num_unique = rd_le(lb, 8);
+		d.uniq_offset = 8;
+		if (d.num_unique > nlb / sw) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+		offset = 8 + static_cast<uint64_t>(sw) * d.num_unique;
+	}
+	else if (h.label_format == PINS_VARIABLE_WIDTH) {
+		if (nlb < static_cast<uint64_t>(sw) + 8) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+		d.bgcolor = read_stored(h, lb, 0);
+		d.num_unique = rd_le(lb + sw, 8);
+		d.uniq_offset = static_cast<uint64_t>(sw) + 8;
+		if (d.num_unique > nlb / sw) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+		offset = 8 + static_cast<uint64_t>(sw) * (d.num_unique + 1);
+	}
+	else {
+		throw Error(CKL_ERR_RUNTIME, "crackle: Unsupported label format. Got: " + std::to_string(h.label_format));
+	}
+	if (offset + static_cast<uint64_t>(component_width) * h.sz > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+	std::vector<uint64_t> comp_prefix(static_cast<size_t>(h.sz) + 1, 0);
+	for (uint64_t z = 0; z < h.sz; z++) {
+		comp_prefix[z + 1] = comp_prefix[z] + rd_le(lb + offset + z * component_width, component_width);
+	}
+	offset += static_cast<uint64_t>(component_width) * h.sz;
+	d.comp_left = comp_prefix[zs];
+	d.total_comp = comp_prefix[ze] - comp_prefix[zs];
+	std::vector<uint64_t> comp_off(d.nslices);
+	std::vector<uint32_t> ncomp_expect(d.nslices);
+	for (uint32_t zi = 0; zi < d.nslices; zi++) {
+		comp_off[zi] = comp_prefix[zs + zi] - comp_prefix[zs];
+		const uint64_t c = comp_prefix[zs + zi + 1] - comp_prefix[zs + zi];
+		if (c > d.sxy) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+		ncomp_expect[zi] = static_cast<uint32_t>(c);
+	}
+	upload(d.d_comp_off, comp_off, s);
+	upload(d.d_ncomp_expect, ncomp_expect, s);
+	d.d_label_map.ensure(d.total_comp + 1);
+
+	if (h.label_format == FLAT) {
+		d.key_width = byte_width(d.num_unique);
+		d.keys_offset = hb + gib + offset;
+		if (offset + comp_prefix[h.sz] * static_cast<uint64_t>(d.key_width) > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+	}
+	else {
+		if (offset + 1 > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+		const uint8_t combined = lb[offset++];
+		const int npw = 1 << (combined & 3), dw = 1 << ((combined >> 2) & 3), ccw = 1 << ((combined >> 4) & 3);
+		const int iw = h.pin_index_width();
+		std::vector<uint64_t> pin_index, pin_depth, pin_label, pin_work_off, ccl_id, ccl_label;
+		const uint64_t comp_right = comp_prefix[ze];
+		uint64_t i = offset, work = 0;
+		for (uint64_t label = 0; label < d.num_unique; label++) {
+			if (i + npw > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+			const uint64_t lv = read_stored(h, lb, d.uniq_offset + label * sw);
+			const uint64_t num_pins = rd_le(lb + i, npw); i += npw;
+			if (num_pins > nlb || i + num_pins * static_cast<uint64_t>(iw + dw) + npw > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+			uint64_t idx = 0;
+			for (uint64_t j = 0; j < num_pins; j++) {
+				idx += rd_le(lb + i + j * iw, iw);
+				const uint64_t depth = rd_le(lb + i + num_pins * iw + j * dw, dw);
+				const int64_t pin_z = static_cast<int64_t>(idx / d.sxy);
+				const int64_t a = std::max<int64_t>(pin_z, zs);
+				const int64_t b = std::min<int64_t>(pin_z + static_cast<int64_t>(depth) + 1, ze);
+				if (idx >= d.sxy * h.sz || b <= a) continue;   // pin does not touch the decoded range
+				pin_index.push_back(idx); pin_depth.push_back(depth); pin_label.push_back(lv);
+				pin_work_off.push_back(work);
+				work += static_cast<uint64_t>(b - a);
+			}
+			i += num_pins * static_cast<uint64_t>(iw + dw);
+			const uint64_t num_cc = rd_le(lb + i, npw); i += npw;
+			if (num_cc > nlb || i + num_cc * static_cast<uint64_t>(ccw) > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+			uint64_t id = 0;
+			for (uint64_t j = 0; j < num_cc; j++) {
+				id = (id + rd_le(lb + i, ccw)) & 0xFFFFFFFFull; i += ccw;
+				if (id >= d.comp_left && id < comp_right) { ccl_id.push_back(id); ccl_label.push_back(lv); }
+			}
+		}
+		d.n_pins = pin_index.size();
+		d.pin_total_work = work;
+		d.n_ccl = ccl_id.size();
+		upload(d.d_pin_index, pin_index, s);
+		upload(d.d_pin_depth, pin_depth, s);
+		upload(d.d_pin_label, pin_label, s);
+		upload(d.d_pin_work_off, pin_work_off, s);
+		upload(d.d_ccl_id, ccl_id, s);
+		upload(d.d_ccl_label, ccl_label, s);
+	}
+	CKL_HIP(hipStreamSynchronize(s));   // host vectors above go out of scope
+}
+
+template <typename OUT>
+void launch_paint(const PaintArgs& pa, uint32_t tiles, uint32_t nslices, hipStream_t s) {
+	hipLaunchKernelGGL(k_paint<OUT>, dim3(tiles, nslices), dim3(kBlock), 0, s, pa);
+}
+
+void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label) {
+	const Header& h = d.head;
+	if (d.sxy == 0 || d.nslices == 0) return;
+	const int ow = has_label ? 1 : h.data_width;
+	const uint64_t need = d.sxy * d.nslices * static_cast<uint64_t>(ow);
+	if (out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
+	hipStream_t s = d.stream;
+	const uint32_t ns = d.nslices;
+
+	CKL_HIP(hipEventRecord(d.ev0, s));
+	CKL_HIP(hipMemsetAsync(d.d_planes.p, 0, 2 * d.plane_words * ns * sizeof(uint32_t), s));
+	CKL_HIP(hipMemsetAsync(d.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
+	CKL_HIP(hipMemsetAsync(d.d_crc_acc.p, 0, ns * sizeof(uint32_t), s));
+
+	CrackArgs ca;
+	ca.stream = d.d_stream.p;
+	ca.code_off = d.d_code_off.p; ca.code_len = d.d_code_len.p;
+	ca.cbase = d.d_cbase.p; ca.ccap = d.d_ccap.p; ca.nbase = d.d_nbase.p; ca.ncap = d.d_ncap.p;
+	ca.sx = static_cast<int>(h.sx); ca.sy = static_cast<int>(h.sy);
+	ca.xw = byte_width(static_cast<uint64_t>(h.sx) + 1); ca.yw = byte_width(static_cast<uint64_t>(h.sy) + 1);
+	ca.markov_order = h.markov_model_order;
+	ca.model = d.d_model.p; ca.ucode = d.d_ucode.p;
+	ca.sym_kind = d.d_sym_kind.p; ca.sym_pos = d.d_sym_pos.p; ca.sym_seg = d.d_sym_seg.p;
+	ca.ctl_sym = d.d_ctl_sym.p; ca.seg_off = d.d_seg_off.p; ca.stack = d.d_stack.p; ca.nodes = d.d_nodes.p;
+	ca.planeV = d.d_planes.p; ca.planeH = d.d_planes.p + d.plane_words * ns;
+	ca.row_words = d.row_words; ca.plane_words = d.plane_words;
+	ca.slice_err = d.d_slice_err.p;
+	hipLaunchKernelGGL(k_decode_cracks, dim3(ns), dim3(kBlock), 0, s, ca);
+
+	PlaneConn conn;
+	conn.planeV = ca.planeV; conn.planeH = ca.planeH;
+	conn.row_words = d.row_words; conn.plane_words = d.plane_words;
+	conn.flip = (h.crack_format == IMPERMISSIBLE) ? 1u : 0u;
+	const int sx = static_cast<int>(h.sx), sy = static_cast<int>(h.sy);
+	hipLaunchKernelGGL(k_ccl_rows<PlaneConn>, dim3(h.sy, ns), dim3(kBlock), 0, s, conn, d.d_L.p, sx, sy);
+	hipLaunchKernelGGL(k_ccl_merge<PlaneConn>, dim3(d.ccl_tiles, ns), dim3(kBlock), 0, s, conn, d.d_L.p, sx, sy);
+	hipLaunchKernelGGL(k_ccl_flatten, dim3(d.ccl_tiles, ns), dim3(kBlock), 0, s, d.d_L.p, d.d_tile_count.p, d.sxy, d.ccl_tiles);
+	hipLaunchKernelGGL(k_ccl_scan, dim3(ns), dim3(kBlock), 0, s, d.d_tile_count.p, d.d_ncomp.p, d.ccl_tiles);
+	hipLaunchKernelGGL(k_ccl_rank, dim3(d.ccl_tiles, ns), dim3(kBlock), 0, s, d.d_L.p, d.d_R.p, d.d_tile_count.p, d.sxy, d.ccl_tiles);
+
+	// component -> label
+	const uint64_t nlm = d.total_comp;
+	if (h.label_format == FLAT) {
+		if (nlm) {
+			const uint8_t* keys = d.d_stream.p + d.keys_offset + d.comp_left * static_cast<uint64_t>(d.key_width);
+			const uint8_t* uniq = d.d_stream.p + h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
+			hipLaunchKernelGGL(k_label_map_flat, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+				keys, d.key_width, uniq, h.stored_data_width, d.num_unique, h.is_signed ? 1u : 0u, nlm, d.d_label_map.p);
+		}
+	}
+	else {
+		if (nlm) hipLaunchKernelGGL(k_fill_u64, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d.d_label_map.p, d.bgcolor, nlm);
+		if (d.n_ccl) hipLaunchKernelGGL(k_label_map_ccids, dim3(static_cast<uint32_t>((d.n_ccl + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+			d.d_ccl_id.p, d.d_ccl_label.p, d.n_ccl, d.comp_left, d.comp_left + nlm, d.d_label_map.p);
+		if (d.pin_total_work) hipLaunchKernelGGL(k_label_map_pins, dim3(static_cast<uint32_t>((d.pin_total_work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+			d.d_pin_index.p, d.d_pin_depth.p, d.d_pin_label.p, d.d_pin_work_off.p, d.n_pins, d.pin_total_work,
+			d.d_L.p, d.d_R.p, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp.p, d.d_label_map.p);
+	}
+
+	PaintArgs pa;
+	pa.L = d.d_L.p; pa.R = d.d_R.p; pa.label_map = d.d_label_map.p; pa.comp_off = d.d_comp_off.p; pa.ncomp = d.d_ncomp.p;
+	pa.crc_stride_tab = d.d_crc_tab.p; pa.crc_lane_pow = d.d_crc_lane_pow.p; pa.crc_tile_pow = d.d_crc_tile_pow.p;
+	pa.crc_acc = d.d_crc_acc.p; pa.slice_err = d.d_slice_err.p;
+	pa.out = out_device; pa.sxy = d.sxy; pa.sx = h.sx; pa.sy = h.sy;
+	pa.tiles = d.crc_tiles; pa.pad = d.crc_pad; pa.nslices = ns;
+	pa.fortran_order = h.fortran_order ? 1u : 0u;
+	pa.has_label = has_label ? 1u : 0u; pa.label = label;
+	CKL_HIP(hipEventRecord(d.evk0, s));
+	if (has_label) launch_paint<uint8_t>(pa, d.crc_tiles, ns, s);
+	else if (h.data_width == 1) launch_paint<uint8_t>(pa, d.crc_tiles, ns, s);
+	else if (h.data_width == 2) launch_paint<uint16_t>(pa, d.crc_tiles, ns, s);
+	else if (h.data_width == 4) launch_paint<uint32_t>(pa, d.crc_tiles, ns, s);
+	else launch_paint<uint64_t>(pa, d.crc_tiles, ns, s);
+	CKL_HIP(hipEventRecord(d.evk1, s));
+
+	hipLaunchKernelGGL(k_check, dim3((ns + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+		d.d_crc_acc.p, d.d_crc_expect.p, d.d_ncomp.p, d.d_ncomp_expect.p,
+		d.check_crc ? 1u : 0u, 1u, ns, d.d_slice_err.p);
+	CKL_HIP(hipEventRecord(d.ev1, s));
+
+	std::vector<uint32_t> errs(ns);
+	CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipStreamSynchronize(s));
+	CKL_HIP(hipGetLastError());
+	CKL_HIP(hipEventElapsedTime(&d.pipeline_ms, d.ev0, d.ev1));
+	CKL_HIP(hipEventElapsedTime(&d.dominant_ms, d.evk0, d.evk1));
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		const uint32_t e = errs[zi];
+		if (!e) continue;
+		const std::string z = std::to_string(d.z_start + zi);
+		if (e & (ERR_BOC | ERR_RANGE | ERR_CAPACITY)) throw Error(CKL_ERR_RUNTIME, "crackle: crack code is malformed or corrupted on z=" + z);
+		if (e & ERR_CRC) throw Error(CKL_ERR_CRC, "crackle: crack code crc mismatch on z=" + z);
+		throw Error(CKL_ERR_RUNTIME, "crackle: component count does not match the label section on z=" + z);
+	}
+}
+
+}  // namespace
+
+extern "C" {
+
+int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, int device, ckl_decoder** out) {
+	try {
+		if (!buf || !out) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		// header problems are format errors even when no device is present
+		if (n < Header::kBytesV0) throw Error(CKL_ERR_FORMAT, "crackle: Input too small to be a valid stream. Bytes: " + std::to_string(n));
+		(void)Header::parse(buf, n);
+		select_device(device);
+		std::unique_ptr<ckl_decoder> d(new ckl_decoder());
+		d->device = device;
+		CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+		CKL_HIP(hipEventCreate(&d->ev0));
+		CKL_HIP(hipEventCreate(&d->ev1));
+		CKL_HIP(hipEventCreate(&d->evk0));
+		CKL_HIP(hipEventCreate(&d->evk1));
+		decoder_build(*d, buf, n, z_start, z_end);
+		*out = d.release();
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label) {
+	try {
+		if (!d) throw Error(CKL_ERR_ARG, "crackle_amd: null decoder");
+		select_device(d->device);
+		decoder_run(*d, out_device, out_capacity_bytes, has_label, label);
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_decoder_last_timing(const ckl_decoder* d, float* pipeline_ms, float* dominant_kernel_ms) {
+	if (!d) { set_last_error("crackle_amd: null decoder"); return CKL_ERR_ARG; }
+	if (pipeline_ms) *pipeline_ms = d->pipeline_ms;
+	if (dominant_kernel_ms) *dominant_kernel_ms = d->dominant_ms;
+	return CKL_OK;
+}
+
+void ckl_decoder_destroy(ckl_decoder* d) { delete d; }
+
+int ckl_decompress(
+	const uint8_t* buf, uint64_t n, void* out, uint64_t out_capacity_bytes, int out_mem,
+	int64_t z_start, int64_t z_end, int has_label, uint64_t label, int device
+) {
+	ckl_decoder* d = nullptr;
+	int rc = ckl_decoder_create(buf, n, z_start, z_end, device, &d);
+	if (rc != CKL_OK) return rc;
+	try {
+		const uint64_t need = d->sxy * d->nslices * static_cast<uint64_t>(has_label ? 1 : d->head.data_width);
+		if (need == 0) { ckl_decoder_destroy(d); return CKL_OK; }
+		if (out_capacity_bytes < need || !out) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
+		if (out_mem == CKL_MEM_DEVICE) {
+			decoder_run(*d, out, out_capacity_bytes, has_label, label);
+		}
+		else {
+			DevBuf<uint8_t> tmp;
+			tmp.ensure(need);
+			decoder_run(*d, tmp.p, need, has_label, label);
+			CKL_HIP(hipMemcpy(out, tmp.p, need, hipMemcpyDeviceToHost));
+		}
+		ckl_decoder_destroy(d);
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); ckl_decoder_destroy(d); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); ckl_decoder_destroy(d); return CKL_ERR_RUNTIME; }
+}
+
+}  // extern "C"

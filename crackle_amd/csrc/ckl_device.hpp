@@ -1,0 +1,169 @@
+// Device-side building blocks shared by the decode and encode kernels (gfx950,
+// wave64).  Block size is fixed at 256 threads = 4 wavefronts everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace ckl {
+namespace dev {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+constexpr int kWaves = kBlock / kWave;
+
+// ---- wavefront / block scans ---------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+	const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+	for (int d = 1; d < kWave; d <<= 1) {
+		uint32_t t = __shfl_up(v, d, kWave);
+		if (lane >= d) v += t;
+	}
+	return v;
+}
+__device__ __forceinline__ int32_t wave_incl_max(int32_t v) {
+	const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+	for (int d = 1; d < kWave; d <<= 1) {
+		int32_t t = __shfl_up(v, d, kWave);
+		if (lane >= d) v = t > v ? t : v;
+	}
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+#pragma unroll
+	for (int d = kWave / 2; d >= 1; d >>= 1) v ^= __shfl_xor(v, d, kWave);
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+	for (int d = kWave / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+	return v;
+}
+
+// Exclusive block scan (sum) of K values per thread at once.  `lds` must hold
+// K * kWaves uint32.  Returns exclusive prefixes in v[], block totals in total[].
+// Ends with a barrier so `lds` can be reused immediately.
+template <int K>
+__device__ __forceinline__ void block_excl_add(uint32_t (&v)[K], uint32_t (&total)[K], uint32_t* lds) {
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = threadIdx.x >> 6;
+	uint32_t incl[K];
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		incl[k] = wave_incl_add(v[k]);
+		if (lane == kWave - 1) lds[k * kWaves + wave] = incl[k];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		uint32_t base = 0, tot = 0;
+#pragma unroll
+		for (int w = 0; w < kWaves; w++) {
+			uint32_t s = lds[k * kWaves + w];
+			if (w < wave) base += s;
+			tot += s;
+		}
+		v[k] = base + incl[k] - v[k];
+		total[k] = tot;
+	}
+	__syncthreads();
+}
+
+// Exclusive block max-scan of one int32 (identity INT32_MIN).  lds: kWaves int32.
+__device__ __forceinline__ int32_t block_excl_max(int32_t v, int32_t& total, int32_t* lds) {
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = threadIdx.x >> 6;
+	const int32_t incl = wave_incl_max(v);
+	if (lane == kWave - 1) lds[wave] = incl;
+	int32_t excl = __shfl_up(incl, 1, kWave);
+	if (lane == 0) excl = INT32_MIN;
+	__syncthreads();
+	int32_t base = INT32_MIN, tot = INT32_MIN;
+#pragma unroll
+	for (int w = 0; w < kWaves; w++) {
+		int32_t s = lds[w];
+		if (w < wave) base = s > base ? s : base;
+		tot = s > tot ? s : tot;
+	}
+	total = tot;
+	__syncthreads();
+	return excl > base ? excl : base;
+}
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds) {
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = threadIdx.x >> 6;
+	v = wave_sum(v);
+	if (lane == 0) lds[wave] = v;
+	__syncthreads();
+	uint32_t tot = 0;
+#pragma unroll
+	for (int w = 0; w < kWaves; w++) tot += lds[w];
+	__syncthreads();
+	return tot;
+}
+__device__ __forceinline__ uint32_t block_xor(uint32_t v, uint32_t* lds) {
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = threadIdx.x >> 6;
+	v = wave_xor(v);
+	if (lane == 0) lds[wave] = v;
+	__syncthreads();
+	uint32_t tot = 0;
+#pragma unroll
+	for (int w = 0; w < kWaves; w++) tot ^= lds[w];
+	__syncthreads();
+	return tot;
+}
+
+// ---- CRC-32C in GF(2)[x]/P, reflected (bit 31 <-> x^0) -------------------------
+constexpr uint32_t kCrcPoly = 0x82F63B78u;
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b) {
+	uint32_t r = 0;
+#pragma unroll 8
+	for (int i = 0; i < 32; i++) {
+		r ^= (a & (0x80000000u >> i)) ? b : 0u;
+		b = (b >> 1) ^ ((b & 1u) ? kCrcPoly : 0u);
+	}
+	return r;
+}
+
+// Per-tile CRC machinery.  A tile is kCrcTile consecutive u32 words of one
+// slice's component image; thread j folds words j, j+256, ... with the Horner
+// step acc = acc * x^(32*256) ^ word, the multiplication done with four
+// 256-entry tables staged in LDS (crc_stride_tab, 4 KiB, computed on the host).
+constexpr int kCrcTile = 1024;                 // words per tile
+constexpr int kCrcRows = kCrcTile / kBlock;    // words per thread
+__device__ __forceinline__ uint32_t crc_stride_step(const uint32_t* tab /* LDS [4][256] */, uint32_t acc) {
+	return tab[acc & 0xFF] ^ tab[256 + ((acc >> 8) & 0xFF)] ^ tab[512 + ((acc >> 16) & 0xFF)] ^ tab[768 + (acc >> 24)];
+}
+
+// ---- union-find on a per-slice u32 parent array (root = smallest index) ---------
+__device__ __forceinline__ uint32_t uf_load(const uint32_t* L, uint32_t i) {
+	return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t uf_find(const uint32_t* L, uint32_t a) {
+	for (;;) {
+		uint32_t p = uf_load(L, a);
+		if (p == a) return a;
+		a = p;
+	}
+}
+// Link the trees of a and b.  Parents only ever decrease, and the link is an
+// atomicMin on a node believed to be a root: if it no longer is, the returned
+// value is its newer (smaller) parent and the merge continues from there.
+__device__ __forceinline__ void uf_unite(uint32_t* L, uint32_t a, uint32_t b) {
+	for (;;) {
+		a = uf_find(L, a);
+		b = uf_find(L, b);
+		if (a == b) return;
+		if (a > b) { uint32_t t = a; a = b; b = t; }
+		uint32_t old = atomicMin(L + b, a);
+		if (old == b) return;
+		b = old;
+	}
+}
+
+}  // namespace dev
+}  // namespace ckl

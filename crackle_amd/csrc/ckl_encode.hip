@@ -1,0 +1,1119 @@
+// Encode path: label volume resident in HBM -> .ckl bytes.
+// Replaces crackle::compress<LABEL> (src/crackle.hpp:34-257) and what it calls:
+//   lib::max_label / pixel_pairs                    src/lib.hpp:224-256        k_stats
+//   crackcodes::Graph::init                         src/crackcodes.hpp:66-125  k_crack_graph
+//   create_crack_codes walk + remove_initial_branch +
+//     remove_spurious_branches + symbols_to_codepoints
+//                                                   src/crackcodes.hpp:128-281, 374-453  k_walk
+//   pack_codepoints / write_boc_index               src/crackcodes.hpp:318-372, 455-496  k_finish
+//   markov::gather_statistics / encode_markov       src/markov.hpp:193-220, 422-473      k_markov_hist / k_markov_pack
+//   cc3d::connected_components2d_4 + relabel        src/cc3d.hpp:114-144, 257-369        ckl_ccl.hpp
+//   labels::encode_flat                             src/labels.hpp:30-155      k_cc_crc, k_mapping + host sort/unique
+//   stream assembly                                 src/crackle.hpp:171-216    host
+#include "ckl_common.hpp"
+#include "ckl_ccl.hpp"
+
+#include <algorithm>
+#include <memory>
+
+namespace ckl {
+
+using namespace dev;
+
+// ------------------------------------------------------------------------------
+// whole-volume reductions (lib.hpp:224-256)
+// ------------------------------------------------------------------------------
+template <typename LABEL>
+__global__ void __launch_bounds__(kBlock) k_stats(const LABEL* __restrict__ labels, uint64_t voxels, unsigned long long* __restrict__ out /* [0]=max [1]=pairs */) {
+	__shared__ unsigned long long s_max[kWaves], s_pairs[kWaves];
+	unsigned long long mx = 0, pairs = 0;
+	const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+	for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < voxels; i += stride) {
+		const LABEL v = labels[i];
+		if (static_cast<unsigned long long>(v) > mx) mx = v;
+		if (i > 0) pairs += (labels[i - 1] == v);
+	}
+	for (int d = kWave / 2; d >= 1; d >>= 1) {
+		const unsigned long long om = __shfl_xor(mx, d, kWave);
+		const unsigned long long op = __shfl_xor(pairs, d, kWave);
+		mx = om > mx ? om : mx;
+		pairs += op;
+	}
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (lane == 0) { s_max[wave] = mx; s_pairs[wave] = pairs; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < kWaves; w++) { mx = s_max[w] > mx ? s_max[w] : mx; pairs += s_pairs[w]; }
+		atomicMax(out, mx);
+		atomicAdd(out + 1, pairs);
+	}
+}
+
+// ------------------------------------------------------------------------------
+// crack graph: one adjacency nibble per vertex of the (sx+1) x (sy+1) corner grid
+// bit0 -> right, bit1 -> left, bit2 -> down, bit3 -> up   (crackcodes.hpp:66-125)
+// grid = (ceil(nverts / 256), nslices)
+// ------------------------------------------------------------------------------
+template <typename LABEL>
+__global__ void __launch_bounds__(kBlock) k_crack_graph(
+	const LABEL* __restrict__ labels, int sx, int sy, uint32_t permissible,
+	uint8_t* __restrict__ adj, uint64_t adj_stride, uint32_t* __restrict__ deg_sum
+) {
+	__shared__ uint32_t s_red[kWaves];
+	const uint32_t zi = blockIdx.y;
+	const uint32_t sxe = sx + 1, sye = sy + 1;
+	const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+	uint32_t nib = 0;
+	if (v < sxe * sye) {
+		const int y = v / sxe;
+		const int x = v - y * sxe;
+		const LABEL* s = labels + static_cast<uint64_t>(zi) * sx * sy;
+		auto L = [&](int xx, int yy) { return s[static_cast<uint64_t>(yy) * sx + xx]; };
+		auto crack = [&](LABEL p, LABEL q) { return static_cast<uint32_t>((p == q) == (permissible != 0)); };
+		if (x < sx && y >= 1 && y < sy) nib |= crack(L(x, y), L(x, y - 1)) << 0;
+		if (x >= 1 && y >= 1 && y < sy) nib |= crack(L(x - 1, y), L(x - 1, y - 1)) << 1;
+		if (x >= 1 && x < sx && y < sy) nib |= crack(L(x, y), L(x - 1, y)) << 2;
+		if (x >= 1 && x < sx && y >= 1) nib |= crack(L(x, y - 1), L(x - 1, y - 1)) << 3;
+		adj[zi * adj_stride + v] = static_cast<uint8_t>(nib);
+	}
+	const uint32_t tot = block_sum(__popc(nib), s_red);
+	if (threadIdx.x == 0 && tot) atomicAdd(deg_sum + zi, tot);
+}
+
+// ------------------------------------------------------------------------------
+// the walk: exact restatement of the reference's deterministic depth-first trail
+// (crackcodes.hpp:390-450), one wavefront per slice.  Lane 0 walks; the whole
+// wavefront cooperates on next_cluster (crackcodes.hpp:41-49).  Code points are
+// produced directly, with the two clean-ups folded in:
+//   remove_initial_branch (185-242): decided at the first 't' of a chain;
+//   remove_spurious_branches (250-281): a 't' that directly follows a 't' deletes
+//     itself and the 'b' popped by its predecessor (tombstone 0xFF, compacted later).
+// ------------------------------------------------------------------------------
+struct WalkArgs {
+	uint8_t* adj;
+	uint64_t adj_stride;
+	int sx, sy;
+	const uint64_t* cbase;    // per slice: base into cp / stacks
+	const uint32_t* ccap;     // capacity of cp (codes)
+	const uint64_t* sbase;    // per slice: base into the branch stack
+	const uint32_t* scap;
+	const uint64_t* kbase;    // per slice: base into the chain table
+	const uint32_t* kcap;
+	uint8_t* cp;
+	uint32_t* stack_node;
+	uint32_t* stack_code;
+	uint32_t* chain_node;     // adjusted start vertex
+	uint32_t* chain_off;      // raw offset into cp
+	uint32_t* chain_clen;     // number of codes that survive compaction
+	uint32_t* n_chains;       // [nslices]
+	uint32_t* n_raw;          // [nslices]
+	uint32_t* n_valid;        // [nslices]
+	uint32_t* slice_err;
+};
+
+enum : uint32_t { ENC_ERR_CAPACITY = 1u };
+enum : uint8_t { CODE_UP = 0, CODE_RIGHT = 1, CODE_DOWN = 2, CODE_LEFT = 3, CODE_NONE = 0xFE, CODE_TOMB = 0xFF };
+
+__global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
+	const uint32_t zi = blockIdx.x;
+	const int lane = threadIdx.x;
+	uint8_t* adj = a.adj + zi * a.adj_stride;
+	const uint32_t sxe = a.sx + 1, sye = a.sy + 1;
+	const uint32_t nverts = sxe * sye;
+	uint8_t* cp = a.cp + a.cbase[zi];
+	const uint32_t cap = a.ccap[zi];
+	uint32_t* st_node = a.stack_node + a.sbase[zi];
+	uint32_t* st_code = a.stack_code + a.sbase[zi];
+	const uint32_t scap = a.scap[zi];
+	uint32_t* ch_node = a.chain_node + a.kbase[zi];
+	uint32_t* ch_off = a.chain_off + a.kbase[zi];
+	uint32_t* ch_clen = a.chain_clen + a.kbase[zi];
+	const uint32_t kcap = a.kcap[zi];
+
+	uint32_t start = 0;     // wave uniform
+	uint32_t nraw = 0, nch = 0, nvalid = 0, err = 0;   // meaningful in lane 0, broadcast after each chain
+
+	for (;;) {
+		// ---- next_cluster: first vertex >= start with edges, 512 vertices per step ----
+		uint32_t found = 0xFFFFFFFFu;
+		for (uint32_t base = start & ~7u; base < nverts; base += kWave * 8) {
+			const uint32_t idx = base + lane * 8;
+			unsigned long long w = 0;
+			if (idx < nverts) {   // adj_stride is padded with zero bytes to a multiple of 8 beyond nverts
+				w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(adj + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (idx < start) {    // mask bytes below start (only in the first step)
+				const uint32_t skip = start - idx;
+				w = skip >= 8 ? 0ull : (w >> (8 * skip)) << (8 * skip);
+			}
+			const unsigned long long m = __ballot(w != 0);
+			if (m) {
+				const int first = __ffsll(static_cast<long long>(m)) - 1;
+				const unsigned long long fw = __shfl(w, first, kWave);
+				found = base + first * 8 + ((__ffsll(static_cast<long long>(fw)) - 1) >> 3);
+				break;
+			}
+		}
+		if (found == 0xFFFFFFFFu || found >= nverts) break;
+		start = found;
+
+		if (lane == 0 && adj[start] != 0) {
+			// ---- one chain -------------------------------------------------------------
+			uint32_t node = start, sp = 0;
+			const uint32_t chain_begin = nraw;
+			uint32_t tomb = 0, sym_index = 0;
+			uint32_t last_code = CODE_NONE;
+			bool rib_pending = false;       // chain began with 'b', no other 'b' and no 't' yet
+			bool prev_t = false;            // previous symbol is a live 't' ...
+			uint32_t prev_t_b = 0;          // ... that popped the 'b' whose codes sit at this offset
+			uint32_t adjusted = start;
+			const int32_t dirs[4] = { 1, -1, static_cast<int32_t>(sxe), -static_cast<int32_t>(sxe) };
+			const uint8_t move_code[4] = { CODE_RIGHT, CODE_LEFT, CODE_DOWN, CODE_UP };
+
+			auto put = [&](uint32_t c) {
+				if (nraw < cap) cp[nraw] = static_cast<uint8_t>(c); else err |= ENC_ERR_CAPACITY;
+				nraw++;
+			};
+			auto emit_t = [&](bool has_pop, uint32_t popped_code) {
+				if (prev_t) {
+					// spurious pair: the 'b' popped by the previous 't' and this 't' vanish
+					if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
+					tomb += 2;
+				}
+				else {
+					if (sym_index > 0 && last_code != CODE_NONE && last_code != CODE_UP) { put(CODE_DOWN); put(CODE_UP); last_code = CODE_UP; }
+					else { put(CODE_RIGHT); put(CODE_LEFT); last_code = CODE_LEFT; }
+					sym_index++;
+				}
+				prev_t = has_pop;
+				prev_t_b = popped_code;
+			};
+
+			// every iteration consumes an edge or pops a branch: bounded by the code capacity
+			for (uint32_t guard = 0;; guard++) {
+				if (guard > cap) { err |= ENC_ERR_CAPACITY; break; }
+				const uint32_t av = adj[node];
+				if (av == 0) {
+					if (sp == 0) break;
+					sp--;
+					const uint32_t pnode = st_node[sp], pcode = st_code[sp];
+					if (rib_pending) {
+						// remove_initial_branch: drop the leading 'b' and this 't', walk the
+						// first stretch backwards (reverse order, opposite directions) and
+						// start the chain where the stretch ended.
+						rib_pending = false;
+						adjusted = node;
+						if (chain_begin + 1 < cap) { cp[chain_begin] = CODE_TOMB; cp[chain_begin + 1] = CODE_TOMB; }
+						tomb += 2;
+						const uint32_t hi_end = nraw < cap ? nraw : cap;
+						if (hi_end > chain_begin + 2) {
+							uint32_t lo = chain_begin + 2, hi = hi_end - 1;
+							while (lo < hi) {
+								const uint8_t x = cp[lo], y = cp[hi];
+								cp[lo] = y ^ 2; cp[hi] = x ^ 2;
+								lo++; hi--;
+							}
+							if (lo == hi) cp[lo] ^= 2;
+							last_code = cp[hi_end - 1];
+						}
+						sym_index++;      // the 's' that replaces the 't' still occupies a symbol slot
+						prev_t = false;
+					}
+					else {
+						emit_t(true, pcode);
+					}
+					node = pnode;
+					continue;
+				}
+				if (__popc(av) > 1) {
+					if (sym_index == 0) rib_pending = true;
+					else rib_pending = false;
+					if (sp < scap) { st_node[sp] = node; st_code[sp] = nraw; } else err |= ENC_ERR_CAPACITY;
+					sp++;
+					if (sym_index > 0 && last_code != CODE_NONE && last_code != CODE_DOWN) { put(CODE_UP); put(CODE_DOWN); last_code = CODE_DOWN; }
+					else { put(CODE_LEFT); put(CODE_RIGHT); last_code = CODE_RIGHT; }
+					sym_index++;
+					prev_t = false;
+					if (err) break;
+				}
+				const int k = __ffs(av) - 1;
+				const uint32_t next = node + dirs[k];
+				put(move_code[k]);
+				last_code = move_code[k];
+				sym_index++;
+				prev_t = false;
+				adj[node] = static_cast<uint8_t>(av & ~(1u << k));
+				adj[next] = static_cast<uint8_t>(adj[next] & ~(1u << (k ^ 1)));
+				node = next;
+			}
+			// the closing 't' (branches_taken returns to 0, crackcodes.hpp:436-439)
+			emit_t(false, 0);
+
+			if (nch < kcap) {
+				ch_node[nch] = adjusted;
+				ch_off[nch] = chain_begin;
+				ch_clen[nch] = (nraw - chain_begin) - tomb;
+			}
+			else err |= ENC_ERR_CAPACITY;
+			nch++;
+			nvalid += (nraw - chain_begin) - tomb;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		err = __shfl(err, 0, kWave);
+		if (err) break;
+		start = start + 1;   // adj[start] is exhausted now (or was already)
+		if (start >= nverts) break;
+	}
+	if (lane == 0) {
+		a.n_chains[zi] = nch;
+		a.n_raw[zi] = nraw;
+		a.n_valid[zi] = nvalid;
+		if (err) atomicOr(a.slice_err + zi, err);
+	}
+}
+
+// ------------------------------------------------------------------------------
+// k_finish: chain order, compaction, difference coding, 2-bit packing, BOC index
+// (crackcodes.hpp:318-372, 455-496); one workgroup per slice.
+// ------------------------------------------------------------------------------
+struct FinishArgs {
+	int sx, sy, xw, yw;
+	uint32_t markov;           // 1: write difference codes to dcode instead of packing
+	const uint64_t* cbase;
+	const uint64_t* kbase;
+	const uint32_t* n_chains;
+	const uint32_t* n_raw;
+	const uint32_t* n_valid;
+	const uint8_t* cp;
+	const uint32_t* chain_node;
+	const uint32_t* chain_off;
+	const uint32_t* chain_clen;
+	uint32_t* chain_order;     // scratch [kcap]
+	uint32_t* chain_dst;       // scratch [kcap]
+	uint32_t* chain_vstart;    // scratch [kcap]
+	uint8_t* fcode;            // final-order code points   (at cbase)
+	uint8_t* dcode;            // final-order difference codes (at cbase; markov only)
+	const uint64_t* pbase;     // per slice: base into payload (4-byte aligned)
+	uint8_t* payload;
+	const uint64_t* bbase;     // per slice: base into boc
+	uint8_t* boc;
+	uint32_t* payload_len;     // [nslices]
+	uint32_t* boc_len;         // [nslices]
+};
+
+__device__ __forceinline__ void put_le_dev(uint8_t* p, uint32_t v, int w) {
+	for (int i = 0; i < w; i++) p[i] = static_cast<uint8_t>((v >> (8 * i)) & 0xFF);
+}
+
+__global__ void __launch_bounds__(kBlock) k_finish(FinishArgs a) {
+	__shared__ uint32_t s_scan[kWaves];
+	const uint32_t zi = blockIdx.x;
+	const int tid = threadIdx.x;
+	const uint32_t nch = a.n_chains[zi], nraw = a.n_raw[zi], nvalid = a.n_valid[zi];
+	const uint8_t* cp = a.cp + a.cbase[zi];
+	uint8_t* fcode = a.fcode + a.cbase[zi];
+	const uint32_t* ch_node = a.chain_node + a.kbase[zi];
+	const uint32_t* ch_off = a.chain_off + a.kbase[zi];
+	const uint32_t* ch_clen = a.chain_clen + a.kbase[zi];
+	uint32_t* order = a.chain_order + a.kbase[zi];
+	uint32_t* dst = a.chain_dst + a.kbase[zi];
+	uint32_t* vstart = a.chain_vstart + a.kbase[zi];
+	const uint32_t sxe = a.sx + 1;
+
+	// ---- phase 1 (serial over chains): order by start vertex, output offsets, BOC index ----
+	if (tid == 0) {
+		uint32_t v = 0;
+		for (uint32_t c = 0; c < nch; c++) { vstart[c] = v; v += ch_clen[c]; }
+		// chains come out in ascending raw start order and remove_initial_branch only
+		// moves a start inside its own component: insertion sort on a nearly sorted list
+		for (uint32_t c = 0; c < nch; c++) {
+			const uint32_t key = ch_node[c];
+			uint32_t p = c;
+			while (p > 0 && ch_node[order[p - 1]] > key) { order[p] = order[p - 1]; p--; }
+			order[p] = c;
+		}
+		uint32_t d = 0;
+		for (uint32_t i = 0; i < nch; i++) { dst[order[i]] = d; d += ch_clen[order[i]]; }
+
+		// write_boc_index (crackcodes.hpp:318-372)
+		uint8_t* b = a.boc + a.bbase[zi];
+		uint32_t num_y = 0, index_size = a.yw;
+		for (uint32_t i = 0; i < nch;) {
+			const uint32_t y = ch_node[order[i]] / sxe;
+			uint32_t j = i;
+			while (j < nch && ch_node[order[j]] / sxe == y) j++;
+			index_size += a.yw + (j - i + 1) * a.xw;
+			num_y++;
+			i = j;
+		}
+		uint32_t idx = 0;
+		put_le_dev(b + idx, index_size, 4); idx += 4;
+		put_le_dev(b + idx, num_y, a.yw); idx += a.yw;
+		uint32_t last_y = 0;
+		for (uint32_t i = 0; i < nch;) {
+			const uint32_t y = ch_node[order[i]] / sxe;
+			uint32_t j = i;
+			while (j < nch && ch_node[order[j]] / sxe == y) j++;
+			put_le_dev(b + idx, y - last_y, a.yw); idx += a.yw;
+			last_y = y;
+			put_le_dev(b + idx, j - i, a.xw); idx += a.xw;
+			uint32_t last_x = 0;
+			for (uint32_t k = i; k < j; k++) {
+				const uint32_t x = ch_node[order[k]] - sxe * y;
+				put_le_dev(b + idx, x - last_x, a.xw); idx += a.xw;
+				last_x = x;
+			}
+			i = j;
+		}
+		a.boc_len[zi] = idx;
+	}
+	__syncthreads();
+	__threadfence_block();
+
+	// ---- phase 2: compaction of tombstones + scatter of each chain to its sorted place ----
+	constexpr uint32_t kPer = 16;
+	uint32_t carry = 0;
+	for (uint32_t tile = 0; tile < nraw; tile += kBlock * kPer) {
+		const uint32_t i0 = tile + tid * kPer;
+		uint32_t cnt = 0;
+		uint8_t c[kPer];
+#pragma unroll
+		for (uint32_t k = 0; k < kPer; k++) {
+			const uint32_t i = i0 + k;
+			c[k] = i < nraw ? cp[i] : CODE_TOMB;
+			cnt += (c[k] != CODE_TOMB);
+		}
+		uint32_t v[1] = { cnt }, tot[1];
+		block_excl_add<1>(v, tot, s_scan);
+		uint32_t g = carry + v[0];
+		if (cnt) {
+			// chain of raw index i0: last chain with ch_off <= i0
+			uint32_t lo = 0, hi = nch;
+			while (lo + 1 < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (ch_off[mid] <= i0) lo = mid; else hi = mid;
+			}
+			uint32_t chain = lo;
+			uint32_t next_off = (chain + 1 < nch) ? ch_off[chain + 1] : 0xFFFFFFFFu;
+#pragma unroll
+			for (uint32_t k = 0; k < kPer; k++) {
+				const uint32_t i = i0 + k;
+				while (i >= next_off) { chain++; next_off = (chain + 1 < nch) ? ch_off[chain + 1] : 0xFFFFFFFFu; }
+				if (c[k] != CODE_TOMB) {
+					fcode[dst[chain] + (g - vstart[chain])] = c[k];
+					g++;
+				}
+			}
+		}
+		carry += tot[0];
+	}
+	__syncthreads();
+	__threadfence_block();
+
+	// ---- phase 3: whole-slice mod-4 difference code, then 2-bit packing ----
+	if (a.markov) {
+		uint8_t* dcode = a.dcode + a.cbase[zi];
+		for (uint32_t g = tid; g < nvalid; g += kBlock) {
+			const uint32_t prev = g ? fcode[g - 1] : 0u;
+			dcode[g] = static_cast<uint8_t>((fcode[g] - prev) & 3u);
+		}
+		if (tid == 0) a.payload_len[zi] = 0;
+	}
+	else {
+		uint8_t* out = a.payload + a.pbase[zi];
+		const uint32_t nbytes = (nvalid + 3) / 4;
+		for (uint32_t b = tid; b < nbytes; b += kBlock) {
+			uint32_t enc = 0;
+#pragma unroll
+			for (uint32_t j = 0; j < 4; j++) {
+				const uint32_t g = b * 4 + j;
+				if (g < nvalid) {
+					const uint32_t prev = g ? fcode[g - 1] : 0u;
+					enc |= ((fcode[g] - prev) & 3u) << (2 * j);
+				}
+			}
+			out[b] = static_cast<uint8_t>(enc);
+		}
+		if (tid == 0) a.payload_len[zi] = nbytes;
+	}
+}
+
+// ------------------------------------------------------------------------------
+// markov (src/markov.hpp): context = previous N difference codes, oldest in the
+// least-significant base-4 digit; codes before the slice start count as 0.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t markov_ctx(const uint8_t* d, uint32_t g, int order) {
+	uint32_t ctx = 0;
+	for (int j = 1; j <= order; j++) {
+		const uint32_t v = (g >= static_cast<uint32_t>(j)) ? d[g - j] : 0u;
+		ctx |= v << (2 * (order - j));
+	}
+	return ctx;
+}
+
+// gather_statistics (markov.hpp:193-220): stats[ctx][code]++ for every code of every
+// slice (the first code of a slice is counted in row 0).  grid = nslices.
+__global__ void __launch_bounds__(kBlock) k_markov_hist(
+	const uint8_t* __restrict__ dcode, const uint64_t* __restrict__ cbase, const uint32_t* __restrict__ n_valid,
+	int order, uint32_t* __restrict__ hist
+) {
+	const uint32_t zi = blockIdx.x;
+	const uint8_t* d = dcode + cbase[zi];
+	const uint32_t n = n_valid[zi];
+	constexpr uint32_t kPer = 32;
+	// each thread owns 32 consecutive codes and merges equal (row, code) neighbours
+	// before touching memory: straight crack runs collapse to one atomic
+	for (uint32_t g0 = threadIdx.x * kPer; g0 < n; g0 += kBlock * kPer) {
+		uint32_t key = 0xFFFFFFFFu, cnt = 0;
+		const uint32_t g1 = g0 + kPer < n ? g0 + kPer : n;
+		for (uint32_t g = g0; g < g1; g++) {
+			const uint32_t k = markov_ctx(d, g, order) * 4u + d[g];
+			if (k == key) cnt++;
+			else {
+				if (cnt) atomicAdd(hist + key, cnt);
+				key = k; cnt = 1;
+			}
+		}
+		if (cnt) atomicAdd(hist + key, cnt);
+	}
+}
+
+// encode_markov (markov.hpp:422-473): first code raw in 2 bits, then rank codes
+// 0 -> `0`, 1 -> `10`, 2 -> `110`, 3 -> `111` (LSB first).  Bit offsets come from
+// a block prefix sum of the code lengths; set bits are OR-ed into 32-bit words.
+__global__ void __launch_bounds__(kBlock) k_markov_pack(
+	const uint8_t* __restrict__ dcode, const uint64_t* __restrict__ cbase, const uint32_t* __restrict__ n_valid,
+	int order, const uint8_t* __restrict__ model /* symbol -> rank */,
+	const uint64_t* __restrict__ pbase, uint8_t* __restrict__ payload, uint32_t* __restrict__ payload_len
+) {
+	__shared__ uint32_t s_scan[kWaves];
+	const uint32_t zi = blockIdx.x;
+	const uint8_t* d = dcode + cbase[zi];
+	const uint32_t n = n_valid[zi];
+	uint32_t* words = reinterpret_cast<uint32_t*>(payload + pbase[zi]);
+	constexpr uint32_t kPer = 8;
+	uint32_t carry = 0;
+	for (uint32_t tile = 0; tile < n; tile += kBlock * kPer) {
+		const uint32_t g0 = tile + threadIdx.x * kPer;
+		uint32_t bits[kPer], lens[kPer], tot_len = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < kPer; k++) {
+			const uint32_t g = g0 + k;
+			bits[k] = 0; lens[k] = 0;
+			if (g < n) {
+				if (g == 0) { bits[k] = d[0]; lens[k] = 2; }
+				else {
+					const uint32_t r = model[markov_ctx(d, g, order) * 4u + d[g]];
+					bits[k] = (r == 0) ? 0u : (r == 1) ? 1u : (r == 2) ? 3u : 7u;
+					lens[k] = (r == 0) ? 1u : (r == 1) ? 2u : 3u;
+				}
+			}
+			tot_len += lens[k];
+		}
+		uint32_t v[1] = { tot_len }, tot[1];
+		block_excl_add<1>(v, tot, s_scan);
+		uint32_t off = carry + v[0];
+#pragma unroll
+		for (uint32_t k = 0; k < kPer; k++) {
+			if (lens[k] && bits[k]) {
+				const uint32_t w = off >> 5, sh = off & 31;
+				atomicOr(words + w, bits[k] << sh);
+				if (sh + lens[k] > 32) atomicOr(words + w + 1, bits[k] >> (32 - sh));
+			}
+			off += lens[k];
+		}
+		carry += tot[0];
+	}
+	if (threadIdx.x == 0) payload_len[zi] = (carry + 7) / 8;
+}
+
+// ------------------------------------------------------------------------------
+// flat labels (labels.hpp:56-88): crc32c of the component image and component -> label
+// ------------------------------------------------------------------------------
+// grid = (crc tiles, nslices); same tiling as k_paint in ckl_decode.hip
+__global__ void __launch_bounds__(kBlock) k_cc_crc(
+	const uint32_t* __restrict__ L, const uint32_t* __restrict__ R, uint64_t sxy, uint32_t pad,
+	const uint32_t* __restrict__ crc_stride_tab, const uint32_t* __restrict__ crc_lane_pow, const uint32_t* __restrict__ crc_tile_pow,
+	uint32_t* __restrict__ crc_acc
+) {
+	__shared__ uint32_t s_tab[1024];
+	__shared__ uint32_t s_red[kWaves];
+	const uint32_t zi = blockIdx.y, t = blockIdx.x;
+	for (int i = threadIdx.x; i < 1024; i += kBlock) s_tab[i] = crc_stride_tab[i];
+	__syncthreads();
+	const uint32_t* Lz = L + zi * sxy;
+	const uint32_t* Rz = R + zi * sxy;
+	uint32_t acc = 0;
+#pragma unroll
+	for (int i = 0; i < kCrcRows; i++) {
+		const uint64_t kp = static_cast<uint64_t>(t) * kCrcTile + i * kBlock + threadIdx.x;
+		const uint32_t word = kp >= pad ? Rz[Lz[kp - pad]] : 0u;
+		acc = crc_stride_step(s_tab, acc) ^ word;
+	}
+	uint32_t val = gf_mul(acc, crc_lane_pow[threadIdx.x]);
+	val = block_xor(val, s_red);
+	if (threadIdx.x == 0) atomicXor(crc_acc + zi, gf_mul(val, crc_tile_pow[t]));
+}
+
+// grid = (ccl tiles, nslices): mapping[comp_off[zi] + rank(root)] = label of the root pixel
+template <typename LABEL>
+__global__ void __launch_bounds__(kBlock) k_mapping(
+	const LABEL* __restrict__ labels, const uint32_t* __restrict__ L, const uint32_t* __restrict__ R, uint64_t sxy,
+	const uint64_t* __restrict__ comp_off, uint64_t* __restrict__ mapping
+) {
+	const uint32_t zi = blockIdx.y;
+#pragma unroll
+	for (int i = 0; i < kCclTile / kBlock; i++) {
+		const uint64_t p = static_cast<uint64_t>(blockIdx.x) * kCclTile + i * kBlock + threadIdx.x;
+		if (p >= sxy) continue;
+		if (L[zi * sxy + p] == static_cast<uint32_t>(p)) {
+			mapping[comp_off[zi] + R[zi * sxy + p]] = static_cast<uint64_t>(labels[zi * sxy + p]);
+		}
+	}
+}
+
+// grid = nslices: copy each slice's BOC index and payload to their final offsets
+__global__ void __launch_bounds__(kBlock) k_gather_codes(
+	const uint8_t* __restrict__ boc, const uint64_t* __restrict__ bbase, const uint32_t* __restrict__ boc_len,
+	const uint8_t* __restrict__ payload, const uint64_t* __restrict__ pbase, const uint32_t* __restrict__ payload_len,
+	const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out
+) {
+	const uint32_t zi = blockIdx.x;
+	uint8_t* o = out + out_off[zi];
+	const uint32_t nb = boc_len[zi], np = payload_len[zi];
+	const uint8_t* b = boc + bbase[zi];
+	const uint8_t* p = payload + pbase[zi];
+	for (uint32_t i = threadIdx.x; i < nb; i += kBlock) o[i] = b[i];
+	for (uint32_t i = threadIdx.x; i < np; i += kBlock) o[nb + i] = p[i];
+}
+
+}  // namespace ckl
+
+// ------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------
+using namespace ckl;
+
+struct ckl_encoder {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+	float pipeline_ms = 0.f, dominant_ms = 0.f;
+	int64_t max_sx = 0, max_sy = 0, max_sz = 0;
+	int dtype_bytes = 0;
+
+	DevBuf<unsigned long long> d_stats;
+	DevBuf<uint8_t> d_adj;
+	DevBuf<uint32_t> d_deg_sum, d_slice_err;
+	DevBuf<uint64_t> d_cbase, d_sbase, d_kbase, d_pbase, d_bbase, d_out_off, d_comp_off;
+	DevBuf<uint32_t> d_ccap, d_scap, d_kcap;
+	DevBuf<uint8_t> d_cp, d_fcode, d_dcode, d_payload, d_boc, d_codes_out, d_model;
+	DevBuf<uint32_t> d_stack_node, d_stack_code;
+	DevBuf<uint32_t> d_chain_node, d_chain_off, d_chain_clen, d_chain_order, d_chain_dst, d_chain_vstart;
+	DevBuf<uint32_t> d_n_chains, d_n_raw, d_n_valid, d_payload_len, d_boc_len;
+	DevBuf<uint32_t> d_hist;
+	DevBuf<uint32_t> d_L, d_R, d_tile_count, d_ncomp;
+	DevBuf<uint32_t> d_crc_tab, d_crc_lane_pow, d_crc_tile_pow, d_crc_acc;
+	DevBuf<uint64_t> d_mapping;
+
+	~ckl_encoder() {
+		if (ev0) (void)hipEventDestroy(ev0);
+		if (ev1) (void)hipEventDestroy(ev1);
+		if (evk0) (void)hipEventDestroy(evk0);
+		if (evk1) (void)hipEventDestroy(evk1);
+		if (stream) (void)hipStreamDestroy(stream);
+	}
+};
+
+namespace {
+
+template <typename T>
+void upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t s) {
+	d.ensure(h.size());
+	if (!h.empty()) CKL_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+template <typename T>
+std::vector<T> download(const T* p, size_t n, hipStream_t s) {
+	std::vector<T> h(n);
+	if (n) CKL_HIP(hipMemcpyAsync(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipStreamSynchronize(s));
+	return h;
+}
+
+struct VolumeStats { uint64_t max_label = 0, pairs = 0, first = 0, last = 0; };
+
+template <typename LABEL>
+VolumeStats volume_stats(ckl_encoder& e, const LABEL* labels, uint64_t voxels) {
+	VolumeStats st;
+	if (voxels == 0) return st;
+	hipStream_t s = e.stream;
+	e.d_stats.ensure(2);
+	CKL_HIP(hipMemsetAsync(e.d_stats.p, 0, 2 * sizeof(unsigned long long), s));
+	const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((voxels + kBlock - 1) / kBlock, 256ull * 8));
+	hipLaunchKernelGGL(k_stats<LABEL>, dim3(blocks), dim3(kBlock), 0, s, labels, voxels, e.d_stats.p);
+	auto r = download(e.d_stats.p, 2, s);
+	st.max_label = r[0]; st.pairs = r[1];
+	LABEL f, l;
+	CKL_HIP(hipMemcpy(&f, labels, sizeof(LABEL), hipMemcpyDeviceToHost));
+	CKL_HIP(hipMemcpy(&l, labels + (voxels - 1), sizeof(LABEL), hipMemcpyDeviceToHost));
+	st.first = f; st.last = l;
+	return st;
+}
+
+struct CrackResult {
+	std::vector<uint32_t> code_len;     // per slice: boc + payload bytes
+	std::vector<uint8_t> codes;         // concatenated crack codes
+	bool any_chain = false;
+};
+
+// Runs graph + walk + finish.  When `hist_only` is set, stops after the markov
+// histogram (returned in hist).  `model` (symbol -> rank) is required for markov packing.
+template <typename LABEL>
+void crack_pass(
+	ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, bool permissible,
+	int markov_order, bool hist_only, const std::vector<uint8_t>* model_in,
+	std::vector<uint32_t>* hist_out, std::vector<uint8_t>* model_out, CrackResult* result
+) {
+	hipStream_t s = e.stream;
+	const uint32_t ns = static_cast<uint32_t>(sz);
+	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
+	const uint64_t adj_stride = ((nverts + 8 + 511) / 512) * 512;
+	e.d_adj.ensure(adj_stride * ns);
+	e.d_deg_sum.ensure(ns);
+	e.d_slice_err.ensure(ns);
+	CKL_HIP(hipMemsetAsync(e.d_adj.p, 0, adj_stride * ns, s));
+	CKL_HIP(hipMemsetAsync(e.d_deg_sum.p, 0, ns * sizeof(uint32_t), s));
+	CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
+	hipLaunchKernelGGL(k_crack_graph<LABEL>, dim3(static_cast<uint32_t>((nverts + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s,
+		labels, static_cast<int>(sx), static_cast<int>(sy), permissible ? 1u : 0u, e.d_adj.p, adj_stride, e.d_deg_sum.p);
+	std::vector<uint32_t> deg = download(e.d_deg_sum.p, ns, s);
+
+	// capacities from the exact edge counts (codes <= 7 E, chains <= E, stack <= E)
+	std::vector<uint64_t> cbase(ns), sbase(ns), kbase(ns);
+	std::vector<uint32_t> ccap(ns), scap(ns), kcap(ns);
+	uint64_t ctot = 0, stot = 0, ktot = 0;
+	bool any = false;
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		const uint64_t E = deg[zi] / 2;
+		any = any || E > 0;
+		const uint64_t cc = 7 * E + 16;
+		if (cc > 0xFFFFFFF0ull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: slice has too many crack edges");
+		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cc); ctot += cc;
+		sbase[zi] = stot; scap[zi] = static_cast<uint32_t>(E + 1); stot += E + 1;
+		kbase[zi] = ktot; kcap[zi] = static_cast<uint32_t>(E + 1); ktot += E + 1;
+	}
+	if (result) result->any_chain = any;
+	upload(e.d_cbase, cbase, s); upload(e.d_ccap, ccap, s);
+	upload(e.d_sbase, sbase, s); upload(e.d_scap, scap, s);
+	upload(e.d_kbase, kbase, s); upload(e.d_kcap, kcap, s);
+	e.d_cp.ensure(ctot); e.d_fcode.ensure(ctot);
+	if (markov_order) e.d_dcode.ensure(ctot);
+	e.d_stack_node.ensure(stot); e.d_stack_code.ensure(stot);
+	e.d_chain_node.ensure(ktot); e.d_chain_off.ensure(ktot); e.d_chain_clen.ensure(ktot);
+	e.d_chain_order.ensure(ktot); e.d_chain_dst.ensure(ktot); e.d_chain_vstart.ensure(ktot);
+	e.d_n_chains.ensure(ns); e.d_n_raw.ensure(ns); e.d_n_valid.ensure(ns);
+	e.d_payload_len.ensure(ns); e.d_boc_len.ensure(ns);
+
+	WalkArgs wa;
+	wa.adj = e.d_adj.p; wa.adj_stride = adj_stride; wa.sx = static_cast<int>(sx); wa.sy = static_cast<int>(sy);
+	wa.cbase = e.d_cbase.p; wa.ccap = e.d_ccap.p; wa.sbase = e.d_sbase.p; wa.scap = e.d_scap.p; wa.kbase = e.d_kbase.p; wa.kcap = e.d_kcap.p;
+	wa.cp = e.d_cp.p; wa.stack_node = e.d_stack_node.p; wa.stack_code = e.d_stack_code.p;
+	wa.chain_node = e.d_chain_node.p; wa.chain_off = e.d_chain_off.p; wa.chain_clen = e.d_chain_clen.p;
+	wa.n_chains = e.d_n_chains.p; wa.n_raw = e.d_n_raw.p; wa.n_valid = e.d_n_valid.p; wa.slice_err = e.d_slice_err.p;
+	CKL_HIP(hipEventRecord(e.evk0, s));
+	hipLaunchKernelGGL(k_walk, dim3(ns), dim3(kWave), 0, s, wa);
+	CKL_HIP(hipEventRecord(e.evk1, s));
+
+	std::vector<uint32_t> n_chains = download(e.d_n_chains.p, ns, s);
+	std::vector<uint32_t> n_valid = download(e.d_n_valid.p, ns, s);
+	std::vector<uint32_t> errs = download(e.d_slice_err.p, ns, s);
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack walk scratch overflow on z=" + std::to_string(zi));
+	}
+
+	// output buffers sized from the walk results
+	const int xw = byte_width(static_cast<uint64_t>(sx) + 1), yw = byte_width(static_cast<uint64_t>(sy) + 1);
+	std::vector<uint64_t> pbase(ns), bbase(ns);
+	uint64_t ptot = 0, btot = 0;
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		// plain: 2 bits / code; markov: at most 3 bits / code (+2)
+		const uint64_t pbytes = markov_order ? (3ull * n_valid[zi] + 2 + 7) / 8 : (static_cast<uint64_t>(n_valid[zi]) + 3) / 4;
+		pbase[zi] = ptot; ptot += ((pbytes + 8 + 3) / 4) * 4;
+		const uint64_t bbytes = 4 + yw + static_cast<uint64_t>(n_chains[zi]) * (yw + 2 * xw);
+		bbase[zi] = btot; btot += bbytes;
+	}
+	upload(e.d_pbase, pbase, s); upload(e.d_bbase, bbase, s);
+	e.d_payload.ensure(ptot + 8); e.d_boc.ensure(btot + 8);
+	if (markov_order) CKL_HIP(hipMemsetAsync(e.d_payload.p, 0, ptot + 8, s));
+
+	FinishArgs fa;
+	fa.sx = static_cast<int>(sx); fa.sy = static_cast<int>(sy); fa.xw = xw; fa.yw = yw;
+	fa.markov = markov_order ? 1u : 0u;
+	fa.cbase = e.d_cbase.p; fa.kbase = e.d_kbase.p;
+	fa.n_chains = e.d_n_chains.p; fa.n_raw = e.d_n_raw.p; fa.n_valid = e.d_n_valid.p;
+	fa.cp = e.d_cp.p; fa.chain_node = e.d_chain_node.p; fa.chain_off = e.d_chain_off.p; fa.chain_clen = e.d_chain_clen.p;
+	fa.chain_order = e.d_chain_order.p; fa.chain_dst = e.d_chain_dst.p; fa.chain_vstart = e.d_chain_vstart.p;
+	fa.fcode = e.d_fcode.p; fa.dcode = e.d_dcode.p;
+	fa.pbase = e.d_pbase.p; fa.payload = e.d_payload.p; fa.bbase = e.d_bbase.p; fa.boc = e.d_boc.p;
+	fa.payload_len = e.d_payload_len.p; fa.boc_len = e.d_boc_len.p;
+	hipLaunchKernelGGL(k_finish, dim3(ns), dim3(kBlock), 0, s, fa);
+
+	if (markov_order) {
+		std::vector<uint8_t> model;
+		if (model_in) {
+			model = *model_in;
+		}
+		else {
+			const size_t rows = static_cast<size_t>(1) << (2 * markov_order);
+			e.d_hist.ensure(rows * 4);
+			CKL_HIP(hipMemsetAsync(e.d_hist.p, 0, rows * 4 * sizeof(uint32_t), s));
+			hipLaunchKernelGGL(k_markov_hist, dim3(ns), dim3(kBlock), 0, s, e.d_dcode.p, e.d_cbase.p, e.d_n_valid.p, markov_order, e.d_hist.p);
+			std::vector<uint32_t> hist = download(e.d_hist.p, rows * 4, s);
+			if (hist_out) *hist_out = hist;
+			if (hist_only) return;
+			model = markov_stats_to_model(hist.data(), rows);
+		}
+		if (model_out) *model_out = model;
+		upload(e.d_model, model, s);
+		hipLaunchKernelGGL(k_markov_pack, dim3(ns), dim3(kBlock), 0, s, e.d_dcode.p, e.d_cbase.p, e.d_n_valid.p, markov_order,
+			e.d_model.p, e.d_pbase.p, e.d_payload.p, e.d_payload_len.p);
+	}
+	if (!result) { CKL_HIP(hipStreamSynchronize(s)); return; }
+
+	std::vector<uint32_t> plen = download(e.d_payload_len.p, ns, s);
+	std::vector<uint32_t> blen = download(e.d_boc_len.p, ns, s);
+	std::vector<uint64_t> out_off(ns);
+	uint64_t otot = 0;
+	result->code_len.resize(ns);
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		out_off[zi] = otot;
+		result->code_len[zi] = plen[zi] + blen[zi];
+		otot += result->code_len[zi];
+	}
+	upload(e.d_out_off, out_off, s);
+	e.d_codes_out.ensure(otot + 8);
+	hipLaunchKernelGGL(k_gather_codes, dim3(ns), dim3(kBlock), 0, s, e.d_boc.p, e.d_bbase.p, e.d_boc_len.p,
+		e.d_payload.p, e.d_pbase.p, e.d_payload_len.p, e.d_out_off.p, e.d_codes_out.p);
+	result->codes = download(e.d_codes_out.p, otot, s);
+}
+
+struct FlatResult {
+	std::vector<uint32_t> ncomp;      // per slice
+	std::vector<uint32_t> crcs;       // per slice crc32c of the component image
+	std::vector<uint64_t> mapping;    // component -> label, slices concatenated
+};
+
+template <typename LABEL>
+void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, FlatResult& out) {
+	hipStream_t s = e.stream;
+	const uint32_t ns = static_cast<uint32_t>(sz);
+	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
+	const uint32_t tiles = static_cast<uint32_t>((sxy + kCclTile - 1) / kCclTile);
+	e.d_L.ensure(sxy * ns); e.d_R.ensure(sxy * ns);
+	e.d_tile_count.ensure(static_cast<size_t>(tiles) * ns);
+	e.d_ncomp.ensure(ns);
+	e.d_crc_acc.ensure(ns);
+	CKL_HIP(hipMemsetAsync(e.d_crc_acc.p, 0, ns * sizeof(uint32_t), s));
+
+	LabelConn<LABEL> conn;
+	conn.labels = labels; conn.sxy = sxy; conn.sx = static_cast<int>(sx);
+	hipLaunchKernelGGL(k_ccl_rows<LabelConn<LABEL>>, dim3(static_cast<uint32_t>(sy), ns), dim3(kBlock), 0, s, conn, e.d_L.p, static_cast<int>(sx), static_cast<int>(sy));
+	hipLaunchKernelGGL(k_ccl_merge<LabelConn<LABEL>>, dim3(tiles, ns), dim3(kBlock), 0, s, conn, e.d_L.p, static_cast<int>(sx), static_cast<int>(sy));
+	hipLaunchKernelGGL(k_ccl_flatten, dim3(tiles, ns), dim3(kBlock), 0, s, e.d_L.p, e.d_tile_count.p, sxy, tiles);
+	hipLaunchKernelGGL(k_ccl_scan, dim3(ns), dim3(kBlock), 0, s, e.d_tile_count.p, e.d_ncomp.p, tiles);
+	hipLaunchKernelGGL(k_ccl_rank, dim3(tiles, ns), dim3(kBlock), 0, s, e.d_L.p, e.d_R.p, e.d_tile_count.p, sxy, tiles);
+
+	// crc32c of each slice's component image
+	const uint32_t crc_tiles = static_cast<uint32_t>((sxy + kCrcTile - 1) / kCrcTile);
+	const uint32_t pad = static_cast<uint32_t>(static_cast<uint64_t>(crc_tiles) * kCrcTile - sxy);
+	{
+		std::vector<uint32_t> tab(1024), lane_pow(kBlock), tile_pow(crc_tiles);
+		const uint32_t M = gf_xpow(32ull * kBlock);
+		for (int k = 0; k < 4; k++)
+			for (uint32_t b = 0; b < 256; b++) tab[k * 256 + b] = gf_mul(b << (8 * k), M);
+		for (int j = 0; j < kBlock; j++) lane_pow[j] = gf_xpow(32ull * (kBlock - j));
+		const uint32_t T = gf_xpow(32ull * kCrcTile);
+		uint32_t acc = 0x80000000u;
+		for (uint32_t t = crc_tiles; t-- > 0;) { tile_pow[t] = acc; acc = gf_mul(acc, T); }
+		upload(e.d_crc_tab, tab, s); upload(e.d_crc_lane_pow, lane_pow, s); upload(e.d_crc_tile_pow, tile_pow, s);
+		CKL_HIP(hipStreamSynchronize(s));
+	}
+	hipLaunchKernelGGL(k_cc_crc, dim3(crc_tiles, ns), dim3(kBlock), 0, s, e.d_L.p, e.d_R.p, sxy, pad,
+		e.d_crc_tab.p, e.d_crc_lane_pow.p, e.d_crc_tile_pow.p, e.d_crc_acc.p);
+
+	out.ncomp = download(e.d_ncomp.p, ns, s);
+	std::vector<uint32_t> acc = download(e.d_crc_acc.p, ns, s);
+	const uint32_t init_term = gf_mul(0xFFFFFFFFu, gf_xpow(32ull * sxy));
+	out.crcs.resize(ns);
+	for (uint32_t zi = 0; zi < ns; zi++) out.crcs[zi] = ~(acc[zi] ^ init_term);
+
+	std::vector<uint64_t> comp_off(ns);
+	uint64_t total = 0;
+	for (uint32_t zi = 0; zi < ns; zi++) { comp_off[zi] = total; total += out.ncomp[zi]; }
+	upload(e.d_comp_off, comp_off, s);
+	e.d_mapping.ensure(total + 1);
+	hipLaunchKernelGGL(k_mapping<LABEL>, dim3(tiles, ns), dim3(kBlock), 0, s, labels, e.d_L.p, e.d_R.p, sxy, e.d_comp_off.p, e.d_mapping.p);
+	out.mapping = download(e.d_mapping.p, total, s);
+}
+
+template <typename LABEL>
+void encode_typed(
+	ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz,
+	bool allow_pins, bool fortran_order, uint64_t markov_model_order,
+	bool optimize_pins, bool auto_bgcolor, int64_t manual_bgcolor,
+	const ckl_encode_overrides* ov, std::vector<uint8_t>& final_binary
+) {
+	(void)auto_bgcolor; (void)manual_bgcolor;
+	const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
+	hipStream_t s = e.stream;
+	CKL_HIP(hipEventRecord(e.ev0, s));
+
+	VolumeStats st = volume_stats<LABEL>(e, labels, voxels);
+	int stored_width = byte_width(st.max_label);                     // crackle.hpp:233-235
+	if (ov && ov->force_stored_width) stored_width = ov->force_stored_width;
+
+	Header head;
+	head.crack_format = IMPERMISSIBLE;
+	head.label_format = PINS_VARIABLE_WIDTH;
+	if (static_cast<int64_t>(st.pairs) < static_cast<int64_t>(voxels) / 2) {   // crackle.hpp:50-55
+		head.crack_format = PERMISSIBLE;
+		head.label_format = FLAT;
+	}
+	if (ov && ov->force_crack_format >= 0) {
+		head.crack_format = ov->force_crack_format;
+		head.label_format = ov->force_crack_format == PERMISSIBLE ? FLAT : PINS_VARIABLE_WIDTH;
+	}
+	if (sz == 1 || !allow_pins) head.label_format = FLAT;           // crackle.hpp:62-64
+	if (ov && ov->force_label_format >= 0) head.label_format = ov->force_label_format;
+	head.is_signed = false;
+	head.data_width = static_cast<int>(sizeof(LABEL));
+	head.stored_data_width = stored_width;
+	head.sx = static_cast<uint32_t>(sx); head.sy = static_cast<uint32_t>(sy); head.sz = static_cast<uint32_t>(sz);
+	head.log2_grid_size = 31;
+	head.fortran_order = fortran_order;
+	head.markov_model_order = static_cast<int>(markov_model_order & 0xFF);
+	head.is_sorted = true;
+
+	if (voxels == 0) {   // crackle.hpp:96-98
+		head.write(final_binary);
+		return;
+	}
+	if (optimize_pins) throw Error(CKL_ERR_ARG, "crackle_amd: allow_pins=2 (find_optimal_pins) is out of scope");
+	if (head.label_format == PINS_VARIABLE_WIDTH) {
+		throw Error(CKL_ERR_RUNTIME, "crackle_amd: pin label encoding (allow_pins=True on a pin-eligible volume) is not implemented yet");
+	}
+	if (head.markov_model_order > 13) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order > 13 is not supported on device");
+
+	// crack codes; a first pass decides whether any slice has chains (crackle.hpp:107-118)
+	CrackResult cr;
+	std::vector<uint8_t> model, stored_model;
+	const bool permissible = head.crack_format == PERMISSIBLE;
+	std::vector<uint8_t> forced_model;
+	const std::vector<uint8_t>* model_in = nullptr;
+	if (ov && ov->has_model && head.markov_model_order > 0) {
+		const size_t rows = static_cast<size_t>(1) << (2 * head.markov_model_order);
+		forced_model.assign(ov->model, ov->model + rows * 4);
+		model_in = &forced_model;
+	}
+	crack_pass<LABEL>(e, labels, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr);
+	if (head.markov_model_order > 0 && !cr.any_chain && !(ov && ov->has_model)) {
+		// every slice empty: the reference resets the order to 0 and packs plainly
+		head.markov_model_order = 0;
+		crack_pass<LABEL>(e, labels, sx, sy, sz, permissible, 0, false, nullptr, nullptr, nullptr, &cr);
+	}
+	if (head.markov_model_order > 0) stored_model = markov_model_to_stored(model);
+
+	// labels (labels.hpp:30-155)
+	FlatResult fr;
+	flat_pass<LABEL>(e, labels, sx, sy, sz, fr);
+	const uint64_t N = fr.mapping.size();
+	std::vector<uint64_t> uniq(fr.mapping);
+	std::sort(uniq.begin(), uniq.end());
+	uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+	const int key_width = byte_width(uniq.size());
+	const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
+	std::vector<uint8_t> labels_binary;
+	labels_binary.reserve(8 + uniq.size() * stored_width + static_cast<size_t>(sz) * component_width + N * key_width);
+	put_le(labels_binary, uniq.size(), 8);
+	for (uint64_t v : uniq) put_le(labels_binary, v, stored_width);
+	for (int64_t z = 0; z < sz; z++) put_le(labels_binary, fr.ncomp[z], component_width);
+	for (uint64_t i = 0; i < N; i++) {
+		const uint64_t key = static_cast<uint64_t>(std::lower_bound(uniq.begin(), uniq.end(), fr.mapping[i]) - uniq.begin());
+		put_le(labels_binary, key, key_width);
+	}
+
+	// assembly (crackle.hpp:171-216)
+	head.num_label_bytes = labels_binary.size();
+	final_binary.reserve(Header::kBytes + 4 * (sz + 1) + labels_binary.size() + stored_model.size() + cr.codes.size() + 4 * (sz + 1));
+	head.write(final_binary);
+	const size_t zi0 = final_binary.size();
+	for (int64_t z = 0; z < sz; z++) put_le(final_binary, cr.code_len[z], 4);
+	put_le(final_binary, crc32c(final_binary.data() + zi0, 4ull * sz), 4);
+	final_binary.insert(final_binary.end(), labels_binary.begin(), labels_binary.end());
+	if (head.markov_model_order > 0) final_binary.insert(final_binary.end(), stored_model.begin(), stored_model.end());
+	final_binary.insert(final_binary.end(), cr.codes.begin(), cr.codes.end());
+	put_le(final_binary, crc32c(labels_binary.data(), labels_binary.size()), 4);
+	for (int64_t z = 0; z < sz; z++) put_le(final_binary, fr.crcs[z], 4);
+
+	CKL_HIP(hipEventRecord(e.ev1, s));
+	CKL_HIP(hipStreamSynchronize(s));
+	CKL_HIP(hipGetLastError());
+	CKL_HIP(hipEventElapsedTime(&e.pipeline_ms, e.ev0, e.ev1));
+	CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evk0, e.evk1));
+}
+
+void check_dims(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int is_signed) {
+	if (is_signed) throw Error(CKL_ERR_ARG, "Signed integer data types are not currently supported.");
+	if (dtype_bytes != 1 && dtype_bytes != 2 && dtype_bytes != 4 && dtype_bytes != 8) throw Error(CKL_ERR_ARG, "crackle_amd: dtype width must be 1, 2, 4 or 8 bytes");
+	if (sx < 0 || sy < 0 || sz < 0) throw Error(CKL_ERR_ARG, "crackle_amd: negative dimension");
+	if (sx > 0x7FFFFFF0ll || sy > 0x7FFFFFF0ll || sz > 0x7FFFFFF0ll) throw Error(CKL_ERR_ARG, "crackle_amd: dimension too large");
+	if (static_cast<uint64_t>(sx + 1) * static_cast<uint64_t>(sy + 1) >= (1ull << 31)) throw Error(CKL_ERR_ARG, "crackle_amd: slices of 2^31 or more crack vertices are not supported");
+}
+
+}  // namespace
+
+extern "C" {
+
+int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int device, ckl_encoder** out) {
+	try {
+		if (!out) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		check_dims(sx, sy, sz, dtype_bytes, 0);
+		select_device(device);
+		std::unique_ptr<ckl_encoder> e(new ckl_encoder());
+		e->device = device;
+		e->max_sx = sx; e->max_sy = sy; e->max_sz = sz; e->dtype_bytes = dtype_bytes;
+		CKL_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+		CKL_HIP(hipEventCreate(&e->ev0));
+		CKL_HIP(hipEventCreate(&e->ev1));
+		CKL_HIP(hipEventCreate(&e->evk0));
+		CKL_HIP(hipEventCreate(&e->evk1));
+		*out = e.release();
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_encoder_run(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	int allow_pins, int fortran_order, uint64_t markov_model_order,
+	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
+	const ckl_encode_overrides* overrides, uint8_t** out, uint64_t* out_len
+) {
+	try {
+		if (!e || !out || !out_len) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		check_dims(sx, sy, sz, e->dtype_bytes, 0);
+		if (markov_model_order > 15) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order must be in [0, 15]");
+		select_device(e->device);
+		std::vector<uint8_t> bin;
+#define CKL_ENC(T) encode_typed<T>(*e, reinterpret_cast<const T*>(labels_device), sx, sy, sz, allow_pins != 0, fortran_order != 0, \
+	markov_model_order, optimize_pins != 0, auto_bgcolor != 0, manual_bgcolor, overrides, bin)
+		if (e->dtype_bytes == 1) CKL_ENC(uint8_t);
+		else if (e->dtype_bytes == 2) CKL_ENC(uint16_t);
+		else if (e->dtype_bytes == 4) CKL_ENC(uint32_t);
+		else CKL_ENC(uint64_t);
+#undef CKL_ENC
+		uint8_t* p = static_cast<uint8_t*>(malloc(bin.size() ? bin.size() : 1));
+		if (!p) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
+		memcpy(p, bin.data(), bin.size());
+		*out = p;
+		*out_len = bin.size();
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_encoder_stats(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	uint64_t* max_label, uint64_t* pixel_pairs, uint64_t* first_voxel, uint64_t* last_voxel
+) {
+	try {
+		if (!e) throw Error(CKL_ERR_ARG, "crackle_amd: null encoder");
+		check_dims(sx, sy, sz, e->dtype_bytes, 0);
+		select_device(e->device);
+		const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
+		VolumeStats st;
+		if (e->dtype_bytes == 1) st = volume_stats<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), voxels);
+		else if (e->dtype_bytes == 2) st = volume_stats<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), voxels);
+		else if (e->dtype_bytes == 4) st = volume_stats<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), voxels);
+		else st = volume_stats<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), voxels);
+		if (max_label) *max_label = st.max_label;
+		if (pixel_pairs) *pixel_pairs = st.pairs;
+		if (first_voxel) *first_voxel = st.first;
+		if (last_voxel) *last_voxel = st.last;
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_encoder_markov_stats(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	int crack_format, uint64_t markov_model_order, uint32_t* hist
+) {
+	try {
+		if (!e || !hist) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		check_dims(sx, sy, sz, e->dtype_bytes, 0);
+		if (markov_model_order == 0 || markov_model_order > 13) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order must be in [1, 13]");
+		select_device(e->device);
+		const size_t rows = static_cast<size_t>(1) << (2 * markov_model_order);
+		std::vector<uint32_t> h(rows * 4, 0);
+		if (static_cast<uint64_t>(sx) * sy * sz > 0) {
+			const bool perm = crack_format == PERMISSIBLE;
+			const int order = static_cast<int>(markov_model_order);
+			if (e->dtype_bytes == 1) crack_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
+			else if (e->dtype_bytes == 2) crack_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
+			else if (e->dtype_bytes == 4) crack_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
+			else crack_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
+		}
+		memcpy(hist, h.data(), h.size() * sizeof(uint32_t));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_encoder_last_timing(const ckl_encoder* e, float* pipeline_ms, float* dominant_kernel_ms) {
+	if (!e) { set_last_error("crackle_amd: null encoder"); return CKL_ERR_ARG; }
+	if (pipeline_ms) *pipeline_ms = e->pipeline_ms;
+	if (dominant_kernel_ms) *dominant_kernel_ms = e->dominant_ms;
+	return CKL_OK;
+}
+
+void ckl_encoder_destroy(ckl_encoder* e) { delete e; }
+
+int ckl_compress(
+	const void* labels, int labels_mem, int dtype_bytes, int is_signed,
+	int64_t sx, int64_t sy, int64_t sz,
+	int allow_pins, int fortran_order, uint64_t markov_model_order,
+	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
+	int device, uint8_t** out, uint64_t* out_len
+) {
+	ckl_encoder* e = nullptr;
+	try {
+		check_dims(sx, sy, sz, dtype_bytes, is_signed);
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	int rc = ckl_encoder_create(sx, sy, sz, dtype_bytes, device, &e);
+	if (rc != CKL_OK) return rc;
+	try {
+		const uint64_t bytes = static_cast<uint64_t>(sx) * sy * sz * dtype_bytes;
+		const void* dev_labels = labels;
+		DevBuf<uint8_t> tmp;
+		if (labels_mem == CKL_MEM_HOST && bytes) {
+			if (!labels) throw Error(CKL_ERR_ARG, "crackle_amd: null labels");
+			tmp.ensure(bytes);
+			CKL_HIP(hipMemcpy(tmp.p, labels, bytes, hipMemcpyHostToDevice));
+			dev_labels = tmp.p;
+		}
+		rc = ckl_encoder_run(e, dev_labels, sx, sy, sz, allow_pins, fortran_order, markov_model_order,
+			optimize_pins, auto_bgcolor, manual_bgcolor, nullptr, out, out_len);
+		ckl_encoder_destroy(e);
+		return rc;
+	}
+	catch (const Error& err) { set_last_error(err.what()); ckl_encoder_destroy(e); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); ckl_encoder_destroy(e); return CKL_ERR_RUNTIME; }
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// Host-only stream surgery: concatenate FLAT-label streams of consecutive z-slabs
+// into the stream of the whole volume.  Native form of crackle.operations.zstack
+// (crackle/operations.py:424-548) for the case the sharded encoder needs: all slabs
+// were encoded with the same crack format, stored width and markov model (the
+// sharded encoder imposes them), so crack codes, per-slice CRCs
+// and component counts are concatenated verbatim and only the key table is re-keyed
+// against the merged, sorted unique-label list (labels.hpp:92-152).
+#include "ckl_common.hpp"
+
+#include <algorithm>
+
+using namespace ckl;
+
+namespace {
+
+struct Slab {
+	Header h;
+	const uint8_t* buf;
+	uint64_t n;
+	const uint8_t* labels;      // label section
+	uint64_t num_unique;
+	std::vector<uint64_t> uniq;
+	const uint8_t* comp;        // cc_per_slice table
+	const uint8_t* keys;
+	uint64_t total_comp;
+	const uint8_t* model;
+	const uint8_t* cracks;
+	uint64_t crack_bytes;
+	const uint8_t* z_index;
+	const uint8_t* crcs;        // per-slice crcs
+};
+
+Slab parse_slab(const uint8_t* buf, uint64_t n) {
+	Slab s;
+	s.h = Header::parse(buf, n);
+	s.buf = buf; s.n = n;
+	const Header& h = s.h;
+	if (h.format_version != 1) throw Error(CKL_ERR_ARG, "crackle_amd: zstack needs version 1 streams");
+	if (h.label_format != FLAT) throw Error(CKL_ERR_ARG, "crackle_amd: zstack is implemented for FLAT label streams only");
+	if (h.voxels() == 0) throw Error(CKL_ERR_ARG, "crackle_amd: zstack of an empty slab");
+	const uint64_t hb = h.header_bytes(), gib = h.grid_index_bytes();
+	const uint64_t tail = 4ull * (static_cast<uint64_t>(h.sz) + 1);
+	if (hb + gib + h.num_label_bytes + h.markov_model_bytes() + tail > n) throw Error(CKL_ERR_RUNTIME, "crackle: Unable to read past end of buffer.");
+	s.z_index = buf + hb;
+	s.labels = buf + hb + gib;
+	const int sw = h.stored_data_width;
+	const int cw = byte_width(static_cast<uint64_t>(h.sx) * h.sy);
+	if (h.num_label_bytes < 8) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+	s.num_unique = rd_le(s.labels, 8);
+	if (8 + s.num_unique * sw + static_cast<uint64_t>(cw) * h.sz > h.num_label_bytes) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+	s.uniq.resize(s.num_unique);
+	for (uint64_t i = 0; i < s.num_unique; i++) s.uniq[i] = rd_le(s.labels + 8 + i * sw, sw);
+	s.comp = s.labels + 8 + s.num_unique * sw;
+	s.total_comp = 0;
+	for (uint64_t z = 0; z < h.sz; z++) s.total_comp += rd_le(s.comp + z * cw, cw);
+	s.keys = s.comp + static_cast<uint64_t>(cw) * h.sz;
+	const int kw = byte_width(s.num_unique);
+	if (static_cast<uint64_t>(s.keys - s.labels) + s.total_comp * kw > h.num_label_bytes) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+	s.model = s.labels + h.num_label_bytes;
+	s.cracks = s.model + h.markov_model_bytes();
+	uint64_t cb = 0;
+	for (uint64_t z = 0; z < h.sz; z++) cb += rd_le(s.z_index + 4 * z, 4);
+	s.crack_bytes = cb;
+	if (static_cast<uint64_t>(s.cracks - buf) + cb + tail > n) throw Error(CKL_ERR_RUNTIME, "crackle: Unable to read past end of buffer.");
+	s.crcs = buf + n - 4ull * h.sz;
+	return s;
+}
+
+}  // namespace
+
+extern "C" int ckl_zstack(const uint8_t* const* bufs, const uint64_t* lens, uint64_t count, uint8_t** out, uint64_t* out_len) {
+	try {
+		if (!bufs || !lens || !out || !out_len || count == 0) throw Error(CKL_ERR_ARG, "crackle_amd: zstack needs at least one stream");
+		std::vector<Slab> slabs;
+		slabs.reserve(count);
+		for (uint64_t i = 0; i < count; i++) slabs.push_back(parse_slab(bufs[i], lens[i]));
+		const Header& h0 = slabs[0].h;
+		uint64_t sz = 0, total_comp = 0, crack_bytes = 0;
+		for (const Slab& s : slabs) {
+			const Header& h = s.h;
+			if (h.sx != h0.sx || h.sy != h0.sy || h.data_width != h0.data_width || h.stored_data_width != h0.stored_data_width
+				|| h.crack_format != h0.crack_format || h.fortran_order != h0.fortran_order || h.is_signed != h0.is_signed
+				|| h.markov_model_order != h0.markov_model_order) {
+				throw Error(CKL_ERR_ARG, "crackle_amd: zstack slabs disagree on shape, dtype, crack format, stored width or markov order");
+			}
+			if (h.markov_model_order && memcmp(s.model, slabs[0].model, h.markov_model_bytes()) != 0) {
+				throw Error(CKL_ERR_ARG, "crackle_amd: zstack slabs were encoded with different markov models");
+			}
+			sz += h.sz; total_comp += s.total_comp; crack_bytes += s.crack_bytes;
+		}
+		if (sz > 0xFFFFFFFFull) throw Error(CKL_ERR_ARG, "crackle_amd: zstack result has too many slices");
+
+		std::vector<uint64_t> uniq;
+		for (const Slab& s : slabs) uniq.insert(uniq.end(), s.uniq.begin(), s.uniq.end());
+		std::sort(uniq.begin(), uniq.end());
+		uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+
+		const int sw = h0.stored_data_width;
+		const int cw = byte_width(static_cast<uint64_t>(h0.sx) * h0.sy);
+		const int kw = byte_width(uniq.size());
+		std::vector<uint8_t> labels_binary;
+		labels_binary.reserve(8 + uniq.size() * sw + sz * cw + total_comp * kw);
+		put_le(labels_binary, uniq.size(), 8);
+		for (uint64_t v : uniq) put_le(labels_binary, v, sw);
+		for (const Slab& s : slabs) labels_binary.insert(labels_binary.end(), s.comp, s.comp + static_cast<uint64_t>(cw) * s.h.sz);
+		for (const Slab& s : slabs) {
+			std::vector<uint64_t> remap(s.uniq.size());
+			for (size_t i = 0; i < s.uniq.size(); i++) remap[i] = static_cast<uint64_t>(std::lower_bound(uniq.begin(), uniq.end(), s.uniq[i]) - uniq.begin());
+			const int skw = byte_width(s.num_unique);
+			for (uint64_t i = 0; i < s.total_comp; i++) {
+				const uint64_t key = rd_le(s.keys + i * skw, skw);
+				if (key >= remap.size()) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+				put_le(labels_binary, remap[key], kw);
+			}
+		}
+
+		Header h = h0;
+		h.sz = static_cast<uint32_t>(sz);
+		h.num_label_bytes = labels_binary.size();
+		std::vector<uint8_t> bin;
+		bin.reserve(Header::kBytes + 8 * (sz + 1) + labels_binary.size() + h.markov_model_bytes() + crack_bytes);
+		h.write(bin);
+		const size_t zi0 = bin.size();
+		for (const Slab& s : slabs) bin.insert(bin.end(), s.z_index, s.z_index + 4ull * s.h.sz);
+		put_le(bin, crc32c(bin.data() + zi0, 4ull * sz), 4);
+		bin.insert(bin.end(), labels_binary.begin(), labels_binary.end());
+		if (h.markov_model_order) bin.insert(bin.end(), slabs[0].model, slabs[0].model + h.markov_model_bytes());
+		for (const Slab& s : slabs) bin.insert(bin.end(), s.cracks, s.cracks + s.crack_bytes);
+		put_le(bin, crc32c(labels_binary.data(), labels_binary.size()), 4);
+		for (const Slab& s : slabs) bin.insert(bin.end(), s.crcs, s.crcs + 4ull * s.h.sz);
+
+		uint8_t* p = static_cast<uint8_t*>(malloc(bin.size() ? bin.size() : 1));
+		if (!p) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
+		memcpy(p, bin.data(), bin.size());
+		*out = p;
+		*out_len = bin.size();
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}

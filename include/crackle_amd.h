@@ -1,0 +1,182 @@
+/* crackle_amd — MI355X-native crackle encode/decode path: C-ABI drop-in boundary.
+ *
+ * Every entry point replaces (or is the device-resident form of) a function the
+ * reference exposes for this path; the reference interface each one stands in
+ * for is cited as /root/reference-relative file:line.
+ *
+ *   reference pybind module   src/fastcrackle.cpp:84-128  (decompress)
+ *                             src/fastcrackle.cpp:163-210 (compress)
+ *   reference C++ core        src/crackle.hpp:220-257     (crackle::compress<LABEL>)
+ *                             src/crackle.hpp:503-663     (crackle::decompress<LABEL,OUT>)
+ *   reference C-ABI precedent wasm/crackle_wasm.cc:22-68  (crackle_compress / crackle_decompress)
+ *
+ * Conventions: plain pointers and sizes only; no exceptions cross the boundary;
+ * every function returns a ckl_status and records a thread-local message
+ * retrievable with ckl_last_error().  Label volumes are x-fastest ("Fortran
+ * order", src/crackle.hpp:219).  All compute runs on the selected HIP device;
+ * there is no CPU fallback — without a usable device the calls fail with
+ * CKL_ERR_NO_DEVICE.
+ */
+#ifndef CRACKLE_AMD_H
+#define CRACKLE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ckl_status {
+	CKL_OK = 0,
+	CKL_ERR_FORMAT = 1,     /* not a crackle stream / corrupt header: crackle.FormatError (crackle/headers.py:78-105) */
+	CKL_ERR_RUNTIME = 2,    /* std::runtime_error("crackle: ...") in the reference -> RuntimeError */
+	CKL_ERR_ARG = 3,        /* bad argument (TypeError/ValueError in the Python shim) */
+	CKL_ERR_NO_DEVICE = 4,  /* no usable HIP device: the product path refuses to run on the CPU */
+	CKL_ERR_CRC = 5         /* a stored crc32c did not match (the reference swallows these) */
+} ckl_status;
+
+/* where a caller-provided buffer lives */
+enum { CKL_MEM_HOST = 0, CKL_MEM_DEVICE = 1 };
+
+/* Thread-local message of the last failing call on this thread. */
+const char* ckl_last_error(void);
+
+/* ABI version of this library (bumped on any signature change). */
+int ckl_abi_version(void);
+
+/* Number of usable HIP devices (0 when none; never fails). */
+int ckl_device_count(void);
+
+/* Parsed stream header — replaces crackle::CrackleHeader (src/header.hpp:35-308)
+ * and crackle/headers.py:78-124 for callers that need to size outputs. */
+typedef struct ckl_header_info {
+	uint32_t format_version;
+	uint32_t label_format;       /* 0 FLAT, 2 PINS_VARIABLE_WIDTH */
+	uint32_t crack_format;       /* 0 IMPERMISSIBLE, 1 PERMISSIBLE */
+	uint32_t is_signed;
+	uint32_t data_width;
+	uint32_t stored_data_width;
+	uint32_t sx, sy, sz;
+	uint32_t fortran_order;
+	uint32_t markov_model_order;
+	uint32_t is_sorted;
+	uint64_t num_label_bytes;
+	uint64_t header_bytes;
+} ckl_header_info;
+
+/* Validates magic/version/crc8 exactly as CrackleHeader::assign_from_buffer
+ * (src/header.hpp:98-150).  CKL_ERR_FORMAT on failure. */
+int ckl_header_info_from_bytes(const uint8_t* buf, uint64_t n, ckl_header_info* out);
+
+/* ---- one-shot entry points ------------------------------------------------ */
+
+/* Replaces fastcrackle.compress (src/fastcrackle.cpp:163-210) /
+ * crackle::compress<LABEL> (src/crackle.hpp:220-257).
+ *   labels        x-fastest volume of sx*sy*sz elements, dtype_bytes in {1,2,4,8}
+ *   labels_mem    CKL_MEM_HOST or CKL_MEM_DEVICE (pointer valid on `device`)
+ *   is_signed     must be 0 (crackle/codec.py:720-721 rejects signed input)
+ *   allow_pins .. manual_bgcolor   same meaning as the reference's arguments
+ *   device        HIP device ordinal
+ *   out/out_len   malloc'd host buffer holding the .ckl bytes; release with ckl_free
+ */
+int ckl_compress(
+	const void* labels, int labels_mem, int dtype_bytes, int is_signed,
+	int64_t sx, int64_t sy, int64_t sz,
+	int allow_pins, int fortran_order, uint64_t markov_model_order,
+	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
+	int device, uint8_t** out, uint64_t* out_len);
+
+void ckl_free(void* p);
+
+/* Replaces fastcrackle.decompress (src/fastcrackle.cpp:84-128) /
+ * crackle::decompress<LABEL,OUT> (src/crackle.hpp:503-663).
+ *   out            sx*sy*(z_end-z_start) elements of data_width bytes (1 byte each
+ *                  when has_label), written x-fastest for fortran_order streams and
+ *                  transposed (z fastest) otherwise, as crackle.hpp:617-656 does
+ *   out_mem        CKL_MEM_HOST or CKL_MEM_DEVICE
+ *   z_start,z_end  slice range; z_end < 0 means sz (clamped like crackle.hpp:527-537)
+ */
+int ckl_decompress(
+	const uint8_t* buf, uint64_t n,
+	void* out, uint64_t out_capacity_bytes, int out_mem,
+	int64_t z_start, int64_t z_end,
+	int has_label, uint64_t label,
+	int device);
+
+/* ---- resident sessions (inputs already in HBM; what bench.py times) -------- */
+
+typedef struct ckl_decoder ckl_decoder;
+
+/* Parses the stream on the host (header, z-index + crc32c, label section layout —
+ * crackle.hpp:262-336, labels.hpp:424-451), uploads it to HBM and allocates the
+ * scratch for slices [z_start, z_end). */
+int ckl_decoder_create(
+	const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end,
+	int device, ckl_decoder** out);
+/* Runs the device pipeline into a DEVICE output buffer and waits for it. */
+int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label);
+/* Elapsed device time of the last run, from HIP events recorded on the library's
+ * own stream around (a) the whole pipeline and (b) the dominant kernel. */
+int ckl_decoder_last_timing(const ckl_decoder* d, float* pipeline_ms, float* dominant_kernel_ms);
+void ckl_decoder_destroy(ckl_decoder* d);
+
+typedef struct ckl_encoder ckl_encoder;
+
+/* Allocates device scratch for volumes up to sx*sy*sz of dtype_bytes. */
+int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int device, ckl_encoder** out);
+
+/* Optional overrides used when z-slabs of one volume are encoded on several GPUs and
+ * merged afterwards: the format decisions that the reference
+ * takes from whole-volume reductions (crackle.hpp:48-64, 233-235) are imposed. */
+typedef struct ckl_encode_overrides {
+	int32_t force_crack_format;      /* -1: decide from this volume; else 0/1 */
+	int32_t force_label_format;      /* -1: decide; else 0 (FLAT) / 2 (PINS) */
+	int32_t force_stored_width;      /* 0: decide; else 1/2/4/8 */
+	int32_t has_model;               /* 1: use `model` (4^order rows x 4 symbol->rank bytes) instead of this volume's statistics */
+	const uint8_t* model;
+} ckl_encode_overrides;
+
+/* Encodes a DEVICE-resident volume; result is a malloc'd host buffer (ckl_free). */
+int ckl_encoder_run(
+	ckl_encoder* e, const void* labels_device,
+	int64_t sx, int64_t sy, int64_t sz,
+	int allow_pins, int fortran_order, uint64_t markov_model_order,
+	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
+	const ckl_encode_overrides* overrides,
+	uint8_t** out, uint64_t* out_len);
+
+/* Whole-volume reductions of the encode path, exposed so that sharded encoders can
+ * all-reduce them (lib.hpp:224-256): max label, count of equal linear neighbours
+ * inside this slab, and the slab's first and last voxel (for the pair that straddles
+ * a slab boundary).  labels_device is a DEVICE pointer. */
+int ckl_encoder_stats(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	uint64_t* max_label, uint64_t* pixel_pairs, uint64_t* first_voxel, uint64_t* last_voxel);
+
+/* Order-N context histogram of this slab's difference-coded crack moves
+ * (markov.hpp:193-220): hist must hold 4^order * 4 uint32.  Must follow a
+ * ckl_encoder_run-compatible crack pass; see ckl_encoder_run docs in DESIGN.md. */
+int ckl_encoder_markov_stats(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	int crack_format, uint64_t markov_model_order, uint32_t* hist);
+
+int ckl_encoder_last_timing(const ckl_encoder* e, float* pipeline_ms, float* dominant_kernel_ms);
+void ckl_encoder_destroy(ckl_encoder* e);
+
+/* ---- host-side stream surgery used by the sharded encoder ------------------ */
+
+/* Concatenates FLAT-label streams of consecutive z-slabs (same sx, sy, dtype, crack
+ * format, stored width, markov order+model) into the stream the reference would have
+ * produced for the whole volume — native form of crackle.operations.zstack
+ * (crackle/operations.py:424-548), host only, no device needed. */
+int ckl_zstack(
+	const uint8_t* const* bufs, const uint64_t* lens, uint64_t count,
+	uint8_t** out, uint64_t* out_len);
+
+/* crc32c (Castagnoli; src/crc.hpp:51-57) of a host buffer — exported for tests. */
+uint32_t ckl_crc32c(const uint8_t* data, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRACKLE_AMD_H */
