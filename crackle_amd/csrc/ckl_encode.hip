@@ -1093,6 +1093,26 @@ int ckl_compress(
 	ckl_encoder* e = nullptr;
 	try {
 		check_dims(sx, sy, sz, dtype_bytes, is_signed);
+		if (!out || !out_len) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		if (static_cast<uint64_t>(sx) * sy * sz == 0) {
+			// crackle.hpp:96-98: an empty volume is just the 29-byte header; nothing to compute
+			Header head;
+			head.crack_format = IMPERMISSIBLE;              // pixel_pairs 0 < 0 / 2 is false (crackle.hpp:50-55)
+			head.label_format = (sz == 1 || !allow_pins) ? FLAT : PINS_VARIABLE_WIDTH;
+			head.data_width = dtype_bytes;
+			head.stored_data_width = 1;                     // max_label of nothing is 0
+			head.sx = static_cast<uint32_t>(sx); head.sy = static_cast<uint32_t>(sy); head.sz = static_cast<uint32_t>(sz);
+			head.fortran_order = fortran_order != 0;
+			head.markov_model_order = static_cast<int>(markov_model_order & 0xFF);
+			std::vector<uint8_t> bin;
+			head.write(bin);
+			uint8_t* p = static_cast<uint8_t*>(malloc(bin.size()));
+			if (!p) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
+			memcpy(p, bin.data(), bin.size());
+			*out = p;
+			*out_len = bin.size();
+			return CKL_OK;
+		}
 	}
 	catch (const Error& err) { set_last_error(err.what()); return err.status; }
 	int rc = ckl_encoder_create(sx, sy, sz, dtype_bytes, device, &e);

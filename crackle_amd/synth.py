@@ -52,17 +52,23 @@ def voronoi_labels(
   offset: int = 0,
   device="cpu",
   z_chunk: int = 8,
+  z_range: Optional[Tuple[int, int]] = None,
 ) -> torch.Tensor:
-  """Jittered-grid anisotropic Voronoi labels, tensor shape (sz, sy, sx)."""
+  """Jittered-grid anisotropic Voronoi labels, tensor shape (sz, sy, sx).
+
+  ``z_range=(z0, z1)`` returns only slices [z0, z1) of the (sx, sy, sz) volume —
+  bit-identical to slicing the full result — so that each GPU of a sharded run can
+  generate its own slab."""
   sx, sy, sz = (int(s) for s in shape)
+  z_lo, z_hi = (0, sz) if z_range is None else (int(z_range[0]), int(z_range[1]))
   cx, cy, cz = (int(c) for c in cell)
   store_dt, final_dt = _torch_dtype(dtype)
   itemsize = np.dtype(dtype).itemsize
   if modulus is None:
     modulus = {1: 250, 2: 60000, 4: 1 << 30, 8: 1 << 30}[itemsize]
   dev = torch.device(device)
-  out = torch.empty((sz, sy, sx), dtype=store_dt, device=dev)
-  if sx * sy * sz == 0:
+  out = torch.empty((max(z_hi - z_lo, 0), sy, sx), dtype=store_dt, device=dev)
+  if sx * sy * max(z_hi - z_lo, 0) == 0:
     return out.view(final_dt)
 
   # lattice of cells covering the volume plus a one-cell halo
@@ -90,8 +96,8 @@ def voronoi_labels(
   cxi = (xs // cx + 1).to(torch.int64)   # +1: halo offset into the lattice
   cyi = (ys // cy + 1).to(torch.int64)
 
-  for z0 in range(0, sz, z_chunk):
-    z1 = min(sz, z0 + z_chunk)
+  for z0 in range(z_lo, z_hi, z_chunk):
+    z1 = min(z_hi, z0 + z_chunk)
     zs = torch.arange(z0, z1, device=dev, dtype=torch.int32)
     czi = (zs // cz + 1).to(torch.int64)
     best_key = None
@@ -113,7 +119,7 @@ def voronoi_labels(
             take = key < best_key
             best_key = torch.where(take, key, best_key)
             best_lab = torch.where(take, cand, best_lab)
-    out[z0:z1] = best_lab.to(store_dt) if store_dt != torch.uint8 else best_lab.to(torch.uint8)
+    out[z0 - z_lo:z1 - z_lo] = best_lab.to(store_dt)
   return out.view(final_dt)
 
 

@@ -1,0 +1,149 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the golden fixtures
+produced by the reference, against the oracle on seeded inputs, and — at sizes the
+oracle cannot cover quickly — through size-independent properties.
+Bit-exact: this is integer/byte work."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import crackle_amd
+from crackle_amd import _lib, synth
+import golden_cases
+from util import golden, manifest, label_format, sha
+
+pytestmark = pytest.mark.gpu
+
+SMALL = golden_cases.small_cases()
+LARGE = golden_cases.large_cases()
+
+
+def _kw(kw):
+  return dict(allow_pins=int(kw["allow_pins"]), markov_model_order=kw["markov_model_order"])
+
+
+def test_extension_loaded_and_device_present():
+  assert _lib.lib().ckl_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_decode_golden(name):
+  arr, _ = SMALL[name]
+  got = crackle_amd.decompress(golden()[name])
+  if arr.size == 0:
+    assert got.size == 0
+    return
+  assert got.dtype == arr.dtype and got.shape == arr.shape
+  assert got.flags.f_contiguous == arr.flags.f_contiguous or arr.ndim < 2
+  assert np.array_equal(got, arr)
+
+
+@pytest.mark.parametrize("name", sorted(n for n in SMALL if label_format(golden()[n]) == 0))
+def test_encode_golden_flat(name):
+  arr, kw = SMALL[name]
+  assert crackle_amd.compress(arr, **_kw(kw)) == golden()[name]
+
+
+@pytest.mark.parametrize("name", sorted(n for n in SMALL if label_format(golden()[n]) == 2 and SMALL[n][0].size))
+def test_encode_golden_pins(name):
+  arr, kw = SMALL[name]
+  try:
+    b = crackle_amd.compress(arr, **_kw(kw))
+  except RuntimeError as e:
+    if "not implemented" in str(e):
+      pytest.xfail("pin label encoding lands in a later round")
+    raise
+  assert b == golden()[name]
+
+
+@pytest.mark.parametrize("name", sorted(LARGE))
+def test_large_manifest(name):
+  thunk, kw = LARGE[name]
+  arr = thunk()
+  m = manifest()[name]
+  if kw["allow_pins"]:
+    pytest.xfail("pin label encoding lands in a later round")
+  b = crackle_amd.compress(arr, **_kw(kw))
+  assert len(b) == m["length"] and sha(b) == m["sha256"]
+  assert np.array_equal(crackle_amd.decompress(b), arr)
+
+
+def test_z_range_label_and_c_order():
+  arr, _ = SMALL["c0_voronoi_u8"]
+  for key in ("c0_voronoi_u8", "c0_voronoi_u8_pins", "c0_voronoi_u8_m5", "c0_voronoi_u8_pins_m5"):
+    b = golden()[key]
+    got = crackle_amd.decompress_range(b, 3, 9)
+    assert got.shape == (64, 64, 6) and np.array_equal(got, arr[:, :, 3:9])
+    lbl = int(arr[10, 10, 5])
+    img = crackle_amd.decompress(b, label=lbl)
+    assert img.dtype == bool and np.array_equal(img, arr == lbl)
+  c = crackle_amd.decompress(golden()["c0_voronoi_u8_c"])
+  assert c.flags.c_contiguous and np.array_equal(c, arr)
+
+
+def test_oracle_agreement_on_seeded_volumes(checker):
+  cases = [
+    ((200, 150, 9), np.uint8, 5, (16, 16, 4), dict(markov_model_order=0)),
+    ((333, 257, 5), np.uint16, 6, (32, 32, 8), dict(markov_model_order=4)),
+    ((512, 512, 6), np.uint32, 7, (32, 32, 8), dict(markov_model_order=0)),
+    ((256, 256, 8), np.uint64, 8, (32, 32, 8), dict(markov_model_order=7)),
+  ]
+  for shape, dt, seed, cell, kw in cases:
+    arr = synth.as_numpy_f(synth.voronoi_labels(shape, dt, seed=seed, cell=cell, offset=(1 << 40) if dt == np.uint64 else 0))
+    want = checker.compress(arr, parallel=4, **kw)
+    got = crackle_amd.compress(arr, **kw)
+    assert got == want, f"{shape} {dt} {kw}"
+    assert np.array_equal(crackle_amd.decompress(want), arr)
+  noise = synth.random_labels((128, 128, 3), np.uint32, seed=9, high=2000)
+  assert crackle_amd.compress(noise) == checker.compress(noise)
+  bits = synth.random_labels((96, 96, 2), np.uint8, seed=10, high=2)
+  assert crackle_amd.compress(bits, markov_model_order=2) == checker.compress(bits, markov_model_order=2)
+
+
+def test_corruption_is_reported():
+  b = bytearray(golden()["c0_voronoi_u8"])
+  b[-1] ^= 0xFF   # last slice's crc32c
+  with pytest.raises(RuntimeError, match="crc"):
+    crackle_amd.decompress(bytes(b))
+  b = bytearray(golden()["c0_voronoi_u8"])
+  b[29] ^= 0x01   # z-index
+  with pytest.raises(RuntimeError):
+    crackle_amd.decompress(bytes(b))
+  with pytest.raises(crackle_amd.FormatError):
+    crackle_amd.decompress(b"crkl" + bytes(40) + b"\x01")
+  trunc = golden()["c0_voronoi_u8"][:200]
+  with pytest.raises(RuntimeError):
+    crackle_amd.decompress(trunc)
+
+
+def test_device_resident_sessions_full_size_properties():
+  """1024x1024x32 uint32 entirely on device: encode -> decode round trip equality,
+  determinism, and agreement between the per-slice crc32c the encoder stored and the
+  one the decoder recomputes (a checksum of checksums over 32 slices)."""
+  import torch
+  L = _lib.lib()
+  dev = torch.device("cuda:0")
+  vol = synth.voronoi_labels((1024, 1024, 32), np.uint32, seed=2, device=dev)
+  sz, sy, sx = vol.shape
+  enc = C.c_void_p()
+  assert L.ckl_encoder_create(sx, sy, sz, 4, 0, C.byref(enc)) == 0
+  outs = []
+  for _ in range(2):
+    out, n = C.c_void_p(), C.c_uint64()
+    rc = L.ckl_encoder_run(enc, vol.data_ptr(), sx, sy, sz, 0, 1, 0, 0, 1, 0, None, C.byref(out), C.byref(n))
+    assert rc == 0, _lib.last_error()
+    outs.append(C.string_at(out.value, n.value))
+    L.ckl_free(out)
+  L.ckl_encoder_destroy(enc)
+  assert outs[0] == outs[1]
+  binary = outs[0]
+  assert len(binary) < vol.numel() * 4 // 50
+  dec = C.c_void_p()
+  assert L.ckl_decoder_create(binary, len(binary), 0, -1, 0, C.byref(dec)) == 0, _lib.last_error()
+  back = torch.empty_like(vol)
+  for _ in range(2):
+    back.zero_()
+    assert L.ckl_decoder_run(dec, back.data_ptr(), back.numel() * 4, 0, 0) == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(back.view(torch.int32), vol.view(torch.int32))
+  L.ckl_decoder_destroy(dec)
