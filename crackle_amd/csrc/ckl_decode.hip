@@ -4,21 +4,29 @@
 //   read_boc_index / packed_codepoints_to_symbols   src/crackcodes.hpp:283-316, 523-603
 //   markov::decode_codepoints / codepoints_to_symbols src/markov.hpp:268-323, crackcodes.hpp:606-676
 //   decode_(im)permissible_crack_code (rasteriser)   src/crackcodes.hpp:706-876
-//   cc3d::color_connectivity_graph + relabel         src/cc3d.hpp:114-254   (ckl_ccl.hpp)
+//   cc3d::color_connectivity_graph + relabel         src/cc3d.hpp:114-254
 //   crc32c of the component image                    src/crackle.hpp:599-611
 //   labels::decode_flat / decode_condensed_pins      src/labels.hpp:453-617
 //   the paint loop                                   src/crackle.hpp:617-656
 //
 // Kernels (block = 256 threads):
-//   k_decode_cracks   one workgroup per slice: BOC index, 2-bit unpack + mod-4
-//                     prefix sum (undo the difference code), control-pair detection,
-//                     symbol compaction and position prefix sums (block scans), a
-//                     short serial pass over the control symbols only (branch stack),
-//                     then parallel rasterisation of every move into two bit planes.
-//   k_ccl_*           see ckl_ccl.hpp
+//   k_decode_cracks   one workgroup per slice: BOC index, 2-bit unpack + mod-4 prefix
+//                     sum (undo the difference code), control-pair detection, symbol
+//                     compaction and displacement prefix sums (block scans), branch
+//                     matching of the control symbols 64 at a time by one wavefront
+//                     (ballot / shuffle pointer jumping, stack in LDS), then parallel
+//                     rasterisation of every move into two bit planes.
+//   k_run_index       horizontal runs of each slice from the vertical-crack plane:
+//                     exclusive prefix sum of break counts per 32-pixel word.
+//   k_run_union       union-find over RUNS (not pixels): vertically adjacent runs that
+//                     are connected through the horizontal-crack plane are united.
+//   k_run_resolve     roots ranked in raster order = the reference's component ids
+//                     (cc3d.hpp:114-144); crc32c of the (never materialised) component
+//                     image accumulated per run from a geometric-sum table.
 //   k_label_map_*     component -> label tables (flat keys / pins)
-//   k_paint           out[p] = label_map[cc(p)] fused with the crc32c of the
-//                     component image (never materialised in memory)
+//   k_run_labels      run -> label
+//   k_paint_runs      streams the output: per 4 pixels one plane word, a popcount and a
+//                     look-up in an LDS-staged run->label table; 16-byte stores.
 #include "ckl_common.hpp"
 #include "ckl_ccl.hpp"
 
@@ -80,6 +88,8 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 	__shared__ int32_t s_scanmax[kWaves];
 	__shared__ uint32_t s_last_move[kBlock];
 	__shared__ uint32_t s_last_ctrl[kBlock];
+	constexpr uint32_t kStackLds = 2048;
+	__shared__ uint32_t s_stack[kStackLds];
 	__shared__ uint32_t s_nnodes, s_ncodes, s_nsyms, s_nctl, s_valid_segs, s_err;
 
 	const uint32_t zi = blockIdx.x;
@@ -305,40 +315,132 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 	__syncthreads();
 	const uint32_t n_syms = s_nsyms, n_ctl = s_nctl;
 
-	// ---- phase C: serial pass over the control symbols only ('b' push / 't' pop) -----
+	// ---- phase C: branch matching over the control symbols, 64 at a time by wave 0 ----
 	// (crackcodes.hpp:771-781, 849-859: the rasteriser's revisit stack; chain
-	// segmentation by branches_taken, crackcodes.hpp:549-598)
+	// segmentation by branches_taken, crackcodes.hpp:549-598).
+	// A 't' returns the cursor to where its matching 'b' was pushed.  Inside a chunk a
+	// 't' matches the nearest earlier control of the same nesting level when that is a
+	// 'b'; otherwise it pops the stack carried between chunks (or ends the chain when
+	// the stack is empty).  Segment offsets chain through earlier 't's of the chunk and
+	// are resolved by pointer jumping with shuffles.
 	uint32_t* seg_off = a.seg_off + cb;
 	uint32_t* stack = a.stack + cb;
-	if (tid == 0) {
+	if (tid < kWave) {
+		const int lane = tid;
 		uint32_t valid = 0;
 		if (n_nodes > 0 && n_syms > 0) {
-			uint32_t off = nodes[0];
+			uint32_t off = nodes[0];          // offset of the current segment (wave uniform)
 			uint32_t chain = 0, sp = 0;
-			seg_off[0] = off;
+			bool done = false;
+			if (lane == 0) seg_off[0] = off;
 			valid = 1;
-			for (uint32_t k = 0; k < n_ctl; k++) {
-				const uint32_t s = ctl_sym[k];
-				const uint32_t kind = sym_kind[s];
-				const uint32_t pos = sym_pos[s];
-				if (kind == SYM_B) {
-					stack[sp++] = off + pos;      // sp <= number of 'b' <= n_ctl <= cap
+			const unsigned long long below = (1ull << lane) - 1ull;
+			constexpr int PTR_NONE = -1, PTR_CARRY = -2;
+			for (uint32_t base = 0; base < n_ctl && !done; base += kWave) {
+				const uint32_t k = base + lane;
+				const bool live = k < n_ctl;
+				uint32_t pos = 0, seg = 0, kind = SYM_U;
+				if (live) {
+					const uint32_t s = ctl_sym[k];
+					kind = sym_kind[s]; pos = sym_pos[s]; seg = sym_seg[s];
 				}
-				else {
-					if (sp > 0) {
-						off = stack[--sp] - pos;
+				const bool isT = live && kind == SYM_T;
+				const bool isB = live && kind == SYM_B;
+				const unsigned long long tmask = __ballot(isT), bmask = __ballot(isB);
+				const uint32_t d = wave_incl_add(isB ? 1u : (isT ? 0xFFFFFFFFu : 0u));
+				const uint32_t level = isT ? d + 1u : d;     // 'b': depth after, 't': depth before
+				int match = -1;           // 't': lane of the matching 'b' in this chunk
+				bool matched_b = false;   // 'b': closed inside this chunk
+				for (unsigned long long todo = tmask | bmask; todo;) {
+					const int lead = __ffsll(static_cast<long long>(todo)) - 1;
+					const uint32_t lv = __shfl(level, lead, kWave);
+					const unsigned long long same = __ballot((isT || isB) && level == lv);
+					if ((isT || isB) && level == lv) {
+						if (isT) {
+							const unsigned long long prev = same & below;
+							if (prev) {
+								const int j = 63 - __clzll(static_cast<long long>(prev));
+								if ((bmask >> j) & 1ull) match = j;
+							}
+						}
+						else {
+							const unsigned long long next = same & ~below & ~(1ull << lane);
+							matched_b = next != 0;   // levels alternate b,t,b,t: the next one is its 't'
+						}
 					}
-					else {
-						chain++;
-						if (chain >= n_nodes) break;   // trailing pad codes are ignored
-						off = nodes[chain] - pos;
-					}
-					const uint32_t seg = sym_seg[s] + 1u;
-					if (seg < cap) { seg_off[seg] = off; valid = seg + 1u; }
+					todo &= ~same;
 				}
+				const bool um_t = isT && match < 0;
+				const unsigned long long um_t_mask = __ballot(um_t);
+				const uint32_t q = __popcll(um_t_mask & below);      // rank among the chunk's unmatched 't'
+				const bool chain_end = um_t && q >= sp;
+				const uint32_t new_chain = chain + (q - sp) + 1u;     // meaningful when chain_end
+				const bool dead = chain_end && new_chain >= n_nodes;   // trailing pad codes start here
+				const unsigned long long dead_mask = __ballot(dead);
+				const int first_dead = dead_mask ? (__ffsll(static_cast<long long>(dead_mask)) - 1) : 64;
+				const bool ok = lane < first_dead;                    // lanes before the pad codes
+
+				// stack pops are read before anything is pushed back
+				uint32_t popped = 0;
+				if (um_t && !chain_end) {
+					const uint32_t idx = sp - 1u - q;
+					popped = idx < kStackLds ? s_stack[idx] : __hip_atomic_load(stack + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				const uint32_t pos_match = __shfl(pos, match >= 0 ? match : 0, kWave);
+				uint32_t val = 0;
+				int ptr = PTR_NONE;
+				if (isT && ok) {
+					if (match >= 0) {
+						const unsigned long long pt = tmask & ((1ull << match) - 1ull);
+						val = pos_match - pos;
+						ptr = pt ? (63 - __clzll(static_cast<long long>(pt))) : PTR_CARRY;
+					}
+					else if (!chain_end) val = popped - pos;
+					else val = nodes[new_chain] - pos;
+				}
+#pragma unroll
+				for (int r = 0; r < 6; r++) {
+					const int pl = ptr >= 0 ? ptr : lane;
+					const uint32_t pv = __shfl(val, pl, kWave);
+					const int pp = __shfl(ptr, pl, kWave);
+					if (ptr >= 0) { val += pv; ptr = pp; }
+				}
+				const uint32_t my_off = val + (ptr == PTR_CARRY ? off : 0u);   // 't' lanes: offset of the segment they open
+
+				// position of every 'b' = offset of the segment it sits in + its displacement
+				const unsigned long long pt_b = tmask & below;
+				const int src = pt_b ? (63 - __clzll(static_cast<long long>(pt_b))) : -1;
+				const uint32_t src_off = __shfl(my_off, src >= 0 ? src : 0, kWave);
+				const uint32_t t_b = (src >= 0 ? src_off : off) + pos;
+
+				const unsigned long long ok_um_t = um_t_mask & (first_dead >= 64 ? ~0ull : ((1ull << first_dead) - 1ull));
+				const uint32_t n_um_t = __popcll(ok_um_t);
+				const uint32_t n_pop = n_um_t < sp ? n_um_t : sp;
+				const uint32_t sp_base = sp - n_pop;
+				const bool um_b = isB && ok && !matched_b;
+				const unsigned long long um_b_mask = __ballot(um_b);
+				if (um_b) {
+					const uint32_t idx = sp_base + __popcll(um_b_mask & below);
+					if (idx < kStackLds) s_stack[idx] = t_b; else stack[idx] = t_b;   // idx < #controls <= cap
+				}
+				if (isT && ok && seg + 1u < cap) seg_off[seg + 1u] = my_off;
+
+				// carries
+				const unsigned long long ok_t = tmask & (first_dead >= 64 ? ~0ull : ((1ull << first_dead) - 1ull));
+				const int last_t = ok_t ? (63 - __clzll(static_cast<long long>(ok_t))) : -1;
+				const uint32_t last_off = __shfl(my_off, last_t >= 0 ? last_t : 0, kWave);
+				const uint32_t last_seg = __shfl(seg, last_t >= 0 ? last_t : 0, kWave);
+				if (last_t >= 0) { off = last_off; valid = last_seg + 2u; }
+				chain += n_um_t - n_pop;
+				sp = sp_base + __popcll(um_b_mask);
+				if (dead_mask) {
+					valid = __shfl(seg, first_dead, kWave) + 1u;
+					done = true;
+				}
+				__threadfence_block();
 			}
 		}
-		s_valid_segs = valid;
+		if (tid == 0) s_valid_segs = valid;
 	}
 	__syncthreads();
 	const uint32_t valid_segs = s_valid_segs;
@@ -381,6 +483,208 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 }
 
 // ------------------------------------------------------------------------------
+// horizontal runs
+// ------------------------------------------------------------------------------
+// A run is a maximal stretch of horizontally connected pixels of one row.  Runs are
+// numbered in raster order of their first pixel; word_base[w] = number of runs that
+// start before 32-pixel word w of the slice, so the run of pixel (x, y) is
+//   word_base[y, x>>5] + popcount(breaks(y, x>>5) & bits <= (x & 31)) - 1.
+struct RunGeom {
+	const uint32_t* planeV;
+	const uint32_t* planeH;
+	uint32_t row_words;
+	uint64_t plane_words;
+	uint32_t flip;          // 1 for IMPERMISSIBLE (a crack bit is a break)
+	uint32_t sx, sy;
+	__device__ __forceinline__ uint32_t valid_mask(uint32_t w) const {
+		const uint32_t left = sx - w * 32u;
+		return left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+	}
+	// bit x set: a run starts at pixel x of this word
+	__device__ __forceinline__ uint32_t breaks(uint32_t zi, uint32_t y, uint32_t w) const {
+		const uint32_t v = planeV[zi * plane_words + static_cast<uint64_t>(y) * row_words + w];
+		uint32_t b = flip ? v : ~v;
+		if (w == 0) b |= 1u;
+		return b & valid_mask(w);
+	}
+	// bit x set: pixel x is connected to the pixel above it
+	__device__ __forceinline__ uint32_t ups(uint32_t zi, uint32_t y, uint32_t w) const {
+		if (y == 0) return 0u;
+		const uint32_t h = planeH[zi * plane_words + static_cast<uint64_t>(y) * row_words + w];
+		return (flip ? ~h : h) & valid_mask(w);
+	}
+};
+__device__ __forceinline__ uint32_t mask_le(uint32_t bit) { return bit >= 31u ? 0xFFFFFFFFu : ((2u << bit) - 1u); }
+
+struct RunArrays {
+	uint32_t* word_base;       // [nslices][plane_words]
+	const uint64_t* rbase;     // per slice base into the run arrays
+	const uint32_t* rcap;
+	uint32_t* parent;          // union-find over runs (root = smallest run index)
+	uint32_t* run_start;       // first pixel of the run (slice-linear)
+	uint32_t* run_cc;          // component id of the run
+	uint32_t* nruns;           // [nslices]
+	uint32_t* ncomp;           // [nslices]
+	uint32_t* slice_err;
+};
+
+// grid = nslices
+__global__ void __launch_bounds__(kBlock) k_run_index(RunGeom g, RunArrays r) {
+	__shared__ uint32_t s_scan[kWaves];
+	const uint32_t zi = blockIdx.x;
+	uint32_t* wb = r.word_base + zi * g.plane_words;
+	uint32_t* parent = r.parent + r.rbase[zi];
+	uint32_t* run_start = r.run_start + r.rbase[zi];
+	const uint32_t cap = r.rcap[zi];
+	const uint32_t words = static_cast<uint32_t>(g.plane_words);
+	constexpr uint32_t kPer = 4;
+	uint32_t carry = 0, err = 0;
+	for (uint32_t w0 = 0; w0 < words; w0 += kBlock * kPer) {
+		uint32_t b[kPer], cnt = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < kPer; j++) {
+			const uint32_t wi = w0 + threadIdx.x * kPer + j;
+			b[j] = 0;
+			if (wi < words) {
+				const uint32_t y = wi / g.row_words;
+				b[j] = g.breaks(zi, y, wi - y * g.row_words);
+			}
+			cnt += __popc(b[j]);
+		}
+		uint32_t v[1] = { cnt }, tot[1];
+		block_excl_add<1>(v, tot, s_scan);
+		uint32_t base = carry + v[0];
+#pragma unroll
+		for (uint32_t j = 0; j < kPer; j++) {
+			const uint32_t wi = w0 + threadIdx.x * kPer + j;
+			if (wi >= words) break;
+			wb[wi] = base;
+			const uint32_t y = wi / g.row_words;
+			const uint32_t x0 = (wi - y * g.row_words) * 32u;
+			for (uint32_t m = b[j]; m; m &= m - 1u) {
+				const uint32_t bit = __ffs(m) - 1;
+				if (base < cap) { run_start[base] = y * g.sx + x0 + bit; parent[base] = base; }
+				else err = ERR_CAPACITY;
+				base++;
+			}
+		}
+		carry += tot[0];
+	}
+	if (threadIdx.x == 0) r.nruns[zi] = carry < cap ? carry : cap;
+	if (err) atomicOr(r.slice_err + zi, err);
+}
+
+__device__ __forceinline__ uint32_t run_find(uint32_t* L, uint32_t a) {
+	// path halving; parents only ever decrease, so racing writers stay consistent
+	uint32_t p = uf_load(L, a);
+	while (p != a) {
+		const uint32_t gp = uf_load(L, p);
+		if (gp != p) atomicMin(L + a, gp);
+		a = p;
+		p = gp;
+	}
+	return a;
+}
+__device__ __forceinline__ void run_unite(uint32_t* L, uint32_t a, uint32_t b) {
+	for (;;) {
+		a = run_find(L, a);
+		b = run_find(L, b);
+		if (a == b) return;
+		if (a > b) { const uint32_t t = a; a = b; b = t; }
+		const uint32_t old = atomicMin(L + b, a);
+		if (old == b) return;
+		b = old;
+	}
+}
+
+// grid = (ceil(words / 256), nslices): one thread per 32-pixel word of rows y >= 1.
+// A union is issued at the first pixel of every stretch along which the pixel stays
+// up-connected and neither its own run nor the run above changes.
+__global__ void __launch_bounds__(kBlock) k_run_union(RunGeom g, RunArrays r) {
+	const uint32_t zi = blockIdx.y;
+	const uint32_t wi = blockIdx.x * kBlock + threadIdx.x;
+	if (wi >= g.plane_words) return;
+	const uint32_t y = wi / g.row_words;
+	if (y == 0) return;
+	const uint32_t w = wi - y * g.row_words;
+	const uint32_t up = g.ups(zi, y, w);
+	if (!up) return;
+	const uint32_t prev_bit = w ? (g.ups(zi, y, w - 1) >> 31) : 0u;
+	const uint32_t b_here = g.breaks(zi, y, w);
+	const uint32_t b_up = g.breaks(zi, y - 1, w);
+	uint32_t cand = up & (~((up << 1) | prev_bit) | b_here | b_up);
+	const uint32_t* wb = r.word_base + zi * g.plane_words;
+	const uint32_t base_here = wb[wi], base_up = wb[wi - g.row_words];
+	uint32_t* parent = r.parent + r.rbase[zi];
+	const uint32_t n = r.nruns[zi];
+	for (; cand; cand &= cand - 1u) {
+		const uint32_t bit = __ffs(cand) - 1;
+		const uint32_t m = mask_le(bit);
+		const uint32_t ra = base_here + __popc(b_here & m) - 1u;
+		const uint32_t rb = base_up + __popc(b_up & m) - 1u;
+		if (ra < n && rb < n) run_unite(parent, ra, rb);
+	}
+}
+
+// grid = nslices.  Phase 1: flatten, rank the roots in run order (= raster order of each
+// component's first pixel, cc3d.hpp:114-144).  Phase 2: component id of every run and the
+// raw crc32c of the component image: a run of id c covering pixels [a, b) of an n-pixel
+// slice contributes c * (G[n-a] ^ G[n-b]) with G[m] = x^32 + x^64 + ... + x^(32 m) mod P.
+// The multiplication walks only the `idbits` significant bits of c; the common factor
+// x^(32-idbits) is applied once per slice on the host side of the comparison.
+__global__ void __launch_bounds__(kBlock) k_run_resolve(RunArrays r, const uint32_t* __restrict__ G, uint32_t n_pixels, uint32_t idbits, uint32_t* __restrict__ crc_acc) {
+	__shared__ uint32_t s_scan[kWaves];
+	const uint32_t zi = blockIdx.x;
+	uint32_t* parent = r.parent + r.rbase[zi];
+	const uint32_t* run_start = r.run_start + r.rbase[zi];
+	uint32_t* run_cc = r.run_cc + r.rbase[zi];
+	const uint32_t n = r.nruns[zi];
+	uint32_t carry = 0;
+	for (uint32_t r0 = 0; r0 < n; r0 += kBlock) {
+		const uint32_t i = r0 + threadIdx.x;
+		uint32_t is_root = 0;
+		if (i < n) {
+			const uint32_t root = run_find(parent, i);
+			parent[i] = root;
+			is_root = (root == i);
+		}
+		uint32_t v[1] = { is_root }, tot[1];
+		block_excl_add<1>(v, tot, s_scan);
+		if (is_root) run_cc[i] = carry + v[0];
+		carry += tot[0];
+	}
+	if (threadIdx.x == 0) r.ncomp[zi] = carry;
+	__syncthreads();
+	__threadfence_block();
+	uint32_t acc = 0;
+	for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+		const uint32_t root = parent[i];
+		const uint32_t cc = run_cc[root];
+		if (root != i) run_cc[i] = cc;
+		const uint32_t a = run_start[i];
+		const uint32_t b = (i + 1 < n) ? run_start[i + 1] : n_pixels;
+		uint32_t wgt = G[n_pixels - a] ^ G[n_pixels - b];
+		// sum over set bits j < idbits of c:  wgt * x^(idbits-1-j)
+		uint32_t part = 0;
+		for (int j = static_cast<int>(idbits) - 1; j >= 0; j--) {
+			part ^= ((cc >> j) & 1u) ? wgt : 0u;
+			wgt = (wgt >> 1) ^ ((wgt & 1u) ? dev::kCrcPoly : 0u);
+		}
+		acc ^= part;
+	}
+	acc = block_xor(acc, s_scan);
+	if (threadIdx.x == 0) crc_acc[zi] = acc;
+}
+
+// G[k*B + i] = G[k*B] ^ x^(32 k B) * G[i]   (B = 1024; per-block constants from the host)
+__global__ void __launch_bounds__(kBlock) k_build_geom_table(const uint32_t* __restrict__ g_base, const uint32_t* __restrict__ blk_g, const uint32_t* __restrict__ blk_x, uint32_t n, uint32_t* __restrict__ G) {
+	const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
+	if (m > n) return;
+	const uint32_t k = m >> 10, i = m & 1023u;
+	G[m] = blk_g[k] ^ gf_mul(blk_x[k], g_base[i]);
+}
+
+// ------------------------------------------------------------------------------
 // component -> label tables
 // ------------------------------------------------------------------------------
 // flat (labels.hpp:453-506): label_map[i] = uniq[key[i]] for the components of the
@@ -419,13 +723,12 @@ __global__ void __launch_bounds__(kBlock) k_label_map_ccids(
 __global__ void __launch_bounds__(kBlock) k_label_map_pins(
 	const uint64_t* __restrict__ pin_index, const uint64_t* __restrict__ pin_depth, const uint64_t* __restrict__ pin_label,
 	const uint64_t* __restrict__ pin_work_off, uint64_t n_pins, uint64_t total_work,
-	const uint32_t* __restrict__ L, const uint32_t* __restrict__ R, uint64_t sxy,
-	int64_t z_start, int64_t z_end, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ ncomp,
+	RunGeom g, RunArrays r, uint64_t sxy,
+	int64_t z_start, int64_t z_end, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ ncomp_expect,
 	uint64_t* __restrict__ label_map
 ) {
 	const uint64_t w = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
 	if (w >= total_work) return;
-	// binary search the pin owning work item w
 	uint64_t lo = 0, hi = n_pins;
 	while (lo + 1 < hi) {
 		const uint64_t mid = (lo + hi) >> 1;
@@ -434,85 +737,116 @@ __global__ void __launch_bounds__(kBlock) k_label_map_pins(
 	const uint64_t j = lo;
 	const int64_t pin_z = static_cast<int64_t>(pin_index[j] / sxy);
 	const uint64_t loc = pin_index[j] - static_cast<uint64_t>(pin_z) * sxy;
-	int64_t zs = pin_z > z_start ? pin_z : z_start;
+	const int64_t zs = pin_z > z_start ? pin_z : z_start;
 	const int64_t z = zs + static_cast<int64_t>(w - pin_work_off[j]);
 	int64_t ze = pin_z + static_cast<int64_t>(pin_depth[j]) + 1;
 	if (ze > z_end) ze = z_end;
 	if (z >= ze) return;
-	const uint64_t zi = static_cast<uint64_t>(z - z_start);
-	const uint32_t root = L[zi * sxy + loc];
-	const uint32_t cc = R[zi * sxy + root];
-	if (cc < ncomp[zi]) label_map[comp_off[zi] + cc] = pin_label[j];
+	const uint32_t zi = static_cast<uint32_t>(z - z_start);
+	const uint32_t y = static_cast<uint32_t>(loc / g.sx);
+	const uint32_t x = static_cast<uint32_t>(loc - static_cast<uint64_t>(y) * g.sx);
+	const uint32_t wi = y * g.row_words + (x >> 5);
+	const uint32_t run = r.word_base[zi * g.plane_words + wi] + __popc(g.breaks(zi, y, x >> 5) & mask_le(x & 31u)) - 1u;
+	if (run >= r.nruns[zi]) return;
+	const uint32_t cc = r.run_cc[r.rbase[zi] + run];
+	if (cc < ncomp_expect[zi]) label_map[comp_off[zi] + cc] = pin_label[j];
+}
+
+// run -> label, typed like the output (has_label: 1 where the label matches).
+// grid = (ceil(max runs / 256), nslices)
+template <typename OUT>
+__global__ void __launch_bounds__(kBlock) k_run_labels(
+	RunArrays r, const uint64_t* __restrict__ label_map, const uint64_t* __restrict__ comp_off,
+	const uint32_t* __restrict__ ncomp_expect, uint32_t has_label, uint64_t label, OUT* __restrict__ run_label
+) {
+	const uint32_t zi = blockIdx.y;
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= r.nruns[zi]) return;
+	const uint32_t cc = r.run_cc[r.rbase[zi] + i];
+	uint64_t v = 0;
+	if (cc < ncomp_expect[zi]) v = label_map[comp_off[zi] + cc];
+	else atomicOr(r.slice_err + zi, ERR_NCOMP);
+	if (has_label) v = (v == label);
+	run_label[r.rbase[zi] + i] = static_cast<OUT>(v);
 }
 
 // ------------------------------------------------------------------------------
-// paint + crc32c of the component image
+// paint (crackle.hpp:617-656): out[p] = label of p's run
 // ------------------------------------------------------------------------------
-struct PaintArgs {
-	const uint32_t* L;
-	const uint32_t* R;
-	const uint64_t* label_map;
-	const uint64_t* comp_off;     // [nslices] first label_map entry of each slice
-	const uint32_t* ncomp;        // [nslices] computed component counts
-	const uint32_t* crc_stride_tab;  // [4][256] multiply by x^(32*256)
-	const uint32_t* crc_lane_pow;    // [256] x^(32*(256-j))
-	const uint32_t* crc_tile_pow;    // [tiles] x^(32*kCrcTile*(tiles-1-t))
-	uint32_t* crc_acc;            // [nslices]
-	uint32_t* slice_err;
-	void* out;
-	uint64_t sxy;
-	uint32_t sx, sy;
-	uint32_t tiles;               // crc tiles per slice
-	uint32_t pad;                 // virtual zero words in front of each slice
-	uint32_t nslices;
-	uint32_t fortran_order;
-	uint32_t has_label;
-	uint64_t label;
-};
+constexpr uint32_t kPaintTile = 4096;          // pixels per workgroup
+constexpr uint32_t kPaintStage = 3072;         // run labels staged in LDS per workgroup
 
-template <typename OUT>
-__global__ void __launch_bounds__(kBlock) k_paint(PaintArgs a) {
-	__shared__ uint32_t s_tab[1024];
-	__shared__ uint32_t s_red[kWaves];
+template <typename OUT> struct Vec4;
+template <> struct Vec4<uint8_t> { typedef uchar4 type; };
+template <> struct Vec4<uint16_t> { typedef ushort4 type; };
+template <> struct Vec4<uint32_t> { typedef uint4 type; };
+template <> struct Vec4<uint64_t> { typedef ulonglong4 type; };
+
+// FAST: sx % 4 == 0 and x-fastest output: a thread paints 4 consecutive pixels of one
+// plane word per step and stores them as one vector.  grid = (ceil(sxy / 4096), nslices)
+template <typename OUT, bool FAST>
+__global__ void __launch_bounds__(kBlock) k_paint_runs(
+	RunGeom g, RunArrays r, const OUT* __restrict__ run_label, OUT* __restrict__ out,
+	uint64_t sxy, uint32_t nslices, uint32_t fortran_order
+) {
+	__shared__ OUT s_lab[kPaintStage];
+	__shared__ uint32_t s_lo, s_hi;
 	const uint32_t zi = blockIdx.y;
-	const uint32_t t = blockIdx.x;
-	for (int i = threadIdx.x; i < 1024; i += kBlock) s_tab[i] = a.crc_stride_tab[i];
+	const uint64_t p_lo = static_cast<uint64_t>(blockIdx.x) * kPaintTile;
+	const uint64_t p_hi = (p_lo + kPaintTile < sxy ? p_lo + kPaintTile : sxy) - 1;   // last pixel of the tile
+	const uint32_t* wb = r.word_base + zi * g.plane_words;
+	const OUT* lab = run_label + r.rbase[zi];
+	const uint32_t nruns = r.nruns[zi];
+	auto run_of = [&](uint64_t p) {
+		const uint32_t y = static_cast<uint32_t>(p / g.sx);
+		const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
+		return wb[y * g.row_words + (x >> 5)] + __popc(g.breaks(zi, y, x >> 5) & mask_le(x & 31u)) - 1u;
+	};
+	if (threadIdx.x == 0) s_lo = run_of(p_lo);
+	if (threadIdx.x == 1) s_hi = run_of(p_hi);
 	__syncthreads();
-	const uint32_t* Lz = a.L + zi * a.sxy;
-	const uint32_t* Rz = a.R + zi * a.sxy;
-	const uint64_t* lm = a.label_map + a.comp_off[zi];
-	const uint32_t nc = a.ncomp[zi];
-	OUT* out = reinterpret_cast<OUT*>(a.out);
-	uint32_t acc = 0;
-	uint32_t bad = 0;
+	const uint32_t lo = s_lo, hi = s_hi;
+	const bool staged = (hi - lo) < kPaintStage && hi < nruns;
+	if (staged) {
+		for (uint32_t i = threadIdx.x; i <= hi - lo; i += kBlock) s_lab[i] = lab[lo + i];
+	}
+	__syncthreads();
+	auto label_of = [&](uint32_t run) -> OUT {
+		if (staged) return s_lab[run - lo];
+		return run < nruns ? lab[run] : static_cast<OUT>(0);
+	};
+	if (FAST) {
+		typedef typename Vec4<OUT>::type V4;
+		OUT* oz = out + static_cast<uint64_t>(zi) * sxy;
 #pragma unroll
-	for (int i = 0; i < kCrcRows; i++) {
-		const uint64_t kp = static_cast<uint64_t>(t) * kCrcTile + i * kBlock + threadIdx.x;
-		uint32_t word = 0;
-		if (kp >= a.pad) {
-			const uint64_t p = kp - a.pad;   // < sxy by construction of tiles/pad
-			const uint32_t cc = Rz[Lz[p]];
-			word = cc;
-			uint64_t v = 0;
-			if (cc < nc) v = lm[cc]; else bad = 1;
-			if (a.has_label) v = (v == a.label);
-			if (a.fortran_order) {
-				out[static_cast<uint64_t>(zi) * a.sxy + p] = static_cast<OUT>(v);
-			}
-			else {
-				const uint32_t y = static_cast<uint32_t>(p / a.sx);
-				const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * a.sx);
-				out[zi + static_cast<uint64_t>(a.nslices) * (y + static_cast<uint64_t>(a.sy) * x)] = static_cast<OUT>(v);
-			}
+		for (uint32_t it = 0; it < kPaintTile / (kBlock * 4); it++) {
+			const uint64_t p = p_lo + it * (kBlock * 4) + threadIdx.x * 4u;
+			if (p >= sxy) break;
+			const uint32_t y = static_cast<uint32_t>(p / g.sx);
+			const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
+			const uint32_t bw = g.breaks(zi, y, x >> 5);
+			const uint32_t sh = x & 31u;
+			uint32_t run = wb[y * g.row_words + (x >> 5)] + __popc(bw & mask_le(sh)) - 1u;
+			const uint32_t nib = (bw >> sh) >> 1;      // break flags of pixels x+1 .. x+3
+			V4 v;
+			v.x = label_of(run);
+			run += nib & 1u;        v.y = label_of(run);
+			run += (nib >> 1) & 1u; v.z = label_of(run);
+			run += (nib >> 2) & 1u; v.w = label_of(run);
+			*reinterpret_cast<V4*>(oz + p) = v;
 		}
-		acc = crc_stride_step(s_tab, acc) ^ word;
 	}
-	uint32_t val = gf_mul(acc, a.crc_lane_pow[threadIdx.x]);
-	val = block_xor(val, s_red);
-	if (threadIdx.x == 0) {
-		atomicXor(a.crc_acc + zi, gf_mul(val, a.crc_tile_pow[t]));
+	else {
+		for (uint32_t i = threadIdx.x; i < kPaintTile; i += kBlock) {
+			const uint64_t p = p_lo + i;
+			if (p >= sxy) break;
+			const uint32_t y = static_cast<uint32_t>(p / g.sx);
+			const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
+			const OUT v = label_of(run_of(p));
+			if (fortran_order) out[static_cast<uint64_t>(zi) * sxy + p] = v;
+			else out[zi + static_cast<uint64_t>(nslices) * (y + static_cast<uint64_t>(g.sy) * x)] = v;
+		}
 	}
-	if (bad) atomicOr(a.slice_err + zi, ERR_NCOMP);
 }
 
 // compares the accumulated raw crc with the stored per-slice crc32c and the computed
@@ -520,13 +854,14 @@ __global__ void __launch_bounds__(kBlock) k_paint(PaintArgs a) {
 __global__ void __launch_bounds__(kBlock) k_check(
 	const uint32_t* __restrict__ crc_acc, const uint32_t* __restrict__ crc_expect_raw,
 	const uint32_t* __restrict__ ncomp, const uint32_t* __restrict__ ncomp_expect,
-	uint32_t check_crc, uint32_t check_ncomp, uint32_t nslices, uint32_t* __restrict__ slice_err
+	uint32_t check_crc, uint32_t crc_fix, uint32_t nslices, uint32_t* __restrict__ slice_err
 ) {
 	const uint32_t zi = blockIdx.x * kBlock + threadIdx.x;
 	if (zi >= nslices) return;
 	uint32_t e = 0;
-	if (check_crc && crc_acc[zi] != crc_expect_raw[zi]) e |= ERR_CRC;
-	if (check_ncomp && ncomp[zi] != ncomp_expect[zi]) e |= ERR_NCOMP;
+	if (ncomp[zi] != ncomp_expect[zi]) e |= ERR_NCOMP;
+	// crc_acc holds the raw crc divided by x^(32 - idbits): multiply it back
+	else if (check_crc && gf_mul(crc_acc[zi], crc_fix) != crc_expect_raw[zi]) e |= ERR_CRC;
 	if (e) atomicOr(slice_err + zi, e);
 }
 
@@ -537,14 +872,21 @@ __global__ void __launch_bounds__(kBlock) k_check(
 // ------------------------------------------------------------------------------
 using namespace ckl;
 
+namespace {
+constexpr int kMaxStages = 12;
+}
+
 struct ckl_decoder {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
-	float pipeline_ms = 0.f, dominant_ms = 0.f;
+	// stage boundaries: ev[i] .. ev[i+1] brackets stage i of the last run
+	hipEvent_t ev[kMaxStages + 1] = {};
+	const char* stage_name[kMaxStages] = {};
+	float stage_ms[kMaxStages] = {};
+	int n_stages = 0;
+	float pipeline_ms = 0.f;
 
 	Header head;
-	std::vector<uint8_t> host_stream;   // only the parts the host parses are kept: header+z-index+labels
 	uint64_t n_bytes = 0;
 	int64_t z_start = 0, z_end = 0;
 	uint32_t nslices = 0;
@@ -552,13 +894,14 @@ struct ckl_decoder {
 
 	// device residents
 	DevBuf<uint8_t> d_stream;
-	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off;
-	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap;
+	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off, d_rbase;
+	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap, d_rcap;
 	DevBuf<uint8_t> d_model, d_ucode, d_sym_kind;
 	DevBuf<uint32_t> d_sym_pos, d_sym_seg, d_ctl_sym, d_seg_off, d_stack, d_nodes;
 	DevBuf<uint32_t> d_planes;          // V then H
-	DevBuf<uint32_t> d_L, d_R, d_tile_count, d_ncomp, d_ncomp_expect;
-	DevBuf<uint32_t> d_crc_tab, d_crc_lane_pow, d_crc_tile_pow, d_crc_acc, d_crc_expect, d_slice_err;
+	DevBuf<uint32_t> d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_ncomp_expect;
+	DevBuf<uint64_t> d_run_label;       // typed on use (1..8 bytes per run)
+	DevBuf<uint32_t> d_G, d_crc_acc, d_crc_expect, d_slice_err;
 	DevBuf<uint64_t> d_label_map;
 	DevBuf<uint64_t> d_pin_index, d_pin_depth, d_pin_label, d_pin_work_off, d_ccl_id, d_ccl_label;
 
@@ -572,14 +915,12 @@ struct ckl_decoder {
 
 	uint32_t row_words = 0;
 	uint64_t plane_words = 0;
-	uint32_t ccl_tiles = 0, crc_tiles = 0, crc_pad = 0;
+	uint32_t max_rcap = 0;
+	uint32_t idbits = 1, crc_fix = 0;
 	bool check_crc = true;
 
 	~ckl_decoder() {
-		if (ev0) (void)hipEventDestroy(ev0);
-		if (ev1) (void)hipEventDestroy(ev1);
-		if (evk0) (void)hipEventDestroy(evk0);
-		if (evk1) (void)hipEventDestroy(evk1);
+		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
 		if (stream) (void)hipStreamDestroy(stream);
 	}
 };
@@ -640,31 +981,38 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	CKL_HIP(hipMemcpyAsync(d.d_stream.p, buf, n, hipMemcpyHostToDevice, s));
 
 	// per-slice descriptors and scratch layout
-	const int xw = byte_width(static_cast<uint64_t>(h.sx) + 1), yw = byte_width(static_cast<uint64_t>(h.sy) + 1);
-	std::vector<uint64_t> code_off(d.nslices), cbase(d.nslices), nbase(d.nslices);
-	std::vector<uint32_t> code_len(d.nslices), ccap(d.nslices), ncap(d.nslices);
-	uint64_t ctot = 0, ntot = 0;
+	const int xw = byte_width(static_cast<uint64_t>(h.sx) + 1);
+	const bool permissible = h.crack_format == PERMISSIBLE;
+	std::vector<uint64_t> code_off(d.nslices), cbase(d.nslices), nbase(d.nslices), rbase(d.nslices);
+	std::vector<uint32_t> code_len(d.nslices), ccap(d.nslices), ncap(d.nslices), rcap(d.nslices);
+	uint64_t ctot = 0, ntot = 0, rtot = 0;
+	d.max_rcap = 0;
 	for (uint32_t zi = 0; zi < d.nslices; zi++) {
 		const uint64_t z = static_cast<uint64_t>(zs) + zi;
 		const uint64_t len = z_index[z + 1] - z_index[z];
 		if (len > 0xFFFFFFF0ull / 8) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack code of a slice is too large");
 		code_off[zi] = z_index[z];
 		code_len[zi] = static_cast<uint32_t>(len);
-		uint64_t index_size = len >= 4 ? rd_le(buf + z_index[z], 4) : 0;
-		uint64_t payload = (len >= 4 + index_size) ? len - 4 - index_size : 0;
+		const uint64_t index_size = len >= 4 ? rd_le(buf + z_index[z], 4) : 0;
+		const uint64_t payload = (len >= 4 + index_size) ? len - 4 - index_size : 0;
 		// codes: 4 per byte (plain) or at most 8 per byte (+1 raw) for the markov bitstream
-		uint64_t cap = (h.markov_model_order ? payload * 8 + 1 : payload * 4) + 2;
-		uint64_t nodes_cap = std::min<uint64_t>(index_size, len) / xw + 1;
+		const uint64_t cap = (h.markov_model_order ? payload * 8 + 1 : payload * 4) + 2;
+		const uint64_t nodes_cap = std::min<uint64_t>(index_size, len) / xw + 1;
+		// runs: one per row plus one per vertical crack move (IMPERMISSIBLE), else up to one per pixel
+		const uint64_t runs_cap = permissible ? d.sxy : std::min<uint64_t>(d.sxy, static_cast<uint64_t>(h.sy) + cap);
 		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cap); ctot += cap;
 		nbase[zi] = ntot; ncap[zi] = static_cast<uint32_t>(nodes_cap); ntot += nodes_cap;
+		rbase[zi] = rtot; rcap[zi] = static_cast<uint32_t>(runs_cap); rtot += runs_cap;
+		d.max_rcap = std::max<uint32_t>(d.max_rcap, static_cast<uint32_t>(runs_cap));
 	}
-	(void)yw;
 	upload(d.d_code_off, code_off, s);
 	upload(d.d_code_len, code_len, s);
 	upload(d.d_cbase, cbase, s);
 	upload(d.d_ccap, ccap, s);
 	upload(d.d_nbase, nbase, s);
 	upload(d.d_ncap, ncap, s);
+	upload(d.d_rbase, rbase, s);
+	upload(d.d_rcap, rcap, s);
 	if (h.markov_model_order) d.d_ucode.ensure(ctot);
 	d.d_sym_kind.ensure(ctot);
 	d.d_sym_pos.ensure(ctot);
@@ -673,52 +1021,24 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	d.d_seg_off.ensure(ctot);
 	d.d_stack.ensure(ctot);
 	d.d_nodes.ensure(ntot);
+	d.d_parent.ensure(rtot);
+	d.d_run_start.ensure(rtot);
+	d.d_run_cc.ensure(rtot);
+	d.d_run_label.ensure(rtot);
 
 	if (h.markov_model_order) {
 		std::vector<uint8_t> model = markov_model_from_stored(buf + hb + gib + h.num_label_bytes, h.markov_model_bytes(), h.markov_model_order);
 		upload(d.d_model, model, s);
 	}
 
-	// planes, CCL arrays
 	d.row_words = (h.sx + 31) / 32;
 	d.plane_words = static_cast<uint64_t>(d.row_words) * h.sy;
 	d.d_planes.ensure(2 * d.plane_words * d.nslices);
-	d.d_L.ensure(d.sxy * d.nslices);
-	d.d_R.ensure(d.sxy * d.nslices);
-	d.ccl_tiles = static_cast<uint32_t>((d.sxy + kCclTile - 1) / kCclTile);
-	d.d_tile_count.ensure(static_cast<size_t>(d.ccl_tiles) * d.nslices);
+	d.d_word_base.ensure(d.plane_words * d.nslices);
+	d.d_nruns.ensure(d.nslices);
 	d.d_ncomp.ensure(d.nslices);
 	d.d_slice_err.ensure(d.nslices);
 	d.d_crc_acc.ensure(d.nslices);
-
-	// crc machinery: multiply-by-x^(32*256) tables, per-lane and per-tile powers
-	d.crc_tiles = static_cast<uint32_t>((d.sxy + kCrcTile - 1) / kCrcTile);
-	d.crc_pad = static_cast<uint32_t>(static_cast<uint64_t>(d.crc_tiles) * kCrcTile - d.sxy);
-	{
-		std::vector<uint32_t> tab(1024), lane_pow(kBlock), tile_pow(d.crc_tiles);
-		const uint32_t M = gf_xpow(32ull * kBlock);
-		for (int k = 0; k < 4; k++)
-			for (uint32_t b = 0; b < 256; b++) tab[k * 256 + b] = gf_mul(b << (8 * k), M);
-		for (int j = 0; j < kBlock; j++) lane_pow[j] = gf_xpow(32ull * (kBlock - j));
-		const uint32_t T = gf_xpow(32ull * kCrcTile);
-		uint32_t acc = 0x80000000u;   // x^0
-		for (uint32_t t = d.crc_tiles; t-- > 0;) { tile_pow[t] = acc; acc = gf_mul(acc, T); }
-		upload(d.d_crc_tab, tab, s);
-		upload(d.d_crc_lane_pow, lane_pow, s);
-		upload(d.d_crc_tile_pow, tile_pow, s);
-	}
-	d.check_crc = h.format_version > 0;
-	if (d.check_crc) {
-		// stored = ~(x^(32 n) * 0xFFFFFFFF ^ raw)  =>  raw = ~stored ^ init_term
-		const uint32_t init_term = gf_mul(0xFFFFFFFFu, gf_xpow(32ull * d.sxy));
-		std::vector<uint32_t> expect(d.nslices);
-		const uint8_t* crcs = buf + n - 4ull * h.sz;
-		for (uint32_t zi = 0; zi < d.nslices; zi++) {
-			const uint32_t stored = static_cast<uint32_t>(rd_le(crcs + 4ull * (zs + zi), 4));
-			expect[zi] = (~stored) ^ init_term;
-		}
-		upload(d.d_crc_expect, expect, s);
-	}
 
 	// label section layout (labels.hpp:424-451, 453-617), parsed once
 	const uint8_t* lb = buf + hb + gib;
@@ -754,15 +1074,58 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	d.total_comp = comp_prefix[ze] - comp_prefix[zs];
 	std::vector<uint64_t> comp_off(d.nslices);
 	std::vector<uint32_t> ncomp_expect(d.nslices);
+	uint32_t max_comp = 1;
 	for (uint32_t zi = 0; zi < d.nslices; zi++) {
 		comp_off[zi] = comp_prefix[zs + zi] - comp_prefix[zs];
 		const uint64_t c = comp_prefix[zs + zi + 1] - comp_prefix[zs + zi];
 		if (c > d.sxy) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
 		ncomp_expect[zi] = static_cast<uint32_t>(c);
+		max_comp = std::max<uint32_t>(max_comp, static_cast<uint32_t>(c));
 	}
 	upload(d.d_comp_off, comp_off, s);
 	upload(d.d_ncomp_expect, ncomp_expect, s);
 	d.d_label_map.ensure(d.total_comp + 1);
+
+	// crc machinery: geometric-sum table G[m] = x^32 + ... + x^(32 m), component ids are
+	// multiplied in over their `idbits` significant bits only (see k_run_resolve)
+	d.check_crc = h.format_version > 0;
+	d.idbits = 1;
+	while (d.idbits < 32 && (1ull << d.idbits) < max_comp) d.idbits++;
+	d.crc_fix = gf_xpow(32 - d.idbits);
+	{
+		const uint32_t npx = static_cast<uint32_t>(d.sxy);
+		const uint32_t B = 1024, nblk = npx / B + 1;
+		std::vector<uint32_t> g_base(B), blk_g(nblk), blk_x(nblk);
+		const uint32_t X = gf_xpow(32);
+		g_base[0] = 0;
+		for (uint32_t i = 1; i < B; i++) g_base[i] = gf_mul(X, g_base[i - 1] ^ 0x80000000u);
+		const uint32_t gB = gf_mul(X, g_base[B - 1] ^ 0x80000000u);   // G[B]
+		const uint32_t XB = gf_xpow(32ull * B);
+		blk_g[0] = 0; blk_x[0] = 0x80000000u;
+		for (uint32_t k = 1; k < nblk; k++) {
+			blk_g[k] = blk_g[k - 1] ^ gf_mul(blk_x[k - 1], gB);
+			blk_x[k] = gf_mul(blk_x[k - 1], XB);
+		}
+		DevBuf<uint32_t> t_base, t_g, t_x;
+		upload(t_base, g_base, s); upload(t_g, blk_g, s); upload(t_x, blk_x, s);
+		d.d_G.ensure(static_cast<size_t>(npx) + 1);
+		hipLaunchKernelGGL(k_build_geom_table, dim3(npx / kBlock + 1), dim3(kBlock), 0, s, t_base.p, t_g.p, t_x.p, npx, d.d_G.p);
+		CKL_HIP(hipStreamSynchronize(s));
+	}
+	if (d.check_crc) {
+		// stored = ~(x^(32 n) * 0xFFFFFFFF ^ raw)  =>  raw = ~stored ^ init_term
+		const uint32_t init_term = gf_mul(0xFFFFFFFFu, gf_xpow(32ull * d.sxy));
+		std::vector<uint32_t> expect(d.nslices);
+		const uint8_t* crcs = buf + n - 4ull * h.sz;
+		for (uint32_t zi = 0; zi < d.nslices; zi++) {
+			const uint32_t stored = static_cast<uint32_t>(rd_le(crcs + 4ull * (zs + zi), 4));
+			expect[zi] = (~stored) ^ init_term;
+		}
+		upload(d.d_crc_expect, expect, s);
+	}
+	else {
+		d.d_crc_expect.ensure(d.nslices);
+	}
 
 	if (h.label_format == FLAT) {
 		d.key_width = byte_width(d.num_unique);
@@ -816,9 +1179,33 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	CKL_HIP(hipStreamSynchronize(s));   // host vectors above go out of scope
 }
 
+struct StageTimer {
+	ckl_decoder& d;
+	hipStream_t s;
+	int i = 0;
+	StageTimer(ckl_decoder& dec, hipStream_t st) : d(dec), s(st) { CKL_HIP(hipEventRecord(d.ev[0], s)); }
+	void done(const char* name) {
+		if (i >= kMaxStages) return;
+		d.stage_name[i] = name;
+		CKL_HIP(hipEventRecord(d.ev[i + 1], s));
+		i++;
+	}
+};
+
 template <typename OUT>
-void launch_paint(const PaintArgs& pa, uint32_t tiles, uint32_t nslices, hipStream_t s) {
-	hipLaunchKernelGGL(k_paint<OUT>, dim3(tiles, nslices), dim3(kBlock), 0, s, pa);
+void launch_labels_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays& ra, void* out_device, int has_label, uint64_t label, StageTimer& st) {
+	const Header& h = d.head;
+	hipStream_t s = d.stream;
+	const uint32_t ns = d.nslices;
+	OUT* run_label = reinterpret_cast<OUT*>(d.d_run_label.p);
+	hipLaunchKernelGGL(k_run_labels<OUT>, dim3((d.max_rcap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s,
+		ra, d.d_label_map.p, d.d_comp_off.p, d.d_ncomp_expect.p, has_label ? 1u : 0u, label, run_label);
+	st.done("k_run_labels");
+	const uint32_t tiles = static_cast<uint32_t>((d.sxy + kPaintTile - 1) / kPaintTile);
+	const bool fast = h.fortran_order && (h.sx % 4 == 0);
+	if (fast) hipLaunchKernelGGL((k_paint_runs<OUT, true>), dim3(tiles, ns), dim3(kBlock), 0, s, g, ra, run_label, reinterpret_cast<OUT*>(out_device), d.sxy, ns, 1u);
+	else hipLaunchKernelGGL((k_paint_runs<OUT, false>), dim3(tiles, ns), dim3(kBlock), 0, s, g, ra, run_label, reinterpret_cast<OUT*>(out_device), d.sxy, ns, h.fortran_order ? 1u : 0u);
+	st.done("k_paint_runs");
 }
 
 void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label) {
@@ -830,10 +1217,10 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 
-	CKL_HIP(hipEventRecord(d.ev0, s));
+	StageTimer st(d, s);
 	CKL_HIP(hipMemsetAsync(d.d_planes.p, 0, 2 * d.plane_words * ns * sizeof(uint32_t), s));
 	CKL_HIP(hipMemsetAsync(d.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
-	CKL_HIP(hipMemsetAsync(d.d_crc_acc.p, 0, ns * sizeof(uint32_t), s));
+	st.done("memset planes");
 
 	CrackArgs ca;
 	ca.stream = d.d_stream.p;
@@ -849,17 +1236,23 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.row_words = d.row_words; ca.plane_words = d.plane_words;
 	ca.slice_err = d.d_slice_err.p;
 	hipLaunchKernelGGL(k_decode_cracks, dim3(ns), dim3(kBlock), 0, s, ca);
+	st.done("k_decode_cracks");
 
-	PlaneConn conn;
-	conn.planeV = ca.planeV; conn.planeH = ca.planeH;
-	conn.row_words = d.row_words; conn.plane_words = d.plane_words;
-	conn.flip = (h.crack_format == IMPERMISSIBLE) ? 1u : 0u;
-	const int sx = static_cast<int>(h.sx), sy = static_cast<int>(h.sy);
-	hipLaunchKernelGGL(k_ccl_rows<PlaneConn>, dim3(h.sy, ns), dim3(kBlock), 0, s, conn, d.d_L.p, sx, sy);
-	hipLaunchKernelGGL(k_ccl_merge<PlaneConn>, dim3(d.ccl_tiles, ns), dim3(kBlock), 0, s, conn, d.d_L.p, sx, sy);
-	hipLaunchKernelGGL(k_ccl_flatten, dim3(d.ccl_tiles, ns), dim3(kBlock), 0, s, d.d_L.p, d.d_tile_count.p, d.sxy, d.ccl_tiles);
-	hipLaunchKernelGGL(k_ccl_scan, dim3(ns), dim3(kBlock), 0, s, d.d_tile_count.p, d.d_ncomp.p, d.ccl_tiles);
-	hipLaunchKernelGGL(k_ccl_rank, dim3(d.ccl_tiles, ns), dim3(kBlock), 0, s, d.d_L.p, d.d_R.p, d.d_tile_count.p, d.sxy, d.ccl_tiles);
+	RunGeom g;
+	g.planeV = ca.planeV; g.planeH = ca.planeH; g.row_words = d.row_words; g.plane_words = d.plane_words;
+	g.flip = (h.crack_format == IMPERMISSIBLE) ? 1u : 0u;
+	g.sx = h.sx; g.sy = h.sy;
+	RunArrays ra;
+	ra.word_base = d.d_word_base.p; ra.rbase = d.d_rbase.p; ra.rcap = d.d_rcap.p;
+	ra.parent = d.d_parent.p; ra.run_start = d.d_run_start.p; ra.run_cc = d.d_run_cc.p;
+	ra.nruns = d.d_nruns.p; ra.ncomp = d.d_ncomp.p; ra.slice_err = d.d_slice_err.p;
+
+	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kBlock), 0, s, g, ra);
+	st.done("k_run_index");
+	hipLaunchKernelGGL(k_run_union, dim3(static_cast<uint32_t>((d.plane_words + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s, g, ra);
+	st.done("k_run_union");
+	hipLaunchKernelGGL(k_run_resolve, dim3(ns), dim3(kBlock), 0, s, ra, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p);
+	st.done("k_run_resolve");
 
 	// component -> label
 	const uint64_t nlm = d.total_comp;
@@ -877,43 +1270,34 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 			d.d_ccl_id.p, d.d_ccl_label.p, d.n_ccl, d.comp_left, d.comp_left + nlm, d.d_label_map.p);
 		if (d.pin_total_work) hipLaunchKernelGGL(k_label_map_pins, dim3(static_cast<uint32_t>((d.pin_total_work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
 			d.d_pin_index.p, d.d_pin_depth.p, d.d_pin_label.p, d.d_pin_work_off.p, d.n_pins, d.pin_total_work,
-			d.d_L.p, d.d_R.p, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp.p, d.d_label_map.p);
+			g, ra, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp_expect.p, d.d_label_map.p);
 	}
+	st.done("k_label_map");
 
-	PaintArgs pa;
-	pa.L = d.d_L.p; pa.R = d.d_R.p; pa.label_map = d.d_label_map.p; pa.comp_off = d.d_comp_off.p; pa.ncomp = d.d_ncomp.p;
-	pa.crc_stride_tab = d.d_crc_tab.p; pa.crc_lane_pow = d.d_crc_lane_pow.p; pa.crc_tile_pow = d.d_crc_tile_pow.p;
-	pa.crc_acc = d.d_crc_acc.p; pa.slice_err = d.d_slice_err.p;
-	pa.out = out_device; pa.sxy = d.sxy; pa.sx = h.sx; pa.sy = h.sy;
-	pa.tiles = d.crc_tiles; pa.pad = d.crc_pad; pa.nslices = ns;
-	pa.fortran_order = h.fortran_order ? 1u : 0u;
-	pa.has_label = has_label ? 1u : 0u; pa.label = label;
-	CKL_HIP(hipEventRecord(d.evk0, s));
-	if (has_label) launch_paint<uint8_t>(pa, d.crc_tiles, ns, s);
-	else if (h.data_width == 1) launch_paint<uint8_t>(pa, d.crc_tiles, ns, s);
-	else if (h.data_width == 2) launch_paint<uint16_t>(pa, d.crc_tiles, ns, s);
-	else if (h.data_width == 4) launch_paint<uint32_t>(pa, d.crc_tiles, ns, s);
-	else launch_paint<uint64_t>(pa, d.crc_tiles, ns, s);
-	CKL_HIP(hipEventRecord(d.evk1, s));
+	if (has_label || h.data_width == 1) launch_labels_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
+	else if (h.data_width == 2) launch_labels_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
+	else if (h.data_width == 4) launch_labels_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
+	else launch_labels_and_paint<uint64_t>(d, g, ra, out_device, has_label, label, st);
 
 	hipLaunchKernelGGL(k_check, dim3((ns + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
 		d.d_crc_acc.p, d.d_crc_expect.p, d.d_ncomp.p, d.d_ncomp_expect.p,
-		d.check_crc ? 1u : 0u, 1u, ns, d.d_slice_err.p);
-	CKL_HIP(hipEventRecord(d.ev1, s));
+		d.check_crc ? 1u : 0u, d.crc_fix, ns, d.d_slice_err.p);
+	st.done("k_check");
+	d.n_stages = st.i;
 
 	std::vector<uint32_t> errs(ns);
 	CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	CKL_HIP(hipStreamSynchronize(s));
 	CKL_HIP(hipGetLastError());
-	CKL_HIP(hipEventElapsedTime(&d.pipeline_ms, d.ev0, d.ev1));
-	CKL_HIP(hipEventElapsedTime(&d.dominant_ms, d.evk0, d.evk1));
+	CKL_HIP(hipEventElapsedTime(&d.pipeline_ms, d.ev[0], d.ev[d.n_stages]));
+	for (int i = 0; i < d.n_stages; i++) CKL_HIP(hipEventElapsedTime(&d.stage_ms[i], d.ev[i], d.ev[i + 1]));
 	for (uint32_t zi = 0; zi < ns; zi++) {
 		const uint32_t e = errs[zi];
 		if (!e) continue;
 		const std::string z = std::to_string(d.z_start + zi);
 		if (e & (ERR_BOC | ERR_RANGE | ERR_CAPACITY)) throw Error(CKL_ERR_RUNTIME, "crackle: crack code is malformed or corrupted on z=" + z);
-		if (e & ERR_CRC) throw Error(CKL_ERR_CRC, "crackle: crack code crc mismatch on z=" + z);
-		throw Error(CKL_ERR_RUNTIME, "crackle: component count does not match the label section on z=" + z);
+		if (e & ERR_NCOMP) throw Error(CKL_ERR_RUNTIME, "crackle: component count does not match the label section on z=" + z);
+		throw Error(CKL_ERR_CRC, "crackle: crack code crc mismatch on z=" + z);
 	}
 }
 
@@ -931,10 +1315,7 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 		std::unique_ptr<ckl_decoder> d(new ckl_decoder());
 		d->device = device;
 		CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-		CKL_HIP(hipEventCreate(&d->ev0));
-		CKL_HIP(hipEventCreate(&d->ev1));
-		CKL_HIP(hipEventCreate(&d->evk0));
-		CKL_HIP(hipEventCreate(&d->evk1));
+		for (auto& e : d->ev) CKL_HIP(hipEventCreate(&e));
 		decoder_build(*d, buf, n, z_start, z_end);
 		*out = d.release();
 		return CKL_OK;
@@ -956,8 +1337,17 @@ int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_byte
 
 int ckl_decoder_last_timing(const ckl_decoder* d, float* pipeline_ms, float* dominant_kernel_ms) {
 	if (!d) { set_last_error("crackle_amd: null decoder"); return CKL_ERR_ARG; }
+	float mx = 0.f;
+	for (int i = 0; i < d->n_stages; i++) mx = d->stage_ms[i] > mx ? d->stage_ms[i] : mx;
 	if (pipeline_ms) *pipeline_ms = d->pipeline_ms;
-	if (dominant_kernel_ms) *dominant_kernel_ms = d->dominant_ms;
+	if (dominant_kernel_ms) *dominant_kernel_ms = mx;
+	return CKL_OK;
+}
+
+int ckl_decoder_stage_timing(const ckl_decoder* d, int index, const char** name, float* ms) {
+	if (!d || index < 0 || index >= d->n_stages) { set_last_error("crackle_amd: stage index out of range"); return CKL_ERR_ARG; }
+	if (name) *name = d->stage_name[index];
+	if (ms) *ms = d->stage_ms[index];
 	return CKL_OK;
 }
 

@@ -84,6 +84,18 @@ class HipDecodeSession:
     self._L.ckl_decoder_last_timing(self._h, C.byref(p), C.byref(k))
     return p.value, k.value
 
+  def stages(self):
+    """[(stage name, ms)] of the last run, in launch order."""
+    out = []
+    i = 0
+    while True:
+      name, ms = C.c_char_p(), C.c_float()
+      if self._L.ckl_decoder_stage_timing(self._h, i, C.byref(name), C.byref(ms)) != _lib.CKL_OK:
+        break
+      out.append((name.value.decode(), ms.value))
+      i += 1
+    return out
+
   def close(self):
     if self._h:
       self._L.ckl_decoder_destroy(self._h)

@@ -118,6 +118,9 @@ int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_byte
 /* Elapsed device time of the last run, from HIP events recorded on the library's
  * own stream around (a) the whole pipeline and (b) the dominant kernel. */
 int ckl_decoder_last_timing(const ckl_decoder* d, float* pipeline_ms, float* dominant_kernel_ms);
+/* Name and elapsed milliseconds of stage `index` (0-based, in launch order) of the last
+ * run; CKL_ERR_ARG past the last stage.  `*name` points to a static string. */
+int ckl_decoder_stage_timing(const ckl_decoder* d, int index, const char** name, float* ms);
 void ckl_decoder_destroy(ckl_decoder* d);
 
 typedef struct ckl_encoder ckl_encoder;
