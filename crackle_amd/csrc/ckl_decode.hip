@@ -28,7 +28,7 @@
 //   k_paint_runs      streams the output: per 4 pixels one plane word, a popcount and a
 //                     look-up in an LDS-staged run->label table; 16-byte stores.
 #include "ckl_common.hpp"
-#include "ckl_ccl.hpp"
+#include "ckl_runs.hpp"
 
 #include <algorithm>
 #include <memory>
@@ -69,13 +69,6 @@ struct CrackArgs {
 	uint32_t* slice_err;         // [nslices] sticky error bits
 };
 
-enum : uint32_t {
-	ERR_BOC = 1u,          // beginning-of-chain index malformed
-	ERR_RANGE = 2u,        // a move left the vertex grid
-	ERR_CAPACITY = 4u,     // scratch capacity exceeded (cannot happen for well-formed sizes)
-	ERR_NCOMP = 8u,        // component count differs from the label section
-	ERR_CRC = 16u,         // crc32c of the component image differs from the stored one
-};
 
 __device__ __forceinline__ uint32_t rd_le_dev(const uint8_t* p, int w) {
 	uint32_t v = 0;
@@ -480,208 +473,6 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 	if (err) atomicOr(&s_err, err);
 	__syncthreads();
 	if (tid == 0 && s_err) atomicOr(a.slice_err + zi, s_err);
-}
-
-// ------------------------------------------------------------------------------
-// horizontal runs
-// ------------------------------------------------------------------------------
-// A run is a maximal stretch of horizontally connected pixels of one row.  Runs are
-// numbered in raster order of their first pixel; word_base[w] = number of runs that
-// start before 32-pixel word w of the slice, so the run of pixel (x, y) is
-//   word_base[y, x>>5] + popcount(breaks(y, x>>5) & bits <= (x & 31)) - 1.
-struct RunGeom {
-	const uint32_t* planeV;
-	const uint32_t* planeH;
-	uint32_t row_words;
-	uint64_t plane_words;
-	uint32_t flip;          // 1 for IMPERMISSIBLE (a crack bit is a break)
-	uint32_t sx, sy;
-	__device__ __forceinline__ uint32_t valid_mask(uint32_t w) const {
-		const uint32_t left = sx - w * 32u;
-		return left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
-	}
-	// bit x set: a run starts at pixel x of this word
-	__device__ __forceinline__ uint32_t breaks(uint32_t zi, uint32_t y, uint32_t w) const {
-		const uint32_t v = planeV[zi * plane_words + static_cast<uint64_t>(y) * row_words + w];
-		uint32_t b = flip ? v : ~v;
-		if (w == 0) b |= 1u;
-		return b & valid_mask(w);
-	}
-	// bit x set: pixel x is connected to the pixel above it
-	__device__ __forceinline__ uint32_t ups(uint32_t zi, uint32_t y, uint32_t w) const {
-		if (y == 0) return 0u;
-		const uint32_t h = planeH[zi * plane_words + static_cast<uint64_t>(y) * row_words + w];
-		return (flip ? ~h : h) & valid_mask(w);
-	}
-};
-__device__ __forceinline__ uint32_t mask_le(uint32_t bit) { return bit >= 31u ? 0xFFFFFFFFu : ((2u << bit) - 1u); }
-
-struct RunArrays {
-	uint32_t* word_base;       // [nslices][plane_words]
-	const uint64_t* rbase;     // per slice base into the run arrays
-	const uint32_t* rcap;
-	uint32_t* parent;          // union-find over runs (root = smallest run index)
-	uint32_t* run_start;       // first pixel of the run (slice-linear)
-	uint32_t* run_cc;          // component id of the run
-	uint32_t* nruns;           // [nslices]
-	uint32_t* ncomp;           // [nslices]
-	uint32_t* slice_err;
-};
-
-// grid = nslices
-__global__ void __launch_bounds__(kBlock) k_run_index(RunGeom g, RunArrays r) {
-	__shared__ uint32_t s_scan[kWaves];
-	const uint32_t zi = blockIdx.x;
-	uint32_t* wb = r.word_base + zi * g.plane_words;
-	uint32_t* parent = r.parent + r.rbase[zi];
-	uint32_t* run_start = r.run_start + r.rbase[zi];
-	const uint32_t cap = r.rcap[zi];
-	const uint32_t words = static_cast<uint32_t>(g.plane_words);
-	constexpr uint32_t kPer = 4;
-	uint32_t carry = 0, err = 0;
-	for (uint32_t w0 = 0; w0 < words; w0 += kBlock * kPer) {
-		uint32_t b[kPer], cnt = 0;
-#pragma unroll
-		for (uint32_t j = 0; j < kPer; j++) {
-			const uint32_t wi = w0 + threadIdx.x * kPer + j;
-			b[j] = 0;
-			if (wi < words) {
-				const uint32_t y = wi / g.row_words;
-				b[j] = g.breaks(zi, y, wi - y * g.row_words);
-			}
-			cnt += __popc(b[j]);
-		}
-		uint32_t v[1] = { cnt }, tot[1];
-		block_excl_add<1>(v, tot, s_scan);
-		uint32_t base = carry + v[0];
-#pragma unroll
-		for (uint32_t j = 0; j < kPer; j++) {
-			const uint32_t wi = w0 + threadIdx.x * kPer + j;
-			if (wi >= words) break;
-			wb[wi] = base;
-			const uint32_t y = wi / g.row_words;
-			const uint32_t x0 = (wi - y * g.row_words) * 32u;
-			for (uint32_t m = b[j]; m; m &= m - 1u) {
-				const uint32_t bit = __ffs(m) - 1;
-				if (base < cap) { run_start[base] = y * g.sx + x0 + bit; parent[base] = base; }
-				else err = ERR_CAPACITY;
-				base++;
-			}
-		}
-		carry += tot[0];
-	}
-	if (threadIdx.x == 0) r.nruns[zi] = carry < cap ? carry : cap;
-	if (err) atomicOr(r.slice_err + zi, err);
-}
-
-__device__ __forceinline__ uint32_t run_find(uint32_t* L, uint32_t a) {
-	// path halving; parents only ever decrease, so racing writers stay consistent
-	uint32_t p = uf_load(L, a);
-	while (p != a) {
-		const uint32_t gp = uf_load(L, p);
-		if (gp != p) atomicMin(L + a, gp);
-		a = p;
-		p = gp;
-	}
-	return a;
-}
-__device__ __forceinline__ void run_unite(uint32_t* L, uint32_t a, uint32_t b) {
-	for (;;) {
-		a = run_find(L, a);
-		b = run_find(L, b);
-		if (a == b) return;
-		if (a > b) { const uint32_t t = a; a = b; b = t; }
-		const uint32_t old = atomicMin(L + b, a);
-		if (old == b) return;
-		b = old;
-	}
-}
-
-// grid = (ceil(words / 256), nslices): one thread per 32-pixel word of rows y >= 1.
-// A union is issued at the first pixel of every stretch along which the pixel stays
-// up-connected and neither its own run nor the run above changes.
-__global__ void __launch_bounds__(kBlock) k_run_union(RunGeom g, RunArrays r) {
-	const uint32_t zi = blockIdx.y;
-	const uint32_t wi = blockIdx.x * kBlock + threadIdx.x;
-	if (wi >= g.plane_words) return;
-	const uint32_t y = wi / g.row_words;
-	if (y == 0) return;
-	const uint32_t w = wi - y * g.row_words;
-	const uint32_t up = g.ups(zi, y, w);
-	if (!up) return;
-	const uint32_t prev_bit = w ? (g.ups(zi, y, w - 1) >> 31) : 0u;
-	const uint32_t b_here = g.breaks(zi, y, w);
-	const uint32_t b_up = g.breaks(zi, y - 1, w);
-	uint32_t cand = up & (~((up << 1) | prev_bit) | b_here | b_up);
-	const uint32_t* wb = r.word_base + zi * g.plane_words;
-	const uint32_t base_here = wb[wi], base_up = wb[wi - g.row_words];
-	uint32_t* parent = r.parent + r.rbase[zi];
-	const uint32_t n = r.nruns[zi];
-	for (; cand; cand &= cand - 1u) {
-		const uint32_t bit = __ffs(cand) - 1;
-		const uint32_t m = mask_le(bit);
-		const uint32_t ra = base_here + __popc(b_here & m) - 1u;
-		const uint32_t rb = base_up + __popc(b_up & m) - 1u;
-		if (ra < n && rb < n) run_unite(parent, ra, rb);
-	}
-}
-
-// grid = nslices.  Phase 1: flatten, rank the roots in run order (= raster order of each
-// component's first pixel, cc3d.hpp:114-144).  Phase 2: component id of every run and the
-// raw crc32c of the component image: a run of id c covering pixels [a, b) of an n-pixel
-// slice contributes c * (G[n-a] ^ G[n-b]) with G[m] = x^32 + x^64 + ... + x^(32 m) mod P.
-// The multiplication walks only the `idbits` significant bits of c; the common factor
-// x^(32-idbits) is applied once per slice on the host side of the comparison.
-__global__ void __launch_bounds__(kBlock) k_run_resolve(RunArrays r, const uint32_t* __restrict__ G, uint32_t n_pixels, uint32_t idbits, uint32_t* __restrict__ crc_acc) {
-	__shared__ uint32_t s_scan[kWaves];
-	const uint32_t zi = blockIdx.x;
-	uint32_t* parent = r.parent + r.rbase[zi];
-	const uint32_t* run_start = r.run_start + r.rbase[zi];
-	uint32_t* run_cc = r.run_cc + r.rbase[zi];
-	const uint32_t n = r.nruns[zi];
-	uint32_t carry = 0;
-	for (uint32_t r0 = 0; r0 < n; r0 += kBlock) {
-		const uint32_t i = r0 + threadIdx.x;
-		uint32_t is_root = 0;
-		if (i < n) {
-			const uint32_t root = run_find(parent, i);
-			parent[i] = root;
-			is_root = (root == i);
-		}
-		uint32_t v[1] = { is_root }, tot[1];
-		block_excl_add<1>(v, tot, s_scan);
-		if (is_root) run_cc[i] = carry + v[0];
-		carry += tot[0];
-	}
-	if (threadIdx.x == 0) r.ncomp[zi] = carry;
-	__syncthreads();
-	__threadfence_block();
-	uint32_t acc = 0;
-	for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-		const uint32_t root = parent[i];
-		const uint32_t cc = run_cc[root];
-		if (root != i) run_cc[i] = cc;
-		const uint32_t a = run_start[i];
-		const uint32_t b = (i + 1 < n) ? run_start[i + 1] : n_pixels;
-		uint32_t wgt = G[n_pixels - a] ^ G[n_pixels - b];
-		// sum over set bits j < idbits of c:  wgt * x^(idbits-1-j)
-		uint32_t part = 0;
-		for (int j = static_cast<int>(idbits) - 1; j >= 0; j--) {
-			part ^= ((cc >> j) & 1u) ? wgt : 0u;
-			wgt = (wgt >> 1) ^ ((wgt & 1u) ? dev::kCrcPoly : 0u);
-		}
-		acc ^= part;
-	}
-	acc = block_xor(acc, s_scan);
-	if (threadIdx.x == 0) crc_acc[zi] = acc;
-}
-
-// G[k*B + i] = G[k*B] ^ x^(32 k B) * G[i]   (B = 1024; per-block constants from the host)
-__global__ void __launch_bounds__(kBlock) k_build_geom_table(const uint32_t* __restrict__ g_base, const uint32_t* __restrict__ blk_g, const uint32_t* __restrict__ blk_x, uint32_t n, uint32_t* __restrict__ G) {
-	const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
-	if (m > n) return;
-	const uint32_t k = m >> 10, i = m & 1023u;
-	G[m] = blk_g[k] ^ gf_mul(blk_x[k], g_base[i]);
 }
 
 // ------------------------------------------------------------------------------
@@ -1251,7 +1042,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	st.done("k_run_index");
 	hipLaunchKernelGGL(k_run_union, dim3(static_cast<uint32_t>((d.plane_words + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s, g, ra);
 	st.done("k_run_union");
-	hipLaunchKernelGGL(k_run_resolve, dim3(ns), dim3(kBlock), 0, s, ra, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p);
+	hipLaunchKernelGGL(k_run_resolve, dim3(ns), dim3(kBlock), 0, s, ra, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
 	st.done("k_run_resolve");
 
 	// component -> label

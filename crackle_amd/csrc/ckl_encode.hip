@@ -1,19 +1,20 @@
 // Encode path: label volume resident in HBM -> .ckl bytes.
 // Replaces crackle::compress<LABEL> (src/crackle.hpp:34-257) and what it calls:
 //   lib::max_label / pixel_pairs                    src/lib.hpp:224-256        k_stats
-//   crackcodes::Graph::init                         src/crackcodes.hpp:66-125  k_crack_graph
+//   crackcodes::Graph::init                         src/crackcodes.hpp:66-125  k_label_planes + k_crack_graph
 //   create_crack_codes walk + remove_initial_branch +
 //     remove_spurious_branches + symbols_to_codepoints
 //                                                   src/crackcodes.hpp:128-281, 374-453  k_walk
 //   pack_codepoints / write_boc_index               src/crackcodes.hpp:318-372, 455-496  k_finish
 //   markov::gather_statistics / encode_markov       src/markov.hpp:193-220, 422-473      k_markov_hist / k_markov_pack
-//   cc3d::connected_components2d_4 + relabel        src/cc3d.hpp:114-144, 257-369        ckl_ccl.hpp
-//   labels::encode_flat                             src/labels.hpp:30-155      k_cc_crc, k_mapping + host sort/unique
+//   cc3d::connected_components2d_4 + relabel        src/cc3d.hpp:114-144, 257-369        ckl_runs.hpp (runs of the label planes)
+//   labels::encode_flat                             src/labels.hpp:30-155      k_run_resolve (crc), k_mapping_runs + host sort/unique
 //   stream assembly                                 src/crackle.hpp:171-216    host
 #include "ckl_common.hpp"
-#include "ckl_ccl.hpp"
+#include "ckl_runs.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 
 namespace ckl {
@@ -50,34 +51,84 @@ __global__ void __launch_bounds__(kBlock) k_stats(const LABEL* __restrict__ labe
 }
 
 // ------------------------------------------------------------------------------
-// crack graph: one adjacency nibble per vertex of the (sx+1) x (sy+1) corner grid
-// bit0 -> right, bit1 -> left, bit2 -> down, bit3 -> up   (crackcodes.hpp:66-125)
-// grid = (ceil(nverts / 256), nslices)
+// label planes: one pass over the labels produces, per slice, two row-aligned bit
+// planes of "differs from the left neighbour" (V) and "differs from the upper
+// neighbour" (H).  Both the crack graph (crackcodes.hpp:66-125) and the 4-connected
+// components (cc3d.hpp:257-369) are derived from these 0.25 B/voxel instead of
+// re-reading the labels.  One wavefront per 64 pixels of a row: coalesced loads, the
+// left neighbour comes from a lane shuffle, the plane words from a ballot.
+// grid = (ceil(chunks_per_row * sy / 4), nslices), chunks_per_row = ceil(sx / 64)
 // ------------------------------------------------------------------------------
 template <typename LABEL>
-__global__ void __launch_bounds__(kBlock) k_crack_graph(
-	const LABEL* __restrict__ labels, int sx, int sy, uint32_t permissible,
-	uint8_t* __restrict__ adj, uint64_t adj_stride, uint32_t* __restrict__ deg_sum
+__global__ void __launch_bounds__(kBlock) k_label_planes(
+	const LABEL* __restrict__ labels, uint32_t sx, uint32_t sy, uint32_t chunks_per_row,
+	uint32_t* __restrict__ planeV, uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
+	uint32_t* __restrict__ count_v, uint32_t* __restrict__ count_h
 ) {
-	__shared__ uint32_t s_red[kWaves];
+	__shared__ uint32_t s_red[2 * kWaves];
+	const uint32_t zi = blockIdx.y;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t unit = blockIdx.x * kWaves + wave;
+	uint32_t nv = 0, nh = 0;
+	if (unit < chunks_per_row * sy) {
+		const uint32_t y = unit / chunks_per_row;
+		const uint32_t c = unit - y * chunks_per_row;
+		const uint32_t x = c * 64u + lane;
+		const LABEL* row = labels + (static_cast<uint64_t>(zi) * sy + y) * sx;
+		const bool valid = x < sx;
+		const LABEL v = valid ? row[x] : LABEL(0);
+		LABEL left = __shfl_up(v, 1, kWave);
+		if (lane == 0 && x > 0 && valid) left = row[x - 1];
+		const bool dv = valid && x > 0 && v != left;
+		const bool dh = valid && y > 0 && v != row[static_cast<int64_t>(x) - static_cast<int64_t>(sx)];
+		const unsigned long long mv = __ballot(dv), mh = __ballot(dh);
+		const uint64_t wbase = zi * plane_words + static_cast<uint64_t>(y) * row_words + c * 2u;
+		if (lane == 0) {
+			planeV[wbase] = static_cast<uint32_t>(mv);
+			planeH[wbase] = static_cast<uint32_t>(mh);
+			if (c * 2u + 1u < row_words) {
+				planeV[wbase + 1] = static_cast<uint32_t>(mv >> 32);
+				planeH[wbase + 1] = static_cast<uint32_t>(mh >> 32);
+			}
+			nv = __popcll(mv);
+			nh = __popcll(mh);
+		}
+	}
+	if (lane == 0) { s_red[wave] = nv; s_red[kWaves + wave] = nh; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tv = 0, th = 0;
+		for (int w = 0; w < kWaves; w++) { tv += s_red[w]; th += s_red[kWaves + w]; }
+		if (tv) atomicAdd(count_v + zi, tv);
+		if (th) atomicAdd(count_h + zi, th);
+	}
+}
+
+// crack graph: one adjacency nibble per vertex of the (sx+1) x (sy+1) corner grid,
+// bit0 -> right, bit1 -> left, bit2 -> down, bit3 -> up (crackcodes.hpp:66-125).
+// An interior pixel pair carries a crack when its labels differ (IMPERMISSIBLE) or are
+// equal (PERMISSIBLE); image-border pairs never do.  grid = (ceil(nverts / 256), nslices)
+__global__ void __launch_bounds__(kBlock) k_crack_graph(
+	const uint32_t* __restrict__ planeV, const uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
+	uint32_t sx, uint32_t sy, uint32_t permissible, uint8_t* __restrict__ adj, uint64_t adj_stride
+) {
 	const uint32_t zi = blockIdx.y;
 	const uint32_t sxe = sx + 1, sye = sy + 1;
 	const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+	if (v >= sxe * sye) return;
+	const uint32_t y = v / sxe;
+	const uint32_t x = v - y * sxe;
+	const uint32_t* pv = planeV + zi * plane_words;
+	const uint32_t* ph = planeH + zi * plane_words;
+	auto bit = [&](const uint32_t* pl, uint32_t xx, uint32_t yy) {
+		return ((pl[static_cast<uint64_t>(yy) * row_words + (xx >> 5)] >> (xx & 31u)) & 1u) ^ permissible;
+	};
 	uint32_t nib = 0;
-	if (v < sxe * sye) {
-		const int y = v / sxe;
-		const int x = v - y * sxe;
-		const LABEL* s = labels + static_cast<uint64_t>(zi) * sx * sy;
-		auto L = [&](int xx, int yy) { return s[static_cast<uint64_t>(yy) * sx + xx]; };
-		auto crack = [&](LABEL p, LABEL q) { return static_cast<uint32_t>((p == q) == (permissible != 0)); };
-		if (x < sx && y >= 1 && y < sy) nib |= crack(L(x, y), L(x, y - 1)) << 0;
-		if (x >= 1 && y >= 1 && y < sy) nib |= crack(L(x - 1, y), L(x - 1, y - 1)) << 1;
-		if (x >= 1 && x < sx && y < sy) nib |= crack(L(x, y), L(x - 1, y)) << 2;
-		if (x >= 1 && x < sx && y >= 1) nib |= crack(L(x, y - 1), L(x - 1, y - 1)) << 3;
-		adj[zi * adj_stride + v] = static_cast<uint8_t>(nib);
-	}
-	const uint32_t tot = block_sum(__popc(nib), s_red);
-	if (threadIdx.x == 0 && tot) atomicAdd(deg_sum + zi, tot);
+	if (x < sx && y >= 1 && y < sy) nib |= bit(ph, x, y) << 0;            // edge (x,y)-(x+1,y): pixels (x,y-1)|(x,y)
+	if (x >= 1 && y >= 1 && y < sy) nib |= bit(ph, x - 1, y) << 1;
+	if (x >= 1 && x < sx && y < sy) nib |= bit(pv, x, y) << 2;            // edge (x,y)-(x,y+1): pixels (x-1,y)|(x,y)
+	if (x >= 1 && x < sx && y >= 1) nib |= bit(pv, x, y - 1) << 3;
+	adj[zi * adj_stride + v] = static_cast<uint8_t>(nib);
 }
 
 // ------------------------------------------------------------------------------
@@ -189,10 +240,12 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 				prev_t_b = popped_code;
 			};
 
-			// every iteration consumes an edge or pops a branch: bounded by the code capacity
+			// every iteration consumes an edge or pops a branch: bounded by the code capacity.
+			// `av` is the nibble of `node`, carried in a register: one dependent memory round
+			// trip per step (the next vertex) instead of two.
+			uint32_t av = adj[node];
 			for (uint32_t guard = 0;; guard++) {
 				if (guard > cap) { err |= ENC_ERR_CAPACITY; break; }
-				const uint32_t av = adj[node];
 				if (av == 0) {
 					if (sp == 0) break;
 					sp--;
@@ -223,6 +276,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 						emit_t(true, pcode);
 					}
 					node = pnode;
+					av = adj[node];
 					continue;
 				}
 				if (__popc(av) > 1) {
@@ -243,7 +297,8 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 				sym_index++;
 				prev_t = false;
 				adj[node] = static_cast<uint8_t>(av & ~(1u << k));
-				adj[next] = static_cast<uint8_t>(adj[next] & ~(1u << (k ^ 1)));
+				av = adj[next] & ~(1u << (k ^ 1));
+				adj[next] = static_cast<uint8_t>(av);
 				node = next;
 			}
 			// the closing 't' (branches_taken returns to 0, crackcodes.hpp:436-439)
@@ -528,48 +583,20 @@ __global__ void __launch_bounds__(kBlock) k_markov_pack(
 }
 
 // ------------------------------------------------------------------------------
-// flat labels (labels.hpp:56-88): crc32c of the component image and component -> label
+// flat labels (labels.hpp:56-88): component -> label, read at the first pixel of every
+// root run.  grid = (ceil(max runs / 256), nslices)
 // ------------------------------------------------------------------------------
-// grid = (crc tiles, nslices); same tiling as k_paint in ckl_decode.hip
-__global__ void __launch_bounds__(kBlock) k_cc_crc(
-	const uint32_t* __restrict__ L, const uint32_t* __restrict__ R, uint64_t sxy, uint32_t pad,
-	const uint32_t* __restrict__ crc_stride_tab, const uint32_t* __restrict__ crc_lane_pow, const uint32_t* __restrict__ crc_tile_pow,
-	uint32_t* __restrict__ crc_acc
-) {
-	__shared__ uint32_t s_tab[1024];
-	__shared__ uint32_t s_red[kWaves];
-	const uint32_t zi = blockIdx.y, t = blockIdx.x;
-	for (int i = threadIdx.x; i < 1024; i += kBlock) s_tab[i] = crc_stride_tab[i];
-	__syncthreads();
-	const uint32_t* Lz = L + zi * sxy;
-	const uint32_t* Rz = R + zi * sxy;
-	uint32_t acc = 0;
-#pragma unroll
-	for (int i = 0; i < kCrcRows; i++) {
-		const uint64_t kp = static_cast<uint64_t>(t) * kCrcTile + i * kBlock + threadIdx.x;
-		const uint32_t word = kp >= pad ? Rz[Lz[kp - pad]] : 0u;
-		acc = crc_stride_step(s_tab, acc) ^ word;
-	}
-	uint32_t val = gf_mul(acc, crc_lane_pow[threadIdx.x]);
-	val = block_xor(val, s_red);
-	if (threadIdx.x == 0) atomicXor(crc_acc + zi, gf_mul(val, crc_tile_pow[t]));
-}
-
-// grid = (ccl tiles, nslices): mapping[comp_off[zi] + rank(root)] = label of the root pixel
 template <typename LABEL>
-__global__ void __launch_bounds__(kBlock) k_mapping(
-	const LABEL* __restrict__ labels, const uint32_t* __restrict__ L, const uint32_t* __restrict__ R, uint64_t sxy,
+__global__ void __launch_bounds__(kBlock) k_mapping_runs(
+	const LABEL* __restrict__ labels, RunArrays r, uint64_t sxy,
 	const uint64_t* __restrict__ comp_off, uint64_t* __restrict__ mapping
 ) {
 	const uint32_t zi = blockIdx.y;
-#pragma unroll
-	for (int i = 0; i < kCclTile / kBlock; i++) {
-		const uint64_t p = static_cast<uint64_t>(blockIdx.x) * kCclTile + i * kBlock + threadIdx.x;
-		if (p >= sxy) continue;
-		if (L[zi * sxy + p] == static_cast<uint32_t>(p)) {
-			mapping[comp_off[zi] + R[zi * sxy + p]] = static_cast<uint64_t>(labels[zi * sxy + p]);
-		}
-	}
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= r.nruns[zi]) return;
+	const uint64_t rb = r.rbase[zi];
+	if (r.parent[rb + i] != i) return;
+	mapping[comp_off[zi] + r.run_cc[rb + i]] = static_cast<uint64_t>(labels[zi * sxy + r.run_start[rb + i]]);
 }
 
 // grid = nslices: copy each slice's BOC index and payload to their final offsets
@@ -604,7 +631,7 @@ struct ckl_encoder {
 
 	DevBuf<unsigned long long> d_stats;
 	DevBuf<uint8_t> d_adj;
-	DevBuf<uint32_t> d_deg_sum, d_slice_err;
+	DevBuf<uint32_t> d_slice_err;
 	DevBuf<uint64_t> d_cbase, d_sbase, d_kbase, d_pbase, d_bbase, d_out_off, d_comp_off;
 	DevBuf<uint32_t> d_ccap, d_scap, d_kcap;
 	DevBuf<uint8_t> d_cp, d_fcode, d_dcode, d_payload, d_boc, d_codes_out, d_model;
@@ -612,8 +639,15 @@ struct ckl_encoder {
 	DevBuf<uint32_t> d_chain_node, d_chain_off, d_chain_clen, d_chain_order, d_chain_dst, d_chain_vstart;
 	DevBuf<uint32_t> d_n_chains, d_n_raw, d_n_valid, d_payload_len, d_boc_len;
 	DevBuf<uint32_t> d_hist;
-	DevBuf<uint32_t> d_L, d_R, d_tile_count, d_ncomp;
-	DevBuf<uint32_t> d_crc_tab, d_crc_lane_pow, d_crc_tile_pow, d_crc_acc;
+	// label planes + run-based CCL (ckl_runs.hpp)
+	DevBuf<uint32_t> d_planes, d_count_vh;
+	uint32_t row_words = 0;
+	uint64_t plane_words = 0;
+	std::vector<uint32_t> count_v, count_h;     // differing neighbour pairs per slice (host copy)
+	DevBuf<uint64_t> d_rbase;
+	DevBuf<uint32_t> d_rcap, d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_idbits;
+	DevBuf<uint32_t> d_G, d_crc_acc;
+	uint64_t g_table_pixels = 0;                // slice size the G table was built for
 	DevBuf<uint64_t> d_mapping;
 
 	~ckl_encoder() {
@@ -660,6 +694,48 @@ VolumeStats volume_stats(ckl_encoder& e, const LABEL* labels, uint64_t voxels) {
 	return st;
 }
 
+// wall-clock breakdown of the host side, printed when CKL_PROFILE is set
+struct HostTimer {
+	bool on;
+	std::chrono::steady_clock::time_point t0;
+	std::vector<std::pair<const char*, double>> marks;
+	HostTimer() : on(getenv("CKL_PROFILE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+	void mark(const char* name) {
+		if (!on) return;
+		auto t1 = std::chrono::steady_clock::now();
+		marks.emplace_back(name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+		t0 = t1;
+	}
+	~HostTimer() {
+		if (!on) return;
+		fprintf(stderr, "[ckl encode host ms]");
+		for (auto& m : marks) fprintf(stderr, " %s=%.2f", m.first, m.second);
+		fprintf(stderr, "\n");
+	}
+};
+
+// One pass over the labels -> the two "differs from neighbour" bit planes and their
+// per-slice population counts (exact crack edge and run counts follow from these).
+template <typename LABEL>
+void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz) {
+	hipStream_t s = e.stream;
+	const uint32_t ns = static_cast<uint32_t>(sz);
+	e.row_words = static_cast<uint32_t>((sx + 31) / 32);
+	e.plane_words = static_cast<uint64_t>(e.row_words) * sy;
+	e.d_planes.ensure(2 * e.plane_words * ns);
+	e.d_count_vh.ensure(2 * static_cast<size_t>(ns));
+	CKL_HIP(hipMemsetAsync(e.d_count_vh.p, 0, 2 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
+	const uint32_t chunks = static_cast<uint32_t>((sx + 63) / 64);
+	const uint64_t units = static_cast<uint64_t>(chunks) * sy;
+	hipLaunchKernelGGL(k_label_planes<LABEL>, dim3(static_cast<uint32_t>((units + kWaves - 1) / kWaves), ns), dim3(kBlock), 0, s,
+		labels, static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), chunks,
+		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
+		e.d_count_vh.p, e.d_count_vh.p + ns);
+	std::vector<uint32_t> c = download(e.d_count_vh.p, 2 * static_cast<size_t>(ns), s);
+	e.count_v.assign(c.begin(), c.begin() + ns);
+	e.count_h.assign(c.begin() + ns, c.end());
+}
+
 struct CrackResult {
 	std::vector<uint32_t> code_len;     // per slice: boc + payload bytes
 	std::vector<uint8_t> codes;         // concatenated crack codes
@@ -668,9 +744,8 @@ struct CrackResult {
 
 // Runs graph + walk + finish.  When `hist_only` is set, stops after the markov
 // histogram (returned in hist).  `model` (symbol -> rank) is required for markov packing.
-template <typename LABEL>
 void crack_pass(
-	ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, bool permissible,
+	ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, bool permissible,
 	int markov_order, bool hist_only, const std::vector<uint8_t>* model_in,
 	std::vector<uint32_t>* hist_out, std::vector<uint8_t>* model_out, CrackResult* result
 ) {
@@ -679,14 +754,14 @@ void crack_pass(
 	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
 	const uint64_t adj_stride = ((nverts + 8 + 511) / 512) * 512;
 	e.d_adj.ensure(adj_stride * ns);
-	e.d_deg_sum.ensure(ns);
 	e.d_slice_err.ensure(ns);
 	CKL_HIP(hipMemsetAsync(e.d_adj.p, 0, adj_stride * ns, s));
-	CKL_HIP(hipMemsetAsync(e.d_deg_sum.p, 0, ns * sizeof(uint32_t), s));
 	CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
-	hipLaunchKernelGGL(k_crack_graph<LABEL>, dim3(static_cast<uint32_t>((nverts + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s,
-		labels, static_cast<int>(sx), static_cast<int>(sy), permissible ? 1u : 0u, e.d_adj.p, adj_stride, e.d_deg_sum.p);
-	std::vector<uint32_t> deg = download(e.d_deg_sum.p, ns, s);
+	hipLaunchKernelGGL(k_crack_graph, dim3(static_cast<uint32_t>((nverts + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s,
+		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
+		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, e.d_adj.p, adj_stride);
+	// exact crack edge count per slice: interior pixel pairs that differ (or are equal)
+	const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
 
 	// capacities from the exact edge counts (codes <= 7 E, chains <= E, stack <= E)
 	std::vector<uint64_t> cbase(ns), sbase(ns), kbase(ns);
@@ -694,7 +769,8 @@ void crack_pass(
 	uint64_t ctot = 0, stot = 0, ktot = 0;
 	bool any = false;
 	for (uint32_t zi = 0; zi < ns; zi++) {
-		const uint64_t E = deg[zi] / 2;
+		const uint64_t differ = static_cast<uint64_t>(e.count_v[zi]) + e.count_h[zi];
+		const uint64_t E = permissible ? interior - differ : differ;
 		any = any || E > 0;
 		const uint64_t cc = 7 * E + 16;
 		if (cc > 0xFFFFFFF0ull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: slice has too many crack edges");
@@ -803,56 +879,87 @@ struct FlatResult {
 	std::vector<uint64_t> mapping;    // component -> label, slices concatenated
 };
 
+// geometric-sum table of ckl_runs.hpp (k_run_resolve), cached per slice size
+void ensure_geom_table(ckl_encoder& e, uint64_t sxy) {
+	if (e.g_table_pixels == sxy && e.d_G.p) return;
+	hipStream_t s = e.stream;
+	const uint32_t npx = static_cast<uint32_t>(sxy);
+	const uint32_t B = 1024, nblk = npx / B + 1;
+	std::vector<uint32_t> g_base(B), blk_g(nblk), blk_x(nblk);
+	const uint32_t X = gf_xpow(32);
+	g_base[0] = 0;
+	for (uint32_t i = 1; i < B; i++) g_base[i] = gf_mul(X, g_base[i - 1] ^ 0x80000000u);
+	const uint32_t gB = gf_mul(X, g_base[B - 1] ^ 0x80000000u);
+	const uint32_t XB = gf_xpow(32ull * B);
+	blk_g[0] = 0; blk_x[0] = 0x80000000u;
+	for (uint32_t k = 1; k < nblk; k++) {
+		blk_g[k] = blk_g[k - 1] ^ gf_mul(blk_x[k - 1], gB);
+		blk_x[k] = gf_mul(blk_x[k - 1], XB);
+	}
+	DevBuf<uint32_t> t_base, t_g, t_x;
+	upload(t_base, g_base, s); upload(t_g, blk_g, s); upload(t_x, blk_x, s);
+	e.d_G.ensure(static_cast<size_t>(npx) + 1);
+	hipLaunchKernelGGL(k_build_geom_table, dim3(npx / kBlock + 1), dim3(kBlock), 0, s, t_base.p, t_g.p, t_x.p, npx, e.d_G.p);
+	CKL_HIP(hipStreamSynchronize(s));
+	e.g_table_pixels = sxy;
+}
+
+// encode_flat per-slice part (labels.hpp:56-88) on runs of the label planes:
+// components, their crc32c, component -> label.
 template <typename LABEL>
 void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, FlatResult& out) {
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
-	const uint32_t tiles = static_cast<uint32_t>((sxy + kCclTile - 1) / kCclTile);
-	e.d_L.ensure(sxy * ns); e.d_R.ensure(sxy * ns);
-	e.d_tile_count.ensure(static_cast<size_t>(tiles) * ns);
-	e.d_ncomp.ensure(ns);
-	e.d_crc_acc.ensure(ns);
-	CKL_HIP(hipMemsetAsync(e.d_crc_acc.p, 0, ns * sizeof(uint32_t), s));
+	ensure_geom_table(e, sxy);
 
-	LabelConn<LABEL> conn;
-	conn.labels = labels; conn.sxy = sxy; conn.sx = static_cast<int>(sx);
-	hipLaunchKernelGGL(k_ccl_rows<LabelConn<LABEL>>, dim3(static_cast<uint32_t>(sy), ns), dim3(kBlock), 0, s, conn, e.d_L.p, static_cast<int>(sx), static_cast<int>(sy));
-	hipLaunchKernelGGL(k_ccl_merge<LabelConn<LABEL>>, dim3(tiles, ns), dim3(kBlock), 0, s, conn, e.d_L.p, static_cast<int>(sx), static_cast<int>(sy));
-	hipLaunchKernelGGL(k_ccl_flatten, dim3(tiles, ns), dim3(kBlock), 0, s, e.d_L.p, e.d_tile_count.p, sxy, tiles);
-	hipLaunchKernelGGL(k_ccl_scan, dim3(ns), dim3(kBlock), 0, s, e.d_tile_count.p, e.d_ncomp.p, tiles);
-	hipLaunchKernelGGL(k_ccl_rank, dim3(tiles, ns), dim3(kBlock), 0, s, e.d_L.p, e.d_R.p, e.d_tile_count.p, sxy, tiles);
-
-	// crc32c of each slice's component image
-	const uint32_t crc_tiles = static_cast<uint32_t>((sxy + kCrcTile - 1) / kCrcTile);
-	const uint32_t pad = static_cast<uint32_t>(static_cast<uint64_t>(crc_tiles) * kCrcTile - sxy);
-	{
-		std::vector<uint32_t> tab(1024), lane_pow(kBlock), tile_pow(crc_tiles);
-		const uint32_t M = gf_xpow(32ull * kBlock);
-		for (int k = 0; k < 4; k++)
-			for (uint32_t b = 0; b < 256; b++) tab[k * 256 + b] = gf_mul(b << (8 * k), M);
-		for (int j = 0; j < kBlock; j++) lane_pow[j] = gf_xpow(32ull * (kBlock - j));
-		const uint32_t T = gf_xpow(32ull * kCrcTile);
-		uint32_t acc = 0x80000000u;
-		for (uint32_t t = crc_tiles; t-- > 0;) { tile_pow[t] = acc; acc = gf_mul(acc, T); }
-		upload(e.d_crc_tab, tab, s); upload(e.d_crc_lane_pow, lane_pow, s); upload(e.d_crc_tile_pow, tile_pow, s);
-		CKL_HIP(hipStreamSynchronize(s));
+	// a run starts at x = 0 of every row and wherever the left neighbour differs
+	std::vector<uint64_t> rbase(ns);
+	std::vector<uint32_t> rcap(ns);
+	uint64_t rtot = 0;
+	uint32_t max_rcap = 0;
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		const uint64_t runs = static_cast<uint64_t>(sy) + e.count_v[zi];
+		rbase[zi] = rtot; rcap[zi] = static_cast<uint32_t>(runs); rtot += runs;
+		max_rcap = std::max<uint32_t>(max_rcap, static_cast<uint32_t>(runs));
 	}
-	hipLaunchKernelGGL(k_cc_crc, dim3(crc_tiles, ns), dim3(kBlock), 0, s, e.d_L.p, e.d_R.p, sxy, pad,
-		e.d_crc_tab.p, e.d_crc_lane_pow.p, e.d_crc_tile_pow.p, e.d_crc_acc.p);
+	upload(e.d_rbase, rbase, s); upload(e.d_rcap, rcap, s);
+	e.d_word_base.ensure(e.plane_words * ns);
+	e.d_parent.ensure(rtot); e.d_run_start.ensure(rtot); e.d_run_cc.ensure(rtot);
+	e.d_nruns.ensure(ns); e.d_ncomp.ensure(ns); e.d_idbits.ensure(ns); e.d_crc_acc.ensure(ns);
+	e.d_slice_err.ensure(ns);
+
+	RunGeom g;
+	g.planeV = e.d_planes.p; g.planeH = e.d_planes.p + e.plane_words * ns;
+	g.row_words = e.row_words; g.plane_words = e.plane_words;
+	g.flip = 1u;   // a set bit (labels differ) is a break, whatever the stream's crack format
+	g.sx = static_cast<uint32_t>(sx); g.sy = static_cast<uint32_t>(sy);
+	RunArrays ra;
+	ra.word_base = e.d_word_base.p; ra.rbase = e.d_rbase.p; ra.rcap = e.d_rcap.p;
+	ra.parent = e.d_parent.p; ra.run_start = e.d_run_start.p; ra.run_cc = e.d_run_cc.p;
+	ra.nruns = e.d_nruns.p; ra.ncomp = e.d_ncomp.p; ra.slice_err = e.d_slice_err.p;
+	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kBlock), 0, s, g, ra);
+	hipLaunchKernelGGL(k_run_union, dim3(static_cast<uint32_t>((e.plane_words + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s, g, ra);
+	hipLaunchKernelGGL(k_run_resolve, dim3(ns), dim3(kBlock), 0, s, ra, e.d_G.p, static_cast<uint32_t>(sxy), 0u, e.d_crc_acc.p, e.d_idbits.p);
 
 	out.ncomp = download(e.d_ncomp.p, ns, s);
 	std::vector<uint32_t> acc = download(e.d_crc_acc.p, ns, s);
+	std::vector<uint32_t> idbits = download(e.d_idbits.p, ns, s);
 	const uint32_t init_term = gf_mul(0xFFFFFFFFu, gf_xpow(32ull * sxy));
 	out.crcs.resize(ns);
-	for (uint32_t zi = 0; zi < ns; zi++) out.crcs[zi] = ~(acc[zi] ^ init_term);
+	uint32_t fix_bits = 0xFFFFFFFFu, fix = 0;
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		if (idbits[zi] != fix_bits) { fix_bits = idbits[zi]; fix = gf_xpow(32 - fix_bits); }
+		out.crcs[zi] = ~(gf_mul(acc[zi], fix) ^ init_term);
+	}
 
 	std::vector<uint64_t> comp_off(ns);
 	uint64_t total = 0;
 	for (uint32_t zi = 0; zi < ns; zi++) { comp_off[zi] = total; total += out.ncomp[zi]; }
 	upload(e.d_comp_off, comp_off, s);
 	e.d_mapping.ensure(total + 1);
-	hipLaunchKernelGGL(k_mapping<LABEL>, dim3(tiles, ns), dim3(kBlock), 0, s, labels, e.d_L.p, e.d_R.p, sxy, e.d_comp_off.p, e.d_mapping.p);
+	hipLaunchKernelGGL(k_mapping_runs<LABEL>, dim3((max_rcap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s,
+		labels, ra, sxy, e.d_comp_off.p, e.d_mapping.p);
 	out.mapping = download(e.d_mapping.p, total, s);
 }
 
@@ -904,6 +1011,9 @@ void encode_typed(
 	}
 	if (head.markov_model_order > 13) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order > 13 is not supported on device");
 
+	HostTimer ht;
+	planes_pass<LABEL>(e, labels, sx, sy, sz);
+	ht.mark("planes");
 	// crack codes; a first pass decides whether any slice has chains (crackle.hpp:107-118)
 	CrackResult cr;
 	std::vector<uint8_t> model, stored_model;
@@ -915,17 +1025,19 @@ void encode_typed(
 		forced_model.assign(ov->model, ov->model + rows * 4);
 		model_in = &forced_model;
 	}
-	crack_pass<LABEL>(e, labels, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr);
+	crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr);
+	ht.mark("cracks");
 	if (head.markov_model_order > 0 && !cr.any_chain && !(ov && ov->has_model)) {
 		// every slice empty: the reference resets the order to 0 and packs plainly
 		head.markov_model_order = 0;
-		crack_pass<LABEL>(e, labels, sx, sy, sz, permissible, 0, false, nullptr, nullptr, nullptr, &cr);
+		crack_pass(e, sx, sy, sz, permissible, 0, false, nullptr, nullptr, nullptr, &cr);
 	}
 	if (head.markov_model_order > 0) stored_model = markov_model_to_stored(model);
 
 	// labels (labels.hpp:30-155)
 	FlatResult fr;
 	flat_pass<LABEL>(e, labels, sx, sy, sz, fr);
+	ht.mark("flat");
 	const uint64_t N = fr.mapping.size();
 	std::vector<uint64_t> uniq(fr.mapping);
 	std::sort(uniq.begin(), uniq.end());
@@ -942,6 +1054,7 @@ void encode_typed(
 		put_le(labels_binary, key, key_width);
 	}
 
+	ht.mark("label_table");
 	// assembly (crackle.hpp:171-216)
 	head.num_label_bytes = labels_binary.size();
 	final_binary.reserve(Header::kBytes + 4 * (sz + 1) + labels_binary.size() + stored_model.size() + cr.codes.size() + 4 * (sz + 1));
@@ -955,6 +1068,7 @@ void encode_typed(
 	put_le(final_binary, crc32c(labels_binary.data(), labels_binary.size()), 4);
 	for (int64_t z = 0; z < sz; z++) put_le(final_binary, fr.crcs[z], 4);
 
+	ht.mark("assembly");
 	CKL_HIP(hipEventRecord(e.ev1, s));
 	CKL_HIP(hipStreamSynchronize(s));
 	CKL_HIP(hipGetLastError());
@@ -1062,10 +1176,11 @@ int ckl_encoder_markov_stats(
 		if (static_cast<uint64_t>(sx) * sy * sz > 0) {
 			const bool perm = crack_format == PERMISSIBLE;
 			const int order = static_cast<int>(markov_model_order);
-			if (e->dtype_bytes == 1) crack_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
-			else if (e->dtype_bytes == 2) crack_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
-			else if (e->dtype_bytes == 4) crack_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
-			else crack_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
+			if (e->dtype_bytes == 1) planes_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz);
+			else if (e->dtype_bytes == 2) planes_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz);
+			else if (e->dtype_bytes == 4) planes_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz);
+			else planes_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz);
+			crack_pass(*e, sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
 		}
 		memcpy(hist, h.data(), h.size() * sizeof(uint32_t));
 		return CKL_OK;
