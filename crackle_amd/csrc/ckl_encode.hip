@@ -59,6 +59,8 @@ __global__ void __launch_bounds__(kBlock) k_stats(const LABEL* __restrict__ labe
 // left neighbour comes from a lane shuffle, the plane words from a ballot.
 // grid = (ceil(chunks_per_row * sy / 4), nslices), chunks_per_row = ceil(sx / 64)
 // ------------------------------------------------------------------------------
+constexpr uint32_t kPlaneUnroll = 4;   // 64-pixel chunks per wavefront (loads issued together)
+
 template <typename LABEL>
 __global__ void __launch_bounds__(kBlock) k_label_planes(
 	const LABEL* __restrict__ labels, uint32_t sx, uint32_t sy, uint32_t chunks_per_row,
@@ -68,30 +70,44 @@ __global__ void __launch_bounds__(kBlock) k_label_planes(
 	__shared__ uint32_t s_red[2 * kWaves];
 	const uint32_t zi = blockIdx.y;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t unit = blockIdx.x * kWaves + wave;
-	uint32_t nv = 0, nh = 0;
-	if (unit < chunks_per_row * sy) {
+	const uint32_t units = chunks_per_row * sy;
+	const uint32_t unit0 = (blockIdx.x * kWaves + wave) * kPlaneUnroll;
+	const LABEL* slice = labels + static_cast<uint64_t>(zi) * sy * sx;
+	LABEL v[kPlaneUnroll], up[kPlaneUnroll], lf[kPlaneUnroll];
+	uint32_t xs[kPlaneUnroll], ys[kPlaneUnroll];
+#pragma unroll
+	for (uint32_t k = 0; k < kPlaneUnroll; k++) {
+		const uint32_t unit = unit0 + k;
 		const uint32_t y = unit / chunks_per_row;
-		const uint32_t c = unit - y * chunks_per_row;
-		const uint32_t x = c * 64u + lane;
-		const LABEL* row = labels + (static_cast<uint64_t>(zi) * sy + y) * sx;
-		const bool valid = x < sx;
-		const LABEL v = valid ? row[x] : LABEL(0);
-		LABEL left = __shfl_up(v, 1, kWave);
-		if (lane == 0 && x > 0 && valid) left = row[x - 1];
-		const bool dv = valid && x > 0 && v != left;
-		const bool dh = valid && y > 0 && v != row[static_cast<int64_t>(x) - static_cast<int64_t>(sx)];
+		const uint32_t x = (unit - y * chunks_per_row) * 64u + lane;
+		xs[k] = x; ys[k] = y;
+		const bool valid = unit < units && x < sx;
+		const LABEL* row = slice + static_cast<uint64_t>(y) * sx;
+		v[k] = valid ? row[x] : LABEL(0);
+		up[k] = (valid && y > 0) ? row[static_cast<int64_t>(x) - static_cast<int64_t>(sx)] : v[k];
+		lf[k] = (valid && lane == 0 && x > 0) ? row[x - 1] : v[k];
+	}
+	uint32_t nv = 0, nh = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < kPlaneUnroll; k++) {
+		const uint32_t unit = unit0 + k;
+		const bool valid = unit < units && xs[k] < sx;
+		LABEL left = __shfl_up(v[k], 1, kWave);
+		if (lane == 0) left = lf[k];
+		const bool dv = valid && xs[k] > 0 && v[k] != left;
+		const bool dh = valid && v[k] != up[k];
 		const unsigned long long mv = __ballot(dv), mh = __ballot(dh);
-		const uint64_t wbase = zi * plane_words + static_cast<uint64_t>(y) * row_words + c * 2u;
-		if (lane == 0) {
+		if (lane == 0 && unit < units) {
+			const uint32_t c = xs[k] >> 6;
+			const uint64_t wbase = zi * plane_words + static_cast<uint64_t>(ys[k]) * row_words + c * 2u;
 			planeV[wbase] = static_cast<uint32_t>(mv);
 			planeH[wbase] = static_cast<uint32_t>(mh);
 			if (c * 2u + 1u < row_words) {
 				planeV[wbase + 1] = static_cast<uint32_t>(mv >> 32);
 				planeH[wbase + 1] = static_cast<uint32_t>(mh >> 32);
 			}
-			nv = __popcll(mv);
-			nh = __popcll(mh);
+			nv += __popcll(mv);
+			nh += __popcll(mh);
 		}
 	}
 	if (lane == 0) { s_red[wave] = nv; s_red[kWaves + wave] = nh; }
@@ -108,9 +124,18 @@ __global__ void __launch_bounds__(kBlock) k_label_planes(
 // bit0 -> right, bit1 -> left, bit2 -> down, bit3 -> up (crackcodes.hpp:66-125).
 // An interior pixel pair carries a crack when its labels differ (IMPERMISSIBLE) or are
 // equal (PERMISSIBLE); image-border pairs never do.  grid = (ceil(nverts / 256), nslices)
+// The nibbles are stored twice: `adj` in raster order (what next_cluster scans) and
+// `adjt` in 16 x 8 vertex tiles of 128 bytes = one cache line, which the walk reads:
+// a trail then stays inside one line for several steps whichever way it turns, while in
+// raster order every vertical move lands in a cold line.
+__device__ __forceinline__ uint32_t tiled_index(uint32_t x, uint32_t y, uint32_t tiles_x) {
+	return (((y >> 3) * tiles_x + (x >> 4)) << 7) + ((y & 7u) << 4) + (x & 15u);
+}
+
 __global__ void __launch_bounds__(kBlock) k_crack_graph(
 	const uint32_t* __restrict__ planeV, const uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
-	uint32_t sx, uint32_t sy, uint32_t permissible, uint8_t* __restrict__ adj, uint64_t adj_stride
+	uint32_t sx, uint32_t sy, uint32_t permissible, uint8_t* __restrict__ adj, uint64_t adj_stride,
+	uint8_t* __restrict__ adjt, uint64_t adjt_stride, uint32_t tiles_x
 ) {
 	const uint32_t zi = blockIdx.y;
 	const uint32_t sxe = sx + 1, sye = sy + 1;
@@ -129,6 +154,7 @@ __global__ void __launch_bounds__(kBlock) k_crack_graph(
 	if (x >= 1 && x < sx && y < sy) nib |= bit(pv, x, y) << 2;            // edge (x,y)-(x,y+1): pixels (x-1,y)|(x,y)
 	if (x >= 1 && x < sx && y >= 1) nib |= bit(pv, x, y - 1) << 3;
 	adj[zi * adj_stride + v] = static_cast<uint8_t>(nib);
+	adjt[zi * adjt_stride + tiled_index(x, y, tiles_x)] = static_cast<uint8_t>(nib);
 }
 
 // ------------------------------------------------------------------------------
@@ -143,6 +169,9 @@ __global__ void __launch_bounds__(kBlock) k_crack_graph(
 struct WalkArgs {
 	uint8_t* adj;
 	uint64_t adj_stride;
+	uint8_t* adjt;            // tiled copy (see tiled_index)
+	uint64_t adjt_stride;
+	uint32_t tiles_x;
 	int sx, sy;
 	const uint64_t* cbase;    // per slice: base into cp / stacks
 	const uint32_t* ccap;     // capacity of cp (codes)
@@ -169,6 +198,8 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 	const uint32_t zi = blockIdx.x;
 	const int lane = threadIdx.x;
 	uint8_t* adj = a.adj + zi * a.adj_stride;
+	uint8_t* adjt = a.adjt + zi * a.adjt_stride;
+	const uint32_t tiles_x = a.tiles_x;
 	const uint32_t sxe = a.sx + 1, sye = a.sy + 1;
 	const uint32_t nverts = sxe * sye;
 	uint8_t* cp = a.cp + a.cbase[zi];
@@ -211,6 +242,8 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 		if (lane == 0 && adj[start] != 0) {
 			// ---- one chain -------------------------------------------------------------
 			uint32_t node = start, sp = 0;
+			uint32_t ny = start / sxe, nx = start - ny * sxe;     // coordinates of `node`
+			uint32_t tnode = tiled_index(nx, ny, tiles_x);
 			const uint32_t chain_begin = nraw;
 			uint32_t tomb = 0, sym_index = 0;
 			uint32_t last_code = CODE_NONE;
@@ -219,6 +252,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 			uint32_t prev_t_b = 0;          // ... that popped the 'b' whose codes sit at this offset
 			uint32_t adjusted = start;
 			const int32_t dirs[4] = { 1, -1, static_cast<int32_t>(sxe), -static_cast<int32_t>(sxe) };
+			const int32_t dxs[4] = { 1, -1, 0, 0 }, dys[4] = { 0, 0, 1, -1 };
 			const uint8_t move_code[4] = { CODE_RIGHT, CODE_LEFT, CODE_DOWN, CODE_UP };
 
 			auto put = [&](uint32_t c) {
@@ -243,7 +277,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 			// every iteration consumes an edge or pops a branch: bounded by the code capacity.
 			// `av` is the nibble of `node`, carried in a register: one dependent memory round
 			// trip per step (the next vertex) instead of two.
-			uint32_t av = adj[node];
+			uint32_t av = adjt[tnode];
 			for (uint32_t guard = 0;; guard++) {
 				if (guard > cap) { err |= ENC_ERR_CAPACITY; break; }
 				if (av == 0) {
@@ -276,7 +310,9 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 						emit_t(true, pcode);
 					}
 					node = pnode;
-					av = adj[node];
+					ny = node / sxe; nx = node - ny * sxe;
+					tnode = tiled_index(nx, ny, tiles_x);
+					av = adjt[tnode];
 					continue;
 				}
 				if (__popc(av) > 1) {
@@ -296,8 +332,13 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 				last_code = move_code[k];
 				sym_index++;
 				prev_t = false;
-				adj[node] = static_cast<uint8_t>(av & ~(1u << k));
-				av = adj[next] & ~(1u << (k ^ 1));
+				const uint8_t left_behind = static_cast<uint8_t>(av & ~(1u << k));
+				adjt[tnode] = left_behind;
+				adj[node] = left_behind;
+				nx += dxs[k]; ny += dys[k];
+				tnode = tiled_index(nx, ny, tiles_x);
+				av = adjt[tnode] & ~(1u << (k ^ 1));
+				adjt[tnode] = static_cast<uint8_t>(av);
 				adj[next] = static_cast<uint8_t>(av);
 				node = next;
 			}
@@ -599,6 +640,59 @@ __global__ void __launch_bounds__(kBlock) k_mapping_runs(
 	mapping[comp_off[zi] + r.run_cc[rb + i]] = static_cast<uint64_t>(labels[zi * sxy + r.run_start[rb + i]]);
 }
 
+// ------------------------------------------------------------------------------
+// label table (labels.hpp:92-152): sorted unique labels and the key of every component.
+// The component -> label list is sorted on device (bitonic network over a power-of-two
+// padded copy), uniqued on the host in one linear pass, and the keys are found by binary
+// search on device and packed at their byte width.
+// ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_bitonic_step(uint64_t* __restrict__ a, uint32_t j, uint32_t k, uint32_t n) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t l = i ^ j;
+	if (l > i) {
+		const uint64_t x = a[i], y = a[l];
+		const bool up = (i & k) == 0;
+		if ((x > y) == up) { a[i] = y; a[l] = x; }
+	}
+}
+// all steps with j < 2048 of one k-stage inside LDS (2048 elements per workgroup)
+__global__ void __launch_bounds__(kBlock) k_bitonic_local(uint64_t* __restrict__ a, uint32_t j_start, uint32_t k, uint32_t n) {
+	__shared__ uint64_t s[2048];
+	const uint32_t base = blockIdx.x * 2048u;
+	for (uint32_t t = threadIdx.x; t < 2048u; t += kBlock) s[t] = base + t < n ? a[base + t] : ~0ull;
+	__syncthreads();
+	for (uint32_t j = j_start; j > 0; j >>= 1) {
+		for (uint32_t t = threadIdx.x; t < 2048u; t += kBlock) {
+			const uint32_t l = t ^ j;
+			if (l > t) {
+				const uint64_t x = s[t], y = s[l];
+				const bool up = ((base + t) & k) == 0;
+				if ((x > y) == up) { s[t] = y; s[l] = x; }
+			}
+		}
+		__syncthreads();
+	}
+	for (uint32_t t = threadIdx.x; t < 2048u; t += kBlock) if (base + t < n) a[base + t] = s[t];
+}
+__global__ void __launch_bounds__(kBlock) k_pad_copy_u64(const uint64_t* __restrict__ src, uint64_t n, uint64_t* __restrict__ dst, uint64_t n_pad) {
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (i < n_pad) dst[i] = i < n ? src[i] : ~0ull;
+}
+__global__ void __launch_bounds__(kBlock) k_label_keys(
+	const uint64_t* __restrict__ mapping, uint64_t n, const uint64_t* __restrict__ uniq, uint64_t nu, int key_width, uint8_t* __restrict__ keys
+) {
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t v = mapping[i];
+	uint64_t lo = 0, hi = nu;          // last index with uniq[idx] <= v
+	while (lo + 1 < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (uniq[mid] <= v) lo = mid; else hi = mid;
+	}
+	for (int b = 0; b < key_width; b++) keys[i * key_width + b] = static_cast<uint8_t>((lo >> (8 * b)) & 0xFF);
+}
+
 // grid = nslices: copy each slice's BOC index and payload to their final offsets
 __global__ void __launch_bounds__(kBlock) k_gather_codes(
 	const uint8_t* __restrict__ boc, const uint64_t* __restrict__ bbase, const uint32_t* __restrict__ boc_len,
@@ -630,7 +724,7 @@ struct ckl_encoder {
 	int dtype_bytes = 0;
 
 	DevBuf<unsigned long long> d_stats;
-	DevBuf<uint8_t> d_adj;
+	DevBuf<uint8_t> d_adj, d_adjt;
 	DevBuf<uint32_t> d_slice_err;
 	DevBuf<uint64_t> d_cbase, d_sbase, d_kbase, d_pbase, d_bbase, d_out_off, d_comp_off;
 	DevBuf<uint32_t> d_ccap, d_scap, d_kcap;
@@ -648,7 +742,8 @@ struct ckl_encoder {
 	DevBuf<uint32_t> d_rcap, d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_idbits;
 	DevBuf<uint32_t> d_G, d_crc_acc;
 	uint64_t g_table_pixels = 0;                // slice size the G table was built for
-	DevBuf<uint64_t> d_mapping;
+	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq;
+	DevBuf<uint8_t> d_keys;
 
 	~ckl_encoder() {
 		if (ev0) (void)hipEventDestroy(ev0);
@@ -727,7 +822,7 @@ void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, in
 	CKL_HIP(hipMemsetAsync(e.d_count_vh.p, 0, 2 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
 	const uint32_t chunks = static_cast<uint32_t>((sx + 63) / 64);
 	const uint64_t units = static_cast<uint64_t>(chunks) * sy;
-	hipLaunchKernelGGL(k_label_planes<LABEL>, dim3(static_cast<uint32_t>((units + kWaves - 1) / kWaves), ns), dim3(kBlock), 0, s,
+	hipLaunchKernelGGL(k_label_planes<LABEL>, dim3(static_cast<uint32_t>((units + kWaves * kPlaneUnroll - 1) / (kWaves * kPlaneUnroll)), ns), dim3(kBlock), 0, s,
 		labels, static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), chunks,
 		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
 		e.d_count_vh.p, e.d_count_vh.p + ns);
@@ -753,13 +848,17 @@ void crack_pass(
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
 	const uint64_t adj_stride = ((nverts + 8 + 511) / 512) * 512;
+	const uint32_t tiles_x = static_cast<uint32_t>((sx + 1 + 15) / 16), tiles_y = static_cast<uint32_t>((sy + 1 + 7) / 8);
+	const uint64_t adjt_stride = static_cast<uint64_t>(tiles_x) * tiles_y * 128;
 	e.d_adj.ensure(adj_stride * ns);
+	e.d_adjt.ensure(adjt_stride * ns);
 	e.d_slice_err.ensure(ns);
 	CKL_HIP(hipMemsetAsync(e.d_adj.p, 0, adj_stride * ns, s));
 	CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
 	hipLaunchKernelGGL(k_crack_graph, dim3(static_cast<uint32_t>((nverts + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s,
 		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
-		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, e.d_adj.p, adj_stride);
+		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, e.d_adj.p, adj_stride,
+		e.d_adjt.p, adjt_stride, tiles_x);
 	// exact crack edge count per slice: interior pixel pairs that differ (or are equal)
 	const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
 
@@ -791,6 +890,7 @@ void crack_pass(
 	e.d_payload_len.ensure(ns); e.d_boc_len.ensure(ns);
 
 	WalkArgs wa;
+	wa.adjt = e.d_adjt.p; wa.adjt_stride = adjt_stride; wa.tiles_x = tiles_x;
 	wa.adj = e.d_adj.p; wa.adj_stride = adj_stride; wa.sx = static_cast<int>(sx); wa.sy = static_cast<int>(sy);
 	wa.cbase = e.d_cbase.p; wa.ccap = e.d_ccap.p; wa.sbase = e.d_sbase.p; wa.scap = e.d_scap.p; wa.kbase = e.d_kbase.p; wa.kcap = e.d_kcap.p;
 	wa.cp = e.d_cp.p; wa.stack_node = e.d_stack_node.p; wa.stack_code = e.d_stack_code.p;
@@ -876,7 +976,7 @@ void crack_pass(
 struct FlatResult {
 	std::vector<uint32_t> ncomp;      // per slice
 	std::vector<uint32_t> crcs;       // per slice crc32c of the component image
-	std::vector<uint64_t> mapping;    // component -> label, slices concatenated
+	uint64_t total = 0;               // components over all slices; mapping stays in e.d_mapping
 };
 
 // geometric-sum table of ckl_runs.hpp (k_run_resolve), cached per slice size
@@ -960,7 +1060,35 @@ void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int6
 	e.d_mapping.ensure(total + 1);
 	hipLaunchKernelGGL(k_mapping_runs<LABEL>, dim3((max_rcap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s,
 		labels, ra, sxy, e.d_comp_off.p, e.d_mapping.p);
-	out.mapping = download(e.d_mapping.p, total, s);
+	out.total = total;
+}
+
+// uniq = sort + unique of the component labels, keys = index of each component's label
+// in uniq (labels.hpp:92-152)
+void label_table(ckl_encoder& e, uint64_t N, std::vector<uint64_t>& uniq, int& key_width, std::vector<uint8_t>& keys) {
+	hipStream_t s = e.stream;
+	uniq.clear(); keys.clear(); key_width = 1;
+	if (N == 0) return;
+	if (N > 0x7FFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
+	uint32_t n_pad = 2048;
+	while (n_pad < N) n_pad <<= 1;
+	e.d_sorted.ensure(n_pad);
+	const uint32_t blocks = (n_pad + kBlock - 1) / kBlock;
+	hipLaunchKernelGGL(k_pad_copy_u64, dim3(blocks), dim3(kBlock), 0, s, e.d_mapping.p, N, e.d_sorted.p, static_cast<uint64_t>(n_pad));
+	for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+		uint32_t j = k >> 1;
+		for (; j >= 2048; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3(blocks), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
+		hipLaunchKernelGGL(k_bitonic_local, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
+	}
+	std::vector<uint64_t> sorted = download(e.d_sorted.p, N, s);
+	uniq.reserve(N / 4 + 16);
+	for (uint64_t i = 0; i < N; i++) if (i == 0 || sorted[i] != sorted[i - 1]) uniq.push_back(sorted[i]);
+	key_width = byte_width(uniq.size());
+	upload(e.d_uniq, uniq, s);
+	e.d_keys.ensure(N * key_width);
+	hipLaunchKernelGGL(k_label_keys, dim3(static_cast<uint32_t>((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+		e.d_mapping.p, N, e.d_uniq.p, static_cast<uint64_t>(uniq.size()), key_width, e.d_keys.p);
+	keys = download(e.d_keys.p, N * key_width, s);
 }
 
 template <typename LABEL>
@@ -1038,22 +1166,18 @@ void encode_typed(
 	FlatResult fr;
 	flat_pass<LABEL>(e, labels, sx, sy, sz, fr);
 	ht.mark("flat");
-	const uint64_t N = fr.mapping.size();
-	std::vector<uint64_t> uniq(fr.mapping);
-	std::sort(uniq.begin(), uniq.end());
-	uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-	const int key_width = byte_width(uniq.size());
+	const uint64_t N = fr.total;
+	std::vector<uint64_t> uniq;
+	std::vector<uint8_t> keys;
+	int key_width = 1;
+	label_table(e, N, uniq, key_width, keys);
 	const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
 	std::vector<uint8_t> labels_binary;
-	labels_binary.reserve(8 + uniq.size() * stored_width + static_cast<size_t>(sz) * component_width + N * key_width);
+	labels_binary.reserve(8 + uniq.size() * stored_width + static_cast<size_t>(sz) * component_width + keys.size());
 	put_le(labels_binary, uniq.size(), 8);
 	for (uint64_t v : uniq) put_le(labels_binary, v, stored_width);
 	for (int64_t z = 0; z < sz; z++) put_le(labels_binary, fr.ncomp[z], component_width);
-	for (uint64_t i = 0; i < N; i++) {
-		const uint64_t key = static_cast<uint64_t>(std::lower_bound(uniq.begin(), uniq.end(), fr.mapping[i]) - uniq.begin());
-		put_le(labels_binary, key, key_width);
-	}
-
+	labels_binary.insert(labels_binary.end(), keys.begin(), keys.end());
 	ht.mark("label_table");
 	// assembly (crackle.hpp:171-216)
 	head.num_label_bytes = labels_binary.size();
