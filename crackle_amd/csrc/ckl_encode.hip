@@ -240,54 +240,34 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 		start = found;
 
 		if (lane == 0 && adj[start] != 0) {
-			// ---- one chain -------------------------------------------------------------
+			// ---- one chain.  All walker state lives in registers: no closures, no
+			// indexed local arrays (both end up in scratch memory, one round trip per use).
 			uint32_t node = start, sp = 0;
 			uint32_t ny = start / sxe, nx = start - ny * sxe;     // coordinates of `node`
 			uint32_t tnode = tiled_index(nx, ny, tiles_x);
 			const uint32_t chain_begin = nraw;
-			uint32_t tomb = 0, sym_index = 0;
+			uint32_t tomb = 0;
+			bool first_symbol = true;       // nothing emitted yet (symbol index 0)
 			uint32_t last_code = CODE_NONE;
 			bool rib_pending = false;       // chain began with 'b', no other 'b' and no 't' yet
 			bool prev_t = false;            // previous symbol is a live 't' ...
 			uint32_t prev_t_b = 0;          // ... that popped the 'b' whose codes sit at this offset
 			uint32_t adjusted = start;
-			const int32_t dirs[4] = { 1, -1, static_cast<int32_t>(sxe), -static_cast<int32_t>(sxe) };
-			const int32_t dxs[4] = { 1, -1, 0, 0 }, dys[4] = { 0, 0, 1, -1 };
-			const uint8_t move_code[4] = { CODE_RIGHT, CODE_LEFT, CODE_DOWN, CODE_UP };
-
-			auto put = [&](uint32_t c) {
-				if (nraw < cap) cp[nraw] = static_cast<uint8_t>(c); else err |= ENC_ERR_CAPACITY;
-				nraw++;
-			};
-			auto emit_t = [&](bool has_pop, uint32_t popped_code) {
-				if (prev_t) {
-					// spurious pair: the 'b' popped by the previous 't' and this 't' vanish
-					if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
-					tomb += 2;
-				}
-				else {
-					if (sym_index > 0 && last_code != CODE_NONE && last_code != CODE_UP) { put(CODE_DOWN); put(CODE_UP); last_code = CODE_UP; }
-					else { put(CODE_RIGHT); put(CODE_LEFT); last_code = CODE_LEFT; }
-					sym_index++;
-				}
-				prev_t = has_pop;
-				prev_t_b = popped_code;
-			};
 
 			// every iteration consumes an edge or pops a branch: bounded by the code capacity.
-			// `av` is the nibble of `node`, carried in a register: one dependent memory round
-			// trip per step (the next vertex) instead of two.
+			// `av` is the nibble of `node`, carried in a register.
 			uint32_t av = adjt[tnode];
 			for (uint32_t guard = 0;; guard++) {
 				if (guard > cap) { err |= ENC_ERR_CAPACITY; break; }
 				if (av == 0) {
+					// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
 					if (sp == 0) break;
 					sp--;
 					const uint32_t pnode = st_node[sp], pcode = st_code[sp];
 					if (rib_pending) {
-						// remove_initial_branch: drop the leading 'b' and this 't', walk the
-						// first stretch backwards (reverse order, opposite directions) and
-						// start the chain where the stretch ended.
+						// remove_initial_branch (crackcodes.hpp:185-242): drop the leading 'b'
+						// and this 't', walk the first stretch backwards (reverse order,
+						// opposite directions) and start the chain where the stretch ended.
 						rib_pending = false;
 						adjusted = node;
 						if (chain_begin + 1 < cap) { cp[chain_begin] = CODE_TOMB; cp[chain_begin + 1] = CODE_TOMB; }
@@ -303,47 +283,74 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 							if (lo == hi) cp[lo] ^= 2;
 							last_code = cp[hi_end - 1];
 						}
-						sym_index++;      // the 's' that replaces the 't' still occupies a symbol slot
 						prev_t = false;
 					}
-					else {
-						emit_t(true, pcode);
+					else if (prev_t) {
+						// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by the
+						// previous 't' and this 't' vanish
+						if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
+						tomb += 2;
+						prev_t_b = pcode;
 					}
+					else {
+						// (DOWN,UP) unless the previous code is UP, then (RIGHT,LEFT)  (crackcodes.hpp:165-174)
+						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
+						const uint32_t c0 = alt ? CODE_RIGHT : CODE_DOWN, c1 = alt ? CODE_LEFT : CODE_UP;
+						if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else err |= ENC_ERR_CAPACITY;
+						nraw += 2;
+						last_code = c1;
+						prev_t = true;
+						prev_t_b = pcode;
+					}
+					first_symbol = false;
 					node = pnode;
 					ny = node / sxe; nx = node - ny * sxe;
 					tnode = tiled_index(nx, ny, tiles_x);
 					av = adjt[tnode];
 					continue;
 				}
-				if (__popc(av) > 1) {
-					if (sym_index == 0) rib_pending = true;
-					else rib_pending = false;
+				if (av & (av - 1u)) {
+					// ---- 'b': more than one edge left here, remember the vertex
+					rib_pending = first_symbol;
 					if (sp < scap) { st_node[sp] = node; st_code[sp] = nraw; } else err |= ENC_ERR_CAPACITY;
 					sp++;
-					if (sym_index > 0 && last_code != CODE_NONE && last_code != CODE_DOWN) { put(CODE_UP); put(CODE_DOWN); last_code = CODE_DOWN; }
-					else { put(CODE_LEFT); put(CODE_RIGHT); last_code = CODE_RIGHT; }
-					sym_index++;
-					prev_t = false;
-					if (err) break;
+					// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
+					const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
+					const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
+					if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else { err |= ENC_ERR_CAPACITY; break; }
+					nraw += 2;
+					last_code = c1;
+					first_symbol = false;
 				}
-				const int k = __ffs(av) - 1;
-				const uint32_t next = node + dirs[k];
-				put(move_code[k]);
-				last_code = move_code[k];
-				sym_index++;
+				// ---- move along the lowest-numbered remaining edge: right, left, down, up
+				const uint32_t k = __ffs(av) - 1;
+				const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
+				if (nraw < cap) cp[nraw] = static_cast<uint8_t>(code); else err |= ENC_ERR_CAPACITY;
+				nraw++;
+				last_code = code;
+				first_symbol = false;
 				prev_t = false;
 				const uint8_t left_behind = static_cast<uint8_t>(av & ~(1u << k));
 				adjt[tnode] = left_behind;
 				adj[node] = left_behind;
-				nx += dxs[k]; ny += dys[k];
+				const uint32_t step = (k & 2u) ? sxe : 1u;
+				if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
+				else { node += step; if (k & 2u) ny++; else nx++; }
 				tnode = tiled_index(nx, ny, tiles_x);
-				av = adjt[tnode] & ~(1u << (k ^ 1));
+				av = adjt[tnode] & ~(1u << (k ^ 1u));
 				adjt[tnode] = static_cast<uint8_t>(av);
-				adj[next] = static_cast<uint8_t>(av);
-				node = next;
+				adj[node] = static_cast<uint8_t>(av);
 			}
 			// the closing 't' (branches_taken returns to 0, crackcodes.hpp:436-439)
-			emit_t(false, 0);
+			if (prev_t) {
+				if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
+				tomb += 2;
+			}
+			else {
+				const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
+				if (nraw + 1 < cap) { cp[nraw] = alt ? CODE_RIGHT : CODE_DOWN; cp[nraw + 1] = alt ? CODE_LEFT : CODE_UP; } else err |= ENC_ERR_CAPACITY;
+				nraw += 2;
+			}
 
 			if (nch < kcap) {
 				ch_node[nch] = adjusted;
