@@ -124,18 +124,15 @@ __global__ void __launch_bounds__(kBlock) k_label_planes(
 // bit0 -> right, bit1 -> left, bit2 -> down, bit3 -> up (crackcodes.hpp:66-125).
 // An interior pixel pair carries a crack when its labels differ (IMPERMISSIBLE) or are
 // equal (PERMISSIBLE); image-border pairs never do.  grid = (ceil(nverts / 256), nslices)
-// The nibbles are stored twice: `adj` in raster order (what next_cluster scans) and
-// `adjt` in 16 x 8 vertex tiles of 128 bytes = one cache line, which the walk reads:
-// a trail then stays inside one line for several steps whichever way it turns, while in
-// raster order every vertical move lands in a cold line.
-__device__ __forceinline__ uint32_t tiled_index(uint32_t x, uint32_t y, uint32_t tiles_x) {
-	return (((y >> 3) * tiles_x + (x >> 4)) << 7) + ((y & 7u) << 4) + (x & 15u);
-}
+// The nibbles are stored in 32 x 32 vertex tiles of 1 KiB (row-major inside a tile, tiles
+// in raster order): the walk caches whole tiles in LDS, one 16-byte load per lane.
+constexpr uint32_t kTileShift = 5, kTileDim = 32, kTileBytes = 1024;
+__device__ __forceinline__ uint32_t tile_of(uint32_t x, uint32_t y, uint32_t tiles_x) { return (y >> kTileShift) * tiles_x + (x >> kTileShift); }
+__device__ __forceinline__ uint32_t tile_local(uint32_t x, uint32_t y) { return ((y & (kTileDim - 1)) << kTileShift) | (x & (kTileDim - 1)); }
 
 __global__ void __launch_bounds__(kBlock) k_crack_graph(
 	const uint32_t* __restrict__ planeV, const uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
-	uint32_t sx, uint32_t sy, uint32_t permissible, uint8_t* __restrict__ adj, uint64_t adj_stride,
-	uint8_t* __restrict__ adjt, uint64_t adjt_stride, uint32_t tiles_x
+	uint32_t sx, uint32_t sy, uint32_t permissible, uint8_t* __restrict__ adjt, uint64_t adjt_stride, uint32_t tiles_x
 ) {
 	const uint32_t zi = blockIdx.y;
 	const uint32_t sxe = sx + 1, sye = sy + 1;
@@ -153,27 +150,26 @@ __global__ void __launch_bounds__(kBlock) k_crack_graph(
 	if (x >= 1 && y >= 1 && y < sy) nib |= bit(ph, x - 1, y) << 1;
 	if (x >= 1 && x < sx && y < sy) nib |= bit(pv, x, y) << 2;            // edge (x,y)-(x,y+1): pixels (x-1,y)|(x,y)
 	if (x >= 1 && x < sx && y >= 1) nib |= bit(pv, x, y - 1) << 3;
-	adj[zi * adj_stride + v] = static_cast<uint8_t>(nib);
-	adjt[zi * adjt_stride + tiled_index(x, y, tiles_x)] = static_cast<uint8_t>(nib);
+	adjt[zi * adjt_stride + static_cast<uint64_t>(tile_of(x, y, tiles_x)) * kTileBytes + tile_local(x, y)] = static_cast<uint8_t>(nib);
 }
 
 // ------------------------------------------------------------------------------
 // the walk: exact restatement of the reference's deterministic depth-first trail
-// (crackcodes.hpp:390-450), one wavefront per slice.  Lane 0 walks; the whole
-// wavefront cooperates on next_cluster (crackcodes.hpp:41-49).  Code points are
-// produced directly, with the two clean-ups folded in:
+// (crackcodes.hpp:390-450), one wavefront per slice.  Lane 0 walks; the wavefront
+// keeps the tiles of the vertex grid the trail is moving through in LDS (4 direct-mapped
+// slots, write-back on eviction), so a step costs an LDS access instead of a dependent
+// round trip to L2/HBM, and cooperates on next_cluster (crackcodes.hpp:41-49).
+// Code points are produced directly, with the two clean-ups folded in:
 //   remove_initial_branch (185-242): decided at the first 't' of a chain;
 //   remove_spurious_branches (250-281): a 't' that directly follows a 't' deletes
 //     itself and the 'b' popped by its predecessor (tombstone 0xFF, compacted later).
 // ------------------------------------------------------------------------------
 struct WalkArgs {
-	uint8_t* adj;
-	uint64_t adj_stride;
-	uint8_t* adjt;            // tiled copy (see tiled_index)
+	uint8_t* adjt;            // tiled vertex nibbles (see tile_of / tile_local)
 	uint64_t adjt_stride;
-	uint32_t tiles_x;
+	uint32_t tiles_x, tiles_y;
 	int sx, sy;
-	const uint64_t* cbase;    // per slice: base into cp / stacks
+	const uint64_t* cbase;    // per slice: base into cp
 	const uint32_t* ccap;     // capacity of cp (codes)
 	const uint64_t* sbase;    // per slice: base into the branch stack
 	const uint32_t* scap;
@@ -195,13 +191,12 @@ enum : uint32_t { ENC_ERR_CAPACITY = 1u };
 enum : uint8_t { CODE_UP = 0, CODE_RIGHT = 1, CODE_DOWN = 2, CODE_LEFT = 3, CODE_NONE = 0xFE, CODE_TOMB = 0xFF };
 
 __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
+	__shared__ __attribute__((aligned(16))) uint8_t s_tile[4][kTileBytes];
 	const uint32_t zi = blockIdx.x;
 	const int lane = threadIdx.x;
-	uint8_t* adj = a.adj + zi * a.adj_stride;
 	uint8_t* adjt = a.adjt + zi * a.adjt_stride;
 	const uint32_t tiles_x = a.tiles_x;
 	const uint32_t sxe = a.sx + 1, sye = a.sy + 1;
-	const uint32_t nverts = sxe * sye;
 	uint8_t* cp = a.cp + a.cbase[zi];
 	const uint32_t cap = a.ccap[zi];
 	uint32_t* st_node = a.stack_node + a.sbase[zi];
@@ -212,135 +207,180 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 	uint32_t* ch_clen = a.chain_clen + a.kbase[zi];
 	const uint32_t kcap = a.kcap[zi];
 
-	uint32_t start = 0;     // wave uniform
-	uint32_t nraw = 0, nch = 0, nvalid = 0, err = 0;   // meaningful in lane 0, broadcast after each chain
+	uint32_t scan_x = 0, scan_y = 0;                    // next_cluster resumes here (wave uniform)
+	uint32_t nraw = 0, nch = 0, nvalid = 0, err = 0;    // meaningful in lane 0
+	constexpr uint32_t kNoTile = 0xFFFFFFFFu;
 
 	for (;;) {
-		// ---- next_cluster: first vertex >= start with edges, 512 vertices per step ----
-		uint32_t found = 0xFFFFFFFFu;
-		for (uint32_t base = start & ~7u; base < nverts; base += kWave * 8) {
-			const uint32_t idx = base + lane * 8;
-			unsigned long long w = 0;
-			if (idx < nverts) {   // adj_stride is padded with zero bytes to a multiple of 8 beyond nverts
-				w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(adj + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			if (idx < start) {    // mask bytes below start (only in the first step)
-				const uint32_t skip = start - idx;
-				w = skip >= 8 ? 0ull : (w >> (8 * skip)) << (8 * skip);
-			}
-			const unsigned long long m = __ballot(w != 0);
-			if (m) {
-				const int first = __ffsll(static_cast<long long>(m)) - 1;
-				const unsigned long long fw = __shfl(w, first, kWave);
-				found = base + first * 8 + ((__ffsll(static_cast<long long>(fw)) - 1) >> 3);
-				break;
+		// ---- next_cluster: first vertex at or after (scan_x, scan_y) in raster order that
+		// still has edges.  Row y lives in tile row y >> 5: lane l reads the 32 bytes of that
+		// row inside tile l (tiles beyond 64 columns in further rounds).  All tiles are in
+		// global memory here (flushed below) and this CU's L1 was invalidated.
+		uint32_t found_x = 0, found_y = 0;
+		bool found = false;
+		for (uint32_t y = scan_y; y < sye && !found; y++) {
+			const uint32_t x_min = (y == scan_y) ? scan_x : 0u;
+			for (uint32_t t0 = 0; t0 < tiles_x && !found; t0 += kWave) {
+				const uint32_t tx = t0 + lane;
+				unsigned long long w[4] = { 0, 0, 0, 0 };
+				if (tx < tiles_x) {
+					const unsigned long long* src = reinterpret_cast<const unsigned long long*>(
+						adjt + static_cast<uint64_t>((y >> kTileShift) * tiles_x + tx) * kTileBytes + ((y & (kTileDim - 1)) << kTileShift));
+#pragma unroll
+					for (int q = 0; q < 4; q++) w[q] = src[q];
+				}
+				// first non-zero byte of my 32 whose x >= x_min
+				uint32_t my = 0xFFFFFFFFu;
+#pragma unroll
+				for (int q = 3; q >= 0; q--) {
+					unsigned long long v = w[q];
+					const uint32_t xq = tx * kTileDim + q * 8u;
+					if (xq + 8u <= x_min) v = 0;
+					else if (xq < x_min) v = (v >> (8u * (x_min - xq))) << (8u * (x_min - xq));
+					if (v) my = xq + ((__ffsll(static_cast<long long>(v)) - 1) >> 3);
+				}
+				const unsigned long long m = __ballot(my != 0xFFFFFFFFu);
+				if (m) {
+					const int first = __ffsll(static_cast<long long>(m)) - 1;
+					found_x = __shfl(my, first, kWave);
+					found_y = y;
+					found = true;
+				}
 			}
 		}
-		if (found == 0xFFFFFFFFu || found >= nverts) break;
-		start = found;
+		if (!found || found_x >= sxe) break;
+		const uint32_t start = found_y * sxe + found_x;
 
-		if (lane == 0 && adj[start] != 0) {
-			// ---- one chain.  All walker state lives in registers: no closures, no
-			// indexed local arrays (both end up in scratch memory, one round trip per use).
-			uint32_t node = start, sp = 0;
-			uint32_t ny = start / sxe, nx = start - ny * sxe;     // coordinates of `node`
-			uint32_t tnode = tiled_index(nx, ny, tiles_x);
-			const uint32_t chain_begin = nraw;
-			uint32_t tomb = 0;
-			bool first_symbol = true;       // nothing emitted yet (symbol index 0)
-			uint32_t last_code = CODE_NONE;
-			bool rib_pending = false;       // chain began with 'b', no other 'b' and no 't' yet
-			bool prev_t = false;            // previous symbol is a live 't' ...
-			uint32_t prev_t_b = 0;          // ... that popped the 'b' whose codes sit at this offset
-			uint32_t adjusted = start;
+		// ---- one chain.  Lane 0's walker state lives in registers: no closures, no indexed
+		// local arrays (both end up in scratch memory).
+		uint32_t node = start, sp = 0;
+		uint32_t nx = found_x, ny = found_y;       // coordinates of `node` (lane 0)
+		const uint32_t chain_begin = nraw;
+		uint32_t tomb = 0;
+		bool first_symbol = true;       // nothing emitted yet (symbol index 0)
+		uint32_t last_code = CODE_NONE;
+		bool rib_pending = false;       // chain began with 'b', no other 'b' and no 't' yet
+		bool prev_t = false;            // previous symbol is a live 't' ...
+		uint32_t prev_t_b = 0;          // ... that popped the 'b' whose codes sit at this offset
+		uint32_t adjusted = start;
+		uint32_t pending_clear = 0;     // edge bit of `node` consumed by the move that led here
+		uint32_t done = 0;
 
-			// every iteration consumes an edge or pops a branch: bounded by the code capacity.
-			// `av` is the nibble of `node`, carried in a register.
-			uint32_t av = adjt[tnode];
-			for (uint32_t guard = 0;; guard++) {
-				if (guard > cap) { err |= ENC_ERR_CAPACITY; break; }
-				if (av == 0) {
+		// tile cache state (wave uniform)
+		uint32_t tag0 = kNoTile, tag1 = kNoTile, tag2 = kNoTile, tag3 = kNoTile, dirty = 0;
+
+		for (uint32_t guard = 0;; guard++) {
+			// -- make sure the tile of `node` is resident
+			const uint32_t ux = __builtin_amdgcn_readfirstlane(nx), uy = __builtin_amdgcn_readfirstlane(ny);
+			const uint32_t tile = tile_of(ux, uy, tiles_x);
+			const uint32_t slot = ((ux >> kTileShift) & 1u) | (((uy >> kTileShift) & 1u) << 1);
+			const uint32_t cur = slot == 0 ? tag0 : slot == 1 ? tag1 : slot == 2 ? tag2 : tag3;
+			if (cur != tile) {
+				uint4* lds = reinterpret_cast<uint4*>(&s_tile[slot][0]) + lane;
+				if (cur != kNoTile && ((dirty >> slot) & 1u)) {
+					*(reinterpret_cast<uint4*>(adjt + static_cast<uint64_t>(cur) * kTileBytes) + lane) = *lds;
+				}
+				// L1-bypassing loads: a tile written back earlier must be read back as written
+				const unsigned long long* src = reinterpret_cast<const unsigned long long*>(adjt + static_cast<uint64_t>(tile) * kTileBytes) + lane * 2;
+				const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				uint4 v;
+				v.x = static_cast<uint32_t>(lo); v.y = static_cast<uint32_t>(lo >> 32);
+				v.z = static_cast<uint32_t>(hi); v.w = static_cast<uint32_t>(hi >> 32);
+				*lds = v;
+				if (slot == 0) tag0 = tile; else if (slot == 1) tag1 = tile; else if (slot == 2) tag2 = tile; else tag3 = tile;
+				dirty &= ~(1u << slot);
+			}
+			dirty |= 1u << slot;
+
+			if (lane == 0) {
+				uint8_t* cell = &s_tile[slot][tile_local(nx, ny)];
+				uint32_t av = *cell & ~pending_clear;
+				pending_clear = 0;
+				if (guard > cap) { err |= ENC_ERR_CAPACITY; done = 1; }
+				else if (av == 0) {
+					*cell = 0;
 					// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
-					if (sp == 0) break;
-					sp--;
-					const uint32_t pnode = st_node[sp], pcode = st_code[sp];
-					if (rib_pending) {
-						// remove_initial_branch (crackcodes.hpp:185-242): drop the leading 'b'
-						// and this 't', walk the first stretch backwards (reverse order,
-						// opposite directions) and start the chain where the stretch ended.
-						rib_pending = false;
-						adjusted = node;
-						if (chain_begin + 1 < cap) { cp[chain_begin] = CODE_TOMB; cp[chain_begin + 1] = CODE_TOMB; }
-						tomb += 2;
-						const uint32_t hi_end = nraw < cap ? nraw : cap;
-						if (hi_end > chain_begin + 2) {
-							uint32_t lo = chain_begin + 2, hi = hi_end - 1;
-							while (lo < hi) {
-								const uint8_t x = cp[lo], y = cp[hi];
-								cp[lo] = y ^ 2; cp[hi] = x ^ 2;
-								lo++; hi--;
-							}
-							if (lo == hi) cp[lo] ^= 2;
-							last_code = cp[hi_end - 1];
-						}
-						prev_t = false;
-					}
-					else if (prev_t) {
-						// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by the
-						// previous 't' and this 't' vanish
-						if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
-						tomb += 2;
-						prev_t_b = pcode;
-					}
+					if (sp == 0) done = 1;
 					else {
-						// (DOWN,UP) unless the previous code is UP, then (RIGHT,LEFT)  (crackcodes.hpp:165-174)
-						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
-						const uint32_t c0 = alt ? CODE_RIGHT : CODE_DOWN, c1 = alt ? CODE_LEFT : CODE_UP;
-						if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else err |= ENC_ERR_CAPACITY;
+						sp--;
+						const uint32_t pnode = st_node[sp], pcode = st_code[sp];
+						if (rib_pending) {
+							// remove_initial_branch (crackcodes.hpp:185-242): drop the leading 'b'
+							// and this 't', walk the first stretch backwards (reverse order,
+							// opposite directions) and start the chain where the stretch ended.
+							rib_pending = false;
+							adjusted = node;
+							if (chain_begin + 1 < cap) { cp[chain_begin] = CODE_TOMB; cp[chain_begin + 1] = CODE_TOMB; }
+							tomb += 2;
+							const uint32_t hi_end = nraw < cap ? nraw : cap;
+							if (hi_end > chain_begin + 2) {
+								uint32_t lo = chain_begin + 2, hi = hi_end - 1;
+								while (lo < hi) {
+									const uint8_t x = cp[lo], y = cp[hi];
+									cp[lo] = y ^ 2; cp[hi] = x ^ 2;
+									lo++; hi--;
+								}
+								if (lo == hi) cp[lo] ^= 2;
+								last_code = cp[hi_end - 1];
+							}
+							prev_t = false;
+						}
+						else if (prev_t) {
+							// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by
+							// the previous 't' and this 't' vanish
+							if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
+							tomb += 2;
+							prev_t_b = pcode;
+						}
+						else {
+							// (DOWN,UP) unless the previous code is UP, then (RIGHT,LEFT)  (crackcodes.hpp:165-174)
+							const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
+							const uint32_t c0 = alt ? CODE_RIGHT : CODE_DOWN, c1 = alt ? CODE_LEFT : CODE_UP;
+							if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else err |= ENC_ERR_CAPACITY;
+							nraw += 2;
+							last_code = c1;
+							prev_t = true;
+							prev_t_b = pcode;
+						}
+						first_symbol = false;
+						node = pnode;
+						ny = node / sxe; nx = node - ny * sxe;
+					}
+				}
+				else {
+					if (av & (av - 1u)) {
+						// ---- 'b': more than one edge left here, remember the vertex
+						rib_pending = first_symbol;
+						if (sp < scap) { st_node[sp] = node; st_code[sp] = nraw; } else err |= ENC_ERR_CAPACITY;
+						sp++;
+						// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
+						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
+						const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
+						if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else { err |= ENC_ERR_CAPACITY; done = 1; }
 						nraw += 2;
 						last_code = c1;
-						prev_t = true;
-						prev_t_b = pcode;
+						first_symbol = false;
 					}
+					// ---- move along the lowest-numbered remaining edge: right, left, down, up
+					const uint32_t k = __ffs(av) - 1;
+					const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
+					if (nraw < cap) cp[nraw] = static_cast<uint8_t>(code); else err |= ENC_ERR_CAPACITY;
+					nraw++;
+					last_code = code;
 					first_symbol = false;
-					node = pnode;
-					ny = node / sxe; nx = node - ny * sxe;
-					tnode = tiled_index(nx, ny, tiles_x);
-					av = adjt[tnode];
-					continue;
+					prev_t = false;
+					*cell = static_cast<uint8_t>(av & ~(1u << k));
+					const uint32_t step = (k & 2u) ? sxe : 1u;
+					if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
+					else { node += step; if (k & 2u) ny++; else nx++; }
+					pending_clear = 1u << (k ^ 1u);
 				}
-				if (av & (av - 1u)) {
-					// ---- 'b': more than one edge left here, remember the vertex
-					rib_pending = first_symbol;
-					if (sp < scap) { st_node[sp] = node; st_code[sp] = nraw; } else err |= ENC_ERR_CAPACITY;
-					sp++;
-					// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
-					const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
-					const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
-					if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else { err |= ENC_ERR_CAPACITY; break; }
-					nraw += 2;
-					last_code = c1;
-					first_symbol = false;
-				}
-				// ---- move along the lowest-numbered remaining edge: right, left, down, up
-				const uint32_t k = __ffs(av) - 1;
-				const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
-				if (nraw < cap) cp[nraw] = static_cast<uint8_t>(code); else err |= ENC_ERR_CAPACITY;
-				nraw++;
-				last_code = code;
-				first_symbol = false;
-				prev_t = false;
-				const uint8_t left_behind = static_cast<uint8_t>(av & ~(1u << k));
-				adjt[tnode] = left_behind;
-				adj[node] = left_behind;
-				const uint32_t step = (k & 2u) ? sxe : 1u;
-				if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
-				else { node += step; if (k & 2u) ny++; else nx++; }
-				tnode = tiled_index(nx, ny, tiles_x);
-				av = adjt[tnode] & ~(1u << (k ^ 1u));
-				adjt[tnode] = static_cast<uint8_t>(av);
-				adj[node] = static_cast<uint8_t>(av);
 			}
+			if (__builtin_amdgcn_readfirstlane(done)) break;
+		}
+
+		if (lane == 0) {
 			// the closing 't' (branches_taken returns to 0, crackcodes.hpp:436-439)
 			if (prev_t) {
 				if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
@@ -351,7 +391,6 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 				if (nraw + 1 < cap) { cp[nraw] = alt ? CODE_RIGHT : CODE_DOWN; cp[nraw + 1] = alt ? CODE_LEFT : CODE_UP; } else err |= ENC_ERR_CAPACITY;
 				nraw += 2;
 			}
-
 			if (nch < kcap) {
 				ch_node[nch] = adjusted;
 				ch_off[nch] = chain_begin;
@@ -361,11 +400,21 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 			nch++;
 			nvalid += (nraw - chain_begin) - tomb;
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		err = __shfl(err, 0, kWave);
-		if (err) break;
-		start = start + 1;   // adj[start] is exhausted now (or was already)
-		if (start >= nverts) break;
+
+		// ---- write the cached tiles back, make them visible to the scan
+#pragma unroll
+		for (uint32_t slot = 0; slot < 4; slot++) {
+			const uint32_t t = slot == 0 ? tag0 : slot == 1 ? tag1 : slot == 2 ? tag2 : tag3;
+			if (t != kNoTile && ((dirty >> slot) & 1u)) {
+				*(reinterpret_cast<uint4*>(adjt + static_cast<uint64_t>(t) * kTileBytes) + lane) = *(reinterpret_cast<const uint4*>(&s_tile[slot][0]) + lane);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		if (__builtin_amdgcn_readfirstlane(err)) break;
+		// the start vertex is exhausted now: resume the scan right after it
+		scan_x = found_x + 1; scan_y = found_y;
+		if (scan_x >= sxe) { scan_x = 0; scan_y++; }
 	}
 	if (lane == 0) {
 		a.n_chains[zi] = nch;
@@ -731,7 +780,7 @@ struct ckl_encoder {
 	int dtype_bytes = 0;
 
 	DevBuf<unsigned long long> d_stats;
-	DevBuf<uint8_t> d_adj, d_adjt;
+	DevBuf<uint8_t> d_adjt;
 	DevBuf<uint32_t> d_slice_err;
 	DevBuf<uint64_t> d_cbase, d_sbase, d_kbase, d_pbase, d_bbase, d_out_off, d_comp_off;
 	DevBuf<uint32_t> d_ccap, d_scap, d_kcap;
@@ -854,18 +903,15 @@ void crack_pass(
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
-	const uint64_t adj_stride = ((nverts + 8 + 511) / 512) * 512;
-	const uint32_t tiles_x = static_cast<uint32_t>((sx + 1 + 15) / 16), tiles_y = static_cast<uint32_t>((sy + 1 + 7) / 8);
-	const uint64_t adjt_stride = static_cast<uint64_t>(tiles_x) * tiles_y * 128;
-	e.d_adj.ensure(adj_stride * ns);
+	const uint32_t tiles_x = static_cast<uint32_t>((sx + 1 + kTileDim - 1) / kTileDim), tiles_y = static_cast<uint32_t>((sy + 1 + kTileDim - 1) / kTileDim);
+	const uint64_t adjt_stride = static_cast<uint64_t>(tiles_x) * tiles_y * kTileBytes;
 	e.d_adjt.ensure(adjt_stride * ns);
 	e.d_slice_err.ensure(ns);
-	CKL_HIP(hipMemsetAsync(e.d_adj.p, 0, adj_stride * ns, s));
+	CKL_HIP(hipMemsetAsync(e.d_adjt.p, 0, adjt_stride * ns, s));
 	CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
 	hipLaunchKernelGGL(k_crack_graph, dim3(static_cast<uint32_t>((nverts + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s,
 		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
-		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, e.d_adj.p, adj_stride,
-		e.d_adjt.p, adjt_stride, tiles_x);
+		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, e.d_adjt.p, adjt_stride, tiles_x);
 	// exact crack edge count per slice: interior pixel pairs that differ (or are equal)
 	const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
 
@@ -897,8 +943,8 @@ void crack_pass(
 	e.d_payload_len.ensure(ns); e.d_boc_len.ensure(ns);
 
 	WalkArgs wa;
-	wa.adjt = e.d_adjt.p; wa.adjt_stride = adjt_stride; wa.tiles_x = tiles_x;
-	wa.adj = e.d_adj.p; wa.adj_stride = adj_stride; wa.sx = static_cast<int>(sx); wa.sy = static_cast<int>(sy);
+	wa.adjt = e.d_adjt.p; wa.adjt_stride = adjt_stride; wa.tiles_x = tiles_x; wa.tiles_y = tiles_y;
+	wa.sx = static_cast<int>(sx); wa.sy = static_cast<int>(sy);
 	wa.cbase = e.d_cbase.p; wa.ccap = e.d_ccap.p; wa.sbase = e.d_sbase.p; wa.scap = e.d_scap.p; wa.kbase = e.d_kbase.p; wa.kcap = e.d_kcap.p;
 	wa.cp = e.d_cp.p; wa.stack_node = e.d_stack_node.p; wa.stack_code = e.d_stack_code.p;
 	wa.chain_node = e.d_chain_node.p; wa.chain_off = e.d_chain_off.p; wa.chain_clen = e.d_chain_clen.p;
