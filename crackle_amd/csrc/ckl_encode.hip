@@ -191,7 +191,9 @@ enum : uint32_t { ENC_ERR_CAPACITY = 1u };
 enum : uint8_t { CODE_UP = 0, CODE_RIGHT = 1, CODE_DOWN = 2, CODE_LEFT = 3, CODE_NONE = 0xFE, CODE_TOMB = 0xFF };
 
 __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
-	__shared__ __attribute__((aligned(16))) uint8_t s_tile[4][kTileBytes];
+	constexpr uint32_t kSlots = 32;     // 8 x 4 tiles: a 256 x 128 vertex window, direct mapped
+	__shared__ __attribute__((aligned(16))) uint8_t s_tile[kSlots][kTileBytes];
+	__shared__ uint32_t s_tag[kSlots], s_dirty[kSlots];
 	const uint32_t zi = blockIdx.x;
 	const int lane = threadIdx.x;
 	uint8_t* adjt = a.adjt + zi * a.adjt_stride;
@@ -264,20 +266,20 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 		uint32_t prev_t_b = 0;          // ... that popped the 'b' whose codes sit at this offset
 		uint32_t adjusted = start;
 		uint32_t pending_clear = 0;     // edge bit of `node` consumed by the move that led here
-		uint32_t done = 0;
+		uint32_t done = 0, guard = 0;
 
-		// tile cache state (wave uniform)
-		uint32_t tag0 = kNoTile, tag1 = kNoTile, tag2 = kNoTile, tag3 = kNoTile, dirty = 0;
+		// tile cache: kSlots direct-mapped slots (tags / dirty flags in LDS, wave uniform)
+		if (lane < static_cast<int>(kSlots)) { s_tag[lane] = kNoTile; s_dirty[lane] = 0; }
 
-		for (uint32_t guard = 0;; guard++) {
+		for (;;) {
 			// -- make sure the tile of `node` is resident
 			const uint32_t ux = __builtin_amdgcn_readfirstlane(nx), uy = __builtin_amdgcn_readfirstlane(ny);
 			const uint32_t tile = tile_of(ux, uy, tiles_x);
-			const uint32_t slot = ((ux >> kTileShift) & 1u) | (((uy >> kTileShift) & 1u) << 1);
-			const uint32_t cur = slot == 0 ? tag0 : slot == 1 ? tag1 : slot == 2 ? tag2 : tag3;
+			const uint32_t slot = ((ux >> kTileShift) & 7u) | (((uy >> kTileShift) & 3u) << 3);
+			const uint32_t cur = s_tag[slot];
 			if (cur != tile) {
 				uint4* lds = reinterpret_cast<uint4*>(&s_tile[slot][0]) + lane;
-				if (cur != kNoTile && ((dirty >> slot) & 1u)) {
+				if (cur != kNoTile && s_dirty[slot]) {
 					*(reinterpret_cast<uint4*>(adjt + static_cast<uint64_t>(cur) * kTileBytes) + lane) = *lds;
 				}
 				// L1-bypassing loads: a tile written back earlier must be read back as written
@@ -288,21 +290,22 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 				v.x = static_cast<uint32_t>(lo); v.y = static_cast<uint32_t>(lo >> 32);
 				v.z = static_cast<uint32_t>(hi); v.w = static_cast<uint32_t>(hi >> 32);
 				*lds = v;
-				if (slot == 0) tag0 = tile; else if (slot == 1) tag1 = tile; else if (slot == 2) tag2 = tile; else tag3 = tile;
-				dirty &= ~(1u << slot);
+				if (lane == 0) s_tag[slot] = tile;
 			}
-			dirty |= 1u << slot;
-
 			if (lane == 0) {
-				uint8_t* cell = &s_tile[slot][tile_local(nx, ny)];
-				uint32_t av = *cell & ~pending_clear;
-				pending_clear = 0;
-				if (guard > cap) { err |= ENC_ERR_CAPACITY; done = 1; }
-				else if (av == 0) {
-					*cell = 0;
-					// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
-					if (sp == 0) done = 1;
-					else {
+				s_dirty[slot] = 1;
+				// -- lane 0 walks for as long as the trail stays inside this tile
+				uint8_t* tbase = &s_tile[slot][0];
+				const uint32_t tx0 = nx >> kTileShift, ty0 = ny >> kTileShift;
+				for (;;) {
+					if (++guard > cap) { err |= ENC_ERR_CAPACITY; done = 1; break; }
+					uint8_t* cell = tbase + tile_local(nx, ny);
+					const uint32_t av = *cell & ~pending_clear;
+					pending_clear = 0;
+					if (av == 0) {
+						*cell = 0;
+						// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
+						if (sp == 0) { done = 1; break; }
 						sp--;
 						const uint32_t pnode = st_node[sp], pcode = st_code[sp];
 						if (rib_pending) {
@@ -347,34 +350,35 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 						node = pnode;
 						ny = node / sxe; nx = node - ny * sxe;
 					}
-				}
-				else {
-					if (av & (av - 1u)) {
-						// ---- 'b': more than one edge left here, remember the vertex
-						rib_pending = first_symbol;
-						if (sp < scap) { st_node[sp] = node; st_code[sp] = nraw; } else err |= ENC_ERR_CAPACITY;
-						sp++;
-						// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
-						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
-						const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
-						if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else { err |= ENC_ERR_CAPACITY; done = 1; }
-						nraw += 2;
-						last_code = c1;
+					else {
+						if (av & (av - 1u)) {
+							// ---- 'b': more than one edge left here, remember the vertex
+							rib_pending = first_symbol;
+							if (sp < scap) { st_node[sp] = node; st_code[sp] = nraw; } else err |= ENC_ERR_CAPACITY;
+							sp++;
+							// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
+							const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
+							const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
+							if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else { err |= ENC_ERR_CAPACITY; done = 1; }
+							nraw += 2;
+							last_code = c1;
+							first_symbol = false;
+						}
+						// ---- move along the lowest-numbered remaining edge: right, left, down, up
+						const uint32_t k = __ffs(av) - 1;
+						const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
+						if (nraw < cap) cp[nraw] = static_cast<uint8_t>(code); else err |= ENC_ERR_CAPACITY;
+						nraw++;
+						last_code = code;
 						first_symbol = false;
+						prev_t = false;
+						*cell = static_cast<uint8_t>(av & ~(1u << k));
+						const uint32_t step = (k & 2u) ? sxe : 1u;
+						if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
+						else { node += step; if (k & 2u) ny++; else nx++; }
+						pending_clear = 1u << (k ^ 1u);
 					}
-					// ---- move along the lowest-numbered remaining edge: right, left, down, up
-					const uint32_t k = __ffs(av) - 1;
-					const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
-					if (nraw < cap) cp[nraw] = static_cast<uint8_t>(code); else err |= ENC_ERR_CAPACITY;
-					nraw++;
-					last_code = code;
-					first_symbol = false;
-					prev_t = false;
-					*cell = static_cast<uint8_t>(av & ~(1u << k));
-					const uint32_t step = (k & 2u) ? sxe : 1u;
-					if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
-					else { node += step; if (k & 2u) ny++; else nx++; }
-					pending_clear = 1u << (k ^ 1u);
+					if (done || (nx >> kTileShift) != tx0 || (ny >> kTileShift) != ty0) break;
 				}
 			}
 			if (__builtin_amdgcn_readfirstlane(done)) break;
@@ -402,10 +406,9 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 		}
 
 		// ---- write the cached tiles back, make them visible to the scan
-#pragma unroll
-		for (uint32_t slot = 0; slot < 4; slot++) {
-			const uint32_t t = slot == 0 ? tag0 : slot == 1 ? tag1 : slot == 2 ? tag2 : tag3;
-			if (t != kNoTile && ((dirty >> slot) & 1u)) {
+		for (uint32_t slot = 0; slot < kSlots; slot++) {
+			const uint32_t t = s_tag[slot];
+			if (t != kNoTile && s_dirty[slot]) {
 				*(reinterpret_cast<uint4*>(adjt + static_cast<uint64_t>(t) * kTileBytes) + lane) = *(reinterpret_cast<const uint4*>(&s_tile[slot][0]) + lane);
 			}
 		}
