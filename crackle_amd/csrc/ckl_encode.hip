@@ -190,7 +190,13 @@ struct WalkArgs {
 enum : uint32_t { ENC_ERR_CAPACITY = 1u };
 enum : uint8_t { CODE_UP = 0, CODE_RIGHT = 1, CODE_DOWN = 2, CODE_LEFT = 3, CODE_NONE = 0xFE, CODE_TOMB = 0xFF };
 
-__global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
+// DIAG builds add cycle stamps and counters (diagnostic only, never timed or shipped):
+// diag[zi*8 + {0 steps, 1 tile fills, 2 pops, 3 scan cycles, 4 fill cycles, 5 walk cycles, 6 total cycles, 7 realtime ticks (100 MHz)}]
+template <bool DIAG>
+__global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* __restrict__ diag) {
+	unsigned long long d_steps = 0, d_fills = 0, d_pops = 0, d_scan = 0, d_fill = 0, d_walk = 0;
+	const unsigned long long d_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+	const unsigned long long d_r0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	constexpr uint32_t kSlots = 32;     // 8 x 4 tiles: a 256 x 128 vertex window, direct mapped
 	__shared__ __attribute__((aligned(16))) uint8_t s_tile[kSlots][kTileBytes];
 	__shared__ uint32_t s_tag[kSlots], s_dirty[kSlots];
@@ -210,7 +216,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 	const uint32_t kcap = a.kcap[zi];
 
 	uint32_t scan_x = 0, scan_y = 0;                    // next_cluster resumes here (wave uniform)
-	uint32_t nraw = 0, nch = 0, nvalid = 0, err = 0;    // meaningful in lane 0
+	uint32_t nraw = 0, nch = 0, nvalid = 0, err = 0;    // wave uniform
 	constexpr uint32_t kNoTile = 0xFFFFFFFFu;
 
 	for (;;) {
@@ -220,6 +226,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 		// global memory here (flushed below) and this CU's L1 was invalidated.
 		uint32_t found_x = 0, found_y = 0;
 		bool found = false;
+		const unsigned long long d_s0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 		for (uint32_t y = scan_y; y < sye && !found; y++) {
 			const uint32_t x_min = (y == scan_y) ? scan_x : 0u;
 			for (uint32_t t0 = 0; t0 < tiles_x && !found; t0 += kWave) {
@@ -250,13 +257,16 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 				}
 			}
 		}
+		if (DIAG) d_scan += __builtin_amdgcn_s_memtime() - d_s0;
 		if (!found || found_x >= sxe) break;
 		const uint32_t start = found_y * sxe + found_x;
 
-		// ---- one chain.  Lane 0's walker state lives in registers: no closures, no indexed
-		// local arrays (both end up in scratch memory).
+		// ---- one chain.  The walker is wave-uniform: every lane carries the same scalar
+		// state (values that come from LDS or global memory pass through readfirstlane), so the
+		// control flow is scalar branches and SALU arithmetic; only stores are predicated on
+		// lane 0.  No closures, no indexed local arrays (both end up in scratch memory).
 		uint32_t node = start, sp = 0;
-		uint32_t nx = found_x, ny = found_y;       // coordinates of `node` (lane 0)
+		uint32_t nx = found_x, ny = found_y;       // coordinates of `node`
 		const uint32_t chain_begin = nraw;
 		uint32_t tomb = 0;
 		bool first_symbol = true;       // nothing emitted yet (symbol index 0)
@@ -266,20 +276,22 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 		uint32_t prev_t_b = 0;          // ... that popped the 'b' whose codes sit at this offset
 		uint32_t adjusted = start;
 		uint32_t pending_clear = 0;     // edge bit of `node` consumed by the move that led here
-		uint32_t done = 0, guard = 0;
+		bool done = false;
+		uint32_t guard = 0;
+		const bool l0 = lane == 0;
 
-		// tile cache: kSlots direct-mapped slots (tags / dirty flags in LDS, wave uniform)
+		// tile cache: kSlots direct-mapped slots (tags / dirty flags in LDS)
 		if (lane < static_cast<int>(kSlots)) { s_tag[lane] = kNoTile; s_dirty[lane] = 0; }
 
 		for (;;) {
 			// -- make sure the tile of `node` is resident
-			const uint32_t ux = __builtin_amdgcn_readfirstlane(nx), uy = __builtin_amdgcn_readfirstlane(ny);
-			const uint32_t tile = tile_of(ux, uy, tiles_x);
-			const uint32_t slot = ((ux >> kTileShift) & 7u) | (((uy >> kTileShift) & 3u) << 3);
-			const uint32_t cur = s_tag[slot];
+			const uint32_t tile = tile_of(nx, ny, tiles_x);
+			const uint32_t slot = ((nx >> kTileShift) & 7u) | (((ny >> kTileShift) & 3u) << 3);
+			const uint32_t cur = __builtin_amdgcn_readfirstlane(s_tag[slot]);
 			if (cur != tile) {
+				const unsigned long long d_f0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 				uint4* lds = reinterpret_cast<uint4*>(&s_tile[slot][0]) + lane;
-				if (cur != kNoTile && s_dirty[slot]) {
+				if (cur != kNoTile && __builtin_amdgcn_readfirstlane(s_dirty[slot])) {
 					*(reinterpret_cast<uint4*>(adjt + static_cast<uint64_t>(cur) * kTileBytes) + lane) = *lds;
 				}
 				// L1-bypassing loads: a tile written back earlier must be read back as written
@@ -290,32 +302,40 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 				v.x = static_cast<uint32_t>(lo); v.y = static_cast<uint32_t>(lo >> 32);
 				v.z = static_cast<uint32_t>(hi); v.w = static_cast<uint32_t>(hi >> 32);
 				*lds = v;
-				if (lane == 0) s_tag[slot] = tile;
+				if (l0) { s_tag[slot] = tile; s_dirty[slot] = 0; }
+				if (DIAG) { __builtin_amdgcn_s_waitcnt(0); d_fill += __builtin_amdgcn_s_memtime() - d_f0; d_fills++; }
 			}
-			if (lane == 0) {
-				s_dirty[slot] = 1;
-				// -- lane 0 walks for as long as the trail stays inside this tile
-				uint8_t* tbase = &s_tile[slot][0];
-				const uint32_t tx0 = nx >> kTileShift, ty0 = ny >> kTileShift;
-				for (;;) {
-					if (++guard > cap) { err |= ENC_ERR_CAPACITY; done = 1; break; }
-					uint8_t* cell = tbase + tile_local(nx, ny);
-					const uint32_t av = *cell & ~pending_clear;
-					pending_clear = 0;
-					if (av == 0) {
-						*cell = 0;
-						// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
-						if (sp == 0) { done = 1; break; }
-						sp--;
-						const uint32_t pnode = st_node[sp], pcode = st_code[sp];
-						if (rib_pending) {
-							// remove_initial_branch (crackcodes.hpp:185-242): drop the leading 'b'
-							// and this 't', walk the first stretch backwards (reverse order,
-							// opposite directions) and start the chain where the stretch ended.
-							rib_pending = false;
-							adjusted = node;
+			if (l0) s_dirty[slot] = 1;
+			const unsigned long long d_w0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+
+			// -- walk for as long as the trail stays inside this tile
+			uint8_t* tbase = &s_tile[slot][0];
+			const uint32_t tx0 = nx >> kTileShift, ty0 = ny >> kTileShift;
+			for (;;) {
+				if (++guard > cap) { err |= ENC_ERR_CAPACITY; done = true; break; }
+				if (DIAG) d_steps++;
+				uint8_t* cell = tbase + tile_local(nx, ny);
+				const uint32_t av = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(*cell)) & ~pending_clear;
+				pending_clear = 0;
+				if (av == 0) {
+					if (l0) *cell = 0;
+					// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
+					if (sp == 0) { done = true; break; }
+					sp--;
+					if (DIAG) d_pops++;
+					// vector (not scalar-cache) loads: the stack was written by lane 0's stores
+					const uint32_t pnode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_node + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+					const uint32_t pcode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_code + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+					if (rib_pending) {
+						// remove_initial_branch (crackcodes.hpp:185-242): drop the leading 'b'
+						// and this 't', walk the first stretch backwards (reverse order,
+						// opposite directions) and start the chain where the stretch ended.
+						rib_pending = false;
+						adjusted = node;
+						tomb += 2;
+						uint32_t lc = last_code;
+						if (l0) {
 							if (chain_begin + 1 < cap) { cp[chain_begin] = CODE_TOMB; cp[chain_begin + 1] = CODE_TOMB; }
-							tomb += 2;
 							const uint32_t hi_end = nraw < cap ? nraw : cap;
 							if (hi_end > chain_begin + 2) {
 								uint32_t lo = chain_begin + 2, hi = hi_end - 1;
@@ -325,96 +345,103 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 									lo++; hi--;
 								}
 								if (lo == hi) cp[lo] ^= 2;
-								last_code = cp[hi_end - 1];
+								lc = cp[hi_end - 1];
 							}
-							prev_t = false;
 						}
-						else if (prev_t) {
-							// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by
-							// the previous 't' and this 't' vanish
-							if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
-							tomb += 2;
-							prev_t_b = pcode;
-						}
-						else {
-							// (DOWN,UP) unless the previous code is UP, then (RIGHT,LEFT)  (crackcodes.hpp:165-174)
-							const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
-							const uint32_t c0 = alt ? CODE_RIGHT : CODE_DOWN, c1 = alt ? CODE_LEFT : CODE_UP;
-							if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else err |= ENC_ERR_CAPACITY;
-							nraw += 2;
-							last_code = c1;
-							prev_t = true;
-							prev_t_b = pcode;
-						}
-						first_symbol = false;
-						node = pnode;
-						ny = node / sxe; nx = node - ny * sxe;
+						last_code = __builtin_amdgcn_readfirstlane(lc);
+						prev_t = false;
+					}
+					else if (prev_t) {
+						// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by
+						// the previous 't' and this 't' vanish
+						if (l0 && prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
+						tomb += 2;
+						prev_t_b = pcode;
 					}
 					else {
-						if (av & (av - 1u)) {
-							// ---- 'b': more than one edge left here, remember the vertex
-							rib_pending = first_symbol;
-							if (sp < scap) { st_node[sp] = node; st_code[sp] = nraw; } else err |= ENC_ERR_CAPACITY;
-							sp++;
-							// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
-							const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
-							const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
-							if (nraw + 1 < cap) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } else { err |= ENC_ERR_CAPACITY; done = 1; }
-							nraw += 2;
-							last_code = c1;
-							first_symbol = false;
-						}
-						// ---- move along the lowest-numbered remaining edge: right, left, down, up
-						const uint32_t k = __ffs(av) - 1;
-						const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
-						if (nraw < cap) cp[nraw] = static_cast<uint8_t>(code); else err |= ENC_ERR_CAPACITY;
-						nraw++;
-						last_code = code;
-						first_symbol = false;
-						prev_t = false;
-						*cell = static_cast<uint8_t>(av & ~(1u << k));
-						const uint32_t step = (k & 2u) ? sxe : 1u;
-						if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
-						else { node += step; if (k & 2u) ny++; else nx++; }
-						pending_clear = 1u << (k ^ 1u);
+						// (DOWN,UP) unless the previous code is UP, then (RIGHT,LEFT)  (crackcodes.hpp:165-174)
+						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
+						const uint32_t c0 = alt ? CODE_RIGHT : CODE_DOWN, c1 = alt ? CODE_LEFT : CODE_UP;
+						if (nraw + 1 < cap) { if (l0) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } }
+						else err |= ENC_ERR_CAPACITY;
+						nraw += 2;
+						last_code = c1;
+						prev_t = true;
+						prev_t_b = pcode;
 					}
-					if (done || (nx >> kTileShift) != tx0 || (ny >> kTileShift) != ty0) break;
+					first_symbol = false;
+					node = pnode;
+					ny = node / sxe; nx = node - ny * sxe;
 				}
+				else {
+					if (av & (av - 1u)) {
+						// ---- 'b': more than one edge left here, remember the vertex
+						rib_pending = first_symbol;
+						if (sp < scap) { if (l0) { st_node[sp] = node; st_code[sp] = nraw; } }
+						else err |= ENC_ERR_CAPACITY;
+						sp++;
+						// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
+						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
+						const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
+						if (nraw + 1 < cap) { if (l0) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } }
+						else { err |= ENC_ERR_CAPACITY; done = true; }
+						nraw += 2;
+						last_code = c1;
+						first_symbol = false;
+					}
+					// ---- move along the lowest-numbered remaining edge: right, left, down, up
+					const uint32_t k = __ffs(av) - 1;
+					const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
+					if (nraw < cap) { if (l0) cp[nraw] = static_cast<uint8_t>(code); }
+					else err |= ENC_ERR_CAPACITY;
+					nraw++;
+					last_code = code;
+					first_symbol = false;
+					prev_t = false;
+					if (l0) *cell = static_cast<uint8_t>(av & ~(1u << k));
+					const uint32_t step = (k & 2u) ? sxe : 1u;
+					if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
+					else { node += step; if (k & 2u) ny++; else nx++; }
+					pending_clear = 1u << (k ^ 1u);
+				}
+				if (done || (nx >> kTileShift) != tx0 || (ny >> kTileShift) != ty0) break;
 			}
-			if (__builtin_amdgcn_readfirstlane(done)) break;
+			if (DIAG) d_walk += __builtin_amdgcn_s_memtime() - d_w0;
+			if (done) break;
 		}
 
-		if (lane == 0) {
-			// the closing 't' (branches_taken returns to 0, crackcodes.hpp:436-439)
-			if (prev_t) {
-				if (prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
-				tomb += 2;
-			}
-			else {
-				const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
-				if (nraw + 1 < cap) { cp[nraw] = alt ? CODE_RIGHT : CODE_DOWN; cp[nraw + 1] = alt ? CODE_LEFT : CODE_UP; } else err |= ENC_ERR_CAPACITY;
-				nraw += 2;
-			}
-			if (nch < kcap) {
+		// the closing 't' (branches_taken returns to 0, crackcodes.hpp:436-439)
+		if (prev_t) {
+			if (l0 && prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
+			tomb += 2;
+		}
+		else {
+			const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
+			if (nraw + 1 < cap) { if (l0) { cp[nraw] = alt ? CODE_RIGHT : CODE_DOWN; cp[nraw + 1] = alt ? CODE_LEFT : CODE_UP; } }
+			else err |= ENC_ERR_CAPACITY;
+			nraw += 2;
+		}
+		if (nch < kcap) {
+			if (l0) {
 				ch_node[nch] = adjusted;
 				ch_off[nch] = chain_begin;
 				ch_clen[nch] = (nraw - chain_begin) - tomb;
 			}
-			else err |= ENC_ERR_CAPACITY;
-			nch++;
-			nvalid += (nraw - chain_begin) - tomb;
 		}
+		else err |= ENC_ERR_CAPACITY;
+		nch++;
+		nvalid += (nraw - chain_begin) - tomb;
 
 		// ---- write the cached tiles back, make them visible to the scan
 		for (uint32_t slot = 0; slot < kSlots; slot++) {
-			const uint32_t t = s_tag[slot];
-			if (t != kNoTile && s_dirty[slot]) {
+			const uint32_t t = __builtin_amdgcn_readfirstlane(s_tag[slot]);
+			if (t != kNoTile && __builtin_amdgcn_readfirstlane(s_dirty[slot])) {
 				*(reinterpret_cast<uint4*>(adjt + static_cast<uint64_t>(t) * kTileBytes) + lane) = *(reinterpret_cast<const uint4*>(&s_tile[slot][0]) + lane);
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		if (__builtin_amdgcn_readfirstlane(err)) break;
+		if (err) break;
 		// the start vertex is exhausted now: resume the scan right after it
 		scan_x = found_x + 1; scan_y = found_y;
 		if (scan_x >= sxe) { scan_x = 0; scan_y++; }
@@ -424,6 +451,12 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a) {
 		a.n_raw[zi] = nraw;
 		a.n_valid[zi] = nvalid;
 		if (err) atomicOr(a.slice_err + zi, err);
+		if (DIAG && diag) {
+			unsigned long long* o = diag + static_cast<uint64_t>(zi) * 8;
+			o[0] = d_steps; o[1] = d_fills; o[2] = d_pops; o[3] = d_scan; o[4] = d_fill; o[5] = d_walk;
+			o[6] = __builtin_amdgcn_s_memtime() - d_t0;
+			o[7] = __builtin_amdgcn_s_memrealtime() - d_r0;
+		}
 	}
 }
 
@@ -953,7 +986,18 @@ void crack_pass(
 	wa.chain_node = e.d_chain_node.p; wa.chain_off = e.d_chain_off.p; wa.chain_clen = e.d_chain_clen.p;
 	wa.n_chains = e.d_n_chains.p; wa.n_raw = e.d_n_raw.p; wa.n_valid = e.d_n_valid.p; wa.slice_err = e.d_slice_err.p;
 	CKL_HIP(hipEventRecord(e.evk0, s));
-	hipLaunchKernelGGL(k_walk, dim3(ns), dim3(kWave), 0, s, wa);
+	if (getenv("CKL_WALK_DIAG")) {
+		DevBuf<unsigned long long> d_diag;
+		d_diag.ensure(static_cast<size_t>(ns) * 8);
+		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 64, s));
+		hipLaunchKernelGGL(k_walk<true>, dim3(ns), dim3(kWave), 0, s, wa, d_diag.p);
+		std::vector<unsigned long long> dg = download(d_diag.p, static_cast<size_t>(ns) * 8, s);
+		double m[8] = { 0 };
+		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 8; k++) m[k] += static_cast<double>(dg[zi * 8 + k]) / ns;
+		fprintf(stderr, "[ckl walk diag, mean per slice] steps=%.0f fills=%.0f pops=%.0f scan_cyc=%.0f fill_cyc=%.0f walk_cyc=%.0f total_cyc=%.0f realtime_us=%.1f (clock %.2f GHz)\n",
+			m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7] / 100.0, m[6] / (m[7] * 10.0));
+	}
+	else hipLaunchKernelGGL(k_walk<false>, dim3(ns), dim3(kWave), 0, s, wa, static_cast<unsigned long long*>(nullptr));
 	CKL_HIP(hipEventRecord(e.evk1, s));
 
 	std::vector<uint32_t> n_chains = download(e.d_n_chains.p, ns, s);
