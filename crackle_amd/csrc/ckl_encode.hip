@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(kBlock) k_label_planes(
 // The nibbles are stored in 32 x 32 vertex tiles of 1 KiB (row-major inside a tile, tiles
 // in raster order): the walk caches whole tiles in LDS, one 16-byte load per lane.
 constexpr uint32_t kTileShift = 5, kTileDim = 32, kTileBytes = 1024;
+constexpr uint32_t kTileMoves = 2 * kTileDim * (kTileDim + 1);   // edges that touch one tile: the most moves per residency
 __device__ __forceinline__ uint32_t tile_of(uint32_t x, uint32_t y, uint32_t tiles_x) { return (y >> kTileShift) * tiles_x + (x >> kTileShift); }
 __device__ __forceinline__ uint32_t tile_local(uint32_t x, uint32_t y) { return ((y & (kTileDim - 1)) << kTileShift) | (x & (kTileDim - 1)); }
 
@@ -185,6 +186,7 @@ struct WalkArgs {
 	uint32_t* n_raw;          // [nslices]
 	uint32_t* n_valid;        // [nslices]
 	uint32_t* slice_err;
+	uint32_t dbg;             // DIAG builds only: bit0 skip code stores, bit1 skip stack stores (timing experiments)
 };
 
 enum : uint32_t { ENC_ERR_CAPACITY = 1u };
@@ -279,6 +281,8 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 		bool done = false;
 		uint32_t guard = 0;
 		const bool l0 = lane == 0;
+		const bool st_cp = l0 && !(DIAG && (a.dbg & 1u));     // lane 0 stores code points
+		const bool st_stk = l0 && !(DIAG && (a.dbg & 2u));    // lane 0 stores the branch stack
 
 		// tile cache: kSlots direct-mapped slots (tags / dirty flags in LDS)
 		if (lane < static_cast<int>(kSlots)) { s_tag[lane] = kNoTile; s_dirty[lane] = 0; }
@@ -308,15 +312,47 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 			if (l0) s_dirty[slot] = 1;
 			const unsigned long long d_w0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 
-			// -- walk for as long as the trail stays inside this tile
+			// -- walk for as long as the trail stays inside this tile.  `local` indexes the
+			// vertex inside the resident tile (5 bits of y, 5 bits of x).
 			uint8_t* tbase = &s_tile[slot][0];
 			const uint32_t tx0 = nx >> kTileShift, ty0 = ny >> kTileShift;
+			if (++guard > cap || nraw + kTileMoves > cap) { err |= ENC_ERR_CAPACITY; done = true; break; }
+			uint32_t local = tile_local(nx, ny);
 			for (;;) {
-				if (++guard > cap) { err |= ENC_ERR_CAPACITY; done = true; break; }
 				if (DIAG) d_steps++;
-				uint8_t* cell = tbase + tile_local(nx, ny);
-				const uint32_t av = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(*cell)) & ~pending_clear;
+				const uint32_t av = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tbase[local])) & ~pending_clear;
 				pending_clear = 0;
+				if (av != 0 && (av & (av - 1u)) == 0) {
+					// ---- fast path: exactly one edge left, the trail passes straight through.
+					// At most kTileMoves of these per residency (each consumes an edge of the tile).
+					const uint32_t k = __ffs(av) - 1;
+					const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
+					if (st_cp) cp[nraw] = static_cast<uint8_t>(code);
+					nraw++;
+					last_code = code;
+					first_symbol = false;
+					prev_t = false;
+					if (l0) tbase[local] = 0;
+					pending_clear = 1u << (k ^ 1u);
+					const uint32_t coord = (k & 2u) ? (local >> kTileShift) : (local & (kTileDim - 1));
+					const uint32_t delta = (k & 2u) ? kTileDim : 1u;
+					if (coord != ((k & 1u) ? 0u : kTileDim - 1)) {
+						local = (k & 1u) ? local - delta : local + delta;
+						continue;
+					}
+					// leaving the tile: materialise the coordinates of the next vertex
+					nx = (tx0 << kTileShift) + (local & (kTileDim - 1));
+					ny = (ty0 << kTileShift) + (local >> kTileShift);
+					if (k & 2u) ny = (k & 1u) ? ny - 1 : ny + 1; else nx = (k & 1u) ? nx - 1 : nx + 1;
+					node = ny * sxe + nx;
+					break;
+				}
+				// ---- general path: dead end ('t') or branch vertex ('b' + move)
+				nx = (tx0 << kTileShift) + (local & (kTileDim - 1));
+				ny = (ty0 << kTileShift) + (local >> kTileShift);
+				node = ny * sxe + nx;
+				uint8_t* cell = tbase + local;
+				if (++guard > cap) { err |= ENC_ERR_CAPACITY; done = true; break; }
 				if (av == 0) {
 					if (l0) *cell = 0;
 					// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
@@ -362,7 +398,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 						// (DOWN,UP) unless the previous code is UP, then (RIGHT,LEFT)  (crackcodes.hpp:165-174)
 						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
 						const uint32_t c0 = alt ? CODE_RIGHT : CODE_DOWN, c1 = alt ? CODE_LEFT : CODE_UP;
-						if (nraw + 1 < cap) { if (l0) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } }
+						if (nraw + 1 < cap) { if (st_cp) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } }
 						else err |= ENC_ERR_CAPACITY;
 						nraw += 2;
 						last_code = c1;
@@ -374,27 +410,20 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 					ny = node / sxe; nx = node - ny * sxe;
 				}
 				else {
-					if (av & (av - 1u)) {
-						// ---- 'b': more than one edge left here, remember the vertex
-						rib_pending = first_symbol;
-						if (sp < scap) { if (l0) { st_node[sp] = node; st_code[sp] = nraw; } }
-						else err |= ENC_ERR_CAPACITY;
-						sp++;
-						// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
-						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
-						const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
-						if (nraw + 1 < cap) { if (l0) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } }
-						else { err |= ENC_ERR_CAPACITY; done = true; }
-						nraw += 2;
-						last_code = c1;
-						first_symbol = false;
-					}
-					// ---- move along the lowest-numbered remaining edge: right, left, down, up
-					const uint32_t k = __ffs(av) - 1;
-					const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
-					if (nraw < cap) { if (l0) cp[nraw] = static_cast<uint8_t>(code); }
+					// ---- 'b': more than one edge left here, remember the vertex
+					rib_pending = first_symbol;
+					if (sp < scap) { if (st_stk) { st_node[sp] = node; st_code[sp] = nraw; } }
 					else err |= ENC_ERR_CAPACITY;
-					nraw++;
+					sp++;
+					// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
+					const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
+					const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
+					// ---- then move along the lowest-numbered remaining edge: right, left, down, up
+					const uint32_t k = __ffs(av) - 1;
+					const uint32_t code = (0x0231u >> (4u * k)) & 3u;
+					if (nraw + 2 < cap) { if (st_cp) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); cp[nraw + 2] = static_cast<uint8_t>(code); } }
+					else { err |= ENC_ERR_CAPACITY; done = true; }
+					nraw += 3;
 					last_code = code;
 					first_symbol = false;
 					prev_t = false;
@@ -405,6 +434,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 					pending_clear = 1u << (k ^ 1u);
 				}
 				if (done || (nx >> kTileShift) != tx0 || (ny >> kTileShift) != ty0) break;
+				local = tile_local(nx, ny);
 			}
 			if (DIAG) d_walk += __builtin_amdgcn_s_memtime() - d_w0;
 			if (done) break;
@@ -960,7 +990,7 @@ void crack_pass(
 		const uint64_t differ = static_cast<uint64_t>(e.count_v[zi]) + e.count_h[zi];
 		const uint64_t E = permissible ? interior - differ : differ;
 		any = any || E > 0;
-		const uint64_t cc = 7 * E + 16;
+		const uint64_t cc = 7 * E + 16 + 2 * kTileMoves;
 		if (cc > 0xFFFFFFF0ull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: slice has too many crack edges");
 		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cc); ctot += cc;
 		sbase[zi] = stot; scap[zi] = static_cast<uint32_t>(E + 1); stot += E + 1;
@@ -986,7 +1016,9 @@ void crack_pass(
 	wa.chain_node = e.d_chain_node.p; wa.chain_off = e.d_chain_off.p; wa.chain_clen = e.d_chain_clen.p;
 	wa.n_chains = e.d_n_chains.p; wa.n_raw = e.d_n_raw.p; wa.n_valid = e.d_n_valid.p; wa.slice_err = e.d_slice_err.p;
 	CKL_HIP(hipEventRecord(e.evk0, s));
+	wa.dbg = 0;
 	if (getenv("CKL_WALK_DIAG")) {
+		wa.dbg = static_cast<uint32_t>(atoi(getenv("CKL_WALK_DIAG"))) >> 4;     // CKL_WALK_DIAG=1: plain; 17: skip code stores; 33: skip stack stores
 		DevBuf<unsigned long long> d_diag;
 		d_diag.ensure(static_cast<size_t>(ns) * 8);
 		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 64, s));
