@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 				const unsigned long long m = __ballot(my != 0xFFFFFFFFu);
 				if (m) {
 					const int first = __ffsll(static_cast<long long>(m)) - 1;
-					found_x = __shfl(my, first, kWave);
+					found_x = __builtin_amdgcn_readfirstlane(__shfl(my, first, kWave));   // provably uniform from here on
 					found_y = y;
 					found = true;
 				}
@@ -271,14 +271,17 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 		uint32_t nx = found_x, ny = found_y;       // coordinates of `node`
 		const uint32_t chain_begin = nraw;
 		uint32_t tomb = 0;
-		bool first_symbol = true;       // nothing emitted yet (symbol index 0)
+		// flag word (plain integer bits: boolean variables would be kept as 64-bit lane masks)
+		//   F_FIRST  nothing emitted yet (symbol index 0)
+		//   F_PREVT  previous symbol is a live 't' that popped the 'b' whose codes sit at prev_t_b
+		//   F_RIB    chain began with 'b', no other 'b' and no 't' yet
+		constexpr uint32_t F_FIRST = 1u, F_PREVT = 2u, F_RIB = 4u;
+		uint32_t flags = F_FIRST;
 		uint32_t last_code = CODE_NONE;
-		bool rib_pending = false;       // chain began with 'b', no other 'b' and no 't' yet
-		bool prev_t = false;            // previous symbol is a live 't' ...
-		uint32_t prev_t_b = 0;          // ... that popped the 'b' whose codes sit at this offset
+		uint32_t prev_t_b = 0;
 		uint32_t adjusted = start;
 		uint32_t pending_clear = 0;     // edge bit of `node` consumed by the move that led here
-		bool done = false;
+		uint32_t done = 0;
 		uint32_t guard = 0;
 		const bool l0 = lane == 0;
 		const bool st_cp = l0 && !(DIAG && (a.dbg & 1u));     // lane 0 stores code points
@@ -288,6 +291,8 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 		if (lane < static_cast<int>(kSlots)) { s_tag[lane] = kNoTile; s_dirty[lane] = 0; }
 
 		for (;;) {
+			nx = __builtin_amdgcn_readfirstlane(nx); ny = __builtin_amdgcn_readfirstlane(ny);
+			node = __builtin_amdgcn_readfirstlane(node); sp = __builtin_amdgcn_readfirstlane(sp);
 			// -- make sure the tile of `node` is resident
 			const uint32_t tile = tile_of(nx, ny, tiles_x);
 			const uint32_t slot = ((nx >> kTileShift) & 7u) | (((ny >> kTileShift) & 3u) << 3);
@@ -316,10 +321,17 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 			// vertex inside the resident tile (5 bits of y, 5 bits of x).
 			uint8_t* tbase = &s_tile[slot][0];
 			const uint32_t tx0 = nx >> kTileShift, ty0 = ny >> kTileShift;
-			if (++guard > cap || nraw + kTileMoves > cap) { err |= ENC_ERR_CAPACITY; done = true; break; }
+			if (++guard > cap || nraw + kTileMoves > cap) { err |= ENC_ERR_CAPACITY; done = 1; break; }
 			uint32_t local = tile_local(nx, ny);
 			for (;;) {
 				if (DIAG) d_steps++;
+				// pin the loop-carried state to scalar registers (the uniformity analysis gives up
+				// on this loop nest otherwise and emits exec-masked vector code)
+				local = __builtin_amdgcn_readfirstlane(local);
+				pending_clear = __builtin_amdgcn_readfirstlane(pending_clear);
+				nraw = __builtin_amdgcn_readfirstlane(nraw);
+				last_code = __builtin_amdgcn_readfirstlane(last_code);
+				flags = __builtin_amdgcn_readfirstlane(flags);
 				const uint32_t av = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tbase[local])) & ~pending_clear;
 				pending_clear = 0;
 				if (av != 0 && (av & (av - 1u)) == 0) {
@@ -330,8 +342,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 					if (st_cp) cp[nraw] = static_cast<uint8_t>(code);
 					nraw++;
 					last_code = code;
-					first_symbol = false;
-					prev_t = false;
+					flags &= F_RIB;
 					if (l0) tbase[local] = 0;
 					pending_clear = 1u << (k ^ 1u);
 					const uint32_t coord = (k & 2u) ? (local >> kTileShift) : (local & (kTileDim - 1));
@@ -352,21 +363,20 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 				ny = (ty0 << kTileShift) + (local >> kTileShift);
 				node = ny * sxe + nx;
 				uint8_t* cell = tbase + local;
-				if (++guard > cap) { err |= ENC_ERR_CAPACITY; done = true; break; }
+				if (++guard > cap) { err |= ENC_ERR_CAPACITY; done = 1; break; }
 				if (av == 0) {
 					if (l0) *cell = 0;
 					// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
-					if (sp == 0) { done = true; break; }
+					if (sp == 0) { done = 1; break; }
 					sp--;
 					if (DIAG) d_pops++;
 					// vector (not scalar-cache) loads: the stack was written by lane 0's stores
 					const uint32_t pnode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_node + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 					const uint32_t pcode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_code + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-					if (rib_pending) {
+					if (flags & F_RIB) {
 						// remove_initial_branch (crackcodes.hpp:185-242): drop the leading 'b'
 						// and this 't', walk the first stretch backwards (reverse order,
 						// opposite directions) and start the chain where the stretch ended.
-						rib_pending = false;
 						adjusted = node;
 						tomb += 2;
 						uint32_t lc = last_code;
@@ -385,48 +395,47 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 							}
 						}
 						last_code = __builtin_amdgcn_readfirstlane(lc);
-						prev_t = false;
+						flags = 0;
 					}
-					else if (prev_t) {
+					else if (flags & F_PREVT) {
 						// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by
 						// the previous 't' and this 't' vanish
 						if (l0 && prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
 						tomb += 2;
 						prev_t_b = pcode;
+						flags = F_PREVT;
 					}
 					else {
 						// (DOWN,UP) unless the previous code is UP, then (RIGHT,LEFT)  (crackcodes.hpp:165-174)
-						const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
+						const bool alt = (flags & F_FIRST) || last_code == CODE_NONE || last_code == CODE_UP;
 						const uint32_t c0 = alt ? CODE_RIGHT : CODE_DOWN, c1 = alt ? CODE_LEFT : CODE_UP;
 						if (nraw + 1 < cap) { if (st_cp) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } }
 						else err |= ENC_ERR_CAPACITY;
 						nraw += 2;
 						last_code = c1;
-						prev_t = true;
+						flags = F_PREVT;
 						prev_t_b = pcode;
 					}
-					first_symbol = false;
 					node = pnode;
 					ny = node / sxe; nx = node - ny * sxe;
 				}
 				else {
 					// ---- 'b': more than one edge left here, remember the vertex
-					rib_pending = first_symbol;
+					const uint32_t was_first = flags & F_FIRST;
 					if (sp < scap) { if (st_stk) { st_node[sp] = node; st_code[sp] = nraw; } }
 					else err |= ENC_ERR_CAPACITY;
 					sp++;
 					// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
-					const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_DOWN;
+					const bool alt = was_first || last_code == CODE_NONE || last_code == CODE_DOWN;
 					const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
 					// ---- then move along the lowest-numbered remaining edge: right, left, down, up
 					const uint32_t k = __ffs(av) - 1;
 					const uint32_t code = (0x0231u >> (4u * k)) & 3u;
 					if (nraw + 2 < cap) { if (st_cp) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); cp[nraw + 2] = static_cast<uint8_t>(code); } }
-					else { err |= ENC_ERR_CAPACITY; done = true; }
+					else { err |= ENC_ERR_CAPACITY; done = 1; }
 					nraw += 3;
 					last_code = code;
-					first_symbol = false;
-					prev_t = false;
+					flags = was_first ? F_RIB : 0u;
 					if (l0) *cell = static_cast<uint8_t>(av & ~(1u << k));
 					const uint32_t step = (k & 2u) ? sxe : 1u;
 					if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
@@ -441,12 +450,12 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 		}
 
 		// the closing 't' (branches_taken returns to 0, crackcodes.hpp:436-439)
-		if (prev_t) {
+		if (flags & F_PREVT) {
 			if (l0 && prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
 			tomb += 2;
 		}
 		else {
-			const bool alt = first_symbol || last_code == CODE_NONE || last_code == CODE_UP;
+			const bool alt = (flags & F_FIRST) || last_code == CODE_NONE || last_code == CODE_UP;
 			if (nraw + 1 < cap) { if (l0) { cp[nraw] = alt ? CODE_RIGHT : CODE_DOWN; cp[nraw + 1] = alt ? CODE_LEFT : CODE_UP; } }
 			else err |= ENC_ERR_CAPACITY;
 			nraw += 2;
