@@ -193,10 +193,10 @@ enum : uint32_t { ENC_ERR_CAPACITY = 1u };
 enum : uint8_t { CODE_UP = 0, CODE_RIGHT = 1, CODE_DOWN = 2, CODE_LEFT = 3, CODE_NONE = 0xFE, CODE_TOMB = 0xFF };
 
 // DIAG builds add cycle stamps and counters (diagnostic only, never timed or shipped):
-// diag[zi*8 + {0 steps, 1 tile fills, 2 pops, 3 scan cycles, 4 fill cycles, 5 walk cycles, 6 total cycles, 7 realtime ticks (100 MHz)}]
+// diag[zi*16 + {0 steps, 1 tile fills, 2 pops, 3 scan cycles, 4 fill cycles, 5 walk cycles, 6 total cycles, 7 realtime ticks (100 MHz)}]
 template <bool DIAG>
 __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* __restrict__ diag) {
-	unsigned long long d_steps = 0, d_fills = 0, d_pops = 0, d_scan = 0, d_fill = 0, d_walk = 0;
+	unsigned long long d_steps = 0, d_fills = 0, d_pops = 0, d_scan = 0, d_fill = 0, d_walk = 0, d_gen = 0, d_ngen = 0;
 	const unsigned long long d_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 	const unsigned long long d_r0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	constexpr uint32_t kSlots = 32;     // 8 x 4 tiles: a 256 x 128 vertex window, direct mapped
@@ -324,41 +324,46 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 			if (++guard > cap || nraw + kTileMoves > cap) { err |= ENC_ERR_CAPACITY; done = 1; break; }
 			uint32_t local = tile_local(nx, ny);
 			for (;;) {
-				if (DIAG) d_steps++;
-				// pin the loop-carried state to scalar registers (the uniformity analysis gives up
-				// on this loop nest otherwise and emits exec-masked vector code)
+				// ---- fast run: while exactly one edge is left at the vertex the trail passes
+				// straight through.  Everything is wave uniform, so the stores need no lane
+				// predicate (all lanes write the same byte to the same address) and the loop is
+				// a handful of scalar instructions around one LDS read.  At most kTileMoves
+				// iterations per residency (each consumes an edge of the tile), which the
+				// capacity check above covers.
 				local = __builtin_amdgcn_readfirstlane(local);
 				pending_clear = __builtin_amdgcn_readfirstlane(pending_clear);
 				nraw = __builtin_amdgcn_readfirstlane(nraw);
-				last_code = __builtin_amdgcn_readfirstlane(last_code);
-				flags = __builtin_amdgcn_readfirstlane(flags);
-				const uint32_t av = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tbase[local])) & ~pending_clear;
-				pending_clear = 0;
-				if (av != 0 && (av & (av - 1u)) == 0) {
-					// ---- fast path: exactly one edge left, the trail passes straight through.
-					// At most kTileMoves of these per residency (each consumes an edge of the tile).
-					const uint32_t k = __ffs(av) - 1;
-					const uint32_t code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
-					if (st_cp) cp[nraw] = static_cast<uint8_t>(code);
+				uint32_t av, code = 0, k = 0, moved = 0, left_tile = 0;
+				for (;;) {
+					if (DIAG) d_steps++;
+					av = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tbase[local])) & ~pending_clear;
+					pending_clear = 0;
+					if (av == 0 || (av & (av - 1u)) != 0) break;
+					k = __ffs(av) - 1;
+					code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
+					if (!(DIAG && (a.dbg & 1u))) cp[nraw] = static_cast<uint8_t>(code);
 					nraw++;
-					last_code = code;
-					flags &= F_RIB;
-					if (l0) tbase[local] = 0;
+					moved = 1;
+					tbase[local] = 0;
 					pending_clear = 1u << (k ^ 1u);
 					const uint32_t coord = (k & 2u) ? (local >> kTileShift) : (local & (kTileDim - 1));
+					if (coord == ((k & 1u) ? 0u : kTileDim - 1)) { left_tile = 1; break; }
 					const uint32_t delta = (k & 2u) ? kTileDim : 1u;
-					if (coord != ((k & 1u) ? 0u : kTileDim - 1)) {
-						local = (k & 1u) ? local - delta : local + delta;
-						continue;
-					}
-					// leaving the tile: materialise the coordinates of the next vertex
+					local = (k & 1u) ? local - delta : local + delta;
+				}
+				if (moved) { last_code = code; flags &= F_RIB; }
+				if (left_tile) {
+					// materialise the coordinates of the next vertex (in a neighbouring tile)
 					nx = (tx0 << kTileShift) + (local & (kTileDim - 1));
 					ny = (ty0 << kTileShift) + (local >> kTileShift);
 					if (k & 2u) ny = (k & 1u) ? ny - 1 : ny + 1; else nx = (k & 1u) ? nx - 1 : nx + 1;
 					node = ny * sxe + nx;
 					break;
 				}
+				last_code = __builtin_amdgcn_readfirstlane(last_code);
+				flags = __builtin_amdgcn_readfirstlane(flags);
 				// ---- general path: dead end ('t') or branch vertex ('b' + move)
+				const unsigned long long d_g0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 				nx = (tx0 << kTileShift) + (local & (kTileDim - 1));
 				ny = (ty0 << kTileShift) + (local >> kTileShift);
 				node = ny * sxe + nx;
@@ -442,6 +447,7 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 					else { node += step; if (k & 2u) ny++; else nx++; }
 					pending_clear = 1u << (k ^ 1u);
 				}
+				if (DIAG) { d_gen += __builtin_amdgcn_s_memtime() - d_g0; d_ngen++; }
 				if (done || (nx >> kTileShift) != tx0 || (ny >> kTileShift) != ty0) break;
 				local = tile_local(nx, ny);
 			}
@@ -491,8 +497,8 @@ __global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* 
 		a.n_valid[zi] = nvalid;
 		if (err) atomicOr(a.slice_err + zi, err);
 		if (DIAG && diag) {
-			unsigned long long* o = diag + static_cast<uint64_t>(zi) * 8;
-			o[0] = d_steps; o[1] = d_fills; o[2] = d_pops; o[3] = d_scan; o[4] = d_fill; o[5] = d_walk;
+			unsigned long long* o = diag + static_cast<uint64_t>(zi) * 16;
+			o[0] = d_steps; o[1] = d_fills; o[2] = d_ngen; o[3] = d_scan; o[4] = d_fill; o[5] = d_walk; o[8] = d_gen; o[9] = d_pops;
 			o[6] = __builtin_amdgcn_s_memtime() - d_t0;
 			o[7] = __builtin_amdgcn_s_memrealtime() - d_r0;
 		}
@@ -1029,14 +1035,14 @@ void crack_pass(
 	if (getenv("CKL_WALK_DIAG")) {
 		wa.dbg = static_cast<uint32_t>(atoi(getenv("CKL_WALK_DIAG"))) >> 4;     // CKL_WALK_DIAG=1: plain; 17: skip code stores; 33: skip stack stores
 		DevBuf<unsigned long long> d_diag;
-		d_diag.ensure(static_cast<size_t>(ns) * 8);
-		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 64, s));
+		d_diag.ensure(static_cast<size_t>(ns) * 16);
+		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 128, s));
 		hipLaunchKernelGGL(k_walk<true>, dim3(ns), dim3(kWave), 0, s, wa, d_diag.p);
-		std::vector<unsigned long long> dg = download(d_diag.p, static_cast<size_t>(ns) * 8, s);
-		double m[8] = { 0 };
-		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 8; k++) m[k] += static_cast<double>(dg[zi * 8 + k]) / ns;
-		fprintf(stderr, "[ckl walk diag, mean per slice] steps=%.0f fills=%.0f pops=%.0f scan_cyc=%.0f fill_cyc=%.0f walk_cyc=%.0f total_cyc=%.0f realtime_us=%.1f (clock %.2f GHz)\n",
-			m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7] / 100.0, m[6] / (m[7] * 10.0));
+		std::vector<unsigned long long> dg = download(d_diag.p, static_cast<size_t>(ns) * 16, s);
+		double m[16] = { 0 };
+		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
+		fprintf(stderr, "[ckl walk diag, mean per slice] steps=%.0f fills=%.0f general=%.0f pops=%.0f scan_cyc=%.0f fill_cyc=%.0f walk_cyc=%.0f general_cyc=%.0f total_cyc=%.0f realtime_us=%.1f (clock %.2f GHz)\n",
+			m[0], m[1], m[2], m[9], m[3], m[4], m[5], m[8], m[6], m[7] / 100.0, m[6] / (m[7] * 10.0));
 	}
 	else hipLaunchKernelGGL(k_walk<false>, dim3(ns), dim3(kWave), 0, s, wa, static_cast<unsigned long long*>(nullptr));
 	CKL_HIP(hipEventRecord(e.evk1, s));
