@@ -822,12 +822,39 @@ static int pins_encode(
 	const header_t* head, int stored_width, int auto_bgcolor, int64_t manual_bgcolor,
 	bytes_t* labels_binary, uint32_t* crcs);
 
+/* Sharded-encode hooks (test infrastructure for crackle_amd/distributed.py): the
+ * whole-volume decisions of compress (src/crackle.hpp:48-64, 107-130, 233-235) can be
+ * imposed from outside, exactly like ckl_encode_overrides in include/crackle_amd.h.
+ * force_crack_format / force_label_format < 0 and force_stored_width == 0 mean "decide
+ * from this volume"; model (4^order x 4 bytes, symbol -> rank) may be NULL. */
+int ckl_oracle_compress_ex(
+	const void* labels_v, int dtype_bytes, int is_signed,
+	int64_t sx, int64_t sy, int64_t sz,
+	int allow_pins, int fortran_order, uint64_t markov_order,
+	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
+	uint64_t parallel,
+	int force_crack_format, int force_label_format, int force_stored_width, const uint8_t* forced_model,
+	unsigned char** out, uint64_t* out_len);
+
 int ckl_oracle_compress(
 	const void* labels_v, int dtype_bytes, int is_signed,
 	int64_t sx, int64_t sy, int64_t sz,
 	int allow_pins, int fortran_order, uint64_t markov_order,
 	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
 	uint64_t parallel, unsigned char** out, uint64_t* out_len
+) {
+	return ckl_oracle_compress_ex(labels_v, dtype_bytes, is_signed, sx, sy, sz, allow_pins, fortran_order,
+		markov_order, optimize_pins, auto_bgcolor, manual_bgcolor, parallel, -1, -1, 0, NULL, out, out_len);
+}
+
+int ckl_oracle_compress_ex(
+	const void* labels_v, int dtype_bytes, int is_signed,
+	int64_t sx, int64_t sy, int64_t sz,
+	int allow_pins, int fortran_order, uint64_t markov_order,
+	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
+	uint64_t parallel,
+	int force_crack_format, int force_label_format, int force_stored_width, const uint8_t* forced_model,
+	unsigned char** out, uint64_t* out_len
 ) {
 	if (is_signed) FAIL("ckl_oracle: signed labels are rejected by crackle.compress (crackle/codec.py:720-721)");
 	if (optimize_pins) FAIL("ckl_oracle: allow_pins=2 (find_optimal_pins) is out of scope (SURVEY.md section 2 row 6)");
@@ -839,7 +866,7 @@ int ckl_oracle_compress(
 	/* max_label + compute_byte_width (src/lib.hpp:224-247) */
 	uint64_t mx = 0;
 	for (int64_t i = 0; i < voxels; i++) if (labels[i] > mx) mx = labels[i];
-	const int stored_width = byte_width(mx);
+	const int stored_width = force_stored_width ? force_stored_width : byte_width(mx);
 	/* pixel_pairs (src/lib.hpp:249-256) */
 	uint64_t num_pairs = 0;
 	for (int64_t i = 1; i < voxels; i++) num_pairs += (labels[i] == labels[i - 1]);
@@ -853,7 +880,12 @@ int ckl_oracle_compress(
 		head.crack_format = PERMISSIBLE;
 		head.label_format = FLAT;
 	}
+	if (force_crack_format >= 0) {
+		head.crack_format = force_crack_format;
+		head.label_format = force_crack_format == PERMISSIBLE ? FLAT : PINS_VARIABLE_WIDTH;
+	}
 	if (sz == 1 || !allow_pins) head.label_format = FLAT;
+	if (force_label_format >= 0) head.label_format = force_label_format;
 	head.is_signed = 0;
 	head.data_width = dtype_bytes;
 	head.stored_data_width = stored_width;
@@ -885,7 +917,7 @@ int ckl_oracle_compress(
 	if (head.markov_model_order > 0) {   /* src/crackle.hpp:107-118 */
 		int empty = 1;
 		for (int64_t z = 0; z < sz; z++) if (e.chains[z].n) { empty = 0; break; }
-		if (empty) head.markov_model_order = 0;
+		if (empty && !forced_model) head.markov_model_order = 0;
 	}
 
 	bytes_t stored_model = { 0 };
@@ -895,9 +927,12 @@ int ckl_oracle_compress(
 		const size_t rows = (size_t)1 << (2 * order);
 		e.order = order;
 		e.stats = (uint32_t*)xcalloc(rows * 4, sizeof(uint32_t));
-		parallel_for(sz, threads, enc_stats_task, &e);
 		uint8_t* model = (uint8_t*)xmalloc(rows * 4);
-		mk_stats_to_model(e.stats, rows, model);
+		if (forced_model) memcpy(model, forced_model, rows * 4);
+		else {
+			parallel_for(sz, threads, enc_stats_task, &e);
+			mk_stats_to_model(e.stats, rows, model);
+		}
 		rc = mk_to_stored(model, rows, &stored_model);
 		e.model = model;
 		if (!rc) parallel_for(sz, threads, enc_markov_task, &e);
@@ -1448,6 +1483,48 @@ int ckl_oracle_slice_vcg(const unsigned char* buf, uint64_t n, int64_t z, uint8_
 	}
 	dec_free(&d, 0);
 	return rc;
+}
+
+/* lib::max_label / pixel_pairs (src/lib.hpp:224-256) of one slab plus its first and last
+ * voxel: what a sharded encoder all-gathers. */
+int ckl_oracle_stats(
+	const void* labels_v, int dtype_bytes, int64_t sx, int64_t sy, int64_t sz,
+	uint64_t* max_label, uint64_t* pixel_pairs, uint64_t* first_voxel, uint64_t* last_voxel
+) {
+	const int64_t voxels = sx * sy * sz;
+	uint64_t* labels = widen(labels_v, dtype_bytes, (uint64_t)voxels);
+	uint64_t mx = 0, pairs = 0;
+	for (int64_t i = 0; i < voxels; i++) if (labels[i] > mx) mx = labels[i];
+	for (int64_t i = 1; i < voxels; i++) pairs += (labels[i] == labels[i - 1]);
+	*max_label = mx; *pixel_pairs = pairs;
+	*first_voxel = voxels ? labels[0] : 0;
+	*last_voxel = voxels ? labels[voxels - 1] : 0;
+	free(labels);
+	return 0;
+}
+
+/* markov::gather_statistics (src/markov.hpp:193-220) of one slab under a given crack format */
+int ckl_oracle_markov_hist(
+	const void* labels_v, int dtype_bytes, int64_t sx, int64_t sy, int64_t sz,
+	int crack_format, uint64_t order, uint32_t* hist
+) {
+	if (order == 0 || order > 15) FAIL("ckl_oracle: bad markov order");
+	const int64_t voxels = sx * sy * sz;
+	const size_t rows = (size_t)1 << (2 * order);
+	memset(hist, 0, rows * 4 * sizeof(uint32_t));
+	if (voxels == 0) return 0;
+	uint64_t* labels = widen(labels_v, dtype_bytes, (uint64_t)voxels);
+	for (int64_t z = 0; z < sz; z++) {
+		chainset_t cs;
+		create_crack_codes(labels + sx * sy * z, sx, sy, crack_format == PERMISSIBLE, &cs);
+		size_t n;
+		uint8_t* d = slice_diffcodes(&cs, &n);
+		mk_stats_slice(d, n, (int)order, hist);
+		free(d);
+		chainset_free(&cs);
+	}
+	free(labels);
+	return 0;
 }
 
 /* ------------------------------------------------------------------ */

@@ -27,6 +27,22 @@ int ckl_oracle_compress(
 	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
 	uint64_t parallel, unsigned char** out, uint64_t* out_len);
 
+/* compress with the whole-volume decisions imposed (sharded-encode tests) */
+int ckl_oracle_compress_ex(
+	const void* labels, int dtype_bytes, int is_signed,
+	int64_t sx, int64_t sy, int64_t sz,
+	int allow_pins, int fortran_order, uint64_t markov_order,
+	int optimize_pins, int auto_bgcolor, int64_t manual_bgcolor,
+	uint64_t parallel,
+	int force_crack_format, int force_label_format, int force_stored_width, const uint8_t* forced_model,
+	unsigned char** out, uint64_t* out_len);
+int ckl_oracle_stats(
+	const void* labels, int dtype_bytes, int64_t sx, int64_t sy, int64_t sz,
+	uint64_t* max_label, uint64_t* pixel_pairs, uint64_t* first_voxel, uint64_t* last_voxel);
+int ckl_oracle_markov_hist(
+	const void* labels, int dtype_bytes, int64_t sx, int64_t sy, int64_t sz,
+	int crack_format, uint64_t order, uint32_t* hist);
+
 /* mirrors crackle::decompress<LABEL,OUT> (src/crackle.hpp:503-663) */
 int ckl_oracle_decompress(
 	const unsigned char* buf, uint64_t n, void* out,

@@ -1,0 +1,97 @@
+"""World-size-2 gloo tests of the sharded codec orchestration
+(crackle_amd/distributed.py): the reductions, the model agreement, the gather and the
+zstack merge must reproduce, byte for byte, what a single encoder produces for the
+whole volume.  The per-slab compute is injected: here the CPU oracle (the product
+backend is the HIP library; its sharded path runs under RCCL in bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from crackle_amd import synth
+from crackle_amd import distributed as ckd
+
+WORLD = 2
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _volume(kind):
+  if kind == "voronoi":
+    return synth.as_numpy_f(synth.voronoi_labels((96, 80, 12), np.uint16, seed=4, cell=(16, 16, 4)))
+  if kind == "wide_labels":
+    # max label lives in the second slab only: stored width must come from the all-gather
+    v = synth.as_numpy_f(synth.voronoi_labels((64, 48, 8), np.uint32, seed=6, cell=(16, 16, 4), modulus=200)).copy(order="F")
+    v[3:9, 4:7, 6] = 70000
+    return v
+  if kind == "noise":
+    # PERMISSIBLE crack format decided by the summed pixel_pairs
+    return synth.random_labels((48, 40, 6), np.uint32, seed=3, high=2000)
+  if kind == "constant":
+    return np.full((40, 30, 4), 5, np.uint8, order="F")
+  raise ValueError(kind)
+
+
+def _worker(rank, port, kind, order, q):
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from oracle_backend import OracleBackend
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+  try:
+    vol = _volume(kind)
+    sx, sy, sz = vol.shape
+    szl = sz // WORLD
+    slab = np.asfortranarray(vol[:, :, rank * szl:(rank + 1) * szl])
+    codec = ckd.ShardedCodec(OracleBackend(), rank=rank, world=WORLD, device="cpu")
+    binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order)
+    session = codec.open_decoder(binary, (sx, sy, szl))
+    back = np.zeros_like(slab)
+    session.run(back)
+    q.put((rank, binary, bool(np.array_equal(back, slab))))
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,order", [("voronoi", 0), ("voronoi", 3), ("wide_labels", 0), ("noise", 2), ("constant", 4)])
+def test_sharded_compress_equals_whole_volume(port, kind, order):
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  p = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, p, kind, order, q)) for r in range(WORLD)]
+  for pr in procs:
+    pr.start()
+  results = {}
+  for _ in range(WORLD):
+    rank, binary, ok = q.get(timeout=120)
+    results[rank] = (binary, ok)
+  for pr in procs:
+    pr.join(timeout=60)
+    assert pr.exitcode == 0
+  vol = _volume(kind)
+  whole = port.compress(vol, markov_model_order=order)
+  assert results[0][0] == whole, "merged slab streams differ from the whole-volume stream"
+  assert results[1][0] is None
+  assert results[0][1] and results[1][1], "a rank decoded its z-range wrongly"
+
+
+def test_stats_to_model_matches_reference_tie_rule(port):
+  # count descending, ties towards the larger symbol; an all-zero row is (3,2,1,0)
+  hist = np.array([[0, 0, 0, 0], [5, 5, 1, 9], [7, 7, 7, 2], [1, 2, 3, 4]], dtype=np.uint32)
+  m = ckd.stats_to_model(hist)
+  # symbol -> rank
+  assert m[0].tolist() == [3, 2, 1, 0]
+  assert m[1].tolist() == [2, 1, 3, 0]
+  assert m[2].tolist() == [2, 1, 0, 3]
+  assert m[3].tolist() == [3, 2, 1, 0]
