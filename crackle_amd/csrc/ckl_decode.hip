@@ -76,11 +76,24 @@ __device__ __forceinline__ uint32_t rd_le_dev(const uint8_t* p, int w) {
 	return v;
 }
 
-__global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
-	__shared__ uint32_t s_scan[4 * kWaves];
-	__shared__ int32_t s_scanmax[kWaves];
-	__shared__ uint32_t s_last_move[kBlock];
-	__shared__ uint32_t s_last_ctrl[kBlock];
+// DIAG builds stamp the phase boundaries (diagnostic only): diag[zi*8 + {A, B, C, D}] cycles
+constexpr int kCrackBlock = 1024;                 // threads per slice
+constexpr int kCrackWaves = kCrackBlock / kWave;
+
+template <bool DIAG>
+__global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsigned long long* __restrict__ diag) {
+	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+	auto stamp = [&](int slot) {
+		if (DIAG && threadIdx.x == 0 && diag) {
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			diag[static_cast<uint64_t>(blockIdx.x) * 8 + slot] = now - d_t;
+			d_t = now;
+		}
+	};
+	__shared__ uint32_t s_scan[4 * kCrackWaves];
+	__shared__ int32_t s_scanmax[kCrackWaves];
+	__shared__ uint32_t s_last_move[kCrackBlock];
+	__shared__ uint32_t s_last_ctrl[kCrackBlock];
 	constexpr uint32_t kStackLds = 2048;
 	__shared__ uint32_t s_stack[kStackLds];
 	__shared__ uint32_t s_nnodes, s_ncodes, s_nsyms, s_nctl, s_valid_segs, s_err;
@@ -168,6 +181,7 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 		s_err = err;
 	}
 	__syncthreads();
+	stamp(0);
 	const uint32_t n_codes = s_ncodes;
 	const uint32_t n_nodes = s_nnodes;
 	const uint32_t index_end = 4u + (code_len >= 4u ? rd_le_dev(code, 4) : 0u);
@@ -189,7 +203,7 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 	int32_t carry_lf = -1;           // last position whose `reverse-of-previous` test was false
 	uint32_t carry_nsym = 0, carry_nt = 0, carry_nctl = 0, carry_pos = 0;
 	constexpr uint32_t kPer = 16;
-	constexpr uint32_t kTile = kBlock * kPer;
+	constexpr uint32_t kTile = kCrackBlock * kPer;
 
 	if (n_nodes > 0 && n_codes > 0) {
 		for (uint32_t tile = 0; tile <= n_codes; tile += kTile) {
@@ -208,7 +222,7 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 				dc[k] = tsum;   // inclusive local sum mod 4
 			}
 			uint32_t v1[1] = { tsum }, t1[1];
-			block_excl_add<1>(v1, t1, s_scan);
+			block_excl_add<1, kCrackWaves>(v1, t1, s_scan);
 			const uint32_t base_sum = (carry_sum + v1[0]) & 3u;
 			uint32_t mv[kPer];
 #pragma unroll
@@ -216,7 +230,7 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 			s_last_move[tid] = mv[kPer - 1];
 			__syncthreads();
 			const uint32_t prev_move = tid ? s_last_move[tid - 1] : carry_move;
-			const uint32_t tile_last_move = s_last_move[kBlock - 1];
+			const uint32_t tile_last_move = s_last_move[kCrackBlock - 1];
 
 			// -- r[g]: code g is the exact reverse of code g-1; runs of r alternate ctrl/move
 			uint32_t rmask = 0;
@@ -230,7 +244,7 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 				else lf = static_cast<int32_t>(g);
 			}
 			int32_t lf_tot;
-			int32_t lf_in = block_excl_max(lf, lf_tot, s_scanmax);
+			int32_t lf_in = block_excl_max<kCrackWaves>(lf, lf_tot, s_scanmax);
 			if (lf_in < carry_lf) lf_in = carry_lf;
 			uint32_t cmask = 0;   // ctrl flags of my 16 codes
 			{
@@ -245,7 +259,7 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 			s_last_ctrl[tid] = (cmask >> (kPer - 1)) & 1u;
 			__syncthreads();
 			const uint32_t prev_ctrl = tid ? s_last_ctrl[tid - 1] : carry_ctrl;
-			const uint32_t tile_last_ctrl = s_last_ctrl[kBlock - 1];
+			const uint32_t tile_last_ctrl = s_last_ctrl[kCrackBlock - 1];
 
 			// -- events: position g emits the symbol of code g-1 unless g-1 was a control half
 			uint32_t kinds = 0;        // 3 bits per event slot k
@@ -269,7 +283,7 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 				}
 			}
 			uint32_t v4[4] = { n_ev, n_t, n_ctl, dpos }, t4[4];
-			block_excl_add<4>(v4, t4, s_scan);
+			block_excl_add<4, kCrackWaves>(v4, t4, s_scan);
 			uint32_t o_sym = carry_nsym + v4[0], o_t = carry_nt + v4[1], o_ctl = carry_nctl + v4[2], o_pos = carry_pos + v4[3];
 #pragma unroll
 			for (uint32_t k = 0; k < kPer; k++) {
@@ -306,6 +320,7 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 		if (carry_nsym > cap) s_err |= ERR_CAPACITY;
 	}
 	__syncthreads();
+	stamp(1);
 	const uint32_t n_syms = s_nsyms, n_ctl = s_nctl;
 
 	// ---- phase C: branch matching over the control symbols, 64 at a time by wave 0 ----
@@ -436,43 +451,65 @@ __global__ void __launch_bounds__(kBlock) k_decode_cracks(CrackArgs a) {
 		if (tid == 0) s_valid_segs = valid;
 	}
 	__syncthreads();
+	stamp(2);
 	const uint32_t valid_segs = s_valid_segs;
 
 	// ---- phase D: rasterise every move into the crack planes (crackcodes.hpp:706-862) ----
+	// A thread takes 8 consecutive symbols; consecutive moves of a straight horizontal
+	// stretch fall into the same plane word, so their bits are merged in a register and
+	// OR-ed into memory once (neighbouring lanes otherwise serialise on one L2 line).
 	uint32_t* pv = a.planeV + zi * a.plane_words;
 	uint32_t* ph = a.planeH + zi * a.plane_words;
 	uint32_t err = 0;
 	const uint32_t sx = a.sx, sy = a.sy;
-	for (uint32_t s = tid; s < n_syms; s += kBlock) {
-		const uint32_t kind = sym_kind[s];
-		if (kind >= SYM_B) continue;
-		const uint32_t seg = sym_seg[s];
-		if (seg >= valid_segs) continue;
-		const uint32_t t = seg_off[seg] + sym_pos[s];
-		if (t >= nverts) { err |= ERR_RANGE; continue; }
-		const uint32_t y = t / sxe;
-		const uint32_t x = t - y * sxe;
-		// vertical moves cross planeV, horizontal moves cross planeH
-		if (kind == SYM_D) {          // edge (x,y)-(x,y+1): between pixels (x-1,y) | (x,y)
-			if (x >= 1 && x < sx && y < sy) atomicOr(pv + static_cast<uint64_t>(y) * a.row_words + (x >> 5), 1u << (x & 31));
-			else if (y >= sy) err |= ERR_RANGE;
+	constexpr uint32_t kChunk = 8;
+	for (uint32_t s0 = tid * kChunk; s0 < n_syms; s0 += kCrackBlock * kChunk) {
+		uint32_t* cur_word = nullptr;
+		uint32_t cur_bits = 0;
+		const uint32_t s1 = s0 + kChunk < n_syms ? s0 + kChunk : n_syms;
+		for (uint32_t s = s0; s < s1; s++) {
+			const uint32_t kind = sym_kind[s];
+			if (kind >= SYM_B) continue;
+			const uint32_t seg = sym_seg[s];
+			if (seg >= valid_segs) continue;
+			const uint32_t t = seg_off[seg] + sym_pos[s];
+			if (t >= nverts) { err |= ERR_RANGE; continue; }
+			const uint32_t y = t / sxe;
+			const uint32_t x = t - y * sxe;
+			// vertical moves cross planeV, horizontal moves cross planeH
+			uint32_t* word = nullptr;
+			uint32_t bx = 0;
+			if (kind == SYM_D) {          // edge (x,y)-(x,y+1): between pixels (x-1,y) | (x,y)
+				if (x >= 1 && x < sx && y < sy) { word = pv + static_cast<uint64_t>(y) * a.row_words + (x >> 5); bx = x; }
+				else if (y >= sy) err |= ERR_RANGE;
+			}
+			else if (kind == SYM_U) {     // edge (x,y-1)-(x,y)
+				if (x >= 1 && x < sx && y >= 1) { word = pv + static_cast<uint64_t>(y - 1) * a.row_words + (x >> 5); bx = x; }
+				else if (y < 1) err |= ERR_RANGE;
+			}
+			else if (kind == SYM_R) {     // edge (x,y)-(x+1,y): between pixels (x,y-1) | (x,y)
+				if (y >= 1 && y < sy && x < sx) { word = ph + static_cast<uint64_t>(y) * a.row_words + (x >> 5); bx = x; }
+				else if (x >= sx) err |= ERR_RANGE;
+			}
+			else {                        // SYM_L: edge (x-1,y)-(x,y)
+				if (y >= 1 && y < sy && x >= 1) { word = ph + static_cast<uint64_t>(y) * a.row_words + ((x - 1) >> 5); bx = x - 1; }
+				else if (x < 1) err |= ERR_RANGE;
+			}
+			if (!word) continue;
+			if (word != cur_word) {
+				if (cur_word) atomicOr(cur_word, cur_bits);
+				cur_word = word;
+				cur_bits = 0;
+			}
+			cur_bits |= 1u << (bx & 31);
 		}
-		else if (kind == SYM_U) {     // edge (x,y-1)-(x,y)
-			if (x >= 1 && x < sx && y >= 1) atomicOr(pv + static_cast<uint64_t>(y - 1) * a.row_words + (x >> 5), 1u << (x & 31));
-			else if (y < 1) err |= ERR_RANGE;
-		}
-		else if (kind == SYM_R) {     // edge (x,y)-(x+1,y): between pixels (x,y-1) | (x,y)
-			if (y >= 1 && y < sy && x < sx) atomicOr(ph + static_cast<uint64_t>(y) * a.row_words + (x >> 5), 1u << (x & 31));
-			else if (x >= sx) err |= ERR_RANGE;
-		}
-		else {                        // SYM_L: edge (x-1,y)-(x,y)
-			if (y >= 1 && y < sy && x >= 1) atomicOr(ph + static_cast<uint64_t>(y) * a.row_words + ((x - 1) >> 5), 1u << ((x - 1) & 31));
-			else if (x < 1) err |= ERR_RANGE;
-		}
+		if (cur_word) atomicOr(cur_word, cur_bits);
 	}
 	if (err) atomicOr(&s_err, err);
 	__syncthreads();
+	stamp(3);
 	if (tid == 0 && s_err) atomicOr(a.slice_err + zi, s_err);
+	if (DIAG && tid == 0 && diag) { diag[static_cast<uint64_t>(zi) * 8 + 4] = n_codes; diag[static_cast<uint64_t>(zi) * 8 + 5] = n_ctl; diag[static_cast<uint64_t>(zi) * 8 + 6] = n_syms; }
 }
 
 // ------------------------------------------------------------------------------
@@ -1026,7 +1063,19 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.planeV = d.d_planes.p; ca.planeH = d.d_planes.p + d.plane_words * ns;
 	ca.row_words = d.row_words; ca.plane_words = d.plane_words;
 	ca.slice_err = d.d_slice_err.p;
-	hipLaunchKernelGGL(k_decode_cracks, dim3(ns), dim3(kBlock), 0, s, ca);
+	if (getenv("CKL_DECODE_DIAG")) {
+		DevBuf<unsigned long long> d_diag;
+		d_diag.ensure(static_cast<size_t>(ns) * 8);
+		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 64, s));
+		hipLaunchKernelGGL(k_decode_cracks<true>, dim3(ns), dim3(kCrackBlock), 0, s, ca, d_diag.p);
+		std::vector<unsigned long long> dg(static_cast<size_t>(ns) * 8);
+		CKL_HIP(hipMemcpyAsync(dg.data(), d_diag.p, dg.size() * 8, hipMemcpyDeviceToHost, s));
+		CKL_HIP(hipStreamSynchronize(s));
+		double m[8] = { 0 };
+		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 8; k++) m[k] += static_cast<double>(dg[zi * 8 + k]) / ns;
+		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f symbols=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+	}
+	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), 0, s, ca, static_cast<unsigned long long*>(nullptr));
 	st.done("k_decode_cracks");
 
 	RunGeom g;

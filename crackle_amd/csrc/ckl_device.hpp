@@ -43,9 +43,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // Exclusive block scan (sum) of K values per thread at once.  `lds` must hold
-// K * kWaves uint32.  Returns exclusive prefixes in v[], block totals in total[].
+// K * NW uint32 (NW = wavefronts per workgroup).  Returns exclusive prefixes in v[], block totals in total[].
 // Ends with a barrier so `lds` can be reused immediately.
-template <int K>
+template <int K, int NW = kWaves>
 __device__ __forceinline__ void block_excl_add(uint32_t (&v)[K], uint32_t (&total)[K], uint32_t* lds) {
 	const int lane = threadIdx.x & (kWave - 1);
 	const int wave = threadIdx.x >> 6;
@@ -53,15 +53,15 @@ __device__ __forceinline__ void block_excl_add(uint32_t (&v)[K], uint32_t (&tota
 #pragma unroll
 	for (int k = 0; k < K; k++) {
 		incl[k] = wave_incl_add(v[k]);
-		if (lane == kWave - 1) lds[k * kWaves + wave] = incl[k];
+		if (lane == kWave - 1) lds[k * NW + wave] = incl[k];
 	}
 	__syncthreads();
 #pragma unroll
 	for (int k = 0; k < K; k++) {
 		uint32_t base = 0, tot = 0;
 #pragma unroll
-		for (int w = 0; w < kWaves; w++) {
-			uint32_t s = lds[k * kWaves + w];
+		for (int w = 0; w < NW; w++) {
+			uint32_t s = lds[k * NW + w];
 			if (w < wave) base += s;
 			tot += s;
 		}
@@ -71,7 +71,8 @@ __device__ __forceinline__ void block_excl_add(uint32_t (&v)[K], uint32_t (&tota
 	__syncthreads();
 }
 
-// Exclusive block max-scan of one int32 (identity INT32_MIN).  lds: kWaves int32.
+// Exclusive block max-scan of one int32 (identity INT32_MIN).  lds: NW int32.
+template <int NW = kWaves>
 __device__ __forceinline__ int32_t block_excl_max(int32_t v, int32_t& total, int32_t* lds) {
 	const int lane = threadIdx.x & (kWave - 1);
 	const int wave = threadIdx.x >> 6;
@@ -82,7 +83,7 @@ __device__ __forceinline__ int32_t block_excl_max(int32_t v, int32_t& total, int
 	__syncthreads();
 	int32_t base = INT32_MIN, tot = INT32_MIN;
 #pragma unroll
-	for (int w = 0; w < kWaves; w++) {
+	for (int w = 0; w < NW; w++) {
 		int32_t s = lds[w];
 		if (w < wave) base = s > base ? s : base;
 		tot = s > tot ? s : tot;
