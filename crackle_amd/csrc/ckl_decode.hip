@@ -55,11 +55,10 @@ struct CrackArgs {
 	int markov_order;
 	const uint8_t* model;        // [4^order][4] rank -> symbol
 	uint8_t* ucode;              // unpacked difference codes (markov only)
-	uint8_t* sym_kind;
-	uint32_t* sym_pos;           // exclusive prefix sum of move displacements (mod 2^32)
-	uint32_t* sym_seg;           // number of 't' symbols before the symbol
-	uint32_t* ctl_sym;           // symbol index of every control symbol, in order
-	uint32_t* seg_off;           // per segment: vertex offset to add to sym_pos
+	uint8_t* ctl_kind;           // control symbols ('b'/'t') in stream order
+	uint32_t* ctl_pos;           // displacement prefix sum (mod 2^32) before each control symbol
+	uint32_t* ctl_seg;           // number of 't' symbols before each control symbol
+	uint32_t* seg_off;           // per segment: vertex offset to add to the displacement
 	uint32_t* stack;
 	uint32_t* nodes;
 	uint32_t* planeV;
@@ -69,19 +68,26 @@ struct CrackArgs {
 	uint32_t* slice_err;         // [nslices] sticky error bits
 };
 
-
 __device__ __forceinline__ uint32_t rd_le_dev(const uint8_t* p, int w) {
 	uint32_t v = 0;
 	for (int i = 0; i < w; i++) v |= static_cast<uint32_t>(p[i]) << (8 * i);
 	return v;
 }
 
-// DIAG builds stamp the phase boundaries (diagnostic only): diag[zi*8 + {A, B, C, D}] cycles
 constexpr int kCrackBlock = 1024;                 // threads per slice
 constexpr int kCrackWaves = kCrackBlock / kWave;
 
+// DIAG builds stamp the phase boundaries (diagnostic only): diag[zi*8 + {A, B, C, D}] cycles
 template <bool DIAG>
 __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsigned long long* __restrict__ diag) {
+	__shared__ uint32_t s_scan[4 * kCrackWaves];
+	__shared__ int32_t s_scanmax[kCrackWaves];
+	__shared__ uint32_t s_last_move[kCrackBlock];
+	__shared__ uint32_t s_last_ctrl[kCrackBlock];
+	constexpr uint32_t kStackLds = 2048;
+	__shared__ uint32_t s_stack[kStackLds];
+	__shared__ uint32_t s_nnodes, s_ncodes, s_nctl, s_valid_segs, s_err;
+
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 	auto stamp = [&](int slot) {
 		if (DIAG && threadIdx.x == 0 && diag) {
@@ -90,13 +96,6 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			d_t = now;
 		}
 	};
-	__shared__ uint32_t s_scan[4 * kCrackWaves];
-	__shared__ int32_t s_scanmax[kCrackWaves];
-	__shared__ uint32_t s_last_move[kCrackBlock];
-	__shared__ uint32_t s_last_ctrl[kCrackBlock];
-	constexpr uint32_t kStackLds = 2048;
-	__shared__ uint32_t s_stack[kStackLds];
-	__shared__ uint32_t s_nnodes, s_ncodes, s_nsyms, s_nctl, s_valid_segs, s_err;
 
 	const uint32_t zi = blockIdx.x;
 	const int tid = threadIdx.x;
@@ -108,6 +107,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	const uint32_t ncap = a.ncap[zi];
 	const uint32_t sxe = a.sx + 1, sye = a.sy + 1;
 	const uint32_t nverts = sxe * sye;
+	const uint32_t sx = a.sx, sy = a.sy;
 
 	// ---- phase A: beginning-of-chain index (crackcodes.hpp:283-316), serial ----
 	if (tid == 0) {
@@ -179,6 +179,8 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		s_nnodes = nn;
 		s_ncodes = ncodes;
 		s_err = err;
+		s_valid_segs = 0;
+		s_nctl = 0;
 	}
 	__syncthreads();
 	stamp(0);
@@ -188,24 +190,35 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	const uint8_t* packed = code + index_end;          // only dereferenced when n_codes > 0 (then index_end <= code_len)
 	const uint8_t* ucode = a.ucode + cb;
 
-	uint8_t* sym_kind = a.sym_kind + cb;
-	uint32_t* sym_pos = a.sym_pos + cb;
-	uint32_t* sym_seg = a.sym_seg + cb;
-	uint32_t* ctl_sym = a.ctl_sym + cb;
+	uint8_t* ctl_kind = a.ctl_kind + cb;
+	uint32_t* ctl_pos = a.ctl_pos + cb;
+	uint32_t* ctl_seg = a.ctl_seg + cb;
+	uint32_t* seg_off = a.seg_off + cb;
+	uint32_t* stack = a.stack + cb;
+	uint32_t* pv = a.planeV + zi * a.plane_words;
+	uint32_t* ph = a.planeH + zi * a.plane_words;
+	uint32_t rerr = 0;
 
-	// ---- phase B: codes -> symbols, tiled block scans with carries -------------------
-	// (crackcodes.hpp:547-598 / SURVEY.md Appendix D6)
-	// Every code position g in [0, n_codes] is visited; position g finalises the
-	// symbol of code g-1 (a move becomes 'b'/'t' when code g is its exact reverse).
-	uint32_t carry_sum = 0;          // running mod-4 sum of difference codes
-	uint32_t carry_move = 0xFF;      // move of code g0-1 (0xFF: none)
-	uint32_t carry_ctrl = 0;         // was code g0-1 the second half of a control pair
-	int32_t carry_lf = -1;           // last position whose `reverse-of-previous` test was false
-	uint32_t carry_nsym = 0, carry_nt = 0, carry_nctl = 0, carry_pos = 0;
-	constexpr uint32_t kPer = 16;
-	constexpr uint32_t kTile = kCrackBlock * kPer;
+	// The symbol stream is derived twice from the packed codes (~25 KiB per slice) instead
+	// of being stored: pass 0 records only the control symbols ('b'/'t', ~3 % of the
+	// stream) for the branch matcher (phase C); pass 1 recomputes every symbol and
+	// rasterises the moves straight from registers (phase D) once the offset of every
+	// segment is known.
+	for (int pass = 0; pass < 2 && n_nodes > 0 && n_codes > 0; pass++) {
+		const uint32_t valid_segs = s_valid_segs;   // pass 1: set by phase C
 
-	if (n_nodes > 0 && n_codes > 0) {
+		// ---- phase B: codes -> symbols, tiled block scans with carries -------------------
+		// (crackcodes.hpp:547-598 / SURVEY.md Appendix D6)
+		// Every code position g in [0, n_codes] is visited; position g finalises the
+		// symbol of code g-1 (a move becomes 'b'/'t' when code g is its exact reverse).
+		uint32_t carry_sum = 0;          // running mod-4 sum of difference codes
+		uint32_t carry_move = 0xFF;      // move of code g0-1 (0xFF: none)
+		uint32_t carry_ctrl = 0;         // was code g0-1 the second half of a control pair
+		int32_t carry_lf = -1;           // last position whose `reverse-of-previous` test was false
+		uint32_t carry_nt = 0, carry_nctl = 0, carry_pos = 0;
+		constexpr uint32_t kPer = 16;
+		constexpr uint32_t kTile = kCrackBlock * kPer;
+
 		for (uint32_t tile = 0; tile <= n_codes; tile += kTile) {
 			const uint32_t g0 = tile + tid * kPer;
 			// -- load 16 difference codes
@@ -262,9 +275,8 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			const uint32_t tile_last_ctrl = s_last_ctrl[kCrackBlock - 1];
 
 			// -- events: position g emits the symbol of code g-1 unless g-1 was a control half
-			uint32_t kinds = 0;        // 3 bits per event slot k
 			uint32_t emask = 0;
-			uint32_t n_ev = 0, n_t = 0, n_ctl = 0, dpos = 0;
+			uint32_t n_t = 0, n_ctl = 0, dpos = 0;
 #pragma unroll
 			for (uint32_t k = 0; k < kPer; k++) {
 				const uint32_t g = g0 + k;
@@ -275,16 +287,17 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 					if (g < n_codes && (cmask & (1u << k))) kind = (mv[k] == 0u || mv[k] == 3u) ? SYM_T : SYM_B;
 					else kind = pm;
 					emask |= (1u << k);
-					kinds |= 0;  // placeholder to keep the compiler from merging branches oddly
-					n_ev++;
 					if (kind == SYM_T) n_t++;
 					if (kind >= SYM_B) n_ctl++;
 					else dpos += (kind == SYM_R) ? 1u : (kind == SYM_L) ? 0xFFFFFFFFu : (kind == SYM_D) ? sxe : (0u - sxe);
 				}
 			}
-			uint32_t v4[4] = { n_ev, n_t, n_ctl, dpos }, t4[4];
-			block_excl_add<4, kCrackWaves>(v4, t4, s_scan);
-			uint32_t o_sym = carry_nsym + v4[0], o_t = carry_nt + v4[1], o_ctl = carry_nctl + v4[2], o_pos = carry_pos + v4[3];
+			uint32_t v3[3] = { n_t, n_ctl, dpos }, t3[3];
+			block_excl_add<3, kCrackWaves>(v3, t3, s_scan);
+			uint32_t o_t = carry_nt + v3[0], o_ctl = carry_nctl + v3[1], o_pos = carry_pos + v3[2];
+
+			uint32_t* cur_word = nullptr;     // pass 1: bits of consecutive moves in one plane word
+			uint32_t cur_bits = 0;
 #pragma unroll
 			for (uint32_t k = 0; k < kPer; k++) {
 				if (!(emask & (1u << k))) continue;
@@ -293,65 +306,95 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 				uint32_t kind;
 				if (g < n_codes && (cmask & (1u << k))) kind = (mv[k] == 0u || mv[k] == 3u) ? SYM_T : SYM_B;
 				else kind = pm;
-				if (o_sym < cap) {
-					sym_kind[o_sym] = static_cast<uint8_t>(kind);
-					sym_pos[o_sym] = o_pos;
-					sym_seg[o_sym] = o_t;
-					if (kind >= SYM_B && o_ctl < cap) ctl_sym[o_ctl] = o_sym;
+				if (pass == 0) {
+					if (kind >= SYM_B && o_ctl < cap) {
+						ctl_kind[o_ctl] = static_cast<uint8_t>(kind);
+						ctl_pos[o_ctl] = o_pos;
+						ctl_seg[o_ctl] = o_t;
+					}
 				}
-				o_sym++;
+				else if (kind < SYM_B && o_t < valid_segs) {
+					// ---- phase D: rasterise the move (crackcodes.hpp:706-862).  Vertical moves
+					// cross planeV, horizontal moves cross planeH; consecutive moves of a straight
+					// horizontal stretch share a plane word and are OR-ed into memory once.
+					const uint32_t t = seg_off[o_t] + o_pos;
+					if (t >= nverts) rerr |= ERR_RANGE;
+					else {
+						const uint32_t y = t / sxe;
+						const uint32_t x = t - y * sxe;
+						uint32_t* word = nullptr;
+						uint32_t bx = 0;
+						if (kind == SYM_D) {          // edge (x,y)-(x,y+1): between pixels (x-1,y) | (x,y)
+							if (x >= 1 && x < sx && y < sy) { word = pv + static_cast<uint64_t>(y) * a.row_words + (x >> 5); bx = x; }
+							else if (y >= sy) rerr |= ERR_RANGE;
+						}
+						else if (kind == SYM_U) {     // edge (x,y-1)-(x,y)
+							if (x >= 1 && x < sx && y >= 1) { word = pv + static_cast<uint64_t>(y - 1) * a.row_words + (x >> 5); bx = x; }
+							else if (y < 1) rerr |= ERR_RANGE;
+						}
+						else if (kind == SYM_R) {     // edge (x,y)-(x+1,y): between pixels (x,y-1) | (x,y)
+							if (y >= 1 && y < sy && x < sx) { word = ph + static_cast<uint64_t>(y) * a.row_words + (x >> 5); bx = x; }
+							else if (x >= sx) rerr |= ERR_RANGE;
+						}
+						else {                        // SYM_L: edge (x-1,y)-(x,y)
+							if (y >= 1 && y < sy && x >= 1) { word = ph + static_cast<uint64_t>(y) * a.row_words + ((x - 1) >> 5); bx = x - 1; }
+							else if (x < 1) rerr |= ERR_RANGE;
+						}
+						if (word) {
+							if (word != cur_word) {
+								if (cur_word) atomicOr(cur_word, cur_bits);
+								cur_word = word;
+								cur_bits = 0;
+							}
+							cur_bits |= 1u << (bx & 31);
+						}
+					}
+				}
 				if (kind == SYM_T) o_t++;
 				if (kind >= SYM_B) o_ctl++;
 				else o_pos += (kind == SYM_R) ? 1u : (kind == SYM_L) ? 0xFFFFFFFFu : (kind == SYM_D) ? sxe : (0u - sxe);
 			}
-			(void)kinds;
+			if (cur_word) atomicOr(cur_word, cur_bits);
+
 			// -- carries to the next tile (uniform across the block)
 			carry_sum = (carry_sum + t1[0]) & 3u;
 			carry_move = (tile + kTile <= n_codes) ? tile_last_move : 0xFF;
 			carry_ctrl = tile_last_ctrl;
 			if (lf_tot > carry_lf) carry_lf = lf_tot;
-			carry_nsym += t4[0]; carry_nt += t4[1]; carry_nctl += t4[2]; carry_pos += t4[3];
+			carry_nt += t3[0]; carry_nctl += t3[1]; carry_pos += t3[2];
 			__syncthreads();
 		}
-	}
-	if (tid == 0) {
-		s_nsyms = carry_nsym < cap ? carry_nsym : cap;
-		s_nctl = carry_nctl < cap ? carry_nctl : cap;
-		if (carry_nsym > cap) s_err |= ERR_CAPACITY;
-	}
-	__syncthreads();
-	stamp(1);
-	const uint32_t n_syms = s_nsyms, n_ctl = s_nctl;
+		if (pass == 1) break;
+		if (tid == 0) {
+			s_nctl = carry_nctl < cap ? carry_nctl : cap;
+			if (carry_nctl > cap) s_err |= ERR_CAPACITY;
+		}
+		__syncthreads();
+		stamp(1);
+		const uint32_t n_ctl = s_nctl;
 
-	// ---- phase C: branch matching over the control symbols, 64 at a time by wave 0 ----
-	// (crackcodes.hpp:771-781, 849-859: the rasteriser's revisit stack; chain
-	// segmentation by branches_taken, crackcodes.hpp:549-598).
-	// A 't' returns the cursor to where its matching 'b' was pushed.  Inside a chunk a
-	// 't' matches the nearest earlier control of the same nesting level when that is a
-	// 'b'; otherwise it pops the stack carried between chunks (or ends the chain when
-	// the stack is empty).  Segment offsets chain through earlier 't's of the chunk and
-	// are resolved by pointer jumping with shuffles.
-	uint32_t* seg_off = a.seg_off + cb;
-	uint32_t* stack = a.stack + cb;
-	if (tid < kWave) {
-		const int lane = tid;
-		uint32_t valid = 0;
-		if (n_nodes > 0 && n_syms > 0) {
+		// ---- phase C: branch matching over the control symbols, 64 at a time by wave 0 ----
+		// (crackcodes.hpp:771-781, 849-859: the rasteriser's revisit stack; chain
+		// segmentation by branches_taken, crackcodes.hpp:549-598).
+		// A 't' returns the cursor to where its matching 'b' was pushed.  Inside a chunk a
+		// 't' matches the nearest earlier control of the same nesting level when that is a
+		// 'b'; otherwise it pops the stack carried between chunks (or ends the chain when
+		// the stack is empty).  Segment offsets chain through earlier 't's of the chunk and
+		// are resolved by pointer jumping with shuffles.
+		if (tid < kWave) {
+			const int lane = tid;
+			uint32_t valid = 1;
 			uint32_t off = nodes[0];          // offset of the current segment (wave uniform)
 			uint32_t chain = 0, sp = 0;
 			bool done = false;
 			if (lane == 0) seg_off[0] = off;
-			valid = 1;
 			const unsigned long long below = (1ull << lane) - 1ull;
 			constexpr int PTR_NONE = -1, PTR_CARRY = -2;
 			for (uint32_t base = 0; base < n_ctl && !done; base += kWave) {
 				const uint32_t k = base + lane;
 				const bool live = k < n_ctl;
 				uint32_t pos = 0, seg = 0, kind = SYM_U;
-				if (live) {
-					const uint32_t s = ctl_sym[k];
-					kind = sym_kind[s]; pos = sym_pos[s]; seg = sym_seg[s];
-				}
+				if (live) { kind = ctl_kind[k]; pos = ctl_pos[k]; seg = ctl_seg[k]; }
 				const bool isT = live && kind == SYM_T;
 				const bool isB = live && kind == SYM_B;
 				const unsigned long long tmask = __ballot(isT), bmask = __ballot(isB);
@@ -409,9 +452,9 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 #pragma unroll
 				for (int r = 0; r < 6; r++) {
 					const int pl = ptr >= 0 ? ptr : lane;
-					const uint32_t pv = __shfl(val, pl, kWave);
+					const uint32_t pvv = __shfl(val, pl, kWave);
 					const int pp = __shfl(ptr, pl, kWave);
-					if (ptr >= 0) { val += pv; ptr = pp; }
+					if (ptr >= 0) { val += pvv; ptr = pp; }
 				}
 				const uint32_t my_off = val + (ptr == PTR_CARRY ? off : 0u);   // 't' lanes: offset of the segment they open
 
@@ -447,69 +490,18 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 				}
 				__threadfence_block();
 			}
+			if (tid == 0) s_valid_segs = valid;
 		}
-		if (tid == 0) s_valid_segs = valid;
+		__syncthreads();
+		__threadfence_block();
+		stamp(2);
 	}
-	__syncthreads();
-	stamp(2);
-	const uint32_t valid_segs = s_valid_segs;
 
-	// ---- phase D: rasterise every move into the crack planes (crackcodes.hpp:706-862) ----
-	// A thread takes 8 consecutive symbols; consecutive moves of a straight horizontal
-	// stretch fall into the same plane word, so their bits are merged in a register and
-	// OR-ed into memory once (neighbouring lanes otherwise serialise on one L2 line).
-	uint32_t* pv = a.planeV + zi * a.plane_words;
-	uint32_t* ph = a.planeH + zi * a.plane_words;
-	uint32_t err = 0;
-	const uint32_t sx = a.sx, sy = a.sy;
-	constexpr uint32_t kChunk = 8;
-	for (uint32_t s0 = tid * kChunk; s0 < n_syms; s0 += kCrackBlock * kChunk) {
-		uint32_t* cur_word = nullptr;
-		uint32_t cur_bits = 0;
-		const uint32_t s1 = s0 + kChunk < n_syms ? s0 + kChunk : n_syms;
-		for (uint32_t s = s0; s < s1; s++) {
-			const uint32_t kind = sym_kind[s];
-			if (kind >= SYM_B) continue;
-			const uint32_t seg = sym_seg[s];
-			if (seg >= valid_segs) continue;
-			const uint32_t t = seg_off[seg] + sym_pos[s];
-			if (t >= nverts) { err |= ERR_RANGE; continue; }
-			const uint32_t y = t / sxe;
-			const uint32_t x = t - y * sxe;
-			// vertical moves cross planeV, horizontal moves cross planeH
-			uint32_t* word = nullptr;
-			uint32_t bx = 0;
-			if (kind == SYM_D) {          // edge (x,y)-(x,y+1): between pixels (x-1,y) | (x,y)
-				if (x >= 1 && x < sx && y < sy) { word = pv + static_cast<uint64_t>(y) * a.row_words + (x >> 5); bx = x; }
-				else if (y >= sy) err |= ERR_RANGE;
-			}
-			else if (kind == SYM_U) {     // edge (x,y-1)-(x,y)
-				if (x >= 1 && x < sx && y >= 1) { word = pv + static_cast<uint64_t>(y - 1) * a.row_words + (x >> 5); bx = x; }
-				else if (y < 1) err |= ERR_RANGE;
-			}
-			else if (kind == SYM_R) {     // edge (x,y)-(x+1,y): between pixels (x,y-1) | (x,y)
-				if (y >= 1 && y < sy && x < sx) { word = ph + static_cast<uint64_t>(y) * a.row_words + (x >> 5); bx = x; }
-				else if (x >= sx) err |= ERR_RANGE;
-			}
-			else {                        // SYM_L: edge (x-1,y)-(x,y)
-				if (y >= 1 && y < sy && x >= 1) { word = ph + static_cast<uint64_t>(y) * a.row_words + ((x - 1) >> 5); bx = x - 1; }
-				else if (x < 1) err |= ERR_RANGE;
-			}
-			if (!word) continue;
-			if (word != cur_word) {
-				if (cur_word) atomicOr(cur_word, cur_bits);
-				cur_word = word;
-				cur_bits = 0;
-			}
-			cur_bits |= 1u << (bx & 31);
-		}
-		if (cur_word) atomicOr(cur_word, cur_bits);
-	}
-	if (err) atomicOr(&s_err, err);
+	if (rerr) atomicOr(&s_err, rerr);
 	__syncthreads();
 	stamp(3);
 	if (tid == 0 && s_err) atomicOr(a.slice_err + zi, s_err);
-	if (DIAG && tid == 0 && diag) { diag[static_cast<uint64_t>(zi) * 8 + 4] = n_codes; diag[static_cast<uint64_t>(zi) * 8 + 5] = n_ctl; diag[static_cast<uint64_t>(zi) * 8 + 6] = n_syms; }
+	if (DIAG && tid == 0 && diag) { diag[static_cast<uint64_t>(zi) * 8 + 4] = n_codes; diag[static_cast<uint64_t>(zi) * 8 + 5] = s_nctl; }
 }
 
 // ------------------------------------------------------------------------------
@@ -724,8 +716,8 @@ struct ckl_decoder {
 	DevBuf<uint8_t> d_stream;
 	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off, d_rbase;
 	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap, d_rcap;
-	DevBuf<uint8_t> d_model, d_ucode, d_sym_kind;
-	DevBuf<uint32_t> d_sym_pos, d_sym_seg, d_ctl_sym, d_seg_off, d_stack, d_nodes;
+	DevBuf<uint8_t> d_model, d_ucode, d_ctl_kind;
+	DevBuf<uint32_t> d_ctl_pos, d_ctl_seg, d_seg_off, d_stack, d_nodes;
 	DevBuf<uint32_t> d_planes;          // V then H
 	DevBuf<uint32_t> d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_ncomp_expect;
 	DevBuf<uint64_t> d_run_label;       // typed on use (1..8 bytes per run)
@@ -842,10 +834,9 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	upload(d.d_rbase, rbase, s);
 	upload(d.d_rcap, rcap, s);
 	if (h.markov_model_order) d.d_ucode.ensure(ctot);
-	d.d_sym_kind.ensure(ctot);
-	d.d_sym_pos.ensure(ctot);
-	d.d_sym_seg.ensure(ctot);
-	d.d_ctl_sym.ensure(ctot);
+	d.d_ctl_kind.ensure(ctot);
+	d.d_ctl_pos.ensure(ctot);
+	d.d_ctl_seg.ensure(ctot);
 	d.d_seg_off.ensure(ctot);
 	d.d_stack.ensure(ctot);
 	d.d_nodes.ensure(ntot);
@@ -1058,8 +1049,8 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.xw = byte_width(static_cast<uint64_t>(h.sx) + 1); ca.yw = byte_width(static_cast<uint64_t>(h.sy) + 1);
 	ca.markov_order = h.markov_model_order;
 	ca.model = d.d_model.p; ca.ucode = d.d_ucode.p;
-	ca.sym_kind = d.d_sym_kind.p; ca.sym_pos = d.d_sym_pos.p; ca.sym_seg = d.d_sym_seg.p;
-	ca.ctl_sym = d.d_ctl_sym.p; ca.seg_off = d.d_seg_off.p; ca.stack = d.d_stack.p; ca.nodes = d.d_nodes.p;
+	ca.ctl_kind = d.d_ctl_kind.p; ca.ctl_pos = d.d_ctl_pos.p; ca.ctl_seg = d.d_ctl_seg.p;
+	ca.seg_off = d.d_seg_off.p; ca.stack = d.d_stack.p; ca.nodes = d.d_nodes.p;
 	ca.planeV = d.d_planes.p; ca.planeH = d.d_planes.p + d.plane_words * ns;
 	ca.row_words = d.row_words; ca.plane_words = d.plane_words;
 	ca.slice_err = d.d_slice_err.p;
@@ -1073,7 +1064,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		CKL_HIP(hipStreamSynchronize(s));
 		double m[8] = { 0 };
 		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 8; k++) m[k] += static_cast<double>(dg[zi * 8 + k]) / ns;
-		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f symbols=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5]);
 	}
 	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), 0, s, ca, static_cast<unsigned long long*>(nullptr));
 	st.done("k_decode_cracks");
