@@ -25,6 +25,75 @@ int select_device(int device) {
 	return count;
 }
 
+// ---- device memory pool ------------------------------------------------------------
+namespace {
+struct PoolBlock { void* p; size_t bytes; int device; };
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t kPoolMaxBytes = 96ull << 30;    // of 288 GB of HBM
+constexpr size_t kPoolMaxBlocks = 512;
+}
+
+void* pool_alloc(size_t bytes) {
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	{
+		std::lock_guard<std::mutex> lock(g_pool_mutex);
+		// best fit among blocks that are not wastefully large for the request
+		size_t best = g_pool.size();
+		for (size_t i = 0; i < g_pool.size(); i++) {
+			const PoolBlock& b = g_pool[i];
+			if (b.device != dev || b.bytes < bytes || b.bytes > 2 * bytes + (1u << 20)) continue;
+			if (best == g_pool.size() || b.bytes < g_pool[best].bytes) best = i;
+		}
+		if (best != g_pool.size()) {
+			void* p = g_pool[best].p;
+			g_pool_bytes -= g_pool[best].bytes;
+			g_pool[best] = g_pool.back();
+			g_pool.pop_back();
+			return p;
+		}
+	}
+	void* p = nullptr;
+	hipError_t e = hipMalloc(&p, bytes);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		pool_trim();                       // give pooled memory back and retry once
+		e = hipMalloc(&p, bytes);
+	}
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		throw Error(CKL_ERR_RUNTIME, std::string("crackle_amd: hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+	}
+	return p;
+}
+
+void pool_free(void* p, size_t bytes) {
+	if (!p) return;
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	{
+		std::lock_guard<std::mutex> lock(g_pool_mutex);
+		if (g_pool.size() < kPoolMaxBlocks && g_pool_bytes + bytes <= kPoolMaxBytes) {
+			g_pool.push_back({ p, bytes, dev });
+			g_pool_bytes += bytes;
+			return;
+		}
+	}
+	(void)hipFree(p);
+}
+
+void pool_trim() {
+	std::vector<PoolBlock> blocks;
+	{
+		std::lock_guard<std::mutex> lock(g_pool_mutex);
+		blocks.swap(g_pool);
+		g_pool_bytes = 0;
+	}
+	for (const PoolBlock& b : blocks) (void)hipFree(b.p);
+}
+
 // ---- checksums -------------------------------------------------------------------
 // crc8 (src/crc.hpp:23-37): poly 0xe7 (implicit +1, reflected), init 0xFF, no xorout
 uint8_t crc8(const uint8_t* data, uint64_t n) {

@@ -109,6 +109,13 @@ struct Header {
 };
 
 // ---- device buffers -------------------------------------------------------------
+// Device allocations go through a small per-device pool: sessions are created and
+// destroyed per call by the one-shot API, and releasing / re-acquiring gigabytes of
+// scratch through hipFree / hipMalloc costs tens of milliseconds each time.
+void* pool_alloc(size_t bytes);            // throws Error on failure
+void pool_free(void* p, size_t bytes);     // returns the block to the pool
+void pool_trim();                          // hipFree everything that is pooled
+
 template <typename T>
 struct DevBuf {
 	T* p = nullptr;
@@ -118,7 +125,7 @@ struct DevBuf {
 	DevBuf& operator=(const DevBuf&) = delete;
 	~DevBuf() { release(); }
 	void release() {
-		if (p) (void)hipFree(p);
+		if (p) pool_free(p, (n ? n : 1) * sizeof(T));
 		p = nullptr;
 		n = 0;
 	}
@@ -126,12 +133,7 @@ struct DevBuf {
 	void ensure(size_t count) {
 		if (count <= n && p) return;
 		release();
-		size_t bytes = (count ? count : 1) * sizeof(T);
-		hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
-		if (e != hipSuccess) {
-			p = nullptr;
-			throw Error(CKL_ERR_RUNTIME, std::string("crackle_amd: hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
-		}
+		p = static_cast<T*>(pool_alloc((count ? count : 1) * sizeof(T)));
 		n = count;
 	}
 	size_t bytes() const { return n * sizeof(T); }

@@ -31,6 +31,7 @@
 #include "ckl_runs.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 
 namespace ckl {
@@ -1035,6 +1036,8 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	if (out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
+	const bool prof = getenv("CKL_PROFILE") != nullptr;
+	auto h0 = std::chrono::steady_clock::now();
 
 	StageTimer st(d, s);
 	CKL_HIP(hipMemsetAsync(d.d_planes.p, 0, 2 * d.plane_words * ns * sizeof(uint32_t), s));
@@ -1116,9 +1119,13 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	st.done("k_check");
 	d.n_stages = st.i;
 
+	auto h1 = std::chrono::steady_clock::now();
 	std::vector<uint32_t> errs(ns);
 	CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	CKL_HIP(hipStreamSynchronize(s));
+	auto h2 = std::chrono::steady_clock::now();
+	if (prof) fprintf(stderr, "[ckl decode host ms] enqueue=%.2f wait=%.2f\n",
+		std::chrono::duration<double, std::milli>(h1 - h0).count(), std::chrono::duration<double, std::milli>(h2 - h1).count());
 	CKL_HIP(hipGetLastError());
 	CKL_HIP(hipEventElapsedTime(&d.pipeline_ms, d.ev[0], d.ev[d.n_stages]));
 	for (int i = 0; i < d.n_stages; i++) CKL_HIP(hipEventElapsedTime(&d.stage_ms[i], d.ev[i], d.ev[i + 1]));
