@@ -110,7 +110,9 @@ def test_corruption_is_reported():
   with pytest.raises(RuntimeError):
     crackle_amd.decompress(bytes(b))
   with pytest.raises(crackle_amd.FormatError):
-    crackle_amd.decompress(b"crkl" + bytes(40) + b"\x01")
+    crackle_amd.decompress(b"crkl" + b"\x07" + bytes(40))   # unknown format version
+  with pytest.raises(crackle_amd.FormatError):
+    crackle_amd.decompress(b"nope" + golden()["c0_voronoi_u8"][4:])
   trunc = golden()["c0_voronoi_u8"][:200]
   with pytest.raises(RuntimeError):
     crackle_amd.decompress(trunc)
