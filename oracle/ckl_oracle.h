@@ -5,7 +5,8 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load it.  Parity status: PINNED — byte-identical to the compiled reference
  * (oracle/_ref) over the golden grid in tests/golden/ (see tests/gen_golden.py)
- * and to the reference's known-answer vectors.
+ * and to the reference's known-answer vectors.  Pin encoding
+ * (hash-container iteration order and all) is restated in ckl_oracle_pins.inc.
  */
 #ifndef CKL_ORACLE_H
 #define CKL_ORACLE_H

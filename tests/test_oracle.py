@@ -44,9 +44,7 @@ def test_kat_c_order_header(port):
 def test_golden_small(port, name):
   arr, kw = SMALL[name]
   want = golden()[name]
-  if label_format(want) == 0 or arr.size == 0:
-    assert port.compress(arr, parallel=2, **kw) == want
-  # TODO(pins encode restatement): pin-format streams are only decoded by the port
+  assert port.compress(arr, parallel=2, **kw) == want
   if arr.size:
     got = port.decompress(want, parallel=2)
     assert np.array_equal(got, flat_1d(arr))
@@ -58,8 +56,6 @@ def test_golden_large(port, name):
   arr = thunk()
   m = manifest()[name]
   assert sha(np.asfortranarray(arr).tobytes(order="F")) == m["input_sha256"], "generator drifted"
-  if kw.get("allow_pins"):
-    pytest.skip("pin encode not restated yet")
   b = port.compress(arr, parallel=4, **kw)
   assert len(b) == m["length"] and sha(b) == m["sha256"]
   assert np.array_equal(port.decompress(b, parallel=4), flat_1d(arr))
@@ -93,6 +89,33 @@ def test_slice_crc_mismatch_reported(port):
   b[-1] ^= 0xFF
   with pytest.raises(RuntimeError, match="crc"):
     port.decompress(bytes(b))
+
+
+def test_pin_encoding_against_live_reference(port, ref):
+  """Pins depend on hash-container iteration order (SURVEY.md hard part 2): randomized and
+  deliberately tied inputs, auto and manual background colour."""
+  if ref is None:
+    pytest.skip("oracle/_ref not built (reference sources absent)")
+  from crackle_amd import synth
+  cases = []
+  for i, (shape, hi, dt) in enumerate([((17, 13, 5), 4, np.uint8), ((30, 30, 8), 3, np.uint16), ((20, 16, 12), 2, np.uint32),
+                                       ((40, 33, 6), 7, np.uint64), ((8, 8, 30), 3, np.uint8), ((64, 48, 10), 12, np.uint16)]):
+    cases.append(synth.random_labels(shape, dt, seed=100 + i, high=hi))
+  a = np.zeros((12, 12, 6), np.uint8, order="F"); a[:6] = 1; a[6:] = 2
+  cases.append(a)                                   # two labels tie on pin count and depth
+  a = np.zeros((16, 16, 4), np.uint16, order="F")
+  for i in range(4):
+    for j in range(4):
+      a[4 * i:4 * i + 4, 4 * j:4 * j + 4] = 10 + 4 * i + j
+  cases.append(a)                                   # sixteen tied labels
+  cases.append(synth.as_numpy_f(synth.voronoi_labels((96, 80, 12), np.uint32, seed=9, cell=(16, 16, 4))))
+  for arr in cases:
+    for mk in (0, 4):
+      assert port.compress(arr, allow_pins=True, markov_model_order=mk) == ref.compress(arr, allow_pins=True, markov_model_order=mk)
+  arr = cases[0]
+  for bg in (0, 1, 2):
+    assert port.compress(arr, allow_pins=True, auto_bgcolor=False, manual_bgcolor=bg) == \
+           ref.compress(arr, allow_pins=True, auto_bgcolor=False, manual_bgcolor=bg)
 
 
 def test_live_reference_agrees(port, ref):
