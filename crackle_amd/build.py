@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrackle_amd.so")
-SOURCES = ["ckl_common.hip", "ckl_decode.hip", "ckl_encode.hip", "ckl_zstack.hip"]
+SOURCES = ["ckl_common.hip", "ckl_decode.hip", "ckl_encode.hip", "ckl_pins.hip", "ckl_zstack.hip"]
 HEADERS = ["ckl_common.hpp", "ckl_device.hpp", "ckl_runs.hpp", os.path.join("..", "..", "include", "crackle_amd.h")]
 ARCH = os.environ.get("CKL_OFFLOAD_ARCH", "gfx950")
 
@@ -47,7 +47,7 @@ def build(force=False, verbose=True):
         print(" ".join(cmd), flush=True)
       subprocess.run(cmd, check=True)
   if force or _stale(LIB, objs):
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+    cmd = [_hipcc(), "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", *objs, "-o", LIB]
     if verbose:
       print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -777,6 +777,36 @@ __global__ void __launch_bounds__(kBlock) k_mapping_runs(
 	mapping[comp_off[zi] + r.run_cc[rb + i]] = static_cast<uint64_t>(labels[zi * sxy + r.run_start[rb + i]]);
 }
 
+// Global component id of every voxel (cc3d.hpp:371-400 numbers components continuously
+// across slices) for the pin encoder: one thread per 32-pixel word of a row, ids read from
+// the run tables.  grid = (ceil(plane_words / 256), nslices)
+__global__ void __launch_bounds__(kBlock) k_paint_components(
+	const uint32_t* __restrict__ planeV, uint32_t row_words, uint64_t plane_words, uint32_t sx, uint64_t sxy,
+	const uint32_t* __restrict__ word_base, const uint64_t* __restrict__ rbase, const uint32_t* __restrict__ run_cc,
+	const uint64_t* __restrict__ comp_off, uint32_t* __restrict__ out
+) {
+	const uint32_t zi = blockIdx.y;
+	const uint32_t wi = blockIdx.x * kBlock + threadIdx.x;
+	if (wi >= plane_words) return;
+	const uint32_t y = wi / row_words, w = wi - y * row_words;
+	const uint32_t left = sx - w * 32u;
+	const uint32_t valid = left >= 32u ? 32u : left;
+	uint32_t b = planeV[zi * plane_words + wi];
+	if (w == 0) b |= 1u;
+	const uint32_t* cc = run_cc + rbase[zi];
+	const uint32_t off = static_cast<uint32_t>(comp_off[zi]);
+	uint32_t run = word_base[zi * plane_words + wi] - 1u;   // run of the pixel left of this word
+	uint32_t* dst = out + zi * sxy + static_cast<uint64_t>(y) * sx + w * 32u;
+	uint32_t id = 0;
+	for (uint32_t i = 0; i < valid; i++) {
+		if (i == 0 || ((b >> i) & 1u)) {
+			run += (b >> i) & 1u;
+			id = cc[run] + off;
+		}
+		dst[i] = id;
+	}
+}
+
 // ------------------------------------------------------------------------------
 // label table (labels.hpp:92-152): sorted unique labels and the key of every component.
 // The component -> label list is sorted on device (bitonic network over a power-of-two
@@ -852,6 +882,15 @@ __global__ void __launch_bounds__(kBlock) k_gather_codes(
 // ------------------------------------------------------------------------------
 using namespace ckl;
 
+namespace ckl {
+// ckl_pins.hip
+template <typename LABEL>
+std::vector<uint8_t> encode_pins_host(
+	const LABEL* labels, const uint32_t* cc, int64_t sx, int64_t sy, int64_t sz,
+	const std::vector<uint32_t>& ncomp, uint64_t n_total,
+	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor);
+}
+
 struct ckl_encoder {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -881,6 +920,7 @@ struct ckl_encoder {
 	uint64_t g_table_pixels = 0;                // slice size the G table was built for
 	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq;
 	DevBuf<uint8_t> d_keys;
+	DevBuf<uint32_t> d_cc_volume;                // global component id of every voxel (pin encoding only)
 
 	~ckl_encoder() {
 		if (ev0) (void)hipEventDestroy(ev0);
@@ -1245,7 +1285,6 @@ void encode_typed(
 	bool optimize_pins, bool auto_bgcolor, int64_t manual_bgcolor,
 	const ckl_encode_overrides* ov, std::vector<uint8_t>& final_binary
 ) {
-	(void)auto_bgcolor; (void)manual_bgcolor;
 	const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
 	hipStream_t s = e.stream;
 	CKL_HIP(hipEventRecord(e.ev0, s));
@@ -1281,9 +1320,7 @@ void encode_typed(
 		return;
 	}
 	if (optimize_pins) throw Error(CKL_ERR_ARG, "crackle_amd: allow_pins=2 (find_optimal_pins) is out of scope");
-	if (head.label_format == PINS_VARIABLE_WIDTH) {
-		throw Error(CKL_ERR_RUNTIME, "crackle_amd: pin label encoding (allow_pins=True on a pin-eligible volume) is not implemented yet");
-	}
+	if (head.label_format != FLAT && head.label_format != PINS_VARIABLE_WIDTH) throw Error(CKL_ERR_ARG, "crackle_amd: unsupported label format");
 	if (head.markov_model_order > 13) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order > 13 is not supported on device");
 
 	HostTimer ht;
@@ -1314,18 +1351,35 @@ void encode_typed(
 	flat_pass<LABEL>(e, labels, sx, sy, sz, fr);
 	ht.mark("flat");
 	const uint64_t N = fr.total;
-	std::vector<uint64_t> uniq;
-	std::vector<uint8_t> keys;
-	int key_width = 1;
-	label_table(e, N, uniq, key_width, keys);
-	const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
 	std::vector<uint8_t> labels_binary;
-	labels_binary.reserve(8 + uniq.size() * stored_width + static_cast<size_t>(sz) * component_width + keys.size());
-	put_le(labels_binary, uniq.size(), 8);
-	for (uint64_t v : uniq) put_le(labels_binary, v, stored_width);
-	for (int64_t z = 0; z < sz; z++) put_le(labels_binary, fr.ncomp[z], component_width);
-	labels_binary.insert(labels_binary.end(), keys.begin(), keys.end());
-	ht.mark("label_table");
+	if (head.label_format == PINS_VARIABLE_WIDTH) {
+		// pins (pins.hpp:348-403, labels.hpp:157-344): components and crcs come from the
+		// device passes above; the order-sensitive cover runs on the host (ckl_pins.hip)
+		if (N > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
+		e.d_cc_volume.ensure(voxels);
+		hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((e.plane_words + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s,
+			e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
+			e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, e.d_cc_volume.p);
+		std::vector<uint32_t> cc_host = download(e.d_cc_volume.p, voxels, s);
+		std::vector<LABEL> labels_host = download(labels, voxels, s);
+		ht.mark("pins_d2h");
+		labels_binary = encode_pins_host<LABEL>(labels_host.data(), cc_host.data(), sx, sy, sz, fr.ncomp, N,
+			head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
+		ht.mark("pins_host");
+	}
+	else {
+		std::vector<uint64_t> uniq;
+		std::vector<uint8_t> keys;
+		int key_width = 1;
+		label_table(e, N, uniq, key_width, keys);
+		const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
+		labels_binary.reserve(8 + uniq.size() * stored_width + static_cast<size_t>(sz) * component_width + keys.size());
+		put_le(labels_binary, uniq.size(), 8);
+		for (uint64_t v : uniq) put_le(labels_binary, v, stored_width);
+		for (int64_t z = 0; z < sz; z++) put_le(labels_binary, fr.ncomp[z], component_width);
+		labels_binary.insert(labels_binary.end(), keys.begin(), keys.end());
+		ht.mark("label_table");
+	}
 	// assembly (crackle.hpp:171-216)
 	head.num_label_bytes = labels_binary.size();
 	final_binary.reserve(Header::kBytes + 4 * (sz + 1) + labels_binary.size() + stored_model.size() + cr.codes.size() + 4 * (sz + 1));

@@ -176,6 +176,20 @@ int ckl_zstack(
 	const uint8_t* const* bufs, const uint64_t* lens, uint64_t count,
 	uint8_t** out, uint64_t* out_len);
 
+/* Host stage of the pin label encoder: candidate pins, greedy cover and the condensed
+ * pin section — pins::compute with the fast solver (src/pins.hpp:95-198, 300-403) +
+ * labels::encode_condensed_pins (src/labels.hpp:157-344).  `labels` (dtype_bytes wide)
+ * and `cc` (global component id of every voxel, as crackle::cc3d::connected_components
+ * numbers them, src/cc3d.hpp:371-400) are HOST pointers in Fortran order; `ncomp` holds
+ * the component count of each of the sz slices.  ckl_encoder_run calls this stage itself
+ * after labelling components on the device; it is exported so that the order-sensitive
+ * host logic can be tested without a GPU.  *out is released with ckl_free. */
+int ckl_pin_labels_host(
+	const void* labels, int dtype_bytes, const uint32_t* cc,
+	int64_t sx, int64_t sy, int64_t sz, const uint32_t* ncomp,
+	int stored_width, int auto_bgcolor, int64_t manual_bgcolor,
+	uint8_t** out, uint64_t* out_len);
+
 /* crc32c (Castagnoli; src/crc.hpp:51-57) of a host buffer — exported for tests. */
 uint32_t ckl_crc32c(const uint8_t* data, uint64_t n);
 

@@ -47,13 +47,7 @@ def test_encode_golden_flat(name):
 @pytest.mark.parametrize("name", sorted(n for n in SMALL if label_format(golden()[n]) == 2 and SMALL[n][0].size))
 def test_encode_golden_pins(name):
   arr, kw = SMALL[name]
-  try:
-    b = crackle_amd.compress(arr, **_kw(kw))
-  except RuntimeError as e:
-    if "not implemented" in str(e):
-      pytest.xfail("pin label encoding lands in a later round")
-    raise
-  assert b == golden()[name]
+  assert crackle_amd.compress(arr, **_kw(kw)) == golden()[name]
 
 
 @pytest.mark.parametrize("name", sorted(LARGE))
@@ -61,8 +55,6 @@ def test_large_manifest(name):
   thunk, kw = LARGE[name]
   arr = thunk()
   m = manifest()[name]
-  if kw["allow_pins"]:
-    pytest.xfail("pin label encoding lands in a later round")
   b = crackle_amd.compress(arr, **_kw(kw))
   assert len(b) == m["length"] and sha(b) == m["sha256"]
   assert np.array_equal(crackle_amd.decompress(b), arr)
@@ -94,6 +86,17 @@ def test_oracle_agreement_on_seeded_volumes(checker):
     got = crackle_amd.compress(arr, **kw)
     assert got == want, f"{shape} {dt} {kw}"
     assert np.array_equal(crackle_amd.decompress(want), arr)
+  # pin label encoding (device CCL + host cover), auto and manual background colour
+  for shape, dt, seed, cell in [((96, 80, 24), np.uint8, 11, (16, 16, 8)), ((130, 70, 33), np.uint32, 12, (20, 20, 10)), ((64, 64, 40), np.uint64, 13, (16, 16, 16))]:
+    arr = synth.as_numpy_f(synth.voronoi_labels(shape, dt, seed=seed, cell=cell))
+    for kw in (dict(), dict(markov_model_order=3), dict(bgcolor=2)):
+      okw = dict(kw)
+      if "bgcolor" in okw:
+        okw.update(auto_bgcolor=False, manual_bgcolor=okw.pop("bgcolor"))
+      want = checker.compress(arr, allow_pins=True, **okw)
+      assert label_format(want) == 2
+      assert crackle_amd.compress(arr, allow_pins=1, **kw) == want, f"pins {shape} {dt} {kw}"
+      assert np.array_equal(crackle_amd.decompress(want), arr)
   noise = synth.random_labels((128, 128, 3), np.uint32, seed=9, high=2000)
   assert crackle_amd.compress(noise) == checker.compress(noise)
   bits = synth.random_labels((96, 96, 2), np.uint8, seed=10, high=2)
