@@ -720,7 +720,8 @@ struct ckl_decoder {
 	DevBuf<uint8_t> d_model, d_ucode, d_ctl_kind;
 	DevBuf<uint32_t> d_ctl_pos, d_ctl_seg, d_seg_off, d_stack, d_nodes;
 	DevBuf<uint32_t> d_planes;          // V then H
-	DevBuf<uint32_t> d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_ncomp_expect;
+	DevBuf<uint32_t> d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_ncomp_expect, d_blk_roots;
+	DevBuf<uint16_t> d_run_local;
 	DevBuf<uint64_t> d_run_label;       // typed on use (1..8 bytes per run)
 	DevBuf<uint32_t> d_G, d_crc_acc, d_crc_expect, d_slice_err;
 	DevBuf<uint64_t> d_label_map;
@@ -844,6 +845,8 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	d.d_parent.ensure(rtot);
 	d.d_run_start.ensure(rtot);
 	d.d_run_cc.ensure(rtot);
+	d.d_run_local.ensure(rtot);
+	d.d_blk_roots.ensure(static_cast<size_t>((d.max_rcap + kBlock - 1) / kBlock) * d.nslices);
 	d.d_run_label.ensure(rtot);
 
 	if (h.markov_model_order) {
@@ -1083,9 +1086,11 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 
 	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kBlock), 0, s, g, ra);
 	st.done("k_run_index");
-	hipLaunchKernelGGL(k_run_union, dim3(static_cast<uint32_t>((d.plane_words + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s, g, ra);
+	launch_run_union(s, ns, g, ra);
 	st.done("k_run_union");
-	hipLaunchKernelGGL(k_run_resolve, dim3(ns), dim3(kBlock), 0, s, ra, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
+	ResolveScratch rs;
+	rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
+	launch_run_resolve(s, ns, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, nullptr);
 	st.done("k_run_resolve");
 
 	// component -> label

@@ -915,7 +915,8 @@ struct ckl_encoder {
 	uint64_t plane_words = 0;
 	std::vector<uint32_t> count_v, count_h;     // differing neighbour pairs per slice (host copy)
 	DevBuf<uint64_t> d_rbase;
-	DevBuf<uint32_t> d_rcap, d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_idbits;
+	DevBuf<uint32_t> d_rcap, d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_idbits, d_blk_roots;
+	DevBuf<uint16_t> d_run_local;
 	DevBuf<uint32_t> d_G, d_crc_acc;
 	uint64_t g_table_pixels = 0;                // slice size the G table was built for
 	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq;
@@ -1226,8 +1227,13 @@ void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int6
 	ra.parent = e.d_parent.p; ra.run_start = e.d_run_start.p; ra.run_cc = e.d_run_cc.p;
 	ra.nruns = e.d_nruns.p; ra.ncomp = e.d_ncomp.p; ra.slice_err = e.d_slice_err.p;
 	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kBlock), 0, s, g, ra);
-	hipLaunchKernelGGL(k_run_union, dim3(static_cast<uint32_t>((e.plane_words + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s, g, ra);
-	hipLaunchKernelGGL(k_run_resolve, dim3(ns), dim3(kBlock), 0, s, ra, e.d_G.p, static_cast<uint32_t>(sxy), 0u, e.d_crc_acc.p, e.d_idbits.p);
+	launch_run_union(s, ns, g, ra);
+	ResolveScratch rs;
+	rs.nblk = (max_rcap + kBlock - 1) / kBlock;
+	e.d_run_local.ensure(rtot);
+	e.d_blk_roots.ensure(static_cast<size_t>(rs.nblk) * ns);
+	rs.run_local = e.d_run_local.p; rs.blk_roots = e.d_blk_roots.p;
+	launch_run_resolve(s, ns, ra, rs, e.d_G.p, static_cast<uint32_t>(sxy), 0u, e.d_crc_acc.p, e.d_idbits.p);
 
 	out.ncomp = download(e.d_ncomp.p, ns, s);
 	std::vector<uint32_t> acc = download(e.d_crc_acc.p, ns, s);

@@ -166,58 +166,219 @@ static __global__ void __launch_bounds__(kBlock) k_run_union(RunGeom g, RunArray
 	}
 }
 
-// grid = nslices.  Phase 1: flatten, rank the roots in run order (= raster order of each
-// component's first pixel, cc3d.hpp:114-144).  Phase 2: component id of every run and the
-// raw crc32c of the component image: a run of id c covering pixels [a, b) of an n-pixel
-// slice contributes c * (G[n-a] ^ G[n-b]) with G[m] = x^32 + x^64 + ... + x^(32 m) mod P.
+// ---- strip-local union-find in LDS ------------------------------------------------
+// Most unions are local: a strip of rows is united entirely in LDS (parents relative to
+// the strip's first run), flattened there and written out as global parents, so that
+// the global forest only ever sees trees of depth one plus the few unions across strip
+// seams (k_run_union_seams).  A strip with more runs than the LDS table holds falls back
+// to the global forest for its own rows.
+constexpr uint32_t kStripRuns = 12288;      // LDS table: 48 KiB
+
+__device__ __forceinline__ uint32_t lds_find(volatile uint32_t* L, uint32_t a) {
+	uint32_t p = L[a];
+	while (p != a) {
+		const uint32_t gp = L[p];
+		if (gp != p) L[a] = gp;     // path halving; a racing writer only ever stores an ancestor
+		a = p;
+		p = gp;
+	}
+	return a;
+}
+__device__ __forceinline__ void lds_unite(uint32_t* L, uint32_t a, uint32_t b) {
+	for (;;) {
+		a = lds_find(L, a);
+		b = lds_find(L, b);
+		if (a == b) return;
+		if (a > b) { const uint32_t t = a; a = b; b = t; }
+		const uint32_t old = atomicMin(L + b, a);
+		if (old == b) return;
+		b = old;
+	}
+}
+
+// grid = (strips per slice, nslices); strip_rows rows per strip
+static __global__ void __launch_bounds__(kBlock) k_run_union_strips(RunGeom g, RunArrays r, uint32_t strip_rows) {
+	__shared__ uint32_t s_parent[kStripRuns];
+	const uint32_t zi = blockIdx.y;
+	const uint32_t y0 = blockIdx.x * strip_rows;
+	if (y0 >= g.sy) return;
+	const uint32_t y1 = min(y0 + strip_rows, g.sy);
+	const uint32_t* wb = r.word_base + zi * g.plane_words;
+	const uint32_t n = r.nruns[zi];
+	const uint32_t base0 = min(wb[static_cast<uint64_t>(y0) * g.row_words], n);
+	const uint32_t base1 = (y1 < g.sy) ? min(wb[static_cast<uint64_t>(y1) * g.row_words], n) : n;
+	const uint32_t nloc = base1 - base0;
+	uint32_t* parent = r.parent + r.rbase[zi];
+	const bool local = nloc <= kStripRuns;
+	if (local) for (uint32_t j = threadIdx.x; j < nloc; j += kBlock) s_parent[j] = j;
+	else for (uint32_t j = threadIdx.x; j < nloc; j += kBlock) parent[base0 + j] = base0 + j;
+	__syncthreads();
+	if (!local) __threadfence();
+	const uint32_t w_end = (y1 - y0) * g.row_words;
+	for (uint32_t wl = g.row_words + threadIdx.x; wl < w_end; wl += kBlock) {   // rows y0+1 .. y1-1
+		const uint32_t yl = wl / g.row_words;
+		const uint32_t w = wl - yl * g.row_words;
+		const uint32_t y = y0 + yl;
+		const uint32_t up = g.ups(zi, y, w);
+		if (!up) continue;
+		const uint32_t prev_bit = w ? (g.ups(zi, y, w - 1) >> 31) : 0u;
+		const uint32_t b_here = g.breaks(zi, y, w);
+		const uint32_t b_up = g.breaks(zi, y - 1, w);
+		uint32_t cand = up & (~((up << 1) | prev_bit) | b_here | b_up);
+		const uint64_t wi = static_cast<uint64_t>(y) * g.row_words + w;
+		const uint32_t base_here = wb[wi], base_up = wb[wi - g.row_words];
+		for (; cand; cand &= cand - 1u) {
+			const uint32_t bit = __ffs(cand) - 1;
+			const uint32_t m = mask_le(bit);
+			const uint32_t ra = base_here + __popc(b_here & m) - 1u;
+			const uint32_t rb = base_up + __popc(b_up & m) - 1u;
+			if (ra >= base1 || rb >= base1 || rb < base0) continue;      // capacity overflow upstream (flagged there)
+			if (local) lds_unite(s_parent, ra - base0, rb - base0);
+			else run_unite(parent, ra, rb);
+		}
+	}
+	if (!local) return;
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < nloc; j += kBlock) parent[base0 + j] = base0 + lds_find(s_parent, j);
+}
+
+// grid = (ceil(seams * row_words / 256), nslices): the unions across strip seams
+// (rows y = k * strip_rows, k >= 1) on the global forest
+static __global__ void __launch_bounds__(kBlock) k_run_union_seams(RunGeom g, RunArrays r, uint32_t strip_rows) {
+	const uint32_t zi = blockIdx.y;
+	const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t seam = t / g.row_words;
+	const uint32_t w = t - seam * g.row_words;
+	const uint32_t y = (seam + 1u) * strip_rows;
+	if (y >= g.sy) return;
+	const uint32_t up = g.ups(zi, y, w);
+	if (!up) return;
+	const uint32_t prev_bit = w ? (g.ups(zi, y, w - 1) >> 31) : 0u;
+	const uint32_t b_here = g.breaks(zi, y, w);
+	const uint32_t b_up = g.breaks(zi, y - 1, w);
+	uint32_t cand = up & (~((up << 1) | prev_bit) | b_here | b_up);
+	const uint32_t* wb = r.word_base + zi * g.plane_words;
+	const uint64_t wi = static_cast<uint64_t>(y) * g.row_words + w;
+	const uint32_t base_here = wb[wi], base_up = wb[wi - g.row_words];
+	uint32_t* parent = r.parent + r.rbase[zi];
+	const uint32_t n = r.nruns[zi];
+	for (; cand; cand &= cand - 1u) {
+		const uint32_t bit = __ffs(cand) - 1;
+		const uint32_t m = mask_le(bit);
+		const uint32_t ra = base_here + __popc(b_here & m) - 1u;
+		const uint32_t rb = base_up + __popc(b_up & m) - 1u;
+		if (ra < n && rb < n) run_unite(parent, ra, rb);
+	}
+}
+
+static inline uint32_t run_strip_rows(uint32_t row_words) {
+	const uint32_t r = 2048u / (row_words ? row_words : 1u);
+	return r < 2u ? 2u : r;
+}
+// all unions of every slice on one stream (replaces a single k_run_union launch)
+static inline void launch_run_union(hipStream_t s, uint32_t nslices, const RunGeom& g, const RunArrays& r) {
+	const uint32_t rows = run_strip_rows(g.row_words);
+	const uint32_t strips = (g.sy + rows - 1) / rows;
+	hipLaunchKernelGGL(k_run_union_strips, dim3(strips, nslices), dim3(kBlock), 0, s, g, r, rows);
+	if (strips > 1) {
+		const uint32_t words = (strips - 1) * g.row_words;
+		hipLaunchKernelGGL(k_run_union_seams, dim3((words + kBlock - 1) / kBlock, nslices), dim3(kBlock), 0, s, g, r, rows);
+	}
+}
+
+// Component ids and the crc32c of the component image, in three fully parallel steps.
+// Roots are ranked in run order (= raster order of each component's first pixel,
+// cc3d.hpp:114-144).  A run of id c covering pixels [a, b) of an n-pixel slice
+// contributes c * (G[n-a] ^ G[n-b]) to the raw crc, G[m] = x^32 + x^64 + ... + x^(32 m) mod P.
 // The multiplication walks only the `idbits` significant bits of c; the common factor
 // x^(32-idbits) is applied once per slice on the host side of the comparison.
-static __global__ void __launch_bounds__(kBlock) k_run_resolve(RunArrays r, const uint32_t* __restrict__ G, uint32_t n_pixels, uint32_t idbits_in, uint32_t* __restrict__ crc_acc, uint32_t* __restrict__ idbits_out) {
+struct ResolveScratch {
+	uint16_t* run_local;       // [runs] roots: rank among the roots of their 256-run block
+	uint32_t* blk_roots;       // [nslices][nblk]: roots per block, then exclusive prefix
+	uint32_t nblk;             // blocks per slice = ceil(max run capacity / 256)
+};
+
+// step 1, grid = (nblk, nslices): flatten every run to its root, count the roots per block
+static __global__ void __launch_bounds__(kBlock) k_run_flatten(RunArrays r, ResolveScratch rs) {
+	__shared__ uint32_t s_scan[kWaves];
+	const uint32_t zi = blockIdx.y;
+	const uint32_t n = r.nruns[zi];
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (blockIdx.x * kBlock >= n) {
+		if (threadIdx.x == 0) rs.blk_roots[zi * rs.nblk + blockIdx.x] = 0;
+		return;
+	}
+	uint32_t* parent = r.parent + r.rbase[zi];
+	uint32_t is_root = 0;
+	if (i < n) {
+		const uint32_t root = run_find(parent, i);
+		if (root != i) __hip_atomic_store(parent + i, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		is_root = (root == i);
+	}
+	uint32_t v[1] = { is_root }, tot[1];
+	block_excl_add<1>(v, tot, s_scan);
+	if (is_root) rs.run_local[r.rbase[zi] + i] = static_cast<uint16_t>(v[0]);
+	if (threadIdx.x == 0) rs.blk_roots[zi * rs.nblk + blockIdx.x] = tot[0];
+}
+
+// step 2, grid = nslices: exclusive prefix of the per-block root counts -> component count
+static __global__ void __launch_bounds__(kBlock) k_run_rank(RunArrays r, ResolveScratch rs, uint32_t idbits_in, uint32_t* __restrict__ crc_acc, uint32_t* __restrict__ idbits_out) {
 	__shared__ uint32_t s_scan[kWaves];
 	const uint32_t zi = blockIdx.x;
-	uint32_t* parent = r.parent + r.rbase[zi];
-	const uint32_t* run_start = r.run_start + r.rbase[zi];
-	uint32_t* run_cc = r.run_cc + r.rbase[zi];
 	const uint32_t n = r.nruns[zi];
-	// idbits_in == 0: ids are below the run count, use its bit length (the encoder does
-	// not know the component counts in advance) and report it
-	const uint32_t idbits = idbits_in ? idbits_in : (n > 1 ? 32u - __clz(n - 1) : 1u);
-	if (threadIdx.x == 0 && idbits_out) idbits_out[zi] = idbits;
+	const uint32_t nb = (n + kBlock - 1) / kBlock;
+	uint32_t* cnt = rs.blk_roots + zi * rs.nblk;
 	uint32_t carry = 0;
-	for (uint32_t r0 = 0; r0 < n; r0 += kBlock) {
-		const uint32_t i = r0 + threadIdx.x;
-		uint32_t is_root = 0;
-		if (i < n) {
-			const uint32_t root = run_find(parent, i);
-			parent[i] = root;
-			is_root = (root == i);
-		}
-		uint32_t v[1] = { is_root }, tot[1];
+	for (uint32_t b0 = 0; b0 < nb; b0 += kBlock) {
+		const uint32_t b = b0 + threadIdx.x;
+		const uint32_t c = b < nb ? cnt[b] : 0u;
+		uint32_t v[1] = { c }, tot[1];
 		block_excl_add<1>(v, tot, s_scan);
-		if (is_root) run_cc[i] = carry + v[0];
+		if (b < nb) cnt[b] = carry + v[0];
 		carry += tot[0];
 	}
-	if (threadIdx.x == 0) r.ncomp[zi] = carry;
-	__syncthreads();
-	__threadfence_block();
-	uint32_t acc = 0;
-	for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-		const uint32_t root = parent[i];
-		const uint32_t cc = run_cc[root];
-		if (root != i) run_cc[i] = cc;
-		const uint32_t a = run_start[i];
-		const uint32_t b = (i + 1 < n) ? run_start[i + 1] : n_pixels;
+	if (threadIdx.x == 0) {
+		r.ncomp[zi] = carry;
+		crc_acc[zi] = 0;
+		// idbits_in == 0: ids are below the run count, use its bit length (the encoder does
+		// not know the component counts in advance) and report it
+		if (idbits_out) idbits_out[zi] = idbits_in ? idbits_in : (n > 1 ? 32u - __clz(n - 1) : 1u);
+	}
+}
+
+// step 3, grid = (nblk, nslices): component id of every run + its crc contribution
+static __global__ void __launch_bounds__(kBlock) k_run_assign(RunArrays r, ResolveScratch rs, const uint32_t* __restrict__ G, uint32_t n_pixels, uint32_t idbits_in, uint32_t* __restrict__ crc_acc) {
+	__shared__ uint32_t s_scan[kWaves];
+	const uint32_t zi = blockIdx.y;
+	const uint32_t n = r.nruns[zi];
+	if (blockIdx.x * kBlock >= n) return;
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint64_t rb = r.rbase[zi];
+	const uint32_t idbits = idbits_in ? idbits_in : (n > 1 ? 32u - __clz(n - 1) : 1u);
+	uint32_t part = 0;
+	if (i < n) {
+		const uint32_t root = r.parent[rb + i];
+		const uint32_t cc = rs.blk_roots[zi * rs.nblk + (root >> 8)] + rs.run_local[rb + root];
+		r.run_cc[rb + i] = cc;
+		const uint32_t a = r.run_start[rb + i];
+		const uint32_t b = (i + 1 < n) ? r.run_start[rb + i + 1] : n_pixels;
 		uint32_t wgt = G[n_pixels - a] ^ G[n_pixels - b];
 		// sum over set bits j < idbits of c:  wgt * x^(idbits-1-j)
-		uint32_t part = 0;
 		for (int j = static_cast<int>(idbits) - 1; j >= 0; j--) {
 			part ^= ((cc >> j) & 1u) ? wgt : 0u;
 			wgt = (wgt >> 1) ^ ((wgt & 1u) ? kCrcPoly : 0u);
 		}
-		acc ^= part;
 	}
-	acc = block_xor(acc, s_scan);
-	if (threadIdx.x == 0) crc_acc[zi] = acc;
+	part = block_xor(part, s_scan);
+	if (threadIdx.x == 0 && part) atomicXor(crc_acc + zi, part);
+}
+
+// the three steps on one stream
+static inline void launch_run_resolve(hipStream_t s, uint32_t nslices, const RunArrays& r, const ResolveScratch& rs, const uint32_t* G, uint32_t n_pixels, uint32_t idbits_in, uint32_t* crc_acc, uint32_t* idbits_out) {
+	static_assert(kBlock == 256, "run_local is indexed by root >> 8");
+	hipLaunchKernelGGL(k_run_flatten, dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs);
+	hipLaunchKernelGGL(k_run_rank, dim3(nslices), dim3(kBlock), 0, s, r, rs, idbits_in, crc_acc, idbits_out);
+	hipLaunchKernelGGL(k_run_assign, dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs, G, n_pixels, idbits_in, crc_acc);
 }
 
 // G[k*B + i] = G[k*B] ^ x^(32 k B) * G[i]   (B = 1024; per-block constants from the host)
