@@ -47,25 +47,34 @@ struct CrackArgs {
 	const uint8_t* stream;
 	const uint64_t* code_off;    // [nslices] byte offset of each slice's crack code
 	const uint32_t* code_len;    // [nslices]
-	const uint64_t* cbase;       // [nslices] base index into the per-code scratch arrays
-	const uint32_t* ccap;        // [nslices] capacity (codes) of this slice's scratch
+	const uint64_t* cbase;       // [nslices] running total of the code capacities
+	const uint32_t* ccap;        // [nslices] capacity (codes) of this slice
 	const uint64_t* nbase;       // [nslices] base index into `nodes`
 	const uint32_t* ncap;        // [nslices]
 	int sx, sy;
 	int xw, yw;
 	int markov_order;
 	const uint8_t* model;        // [4^order][4] rank -> symbol
-	uint8_t* ucode;              // unpacked difference codes (markov only)
-	uint8_t* ctl_kind;           // control symbols ('b'/'t') in stream order
-	uint32_t* ctl_pos;           // displacement prefix sum (mod 2^32) before each control symbol
-	uint32_t* ctl_seg;           // number of 't' symbols before each control symbol
-	uint32_t* seg_off;           // per segment: vertex offset to add to the displacement
-	uint32_t* stack;
+	uint32_t* upacked;           // markov only: decoded difference codes, 16 per word (slice base cbase/16 + 2 zi)
+	// control symbol tables in global memory, used when a slice has more control symbols
+	// than the LDS tables hold (slice base cbase/2 + 4 zi, capacity ccap/2 + 4)
+	uint8_t* g_kind;
+	uint32_t* g_dx;
+	uint32_t* g_dy;
+	int32_t* g_depth;
+	uint32_t* g_lastT;
+	unsigned long long* g_link;
+	uint32_t* g_seg_x;
+	uint32_t* g_seg_y;
+	int32_t* g_gmin;
 	uint32_t* nodes;
 	uint32_t* planeV;
 	uint32_t* planeH;
 	uint32_t row_words;
 	uint64_t plane_words;
+	uint32_t lds_controls;       // capacity of the LDS control tables (dynamic LDS is sized for it)
+	uint32_t lds_words;          // dynamic LDS size in 4-byte words
+	uint32_t lds_raster;         // 1: planes are built in LDS bands and stored; 0: zeroed by the host, atomics on HBM
 	uint32_t* slice_err;         // [nslices] sticky error bits
 };
 
@@ -77,17 +86,420 @@ __device__ __forceinline__ uint32_t rd_le_dev(const uint8_t* p, int w) {
 
 constexpr int kCrackBlock = 1024;                 // threads per slice
 constexpr int kCrackWaves = kCrackBlock / kWave;
+constexpr uint32_t kCrackWords = 8;               // packed words (16 codes each) per thread and tile
+constexpr uint32_t kCrackTile = kCrackBlock * kCrackWords * 16u;
+
+// ---- sixteen 2-bit fields per word ("spread" masks carry one flag per field at bit 2k) ----
+constexpr uint32_t kLo = 0x55555555u;     // low bit of every field
+constexpr uint32_t kEvenF = 0x11111111u;  // low bit of the even fields
+constexpr uint32_t kOddF = 0x44444444u;   // low bit of the odd fields
+__device__ __forceinline__ uint32_t add_fields(uint32_t a, uint32_t b) {   // per-field sum mod 4
+	return (a ^ b) ^ (((a & b) & kLo) << 1);
+}
+__device__ __forceinline__ uint32_t prefix_fields(uint32_t c) {            // inclusive running sum mod 4
+	c = add_fields(c, c << 2);
+	c = add_fields(c, c << 4);
+	c = add_fields(c, c << 8);
+	c = add_fields(c, c << 16);
+	return c;
+}
+__device__ __forceinline__ uint32_t fields_below(int64_t n) {              // spread mask of fields k < n
+	return n <= 0 ? 0u : (n >= 16 ? kLo : (((1u << (2 * n)) - 1u) & kLo));
+}
+
+// Symbols of one packed word (code positions gw .. gw+15), crackcodes.hpp:547-598 /
+// SURVEY.md Appendix D6.  Position g finalises the symbol of code g-1: a move becomes
+// 'b'/'t' when code g is its exact reverse and g sits at an odd distance from the last
+// position that was not a reverse (runs of reverses alternate control / move).
+struct WordSyms {
+	uint32_t prevs;     // move of code g-1 per field
+	uint32_t ms;        // spread: position emits a move (of kind prevs)
+	uint32_t ctl;       // spread: position emits a control symbol
+	uint32_t isT;       // spread: ... and it is a 't'
+	// spread masks of the emitted moves by direction
+	__device__ __forceinline__ uint32_t right() const { return ms & ~(prevs >> 1) & prevs; }
+	__device__ __forceinline__ uint32_t left() const { return ms & (prevs >> 1) & prevs; }
+	__device__ __forceinline__ uint32_t down() const { return ms & (prevs >> 1) & ~prevs; }
+	__device__ __forceinline__ uint32_t up() const { return ms & ~(prevs >> 1) & ~prevs; }
+};
+
+// control tables (LDS: 16-bit indices / depths, global: 32-bit)
+template <typename IDX, typename DEP>
+struct CtlTables {
+	uint8_t* kind;
+	uint32_t* dx;
+	uint32_t* dy;
+	DEP* depth;
+	IDX* lastT;
+	unsigned long long* link;    // low: value, high: index of the 't' it is relative to (or NONE)
+	uint32_t* seg_x;
+	uint32_t* seg_y;
+	DEP* gmin;
+};
+constexpr uint32_t kLinkNone = 0xFFFFFFFFu;
+
+// largest p < i with depth[p] < L, or -1 (groups of 64 are skipped through their minima)
+template <typename DEP>
+__device__ __forceinline__ int32_t prev_smaller(const DEP* depth, const DEP* gmin, int32_t i, int32_t L) {
+	int32_t p = i - 1;
+	while (p >= 0) {
+		const int32_t gs = p & ~63;
+		for (; p >= gs; p--) if (static_cast<int32_t>(depth[p]) < L) return p;
+		while (p >= 0 && static_cast<int32_t>(gmin[p >> 6]) >= L) p -= 64;
+	}
+	return -1;
+}
+
+// Branch matching over the N control symbols of a slice, all threads of the workgroup
+// (crackcodes.hpp:771-781, 849-859: the rasteriser's revisit stack; chain segmentation
+// by branches_taken, crackcodes.hpp:549-598).
+//   depth      stack depth after each symbol ('b' pushes, 't' pops, a 't' on the empty
+//              stack ends the chain): a clamped running sum = sum - running minimum.
+//   match      the 'b' a 't' returns to is the first symbol after the previous symbol of
+//              smaller depth.
+//   positions  the vertex after a 't' = vertex of its 'b' = vertex after the last 't'
+//              before that 'b' + displacement between them: a forest resolved by pointer
+//              jumping on (value, parent) pairs updated in single 8-byte accesses, so no
+//              barrier is needed between rounds.
+// Output: per segment (stretch between 't's) the vertex offset (seg_x, seg_y) to add to
+// the 2-D displacement prefix sums, and the number of valid segments.
+template <typename IDX, typename DEP>
+__device__ __forceinline__ void match_controls(
+	const CtlTables<IDX, DEP>& t, uint32_t N, const uint32_t* nodes, uint32_t n_nodes, uint32_t sxe, uint32_t nverts,
+	uint32_t* s_scan, int32_t* s_scanmax, uint32_t* s_first_dead, uint32_t* s_valid_segs, uint32_t& rerr
+) {
+	constexpr IDX NONE = static_cast<IDX>(~static_cast<IDX>(0));
+	const uint32_t tid = threadIdx.x;
+	const uint32_t per = (N + kCrackBlock - 1) / kCrackBlock;
+	const uint32_t i0 = min(N, tid * per), i1 = min(N, i0 + per);
+
+	int32_t s = 0, mn = INT32_MAX;
+	for (uint32_t i = i0; i < i1; i++) {
+		s += (t.kind[i] == SYM_T) ? -1 : 1;
+		mn = s < mn ? s : mn;
+	}
+	uint32_t v1[1] = { static_cast<uint32_t>(s) }, t1[1];
+	block_excl_add<1, kCrackWaves>(v1, t1, s_scan);
+	const int32_t S0 = static_cast<int32_t>(v1[0]);
+	int32_t neg_tot;
+	const int32_t neg_ex = block_excl_max<kCrackWaves>((i0 < i1) ? -(S0 + mn) : INT32_MIN, neg_tot, s_scanmax);
+	const int32_t M0 = -(neg_ex > 0 ? neg_ex : 0);     // min(0, running minimum before my symbols)
+
+	uint32_t nT = 0, nCE = 0;
+	int32_t lt = -1;
+	{
+		int32_t sr = S0, m = M0;
+		for (uint32_t i = i0; i < i1; i++) {
+			const bool isT = t.kind[i] == SYM_T;
+			const int32_t before = sr - m;
+			sr += isT ? -1 : 1;
+			m = sr < m ? sr : m;
+			t.depth[i] = static_cast<DEP>(sr - m);
+			if (isT) { nT++; nCE += (before == 0); lt = static_cast<int32_t>(i); }
+		}
+	}
+	uint32_t v2[2] = { nT, nCE }, t2[2];
+	block_excl_add<2, kCrackWaves>(v2, t2, s_scan);
+	const uint32_t T0 = v2[0], C0 = v2[1], totalT = t2[0];
+	int32_t lt_tot;
+	const int32_t LT0 = block_excl_max<kCrackWaves>(lt, lt_tot, s_scanmax);
+	{
+		int32_t cur = LT0 < 0 ? -1 : LT0;
+		int32_t sr = S0, m = M0;
+		uint32_t c = C0;
+		for (uint32_t i = i0; i < i1; i++) {
+			const bool isT = t.kind[i] == SYM_T;
+			const int32_t before = sr - m;
+			sr += isT ? -1 : 1;
+			m = sr < m ? sr : m;
+			if (isT) {
+				cur = static_cast<int32_t>(i);
+				if (before == 0) {
+					c++;
+					if (c >= n_nodes) atomicMin(s_first_dead, i);   // trailing pad codes start here
+				}
+			}
+			t.lastT[i] = cur < 0 ? NONE : static_cast<IDX>(cur);
+		}
+	}
+	__syncthreads();
+	const uint32_t ngroups = (N + 63u) / 64u;
+	for (uint32_t gi = tid; gi < ngroups; gi += kCrackBlock) {
+		int32_t mv = INT32_MAX;
+		const uint32_t e = min(N, gi * 64u + 64u);
+		for (uint32_t i = gi * 64u; i < e; i++) { const int32_t d = static_cast<int32_t>(t.depth[i]); mv = d < mv ? d : mv; }
+		t.gmin[gi] = static_cast<DEP>(mv > 32767 ? 32767 : mv);
+	}
+	__syncthreads();
+	const uint32_t first_dead = *s_first_dead;
+	const uint32_t n_eff = min(N, first_dead);
+
+	{
+		int32_t sr = S0, m = M0;
+		uint32_t c = C0;
+		for (uint32_t i = i0; i < i1; i++) {
+			const bool isT = t.kind[i] == SYM_T;
+			const int32_t before = sr - m;
+			sr += isT ? -1 : 1;
+			m = sr < m ? sr : m;
+			uint32_t val = 0, ptr = kLinkNone;
+			if (isT && before == 0) c++;
+			if (isT && i < n_eff) {
+				if (before == 0) val = nodes[c];                    // next chain (c < n_nodes: i is before the pad)
+				else {
+					const uint32_t j = static_cast<uint32_t>(prev_smaller<DEP>(t.depth, t.gmin, static_cast<int32_t>(i), before) + 1);
+					const uint32_t pos_j = t.dx[j] + sxe * t.dy[j];
+					const IDX tp = t.lastT[j];
+					if (tp == NONE) val = nodes[0] + pos_j;
+					else { val = pos_j - (t.dx[tp] + sxe * t.dy[tp]); ptr = static_cast<uint32_t>(tp); }
+				}
+			}
+			t.link[i] = (static_cast<unsigned long long>(ptr) << 32) | val;
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = i0; i < i1; i++) {
+		if (t.kind[i] != SYM_T || i >= n_eff) continue;
+		volatile unsigned long long* lk = t.link;
+		unsigned long long me = lk[i];
+		for (uint32_t guard = 0; (me >> 32) != kLinkNone && guard <= N; guard++) {
+			const unsigned long long other = lk[static_cast<uint32_t>(me >> 32)];
+			me = (other & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(static_cast<uint32_t>(me) + static_cast<uint32_t>(other));
+			lk[i] = me;
+		}
+	}
+	__syncthreads();
+	{
+		uint32_t tc = T0;
+		for (uint32_t i = i0; i < i1; i++) {
+			if (t.kind[i] != SYM_T) continue;
+			if (i < n_eff) {
+				uint32_t A = static_cast<uint32_t>(t.link[i]);
+				if (A >= nverts) { rerr |= ERR_RANGE; A = 0; }
+				const uint32_t ay = A / sxe;
+				t.seg_x[tc + 1] = (A - ay * sxe) - t.dx[i];
+				t.seg_y[tc + 1] = ay - t.dy[i];
+			}
+			if (i == first_dead) *s_valid_segs = tc + 1u;
+			tc++;
+		}
+	}
+	if (tid == 0) {
+		const uint32_t n0 = nodes[0];
+		t.seg_x[0] = n0 % sxe;
+		t.seg_y[0] = n0 / sxe;
+		if (first_dead >= N) *s_valid_segs = totalT + 1u;
+	}
+	__syncthreads();
+}
+
+// LDS carving for a capacity of n control symbols: seg_x | seg_y | link | dx | dy | depth | lastT | gmin | kind.
+// In pass 1 only the segment offsets are still needed; everything behind them is reused as
+// the raster band buffer.
+static inline size_t crack_lds_seg_bytes(uint32_t n) { return (static_cast<size_t>(n) + 2) * 4 * 2; }
+static inline size_t crack_lds_bytes(uint32_t n) {
+	return crack_lds_seg_bytes(n) + static_cast<size_t>(n) * 8 + static_cast<size_t>(n) * 4 * 2
+		+ static_cast<size_t>(n) * 2 * 2 + (static_cast<size_t>(n) / 64 + 2) * 2 + n + 16;
+}
+
+struct TileCarry {
+	uint32_t sum = 0;        // running mod-4 sum of difference codes
+	uint32_t move = 0;       // move of the last code of the previous tile
+	uint32_t ctrl = 0;       // was that code the second half of a control pair
+	int32_t lf = -1;         // last position whose `reverse-of-previous` test was false
+	uint32_t a = 0, dx = 0, dy = 0;   // a: controls (pass 0) / 't's (pass 1); displacement
+};
+
+// Symbols of one tile (kCrackTile code positions from `tile`), all threads of the
+// workgroup: thread t derives the symbols of its 128 positions into ws[] and gets the
+// exclusive counts before its first position (o_a, o_dx, o_dy); the carries advance
+// to the next tile.  The last barrier inside is behind every use of the LDS scratch.
+template <bool COUNT_T>
+__device__ __forceinline__ void tile_symbols(
+	const uint32_t* __restrict__ words, uint32_t wshift, uint32_t n_codes, uint32_t tile, TileCarry& c,
+	WordSyms (&ws)[kCrackWords], uint32_t& o_a, uint32_t& o_dx, uint32_t& o_dy,
+	uint32_t* s_scan, int32_t* s_scanmax, uint8_t* s_last_move, uint8_t* s_last_ctrl
+) {
+	const uint32_t tid = threadIdx.x;
+	const uint32_t g0 = tile + tid * (kCrackWords * 16u);
+	// -- load, running sums mod 4
+	uint32_t mv[kCrackWords];
+	uint32_t tsum = 0;
+	{
+		uint32_t q[kCrackWords + 1];
+		const uint32_t w0 = g0 / 16u;
+#pragma unroll
+		for (uint32_t j = 0; j <= kCrackWords; j++) {
+			// word j is needed when any of its codes exists; the shifted read also takes the low bytes of word j+1
+			const bool need = (g0 + 16u * j < n_codes) || (j > 0 && wshift && g0 + 16u * (j - 1u) < n_codes);
+			q[j] = need ? words[w0 + j] : 0u;
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < kCrackWords; j++) {
+			uint32_t cw = wshift ? __funnelshift_r(q[j], q[j + 1], wshift) : q[j];
+			const uint32_t fm = fields_below(static_cast<int64_t>(n_codes) - static_cast<int64_t>(g0 + 16u * j));
+			cw &= fm | (fm << 1);
+			cw = prefix_fields(cw);
+			mv[j] = add_fields(cw, tsum * kLo);
+			tsum = mv[j] >> 30;
+		}
+	}
+	uint32_t v1[1] = { tsum }, t1[1];
+	block_excl_add<1, kCrackWaves>(v1, t1, s_scan);
+	const uint32_t base_sum = ((c.sum + v1[0]) & 3u) * kLo;
+#pragma unroll
+	for (uint32_t j = 0; j < kCrackWords; j++) mv[j] = add_fields(mv[j], base_sum);
+	s_last_move[tid] = static_cast<uint8_t>(mv[kCrackWords - 1] >> 30);
+	__syncthreads();
+	const uint32_t prev_move = tid ? s_last_move[tid - 1] : c.move;
+	const uint32_t tile_last_move = s_last_move[kCrackBlock - 1];
+
+	// -- r: code g is the exact reverse of code g-1
+	uint32_t r[kCrackWords];
+	int32_t lf = INT32_MIN;
+#pragma unroll
+	for (uint32_t j = 0; j < kCrackWords; j++) {
+		const uint32_t gw = g0 + 16u * j;
+		const uint32_t prevs = (mv[j] << 2) | (j ? (mv[j - 1] >> 30) : prev_move);
+		const uint32_t x = mv[j] ^ prevs;
+		uint32_t rv = fields_below(static_cast<int64_t>(n_codes) - static_cast<int64_t>(gw));
+		if (gw == 0) rv &= ~1u;
+		r[j] = (x >> 1) & ~x & rv;
+		const uint32_t nr = ~r[j] & kLo;
+		if (nr) lf = static_cast<int32_t>(gw + ((31u - __clz(nr)) >> 1));
+	}
+	int32_t lf_tot;
+	int32_t lf_in = block_excl_max<kCrackWaves>(lf, lf_tot, s_scanmax);
+	if (lf_in < c.lf) lf_in = c.lf;
+	// -- ctrl: within a run of reverses, the positions at an odd distance from the last non-reverse
+	uint32_t ctrl[kCrackWords];
+#pragma unroll
+	for (uint32_t j = 0; j < kCrackWords; j++) {
+		const uint32_t gw = g0 + 16u * j;
+		const uint32_t rj = r[j];
+		uint32_t es = rj & ~(rj << 2) & kEvenF;           // runs starting on an even field
+		if ((rj & 1u) && !((gw - static_cast<uint32_t>(lf_in)) & 1u)) es &= ~1u;   // run continues from before and field 0 is not a control
+		const uint32_t r2 = rj | (rj << 1);
+		const uint32_t inA = rj & ~(r2 + es);             // fields of the runs counted from an even field
+		ctrl[j] = (inA & kEvenF) | (rj & ~inA & kOddF);
+		const uint32_t nr = ~rj & kLo;
+		if (nr) lf_in = static_cast<int32_t>(gw + ((31u - __clz(nr)) >> 1));
+	}
+	s_last_ctrl[tid] = static_cast<uint8_t>((ctrl[kCrackWords - 1] >> 30) & 1u);
+	__syncthreads();
+	const uint32_t prev_ctrl = tid ? s_last_ctrl[tid - 1] : c.ctrl;
+	const uint32_t tile_last_ctrl = s_last_ctrl[kCrackBlock - 1];
+
+	// -- events: position g emits the symbol of code g-1 unless g-1 was a control half
+	uint32_t n_a = 0, ddx = 0, ddy = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < kCrackWords; j++) {
+		const uint32_t gw = g0 + 16u * j;
+		WordSyms& w = ws[j];
+		w.prevs = (mv[j] << 2) | (j ? (mv[j - 1] >> 30) : prev_move);
+		const uint32_t pc = ((ctrl[j] << 2) | (j ? ((ctrl[j - 1] >> 30) & 1u) : prev_ctrl)) & kLo;
+		uint32_t ev = fields_below(static_cast<int64_t>(n_codes) + 1 - static_cast<int64_t>(gw));
+		if (gw == 0) ev &= ~1u;
+		const uint32_t emit = ev & ~pc;
+		w.ctl = emit & ctrl[j];
+		w.isT = w.ctl & ~(mv[j] ^ (mv[j] >> 1));
+		w.ms = emit & ~ctrl[j];
+		n_a += __popc(COUNT_T ? w.isT : w.ctl);
+		ddx += __popc(w.right()) - __popc(w.left());
+		ddy += __popc(w.down()) - __popc(w.up());
+	}
+	uint32_t v3[3] = { n_a, ddx, ddy }, t3[3];
+	block_excl_add<3, kCrackWaves>(v3, t3, s_scan);
+	o_a = c.a + v3[0]; o_dx = c.dx + v3[1]; o_dy = c.dy + v3[2];
+
+	c.sum = (c.sum + t1[0]) & 3u;
+	c.move = tile_last_move;
+	c.ctrl = tile_last_ctrl;
+	if (lf_tot > c.lf) c.lf = lf_tot;
+	c.a += t3[0]; c.dx += t3[1]; c.dy += t3[2];
+}
+
+// Rasterises the moves of one thread's 128 positions (crackcodes.hpp:706-862).  Vertical
+// moves cross planeV, horizontal moves cross planeH; consecutive moves that land in one
+// plane word are OR-ed into it once.  BAND: the target is the LDS band buffer holding
+// rows [band_y0, band_y0 + band_rows) of both planes; otherwise the planes in HBM.
+template <bool BAND>
+__device__ __forceinline__ void raster_moves(
+	const WordSyms (&ws)[kCrackWords], uint32_t o_t, uint32_t o_dx, uint32_t o_dy, uint32_t valid_segs,
+	const uint32_t* seg_x, const uint32_t* seg_y, uint32_t sx, uint32_t sy, uint32_t row_words,
+	uint32_t* band, uint32_t band_y0, uint32_t band_rows, uint32_t* pv, uint32_t* ph, uint32_t& rerr
+) {
+	uint32_t bx = 0, by = 0;
+	bool act = o_t < valid_segs;
+	if (act) { bx = seg_x[o_t]; by = seg_y[o_t]; }
+	uint32_t x = bx + o_dx, y = by + o_dy;
+	constexpr uint32_t kNoWord = 0xFFFFFFFFu;
+	uint32_t cur_idx = kNoWord, cur_bits = 0;
+	uint32_t* cur_word = nullptr;
+	const uint32_t h_off = band_rows * row_words;
+#pragma unroll
+	for (uint32_t j = 0; j < kCrackWords; j++) {
+		const WordSyms& w = ws[j];
+		for (uint32_t m = w.ms | w.isT; m; m &= m - 1u) {
+			const uint32_t b = __ffs(m) - 1u;
+			if ((w.isT >> b) & 1u) {
+				o_t++;
+				act = o_t < valid_segs;
+				if (act) {
+					const uint32_t nbx = seg_x[o_t], nby = seg_y[o_t];
+					x += nbx - bx; y += nby - by;
+					bx = nbx; by = nby;
+				}
+				continue;
+			}
+			const uint32_t k = (w.prevs >> b) & 3u;
+			const uint32_t isU = (k == SYM_U), isL = (k == SYM_L);
+			const uint32_t row = y - isU, col = x - isL;
+			const uint32_t nx = x + (k == SYM_R) - isL, ny = y + (k == SYM_D) - isU;
+			if (act) {
+				if (x > sx || y > sy || nx > sx || ny > sy) rerr |= ERR_RANGE;
+				else {
+					const bool horiz = k & 1u;
+					const bool ok = horiz ? (row - 1u < sy - 1u && col < sx) : (col - 1u < sx - 1u && row < sy);
+					if (BAND) {
+						const uint32_t rel = row - band_y0;
+						if (ok && rel < band_rows) {
+							const uint32_t idx = (horiz ? h_off : 0u) + rel * row_words + (col >> 5);
+							if (idx != cur_idx) {
+								if (cur_idx != kNoWord) atomicOr(band + cur_idx, cur_bits);
+								cur_idx = idx;
+								cur_bits = 0;
+							}
+							cur_bits |= 1u << (col & 31u);
+						}
+					}
+					else if (ok) {
+						uint32_t* word = (horiz ? ph : pv) + static_cast<uint64_t>(row) * row_words + (col >> 5);
+						if (word != cur_word) {
+							if (cur_word) atomicOr(cur_word, cur_bits);
+							cur_word = word;
+							cur_bits = 0;
+						}
+						cur_bits |= 1u << (col & 31u);
+					}
+				}
+			}
+			x = nx; y = ny;
+		}
+	}
+	if (BAND) { if (cur_idx != kNoWord) atomicOr(band + cur_idx, cur_bits); }
+	else if (cur_word) atomicOr(cur_word, cur_bits);
+}
 
 // DIAG builds stamp the phase boundaries (diagnostic only): diag[zi*8 + {A, B, C, D}] cycles
 template <bool DIAG>
 __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsigned long long* __restrict__ diag) {
+	extern __shared__ unsigned long long s_dyn[];
 	__shared__ uint32_t s_scan[4 * kCrackWaves];
 	__shared__ int32_t s_scanmax[kCrackWaves];
-	__shared__ uint32_t s_last_move[kCrackBlock];
-	__shared__ uint32_t s_last_ctrl[kCrackBlock];
-	constexpr uint32_t kStackLds = 2048;
-	__shared__ uint32_t s_stack[kStackLds];
-	__shared__ uint32_t s_nnodes, s_ncodes, s_nctl, s_valid_segs, s_err;
+	__shared__ uint8_t s_last_move[kCrackBlock];
+	__shared__ uint8_t s_last_ctrl[kCrackBlock];
+	__shared__ uint32_t s_nnodes, s_ncodes, s_valid_segs, s_err, s_first_dead;
 
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 	auto stamp = [&](int slot) {
@@ -99,7 +511,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	};
 
 	const uint32_t zi = blockIdx.x;
-	const int tid = threadIdx.x;
+	const uint32_t tid = threadIdx.x;
 	const uint8_t* code = a.stream + a.code_off[zi];
 	const uint32_t code_len = a.code_len[zi];
 	const uint64_t cb = a.cbase[zi];
@@ -109,6 +521,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	const uint32_t sxe = a.sx + 1, sye = a.sy + 1;
 	const uint32_t nverts = sxe * sye;
 	const uint32_t sx = a.sx, sy = a.sy;
+	uint32_t* upacked = a.upacked ? a.upacked + cb / 16u + 2ull * zi : nullptr;
 
 	// ---- phase A: beginning-of-chain index (crackcodes.hpp:283-316), serial ----
 	if (tid == 0) {
@@ -142,18 +555,16 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 					}
 				}
 			}
-			// ---- markov bitstream -> unpacked difference codes (markov.hpp:268-313), serial ----
+			// ---- markov bitstream -> difference codes, 16 per word (markov.hpp:268-313), serial ----
 			const uint32_t nbytes = code_len - index_end;
 			if (a.markov_order == 0) {
 				ncodes = nbytes * 4u;
 			}
 			else if (nbytes > 0) {
 				const uint8_t* s = code + index_end;
-				uint8_t* uc = a.ucode + cb;
 				const int shift = 2 * (a.markov_order - 1);
-				uint32_t m = 0;
 				const uint32_t start = s[0] & 3u;
-				uc[m++] = static_cast<uint8_t>(start);
+				uint32_t m = 1, word = start;
 				uint32_t ctx = start << shift;
 				int pos = 2;
 				for (uint32_t i = 0; i < nbytes; i++) {
@@ -167,12 +578,17 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 						else if ((cp & 4u) == 0) { rank = 2; pos += 3; }
 						else { rank = 3; pos += 3; }
 						const uint32_t v = a.model[ctx * 4u + rank];
-						if (m < cap) uc[m++] = static_cast<uint8_t>(v);
+						if (m < cap) {
+							word |= v << (2u * (m & 15u));
+							m++;
+							if ((m & 15u) == 0) { upacked[(m >> 4) - 1u] = word; word = 0; }
+						}
 						else err |= ERR_CAPACITY;
 						ctx = (ctx >> 2) + (v << shift);
 					}
 					pos -= 8;
 				}
+				upacked[m >> 4] = word;
 				ncodes = m;
 			}
 		}
@@ -180,329 +596,178 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		s_nnodes = nn;
 		s_ncodes = ncodes;
 		s_err = err;
-		s_valid_segs = 0;
-		s_nctl = 0;
+		s_valid_segs = 1;
+		s_first_dead = 0xFFFFFFFFu;
 	}
 	__syncthreads();
+	if (a.markov_order) __threadfence_block();
 	stamp(0);
 	const uint32_t n_codes = s_ncodes;
 	const uint32_t n_nodes = s_nnodes;
 	const uint32_t index_end = 4u + (code_len >= 4u ? rd_le_dev(code, 4) : 0u);
-	const uint8_t* packed = code + index_end;          // only dereferenced when n_codes > 0 (then index_end <= code_len)
-	const uint8_t* ucode = a.ucode + cb;
+	// packed difference codes as aligned words + a byte shift (only dereferenced when n_codes > 0)
+	const uint8_t* packed = code + index_end;
+	const uint32_t* words;
+	uint32_t wshift;
+	if (a.markov_order) { words = upacked; wshift = 0; }
+	else {
+		const uintptr_t pa = reinterpret_cast<uintptr_t>(packed);
+		words = reinterpret_cast<const uint32_t*>(pa & ~static_cast<uintptr_t>(3));
+		wshift = static_cast<uint32_t>(pa & 3u) * 8u;
+	}
 
-	uint8_t* ctl_kind = a.ctl_kind + cb;
-	uint32_t* ctl_pos = a.ctl_pos + cb;
-	uint32_t* ctl_seg = a.ctl_seg + cb;
-	uint32_t* seg_off = a.seg_off + cb;
-	uint32_t* stack = a.stack + cb;
+	// control tables: LDS when the slice's control symbols fit, else global
+	const uint32_t lcap = a.lds_controls;
+	CtlTables<uint16_t, int16_t> lt;
+	{
+		uint32_t* p4 = reinterpret_cast<uint32_t*>(s_dyn);
+		lt.seg_x = p4; p4 += lcap + 2;
+		lt.seg_y = p4; p4 += lcap + 2;
+		unsigned long long* p8 = reinterpret_cast<unsigned long long*>(p4);   // (lcap + 2) * 8 bytes in: still 8-byte aligned
+		lt.link = p8; p8 += lcap;
+		p4 = reinterpret_cast<uint32_t*>(p8);
+		lt.dx = p4; p4 += lcap;
+		lt.dy = p4; p4 += lcap;
+		uint16_t* p2 = reinterpret_cast<uint16_t*>(p4);
+		lt.depth = reinterpret_cast<int16_t*>(p2); p2 += lcap;
+		lt.lastT = p2; p2 += lcap;
+		lt.gmin = reinterpret_cast<int16_t*>(p2); p2 += lcap / 64 + 2;
+		lt.kind = reinterpret_cast<uint8_t*>(p2);
+	}
+	const uint64_t kb = cb / 2u + 4ull * zi;
+	const uint32_t kcap = cap / 2u + 4u;
+
 	uint32_t* pv = a.planeV + zi * a.plane_words;
 	uint32_t* ph = a.planeH + zi * a.plane_words;
+	const uint32_t row_words = a.row_words;
 	uint32_t rerr = 0;
+	const uint32_t* seg_x = lt.seg_x;
+	const uint32_t* seg_y = lt.seg_y;
+	uint32_t band_off_words = 2u * (lcap + 2u);   // LDS words in front of the raster band buffer
+	const bool have_cracks = n_nodes > 0 && n_codes > 0;
 
 	// The symbol stream is derived twice from the packed codes (~25 KiB per slice) instead
 	// of being stored: pass 0 records only the control symbols ('b'/'t', ~3 % of the
-	// stream) for the branch matcher (phase C); pass 1 recomputes every symbol and
-	// rasterises the moves straight from registers (phase D) once the offset of every
-	// segment is known.
-	for (int pass = 0; pass < 2 && n_nodes > 0 && n_codes > 0; pass++) {
-		const uint32_t valid_segs = s_valid_segs;   // pass 1: set by phase C
-
-		// ---- phase B: codes -> symbols, tiled block scans with carries -------------------
-		// (crackcodes.hpp:547-598 / SURVEY.md Appendix D6)
-		// Every code position g in [0, n_codes] is visited; position g finalises the
-		// symbol of code g-1 (a move becomes 'b'/'t' when code g is its exact reverse).
-		uint32_t carry_sum = 0;          // running mod-4 sum of difference codes
-		uint32_t carry_move = 0xFF;      // move of code g0-1 (0xFF: none)
-		uint32_t carry_ctrl = 0;         // was code g0-1 the second half of a control pair
-		int32_t carry_lf = -1;           // last position whose `reverse-of-previous` test was false
-		uint32_t carry_nt = 0, carry_nctl = 0, carry_pos = 0;
-		constexpr uint32_t kPer = 16;
-		constexpr uint32_t kTile = kCrackBlock * kPer;
-
-		for (uint32_t tile = 0; tile <= n_codes; tile += kTile) {
-			const uint32_t g0 = tile + tid * kPer;
-			// -- load 16 difference codes
-			uint32_t dc[kPer];
-			uint32_t tsum = 0;
+	// stream) for the branch matcher; pass 1 recomputes every symbol and rasterises the
+	// moves straight from registers once the offset of every segment is known.
+	if (have_cracks) {
+		TileCarry c;
+		for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile) {
+			WordSyms ws[kCrackWords];
+			uint32_t o_a, o_dx, o_dy;
+			tile_symbols<false>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+			// ---- record the control symbols with the displacement before them
 #pragma unroll
-			for (uint32_t k = 0; k < kPer; k++) {
-				const uint32_t g = g0 + k;
-				uint32_t c = 0;
-				if (g < n_codes) {
-					c = a.markov_order ? ucode[g] : ((packed[g >> 2] >> (2 * (g & 3))) & 3u);
+			for (uint32_t j = 0; j < kCrackWords; j++) {
+				const WordSyms& w = ws[j];
+				const uint32_t mR = w.right(), mL = w.left(), mD = w.down(), mU = w.up();
+				for (uint32_t m = w.ctl; m; m &= m - 1u) {
+					const uint32_t b = __ffs(m) - 1u;
+					const uint32_t below = (1u << b) - 1u;
+					const uint32_t kind = ((w.isT >> b) & 1u) ? SYM_T : SYM_B;
+					const uint32_t cx = o_dx + __popc(mR & below) - __popc(mL & below);
+					const uint32_t cy = o_dy + __popc(mD & below) - __popc(mU & below);
+					if (o_a < lcap) { lt.kind[o_a] = static_cast<uint8_t>(kind); lt.dx[o_a] = cx; lt.dy[o_a] = cy; }
+					else if (o_a + 2u < kcap) { a.g_kind[kb + o_a] = static_cast<uint8_t>(kind); a.g_dx[kb + o_a] = cx; a.g_dy[kb + o_a] = cy; }
+					o_a++;
 				}
-				tsum = (tsum + c) & 3u;
-				dc[k] = tsum;   // inclusive local sum mod 4
+				o_dx += __popc(mR) - __popc(mL);
+				o_dy += __popc(mD) - __popc(mU);
 			}
-			uint32_t v1[1] = { tsum }, t1[1];
-			block_excl_add<1, kCrackWaves>(v1, t1, s_scan);
-			const uint32_t base_sum = (carry_sum + v1[0]) & 3u;
-			uint32_t mv[kPer];
-#pragma unroll
-			for (uint32_t k = 0; k < kPer; k++) mv[k] = (dc[k] + base_sum) & 3u;
-			s_last_move[tid] = mv[kPer - 1];
-			__syncthreads();
-			const uint32_t prev_move = tid ? s_last_move[tid - 1] : carry_move;
-			const uint32_t tile_last_move = s_last_move[kCrackBlock - 1];
-
-			// -- r[g]: code g is the exact reverse of code g-1; runs of r alternate ctrl/move
-			uint32_t rmask = 0;
-			int32_t lf = INT32_MIN;
-#pragma unroll
-			for (uint32_t k = 0; k < kPer; k++) {
-				const uint32_t g = g0 + k;
-				const uint32_t pm = k ? mv[k - 1] : prev_move;
-				const bool r = (g > 0) && (g < n_codes) && (pm != 0xFF) && ((mv[k] ^ pm) == 2u);
-				if (r) rmask |= (1u << k);
-				else lf = static_cast<int32_t>(g);
-			}
-			int32_t lf_tot;
-			int32_t lf_in = block_excl_max<kCrackWaves>(lf, lf_tot, s_scanmax);
-			if (lf_in < carry_lf) lf_in = carry_lf;
-			uint32_t cmask = 0;   // ctrl flags of my 16 codes
-			{
-				int32_t cur = lf_in;
-#pragma unroll
-				for (uint32_t k = 0; k < kPer; k++) {
-					const int32_t g = static_cast<int32_t>(g0 + k);
-					if (rmask & (1u << k)) { if ((g - cur) & 1) cmask |= (1u << k); }
-					else cur = g;
-				}
-			}
-			s_last_ctrl[tid] = (cmask >> (kPer - 1)) & 1u;
-			__syncthreads();
-			const uint32_t prev_ctrl = tid ? s_last_ctrl[tid - 1] : carry_ctrl;
-			const uint32_t tile_last_ctrl = s_last_ctrl[kCrackBlock - 1];
-
-			// -- events: position g emits the symbol of code g-1 unless g-1 was a control half
-			uint32_t emask = 0;
-			uint32_t n_t = 0, n_ctl = 0, dpos = 0;
-#pragma unroll
-			for (uint32_t k = 0; k < kPer; k++) {
-				const uint32_t g = g0 + k;
-				const uint32_t pm = k ? mv[k - 1] : prev_move;
-				const uint32_t pc = k ? ((cmask >> (k - 1)) & 1u) : prev_ctrl;
-				if (g >= 1 && g <= n_codes && !pc && pm != 0xFF) {
-					uint32_t kind;
-					if (g < n_codes && (cmask & (1u << k))) kind = (mv[k] == 0u || mv[k] == 3u) ? SYM_T : SYM_B;
-					else kind = pm;
-					emask |= (1u << k);
-					if (kind == SYM_T) n_t++;
-					if (kind >= SYM_B) n_ctl++;
-					else dpos += (kind == SYM_R) ? 1u : (kind == SYM_L) ? 0xFFFFFFFFu : (kind == SYM_D) ? sxe : (0u - sxe);
-				}
-			}
-			uint32_t v3[3] = { n_t, n_ctl, dpos }, t3[3];
-			block_excl_add<3, kCrackWaves>(v3, t3, s_scan);
-			uint32_t o_t = carry_nt + v3[0], o_ctl = carry_nctl + v3[1], o_pos = carry_pos + v3[2];
-
-			uint32_t* cur_word = nullptr;     // pass 1: bits of consecutive moves in one plane word
-			uint32_t cur_bits = 0;
-#pragma unroll
-			for (uint32_t k = 0; k < kPer; k++) {
-				if (!(emask & (1u << k))) continue;
-				const uint32_t g = g0 + k;
-				const uint32_t pm = k ? mv[k - 1] : prev_move;
-				uint32_t kind;
-				if (g < n_codes && (cmask & (1u << k))) kind = (mv[k] == 0u || mv[k] == 3u) ? SYM_T : SYM_B;
-				else kind = pm;
-				if (pass == 0) {
-					if (kind >= SYM_B && o_ctl < cap) {
-						ctl_kind[o_ctl] = static_cast<uint8_t>(kind);
-						ctl_pos[o_ctl] = o_pos;
-						ctl_seg[o_ctl] = o_t;
-					}
-				}
-				else if (kind < SYM_B && o_t < valid_segs) {
-					// ---- phase D: rasterise the move (crackcodes.hpp:706-862).  Vertical moves
-					// cross planeV, horizontal moves cross planeH; consecutive moves of a straight
-					// horizontal stretch share a plane word and are OR-ed into memory once.
-					const uint32_t t = seg_off[o_t] + o_pos;
-					if (t >= nverts) rerr |= ERR_RANGE;
-					else {
-						const uint32_t y = t / sxe;
-						const uint32_t x = t - y * sxe;
-						uint32_t* word = nullptr;
-						uint32_t bx = 0;
-						if (kind == SYM_D) {          // edge (x,y)-(x,y+1): between pixels (x-1,y) | (x,y)
-							if (x >= 1 && x < sx && y < sy) { word = pv + static_cast<uint64_t>(y) * a.row_words + (x >> 5); bx = x; }
-							else if (y >= sy) rerr |= ERR_RANGE;
-						}
-						else if (kind == SYM_U) {     // edge (x,y-1)-(x,y)
-							if (x >= 1 && x < sx && y >= 1) { word = pv + static_cast<uint64_t>(y - 1) * a.row_words + (x >> 5); bx = x; }
-							else if (y < 1) rerr |= ERR_RANGE;
-						}
-						else if (kind == SYM_R) {     // edge (x,y)-(x+1,y): between pixels (x,y-1) | (x,y)
-							if (y >= 1 && y < sy && x < sx) { word = ph + static_cast<uint64_t>(y) * a.row_words + (x >> 5); bx = x; }
-							else if (x >= sx) rerr |= ERR_RANGE;
-						}
-						else {                        // SYM_L: edge (x-1,y)-(x,y)
-							if (y >= 1 && y < sy && x >= 1) { word = ph + static_cast<uint64_t>(y) * a.row_words + ((x - 1) >> 5); bx = x - 1; }
-							else if (x < 1) rerr |= ERR_RANGE;
-						}
-						if (word) {
-							if (word != cur_word) {
-								if (cur_word) atomicOr(cur_word, cur_bits);
-								cur_word = word;
-								cur_bits = 0;
-							}
-							cur_bits |= 1u << (bx & 31);
-						}
-					}
-				}
-				if (kind == SYM_T) o_t++;
-				if (kind >= SYM_B) o_ctl++;
-				else o_pos += (kind == SYM_R) ? 1u : (kind == SYM_L) ? 0xFFFFFFFFu : (kind == SYM_D) ? sxe : (0u - sxe);
-			}
-			if (cur_word) atomicOr(cur_word, cur_bits);
-
-			// -- carries to the next tile (uniform across the block)
-			carry_sum = (carry_sum + t1[0]) & 3u;
-			carry_move = (tile + kTile <= n_codes) ? tile_last_move : 0xFF;
-			carry_ctrl = tile_last_ctrl;
-			if (lf_tot > carry_lf) carry_lf = lf_tot;
-			carry_nt += t3[0]; carry_nctl += t3[1]; carry_pos += t3[2];
 			__syncthreads();
 		}
-		if (pass == 1) break;
-		if (tid == 0) {
-			s_nctl = carry_nctl < cap ? carry_nctl : cap;
-			if (carry_nctl > cap) s_err |= ERR_CAPACITY;
-		}
-		__syncthreads();
 		stamp(1);
-		const uint32_t n_ctl = s_nctl;
 
-		// ---- phase C: branch matching over the control symbols, 64 at a time by wave 0 ----
-		// (crackcodes.hpp:771-781, 849-859: the rasteriser's revisit stack; chain
-		// segmentation by branches_taken, crackcodes.hpp:549-598).
-		// A 't' returns the cursor to where its matching 'b' was pushed.  Inside a chunk a
-		// 't' matches the nearest earlier control of the same nesting level when that is a
-		// 'b'; otherwise it pops the stack carried between chunks (or ends the chain when
-		// the stack is empty).  Segment offsets chain through earlier 't's of the chunk and
-		// are resolved by pointer jumping with shuffles.
-		if (tid < kWave) {
-			const int lane = tid;
-			uint32_t valid = 1;
-			uint32_t off = nodes[0];          // offset of the current segment (wave uniform)
-			uint32_t chain = 0, sp = 0;
-			bool done = false;
-			if (lane == 0) seg_off[0] = off;
-			const unsigned long long below = (1ull << lane) - 1ull;
-			constexpr int PTR_NONE = -1, PTR_CARRY = -2;
-			for (uint32_t base = 0; base < n_ctl && !done; base += kWave) {
-				const uint32_t k = base + lane;
-				const bool live = k < n_ctl;
-				uint32_t pos = 0, seg = 0, kind = SYM_U;
-				if (live) { kind = ctl_kind[k]; pos = ctl_pos[k]; seg = ctl_seg[k]; }
-				const bool isT = live && kind == SYM_T;
-				const bool isB = live && kind == SYM_B;
-				const unsigned long long tmask = __ballot(isT), bmask = __ballot(isB);
-				const uint32_t d = wave_incl_add(isB ? 1u : (isT ? 0xFFFFFFFFu : 0u));
-				const uint32_t level = isT ? d + 1u : d;     // 'b': depth after, 't': depth before
-				int match = -1;           // 't': lane of the matching 'b' in this chunk
-				bool matched_b = false;   // 'b': closed inside this chunk
-				for (unsigned long long todo = tmask | bmask; todo;) {
-					const int lead = __ffsll(static_cast<long long>(todo)) - 1;
-					const uint32_t lv = __shfl(level, lead, kWave);
-					const unsigned long long same = __ballot((isT || isB) && level == lv);
-					if ((isT || isB) && level == lv) {
-						if (isT) {
-							const unsigned long long prev = same & below;
-							if (prev) {
-								const int j = 63 - __clzll(static_cast<long long>(prev));
-								if ((bmask >> j) & 1ull) match = j;
-							}
-						}
-						else {
-							const unsigned long long next = same & ~below & ~(1ull << lane);
-							matched_b = next != 0;   // levels alternate b,t,b,t: the next one is its 't'
-						}
-					}
-					todo &= ~same;
-				}
-				const bool um_t = isT && match < 0;
-				const unsigned long long um_t_mask = __ballot(um_t);
-				const uint32_t q = __popcll(um_t_mask & below);      // rank among the chunk's unmatched 't'
-				const bool chain_end = um_t && q >= sp;
-				const uint32_t new_chain = chain + (q - sp) + 1u;     // meaningful when chain_end
-				const bool dead = chain_end && new_chain >= n_nodes;   // trailing pad codes start here
-				const unsigned long long dead_mask = __ballot(dead);
-				const int first_dead = dead_mask ? (__ffsll(static_cast<long long>(dead_mask)) - 1) : 64;
-				const bool ok = lane < first_dead;                    // lanes before the pad codes
-
-				// stack pops are read before anything is pushed back
-				uint32_t popped = 0;
-				if (um_t && !chain_end) {
-					const uint32_t idx = sp - 1u - q;
-					popped = idx < kStackLds ? s_stack[idx] : __hip_atomic_load(stack + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				const uint32_t pos_match = __shfl(pos, match >= 0 ? match : 0, kWave);
-				uint32_t val = 0;
-				int ptr = PTR_NONE;
-				if (isT && ok) {
-					if (match >= 0) {
-						const unsigned long long pt = tmask & ((1ull << match) - 1ull);
-						val = pos_match - pos;
-						ptr = pt ? (63 - __clzll(static_cast<long long>(pt))) : PTR_CARRY;
-					}
-					else if (!chain_end) val = popped - pos;
-					else val = nodes[new_chain] - pos;
-				}
+		// ---- branch matching
+		const uint32_t n_ctl = c.a;
+		if (n_ctl <= lcap) {
+			match_controls<uint16_t, int16_t>(lt, n_ctl, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, rerr);
+			// pack seg_y right behind the used part of seg_x: the rest of the LDS becomes the band buffer
+			const uint32_t vs = s_valid_segs;
+			constexpr uint32_t kMoves = 8;
+			uint32_t tmp[kMoves];
 #pragma unroll
-				for (int r = 0; r < 6; r++) {
-					const int pl = ptr >= 0 ? ptr : lane;
-					const uint32_t pvv = __shfl(val, pl, kWave);
-					const int pp = __shfl(ptr, pl, kWave);
-					if (ptr >= 0) { val += pvv; ptr = pp; }
-				}
-				const uint32_t my_off = val + (ptr == PTR_CARRY ? off : 0u);   // 't' lanes: offset of the segment they open
-
-				// position of every 'b' = offset of the segment it sits in + its displacement
-				const unsigned long long pt_b = tmask & below;
-				const int src = pt_b ? (63 - __clzll(static_cast<long long>(pt_b))) : -1;
-				const uint32_t src_off = __shfl(my_off, src >= 0 ? src : 0, kWave);
-				const uint32_t t_b = (src >= 0 ? src_off : off) + pos;
-
-				const unsigned long long ok_um_t = um_t_mask & (first_dead >= 64 ? ~0ull : ((1ull << first_dead) - 1ull));
-				const uint32_t n_um_t = __popcll(ok_um_t);
-				const uint32_t n_pop = n_um_t < sp ? n_um_t : sp;
-				const uint32_t sp_base = sp - n_pop;
-				const bool um_b = isB && ok && !matched_b;
-				const unsigned long long um_b_mask = __ballot(um_b);
-				if (um_b) {
-					const uint32_t idx = sp_base + __popcll(um_b_mask & below);
-					if (idx < kStackLds) s_stack[idx] = t_b; else stack[idx] = t_b;   // idx < #controls <= cap
-				}
-				if (isT && ok && seg + 1u < cap) seg_off[seg + 1u] = my_off;
-
-				// carries
-				const unsigned long long ok_t = tmask & (first_dead >= 64 ? ~0ull : ((1ull << first_dead) - 1ull));
-				const int last_t = ok_t ? (63 - __clzll(static_cast<long long>(ok_t))) : -1;
-				const uint32_t last_off = __shfl(my_off, last_t >= 0 ? last_t : 0, kWave);
-				const uint32_t last_seg = __shfl(seg, last_t >= 0 ? last_t : 0, kWave);
-				if (last_t >= 0) { off = last_off; valid = last_seg + 2u; }
-				chain += n_um_t - n_pop;
-				sp = sp_base + __popcll(um_b_mask);
-				if (dead_mask) {
-					valid = __shfl(seg, first_dead, kWave) + 1u;
-					done = true;
-				}
-				__threadfence_block();
+			for (uint32_t k = 0; k < kMoves; k++) { const uint32_t i = tid + k * kCrackBlock; tmp[k] = i < vs ? lt.seg_y[i] : 0u; }
+			__syncthreads();
+			if (vs <= kMoves * kCrackBlock) {
+#pragma unroll
+				for (uint32_t k = 0; k < kMoves; k++) { const uint32_t i = tid + k * kCrackBlock; if (i < vs) lt.seg_x[vs + i] = tmp[k]; }
+				seg_y = lt.seg_x + vs;
+				band_off_words = 2u * vs;
 			}
-			if (tid == 0) s_valid_segs = valid;
+			__syncthreads();
 		}
-		__syncthreads();
-		__threadfence_block();
+		else {
+			// more control symbols than the LDS tables hold: the first lcap were recorded in LDS
+			CtlTables<uint32_t, int32_t> gt;
+			gt.kind = a.g_kind + kb; gt.dx = a.g_dx + kb; gt.dy = a.g_dy + kb; gt.depth = a.g_depth + kb;
+			gt.lastT = a.g_lastT + kb; gt.link = a.g_link + kb; gt.seg_x = a.g_seg_x + kb; gt.seg_y = a.g_seg_y + kb;
+			gt.gmin = a.g_gmin + kb;
+			seg_x = gt.seg_x; seg_y = gt.seg_y;
+			band_off_words = 0;
+			uint32_t n = n_ctl;
+			if (n + 2u >= kcap) { n = kcap - 3u; rerr |= ERR_CAPACITY; }
+			for (uint32_t i = tid; i < lcap && i < n; i += kCrackBlock) { gt.kind[i] = lt.kind[i]; gt.dx[i] = lt.dx[i]; gt.dy[i] = lt.dy[i]; }
+			__syncthreads();
+			__threadfence_block();
+			match_controls<uint32_t, int32_t>(gt, n, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, rerr);
+			__threadfence_block();
+		}
+		if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 8 + 5] = n_ctl;
 		stamp(2);
+	}
+
+	// ---- pass 1: rasterise
+	const uint32_t valid_segs = s_valid_segs;
+	if (a.lds_raster) {
+		// Both planes are built band by band in LDS (ds_or) and streamed out with plain
+		// stores: no memset of the planes, no atomics on HBM.
+		uint32_t* band = reinterpret_cast<uint32_t*>(s_dyn) + band_off_words;
+		const uint32_t band_words = a.lds_words - band_off_words;
+		uint32_t band_rows = band_words / (2u * row_words);      // >= 1 (checked by the host)
+		if (band_rows > sy) band_rows = sy;
+		const bool single_tile = n_codes < kCrackTile;
+		WordSyms ws[kCrackWords];
+		uint32_t o_a = 0, o_dx = 0, o_dy = 0;
+		for (uint32_t y0 = 0; y0 < sy; y0 += band_rows) {
+			const uint32_t rows = min(band_rows, sy - y0);
+			const uint32_t nw = rows * row_words;
+			for (uint32_t i = tid; i < 2u * band_rows * row_words; i += kCrackBlock) band[i] = 0u;
+			__syncthreads();
+			if (have_cracks) {
+				TileCarry c;
+				for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile) {
+					if (!single_tile || y0 == 0) {
+						tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+					}
+					raster_moves<true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, nullptr, nullptr, rerr);
+				}
+			}
+			__syncthreads();
+			uint32_t* dv = pv + static_cast<uint64_t>(y0) * row_words;
+			uint32_t* dh = ph + static_cast<uint64_t>(y0) * row_words;
+			const uint32_t* bh = band + band_rows * row_words;
+			for (uint32_t i = tid; i < nw; i += kCrackBlock) { dv[i] = band[i]; dh[i] = bh[i]; }
+			__syncthreads();
+		}
+	}
+	else if (have_cracks) {
+		// planes were zeroed by the host; bits go straight to HBM
+		TileCarry c;
+		for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile) {
+			WordSyms ws[kCrackWords];
+			uint32_t o_a, o_dx, o_dy;
+			tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+			raster_moves<false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, nullptr, 0u, 0u, pv, ph, rerr);
+			__syncthreads();
+		}
 	}
 
 	if (rerr) atomicOr(&s_err, rerr);
 	__syncthreads();
 	stamp(3);
 	if (tid == 0 && s_err) atomicOr(a.slice_err + zi, s_err);
-	if (DIAG && tid == 0 && diag) { diag[static_cast<uint64_t>(zi) * 8 + 4] = n_codes; diag[static_cast<uint64_t>(zi) * 8 + 5] = s_nctl; }
+	if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 8 + 4] = n_codes;
 }
 
 // ------------------------------------------------------------------------------
@@ -717,8 +982,11 @@ struct ckl_decoder {
 	DevBuf<uint8_t> d_stream;
 	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off, d_rbase;
 	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap, d_rcap;
-	DevBuf<uint8_t> d_model, d_ucode, d_ctl_kind;
-	DevBuf<uint32_t> d_ctl_pos, d_ctl_seg, d_seg_off, d_stack, d_nodes;
+	DevBuf<uint8_t> d_model, d_ctl_kind;
+	DevBuf<uint32_t> d_upacked, d_ctl_dx, d_ctl_dy, d_ctl_lastT, d_seg_x, d_seg_y, d_nodes;
+	DevBuf<int32_t> d_ctl_depth, d_ctl_gmin;
+	DevBuf<unsigned long long> d_ctl_link;
+	uint32_t lds_controls = 0;          // capacity of k_decode_cracks' LDS control tables
 	DevBuf<uint32_t> d_planes;          // V then H
 	DevBuf<uint32_t> d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_ncomp_expect, d_blk_roots;
 	DevBuf<uint16_t> d_run_local;
@@ -835,12 +1103,14 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	upload(d.d_ncap, ncap, s);
 	upload(d.d_rbase, rbase, s);
 	upload(d.d_rcap, rcap, s);
-	if (h.markov_model_order) d.d_ucode.ensure(ctot);
-	d.d_ctl_kind.ensure(ctot);
-	d.d_ctl_pos.ensure(ctot);
-	d.d_ctl_seg.ensure(ctot);
-	d.d_seg_off.ensure(ctot);
-	d.d_stack.ensure(ctot);
+	if (h.markov_model_order) d.d_upacked.ensure(ctot / 16 + 2ull * d.nslices + 4);
+	{
+		// control symbol tables (global fallback of the LDS tables): a control symbol takes two codes
+		const size_t ktot = ctot / 2 + 4ull * d.nslices + 8;
+		d.d_ctl_kind.ensure(ktot); d.d_ctl_dx.ensure(ktot); d.d_ctl_dy.ensure(ktot);
+		d.d_ctl_depth.ensure(ktot); d.d_ctl_lastT.ensure(ktot); d.d_ctl_link.ensure(ktot);
+		d.d_seg_x.ensure(ktot); d.d_seg_y.ensure(ktot); d.d_ctl_gmin.ensure(ktot);
+	}
 	d.d_nodes.ensure(ntot);
 	d.d_parent.ensure(rtot);
 	d.d_run_start.ensure(rtot);
@@ -1043,9 +1313,14 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	auto h0 = std::chrono::steady_clock::now();
 
 	StageTimer st(d, s);
-	CKL_HIP(hipMemsetAsync(d.d_planes.p, 0, 2 * d.plane_words * ns * sizeof(uint32_t), s));
+	// k_decode_cracks builds the planes band by band in LDS when at least one row of both
+	// planes fits behind the segment tables; otherwise it ORs bits into zeroed planes in HBM
+	const size_t crack_lds = crack_lds_bytes(d.lds_controls);
+	const bool lds_raster = !getenv("CKL_NO_LDS_RASTER") &&
+		crack_lds >= crack_lds_seg_bytes(d.lds_controls) + 2ull * d.row_words * sizeof(uint32_t);
+	if (!lds_raster) CKL_HIP(hipMemsetAsync(d.d_planes.p, 0, 2 * d.plane_words * ns * sizeof(uint32_t), s));
 	CKL_HIP(hipMemsetAsync(d.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
-	st.done("memset planes");
+	st.done("memset");
 
 	CrackArgs ca;
 	ca.stream = d.d_stream.p;
@@ -1054,9 +1329,14 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.sx = static_cast<int>(h.sx); ca.sy = static_cast<int>(h.sy);
 	ca.xw = byte_width(static_cast<uint64_t>(h.sx) + 1); ca.yw = byte_width(static_cast<uint64_t>(h.sy) + 1);
 	ca.markov_order = h.markov_model_order;
-	ca.model = d.d_model.p; ca.ucode = d.d_ucode.p;
-	ca.ctl_kind = d.d_ctl_kind.p; ca.ctl_pos = d.d_ctl_pos.p; ca.ctl_seg = d.d_ctl_seg.p;
-	ca.seg_off = d.d_seg_off.p; ca.stack = d.d_stack.p; ca.nodes = d.d_nodes.p;
+	ca.model = d.d_model.p; ca.upacked = h.markov_model_order ? d.d_upacked.p : nullptr;
+	ca.g_kind = d.d_ctl_kind.p; ca.g_dx = d.d_ctl_dx.p; ca.g_dy = d.d_ctl_dy.p;
+	ca.g_depth = d.d_ctl_depth.p; ca.g_lastT = d.d_ctl_lastT.p; ca.g_link = d.d_ctl_link.p;
+	ca.g_seg_x = d.d_seg_x.p; ca.g_seg_y = d.d_seg_y.p; ca.g_gmin = d.d_ctl_gmin.p;
+	ca.nodes = d.d_nodes.p;
+	ca.lds_controls = d.lds_controls;
+	ca.lds_words = static_cast<uint32_t>(crack_lds / 4);
+	ca.lds_raster = lds_raster ? 1u : 0u;
 	ca.planeV = d.d_planes.p; ca.planeH = d.d_planes.p + d.plane_words * ns;
 	ca.row_words = d.row_words; ca.plane_words = d.plane_words;
 	ca.slice_err = d.d_slice_err.p;
@@ -1064,7 +1344,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		DevBuf<unsigned long long> d_diag;
 		d_diag.ensure(static_cast<size_t>(ns) * 8);
 		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 64, s));
-		hipLaunchKernelGGL(k_decode_cracks<true>, dim3(ns), dim3(kCrackBlock), 0, s, ca, d_diag.p);
+		hipLaunchKernelGGL(k_decode_cracks<true>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, d_diag.p);
 		std::vector<unsigned long long> dg(static_cast<size_t>(ns) * 8);
 		CKL_HIP(hipMemcpyAsync(dg.data(), d_diag.p, dg.size() * 8, hipMemcpyDeviceToHost, s));
 		CKL_HIP(hipStreamSynchronize(s));
@@ -1072,7 +1352,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 8; k++) m[k] += static_cast<double>(dg[zi * 8 + k]) / ns;
 		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5]);
 	}
-	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), 0, s, ca, static_cast<unsigned long long*>(nullptr));
+	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, static_cast<unsigned long long*>(nullptr));
 	st.done("k_decode_cracks");
 
 	RunGeom g;
@@ -1159,6 +1439,21 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 		d->device = device;
 		CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
 		for (auto& e : d->ev) CKL_HIP(hipEventCreate(&e));
+		{
+			// LDS control tables of k_decode_cracks: as many symbols as the workgroup's LDS allows
+			int max_lds = 0;
+			CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+			const size_t budget = static_cast<size_t>(max_lds > 4096 ? max_lds - 4096 : 0);   // static LDS of the kernel: ~2.4 KiB
+			uint32_t nctl = 5120;
+			if (const char* env = getenv("CKL_LDS_CONTROLS")) nctl = static_cast<uint32_t>(std::max(0, atoi(env)));   // testing: forces the global tables
+			while (nctl > 64 && crack_lds_bytes(nctl) > budget) nctl -= 64;
+			if (crack_lds_bytes(nctl) > budget) nctl = 0;
+			if (nctl > 32000) nctl = 32000;
+			d->lds_controls = nctl;
+			const int bytes = static_cast<int>(crack_lds_bytes(nctl));
+			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+		}
 		decoder_build(*d, buf, n, z_start, z_end);
 		*out = d.release();
 		return CKL_OK;
