@@ -41,6 +41,39 @@ def parse_args():
   return ap.parse_args()
 
 
+def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=5):
+  """Device-to-device copy rate on this box (read + write bytes per second), for context
+  next to the 8 TB/s spec figure."""
+  a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+  b = torch.empty_like(a)
+  b.copy_(a)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    b.copy_(a)
+  e1.record()
+  torch.cuda.synchronize()
+  ms = e0.elapsed_time(e1) / reps
+  del a, b
+  return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def pmc_traffic(kernel, workload_key):
+  """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass
+  (profiles/pmc_traffic.json, produced by tools/pmc_summary.py from the same workload);
+  None when no counters were collected for this workload."""
+  path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+  try:
+    with open(path) as f:
+      t = json.load(f)
+    if t.get("workload") != workload_key:
+      return None
+    return t["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+  except (OSError, ValueError, KeyError):
+    return None
+
+
 def cpu_baseline(vol_np_slab, markov, hip_bytes_for_slab=None):
   """Times the CPU checker (the compiled reference when oracle/_ref travelled here,
   else the C restatement) on a bounded z-slab of the same workload."""
@@ -59,6 +92,12 @@ def cpu_baseline(vol_np_slab, markov, hip_bytes_for_slab=None):
     best_d = td if best_d is None else min(best_d, td)
   ok = bool(np.array_equal(out.reshape(vol_np_slab.shape, order="F"), vol_np_slab))
   vox = vol_np_slab.size
+  # one-thread row on a quarter of the sample
+  q = np.asfortranarray(vol_np_slab[:, :, :max(1, vol_np_slab.shape[2] // 4)])
+  t = time.perf_counter()
+  b1 = chk.compress(q, markov_model_order=markov, parallel=1)
+  chk.decompress(b1, parallel=1)
+  t1 = time.perf_counter() - t
   res = {
     "value": vox / (best_e + best_d),
     "unit": "voxels/s",
@@ -67,6 +106,7 @@ def cpu_baseline(vol_np_slab, markov, hip_bytes_for_slab=None):
     "sample": f"{vol_np_slab.shape[0]}x{vol_np_slab.shape[1]}x{vol_np_slab.shape[2]} {vol_np_slab.dtype} z-slab of the same synthetic volume, encode+decode, parallel={cores}, best of 2",
     "encode_voxels_per_s": vox / best_e,
     "decode_voxels_per_s": vox / best_d,
+    "single_thread_voxels_per_s": q.size / t1,
     "roundtrip_ok": ok,
   }
   if hip_bytes_for_slab is not None:
@@ -167,6 +207,8 @@ def main():
     dom = max(stage_ms, key=stage_ms.get)
     k_ms = stage_ms[dom]
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    copy_gbs = measured_copy_bandwidth(torch, dev)
+    workload_key = f"{sx}x{sy}x{sz} {np_dtype.name} markov {args.markov}"
     res = {
       "metric": "voxels/s encode+decode, 1024x1024x512 uint32; bit-exact .ckl bytes",
       "value": voxels_total * K / total_s,
@@ -202,7 +244,9 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": pmc_traffic(dom, workload_key),
+        "measured_copy_GBs": copy_gbs,
+        "frac_of_measured_copy": achieved / copy_gbs,
         "algorithmic_bytes_per_launch": alg_bytes,
         "kernel_ms": k_ms,
         "decode_pipeline_frac": alg_bytes / (float(np.mean(dec_pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -959,7 +959,7 @@ __global__ void __launch_bounds__(kBlock) k_check(
 using namespace ckl;
 
 namespace {
-constexpr int kMaxStages = 12;
+constexpr int kMaxStages = 16;
 }
 
 struct ckl_decoder {
@@ -1366,12 +1366,26 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 
 	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kBlock), 0, s, g, ra);
 	st.done("k_run_index");
-	launch_run_union(s, ns, g, ra);
-	st.done("k_run_union");
-	ResolveScratch rs;
-	rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
-	launch_run_resolve(s, ns, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, nullptr);
-	st.done("k_run_resolve");
+	{
+		// launch_run_union / launch_run_resolve of ckl_runs.hpp, kernel by kernel for the stage timers
+		const uint32_t rows = run_strip_rows(g.row_words);
+		const uint32_t strips = (g.sy + rows - 1) / rows;
+		hipLaunchKernelGGL(k_run_union_strips, dim3(strips, ns), dim3(kBlock), 0, s, g, ra, rows);
+		st.done("k_run_union_strips");
+		if (strips > 1) {
+			const uint32_t words = (strips - 1) * g.row_words;
+			hipLaunchKernelGGL(k_run_union_seams, dim3((words + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, g, ra, rows);
+		}
+		st.done("k_run_union_seams");
+		ResolveScratch rs;
+		rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
+		hipLaunchKernelGGL(k_run_flatten, dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs);
+		st.done("k_run_flatten");
+		hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
+		st.done("k_run_rank");
+		hipLaunchKernelGGL(k_run_assign, dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p);
+		st.done("k_run_assign");
+	}
 
 	// component -> label
 	const uint64_t nlm = d.total_comp;
