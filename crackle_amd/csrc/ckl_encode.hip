@@ -12,6 +12,7 @@
 //   stream assembly                                 src/crackle.hpp:171-216    host
 #include "ckl_common.hpp"
 #include "ckl_runs.hpp"
+#include "ckl_trail.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -120,6 +121,127 @@ __global__ void __launch_bounds__(kBlock) k_label_planes(
 	}
 }
 
+// Fast path (sx a multiple of the 16-byte vector, 16-byte aligned volume): one wavefront
+// owns a strip of 64 vectors x kBandRows rows and walks down it, so every label is loaded
+// once with 16-byte loads (the row above stays in registers) and the same pass yields
+// lib::max_label and lib::pixel_pairs (lib.hpp:224-256).  Plane words are assembled from
+// the per-lane bit groups with an OR butterfly.  No atomics: per-workgroup partial counts
+// go to `partial` and are folded per slice by k_planes_reduce.
+// grid = (ceil(strips * bands / 4), nslices)
+constexpr uint32_t kBandRows = 32;
+
+template <typename LABEL>
+__global__ void __launch_bounds__(kBlock) k_label_planes_fast(
+	const LABEL* __restrict__ labels, uint32_t sx, uint32_t sy, uint32_t strips, uint32_t bands,
+	uint32_t* __restrict__ planeV, uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
+	uint32_t* __restrict__ partial /* [nslices][gridDim.x][4]: nv, nh, pairs, - */, unsigned long long* __restrict__ partial_max
+) {
+	constexpr uint32_t P = 16 / sizeof(LABEL);        // pixels per lane
+	constexpr uint32_t G = 32 / P;                    // lanes per plane word
+	struct alignas(16) Vec { LABEL v[P]; };
+	__shared__ uint32_t s_red[3 * kWaves];
+	__shared__ unsigned long long s_max[kWaves];
+	const uint32_t zi = blockIdx.y;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t task = blockIdx.x * kWaves + wave;
+	uint32_t nv = 0, nh = 0, pairs = 0;
+	unsigned long long mx = 0;
+	if (task < strips * bands) {
+		const uint32_t band = task / strips, strip = task - band * strips;
+		const uint32_t x = strip * (64u * P) + lane * P;
+		const uint32_t y0 = band * kBandRows, y1 = min(y0 + kBandRows, sy);
+		const bool active = x < sx;
+		const uint64_t slice_off = static_cast<uint64_t>(zi) * sy * sx;
+		const LABEL* col = labels + slice_off + x;
+		Vec prev;
+#pragma unroll
+		for (uint32_t i = 0; i < P; i++) prev.v[i] = 0;
+		if (active && y0 > 0) prev = *reinterpret_cast<const Vec*>(col + static_cast<uint64_t>(y0 - 1) * sx);
+		uint32_t* pv = planeV + zi * plane_words;
+		uint32_t* ph = planeH + zi * plane_words;
+		const uint32_t word = (x >> 5);
+		for (uint32_t y = y0; y < y1; y++) {
+			Vec cur = prev;
+			LABEL edge = 0;
+			bool have_edge = false;
+			if (active) {
+				cur = *reinterpret_cast<const Vec*>(col + static_cast<uint64_t>(y) * sx);
+				if (lane == 0) {
+					// linear predecessor of the strip's first pixel (previous row / slice when x == 0)
+					const uint64_t lin = slice_off + static_cast<uint64_t>(y) * sx + x;
+					if (lin > 0) { edge = labels[lin - 1]; have_edge = true; }
+				}
+			}
+			LABEL left = __shfl_up(cur.v[P - 1], 1, kWave);
+			bool have_left = true;
+			if (lane == 0) { left = edge; have_left = have_edge; }
+			uint32_t bv = 0, bh = 0;
+			if (active) {
+#pragma unroll
+				for (uint32_t i = 0; i < P; i++) {
+					const LABEL l = i ? cur.v[i - 1] : left;
+					const bool differs = cur.v[i] != l;
+					const bool counted = i ? true : have_left;
+					pairs += (counted && !differs) ? 1u : 0u;
+					bv |= ((differs && (x + i) > 0) ? 1u : 0u) << i;
+					bh |= ((y > 0 && cur.v[i] != prev.v[i]) ? 1u : 0u) << i;
+					mx = static_cast<unsigned long long>(cur.v[i]) > mx ? static_cast<unsigned long long>(cur.v[i]) : mx;
+				}
+			}
+			nv += __popc(bv); nh += __popc(bh);
+			bv <<= (lane % G) * P; bh <<= (lane % G) * P;
+#pragma unroll
+			for (uint32_t sft = 1; sft < G; sft <<= 1) {
+				bv |= __shfl_xor(bv, sft, kWave);
+				bh |= __shfl_xor(bh, sft, kWave);
+			}
+			if ((lane % G) == 0 && word < row_words && active) {
+				pv[static_cast<uint64_t>(y) * row_words + word] = bv;
+				ph[static_cast<uint64_t>(y) * row_words + word] = bh;
+			}
+			prev = cur;
+		}
+	}
+	nv = wave_sum(nv); nh = wave_sum(nh); pairs = wave_sum(pairs);
+	for (int d = kWave / 2; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d, kWave); mx = o > mx ? o : mx; }
+	if (lane == 0) { s_red[wave] = nv; s_red[kWaves + wave] = nh; s_red[2 * kWaves + wave] = pairs; s_max[wave] = mx; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tv = 0, th = 0, tp = 0;
+		unsigned long long tm = 0;
+		for (int w = 0; w < kWaves; w++) { tv += s_red[w]; th += s_red[kWaves + w]; tp += s_red[2 * kWaves + w]; tm = s_max[w] > tm ? s_max[w] : tm; }
+		const uint64_t o = static_cast<uint64_t>(zi) * gridDim.x + blockIdx.x;
+		partial[o * 4 + 0] = tv; partial[o * 4 + 1] = th; partial[o * 4 + 2] = tp; partial[o * 4 + 3] = 0;
+		partial_max[o] = tm;
+	}
+}
+
+// grid = nslices: folds the per-workgroup partials of one slice
+__global__ void __launch_bounds__(kBlock) k_planes_reduce(
+	const uint32_t* __restrict__ partial, const unsigned long long* __restrict__ partial_max, uint32_t nblk,
+	unsigned long long* __restrict__ out /* [nslices][4]: count_v, count_h, pairs, max */
+) {
+	__shared__ uint32_t s_red[kWaves];
+	__shared__ unsigned long long s_max[kWaves];
+	const uint32_t zi = blockIdx.x;
+	uint32_t tv = 0, th = 0, tp = 0;
+	unsigned long long tm = 0;
+	for (uint32_t b = threadIdx.x; b < nblk; b += kBlock) {
+		const uint64_t o = static_cast<uint64_t>(zi) * nblk + b;
+		tv += partial[o * 4 + 0]; th += partial[o * 4 + 1]; tp += partial[o * 4 + 2];
+		const unsigned long long m = partial_max[o];
+		tm = m > tm ? m : tm;
+	}
+	tv = block_sum(tv, s_red); th = block_sum(th, s_red); tp = block_sum(tp, s_red);
+	for (int d = kWave / 2; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(tm, d, kWave); tm = o > tm ? o : tm; }
+	if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tm;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 0; w < kWaves; w++) tm = s_max[w] > tm ? s_max[w] : tm;
+		out[4ull * zi + 0] = tv; out[4ull * zi + 1] = th; out[4ull * zi + 2] = tp; out[4ull * zi + 3] = tm;
+	}
+}
+
 // crack graph: one adjacency nibble per vertex of the (sx+1) x (sy+1) corner grid,
 // bit0 -> right, bit1 -> left, bit2 -> down, bit3 -> up (crackcodes.hpp:66-125).
 // An interior pixel pair carries a crack when its labels differ (IMPERMISSIBLE) or are
@@ -130,29 +252,6 @@ constexpr uint32_t kTileShift = 5, kTileDim = 32, kTileBytes = 1024;
 constexpr uint32_t kTileMoves = 2 * kTileDim * (kTileDim + 1);   // edges that touch one tile: the most moves per residency
 __device__ __forceinline__ uint32_t tile_of(uint32_t x, uint32_t y, uint32_t tiles_x) { return (y >> kTileShift) * tiles_x + (x >> kTileShift); }
 __device__ __forceinline__ uint32_t tile_local(uint32_t x, uint32_t y) { return ((y & (kTileDim - 1)) << kTileShift) | (x & (kTileDim - 1)); }
-
-__global__ void __launch_bounds__(kBlock) k_crack_graph(
-	const uint32_t* __restrict__ planeV, const uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
-	uint32_t sx, uint32_t sy, uint32_t permissible, uint8_t* __restrict__ adjt, uint64_t adjt_stride, uint32_t tiles_x
-) {
-	const uint32_t zi = blockIdx.y;
-	const uint32_t sxe = sx + 1, sye = sy + 1;
-	const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-	if (v >= sxe * sye) return;
-	const uint32_t y = v / sxe;
-	const uint32_t x = v - y * sxe;
-	const uint32_t* pv = planeV + zi * plane_words;
-	const uint32_t* ph = planeH + zi * plane_words;
-	auto bit = [&](const uint32_t* pl, uint32_t xx, uint32_t yy) {
-		return ((pl[static_cast<uint64_t>(yy) * row_words + (xx >> 5)] >> (xx & 31u)) & 1u) ^ permissible;
-	};
-	uint32_t nib = 0;
-	if (x < sx && y >= 1 && y < sy) nib |= bit(ph, x, y) << 0;            // edge (x,y)-(x+1,y): pixels (x,y-1)|(x,y)
-	if (x >= 1 && y >= 1 && y < sy) nib |= bit(ph, x - 1, y) << 1;
-	if (x >= 1 && x < sx && y < sy) nib |= bit(pv, x, y) << 2;            // edge (x,y)-(x,y+1): pixels (x-1,y)|(x,y)
-	if (x >= 1 && x < sx && y >= 1) nib |= bit(pv, x, y - 1) << 3;
-	adjt[zi * adjt_stride + static_cast<uint64_t>(tile_of(x, y, tiles_x)) * kTileBytes + tile_local(x, y)] = static_cast<uint8_t>(nib);
-}
 
 // ------------------------------------------------------------------------------
 // the walk: exact restatement of the reference's deterministic depth-first trail
@@ -922,6 +1021,21 @@ struct ckl_encoder {
 	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq;
 	DevBuf<uint8_t> d_keys;
 	DevBuf<uint32_t> d_cc_volume;                // global component id of every voxel (pin encoding only)
+	// trail graph (ckl_trail.hpp)
+	std::vector<uint32_t> count_special, count_corner;
+	DevBuf<uint32_t> d_plane_partial, t_blk_special, t_blk_corner;
+	DevBuf<unsigned long long> d_plane_partial_max, d_plane_out;
+	uint32_t graph_blocks = 0;
+	uint32_t tiles_x = 0, tiles_y = 0;
+	uint64_t adjt_stride = 0;
+	DevBuf<uint64_t> t_nbase, t_cobase, t_ibase;
+	DevBuf<uint32_t> t_ncap, t_cocap, t_icap, t_max_steps;
+	DevBuf<uint32_t> t_counters;                 // n_nodes | n_snap | n_corners | n_starts | n_items, [nslices] each
+	DevBuf<uint32_t> t_node_vertex, t_vert2node, t_corner_vertex;
+	DevBuf<uint8_t> t_node_adj;
+	DevBuf<uint32_t> t_dart_end, t_dart_len, t_dart_minv, t_dart_minpos, t_parent, t_start_bits, t_starts;
+	DevBuf<unsigned long long> t_compmin;
+	DevBuf<uint32_t> t_items, t_item_off, t_chain_item0;
 
 	~ckl_encoder() {
 		if (ev0) (void)hipEventDestroy(ev0);
@@ -990,12 +1104,45 @@ struct HostTimer {
 // One pass over the labels -> the two "differs from neighbour" bit planes and their
 // per-slice population counts (exact crack edge and run counts follow from these).
 template <typename LABEL>
-void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz) {
+VolumeStats volume_stats(ckl_encoder& e, const LABEL* labels, uint64_t voxels);
+
+// One pass over the labels -> the two "differs from neighbour" bit planes and their
+// per-slice population counts (exact crack edge and run counts follow from these) and,
+// on the fast path, the whole-volume reductions of lib.hpp:224-256 from the same read.
+template <typename LABEL>
+void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, VolumeStats* st) {
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	e.row_words = static_cast<uint32_t>((sx + 31) / 32);
 	e.plane_words = static_cast<uint64_t>(e.row_words) * sy;
 	e.d_planes.ensure(2 * e.plane_words * ns);
+	constexpr uint32_t P = 16 / sizeof(LABEL);
+	const bool fast = !getenv("CKL_PLANES_GENERIC") && sx >= static_cast<int64_t>(P) && sx % P == 0 && (reinterpret_cast<uintptr_t>(labels) & 15u) == 0;
+	if (fast) {
+		const uint32_t strips = static_cast<uint32_t>((sx + 64 * P - 1) / (64 * P));
+		const uint32_t bands = static_cast<uint32_t>((sy + kBandRows - 1) / kBandRows);
+		const uint32_t nblk = (strips * bands + kWaves - 1) / kWaves;
+		e.d_plane_partial.ensure(4ull * nblk * ns);
+		e.d_plane_partial_max.ensure(static_cast<size_t>(nblk) * ns);
+		e.d_plane_out.ensure(4ull * ns);
+		hipLaunchKernelGGL(k_label_planes_fast<LABEL>, dim3(nblk, ns), dim3(kBlock), 0, s,
+			labels, static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), strips, bands,
+			e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
+			e.d_plane_partial.p, e.d_plane_partial_max.p);
+		hipLaunchKernelGGL(k_planes_reduce, dim3(ns), dim3(kBlock), 0, s, e.d_plane_partial.p, e.d_plane_partial_max.p, nblk, e.d_plane_out.p);
+		std::vector<unsigned long long> o = download(e.d_plane_out.p, 4ull * ns, s);
+		e.count_v.resize(ns); e.count_h.resize(ns);
+		VolumeStats v;
+		for (uint32_t zi = 0; zi < ns; zi++) {
+			e.count_v[zi] = static_cast<uint32_t>(o[4ull * zi]);
+			e.count_h[zi] = static_cast<uint32_t>(o[4ull * zi + 1]);
+			v.pairs += o[4ull * zi + 2];
+			v.max_label = std::max<uint64_t>(v.max_label, o[4ull * zi + 3]);
+		}
+		if (st) *st = v;
+		return;
+	}
+	if (st) *st = volume_stats<LABEL>(e, labels, static_cast<uint64_t>(sx) * sy * sz);
 	e.d_count_vh.ensure(2 * static_cast<size_t>(ns));
 	CKL_HIP(hipMemsetAsync(e.d_count_vh.p, 0, 2 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
 	const uint32_t chunks = static_cast<uint32_t>((sx + 63) / 64);
@@ -1007,6 +1154,30 @@ void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, in
 	std::vector<uint32_t> c = download(e.d_count_vh.p, 2 * static_cast<size_t>(ns), s);
 	e.count_v.assign(c.begin(), c.begin() + ns);
 	e.count_h.assign(c.begin() + ns, c.end());
+}
+
+// crack graph (vertex nibbles in tiles, crackcodes.hpp:66-125) + the node / corner counts
+// of the trail graph (ckl_trail.hpp)
+void graph_pass(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, bool permissible) {
+	hipStream_t s = e.stream;
+	const uint32_t ns = static_cast<uint32_t>(sz);
+	e.tiles_x = static_cast<uint32_t>((sx + 1 + kTileDim - 1) / kTileDim);
+	e.tiles_y = static_cast<uint32_t>((sy + 1 + kTileDim - 1) / kTileDim);
+	e.adjt_stride = static_cast<uint64_t>(e.tiles_x) * e.tiles_y * kTileBytes;
+	e.d_adjt.ensure(e.adjt_stride * ns);
+	e.graph_blocks = (e.tiles_x * e.tiles_y + kGraphTiles - 1) / kGraphTiles;
+	e.t_blk_special.ensure(static_cast<size_t>(e.graph_blocks) * ns);
+	e.t_blk_corner.ensure(static_cast<size_t>(e.graph_blocks) * ns);
+	e.d_count_vh.ensure(4 * static_cast<size_t>(ns));
+	hipLaunchKernelGGL(k_trail_graph, dim3(e.graph_blocks, ns), dim3(kBlock), 0, s,
+		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
+		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, e.d_adjt.p, e.adjt_stride,
+		e.tiles_x, e.tiles_y, e.t_blk_special.p, e.t_blk_corner.p);
+	hipLaunchKernelGGL(k_trail_count_scan, dim3(ns), dim3(kBlock), 0, s, e.t_blk_special.p, e.t_blk_corner.p, e.graph_blocks,
+		e.d_count_vh.p + 2 * static_cast<size_t>(ns), e.d_count_vh.p + 3 * static_cast<size_t>(ns));
+	std::vector<uint32_t> c = download(e.d_count_vh.p + 2 * static_cast<size_t>(ns), 2 * static_cast<size_t>(ns), s);
+	e.count_special.assign(c.begin(), c.begin() + ns);
+	e.count_corner.assign(c.begin() + ns, c.end());
 }
 
 struct CrackResult {
@@ -1025,22 +1196,21 @@ void crack_pass(
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
-	const uint32_t tiles_x = static_cast<uint32_t>((sx + 1 + kTileDim - 1) / kTileDim), tiles_y = static_cast<uint32_t>((sy + 1 + kTileDim - 1) / kTileDim);
-	const uint64_t adjt_stride = static_cast<uint64_t>(tiles_x) * tiles_y * kTileBytes;
-	e.d_adjt.ensure(adjt_stride * ns);
+	const uint32_t tiles_x = e.tiles_x, tiles_y = e.tiles_y;
+	const uint64_t adjt_stride = e.adjt_stride;
 	e.d_slice_err.ensure(ns);
-	CKL_HIP(hipMemsetAsync(e.d_adjt.p, 0, adjt_stride * ns, s));
 	CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
-	hipLaunchKernelGGL(k_crack_graph, dim3(static_cast<uint32_t>((nverts + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s,
-		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
-		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, e.d_adjt.p, adjt_stride, tiles_x);
 	// exact crack edge count per slice: interior pixel pairs that differ (or are equal)
 	const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
+	const bool walk_v1 = getenv("CKL_WALK_V1") != nullptr;
 
 	// capacities from the exact edge counts (codes <= 7 E, chains <= E, stack <= E)
 	std::vector<uint64_t> cbase(ns), sbase(ns), kbase(ns);
-	std::vector<uint32_t> ccap(ns), scap(ns), kcap(ns);
-	uint64_t ctot = 0, stot = 0, ktot = 0;
+	std::vector<uint32_t> ccap(ns), scap(ns), kcap(ns), max_steps(ns);
+	std::vector<uint64_t> nbase(ns), cobase(ns), ibase(ns);
+	std::vector<uint32_t> ncap(ns), cocap(ns), icap(ns);
+	uint64_t ctot = 0, stot = 0, ktot = 0, ntot = 0, cotot = 0, itot = 0;
+	uint32_t max_ncap = 0, max_cocap = 0, max_icap = 0, max_special = 0;
 	bool any = false;
 	for (uint32_t zi = 0; zi < ns; zi++) {
 		const uint64_t differ = static_cast<uint64_t>(e.count_v[zi]) + e.count_h[zi];
@@ -1049,8 +1219,26 @@ void crack_pass(
 		const uint64_t cc = 7 * E + 16 + 2 * kTileMoves;
 		if (cc > 0xFFFFFFF0ull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: slice has too many crack edges");
 		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cc); ctot += cc;
-		sbase[zi] = stot; scap[zi] = static_cast<uint32_t>(E + 1); stot += E + 1;
-		kbase[zi] = ktot; kcap[zi] = static_cast<uint32_t>(E + 1); ktot += E + 1;
+		max_steps[zi] = static_cast<uint32_t>(E + 1);
+		if (walk_v1) {
+			sbase[zi] = stot; scap[zi] = static_cast<uint32_t>(E + 1); stot += E + 1;
+			kbase[zi] = ktot; kcap[zi] = static_cast<uint32_t>(E + 1); ktot += E + 1;
+			continue;
+		}
+		// trail graph: nodes = vertices of degree 1, 3, 4 plus at most one per "right+down" corner
+		// (loop starts, chain starts inside a segment); segments <= 2 nodes; items <= 3 segments + 1 per chain
+		const uint64_t nc = ((static_cast<uint64_t>(e.count_special[zi]) + e.count_corner[zi] + 16) / 16) * 16;
+		if (nc >= (1ull << 28)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: slice has too many crack vertices");
+		nbase[zi] = ntot; ncap[zi] = static_cast<uint32_t>(nc); ntot += nc;
+		cobase[zi] = cotot; cocap[zi] = e.count_corner[zi]; cotot += e.count_corner[zi];
+		const uint64_t ic = 7 * nc + 16;
+		ibase[zi] = itot; icap[zi] = static_cast<uint32_t>(ic); itot += ic;
+		sbase[zi] = stot; scap[zi] = static_cast<uint32_t>(2 * nc + 4); stot += 2 * nc + 4;
+		kbase[zi] = ktot; kcap[zi] = static_cast<uint32_t>(nc); ktot += nc;
+		max_ncap = std::max<uint32_t>(max_ncap, ncap[zi]);
+		max_cocap = std::max<uint32_t>(max_cocap, cocap[zi]);
+		max_icap = std::max<uint32_t>(max_icap, icap[zi]);
+		max_special = std::max<uint32_t>(max_special, e.count_special[zi]);
 	}
 	if (result) result->any_chain = any;
 	upload(e.d_cbase, cbase, s); upload(e.d_ccap, ccap, s);
@@ -1064,28 +1252,92 @@ void crack_pass(
 	e.d_n_chains.ensure(ns); e.d_n_raw.ensure(ns); e.d_n_valid.ensure(ns);
 	e.d_payload_len.ensure(ns); e.d_boc_len.ensure(ns);
 
-	WalkArgs wa;
-	wa.adjt = e.d_adjt.p; wa.adjt_stride = adjt_stride; wa.tiles_x = tiles_x; wa.tiles_y = tiles_y;
-	wa.sx = static_cast<int>(sx); wa.sy = static_cast<int>(sy);
-	wa.cbase = e.d_cbase.p; wa.ccap = e.d_ccap.p; wa.sbase = e.d_sbase.p; wa.scap = e.d_scap.p; wa.kbase = e.d_kbase.p; wa.kcap = e.d_kcap.p;
-	wa.cp = e.d_cp.p; wa.stack_node = e.d_stack_node.p; wa.stack_code = e.d_stack_code.p;
-	wa.chain_node = e.d_chain_node.p; wa.chain_off = e.d_chain_off.p; wa.chain_clen = e.d_chain_clen.p;
-	wa.n_chains = e.d_n_chains.p; wa.n_raw = e.d_n_raw.p; wa.n_valid = e.d_n_valid.p; wa.slice_err = e.d_slice_err.p;
 	CKL_HIP(hipEventRecord(e.evk0, s));
-	wa.dbg = 0;
-	if (getenv("CKL_WALK_DIAG")) {
-		wa.dbg = static_cast<uint32_t>(atoi(getenv("CKL_WALK_DIAG"))) >> 4;     // CKL_WALK_DIAG=1: plain; 17: skip code stores; 33: skip stack stores
-		DevBuf<unsigned long long> d_diag;
-		d_diag.ensure(static_cast<size_t>(ns) * 16);
-		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 128, s));
-		hipLaunchKernelGGL(k_walk<true>, dim3(ns), dim3(kWave), 0, s, wa, d_diag.p);
-		std::vector<unsigned long long> dg = download(d_diag.p, static_cast<size_t>(ns) * 16, s);
-		double m[16] = { 0 };
-		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
-		fprintf(stderr, "[ckl walk diag, mean per slice] steps=%.0f fills=%.0f general=%.0f pops=%.0f scan_cyc=%.0f fill_cyc=%.0f walk_cyc=%.0f general_cyc=%.0f total_cyc=%.0f realtime_us=%.1f (clock %.2f GHz)\n",
-			m[0], m[1], m[2], m[9], m[3], m[4], m[5], m[8], m[6], m[7] / 100.0, m[6] / (m[7] * 10.0));
+	if (walk_v1) {
+		WalkArgs wa;
+		wa.adjt = e.d_adjt.p; wa.adjt_stride = adjt_stride; wa.tiles_x = tiles_x; wa.tiles_y = tiles_y;
+		wa.sx = static_cast<int>(sx); wa.sy = static_cast<int>(sy);
+		wa.cbase = e.d_cbase.p; wa.ccap = e.d_ccap.p; wa.sbase = e.d_sbase.p; wa.scap = e.d_scap.p; wa.kbase = e.d_kbase.p; wa.kcap = e.d_kcap.p;
+		wa.cp = e.d_cp.p; wa.stack_node = e.d_stack_node.p; wa.stack_code = e.d_stack_code.p;
+		wa.chain_node = e.d_chain_node.p; wa.chain_off = e.d_chain_off.p; wa.chain_clen = e.d_chain_clen.p;
+		wa.n_chains = e.d_n_chains.p; wa.n_raw = e.d_n_raw.p; wa.n_valid = e.d_n_valid.p; wa.slice_err = e.d_slice_err.p;
+		wa.dbg = 0;
+		if (getenv("CKL_WALK_DIAG")) {
+			wa.dbg = static_cast<uint32_t>(atoi(getenv("CKL_WALK_DIAG"))) >> 4;     // CKL_WALK_DIAG=1: plain; 17: skip code stores; 33: skip stack stores
+			DevBuf<unsigned long long> d_diag;
+			d_diag.ensure(static_cast<size_t>(ns) * 16);
+			CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 128, s));
+			hipLaunchKernelGGL(k_walk<true>, dim3(ns), dim3(kWave), 0, s, wa, d_diag.p);
+			std::vector<unsigned long long> dg = download(d_diag.p, static_cast<size_t>(ns) * 16, s);
+			double m[16] = { 0 };
+			for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
+			fprintf(stderr, "[ckl walk diag, mean per slice] steps=%.0f fills=%.0f general=%.0f pops=%.0f scan_cyc=%.0f fill_cyc=%.0f walk_cyc=%.0f general_cyc=%.0f total_cyc=%.0f realtime_us=%.1f (clock %.2f GHz)\n",
+				m[0], m[1], m[2], m[9], m[3], m[4], m[5], m[8], m[6], m[7] / 100.0, m[6] / (m[7] * 10.0));
+		}
+		else hipLaunchKernelGGL(k_walk<false>, dim3(ns), dim3(kWave), 0, s, wa, static_cast<unsigned long long*>(nullptr));
 	}
-	else hipLaunchKernelGGL(k_walk<false>, dim3(ns), dim3(kWave), 0, s, wa, static_cast<unsigned long long*>(nullptr));
+	else {
+		// ---- the trail over the node graph (ckl_trail.hpp)
+		upload(e.t_nbase, nbase, s); upload(e.t_ncap, ncap, s);
+		upload(e.t_cobase, cobase, s); upload(e.t_cocap, cocap, s);
+		upload(e.t_ibase, ibase, s); upload(e.t_icap, icap, s);
+		upload(e.t_max_steps, max_steps, s);
+		e.t_counters.ensure(5 * static_cast<size_t>(ns));
+		CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 5 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
+		e.t_node_vertex.ensure(ntot); e.t_node_adj.ensure(ntot + 16); e.t_vert2node.ensure(nverts * ns);
+		e.t_corner_vertex.ensure(cotot);
+		e.t_dart_end.ensure(4 * ntot); e.t_dart_len.ensure(4 * ntot); e.t_dart_minv.ensure(4 * ntot); e.t_dart_minpos.ensure(4 * ntot);
+		e.t_parent.ensure(ntot); e.t_compmin.ensure(ntot); e.t_starts.ensure(ntot);
+		const uint32_t start_words = static_cast<uint32_t>((nverts + 31) / 32);
+		e.t_start_bits.ensure(static_cast<size_t>(start_words) * ns);
+		CKL_HIP(hipMemsetAsync(e.t_start_bits.p, 0, static_cast<size_t>(start_words) * ns * sizeof(uint32_t), s));
+		e.t_items.ensure(itot); e.t_item_off.ensure(itot); e.t_chain_item0.ensure(ktot);
+
+		TrailArgs ta;
+		ta.adjt = e.d_adjt.p; ta.adjt_stride = adjt_stride; ta.tiles_x = tiles_x; ta.tiles_y = tiles_y;
+		ta.sxe = static_cast<uint32_t>(sx + 1); ta.sye = static_cast<uint32_t>(sy + 1); ta.nverts = static_cast<uint32_t>(nverts);
+		ta.max_steps = e.t_max_steps.p;
+		ta.nbase = e.t_nbase.p; ta.ncap = e.t_ncap.p;
+		ta.n_nodes = e.t_counters.p; ta.n_corners = e.t_counters.p + 2 * ns;
+		ta.n_starts = e.t_counters.p + 3 * ns; ta.n_items = e.t_counters.p + 4 * ns;
+		ta.node_vertex = e.t_node_vertex.p; ta.node_adj = e.t_node_adj.p; ta.vert2node = e.t_vert2node.p;
+		ta.cobase = e.t_cobase.p; ta.cocap = e.t_cocap.p; ta.corner_vertex = e.t_corner_vertex.p;
+		ta.dart_end = e.t_dart_end.p; ta.dart_len = e.t_dart_len.p; ta.dart_minv = e.t_dart_minv.p; ta.dart_minpos = e.t_dart_minpos.p;
+		ta.parent = e.t_parent.p; ta.compmin = e.t_compmin.p;
+		ta.start_bits = e.t_start_bits.p; ta.start_words = start_words; ta.starts = e.t_starts.p;
+		ta.ibase = e.t_ibase.p; ta.icap = e.t_icap.p; ta.items = e.t_items.p; ta.item_off = e.t_item_off.p;
+		ta.sbase = e.d_sbase.p; ta.scap = e.d_scap.p; ta.stack_node = e.d_stack_node.p; ta.stack_item = e.d_stack_code.p;
+		ta.kbase = e.d_kbase.p; ta.kcap = e.d_kcap.p;
+		ta.chain_node = e.d_chain_node.p; ta.chain_item0 = e.t_chain_item0.p; ta.chain_off = e.d_chain_off.p; ta.chain_clen = e.d_chain_clen.p;
+		ta.n_chains = e.d_n_chains.p; ta.n_raw = e.d_n_raw.p; ta.n_valid = e.d_n_valid.p;
+		ta.cbase = e.d_cbase.p; ta.ccap = e.d_ccap.p; ta.cp = e.d_cp.p; ta.slice_err = e.d_slice_err.p;
+
+		ta.graph_blocks = e.graph_blocks; ta.blk_special = e.t_blk_special.p; ta.blk_corner = e.t_blk_corner.p;
+		int max_lds = 0;
+		CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, e.device));
+		const size_t budget = static_cast<size_t>(max_lds > 1024 ? max_lds - 1024 : 0);
+		const uint32_t dart_blocks = (4 * max_ncap + kBlock - 1) / kBlock;
+		if (any) {
+			hipLaunchKernelGGL(k_trail_nodes, dim3(e.graph_blocks, ns), dim3(kBlock), 0, s, ta);
+			hipLaunchKernelGGL(k_trail_segments, dim3(dart_blocks, ns), dim3(kBlock), 0, s, ta);
+			if (max_cocap) hipLaunchKernelGGL(k_trail_loops, dim3((max_cocap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, ta);
+			// union-find table of k_trail_components in LDS: 4 bytes per node
+			size_t clds = (static_cast<size_t>(max_special) + 1024) * 4;
+			if (const char* env = getenv("CKL_TRAIL_LDS")) clds = static_cast<size_t>(std::max(0, atoi(env)));
+			clds = (std::min(budget, std::max<size_t>(clds, 1024)) / 16) * 16;
+			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_components), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(clds)));
+			hipLaunchKernelGGL(k_trail_components, dim3(ns), dim3(kBlock), clds, s, ta, static_cast<uint32_t>(clds));
+		}
+		// node tables of k_trail_dfs in LDS: 9 bytes per node + 16 KiB of branch stack when that fits
+		size_t lds = (static_cast<size_t>(max_special) + 256) * 9 + 16384;
+		if (const char* env = getenv("CKL_TRAIL_LDS")) lds = static_cast<size_t>(std::max(0, atoi(env)));   // testing: small values force the global tables
+		lds = std::min(budget, std::max<size_t>(lds, 4096));
+		lds = (lds / 16) * 16;
+		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_dfs), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+		hipLaunchKernelGGL(k_trail_dfs, dim3(ns), dim3(kWave), lds, s, ta, static_cast<uint32_t>(lds));
+		hipLaunchKernelGGL(k_trail_offsets, dim3(ns), dim3(kBlock), 0, s, ta);
+		hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, ta);
+	}
 	CKL_HIP(hipEventRecord(e.evk1, s));
 
 	std::vector<uint32_t> n_chains = download(e.d_n_chains.p, ns, s);
@@ -1295,7 +1547,8 @@ void encode_typed(
 	hipStream_t s = e.stream;
 	CKL_HIP(hipEventRecord(e.ev0, s));
 
-	VolumeStats st = volume_stats<LABEL>(e, labels, voxels);
+	VolumeStats st;
+	if (voxels > 0) planes_pass<LABEL>(e, labels, sx, sy, sz, &st);
 	int stored_width = byte_width(st.max_label);                     // crackle.hpp:233-235
 	if (ov && ov->force_stored_width) stored_width = ov->force_stored_width;
 
@@ -1330,8 +1583,8 @@ void encode_typed(
 	if (head.markov_model_order > 13) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order > 13 is not supported on device");
 
 	HostTimer ht;
-	planes_pass<LABEL>(e, labels, sx, sy, sz);
-	ht.mark("planes");
+	graph_pass(e, sx, sy, sz, head.crack_format == PERMISSIBLE);
+	ht.mark("graph");
 	// crack codes; a first pass decides whether any slice has chains (crackle.hpp:107-118)
 	CrackResult cr;
 	std::vector<uint8_t> model, stored_model;
@@ -1507,10 +1760,11 @@ int ckl_encoder_markov_stats(
 		if (static_cast<uint64_t>(sx) * sy * sz > 0) {
 			const bool perm = crack_format == PERMISSIBLE;
 			const int order = static_cast<int>(markov_model_order);
-			if (e->dtype_bytes == 1) planes_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz);
-			else if (e->dtype_bytes == 2) planes_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz);
-			else if (e->dtype_bytes == 4) planes_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz);
-			else planes_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz);
+			if (e->dtype_bytes == 1) planes_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz, nullptr);
+			else if (e->dtype_bytes == 2) planes_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz, nullptr);
+			else if (e->dtype_bytes == 4) planes_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz, nullptr);
+			else planes_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz, nullptr);
+			graph_pass(*e, sx, sy, sz, perm);
 			crack_pass(*e, sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
 		}
 		memcpy(hist, h.data(), h.size() * sizeof(uint32_t));

@@ -148,6 +148,7 @@ def test_device_resident_sessions_full_size_properties():
   back = torch.empty_like(vol)
   for _ in range(2):
     back.zero_()
+    torch.cuda.synchronize()   # the session runs on its own stream: the buffer must be ready before the call
     assert L.ckl_decoder_run(dec, back.data_ptr(), back.numel() * 4, 0, 0) == 0, _lib.last_error()
     torch.cuda.synchronize()
     assert torch.equal(back.view(torch.int32), vol.view(torch.int32))
