@@ -25,6 +25,11 @@ int select_device(int device) {
 	return count;
 }
 
+void wait_for_default_stream(hipStream_t s, hipEvent_t ev) {
+	CKL_HIP(hipEventRecord(ev, nullptr));
+	CKL_HIP(hipStreamWaitEvent(s, ev, 0));
+}
+
 // ---- device memory pool ------------------------------------------------------------
 namespace {
 struct PoolBlock { void* p; size_t bytes; int device; };

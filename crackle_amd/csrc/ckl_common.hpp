@@ -141,6 +141,10 @@ struct DevBuf {
 
 void set_last_error(const std::string& msg);
 int select_device(int device);   // throws CKL_ERR_NO_DEVICE
+// Orders `s` after everything already submitted to the device's default (null) stream:
+// the sessions run on their own non-blocking streams, and callers such as PyTorch fill /
+// clear the buffers they hand over on the default stream.
+void wait_for_default_stream(hipStream_t s, hipEvent_t scratch_event);
 
 // markov model tables (src/markov.hpp:43-68, 222-266, 325-420)
 extern const uint8_t kMarkovLUT[24];

@@ -967,6 +967,7 @@ struct ckl_decoder {
 	hipStream_t stream = nullptr;
 	// stage boundaries: ev[i] .. ev[i+1] brackets stage i of the last run
 	hipEvent_t ev[kMaxStages + 1] = {};
+	hipEvent_t ev_in = nullptr;
 	const char* stage_name[kMaxStages] = {};
 	float stage_ms[kMaxStages] = {};
 	int n_stages = 0;
@@ -1011,6 +1012,7 @@ struct ckl_decoder {
 
 	~ckl_decoder() {
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+		if (ev_in) (void)hipEventDestroy(ev_in);
 		if (stream) (void)hipStreamDestroy(stream);
 	}
 };
@@ -1453,6 +1455,7 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 		d->device = device;
 		CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
 		for (auto& e : d->ev) CKL_HIP(hipEventCreate(&e));
+		CKL_HIP(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
 		{
 			// LDS control tables of k_decode_cracks: as many symbols as the workgroup's LDS allows
 			int max_lds = 0;
@@ -1480,6 +1483,7 @@ int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_byte
 	try {
 		if (!d) throw Error(CKL_ERR_ARG, "crackle_amd: null decoder");
 		select_device(d->device);
+		wait_for_default_stream(d->stream, d->ev_in);
 		decoder_run(*d, out_device, out_capacity_bytes, has_label, label);
 		return CKL_OK;
 	}

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <memory>
 
 namespace ckl {
@@ -959,6 +960,67 @@ __global__ void __launch_bounds__(kBlock) k_label_keys(
 	for (int b = 0; b < key_width; b++) keys[i * key_width + b] = static_cast<uint8_t>((lo >> (8 * b)) & 0xFF);
 }
 
+// sorted[N] -> uniq[U] (first of every run of equal values), U; one workgroup
+__global__ void __launch_bounds__(kBlock) k_unique_sorted(const uint64_t* __restrict__ sorted, uint32_t n, uint64_t* __restrict__ uniq, uint32_t* __restrict__ n_uniq) {
+	__shared__ uint32_t s_scan[kWaves];
+	constexpr uint32_t kPer = 8;
+	uint32_t carry = 0;
+	for (uint32_t i0 = 0; i0 < n; i0 += kBlock * kPer) {
+		uint64_t v[kPer];
+		uint32_t flag = 0, cnt = 0;
+#pragma unroll
+		for (uint32_t q = 0; q < kPer; q++) {
+			const uint32_t i = i0 + threadIdx.x * kPer + q;
+			v[q] = i < n ? sorted[i] : 0;
+			const uint64_t prev = q ? v[q - 1] : ((i > 0 && i < n) ? sorted[i - 1] : 0);
+			const bool first = i < n && (i == 0 || v[q] != prev);
+			flag |= (first ? 1u : 0u) << q;
+			cnt += first ? 1u : 0u;
+		}
+		uint32_t c[1] = { cnt }, tot[1];
+		block_excl_add<1>(c, tot, s_scan);
+		uint32_t o = carry + c[0];
+#pragma unroll
+		for (uint32_t q = 0; q < kPer; q++) if ((flag >> q) & 1u) uniq[o++] = v[q];
+		carry += tot[0];
+	}
+	if (threadIdx.x == 0) *n_uniq = carry;
+}
+
+// The flat label section (labels.hpp:123-152) assembled on device:
+//   u64 num_unique | uniq[num_unique] : stored_width | cc_per_slice[sz] : component_width | key[N] : byte_width(num_unique)
+// grid = ceil(max(U, sz, N) / 256) over three index spaces handled by one kernel
+__global__ void __launch_bounds__(kBlock) k_flat_section(
+	const uint64_t* __restrict__ uniq, const uint32_t* __restrict__ n_uniq, int stored_width,
+	const uint32_t* __restrict__ ncomp, uint32_t nslices, int component_width,
+	const uint64_t* __restrict__ mapping, uint32_t n, uint8_t* __restrict__ out
+) {
+	const uint32_t nu = *n_uniq;
+	const int key_width = nu <= 0xFFu ? 1 : (nu <= 0xFFFFu ? 2 : 4);
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i == 0) for (int b = 0; b < 8; b++) out[b] = static_cast<uint8_t>((static_cast<uint64_t>(nu) >> (8 * b)) & 0xFF);
+	uint8_t* o_uniq = out + 8;
+	uint8_t* o_cc = o_uniq + static_cast<uint64_t>(nu) * stored_width;
+	uint8_t* o_keys = o_cc + static_cast<uint64_t>(nslices) * component_width;
+	if (i < nu) {
+		const uint64_t v = uniq[i];
+		for (int b = 0; b < stored_width; b++) o_uniq[static_cast<uint64_t>(i) * stored_width + b] = static_cast<uint8_t>((v >> (8 * b)) & 0xFF);
+	}
+	if (i < nslices) {
+		const uint32_t v = ncomp[i];
+		for (int b = 0; b < component_width; b++) o_cc[static_cast<uint64_t>(i) * component_width + b] = b < 4 ? static_cast<uint8_t>((v >> (8 * b)) & 0xFF) : 0;
+	}
+	if (i < n) {
+		const uint64_t v = mapping[i];
+		uint32_t lo = 0, hi = nu;          // last index with uniq[idx] <= v
+		while (lo + 1 < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (uniq[mid] <= v) lo = mid; else hi = mid;
+		}
+		for (int b = 0; b < key_width; b++) o_keys[static_cast<uint64_t>(i) * key_width + b] = static_cast<uint8_t>((lo >> (8 * b)) & 0xFF);
+	}
+}
+
 // grid = nslices: copy each slice's BOC index and payload to their final offsets
 __global__ void __launch_bounds__(kBlock) k_gather_codes(
 	const uint8_t* __restrict__ boc, const uint64_t* __restrict__ bbase, const uint32_t* __restrict__ boc_len,
@@ -992,8 +1054,9 @@ std::vector<uint8_t> encode_pins_host(
 
 struct ckl_encoder {
 	int device = 0;
-	hipStream_t stream = nullptr;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+	hipStream_t stream = nullptr;      // crack codes
+	hipStream_t stream2 = nullptr;     // labels (components, crcs, label table), concurrent with the crack trail
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr, ev_in = nullptr;
 	float pipeline_ms = 0.f, dominant_ms = 0.f;
 	int64_t max_sx = 0, max_sy = 0, max_sz = 0;
 	int dtype_bytes = 0;
@@ -1021,6 +1084,11 @@ struct ckl_encoder {
 	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq;
 	DevBuf<uint8_t> d_keys;
 	DevBuf<uint32_t> d_cc_volume;                // global component id of every voxel (pin encoding only)
+	DevBuf<uint32_t> d_slice_err2, d_n_uniq;
+	DevBuf<uint8_t> d_labels_bin;                // the flat label section, assembled on device
+	uint32_t flat_max_rcap = 0;
+	std::vector<uint64_t> h_rbase;
+	std::vector<uint32_t> h_rcap;
 	// trail graph (ckl_trail.hpp)
 	std::vector<uint32_t> count_special, count_corner;
 	DevBuf<uint32_t> d_plane_partial, t_blk_special, t_blk_corner;
@@ -1042,7 +1110,9 @@ struct ckl_encoder {
 		if (ev1) (void)hipEventDestroy(ev1);
 		if (evk0) (void)hipEventDestroy(evk0);
 		if (evk1) (void)hipEventDestroy(evk1);
+		if (ev_in) (void)hipEventDestroy(ev_in);
 		if (stream) (void)hipStreamDestroy(stream);
+		if (stream2) (void)hipStreamDestroy(stream2);
 	}
 };
 
@@ -1093,13 +1163,17 @@ struct HostTimer {
 		marks.emplace_back(name, std::chrono::duration<double, std::milli>(t1 - t0).count());
 		t0 = t1;
 	}
-	~HostTimer() {
+	~HostTimer();
+};
+thread_local HostTimer* g_ht = nullptr;
+#define HT_MARK(name) do { if (g_ht) g_ht->mark(name); } while (0)
+inline HostTimer::~HostTimer() {
+		g_ht = nullptr;
 		if (!on) return;
 		fprintf(stderr, "[ckl encode host ms]");
 		for (auto& m : marks) fprintf(stderr, " %s=%.2f", m.first, m.second);
 		fprintf(stderr, "\n");
-	}
-};
+}
 
 // One pass over the labels -> the two "differs from neighbour" bit planes and their
 // per-slice population counts (exact crack edge and run counts follow from these).
@@ -1182,7 +1256,7 @@ void graph_pass(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, bool permiss
 
 struct CrackResult {
 	std::vector<uint32_t> code_len;     // per slice: boc + payload bytes
-	std::vector<uint8_t> codes;         // concatenated crack codes
+	uint64_t total = 0;                 // bytes of all crack codes; they stay in e.d_codes_out
 	bool any_chain = false;
 };
 
@@ -1191,7 +1265,8 @@ struct CrackResult {
 void crack_pass(
 	ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, bool permissible,
 	int markov_order, bool hist_only, const std::vector<uint8_t>* model_in,
-	std::vector<uint32_t>* hist_out, std::vector<uint8_t>* model_out, CrackResult* result
+	std::vector<uint32_t>* hist_out, std::vector<uint8_t>* model_out, CrackResult* result,
+	const std::function<void()>& overlap = std::function<void()>()
 ) {
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
@@ -1339,23 +1414,30 @@ void crack_pass(
 		hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, ta);
 	}
 	CKL_HIP(hipEventRecord(e.evk1, s));
-
-	std::vector<uint32_t> n_chains = download(e.d_n_chains.p, ns, s);
-	std::vector<uint32_t> n_valid = download(e.d_n_valid.p, ns, s);
-	std::vector<uint32_t> errs = download(e.d_slice_err.p, ns, s);
-	for (uint32_t zi = 0; zi < ns; zi++) {
-		if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack walk scratch overflow on z=" + std::to_string(zi));
+	HT_MARK("c:enqueue");
+	if (!walk_v1 && getenv("CKL_TRAIL_DIAG")) {
+		std::vector<uint32_t> c = download(e.t_counters.p, 5 * static_cast<size_t>(ns), s);
+		double m[5] = { 0 };
+		for (int k = 0; k < 5; k++) for (uint32_t zi = 0; zi < ns; zi++) m[k] += static_cast<double>(c[static_cast<size_t>(k) * ns + zi]) / ns;
+		double sp = 0, co = 0;
+		for (uint32_t zi = 0; zi < ns; zi++) { sp += static_cast<double>(e.count_special[zi]) / ns; co += static_cast<double>(e.count_corner[zi]) / ns; }
+		fprintf(stderr, "[ckl trail diag, mean per slice] degree-1/3/4 vertices=%.0f corners=%.0f nodes=%.0f starts=%.0f items=%.0f\n", sp, co, m[0], m[3], m[4]);
 	}
 
-	// output buffers sized from the walk results
+	// the label side (other stream, host-synchronous) runs while the trail kernels execute
+	if (overlap) overlap();
+	HT_MARK("c:overlap");
+
+	// output buffers sized from the capacities (no round trip to the host before k_finish)
 	const int xw = byte_width(static_cast<uint64_t>(sx) + 1), yw = byte_width(static_cast<uint64_t>(sy) + 1);
 	std::vector<uint64_t> pbase(ns), bbase(ns);
 	uint64_t ptot = 0, btot = 0;
 	for (uint32_t zi = 0; zi < ns; zi++) {
-		// plain: 2 bits / code; markov: at most 3 bits / code (+2)
-		const uint64_t pbytes = markov_order ? (3ull * n_valid[zi] + 2 + 7) / 8 : (static_cast<uint64_t>(n_valid[zi]) + 3) / 4;
+		// codes <= E + 2 (b + t) <= 5 E + 2; plain: 2 bits / code; markov: at most 3 bits / code (+2)
+		const uint64_t ncodes = ccap[zi];
+		const uint64_t pbytes = markov_order ? (3ull * ncodes + 2 + 7) / 8 : (ncodes + 3) / 4;
 		pbase[zi] = ptot; ptot += ((pbytes + 8 + 3) / 4) * 4;
-		const uint64_t bbytes = 4 + yw + static_cast<uint64_t>(n_chains[zi]) * (yw + 2 * xw);
+		const uint64_t bbytes = 4 + yw + static_cast<uint64_t>(kcap[zi]) * (yw + 2 * xw);
 		bbase[zi] = btot; btot += bbytes;
 	}
 	upload(e.d_pbase, pbase, s); upload(e.d_bbase, bbase, s);
@@ -1386,7 +1468,11 @@ void crack_pass(
 			hipLaunchKernelGGL(k_markov_hist, dim3(ns), dim3(kBlock), 0, s, e.d_dcode.p, e.d_cbase.p, e.d_n_valid.p, markov_order, e.d_hist.p);
 			std::vector<uint32_t> hist = download(e.d_hist.p, rows * 4, s);
 			if (hist_out) *hist_out = hist;
-			if (hist_only) return;
+			if (hist_only) {
+				std::vector<uint32_t> errs = download(e.d_slice_err.p, ns, s);
+				for (uint32_t zi = 0; zi < ns; zi++) if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack walk scratch overflow on z=" + std::to_string(zi));
+				return;
+			}
 			model = markov_stats_to_model(hist.data(), rows);
 		}
 		if (model_out) *model_out = model;
@@ -1396,8 +1482,14 @@ void crack_pass(
 	}
 	if (!result) { CKL_HIP(hipStreamSynchronize(s)); return; }
 
+	HT_MARK("c:finish_enq");
 	std::vector<uint32_t> plen = download(e.d_payload_len.p, ns, s);
+	HT_MARK("c:finish_wait");
 	std::vector<uint32_t> blen = download(e.d_boc_len.p, ns, s);
+	std::vector<uint32_t> errs = download(e.d_slice_err.p, ns, s);
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack walk scratch overflow on z=" + std::to_string(zi));
+	}
 	std::vector<uint64_t> out_off(ns);
 	uint64_t otot = 0;
 	result->code_len.resize(ns);
@@ -1410,7 +1502,7 @@ void crack_pass(
 	e.d_codes_out.ensure(otot + 8);
 	hipLaunchKernelGGL(k_gather_codes, dim3(ns), dim3(kBlock), 0, s, e.d_boc.p, e.d_bbase.p, e.d_boc_len.p,
 		e.d_payload.p, e.d_pbase.p, e.d_payload_len.p, e.d_out_off.p, e.d_codes_out.p);
-	result->codes = download(e.d_codes_out.p, otot, s);
+	result->total = otot;
 }
 
 struct FlatResult {
@@ -1422,7 +1514,7 @@ struct FlatResult {
 // geometric-sum table of ckl_runs.hpp (k_run_resolve), cached per slice size
 void ensure_geom_table(ckl_encoder& e, uint64_t sxy) {
 	if (e.g_table_pixels == sxy && e.d_G.p) return;
-	hipStream_t s = e.stream;
+	hipStream_t s = e.stream2;
 	const uint32_t npx = static_cast<uint32_t>(sxy);
 	const uint32_t B = 1024, nblk = npx / B + 1;
 	std::vector<uint32_t> g_base(B), blk_g(nblk), blk_x(nblk);
@@ -1444,18 +1536,20 @@ void ensure_geom_table(ckl_encoder& e, uint64_t sxy) {
 	e.g_table_pixels = sxy;
 }
 
-// encode_flat per-slice part (labels.hpp:56-88) on runs of the label planes:
-// components, their crc32c, component -> label.
-template <typename LABEL>
-void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, FlatResult& out) {
-	hipStream_t s = e.stream;
+// encode_flat per-slice part (labels.hpp:56-88) on runs of the label planes: components
+// and their crc32c.  Enqueued on the label stream right after the planes exist; the
+// results are collected (flat_collect) while the crack trail runs on the other stream.
+void flat_enqueue(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz) {
+	hipStream_t s = e.stream2;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
 	ensure_geom_table(e, sxy);
 
 	// a run starts at x = 0 of every row and wherever the left neighbour differs
-	std::vector<uint64_t> rbase(ns);
-	std::vector<uint32_t> rcap(ns);
+	// (the host tables stay alive in the session: nothing here waits for the uploads)
+	std::vector<uint64_t>& rbase = e.h_rbase;
+	std::vector<uint32_t>& rcap = e.h_rcap;
+	rbase.assign(ns, 0); rcap.assign(ns, 0);
 	uint64_t rtot = 0;
 	uint32_t max_rcap = 0;
 	for (uint32_t zi = 0; zi < ns; zi++) {
@@ -1463,11 +1557,13 @@ void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int6
 		rbase[zi] = rtot; rcap[zi] = static_cast<uint32_t>(runs); rtot += runs;
 		max_rcap = std::max<uint32_t>(max_rcap, static_cast<uint32_t>(runs));
 	}
+	e.flat_max_rcap = max_rcap;
 	upload(e.d_rbase, rbase, s); upload(e.d_rcap, rcap, s);
 	e.d_word_base.ensure(e.plane_words * ns);
 	e.d_parent.ensure(rtot); e.d_run_start.ensure(rtot); e.d_run_cc.ensure(rtot);
 	e.d_nruns.ensure(ns); e.d_ncomp.ensure(ns); e.d_idbits.ensure(ns); e.d_crc_acc.ensure(ns);
-	e.d_slice_err.ensure(ns);
+	e.d_slice_err2.ensure(ns);
+	CKL_HIP(hipMemsetAsync(e.d_slice_err2.p, 0, ns * sizeof(uint32_t), s));
 
 	RunGeom g;
 	g.planeV = e.d_planes.p; g.planeH = e.d_planes.p + e.plane_words * ns;
@@ -1477,7 +1573,7 @@ void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int6
 	RunArrays ra;
 	ra.word_base = e.d_word_base.p; ra.rbase = e.d_rbase.p; ra.rcap = e.d_rcap.p;
 	ra.parent = e.d_parent.p; ra.run_start = e.d_run_start.p; ra.run_cc = e.d_run_cc.p;
-	ra.nruns = e.d_nruns.p; ra.ncomp = e.d_ncomp.p; ra.slice_err = e.d_slice_err.p;
+	ra.nruns = e.d_nruns.p; ra.ncomp = e.d_ncomp.p; ra.slice_err = e.d_slice_err2.p;
 	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kBlock), 0, s, g, ra);
 	launch_run_union(s, ns, g, ra);
 	ResolveScratch rs;
@@ -1486,10 +1582,21 @@ void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int6
 	e.d_blk_roots.ensure(static_cast<size_t>(rs.nblk) * ns);
 	rs.run_local = e.d_run_local.p; rs.blk_roots = e.d_blk_roots.p;
 	launch_run_resolve(s, ns, ra, rs, e.d_G.p, static_cast<uint32_t>(sxy), 0u, e.d_crc_acc.p, e.d_idbits.p);
+	HT_MARK("f:enqueue");
+}
 
+// component counts, crcs, component -> label (labels.hpp:71-88)
+template <typename LABEL>
+void flat_collect(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, FlatResult& out) {
+	hipStream_t s = e.stream2;
+	const uint32_t ns = static_cast<uint32_t>(sz);
+	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
 	out.ncomp = download(e.d_ncomp.p, ns, s);
+	HT_MARK("f:wait");
 	std::vector<uint32_t> acc = download(e.d_crc_acc.p, ns, s);
 	std::vector<uint32_t> idbits = download(e.d_idbits.p, ns, s);
+	std::vector<uint32_t> errs = download(e.d_slice_err2.p, ns, s);
+	for (uint32_t zi = 0; zi < ns; zi++) if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: run table overflow on z=" + std::to_string(zi));
 	const uint32_t init_term = gf_mul(0xFFFFFFFFu, gf_xpow(32ull * sxy));
 	out.crcs.resize(ns);
 	uint32_t fix_bits = 0xFFFFFFFFu, fix = 0;
@@ -1503,21 +1610,27 @@ void flat_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int6
 	for (uint32_t zi = 0; zi < ns; zi++) { comp_off[zi] = total; total += out.ncomp[zi]; }
 	upload(e.d_comp_off, comp_off, s);
 	e.d_mapping.ensure(total + 1);
-	hipLaunchKernelGGL(k_mapping_runs<LABEL>, dim3((max_rcap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s,
+	RunArrays ra;
+	ra.word_base = e.d_word_base.p; ra.rbase = e.d_rbase.p; ra.rcap = e.d_rcap.p;
+	ra.parent = e.d_parent.p; ra.run_start = e.d_run_start.p; ra.run_cc = e.d_run_cc.p;
+	ra.nruns = e.d_nruns.p; ra.ncomp = e.d_ncomp.p; ra.slice_err = e.d_slice_err2.p;
+	hipLaunchKernelGGL(k_mapping_runs<LABEL>, dim3((e.flat_max_rcap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s,
 		labels, ra, sxy, e.d_comp_off.p, e.d_mapping.p);
+	CKL_HIP(hipStreamSynchronize(s));   // comp_off (pageable) must be consumed before it goes out of scope
 	out.total = total;
 }
 
-// uniq = sort + unique of the component labels, keys = index of each component's label
-// in uniq (labels.hpp:92-152)
-void label_table(ckl_encoder& e, uint64_t N, std::vector<uint64_t>& uniq, int& key_width, std::vector<uint8_t>& keys) {
-	hipStream_t s = e.stream;
-	uniq.clear(); keys.clear(); key_width = 1;
-	if (N == 0) return;
+// The flat label section (labels.hpp:92-152) on device: sort + unique of the component
+// labels, keys by binary search, everything packed at its byte width into e.d_labels_bin.
+// Returns the section size; num_unique comes back for the header arithmetic only.
+uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int component_width, uint32_t ns) {
+	hipStream_t s = e.stream2;
 	if (N > 0x7FFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
+	e.d_n_uniq.ensure(1);
 	uint32_t n_pad = 2048;
 	while (n_pad < N) n_pad <<= 1;
 	e.d_sorted.ensure(n_pad);
+	e.d_uniq.ensure(N + 1);
 	const uint32_t blocks = (n_pad + kBlock - 1) / kBlock;
 	hipLaunchKernelGGL(k_pad_copy_u64, dim3(blocks), dim3(kBlock), 0, s, e.d_mapping.p, N, e.d_sorted.p, static_cast<uint64_t>(n_pad));
 	for (uint32_t k = 2; k <= n_pad; k <<= 1) {
@@ -1525,15 +1638,16 @@ void label_table(ckl_encoder& e, uint64_t N, std::vector<uint64_t>& uniq, int& k
 		for (; j >= 2048; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3(blocks), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 		hipLaunchKernelGGL(k_bitonic_local, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 	}
-	std::vector<uint64_t> sorted = download(e.d_sorted.p, N, s);
-	uniq.reserve(N / 4 + 16);
-	for (uint64_t i = 0; i < N; i++) if (i == 0 || sorted[i] != sorted[i - 1]) uniq.push_back(sorted[i]);
-	key_width = byte_width(uniq.size());
-	upload(e.d_uniq, uniq, s);
-	e.d_keys.ensure(N * key_width);
-	hipLaunchKernelGGL(k_label_keys, dim3(static_cast<uint32_t>((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-		e.d_mapping.p, N, e.d_uniq.p, static_cast<uint64_t>(uniq.size()), key_width, e.d_keys.p);
-	keys = download(e.d_keys.p, N * key_width, s);
+	hipLaunchKernelGGL(k_unique_sorted, dim3(1), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(N), e.d_uniq.p, e.d_n_uniq.p);
+	// worst case: every component has its own label and 4-byte keys
+	e.d_labels_bin.ensure(8 + N * static_cast<uint64_t>(stored_width) + static_cast<uint64_t>(ns) * component_width + N * 4 + 16);
+	const uint64_t work = std::max<uint64_t>(std::max<uint64_t>(N, ns), 1);
+	hipLaunchKernelGGL(k_flat_section, dim3(static_cast<uint32_t>((work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+		e.d_uniq.p, e.d_n_uniq.p, stored_width, e.d_ncomp.p, ns, component_width, e.d_mapping.p, static_cast<uint32_t>(N), e.d_labels_bin.p);
+	HT_MARK("l:enqueue");
+	const uint32_t nu = download(e.d_n_uniq.p, 1, s)[0];
+	HT_MARK("l:wait");
+	return 8 + static_cast<uint64_t>(nu) * stored_width + static_cast<uint64_t>(ns) * component_width + N * static_cast<uint64_t>(byte_width(nu));
 }
 
 template <typename LABEL>
@@ -1541,14 +1655,17 @@ void encode_typed(
 	ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz,
 	bool allow_pins, bool fortran_order, uint64_t markov_model_order,
 	bool optimize_pins, bool auto_bgcolor, int64_t manual_bgcolor,
-	const ckl_encode_overrides* ov, std::vector<uint8_t>& final_binary
+	const ckl_encode_overrides* ov, uint8_t** out, uint64_t* out_len
 ) {
 	const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
 	hipStream_t s = e.stream;
 	CKL_HIP(hipEventRecord(e.ev0, s));
 
+	HostTimer ht;
+	g_ht = &ht;
 	VolumeStats st;
 	if (voxels > 0) planes_pass<LABEL>(e, labels, sx, sy, sz, &st);
+	ht.mark("planes");
 	int stored_width = byte_width(st.max_label);                     // crackle.hpp:233-235
 	if (ov && ov->force_stored_width) stored_width = ov->force_stored_width;
 
@@ -1575,20 +1692,35 @@ void encode_typed(
 	head.is_sorted = true;
 
 	if (voxels == 0) {   // crackle.hpp:96-98
-		head.write(final_binary);
+		std::vector<uint8_t> hb;
+		head.write(hb);
+		uint8_t* o = static_cast<uint8_t*>(malloc(hb.size()));
+		if (!o) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
+		memcpy(o, hb.data(), hb.size());
+		*out = o; *out_len = hb.size();
 		return;
 	}
 	if (optimize_pins) throw Error(CKL_ERR_ARG, "crackle_amd: allow_pins=2 (find_optimal_pins) is out of scope");
 	if (head.label_format != FLAT && head.label_format != PINS_VARIABLE_WIDTH) throw Error(CKL_ERR_ARG, "crackle_amd: unsupported label format");
 	if (head.markov_model_order > 13) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order > 13 is not supported on device");
 
-	HostTimer ht;
+	// labels (labels.hpp:30-155): components + crcs start on the label stream now and are
+	// collected while the crack trail runs
+	flat_enqueue(e, sx, sy, sz);
 	graph_pass(e, sx, sy, sz, head.crack_format == PERMISSIBLE);
 	ht.mark("graph");
-	// crack codes; a first pass decides whether any slice has chains (crackle.hpp:107-118)
-	CrackResult cr;
-	std::vector<uint8_t> model, stored_model;
+
 	const bool permissible = head.crack_format == PERMISSIBLE;
+	// if no slice has a crack edge the reference resets the markov order to 0 (crackle.hpp:107-118)
+	{
+		const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
+		bool any = false;
+		for (int64_t z = 0; z < sz && !any; z++) {
+			const uint64_t differ = static_cast<uint64_t>(e.count_v[z]) + e.count_h[z];
+			any = (permissible ? interior - differ : differ) > 0;
+		}
+		if (!any && !(ov && ov->has_model)) head.markov_model_order = 0;
+	}
 	std::vector<uint8_t> forced_model;
 	const std::vector<uint8_t>* model_in = nullptr;
 	if (ov && ov->has_model && head.markov_model_order > 0) {
@@ -1596,68 +1728,80 @@ void encode_typed(
 		forced_model.assign(ov->model, ov->model + rows * 4);
 		model_in = &forced_model;
 	}
-	crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr);
+
+	FlatResult fr;
+	std::vector<uint8_t> pins_binary;      // pin label section (host built)
+	uint64_t label_bytes = 0;
+	const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
+	hipStream_t s2 = e.stream2;
+	auto label_side = [&]() {
+		flat_collect<LABEL>(e, labels, sx, sy, sz, fr);
+		HT_MARK("flat");
+		const uint64_t N = fr.total;
+		if (head.label_format == PINS_VARIABLE_WIDTH) {
+			// pins (pins.hpp:348-403, labels.hpp:157-344): components and crcs come from the
+			// device passes above; the order-sensitive cover runs on the host (ckl_pins.hip)
+			if (N > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
+			e.d_cc_volume.ensure(voxels);
+			hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((e.plane_words + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
+				e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
+				e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, e.d_cc_volume.p);
+			std::vector<uint32_t> cc_host = download(e.d_cc_volume.p, voxels, s2);
+			std::vector<LABEL> labels_host = download(labels, voxels, s2);
+			HT_MARK("pins_d2h");
+			pins_binary = encode_pins_host<LABEL>(labels_host.data(), cc_host.data(), sx, sy, sz, fr.ncomp, N,
+				head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
+			label_bytes = pins_binary.size();
+			HT_MARK("pins_host");
+		}
+		else {
+			label_bytes = flat_section(e, N, stored_width, component_width, static_cast<uint32_t>(sz));
+			HT_MARK("label_table");
+		}
+	};
+
+	CrackResult cr;
+	std::vector<uint8_t> model, stored_model;
+	crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr, label_side);
 	ht.mark("cracks");
-	if (head.markov_model_order > 0 && !cr.any_chain && !(ov && ov->has_model)) {
-		// every slice empty: the reference resets the order to 0 and packs plainly
-		head.markov_model_order = 0;
-		crack_pass(e, sx, sy, sz, permissible, 0, false, nullptr, nullptr, nullptr, &cr);
-	}
 	if (head.markov_model_order > 0) stored_model = markov_model_to_stored(model);
 
-	// labels (labels.hpp:30-155)
-	FlatResult fr;
-	flat_pass<LABEL>(e, labels, sx, sy, sz, fr);
-	ht.mark("flat");
-	const uint64_t N = fr.total;
-	std::vector<uint8_t> labels_binary;
-	if (head.label_format == PINS_VARIABLE_WIDTH) {
-		// pins (pins.hpp:348-403, labels.hpp:157-344): components and crcs come from the
-		// device passes above; the order-sensitive cover runs on the host (ckl_pins.hip)
-		if (N > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
-		e.d_cc_volume.ensure(voxels);
-		hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((e.plane_words + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s,
-			e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
-			e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, e.d_cc_volume.p);
-		std::vector<uint32_t> cc_host = download(e.d_cc_volume.p, voxels, s);
-		std::vector<LABEL> labels_host = download(labels, voxels, s);
-		ht.mark("pins_d2h");
-		labels_binary = encode_pins_host<LABEL>(labels_host.data(), cc_host.data(), sx, sy, sz, fr.ncomp, N,
-			head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
-		ht.mark("pins_host");
+	// assembly (crackle.hpp:171-216), straight into the caller's buffer:
+	// header | z-index + crc | labels | model | crack codes | labels crc | slice crcs
+	head.num_label_bytes = label_bytes;
+	const uint64_t off_index = Header::kBytes;
+	const uint64_t off_labels = off_index + 4ull * (sz + 1);
+	const uint64_t off_model = off_labels + label_bytes;
+	const uint64_t off_codes = off_model + stored_model.size();
+	const uint64_t off_tail = off_codes + cr.total;
+	const uint64_t total = off_tail + 4ull * (sz + 1);
+	uint8_t* o = static_cast<uint8_t*>(malloc(total));
+	if (!o) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
+	try {
+		if (cr.total) CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
+		if (head.label_format == PINS_VARIABLE_WIDTH) { if (label_bytes) memcpy(o + off_labels, pins_binary.data(), label_bytes); }
+		else if (label_bytes) CKL_HIP(hipMemcpyAsync(o + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToHost, s2));
+		std::vector<uint8_t> hb;
+		head.write(hb);
+		memcpy(o, hb.data(), hb.size());
+		auto put4 = [&](uint64_t at, uint32_t v) { for (int b = 0; b < 4; b++) o[at + b] = static_cast<uint8_t>((v >> (8 * b)) & 0xFF); };
+		for (int64_t z = 0; z < sz; z++) put4(off_index + 4ull * z, cr.code_len[z]);
+		put4(off_index + 4ull * sz, crc32c(o + off_index, 4ull * sz));
+		if (!stored_model.empty()) memcpy(o + off_model, stored_model.data(), stored_model.size());
+		for (int64_t z = 0; z < sz; z++) put4(off_tail + 4 + 4ull * z, fr.crcs[z]);
+		CKL_HIP(hipStreamSynchronize(s2));
+		put4(off_tail, crc32c(o + off_labels, label_bytes));
+		ht.mark("assembly");
+		CKL_HIP(hipEventRecord(e.ev1, s));
+		CKL_HIP(hipStreamSynchronize(s));
+		ht.mark("codes_d2h");
+		CKL_HIP(hipGetLastError());
+		CKL_HIP(hipEventElapsedTime(&e.pipeline_ms, e.ev0, e.ev1));
+		CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evk0, e.evk1));
 	}
-	else {
-		std::vector<uint64_t> uniq;
-		std::vector<uint8_t> keys;
-		int key_width = 1;
-		label_table(e, N, uniq, key_width, keys);
-		const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
-		labels_binary.reserve(8 + uniq.size() * stored_width + static_cast<size_t>(sz) * component_width + keys.size());
-		put_le(labels_binary, uniq.size(), 8);
-		for (uint64_t v : uniq) put_le(labels_binary, v, stored_width);
-		for (int64_t z = 0; z < sz; z++) put_le(labels_binary, fr.ncomp[z], component_width);
-		labels_binary.insert(labels_binary.end(), keys.begin(), keys.end());
-		ht.mark("label_table");
-	}
-	// assembly (crackle.hpp:171-216)
-	head.num_label_bytes = labels_binary.size();
-	final_binary.reserve(Header::kBytes + 4 * (sz + 1) + labels_binary.size() + stored_model.size() + cr.codes.size() + 4 * (sz + 1));
-	head.write(final_binary);
-	const size_t zi0 = final_binary.size();
-	for (int64_t z = 0; z < sz; z++) put_le(final_binary, cr.code_len[z], 4);
-	put_le(final_binary, crc32c(final_binary.data() + zi0, 4ull * sz), 4);
-	final_binary.insert(final_binary.end(), labels_binary.begin(), labels_binary.end());
-	if (head.markov_model_order > 0) final_binary.insert(final_binary.end(), stored_model.begin(), stored_model.end());
-	final_binary.insert(final_binary.end(), cr.codes.begin(), cr.codes.end());
-	put_le(final_binary, crc32c(labels_binary.data(), labels_binary.size()), 4);
-	for (int64_t z = 0; z < sz; z++) put_le(final_binary, fr.crcs[z], 4);
-
-	ht.mark("assembly");
-	CKL_HIP(hipEventRecord(e.ev1, s));
-	CKL_HIP(hipStreamSynchronize(s));
-	CKL_HIP(hipGetLastError());
-	CKL_HIP(hipEventElapsedTime(&e.pipeline_ms, e.ev0, e.ev1));
-	CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evk0, e.evk1));
+	catch (...) { free(o); throw; }
+	*out = o;
+	*out_len = total;
 }
 
 void check_dims(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int is_signed) {
@@ -1681,10 +1825,12 @@ int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int 
 		e->device = device;
 		e->max_sx = sx; e->max_sy = sy; e->max_sz = sz; e->dtype_bytes = dtype_bytes;
 		CKL_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+		CKL_HIP(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
 		CKL_HIP(hipEventCreate(&e->ev0));
 		CKL_HIP(hipEventCreate(&e->ev1));
 		CKL_HIP(hipEventCreate(&e->evk0));
 		CKL_HIP(hipEventCreate(&e->evk1));
+		CKL_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
 		*out = e.release();
 		return CKL_OK;
 	}
@@ -1703,19 +1849,19 @@ int ckl_encoder_run(
 		check_dims(sx, sy, sz, e->dtype_bytes, 0);
 		if (markov_model_order > 15) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order must be in [0, 15]");
 		select_device(e->device);
-		std::vector<uint8_t> bin;
+		wait_for_default_stream(e->stream, e->ev_in);
+		wait_for_default_stream(e->stream2, e->ev_in);
+		const auto t_run0 = std::chrono::steady_clock::now();
 #define CKL_ENC(T) encode_typed<T>(*e, reinterpret_cast<const T*>(labels_device), sx, sy, sz, allow_pins != 0, fortran_order != 0, \
-	markov_model_order, optimize_pins != 0, auto_bgcolor != 0, manual_bgcolor, overrides, bin)
+	markov_model_order, optimize_pins != 0, auto_bgcolor != 0, manual_bgcolor, overrides, out, out_len)
 		if (e->dtype_bytes == 1) CKL_ENC(uint8_t);
 		else if (e->dtype_bytes == 2) CKL_ENC(uint16_t);
 		else if (e->dtype_bytes == 4) CKL_ENC(uint32_t);
 		else CKL_ENC(uint64_t);
 #undef CKL_ENC
-		uint8_t* p = static_cast<uint8_t*>(malloc(bin.size() ? bin.size() : 1));
-		if (!p) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
-		memcpy(p, bin.data(), bin.size());
-		*out = p;
-		*out_len = bin.size();
+		if (getenv("CKL_PROFILE")) {
+			fprintf(stderr, "[ckl encoder_run ms] encode=%.2f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count());
+		}
 		return CKL_OK;
 	}
 	catch (const Error& err) { set_last_error(err.what()); return err.status; }
@@ -1730,6 +1876,8 @@ int ckl_encoder_stats(
 		if (!e) throw Error(CKL_ERR_ARG, "crackle_amd: null encoder");
 		check_dims(sx, sy, sz, e->dtype_bytes, 0);
 		select_device(e->device);
+		wait_for_default_stream(e->stream, e->ev_in);
+		wait_for_default_stream(e->stream2, e->ev_in);
 		const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
 		VolumeStats st;
 		if (e->dtype_bytes == 1) st = volume_stats<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), voxels);
@@ -1755,6 +1903,8 @@ int ckl_encoder_markov_stats(
 		check_dims(sx, sy, sz, e->dtype_bytes, 0);
 		if (markov_model_order == 0 || markov_model_order > 13) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order must be in [1, 13]");
 		select_device(e->device);
+		wait_for_default_stream(e->stream, e->ev_in);
+		wait_for_default_stream(e->stream2, e->ev_in);
 		const size_t rows = static_cast<size_t>(1) << (2 * markov_model_order);
 		std::vector<uint32_t> h(rows * 4, 0);
 		if (static_cast<uint64_t>(sx) * sy * sz > 0) {
