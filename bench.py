@@ -147,7 +147,8 @@ def main():
         synth.voronoi_labels((sx, sy, sz), np_dtype, seed=2, device=dev, offset=offset)
   torch.cuda.synchronize()
 
-  backend = ckd.HipBackend(dev_index)
+  # the stream stays in the library's pinned host buffer (no copy into a Python bytes object)
+  backend = ckd.HipBackend(dev_index, zero_copy=True)
   codec = ckd.ShardedCodec(backend, rank=rank, world=world, device=dev)
 
   def barrier():

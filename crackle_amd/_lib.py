@@ -44,9 +44,9 @@ EXPORTS = {
     C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_free": (None, [C.c_void_p]),
   "ckl_decompress": (C.c_int, [
-    C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
+    C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
     C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_int]),
-  "ckl_decoder_create": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+  "ckl_decoder_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
   "ckl_decoder_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]),
   "ckl_decoder_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
   "ckl_decoder_stage_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
@@ -94,3 +94,45 @@ def lib():
 
 def last_error() -> str:
   return lib().ckl_last_error().decode("utf-8", "replace")
+
+
+class HostStream:
+  """A .ckl stream in the library's own (pinned) host buffer, as ckl_encoder_run hands it
+  over: no copy into a Python bytes object.  bytes(stream) / stream.tobytes() copy;
+  the buffer goes back to the library (ckl_free) when the object dies."""
+
+  def __init__(self, ptr: int, n: int):
+    self.ptr, self.n = int(ptr), int(n)
+
+  def __len__(self):
+    return self.n
+
+  def view(self) -> memoryview:
+    return memoryview((C.c_ubyte * self.n).from_address(self.ptr)).cast("B")
+
+  def tobytes(self) -> bytes:
+    return C.string_at(self.ptr, self.n)
+
+  __bytes__ = tobytes
+
+  def __eq__(self, other):
+    if isinstance(other, HostStream):
+      return self.tobytes() == other.tobytes()
+    if isinstance(other, (bytes, bytearray, memoryview)):
+      return self.tobytes() == bytes(other)
+    return NotImplemented
+
+  def __del__(self):
+    try:
+      if self.ptr:
+        lib().ckl_free(self.ptr)
+        self.ptr = 0
+    except Exception:
+      pass
+
+
+def as_pointer(binary):
+  """(address-or-bytes, length) of a stream given as bytes or HostStream, for c_void_p arguments."""
+  if isinstance(binary, HostStream):
+    return binary.ptr, binary.n
+  return binary, len(binary)

@@ -99,6 +99,72 @@ void pool_trim() {
 	for (const PoolBlock& b : blocks) (void)hipFree(b.p);
 }
 
+// ---- host output buffers -----------------------------------------------------------
+// Streams are handed to the caller in pinned host memory (device -> host copies land in
+// it directly, at full link rate) and come back through ckl_free into a small cache, so
+// that a codec called in a loop does not pay for page faults / pinning on every call.
+namespace {
+struct HostBlock { void* p; size_t bytes; };
+std::mutex g_host_mutex;
+std::vector<HostBlock> g_host_live, g_host_free;
+constexpr size_t kHostCacheBlocks = 4;
+constexpr size_t kHostCacheMaxBytes = 1ull << 30;
+}
+
+void* host_out_alloc(size_t bytes) {
+	if (bytes == 0) bytes = 1;
+	{
+		std::lock_guard<std::mutex> lock(g_host_mutex);
+		size_t best = g_host_free.size();
+		for (size_t i = 0; i < g_host_free.size(); i++) {
+			if (g_host_free[i].bytes < bytes) continue;
+			if (best == g_host_free.size() || g_host_free[i].bytes < g_host_free[best].bytes) best = i;
+		}
+		if (best != g_host_free.size()) {
+			HostBlock b = g_host_free[best];
+			g_host_free[best] = g_host_free.back();
+			g_host_free.pop_back();
+			g_host_live.push_back(b);
+			return b.p;
+		}
+	}
+	const size_t cap = bytes < (1u << 20) ? bytes : bytes + bytes / 4;
+	void* p = nullptr;
+	if (bytes >= (64u << 10) && hipHostMalloc(&p, cap, hipHostMallocDefault) == hipSuccess && p) {
+		std::lock_guard<std::mutex> lock(g_host_mutex);
+		g_host_live.push_back({ p, cap });
+		return p;
+	}
+	(void)hipGetLastError();
+	p = malloc(bytes);
+	if (!p) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
+	return p;
+}
+
+void host_out_free(void* p) {
+	if (!p) return;
+	HostBlock b = { nullptr, 0 };
+	bool drop = false;
+	{
+		std::lock_guard<std::mutex> lock(g_host_mutex);
+		for (size_t i = 0; i < g_host_live.size(); i++) {
+			if (g_host_live[i].p != p) continue;
+			b = g_host_live[i];
+			g_host_live[i] = g_host_live.back();
+			g_host_live.pop_back();
+			break;
+		}
+		if (b.p) {
+			size_t cached = 0;
+			for (const HostBlock& f : g_host_free) cached += f.bytes;
+			if (g_host_free.size() < kHostCacheBlocks && cached + b.bytes <= kHostCacheMaxBytes) g_host_free.push_back(b);
+			else drop = true;
+		}
+	}
+	if (!b.p) free(p);                       // a plain malloc'd buffer
+	else if (drop) (void)hipHostFree(b.p);
+}
+
 // ---- checksums -------------------------------------------------------------------
 // crc8 (src/crc.hpp:23-37): poly 0xe7 (implicit +1, reflected), init 0xFF, no xorout
 uint8_t crc8(const uint8_t* data, uint64_t n) {
@@ -126,8 +192,29 @@ static void crc_tab_init() {
 		}
 	}
 }
+// SSE4.2 crc32 instruction (the same polynomial); three independent streams would be
+// faster still, one is plenty for the label section (< 1 MB) and the z-index
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) static uint32_t crc32c_sse42(const uint8_t* data, uint64_t n) {
+	uint64_t crc = 0xFFFFFFFFu;
+	while (n >= 8) {
+		uint64_t w;
+		memcpy(&w, data, 8);
+		crc = __builtin_ia32_crc32di(crc, w);
+		data += 8;
+		n -= 8;
+	}
+	uint32_t c = static_cast<uint32_t>(crc);
+	while (n--) c = __builtin_ia32_crc32qi(c, *data++);
+	return ~c;
+}
+#endif
 // crc32c (src/crc.hpp:39-57 -> crc32_impl(0, ...)): Castagnoli, init/xorout ~0
 uint32_t crc32c(const uint8_t* data, uint64_t n) {
+#if defined(__x86_64__)
+	static const bool have_sse42 = __builtin_cpu_supports("sse4.2");
+	if (have_sse42) return crc32c_sse42(data, n);
+#endif
 	std::call_once(g_tab_once, crc_tab_init);
 	uint32_t crc = 0xFFFFFFFFu;
 	while (n >= 8) {
@@ -302,7 +389,7 @@ int ckl_header_info_from_bytes(const uint8_t* buf, uint64_t n, ckl_header_info* 
 	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
 }
 
-void ckl_free(void* p) { free(p); }
+void ckl_free(void* p) { host_out_free(p); }
 
 uint32_t ckl_crc32c(const uint8_t* data, uint64_t n) { return crc32c(data, n); }
 

@@ -112,6 +112,8 @@ struct Header {
 // Device allocations go through a small per-device pool: sessions are created and
 // destroyed per call by the one-shot API, and releasing / re-acquiring gigabytes of
 // scratch through hipFree / hipMalloc costs tens of milliseconds each time.
+void* host_out_alloc(size_t bytes);        // pinned (cached) host buffer for results; release with ckl_free / host_out_free
+void host_out_free(void* p);               // also accepts plain malloc'd pointers
 void* pool_alloc(size_t bytes);            // throws Error on failure
 void pool_free(void* p, size_t bytes);     // returns the block to the pool
 void pool_trim();                          // hipFree everything that is pooled

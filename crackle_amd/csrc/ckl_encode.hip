@@ -1404,7 +1404,7 @@ void crack_pass(
 			hipLaunchKernelGGL(k_trail_components, dim3(ns), dim3(kBlock), clds, s, ta, static_cast<uint32_t>(clds));
 		}
 		// node tables of k_trail_dfs in LDS: 9 bytes per node + 16 KiB of branch stack when that fits
-		size_t lds = (static_cast<size_t>(max_special) + 256) * 9 + 16384;
+		size_t lds = (static_cast<size_t>(max_special) + 256) * 9 + 16384 + 1024;
 		if (const char* env = getenv("CKL_TRAIL_LDS")) lds = static_cast<size_t>(std::max(0, atoi(env)));   // testing: small values force the global tables
 		lds = std::min(budget, std::max<size_t>(lds, 4096));
 		lds = (lds / 16) * 16;
@@ -1762,7 +1762,11 @@ void encode_typed(
 
 	CrackResult cr;
 	std::vector<uint8_t> model, stored_model;
-	crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr, label_side);
+	if (getenv("CKL_NO_OVERLAP")) {   // diagnostic: kernel timings without the two streams competing
+		crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr);
+		label_side();
+	}
+	else crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr, label_side);
 	ht.mark("cracks");
 	if (head.markov_model_order > 0) stored_model = markov_model_to_stored(model);
 
@@ -1775,8 +1779,7 @@ void encode_typed(
 	const uint64_t off_codes = off_model + stored_model.size();
 	const uint64_t off_tail = off_codes + cr.total;
 	const uint64_t total = off_tail + 4ull * (sz + 1);
-	uint8_t* o = static_cast<uint8_t*>(malloc(total));
-	if (!o) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
+	uint8_t* o = static_cast<uint8_t*>(host_out_alloc(total));
 	try {
 		if (cr.total) CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
 		if (head.label_format == PINS_VARIABLE_WIDTH) { if (label_bytes) memcpy(o + off_labels, pins_binary.data(), label_bytes); }
@@ -1799,7 +1802,7 @@ void encode_typed(
 		CKL_HIP(hipEventElapsedTime(&e.pipeline_ms, e.ev0, e.ev1));
 		CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evk0, e.evk1));
 	}
-	catch (...) { free(o); throw; }
+	catch (...) { host_out_free(o); throw; }
 	*out = o;
 	*out_len = total;
 }

@@ -497,6 +497,7 @@ enum : uint32_t { TCODE_UP = 0, TCODE_RIGHT = 1, TCODE_DOWN = 2, TCODE_LEFT = 3,
 struct TrailTabLds {
 	uint8_t* adj;
 	unsigned long long* end4;      // four 16-bit dart ends (node << 2 | arrival) per node
+	uint32_t dummy;                // byte offset from adj of 64 scratch dwords: where the lanes other than 0 write
 	__device__ __forceinline__ void load(uint32_t j, uint32_t& av, uint32_t& e_lo, uint32_t& e_hi) const {
 		const uint32_t a0 = adj[j];
 		const unsigned long long e = end4[j];
@@ -508,7 +509,11 @@ struct TrailTabLds {
 		const uint32_t w = (k & 2u) ? e_hi : e_lo;
 		return (w >> ((k & 1u) * 16u)) & 0xFFFFu;
 	}
-	__device__ __forceinline__ void set_adj(uint32_t j, uint32_t v, bool l0) const { if (l0) adj[j] = static_cast<uint8_t>(v); }
+	// no exec-mask juggling and no 64-way same-address write: lane 0 stores to the table,
+	// every other lane to its own scratch dword
+	__device__ __forceinline__ void set_adj(uint32_t j, uint32_t v, bool l0) const {
+		adj[l0 ? j : dummy + (threadIdx.x << 2)] = static_cast<uint8_t>(v);
+	}
 	__device__ __forceinline__ uint32_t get_end(uint32_t d) const {
 		return __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(end4)[d]));
 	}
@@ -553,48 +558,51 @@ __device__ __forceinline__ void trail_dfs_slice(
 	uint32_t* ch_item0 = a.chain_item0 + a.kbase[zi];
 	const uint32_t kcap = a.kcap[zi];
 	const uint32_t* vert2node = a.vert2node + static_cast<uint64_t>(zi) * a.nverts;
+	uint2* s_stack2 = reinterpret_cast<uint2*>(s_stack);
 
+	// Every lane carries the same state, so stores need no lane predicate: all lanes write
+	// the same value to the same address (one LDS / memory transaction).
 	uint32_t ni = 0, nch = 0, err = 0;
-	constexpr uint32_t F_FIRST = 1u, F_PREVT = 2u, F_RIB = 4u;
+	// last: code of the previous symbol's last code point, 4 = nothing emitted yet
+	// 'b' is (UP,DOWN) unless the previous code is DOWN (or there is none), then (LEFT,RIGHT);
+	// 't' is (DOWN,UP) unless the previous code is UP (or there is none), then (RIGHT,LEFT)   (crackcodes.hpp:155-174)
+	constexpr uint32_t kNone = 4u;
+	constexpr uint32_t kB = kItemCtl | TCODE_UP | (TCODE_DOWN << 2), kBalt = kItemCtl | TCODE_LEFT | (TCODE_RIGHT << 2);
+	constexpr uint32_t kT = kItemCtl | TCODE_DOWN | (TCODE_UP << 2), kTalt = kItemCtl | TCODE_RIGHT | (TCODE_LEFT << 2);
 	for (uint32_t si = 0; si < n_starts; si++) {
 		const uint32_t sv = __builtin_amdgcn_readfirstlane(starts[si]);
 		uint32_t j = __builtin_amdgcn_readfirstlane(vert2node[sv]);
 		const uint32_t chain_begin = ni;
-		uint32_t sp = 0, flags = F_FIRST, last_code = TCODE_NONE, prev_t_b = 0, adjusted = sv;
-		uint32_t pend = 0;          // edge of node j consumed by the move that led here
-		uint32_t guard = 0;
+		uint32_t sp = 0, last = kNone, prev_t_b = 0, adjusted = sv;
+		uint32_t prevt = 0;        // previous symbol is a live 't' that popped the 'b' item prev_t_b
+		uint32_t rib = 0;          // chain began with 'b', no other 'b' and no 't' yet
+		uint32_t pend = 0;         // edge of node j consumed by the move that led here
 		for (;;) {
-			j = __builtin_amdgcn_readfirstlane(j);
-			ni = __builtin_amdgcn_readfirstlane(ni);
-			sp = __builtin_amdgcn_readfirstlane(sp);
-			flags = __builtin_amdgcn_readfirstlane(flags);
-			last_code = __builtin_amdgcn_readfirstlane(last_code);
-			pend = __builtin_amdgcn_readfirstlane(pend);
-			if (ni + 4u > icap || ++guard > 2u * icap) { err |= TRAIL_ERR_CAPACITY; break; }
+			if (ni + 4u > icap) { err |= TRAIL_ERR_CAPACITY; break; }
 			uint32_t av_raw, e_lo, e_hi;
 			tab.load(j, av_raw, e_lo, e_hi);
 			const uint32_t av = av_raw & ~pend;
-			pend = 0;
 			if (av == 0) {
-				if (av_raw) tab.set_adj(j, 0u, l0);
+				if (pend) tab.set_adj(j, 0u, l0);
+				pend = 0;
 				// ---- 't': dead end, back to the most recent branch vertex
 				if (sp == 0) break;
 				sp--;
 				uint32_t pj, pitem;
 				if (sp < lds_stack_cap) {
-					const uint32_t p0 = s_stack[2u * sp], p1 = s_stack[2u * sp + 1u];
-					pj = __builtin_amdgcn_readfirstlane(p0);
-					pitem = __builtin_amdgcn_readfirstlane(p1);
+					const uint2 pr = s_stack2[sp];
+					pj = __builtin_amdgcn_readfirstlane(pr.x);
+					pitem = __builtin_amdgcn_readfirstlane(pr.y);
 				}
 				else {
 					pj = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_node + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 					pitem = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_item + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 				}
-				if (flags & F_RIB) {
+				if (rib) {
 					// remove_initial_branch (crackcodes.hpp:185-242): the leading 'b' and this 't'
 					// vanish, the first stretch is walked backwards from where it ended
 					adjusted = __builtin_amdgcn_readfirstlane(a.node_vertex[nb + j]);
-					uint32_t lc = last_code;
+					uint32_t lc = last;
 					if (l0) {
 						items[chain_begin] = kItemDead;
 						if (ni > chain_begin + 1u) {
@@ -610,61 +618,59 @@ __device__ __forceinline__ void trail_dfs_slice(
 							lc = trail_code((e & 3u) ^ 1u);
 						}
 					}
-					last_code = __builtin_amdgcn_readfirstlane(lc);
-					flags = 0;
+					last = __builtin_amdgcn_readfirstlane(lc);
+					rib = 0;
 				}
-				else if (flags & F_PREVT) {
-					// remove_spurious_branches (crackcodes.hpp:250-281)
-					if (l0) items[prev_t_b] = kItemDead;
+				else if (prevt) {
+					// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by the
+					// previous 't' and this 't' vanish
+					items[prev_t_b] = kItemDead;
 					prev_t_b = pitem;
-					flags = F_PREVT;
 				}
 				else {
-					const bool alt = (flags & F_FIRST) || last_code == TCODE_NONE || last_code == TCODE_UP;
-					const uint32_t c0 = alt ? TCODE_RIGHT : TCODE_DOWN, c1 = alt ? TCODE_LEFT : TCODE_UP;
-					if (l0) items[ni] = kItemCtl | c0 | (c1 << 2);
+					const bool alt = (last == kNone) || (last == TCODE_UP);
+					items[ni] = alt ? kTalt : kT;
 					ni++;
-					last_code = c1;
-					flags = F_PREVT;
+					last = alt ? TCODE_LEFT : TCODE_UP;
+					prevt = 1;
 					prev_t_b = pitem;
 				}
 				j = pj;
 				continue;
 			}
+			pend = 0;
 			if (av & (av - 1u)) {
 				// ---- 'b': more than one edge left, remember the vertex
-				const uint32_t was_first = flags & F_FIRST;
-				if (sp < lds_stack_cap) { if (l0) { s_stack[2u * sp] = j; s_stack[2u * sp + 1u] = ni; } }
+				if (sp < lds_stack_cap) s_stack2[l0 ? sp : lds_stack_cap + threadIdx.x] = make_uint2(j, ni);
 				else if (sp < scap) { if (l0) { st_node[sp] = j; st_item[sp] = ni; } }
 				else err |= TRAIL_ERR_CAPACITY;
 				sp++;
-				const bool alt = was_first || last_code == TCODE_NONE || last_code == TCODE_DOWN;
-				const uint32_t c0 = alt ? TCODE_LEFT : TCODE_UP, c1 = alt ? TCODE_RIGHT : TCODE_DOWN;
-				if (l0) items[ni] = kItemCtl | c0 | (c1 << 2);
+				const bool alt = (last == kNone) || (last == TCODE_DOWN);
+				items[ni] = alt ? kBalt : kB;
 				ni++;
-				flags = was_first ? F_RIB : 0u;
+				rib = (last == kNone) ? 1u : 0u;
 			}
-			else flags &= F_RIB;
+			prevt = 0;
 			// ---- along the lowest-numbered remaining edge: right, left, down, up
 			const uint32_t k = __ffs(av) - 1;
 			tab.set_adj(j, av & ~(1u << k), l0);
 			const uint32_t e = tab.pick(e_lo, e_hi, k);
-			if (l0) items[ni] = kItemSeg | (j * 4u + k);
+			items[ni] = kItemSeg | (j * 4u + k);
 			ni++;
 			const uint32_t k2 = e & 3u;
-			last_code = trail_code(k2 ^ 1u);
+			last = trail_code(k2 ^ 1u);
 			pend = 1u << k2;
 			j = e >> 2;
 		}
 		// the closing 't' (crackcodes.hpp:436-439)
-		if (flags & F_PREVT) { if (l0) items[prev_t_b] = kItemDead; }
+		if (prevt) items[prev_t_b] = kItemDead;
 		else {
-			const bool alt = (flags & F_FIRST) || last_code == TCODE_NONE || last_code == TCODE_UP;
-			if (ni < icap) { if (l0) items[ni] = kItemCtl | (alt ? TCODE_RIGHT : TCODE_DOWN) | ((alt ? TCODE_LEFT : TCODE_UP) << 2); }
+			const bool alt = (last == kNone) || (last == TCODE_UP);
+			if (ni < icap) items[ni] = alt ? kTalt : kT;
 			else err |= TRAIL_ERR_CAPACITY;
 			ni++;
 		}
-		if (nch < kcap) { if (l0) { ch_node[nch] = adjusted; ch_item0[nch] = chain_begin; } }
+		if (nch < kcap) { ch_node[nch] = adjusted; ch_item0[nch] = chain_begin; }
 		else err |= TRAIL_ERR_CAPACITY;
 		nch++;
 		if (err) break;
@@ -686,13 +692,14 @@ static __global__ void __launch_bounds__(kWave) k_trail_dfs(TrailArgs a, uint32_
 		if (threadIdx.x == 0) { a.n_items[zi] = 0; a.n_chains[zi] = 0; }
 		return;
 	}
-	// LDS: [dart ends u16 x 4 nn][adj u8 x nn][branch stack: (node, item) pairs]
-	const uint32_t tab_bytes = ((nn * 9u + 15u) / 16u) * 16u;
-	const bool in_lds = nn < 16384u && tab_bytes + 2048u <= lds_bytes;
+	// LDS: [dart ends u16 x 4 nn][adj u8 x nn][64 scratch dwords][branch stack: (node, item) pairs + 64 scratch pairs]
+	const uint32_t tab_bytes = ((nn * 9u + 15u) / 16u) * 16u + 256u;
+	const bool in_lds = nn < 16384u && tab_bytes + 2048u + 512u <= lds_bytes;
 	if (in_lds) {
 		TrailTabLds t;
 		t.end4 = reinterpret_cast<unsigned long long*>(s_trail);
 		t.adj = reinterpret_cast<uint8_t*>(s_trail) + nn * 8u;
+		t.dummy = (tab_bytes - 256u) - nn * 8u;
 		uint16_t* e16 = reinterpret_cast<uint16_t*>(s_trail);
 		for (uint32_t d = threadIdx.x; d < nn * 4u; d += kWave) {
 			const uint32_t e = a.dart_end[nb * 4u + d];
@@ -701,13 +708,13 @@ static __global__ void __launch_bounds__(kWave) k_trail_dfs(TrailArgs a, uint32_
 		for (uint32_t j = threadIdx.x; j < nn; j += kWave) t.adj[j] = a.node_adj[nb + j];
 		__syncthreads();
 		uint32_t* stack = s_trail + tab_bytes / 4u;
-		trail_dfs_slice<TrailTabLds>(a, zi, t, stack, (lds_bytes - tab_bytes) / 8u);
+		trail_dfs_slice<TrailTabLds>(a, zi, t, stack, (lds_bytes - tab_bytes) / 8u - 64u);
 	}
 	else {
 		TrailTabGlobal t;
 		t.adj = a.node_adj + nb;
 		t.end = a.dart_end + nb * 4u;
-		trail_dfs_slice<TrailTabGlobal>(a, zi, t, s_trail, lds_bytes / 8u);
+		trail_dfs_slice<TrailTabGlobal>(a, zi, t, s_trail, lds_bytes / 8u - 64u);
 	}
 }
 

@@ -66,11 +66,12 @@ def zstack(bufs: Sequence[bytes]) -> bytes:
 
 
 class HipDecodeSession:
-  def __init__(self, binary: bytes, z_start: int, z_end: int, device_index: int):
+  def __init__(self, binary, z_start: int, z_end: int, device_index: int):
     self._L = _lib.lib()
     self._h = C.c_void_p()
     self._binary = binary   # keep alive
-    rc = self._L.ckl_decoder_create(binary, len(binary), z_start, z_end, device_index, C.byref(self._h))
+    ptr, n = _lib.as_pointer(binary)
+    rc = self._L.ckl_decoder_create(ptr, n, z_start, z_end, device_index, C.byref(self._h))
     if rc != _lib.CKL_OK:
       raise RuntimeError(_lib.last_error())
 
@@ -111,8 +112,9 @@ class HipDecodeSession:
 class HipBackend:
   """Device-resident volumes: torch tensors of shape (sz, sy, sx) on the rank's GPU."""
 
-  def __init__(self, device_index: int = 0):
+  def __init__(self, device_index: int = 0, zero_copy: bool = False):
     self.device_index = int(device_index)
+    self.zero_copy = bool(zero_copy)   # encode() returns _lib.HostStream (the library's buffer) instead of bytes
     self._L = _lib.lib()
     self._enc = None
     self._enc_key = None
@@ -171,6 +173,8 @@ class HipBackend:
     del keep
     if rc != _lib.CKL_OK:
       raise RuntimeError(_lib.last_error())
+    if self.zero_copy:
+      return _lib.HostStream(out.value, n.value)
     try:
       return C.string_at(out.value, n.value)
     finally:
@@ -241,7 +245,7 @@ class ShardedCodec:
         overrides["model"] = stats_to_model(hist).reshape(-1)
 
     # 3. per-slab streams, gathered to rank 0 and merged
-    slab = be.encode(vol, slab_shape, False, fortran_order, order, overrides)
+    slab = bytes(be.encode(vol, slab_shape, False, fortran_order, order, overrides))
     n_mine = torch.tensor([len(slab)], dtype=torch.int64, device=self.device)
     sizes = [torch.empty_like(n_mine) for _ in range(self.world)]
     dist.all_gather(sizes, n_mine)
@@ -265,7 +269,7 @@ class ShardedCodec:
       n = torch.tensor([len(binary) if self.rank == 0 else 0], dtype=torch.int64, device=self.device)
       dist.broadcast(n, src=0)
       if self.rank == 0:
-        buf = torch.frombuffer(bytearray(binary), dtype=torch.uint8).to(self.device)
+        buf = torch.frombuffer(bytearray(bytes(binary)), dtype=torch.uint8).to(self.device)
       else:
         buf = torch.empty(int(n.item()), dtype=torch.uint8, device=self.device)
       dist.broadcast(buf, src=0)

@@ -77,7 +77,7 @@ int ckl_header_info_from_bytes(const uint8_t* buf, uint64_t n, ckl_header_info* 
  *   is_signed     must be 0 (crackle/codec.py:720-721 rejects signed input)
  *   allow_pins .. manual_bgcolor   same meaning as the reference's arguments
  *   device        HIP device ordinal
- *   out/out_len   malloc'd host buffer holding the .ckl bytes; release with ckl_free
+ *   out/out_len   library-owned host buffer holding the .ckl bytes; release with ckl_free (only)
  */
 int ckl_compress(
 	const void* labels, int labels_mem, int dtype_bytes, int is_signed,
@@ -139,7 +139,7 @@ typedef struct ckl_encode_overrides {
 	const uint8_t* model;
 } ckl_encode_overrides;
 
-/* Encodes a DEVICE-resident volume; result is a malloc'd host buffer (ckl_free). */
+/* Encodes a DEVICE-resident volume; result is a library-owned (pinned, cached) host buffer: release with ckl_free. */
 int ckl_encoder_run(
 	ckl_encoder* e, const void* labels_device,
 	int64_t sx, int64_t sy, int64_t sz,
