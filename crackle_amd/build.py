@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrackle_amd.so")
 SOURCES = ["ckl_common.hip", "ckl_decode.hip", "ckl_encode.hip", "ckl_pins.hip", "ckl_zstack.hip"]
-HEADERS = ["ckl_common.hpp", "ckl_device.hpp", "ckl_runs.hpp", os.path.join("..", "..", "include", "crackle_amd.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "crackle_amd.h")]
 ARCH = os.environ.get("CKL_OFFLOAD_ARCH", "gfx950")
 
 

@@ -166,8 +166,11 @@ __device__ __forceinline__ int32_t prev_smaller(const DEP* depth, const DEP* gmi
 template <typename IDX, typename DEP>
 __device__ __forceinline__ void match_controls(
 	const CtlTables<IDX, DEP>& t, uint32_t N, const uint32_t* nodes, uint32_t n_nodes, uint32_t sxe, uint32_t nverts,
-	uint32_t* s_scan, int32_t* s_scanmax, uint32_t* s_first_dead, uint32_t* s_valid_segs, uint32_t& rerr
+	uint32_t* s_scan, int32_t* s_scanmax, uint32_t* s_first_dead, uint32_t* s_valid_segs, uint32_t& rerr,
+	unsigned long long* dg = nullptr
 ) {
+	unsigned long long dg_t = dg ? __builtin_amdgcn_s_memtime() : 0ull;
+	auto sub = [&](int slot) { if (dg && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); dg[slot] = now - dg_t; dg_t = now; } };
 	constexpr IDX NONE = static_cast<IDX>(~static_cast<IDX>(0));
 	const uint32_t tid = threadIdx.x;
 	const uint32_t per = (N + kCrackBlock - 1) / kCrackBlock;
@@ -223,6 +226,7 @@ __device__ __forceinline__ void match_controls(
 		}
 	}
 	__syncthreads();
+	sub(8);
 	const uint32_t ngroups = (N + 63u) / 64u;
 	for (uint32_t gi = tid; gi < ngroups; gi += kCrackBlock) {
 		int32_t mv = INT32_MAX;
@@ -231,6 +235,7 @@ __device__ __forceinline__ void match_controls(
 		t.gmin[gi] = static_cast<DEP>(mv > 32767 ? 32767 : mv);
 	}
 	__syncthreads();
+	sub(9);
 	const uint32_t first_dead = *s_first_dead;
 	const uint32_t n_eff = min(N, first_dead);
 
@@ -258,6 +263,7 @@ __device__ __forceinline__ void match_controls(
 		}
 	}
 	__syncthreads();
+	sub(10);
 	for (uint32_t i = i0; i < i1; i++) {
 		if (t.kind[i] != SYM_T || i >= n_eff) continue;
 		volatile unsigned long long* lk = t.link;
@@ -269,6 +275,7 @@ __device__ __forceinline__ void match_controls(
 		}
 	}
 	__syncthreads();
+	sub(11);
 	{
 		uint32_t tc = T0;
 		for (uint32_t i = i0; i < i1; i++) {
@@ -505,7 +512,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	auto stamp = [&](int slot) {
 		if (DIAG && threadIdx.x == 0 && diag) {
 			const unsigned long long now = __builtin_amdgcn_s_memtime();
-			diag[static_cast<uint64_t>(blockIdx.x) * 8 + slot] = now - d_t;
+			diag[static_cast<uint64_t>(blockIdx.x) * 16 + slot] = now - d_t;
 			d_t = now;
 		}
 	};
@@ -681,7 +688,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		// ---- branch matching
 		const uint32_t n_ctl = c.a;
 		if (n_ctl <= lcap) {
-			match_controls<uint16_t, int16_t>(lt, n_ctl, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, rerr);
+			match_controls<uint16_t, int16_t>(lt, n_ctl, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, rerr, (DIAG && diag) ? diag + static_cast<uint64_t>(zi) * 16 : nullptr);
 			// pack seg_y right behind the used part of seg_x: the rest of the LDS becomes the band buffer
 			const uint32_t vs = s_valid_segs;
 			constexpr uint32_t kMoves = 8;
@@ -713,7 +720,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			match_controls<uint32_t, int32_t>(gt, n, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, rerr);
 			__threadfence_block();
 		}
-		if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 8 + 5] = n_ctl;
+		if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 16 + 5] = n_ctl;
 		stamp(2);
 	}
 
@@ -767,7 +774,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	__syncthreads();
 	stamp(3);
 	if (tid == 0 && s_err) atomicOr(a.slice_err + zi, s_err);
-	if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 8 + 4] = n_codes;
+	if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 16 + 4] = n_codes;
 }
 
 // ------------------------------------------------------------------------------
@@ -1344,15 +1351,15 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.slice_err = d.d_slice_err.p;
 	if (getenv("CKL_DECODE_DIAG")) {
 		DevBuf<unsigned long long> d_diag;
-		d_diag.ensure(static_cast<size_t>(ns) * 8);
-		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 64, s));
+		d_diag.ensure(static_cast<size_t>(ns) * 16);
+		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 128, s));
 		hipLaunchKernelGGL(k_decode_cracks<true>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, d_diag.p);
-		std::vector<unsigned long long> dg(static_cast<size_t>(ns) * 8);
+		std::vector<unsigned long long> dg(static_cast<size_t>(ns) * 16);
 		CKL_HIP(hipMemcpyAsync(dg.data(), d_diag.p, dg.size() * 8, hipMemcpyDeviceToHost, s));
 		CKL_HIP(hipStreamSynchronize(s));
-		double m[8] = { 0 };
-		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 8; k++) m[k] += static_cast<double>(dg[zi * 8 + k]) / ns;
-		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5]);
+		double m[16] = { 0 };
+		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
+		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f | match: depth/lastT=%.0f gmin=%.0f links=%.0f jump=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[8], m[9], m[10], m[11]);
 	}
 	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, static_cast<unsigned long long*>(nullptr));
 	st.done("k_decode_cracks");

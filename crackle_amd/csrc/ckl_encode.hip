@@ -1,10 +1,10 @@
 // Encode path: label volume resident in HBM -> .ckl bytes.
 // Replaces crackle::compress<LABEL> (src/crackle.hpp:34-257) and what it calls:
 //   lib::max_label / pixel_pairs                    src/lib.hpp:224-256        k_stats
-//   crackcodes::Graph::init                         src/crackcodes.hpp:66-125  k_label_planes + k_crack_graph
+//   crackcodes::Graph::init                         src/crackcodes.hpp:66-125  k_label_planes + k_trail_graph (ckl_trail.hpp)
 //   create_crack_codes walk + remove_initial_branch +
 //     remove_spurious_branches + symbols_to_codepoints
-//                                                   src/crackcodes.hpp:128-281, 374-453  k_walk
+//                                                   src/crackcodes.hpp:128-281, 374-453  k_trail_* (ckl_trail.hpp)
 //   pack_codepoints / write_boc_index               src/crackcodes.hpp:318-372, 455-496  k_finish
 //   markov::gather_statistics / encode_markov       src/markov.hpp:193-220, 422-473      k_markov_hist / k_markov_pack
 //   cc3d::connected_components2d_4 + relabel        src/cc3d.hpp:114-144, 257-369        ckl_runs.hpp (runs of the label planes)
@@ -243,367 +243,7 @@ __global__ void __launch_bounds__(kBlock) k_planes_reduce(
 	}
 }
 
-// crack graph: one adjacency nibble per vertex of the (sx+1) x (sy+1) corner grid,
-// bit0 -> right, bit1 -> left, bit2 -> down, bit3 -> up (crackcodes.hpp:66-125).
-// An interior pixel pair carries a crack when its labels differ (IMPERMISSIBLE) or are
-// equal (PERMISSIBLE); image-border pairs never do.  grid = (ceil(nverts / 256), nslices)
-// The nibbles are stored in 32 x 32 vertex tiles of 1 KiB (row-major inside a tile, tiles
-// in raster order): the walk caches whole tiles in LDS, one 16-byte load per lane.
-constexpr uint32_t kTileShift = 5, kTileDim = 32, kTileBytes = 1024;
-constexpr uint32_t kTileMoves = 2 * kTileDim * (kTileDim + 1);   // edges that touch one tile: the most moves per residency
-__device__ __forceinline__ uint32_t tile_of(uint32_t x, uint32_t y, uint32_t tiles_x) { return (y >> kTileShift) * tiles_x + (x >> kTileShift); }
-__device__ __forceinline__ uint32_t tile_local(uint32_t x, uint32_t y) { return ((y & (kTileDim - 1)) << kTileShift) | (x & (kTileDim - 1)); }
-
-// ------------------------------------------------------------------------------
-// the walk: exact restatement of the reference's deterministic depth-first trail
-// (crackcodes.hpp:390-450), one wavefront per slice.  Lane 0 walks; the wavefront
-// keeps the tiles of the vertex grid the trail is moving through in LDS (4 direct-mapped
-// slots, write-back on eviction), so a step costs an LDS access instead of a dependent
-// round trip to L2/HBM, and cooperates on next_cluster (crackcodes.hpp:41-49).
-// Code points are produced directly, with the two clean-ups folded in:
-//   remove_initial_branch (185-242): decided at the first 't' of a chain;
-//   remove_spurious_branches (250-281): a 't' that directly follows a 't' deletes
-//     itself and the 'b' popped by its predecessor (tombstone 0xFF, compacted later).
-// ------------------------------------------------------------------------------
-struct WalkArgs {
-	uint8_t* adjt;            // tiled vertex nibbles (see tile_of / tile_local)
-	uint64_t adjt_stride;
-	uint32_t tiles_x, tiles_y;
-	int sx, sy;
-	const uint64_t* cbase;    // per slice: base into cp
-	const uint32_t* ccap;     // capacity of cp (codes)
-	const uint64_t* sbase;    // per slice: base into the branch stack
-	const uint32_t* scap;
-	const uint64_t* kbase;    // per slice: base into the chain table
-	const uint32_t* kcap;
-	uint8_t* cp;
-	uint32_t* stack_node;
-	uint32_t* stack_code;
-	uint32_t* chain_node;     // adjusted start vertex
-	uint32_t* chain_off;      // raw offset into cp
-	uint32_t* chain_clen;     // number of codes that survive compaction
-	uint32_t* n_chains;       // [nslices]
-	uint32_t* n_raw;          // [nslices]
-	uint32_t* n_valid;        // [nslices]
-	uint32_t* slice_err;
-	uint32_t dbg;             // DIAG builds only: bit0 skip code stores, bit1 skip stack stores (timing experiments)
-};
-
-enum : uint32_t { ENC_ERR_CAPACITY = 1u };
 enum : uint8_t { CODE_UP = 0, CODE_RIGHT = 1, CODE_DOWN = 2, CODE_LEFT = 3, CODE_NONE = 0xFE, CODE_TOMB = 0xFF };
-
-// DIAG builds add cycle stamps and counters (diagnostic only, never timed or shipped):
-// diag[zi*16 + {0 steps, 1 tile fills, 2 pops, 3 scan cycles, 4 fill cycles, 5 walk cycles, 6 total cycles, 7 realtime ticks (100 MHz)}]
-template <bool DIAG>
-__global__ void __launch_bounds__(kWave) k_walk(WalkArgs a, unsigned long long* __restrict__ diag) {
-	unsigned long long d_steps = 0, d_fills = 0, d_pops = 0, d_scan = 0, d_fill = 0, d_walk = 0, d_gen = 0, d_ngen = 0;
-	const unsigned long long d_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-	const unsigned long long d_r0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
-	constexpr uint32_t kSlots = 32;     // 8 x 4 tiles: a 256 x 128 vertex window, direct mapped
-	__shared__ __attribute__((aligned(16))) uint8_t s_tile[kSlots][kTileBytes];
-	__shared__ uint32_t s_tag[kSlots], s_dirty[kSlots];
-	const uint32_t zi = blockIdx.x;
-	const int lane = threadIdx.x;
-	uint8_t* adjt = a.adjt + zi * a.adjt_stride;
-	const uint32_t tiles_x = a.tiles_x;
-	const uint32_t sxe = a.sx + 1, sye = a.sy + 1;
-	uint8_t* cp = a.cp + a.cbase[zi];
-	const uint32_t cap = a.ccap[zi];
-	uint32_t* st_node = a.stack_node + a.sbase[zi];
-	uint32_t* st_code = a.stack_code + a.sbase[zi];
-	const uint32_t scap = a.scap[zi];
-	uint32_t* ch_node = a.chain_node + a.kbase[zi];
-	uint32_t* ch_off = a.chain_off + a.kbase[zi];
-	uint32_t* ch_clen = a.chain_clen + a.kbase[zi];
-	const uint32_t kcap = a.kcap[zi];
-
-	uint32_t scan_x = 0, scan_y = 0;                    // next_cluster resumes here (wave uniform)
-	uint32_t nraw = 0, nch = 0, nvalid = 0, err = 0;    // wave uniform
-	constexpr uint32_t kNoTile = 0xFFFFFFFFu;
-
-	for (;;) {
-		// ---- next_cluster: first vertex at or after (scan_x, scan_y) in raster order that
-		// still has edges.  Row y lives in tile row y >> 5: lane l reads the 32 bytes of that
-		// row inside tile l (tiles beyond 64 columns in further rounds).  All tiles are in
-		// global memory here (flushed below) and this CU's L1 was invalidated.
-		uint32_t found_x = 0, found_y = 0;
-		bool found = false;
-		const unsigned long long d_s0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-		for (uint32_t y = scan_y; y < sye && !found; y++) {
-			const uint32_t x_min = (y == scan_y) ? scan_x : 0u;
-			for (uint32_t t0 = 0; t0 < tiles_x && !found; t0 += kWave) {
-				const uint32_t tx = t0 + lane;
-				unsigned long long w[4] = { 0, 0, 0, 0 };
-				if (tx < tiles_x) {
-					const unsigned long long* src = reinterpret_cast<const unsigned long long*>(
-						adjt + static_cast<uint64_t>((y >> kTileShift) * tiles_x + tx) * kTileBytes + ((y & (kTileDim - 1)) << kTileShift));
-#pragma unroll
-					for (int q = 0; q < 4; q++) w[q] = src[q];
-				}
-				// first non-zero byte of my 32 whose x >= x_min
-				uint32_t my = 0xFFFFFFFFu;
-#pragma unroll
-				for (int q = 3; q >= 0; q--) {
-					unsigned long long v = w[q];
-					const uint32_t xq = tx * kTileDim + q * 8u;
-					if (xq + 8u <= x_min) v = 0;
-					else if (xq < x_min) v = (v >> (8u * (x_min - xq))) << (8u * (x_min - xq));
-					if (v) my = xq + ((__ffsll(static_cast<long long>(v)) - 1) >> 3);
-				}
-				const unsigned long long m = __ballot(my != 0xFFFFFFFFu);
-				if (m) {
-					const int first = __ffsll(static_cast<long long>(m)) - 1;
-					found_x = __builtin_amdgcn_readfirstlane(__shfl(my, first, kWave));   // provably uniform from here on
-					found_y = y;
-					found = true;
-				}
-			}
-		}
-		if (DIAG) d_scan += __builtin_amdgcn_s_memtime() - d_s0;
-		if (!found || found_x >= sxe) break;
-		const uint32_t start = found_y * sxe + found_x;
-
-		// ---- one chain.  The walker is wave-uniform: every lane carries the same scalar
-		// state (values that come from LDS or global memory pass through readfirstlane), so the
-		// control flow is scalar branches and SALU arithmetic; only stores are predicated on
-		// lane 0.  No closures, no indexed local arrays (both end up in scratch memory).
-		uint32_t node = start, sp = 0;
-		uint32_t nx = found_x, ny = found_y;       // coordinates of `node`
-		const uint32_t chain_begin = nraw;
-		uint32_t tomb = 0;
-		// flag word (plain integer bits: boolean variables would be kept as 64-bit lane masks)
-		//   F_FIRST  nothing emitted yet (symbol index 0)
-		//   F_PREVT  previous symbol is a live 't' that popped the 'b' whose codes sit at prev_t_b
-		//   F_RIB    chain began with 'b', no other 'b' and no 't' yet
-		constexpr uint32_t F_FIRST = 1u, F_PREVT = 2u, F_RIB = 4u;
-		uint32_t flags = F_FIRST;
-		uint32_t last_code = CODE_NONE;
-		uint32_t prev_t_b = 0;
-		uint32_t adjusted = start;
-		uint32_t pending_clear = 0;     // edge bit of `node` consumed by the move that led here
-		uint32_t done = 0;
-		uint32_t guard = 0;
-		const bool l0 = lane == 0;
-		const bool st_cp = l0 && !(DIAG && (a.dbg & 1u));     // lane 0 stores code points
-		const bool st_stk = l0 && !(DIAG && (a.dbg & 2u));    // lane 0 stores the branch stack
-
-		// tile cache: kSlots direct-mapped slots (tags / dirty flags in LDS)
-		if (lane < static_cast<int>(kSlots)) { s_tag[lane] = kNoTile; s_dirty[lane] = 0; }
-
-		for (;;) {
-			nx = __builtin_amdgcn_readfirstlane(nx); ny = __builtin_amdgcn_readfirstlane(ny);
-			node = __builtin_amdgcn_readfirstlane(node); sp = __builtin_amdgcn_readfirstlane(sp);
-			// -- make sure the tile of `node` is resident
-			const uint32_t tile = tile_of(nx, ny, tiles_x);
-			const uint32_t slot = ((nx >> kTileShift) & 7u) | (((ny >> kTileShift) & 3u) << 3);
-			const uint32_t cur = __builtin_amdgcn_readfirstlane(s_tag[slot]);
-			if (cur != tile) {
-				const unsigned long long d_f0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-				uint4* lds = reinterpret_cast<uint4*>(&s_tile[slot][0]) + lane;
-				if (cur != kNoTile && __builtin_amdgcn_readfirstlane(s_dirty[slot])) {
-					*(reinterpret_cast<uint4*>(adjt + static_cast<uint64_t>(cur) * kTileBytes) + lane) = *lds;
-				}
-				// L1-bypassing loads: a tile written back earlier must be read back as written
-				const unsigned long long* src = reinterpret_cast<const unsigned long long*>(adjt + static_cast<uint64_t>(tile) * kTileBytes) + lane * 2;
-				const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				uint4 v;
-				v.x = static_cast<uint32_t>(lo); v.y = static_cast<uint32_t>(lo >> 32);
-				v.z = static_cast<uint32_t>(hi); v.w = static_cast<uint32_t>(hi >> 32);
-				*lds = v;
-				if (l0) { s_tag[slot] = tile; s_dirty[slot] = 0; }
-				if (DIAG) { __builtin_amdgcn_s_waitcnt(0); d_fill += __builtin_amdgcn_s_memtime() - d_f0; d_fills++; }
-			}
-			if (l0) s_dirty[slot] = 1;
-			const unsigned long long d_w0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-
-			// -- walk for as long as the trail stays inside this tile.  `local` indexes the
-			// vertex inside the resident tile (5 bits of y, 5 bits of x).
-			uint8_t* tbase = &s_tile[slot][0];
-			const uint32_t tx0 = nx >> kTileShift, ty0 = ny >> kTileShift;
-			if (++guard > cap || nraw + kTileMoves > cap) { err |= ENC_ERR_CAPACITY; done = 1; break; }
-			uint32_t local = tile_local(nx, ny);
-			for (;;) {
-				// ---- fast run: while exactly one edge is left at the vertex the trail passes
-				// straight through.  Everything is wave uniform, so the stores need no lane
-				// predicate (all lanes write the same byte to the same address) and the loop is
-				// a handful of scalar instructions around one LDS read.  At most kTileMoves
-				// iterations per residency (each consumes an edge of the tile), which the
-				// capacity check above covers.
-				local = __builtin_amdgcn_readfirstlane(local);
-				pending_clear = __builtin_amdgcn_readfirstlane(pending_clear);
-				nraw = __builtin_amdgcn_readfirstlane(nraw);
-				uint32_t av, code = 0, k = 0, moved = 0, left_tile = 0;
-				for (;;) {
-					if (DIAG) d_steps++;
-					av = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tbase[local])) & ~pending_clear;
-					pending_clear = 0;
-					if (av == 0 || (av & (av - 1u)) != 0) break;
-					k = __ffs(av) - 1;
-					code = (0x0231u >> (4u * k)) & 3u;     // right->1, left->3, down->2, up->0
-					if (!(DIAG && (a.dbg & 1u))) cp[nraw] = static_cast<uint8_t>(code);
-					nraw++;
-					moved = 1;
-					tbase[local] = 0;
-					pending_clear = 1u << (k ^ 1u);
-					const uint32_t coord = (k & 2u) ? (local >> kTileShift) : (local & (kTileDim - 1));
-					if (coord == ((k & 1u) ? 0u : kTileDim - 1)) { left_tile = 1; break; }
-					const uint32_t delta = (k & 2u) ? kTileDim : 1u;
-					local = (k & 1u) ? local - delta : local + delta;
-				}
-				if (moved) { last_code = code; flags &= F_RIB; }
-				if (left_tile) {
-					// materialise the coordinates of the next vertex (in a neighbouring tile)
-					nx = (tx0 << kTileShift) + (local & (kTileDim - 1));
-					ny = (ty0 << kTileShift) + (local >> kTileShift);
-					if (k & 2u) ny = (k & 1u) ? ny - 1 : ny + 1; else nx = (k & 1u) ? nx - 1 : nx + 1;
-					node = ny * sxe + nx;
-					break;
-				}
-				last_code = __builtin_amdgcn_readfirstlane(last_code);
-				flags = __builtin_amdgcn_readfirstlane(flags);
-				// ---- general path: dead end ('t') or branch vertex ('b' + move)
-				const unsigned long long d_g0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-				nx = (tx0 << kTileShift) + (local & (kTileDim - 1));
-				ny = (ty0 << kTileShift) + (local >> kTileShift);
-				node = ny * sxe + nx;
-				uint8_t* cell = tbase + local;
-				if (++guard > cap) { err |= ENC_ERR_CAPACITY; done = 1; break; }
-				if (av == 0) {
-					if (l0) *cell = 0;
-					// ---- 't': dead end.  Pop the most recent branch vertex (or finish).
-					if (sp == 0) { done = 1; break; }
-					sp--;
-					if (DIAG) d_pops++;
-					// vector (not scalar-cache) loads: the stack was written by lane 0's stores
-					const uint32_t pnode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_node + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-					const uint32_t pcode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_code + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-					if (flags & F_RIB) {
-						// remove_initial_branch (crackcodes.hpp:185-242): drop the leading 'b'
-						// and this 't', walk the first stretch backwards (reverse order,
-						// opposite directions) and start the chain where the stretch ended.
-						adjusted = node;
-						tomb += 2;
-						uint32_t lc = last_code;
-						if (l0) {
-							if (chain_begin + 1 < cap) { cp[chain_begin] = CODE_TOMB; cp[chain_begin + 1] = CODE_TOMB; }
-							const uint32_t hi_end = nraw < cap ? nraw : cap;
-							if (hi_end > chain_begin + 2) {
-								uint32_t lo = chain_begin + 2, hi = hi_end - 1;
-								while (lo < hi) {
-									const uint8_t x = cp[lo], y = cp[hi];
-									cp[lo] = y ^ 2; cp[hi] = x ^ 2;
-									lo++; hi--;
-								}
-								if (lo == hi) cp[lo] ^= 2;
-								lc = cp[hi_end - 1];
-							}
-						}
-						last_code = __builtin_amdgcn_readfirstlane(lc);
-						flags = 0;
-					}
-					else if (flags & F_PREVT) {
-						// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by
-						// the previous 't' and this 't' vanish
-						if (l0 && prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
-						tomb += 2;
-						prev_t_b = pcode;
-						flags = F_PREVT;
-					}
-					else {
-						// (DOWN,UP) unless the previous code is UP, then (RIGHT,LEFT)  (crackcodes.hpp:165-174)
-						const bool alt = (flags & F_FIRST) || last_code == CODE_NONE || last_code == CODE_UP;
-						const uint32_t c0 = alt ? CODE_RIGHT : CODE_DOWN, c1 = alt ? CODE_LEFT : CODE_UP;
-						if (nraw + 1 < cap) { if (st_cp) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); } }
-						else err |= ENC_ERR_CAPACITY;
-						nraw += 2;
-						last_code = c1;
-						flags = F_PREVT;
-						prev_t_b = pcode;
-					}
-					node = pnode;
-					ny = node / sxe; nx = node - ny * sxe;
-				}
-				else {
-					// ---- 'b': more than one edge left here, remember the vertex
-					const uint32_t was_first = flags & F_FIRST;
-					if (sp < scap) { if (st_stk) { st_node[sp] = node; st_code[sp] = nraw; } }
-					else err |= ENC_ERR_CAPACITY;
-					sp++;
-					// (UP,DOWN) unless the previous code is DOWN, then (LEFT,RIGHT)  (crackcodes.hpp:155-164)
-					const bool alt = was_first || last_code == CODE_NONE || last_code == CODE_DOWN;
-					const uint32_t c0 = alt ? CODE_LEFT : CODE_UP, c1 = alt ? CODE_RIGHT : CODE_DOWN;
-					// ---- then move along the lowest-numbered remaining edge: right, left, down, up
-					const uint32_t k = __ffs(av) - 1;
-					const uint32_t code = (0x0231u >> (4u * k)) & 3u;
-					if (nraw + 2 < cap) { if (st_cp) { cp[nraw] = static_cast<uint8_t>(c0); cp[nraw + 1] = static_cast<uint8_t>(c1); cp[nraw + 2] = static_cast<uint8_t>(code); } }
-					else { err |= ENC_ERR_CAPACITY; done = 1; }
-					nraw += 3;
-					last_code = code;
-					flags = was_first ? F_RIB : 0u;
-					if (l0) *cell = static_cast<uint8_t>(av & ~(1u << k));
-					const uint32_t step = (k & 2u) ? sxe : 1u;
-					if (k & 1u) { node -= step; if (k & 2u) ny--; else nx--; }
-					else { node += step; if (k & 2u) ny++; else nx++; }
-					pending_clear = 1u << (k ^ 1u);
-				}
-				if (DIAG) { d_gen += __builtin_amdgcn_s_memtime() - d_g0; d_ngen++; }
-				if (done || (nx >> kTileShift) != tx0 || (ny >> kTileShift) != ty0) break;
-				local = tile_local(nx, ny);
-			}
-			if (DIAG) d_walk += __builtin_amdgcn_s_memtime() - d_w0;
-			if (done) break;
-		}
-
-		// the closing 't' (branches_taken returns to 0, crackcodes.hpp:436-439)
-		if (flags & F_PREVT) {
-			if (l0 && prev_t_b + 1 < cap) { cp[prev_t_b] = CODE_TOMB; cp[prev_t_b + 1] = CODE_TOMB; }
-			tomb += 2;
-		}
-		else {
-			const bool alt = (flags & F_FIRST) || last_code == CODE_NONE || last_code == CODE_UP;
-			if (nraw + 1 < cap) { if (l0) { cp[nraw] = alt ? CODE_RIGHT : CODE_DOWN; cp[nraw + 1] = alt ? CODE_LEFT : CODE_UP; } }
-			else err |= ENC_ERR_CAPACITY;
-			nraw += 2;
-		}
-		if (nch < kcap) {
-			if (l0) {
-				ch_node[nch] = adjusted;
-				ch_off[nch] = chain_begin;
-				ch_clen[nch] = (nraw - chain_begin) - tomb;
-			}
-		}
-		else err |= ENC_ERR_CAPACITY;
-		nch++;
-		nvalid += (nraw - chain_begin) - tomb;
-
-		// ---- write the cached tiles back, make them visible to the scan
-		for (uint32_t slot = 0; slot < kSlots; slot++) {
-			const uint32_t t = __builtin_amdgcn_readfirstlane(s_tag[slot]);
-			if (t != kNoTile && __builtin_amdgcn_readfirstlane(s_dirty[slot])) {
-				*(reinterpret_cast<uint4*>(adjt + static_cast<uint64_t>(t) * kTileBytes) + lane) = *(reinterpret_cast<const uint4*>(&s_tile[slot][0]) + lane);
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		if (err) break;
-		// the start vertex is exhausted now: resume the scan right after it
-		scan_x = found_x + 1; scan_y = found_y;
-		if (scan_x >= sxe) { scan_x = 0; scan_y++; }
-	}
-	if (lane == 0) {
-		a.n_chains[zi] = nch;
-		a.n_raw[zi] = nraw;
-		a.n_valid[zi] = nvalid;
-		if (err) atomicOr(a.slice_err + zi, err);
-		if (DIAG && diag) {
-			unsigned long long* o = diag + static_cast<uint64_t>(zi) * 16;
-			o[0] = d_steps; o[1] = d_fills; o[2] = d_ngen; o[3] = d_scan; o[4] = d_fill; o[5] = d_walk; o[8] = d_gen; o[9] = d_pops;
-			o[6] = __builtin_amdgcn_s_memtime() - d_t0;
-			o[7] = __builtin_amdgcn_s_memrealtime() - d_r0;
-		}
-	}
-}
 
 // ------------------------------------------------------------------------------
 // k_finish: chain order, compaction, difference coding, 2-bit packing, BOC index
@@ -1062,7 +702,7 @@ struct ckl_encoder {
 	int dtype_bytes = 0;
 
 	DevBuf<unsigned long long> d_stats;
-	DevBuf<uint8_t> d_adjt;
+	DevBuf<uint4> d_adjm;                        // crack graph in micro-tiles (ckl_trail.hpp)
 	DevBuf<uint32_t> d_slice_err;
 	DevBuf<uint64_t> d_cbase, d_sbase, d_kbase, d_pbase, d_bbase, d_out_off, d_comp_off;
 	DevBuf<uint32_t> d_ccap, d_scap, d_kcap;
@@ -1094,8 +734,9 @@ struct ckl_encoder {
 	DevBuf<uint32_t> d_plane_partial, t_blk_special, t_blk_corner;
 	DevBuf<unsigned long long> d_plane_partial_max, d_plane_out;
 	uint32_t graph_blocks = 0;
-	uint32_t tiles_x = 0, tiles_y = 0;
-	uint64_t adjt_stride = 0;
+	uint32_t tiles_x = 0, tiles_y = 0, mtx2 = 0;
+	uint64_t adjm_stride = 0;
+	bool graph_permissible = false;
 	DevBuf<uint64_t> t_nbase, t_cobase, t_ibase;
 	DevBuf<uint32_t> t_ncap, t_cocap, t_icap, t_max_steps;
 	DevBuf<uint32_t> t_counters;                 // n_nodes | n_snap | n_corners | n_starts | n_items, [nslices] each
@@ -1235,18 +876,22 @@ void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, in
 void graph_pass(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, bool permissible) {
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
-	e.tiles_x = static_cast<uint32_t>((sx + 1 + kTileDim - 1) / kTileDim);
-	e.tiles_y = static_cast<uint32_t>((sy + 1 + kTileDim - 1) / kTileDim);
-	e.adjt_stride = static_cast<uint64_t>(e.tiles_x) * e.tiles_y * kTileBytes;
-	e.d_adjt.ensure(e.adjt_stride * ns);
+	e.tiles_x = static_cast<uint32_t>((sx + 1 + kTrailTileDim - 1) / kTrailTileDim);
+	e.tiles_y = static_cast<uint32_t>((sy + 1 + kTrailTileDim - 1) / kTrailTileDim);
+	// micro-tiles of 8 x 8 vertices, 32 bytes (2 uint4) each, 2 x 2 of them per 128-byte line
+	const uint32_t mtx = static_cast<uint32_t>((sx + 1 + 7) / 8), mty = static_cast<uint32_t>((sy + 1 + 7) / 8);
+	e.mtx2 = (mtx + 1) / 2;
+	e.adjm_stride = static_cast<uint64_t>(e.mtx2) * ((mty + 1) / 2) * 4 * 2;      // uint4 per slice
+	e.d_adjm.ensure(e.adjm_stride * ns);
 	e.graph_blocks = (e.tiles_x * e.tiles_y + kGraphTiles - 1) / kGraphTiles;
 	e.t_blk_special.ensure(static_cast<size_t>(e.graph_blocks) * ns);
 	e.t_blk_corner.ensure(static_cast<size_t>(e.graph_blocks) * ns);
 	e.d_count_vh.ensure(4 * static_cast<size_t>(ns));
+	e.graph_permissible = permissible;
 	hipLaunchKernelGGL(k_trail_graph, dim3(e.graph_blocks, ns), dim3(kBlock), 0, s,
 		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
-		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, e.d_adjt.p, e.adjt_stride,
-		e.tiles_x, e.tiles_y, e.t_blk_special.p, e.t_blk_corner.p);
+		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, reinterpret_cast<uint32_t*>(e.d_adjm.p), e.adjm_stride * 4,
+		e.mtx2, e.tiles_x, e.tiles_y, e.t_blk_special.p, e.t_blk_corner.p);
 	hipLaunchKernelGGL(k_trail_count_scan, dim3(ns), dim3(kBlock), 0, s, e.t_blk_special.p, e.t_blk_corner.p, e.graph_blocks,
 		e.d_count_vh.p + 2 * static_cast<size_t>(ns), e.d_count_vh.p + 3 * static_cast<size_t>(ns));
 	std::vector<uint32_t> c = download(e.d_count_vh.p + 2 * static_cast<size_t>(ns), 2 * static_cast<size_t>(ns), s);
@@ -1271,13 +916,10 @@ void crack_pass(
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
-	const uint32_t tiles_x = e.tiles_x, tiles_y = e.tiles_y;
-	const uint64_t adjt_stride = e.adjt_stride;
 	e.d_slice_err.ensure(ns);
 	CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
 	// exact crack edge count per slice: interior pixel pairs that differ (or are equal)
 	const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
-	const bool walk_v1 = getenv("CKL_WALK_V1") != nullptr;
 
 	// capacities from the exact edge counts (codes <= 7 E, chains <= E, stack <= E)
 	std::vector<uint64_t> cbase(ns), sbase(ns), kbase(ns);
@@ -1291,15 +933,10 @@ void crack_pass(
 		const uint64_t differ = static_cast<uint64_t>(e.count_v[zi]) + e.count_h[zi];
 		const uint64_t E = permissible ? interior - differ : differ;
 		any = any || E > 0;
-		const uint64_t cc = 7 * E + 16 + 2 * kTileMoves;
+		const uint64_t cc = 7 * E + 16;
 		if (cc > 0xFFFFFFF0ull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: slice has too many crack edges");
 		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cc); ctot += cc;
 		max_steps[zi] = static_cast<uint32_t>(E + 1);
-		if (walk_v1) {
-			sbase[zi] = stot; scap[zi] = static_cast<uint32_t>(E + 1); stot += E + 1;
-			kbase[zi] = ktot; kcap[zi] = static_cast<uint32_t>(E + 1); ktot += E + 1;
-			continue;
-		}
 		// trail graph: nodes = vertices of degree 1, 3, 4 plus at most one per "right+down" corner
 		// (loop starts, chain starts inside a segment); segments <= 2 nodes; items <= 3 segments + 1 per chain
 		const uint64_t nc = ((static_cast<uint64_t>(e.count_special[zi]) + e.count_corner[zi] + 16) / 16) * 16;
@@ -1327,31 +964,10 @@ void crack_pass(
 	e.d_n_chains.ensure(ns); e.d_n_raw.ensure(ns); e.d_n_valid.ensure(ns);
 	e.d_payload_len.ensure(ns); e.d_boc_len.ensure(ns);
 
+	unsigned long long* ta_dbg = nullptr;
+	DevBuf<unsigned long long> d_tdbg;
 	CKL_HIP(hipEventRecord(e.evk0, s));
-	if (walk_v1) {
-		WalkArgs wa;
-		wa.adjt = e.d_adjt.p; wa.adjt_stride = adjt_stride; wa.tiles_x = tiles_x; wa.tiles_y = tiles_y;
-		wa.sx = static_cast<int>(sx); wa.sy = static_cast<int>(sy);
-		wa.cbase = e.d_cbase.p; wa.ccap = e.d_ccap.p; wa.sbase = e.d_sbase.p; wa.scap = e.d_scap.p; wa.kbase = e.d_kbase.p; wa.kcap = e.d_kcap.p;
-		wa.cp = e.d_cp.p; wa.stack_node = e.d_stack_node.p; wa.stack_code = e.d_stack_code.p;
-		wa.chain_node = e.d_chain_node.p; wa.chain_off = e.d_chain_off.p; wa.chain_clen = e.d_chain_clen.p;
-		wa.n_chains = e.d_n_chains.p; wa.n_raw = e.d_n_raw.p; wa.n_valid = e.d_n_valid.p; wa.slice_err = e.d_slice_err.p;
-		wa.dbg = 0;
-		if (getenv("CKL_WALK_DIAG")) {
-			wa.dbg = static_cast<uint32_t>(atoi(getenv("CKL_WALK_DIAG"))) >> 4;     // CKL_WALK_DIAG=1: plain; 17: skip code stores; 33: skip stack stores
-			DevBuf<unsigned long long> d_diag;
-			d_diag.ensure(static_cast<size_t>(ns) * 16);
-			CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 128, s));
-			hipLaunchKernelGGL(k_walk<true>, dim3(ns), dim3(kWave), 0, s, wa, d_diag.p);
-			std::vector<unsigned long long> dg = download(d_diag.p, static_cast<size_t>(ns) * 16, s);
-			double m[16] = { 0 };
-			for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
-			fprintf(stderr, "[ckl walk diag, mean per slice] steps=%.0f fills=%.0f general=%.0f pops=%.0f scan_cyc=%.0f fill_cyc=%.0f walk_cyc=%.0f general_cyc=%.0f total_cyc=%.0f realtime_us=%.1f (clock %.2f GHz)\n",
-				m[0], m[1], m[2], m[9], m[3], m[4], m[5], m[8], m[6], m[7] / 100.0, m[6] / (m[7] * 10.0));
-		}
-		else hipLaunchKernelGGL(k_walk<false>, dim3(ns), dim3(kWave), 0, s, wa, static_cast<unsigned long long*>(nullptr));
-	}
-	else {
+	{
 		// ---- the trail over the node graph (ckl_trail.hpp)
 		upload(e.t_nbase, nbase, s); upload(e.t_ncap, ncap, s);
 		upload(e.t_cobase, cobase, s); upload(e.t_cocap, cocap, s);
@@ -1369,7 +985,9 @@ void crack_pass(
 		e.t_items.ensure(itot); e.t_item_off.ensure(itot); e.t_chain_item0.ensure(ktot);
 
 		TrailArgs ta;
-		ta.adjt = e.d_adjt.p; ta.adjt_stride = adjt_stride; ta.tiles_x = tiles_x; ta.tiles_y = tiles_y;
+		ta.adjm = e.d_adjm.p; ta.adjm_stride = e.adjm_stride; ta.mtx2 = e.mtx2; ta.tiles_x = e.tiles_x; ta.tiles_y = e.tiles_y;
+		ta.planeV = e.d_planes.p; ta.planeH = e.d_planes.p + e.plane_words * ns; ta.row_words = e.row_words; ta.plane_words = e.plane_words;
+		ta.sx = static_cast<uint32_t>(sx); ta.sy = static_cast<uint32_t>(sy); ta.inv = e.graph_permissible ? 0xFFFFFFFFu : 0u;
 		ta.sxe = static_cast<uint32_t>(sx + 1); ta.sye = static_cast<uint32_t>(sy + 1); ta.nverts = static_cast<uint32_t>(nverts);
 		ta.max_steps = e.t_max_steps.p;
 		ta.nbase = e.t_nbase.p; ta.ncap = e.t_ncap.p;
@@ -1387,11 +1005,13 @@ void crack_pass(
 		ta.n_chains = e.d_n_chains.p; ta.n_raw = e.d_n_raw.p; ta.n_valid = e.d_n_valid.p;
 		ta.cbase = e.d_cbase.p; ta.ccap = e.d_ccap.p; ta.cp = e.d_cp.p; ta.slice_err = e.d_slice_err.p;
 
+		ta.dbg = nullptr;
+		if (getenv("CKL_TRAIL_DIAG")) { d_tdbg.ensure(8); CKL_HIP(hipMemsetAsync(d_tdbg.p, 0, 64, s)); ta.dbg = d_tdbg.p; ta_dbg = d_tdbg.p; }
 		ta.graph_blocks = e.graph_blocks; ta.blk_special = e.t_blk_special.p; ta.blk_corner = e.t_blk_corner.p;
 		int max_lds = 0;
 		CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, e.device));
 		const size_t budget = static_cast<size_t>(max_lds > 1024 ? max_lds - 1024 : 0);
-		const uint32_t dart_blocks = (4 * max_ncap + kBlock - 1) / kBlock;
+		const uint32_t dart_blocks = (4 * max_ncap + kWalkChunk * kWaves - 1) / (kWalkChunk * kWaves);
 		if (any) {
 			hipLaunchKernelGGL(k_trail_nodes, dim3(e.graph_blocks, ns), dim3(kBlock), 0, s, ta);
 			hipLaunchKernelGGL(k_trail_segments, dim3(dart_blocks, ns), dim3(kBlock), 0, s, ta);
@@ -1411,16 +1031,22 @@ void crack_pass(
 		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_dfs), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
 		hipLaunchKernelGGL(k_trail_dfs, dim3(ns), dim3(kWave), lds, s, ta, static_cast<uint32_t>(lds));
 		hipLaunchKernelGGL(k_trail_offsets, dim3(ns), dim3(kBlock), 0, s, ta);
-		hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, ta);
+		hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kExpandChunk * kWaves - 1) / (kExpandChunk * kWaves), ns), dim3(kBlock), 0, s, ta);
 	}
 	CKL_HIP(hipEventRecord(e.evk1, s));
 	HT_MARK("c:enqueue");
-	if (!walk_v1 && getenv("CKL_TRAIL_DIAG")) {
+	if (getenv("CKL_TRAIL_DIAG")) {
 		std::vector<uint32_t> c = download(e.t_counters.p, 5 * static_cast<size_t>(ns), s);
 		double m[5] = { 0 };
 		for (int k = 0; k < 5; k++) for (uint32_t zi = 0; zi < ns; zi++) m[k] += static_cast<double>(c[static_cast<size_t>(k) * ns + zi]) / ns;
 		double sp = 0, co = 0;
 		for (uint32_t zi = 0; zi < ns; zi++) { sp += static_cast<double>(e.count_special[zi]) / ns; co += static_cast<double>(e.count_corner[zi]) / ns; }
+		if (ta_dbg) {
+			std::vector<unsigned long long> g = download(ta_dbg, 8, s);
+			fprintf(stderr, "[ckl trail diag, k_trail_segments] waves=%llu iterations/wave mean=%.1f max=%llu cycles/wave mean=%.0f max=%llu cycles/iteration=%.0f active lanes/iteration=%.1f\n",
+				g[4], g[4] ? static_cast<double>(g[0]) / g[4] : 0.0, g[1], g[4] ? static_cast<double>(g[2]) / g[4] : 0.0, g[3],
+				g[0] ? static_cast<double>(g[2]) / g[0] : 0.0, g[0] ? static_cast<double>(g[5]) / g[0] : 0.0);
+		}
 		fprintf(stderr, "[ckl trail diag, mean per slice] degree-1/3/4 vertices=%.0f corners=%.0f nodes=%.0f starts=%.0f items=%.0f\n", sp, co, m[0], m[3], m[4]);
 	}
 

@@ -35,9 +35,26 @@
 namespace ckl {
 namespace dev {
 
-constexpr uint32_t kTrailTileShift = 5, kTrailTileDim = 32, kTrailTileBytes = 1024;
-__device__ __forceinline__ uint32_t trail_tile_of(uint32_t x, uint32_t y, uint32_t tiles_x) { return (y >> kTrailTileShift) * tiles_x + (x >> kTrailTileShift); }
-__device__ __forceinline__ uint32_t trail_tile_local(uint32_t x, uint32_t y) { return ((y & (kTrailTileDim - 1)) << kTrailTileShift) | (x & (kTrailTileDim - 1)); }
+// The crack graph is stored in MICRO-TILES of 8 x 8 vertices, one nibble per vertex
+// (bit0 right, bit1 left, bit2 down, bit3 up): 32 bytes, dword r = row r, nibble i = vertex i
+// of the row.  Four micro-tiles (2 x 2) share one 128-byte line.  A walking lane keeps the
+// micro-tile it is in in registers and only goes to memory when it leaves it: the walks are
+// bound by cache-line traffic, not arithmetic, and this serves ~6 steps per fetch.
+constexpr uint32_t kTrailTileShift = 5, kTrailTileDim = 32;        // thread mapping of k_trail_graph / k_trail_nodes: one thread per 32-vertex row piece
+__device__ __forceinline__ uint32_t mt_index(uint32_t mx, uint32_t my, uint32_t mtx2) {
+	return (((my >> 1) * mtx2 + (mx >> 1)) << 2) | ((my & 1u) << 1) | (mx & 1u);
+}
+struct MicroTile {
+	uint4 lo, hi;          // rows 0-3, rows 4-7
+	uint32_t mx, my;       // which micro-tile is cached (0xFFFFFFFF: none)
+	__device__ __forceinline__ bool holds(uint32_t x, uint32_t y) const { return (x >> 3) == mx && (y >> 3) == my; }
+	__device__ __forceinline__ uint32_t nib(uint32_t x, uint32_t y) const {
+		const uint32_t r = y & 7u;
+		const uint32_t a0 = (r & 1u) ? lo.y : lo.x, a1 = (r & 1u) ? lo.w : lo.z, a2 = (r & 1u) ? hi.y : hi.x, a3 = (r & 1u) ? hi.w : hi.z;
+		const uint32_t b0 = (r & 2u) ? a1 : a0, b1 = (r & 2u) ? a3 : a2;
+		return (((r & 4u) ? b1 : b0) >> ((x & 7u) * 4u)) & 15u;
+	}
+};
 
 enum : uint32_t { TRAIL_ERR_CAPACITY = 1u };
 constexpr uint32_t kDartNone = 0xFFFFFFFFu;
@@ -45,9 +62,15 @@ constexpr uint32_t kDartNone = 0xFFFFFFFFu;
 constexpr uint32_t kItemSeg = 0u << 30, kItemCtl = 1u << 30, kItemDead = 2u << 30, kItemMask = 3u << 30;
 
 struct TrailArgs {
-	const uint8_t* adjt;         // tiled vertex nibbles (bit0 right, bit1 left, bit2 down, bit3 up)
-	uint64_t adjt_stride;
-	uint32_t tiles_x, tiles_y;
+	const uint4* adjm;           // micro-tiles (2 x uint4 each), see mt_index
+	uint64_t adjm_stride;        // uint4 per slice
+	uint32_t mtx2;               // micro-tile column pairs per row
+	uint32_t tiles_x, tiles_y;   // 32 x 32 vertex tiles: thread mapping of k_trail_graph / k_trail_nodes
+	const uint32_t* planeV;      // crack planes (k_trail_nodes recomputes the vertex nibbles from them)
+	const uint32_t* planeH;
+	uint32_t row_words;
+	uint64_t plane_words;
+	uint32_t sx, sy, inv;
 	uint32_t sxe, sye;
 	uint32_t nverts;
 	const uint32_t* max_steps;   // [nslices] crack edges of the slice + 1
@@ -102,10 +125,13 @@ struct TrailArgs {
 	const uint32_t* ccap;
 	uint8_t* cp;
 	uint32_t* slice_err;
+	unsigned long long* dbg;     // diagnostics (nullable): [0] wave iterations, [1] max per wave, [2] cycles, [3] max cycles, [4] waves, [5] lane-steps
 };
 
-__device__ __forceinline__ uint32_t trail_nib(const uint8_t* adjt, uint32_t x, uint32_t y, uint32_t tiles_x) {
-	return adjt[static_cast<uint64_t>(trail_tile_of(x, y, tiles_x)) * kTrailTileBytes + trail_tile_local(x, y)];
+__device__ __forceinline__ void mt_load(MicroTile& c, const uint4* adjm, uint32_t x, uint32_t y, uint32_t mtx2) {
+	const uint4* p = adjm + static_cast<uint64_t>(mt_index(x >> 3, y >> 3, mtx2)) * 2u;
+	c.lo = p[0]; c.hi = p[1];
+	c.mx = x >> 3; c.my = y >> 3;
 }
 __device__ __forceinline__ void trail_step(uint32_t& x, uint32_t& y, uint32_t k) {
 	if (k & 2u) y = (k & 1u) ? y - 1u : y + 1u;
@@ -151,36 +177,45 @@ __device__ __forceinline__ uint32_t trail_special_mask(const TileRowBits& b) {
 	return (b.R | b.L | b.D | b.U) & ~deg2;
 }
 __device__ __forceinline__ uint32_t trail_corner_mask(const TileRowBits& b) { return b.R & b.D & ~b.L & ~b.U; }
-__device__ __forceinline__ uint32_t spread4(uint32_t nib4) { return (nib4 * 0x00204081u) & 0x01010101u; }     // bit k -> byte k
-__device__ __forceinline__ uint32_t gather4(uint32_t w) { return ((w & 0x01010101u) * 0x10204080u) >> 28; }   // byte k bit 0 -> bit k
+// bit i of an 8-bit mask -> bit 4 i
+__device__ __forceinline__ uint32_t spread8(uint32_t m) {
+	uint32_t x = (m | (m << 12)) & 0x000F000Fu;
+	x = (x | (x << 6)) & 0x03030303u;
+	x = (x | (x << 3)) & 0x11111111u;
+	return x;
+}
 
-constexpr uint32_t kGraphTiles = kBlock / kTrailTileDim;     // tiles per workgroup
+constexpr uint32_t kGraphTiles = kBlock / kTrailTileDim;     // 32 x 32 vertex tiles per workgroup
 
 // grid = (graph_blocks, nslices)
 static __global__ void __launch_bounds__(kBlock) k_trail_graph(
 	const uint32_t* __restrict__ planeV, const uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
-	uint32_t sx, uint32_t sy, uint32_t permissible, uint8_t* __restrict__ adjt, uint64_t adjt_stride,
-	uint32_t tiles_x, uint32_t tiles_y, uint32_t* __restrict__ blk_special, uint32_t* __restrict__ blk_corner
+	uint32_t sx, uint32_t sy, uint32_t permissible, uint32_t* __restrict__ adjm_words, uint64_t adjm_stride_words,
+	uint32_t mtx2, uint32_t tiles_x, uint32_t tiles_y, uint32_t* __restrict__ blk_special, uint32_t* __restrict__ blk_corner
 ) {
 	__shared__ uint32_t s_red[2 * kWaves];
 	const uint32_t zi = blockIdx.y;
 	const uint32_t tile = blockIdx.x * kGraphTiles + (threadIdx.x >> 5);
 	const uint32_t r = threadIdx.x & 31u;
+	const uint32_t mtx = (sx + 1u + 7u) >> 3, mty = (sy + 1u + 7u) >> 3;
 	uint32_t ns = 0, nc = 0;
 	if (tile < tiles_x * tiles_y) {
 		const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
 		const uint32_t y = (ty << kTrailTileShift) + r;
 		TileRowBits b = { 0, 0, 0, 0 };
 		if (y <= sy) b = trail_row_bits(planeV + zi * plane_words, planeH + zi * plane_words, row_words, sx, sy, tx, y, permissible ? 0xFFFFFFFFu : 0u);
-		uint4 o[2];
-		uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+		uint32_t* dst = adjm_words + zi * adjm_stride_words;
+		const uint32_t my = y >> 3;
+		if (my < mty) {
 #pragma unroll
-		for (uint32_t g = 0; g < 8; g++) {
-			ow[g] = spread4((b.R >> (4 * g)) & 15u) | (spread4((b.L >> (4 * g)) & 15u) << 1)
-				| (spread4((b.D >> (4 * g)) & 15u) << 2) | (spread4((b.U >> (4 * g)) & 15u) << 3);
+			for (uint32_t q = 0; q < 4; q++) {
+				const uint32_t mx = tx * 4u + q;
+				if (mx >= mtx) break;
+				const uint32_t w = spread8((b.R >> (8 * q)) & 255u) | (spread8((b.L >> (8 * q)) & 255u) << 1)
+					| (spread8((b.D >> (8 * q)) & 255u) << 2) | (spread8((b.U >> (8 * q)) & 255u) << 3);
+				dst[static_cast<uint64_t>(mt_index(mx, my, mtx2)) * 8u + (y & 7u)] = w;
+			}
 		}
-		uint4* dst = reinterpret_cast<uint4*>(adjt + zi * adjt_stride + static_cast<uint64_t>(tile) * kTrailTileBytes + r * 32u);
-		dst[0] = o[0]; dst[1] = o[1];
 		ns = __popc(trail_special_mask(b));
 		nc = __popc(trail_corner_mask(b));
 	}
@@ -228,16 +263,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_nodes(TrailArgs a) {
 	if (tile < a.tiles_x * a.tiles_y) {
 		const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
 		x0 = tx << kTrailTileShift; y = (ty << kTrailTileShift) + r;
-		if (y < a.sye) {
-			const uint4* src = reinterpret_cast<const uint4*>(a.adjt + zi * a.adjt_stride + static_cast<uint64_t>(tile) * kTrailTileBytes + r * 32u);
-			uint4 o[2] = { src[0], src[1] };
-			const uint32_t* ow = reinterpret_cast<const uint32_t*>(o);
-#pragma unroll
-			for (uint32_t g = 0; g < 8; g++) {
-				b.R |= gather4(ow[g]) << (4 * g); b.L |= gather4(ow[g] >> 1) << (4 * g);
-				b.D |= gather4(ow[g] >> 2) << (4 * g); b.U |= gather4(ow[g] >> 3) << (4 * g);
-			}
-		}
+		if (y <= a.sy) b = trail_row_bits(a.planeV + zi * a.plane_words, a.planeH + zi * a.plane_words, a.row_words, a.sx, a.sy, tx, y, a.inv);
 	}
 	const uint32_t ms = trail_special_mask(b), mc = trail_corner_mask(b);
 	uint32_t v[2] = { static_cast<uint32_t>(__popc(ms)), static_cast<uint32_t>(__popc(mc)) }, tot[2];
@@ -272,60 +298,133 @@ static __global__ void __launch_bounds__(kBlock) k_trail_nodes(TrailArgs a) {
 	}
 }
 
-// grid = (ceil(4 * max nodes / 256), nslices): one thread per (node, direction)
+// Segment walks have very uneven lengths (mean ~20 edges, long tail), so a lane that
+// finishes its segment takes the next one of its wavefront's range instead of idling
+// until the slowest lane is done: kWalkChunk darts (node * 4 + direction) per wavefront
+// (small: the walks are latency bound, so the chip wants many wavefronts in flight).
+constexpr uint32_t kWalkChunk = 192;       // darts per wavefront (k_trail_segments)
+constexpr uint32_t kExpandChunk = 384;     // items per wavefront (k_trail_expand)
+constexpr int kWalkRefill = 16;     // idle lanes that trigger a refill (its loads cost as much as a step)
+constexpr int kWalkAhead = 3;       // steps a lane may run ahead inside its micro-tile per memory round trip
+
+// Results are staged in LDS and written out once per wavefront: on this architecture loads
+// and stores retire in order on one counter, so a store inside the loop would make every
+// following step wait for it.
+// grid = (ceil(4 * max nodes / (kWalkChunk * 4)), nslices)
 static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
+	__shared__ uint4 s_res[kWaves][kWalkChunk];       // end, len, minv, minpos
 	const uint32_t zi = blockIdx.y;
-	const uint32_t d = blockIdx.x * kBlock + threadIdx.x;
-	const uint32_t j = d >> 2;
-	uint32_t k = d & 3u;
-	if (j >= min(a.n_nodes[zi], a.ncap[zi])) return;      // (k_trail_loops appends later, in its own launch)
+	const uint32_t lane = threadIdx.x & (kWave - 1);
+	const uint32_t wv = threadIdx.x >> 6;
+	const uint32_t wave = blockIdx.x * kWaves + wv;
+	const uint32_t n_darts = min(a.n_nodes[zi], a.ncap[zi]) * 4u;      // (k_trail_loops appends later, in its own launch)
+	const uint32_t range_begin = wave * kWalkChunk;
+	uint32_t next = range_begin;
+	const uint32_t range_end = min(next + kWalkChunk, n_darts);
+	if (next >= range_end) return;
 	const uint64_t nb = a.nbase[zi];
-	const uint64_t db = nb * 4u + d;
-	if (!((a.node_adj[nb + j] >> k) & 1u)) { a.dart_end[db] = kDartNone; a.dart_len[db] = 0; return; }
-	const uint8_t* adjt = a.adjt + zi * a.adjt_stride;
-	const uint32_t v0 = a.node_vertex[nb + j];
-	uint32_t y = v0 / a.sxe, x = v0 - y * a.sxe;
-	uint32_t minv = v0, minpos = 0, steps = 0, end = kDartNone;
+	const uint4* adjm = a.adjm + zi * a.adjm_stride;
+	const uint32_t* v2n = a.vert2node + static_cast<uint64_t>(zi) * a.nverts;
 	const uint32_t cap = a.max_steps[zi];
-	while (steps < cap) {
-		trail_step(x, y, k);
-		steps++;
-		const uint32_t w = y * a.sxe + x;
-		const uint32_t arr = k ^ 1u;
-		if (w < minv) { minv = w; minpos = (steps << 2) | arr; }
-		const uint32_t nib = trail_nib(adjt, x, y, a.tiles_x);
-		if (__popc(nib) != 2) { end = (a.vert2node[static_cast<uint64_t>(zi) * a.nverts + w] << 2) | arr; break; }
-		k = __ffs(nib & ~(1u << arr)) - 1;
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+	uint4* res = s_res[wv];
+	for (uint32_t i = lane; i < kWalkChunk; i += kWave) res[i] = make_uint4(kDartNone, 0u, 0u, 0u);
+	MicroTile c;
+	c.lo = c.hi = make_uint4(0, 0, 0, 0); c.mx = c.my = 0xFFFFFFFFu;
+	bool active = false;
+	// (x, y): the vertex to look at next, reached by a move in direction k after `steps` edges
+	uint32_t d = 0, x = 0, y = 0, k = 0, steps = 0, minv = 0, minpos = 0, err = 0;
+	unsigned long long dbg_iter = 0, dbg_lane = 0;
+	const unsigned long long dbg_t0 = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+	for (;;) {
+		if (a.dbg) { dbg_iter++; dbg_lane += __popcll(__ballot(active)); }
+		// One memory round trip per iteration: the loads of the lanes that take a new dart and
+		// the micro-tile loads of the lanes that left theirs are issued together, then consumed.
+		const unsigned long long need = __ballot(!active);
+		const bool refill = next < range_end && (__popcll(need) >= kWalkRefill || need == ~0ull);
+		const uint32_t cand = next + static_cast<uint32_t>(__popcll(need & lt_mask));
+		const bool take = refill && !active && cand < range_end;
+		uint32_t r_adj = 0, r_v0 = 0;
+		if (take) { r_adj = a.node_adj[nb + (cand >> 2)]; r_v0 = a.node_vertex[nb + (cand >> 2)]; }
+		if (active && !c.holds(x, y)) mt_load(c, adjm, x, y, a.mtx2);
+		// every lane runs ahead for as long as it stays inside its micro-tile
+		for (int it = 0; it < kWalkAhead; it++) {
+			const bool go = active && c.holds(x, y);
+			if (!__ballot(go)) break;
+			if (go) {
+				const uint32_t w = y * a.sxe + x;
+				const uint32_t arr = k ^ 1u;
+				if (w < minv) { minv = w; minpos = (steps << 2) | arr; }
+				const uint32_t nib = c.nib(x, y);
+				bool fin = false;
+				if (__popc(nib) != 2) fin = true;
+				else if (steps >= cap) { err = TRAIL_ERR_CAPACITY; fin = true; }
+				else { k = __ffs(nib & ~(1u << arr)) - 1; trail_step(x, y, k); steps++; }
+				if (fin) {
+					// x: end vertex << 2 | arrival edge (the vertex becomes a node index in the flush below)
+					res[d - range_begin] = make_uint4((w << 2) | arr, steps, minv, minpos);
+					active = false;
+				}
+			}
+		}
+		if (take && ((r_adj >> (cand & 3u)) & 1u)) {
+			d = cand; k = cand & 3u;
+			y = r_v0 / a.sxe; x = r_v0 - y * a.sxe;
+			minv = r_v0; minpos = 0;
+			trail_step(x, y, k);
+			steps = 1;
+			active = true;
+		}
+		if (refill) next += static_cast<uint32_t>(__popcll(need));
+		if (!__ballot(active) && next >= range_end) break;
 	}
-	if (end == kDartNone) atomicOr(a.slice_err + zi, TRAIL_ERR_CAPACITY);
-	a.dart_end[db] = end;
-	a.dart_len[db] = steps;
-	a.dart_minv[db] = minv;
-	a.dart_minpos[db] = minpos;
+	if (a.dbg && lane == 0) {
+		const unsigned long long cyc = __builtin_amdgcn_s_memtime() - dbg_t0;
+		atomicAdd(a.dbg + 0, dbg_iter); atomicMax(a.dbg + 1, dbg_iter);
+		atomicAdd(a.dbg + 2, cyc); atomicMax(a.dbg + 3, cyc);
+		atomicAdd(a.dbg + 4, 1ull); atomicAdd(a.dbg + 5, dbg_lane);
+	}
+	// (LDS accesses of one wavefront are ordered: no barrier needed for its own rows)
+	const uint64_t db = nb * 4u + range_begin;
+	for (uint32_t i = lane; i < range_end - range_begin; i += kWave) {
+		const uint4 r = res[i];
+		a.dart_end[db + i] = r.x == kDartNone ? kDartNone : ((v2n[r.x >> 2] << 2) | (r.x & 3u));
+		a.dart_len[db + i] = r.y;
+		a.dart_minv[db + i] = r.z;
+		a.dart_minpos[db + i] = r.w;
+	}
+	if (err) atomicOr(a.slice_err + zi, err);
 }
 
 // grid = (ceil(max corners / 256), nslices): a "right+down" corner is the start of a
 // closed loop when following the loop from it never meets a node or a smaller vertex
 static __global__ void __launch_bounds__(kBlock) k_trail_loops(TrailArgs a) {
 	const uint32_t zi = blockIdx.y;
-	const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t ci = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t nc = min(a.n_corners[zi], a.cocap[zi]);
-	if (c >= nc) return;
-	const uint8_t* adjt = a.adjt + zi * a.adjt_stride;
-	const uint32_t v0 = a.corner_vertex[a.cobase[zi] + c];
-	uint32_t y = v0 / a.sxe, x = v0 - y * a.sxe;
-	uint32_t k = 0, steps = 0;
+	const uint4* adjm = a.adjm + zi * a.adjm_stride;
 	const uint32_t cap = a.max_steps[zi];
+	bool active = ci < nc;
+	const uint32_t v0 = active ? a.corner_vertex[a.cobase[zi] + ci] : 0u;
+	uint32_t y = v0 / a.sxe, x = v0 - y * a.sxe;
+	uint32_t k = 0, steps = 1;
+	trail_step(x, y, k);
 	bool loop = false;
-	while (steps < cap) {
-		trail_step(x, y, k);
-		steps++;
-		const uint32_t w = y * a.sxe + x;
-		if (w == v0) { loop = true; break; }
-		if (w < v0) break;
-		const uint32_t nib = trail_nib(adjt, x, y, a.tiles_x);
-		if (__popc(nib) != 2) break;
-		k = __ffs(nib & ~(1u << (k ^ 1u))) - 1;
+	MicroTile c;
+	c.lo = c.hi = make_uint4(0, 0, 0, 0); c.mx = c.my = 0xFFFFFFFFu;
+	while (__ballot(active)) {
+		if (active && !c.holds(x, y)) mt_load(c, adjm, x, y, a.mtx2);
+		for (int it = 0; it < kWalkAhead; it++) {
+			const bool go = active && c.holds(x, y);
+			if (!__ballot(go)) break;
+			if (go) {
+				const uint32_t w = y * a.sxe + x;
+				const uint32_t nib = c.nib(x, y);
+				if (w == v0) { loop = true; active = false; }
+				else if (w < v0 || __popc(nib) != 2 || steps >= cap) active = false;
+				else { k = __ffs(nib & ~(1u << (k ^ 1u))) - 1; trail_step(x, y, k); steps++; }
+			}
+		}
 	}
 	if (!loop) return;
 	const uint32_t j = atomicAdd(a.n_nodes + zi, 1u);
@@ -772,30 +871,78 @@ static __global__ void __launch_bounds__(kBlock) k_trail_offsets(TrailArgs a) {
 	}
 }
 
-// grid = (ceil(max items / 256), nslices): one thread per item writes its code points
+// grid = (ceil(max items / (kExpandChunk * 4)), nslices): every item writes its code points;
+// segment items are re-walked, lanes refill from the wavefront's range like k_trail_segments
 static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
 	const uint32_t zi = blockIdx.y;
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= a.n_items[zi] || a.slice_err[zi]) return;
-	const uint32_t it = a.items[a.ibase[zi] + i];
-	const uint32_t kind = it & kItemMask;
-	if (kind == kItemDead) return;
-	uint8_t* cp = a.cp + a.cbase[zi] + a.item_off[a.ibase[zi] + i];
-	if (kind == kItemCtl) { cp[0] = static_cast<uint8_t>(it & 3u); cp[1] = static_cast<uint8_t>((it >> 2) & 3u); return; }
-	const uint32_t d = it & ~kItemMask;
+	if (a.slice_err[zi]) return;
+	const uint32_t lane = threadIdx.x & (kWave - 1);
+	const uint32_t wave = blockIdx.x * kWaves + (threadIdx.x >> 6);
+	const uint32_t n_items = a.n_items[zi];
+	uint32_t next = wave * kExpandChunk;
+	const uint32_t range_end = min(next + kExpandChunk, n_items);
+	if (next >= range_end) return;
 	const uint64_t nb = a.nbase[zi];
-	const uint32_t len = a.dart_len[nb * 4u + d];
-	const uint8_t* adjt = a.adjt + zi * a.adjt_stride;
-	const uint32_t v0 = a.node_vertex[nb + (d >> 2)];
-	uint32_t y = v0 / a.sxe, x = v0 - y * a.sxe;
-	uint32_t k = d & 3u;
-	for (uint32_t s = 0; s < len; s++) {
-		cp[s] = static_cast<uint8_t>(trail_code(k));
-		trail_step(x, y, k);
-		if (s + 1 < len) {
-			const uint32_t nib = trail_nib(adjt, x, y, a.tiles_x);
-			k = __ffs(nib & ~(1u << (k ^ 1u))) - 1;
+	const uint32_t* items = a.items + a.ibase[zi];
+	const uint32_t* item_off = a.item_off + a.ibase[zi];
+	uint8_t* cp0 = a.cp + a.cbase[zi];
+	const uint4* adjm = a.adjm + zi * a.adjm_stride;
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+	MicroTile c;
+	c.lo = c.hi = make_uint4(0, 0, 0, 0); c.mx = c.my = 0xFFFFFFFFu;
+	bool active = false, need_nib = false;
+	// at vertex (x, y); k: direction of the next move, or (need_nib) of the move that led here
+	uint32_t x = 0, y = 0, k = 0, left = 0, nacc = 0;
+	unsigned long long acc = 0;
+	uint8_t* cp = cp0;
+	for (;;) {
+		const unsigned long long need = __ballot(!active);
+		const bool refill = next < range_end && (__popcll(need) >= kWalkRefill || need == ~0ull);
+		const uint32_t cand = next + static_cast<uint32_t>(__popcll(need & lt_mask));
+		const bool take = refill && !active && cand < range_end;
+		uint32_t r_it = kItemDead, r_off = 0;
+		if (take) { r_it = items[cand]; r_off = item_off[cand]; }
+		if (active && need_nib && !c.holds(x, y)) mt_load(c, adjm, x, y, a.mtx2);
+		for (int it = 0; it < kWalkAhead; it++) {
+			const bool go = active && (!need_nib || c.holds(x, y));
+			if (!__ballot(go)) break;
+			if (go) {
+				if (need_nib) { k = __ffs(c.nib(x, y) & ~(1u << (k ^ 1u))) - 1; need_nib = false; }
+				// eight code points per (unaligned) 8-byte store
+				acc |= static_cast<unsigned long long>(trail_code(k)) << (8u * nacc);
+				nacc++;
+				trail_step(x, y, k);
+				--left;
+				if (nacc == 8u || left == 0) {
+					if (nacc == 8u) { struct __attribute__((packed)) U64 { unsigned long long v; }; reinterpret_cast<U64*>(cp)->v = acc; }
+					else for (uint32_t q = 0; q < nacc; q++) cp[q] = static_cast<uint8_t>(acc >> (8u * q));
+					cp += nacc; acc = 0; nacc = 0;
+				}
+				if (left == 0) active = false;
+				else need_nib = true;
+			}
 		}
+		if (take) {
+			const uint32_t kind = r_it & kItemMask;
+			if (kind == kItemCtl) {
+				uint8_t* o = cp0 + r_off;
+				o[0] = static_cast<uint8_t>(r_it & 3u); o[1] = static_cast<uint8_t>((r_it >> 2) & 3u);
+			}
+			else if (kind == kItemSeg) {
+				const uint32_t d = r_it & ~kItemMask;
+				left = a.dart_len[nb * 4u + d];
+				if (left) {
+					const uint32_t v0 = a.node_vertex[nb + (d >> 2)];
+					y = v0 / a.sxe; x = v0 - y * a.sxe;
+					k = d & 3u;
+					cp = cp0 + r_off;
+					need_nib = false;
+					active = true;
+				}
+			}
+		}
+		if (refill) next += static_cast<uint32_t>(__popcll(need));
+		if (!__ballot(active) && next >= range_end) break;
 	}
 }
 
