@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=3)
-  ap.add_argument("--warmup", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--shape", type=str, default="1024x1024x512", help="per-GPU slab, SXxSYxSZ")
   ap.add_argument("--dtype", type=str, default="uint32")
   ap.add_argument("--markov", type=int, default=0)

@@ -153,3 +153,44 @@ def test_device_resident_sessions_full_size_properties():
     torch.cuda.synchronize()
     assert torch.equal(back.view(torch.int32), vol.view(torch.int32))
   L.ckl_decoder_destroy(dec)
+
+
+def test_large_slices_and_dense_graphs(checker):
+  """Slices of the C4 shape (2048 x 2048: node tables of the trail near the LDS limit),
+  a PERMISSIBLE volume big enough to leave the LDS tables (dense crack graph, loops,
+  dead ends everywhere) and binary noise; bytes against the oracle."""
+  arr = synth.as_numpy_f(synth.voronoi_labels((2048, 2048, 3), np.uint32, seed=21, cell=(32, 32, 8)))
+  for kw in (dict(markov_model_order=0), dict(markov_model_order=5)):
+    want = checker.compress(arr, parallel=8, **kw)
+    assert crackle_amd.compress(arr, **kw) == want, f"2048x2048x3 {kw}"
+  assert np.array_equal(crackle_amd.decompress(want), arr)
+  small_cells = synth.as_numpy_f(synth.voronoi_labels((1024, 768, 2), np.uint16, seed=22, cell=(6, 6, 2)))
+  assert crackle_amd.compress(small_cells) == checker.compress(small_cells, parallel=8)
+  noise = synth.random_labels((512, 384, 2), np.uint32, seed=23, high=2000)
+  want = checker.compress(noise, parallel=8)
+  assert crackle_amd.compress(noise) == want
+  assert np.array_equal(crackle_amd.decompress(want), noise)
+  bits = synth.random_labels((640, 512, 2), np.uint8, seed=24, high=2)
+  for kw in (dict(), dict(markov_model_order=3)):
+    want = checker.compress(bits, parallel=8, **kw)
+    assert crackle_amd.compress(bits, **kw) == want, f"binary noise {kw}"
+  assert np.array_equal(crackle_amd.decompress(want), bits)
+
+
+@pytest.mark.parametrize("env", [{"CKL_TRAIL_LDS": "4096"}, {"CKL_PLANES_GENERIC": "1"}, {"CKL_NO_OVERLAP": "1"}])
+def test_encoder_fallback_paths(env, checker, monkeypatch):
+  """The encoder's alternate code paths (node tables / union-find in global memory instead
+  of LDS, the generic label-plane kernel, no stream overlap) produce the same bytes."""
+  for k, v in env.items():
+    monkeypatch.setenv(k, v)
+  arr = synth.as_numpy_f(synth.voronoi_labels((320, 288, 5), np.uint32, seed=31, cell=(16, 16, 4)))
+  for kw in (dict(markov_model_order=0), dict(markov_model_order=4), dict(allow_pins=1)):
+    okw = dict(kw)
+    if "allow_pins" in okw:
+      okw["allow_pins"] = True
+    assert crackle_amd.compress(arr, **kw) == checker.compress(arr, **okw), f"{env} {kw}"
+  noise = synth.random_labels((160, 144, 3), np.uint16, seed=32, high=300)
+  assert crackle_amd.compress(noise) == checker.compress(noise), f"{env} noise"
+  for name in ("c0_voronoi_u8", "c0_voronoi_u8_m5"):
+    arr8, kw8 = SMALL[name]
+    assert crackle_amd.compress(arr8, **_kw(kw8)) == golden()[name]
