@@ -20,9 +20,10 @@
 //                     exclusive prefix sum of break counts per 32-pixel word.
 //   k_run_union       union-find over RUNS (not pixels): vertically adjacent runs that
 //                     are connected through the horizontal-crack plane are united.
-//   k_run_resolve     roots ranked in raster order = the reference's component ids
+//   k_run_count/rank/assign  roots ranked in raster order = the reference's component ids
 //                     (cc3d.hpp:114-144); crc32c of the (never materialised) component
-//                     image accumulated per run from a geometric-sum table.
+//                     image accumulated per run from a geometric-sum table; flat labels
+//                     are applied to the runs in the same pass.
 //   k_label_map_*     component -> label tables (flat keys / pins)
 //   k_run_labels      run -> label
 //   k_paint_runs      streams the output: per 4 pixels one plane word, a popcount and a
@@ -138,16 +139,50 @@ struct CtlTables {
 };
 constexpr uint32_t kLinkNone = 0xFFFFFFFFu;
 
-// largest p < i with depth[p] < L, or -1 (groups of 64 are skipped through their minima)
-template <typename DEP>
-__device__ __forceinline__ int32_t prev_smaller(const DEP* depth, const DEP* gmin, int32_t i, int32_t L) {
-	int32_t p = i - 1;
-	while (p >= 0) {
-		const int32_t gs = p & ~63;
-		for (; p >= gs; p--) if (static_cast<int32_t>(depth[p]) < L) return p;
-		while (p >= 0 && static_cast<int32_t>(gmin[p >> 6]) >= L) p -= 64;
+// Which of the 8 consecutive values at p (16-byte aligned for the 16-bit tables) are < L.
+template <typename DEP> __device__ __forceinline__ uint32_t below_mask8(const DEP* p, int32_t L);
+template <> __device__ __forceinline__ uint32_t below_mask8<int16_t>(const int16_t* p, int32_t L) {
+	const uint4 q = *reinterpret_cast<const uint4*>(p);
+	const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+	uint32_t m = 0;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		m |= ((static_cast<int32_t>(w[k] << 16) >> 16) < L ? 1u : 0u) << (2 * k);
+		m |= ((static_cast<int32_t>(w[k]) >> 16) < L ? 1u : 0u) << (2 * k + 1);
 	}
-	return -1;
+	return m;
+}
+template <> __device__ __forceinline__ uint32_t below_mask8<int32_t>(const int32_t* p, int32_t L) {
+	uint32_t m = 0;
+#pragma unroll
+	for (int k = 0; k < 8; k++) m |= (p[k] < L ? 1u : 0u) << k;
+	return m;
+}
+
+// largest p < i with depth[p] < L, or -1: a tree of minima with fan-out 8 over depth[]
+// (level l entry g = min of the 8 entries 8g..8g+7 of level l-1; level 0 = depth).  One
+// 8-wide read per step; up to the first level whose block holds a smaller value, then down
+// again: at most 2 log8(N) steps for every lane (the lanes of a wavefront search very
+// different distances; a linear scan makes all of them wait for the farthest).
+// loff / lcnt: offset into gmin / number of entries of each level.
+template <typename DEP>
+__device__ __forceinline__ int32_t prev_smaller(const DEP* depth, const DEP* gmin, const uint32_t* loff, const uint32_t* lcnt, int32_t i, int32_t L, uint32_t* iters = nullptr) {
+	int32_t level = 0, idx = i - 1;
+	for (;;) {
+		if (idx < 0) return -1;
+		if (iters) (*iters)++;
+		const DEP* base = level == 0 ? depth : gmin + loff[level];
+		const int32_t blk = idx & ~7;
+		const uint32_t m = below_mask8<DEP>(base + blk, L) & ((2u << (idx & 7)) - 1u);
+		if (m) {
+			const int32_t e = blk + (31 - __clz(m));
+			if (level == 0) return e;
+			level--;
+			const int32_t last = static_cast<int32_t>(lcnt[level]) - 1;
+			idx = e * 8 + 7 < last ? e * 8 + 7 : last;
+		}
+		else { idx = (idx >> 3) - 1; level++; }
+	}
 }
 
 // Branch matching over the N control symbols of a slice, all threads of the workgroup
@@ -166,7 +201,7 @@ __device__ __forceinline__ int32_t prev_smaller(const DEP* depth, const DEP* gmi
 template <typename IDX, typename DEP>
 __device__ __forceinline__ void match_controls(
 	const CtlTables<IDX, DEP>& t, uint32_t N, const uint32_t* nodes, uint32_t n_nodes, uint32_t sxe, uint32_t nverts,
-	uint32_t* s_scan, int32_t* s_scanmax, uint32_t* s_first_dead, uint32_t* s_valid_segs, uint32_t& rerr,
+	uint32_t* s_scan, int32_t* s_scanmax, uint32_t* s_first_dead, uint32_t* s_valid_segs, uint32_t* s_loff, uint32_t* s_lcnt, uint32_t& rerr,
 	unsigned long long* dg = nullptr
 ) {
 	unsigned long long dg_t = dg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -227,18 +262,40 @@ __device__ __forceinline__ void match_controls(
 	}
 	__syncthreads();
 	sub(8);
-	const uint32_t ngroups = (N + 63u) / 64u;
-	for (uint32_t gi = tid; gi < ngroups; gi += kCrackBlock) {
-		int32_t mv = INT32_MAX;
-		const uint32_t e = min(N, gi * 64u + 64u);
-		for (uint32_t i = gi * 64u; i < e; i++) { const int32_t d = static_cast<int32_t>(t.depth[i]); mv = d < mv ? d : mv; }
-		t.gmin[gi] = static_cast<DEP>(mv > 32767 ? 32767 : mv);
+	// the tree of minima over depth[] (see prev_smaller)
+	if (tid == 0) {
+		uint32_t c = N, off = 0, l = 0;
+		s_lcnt[0] = N; s_loff[0] = 0;
+		while (c > 8u && l < 11u) {
+			c = (c + 7u) / 8u;
+			l++;
+			s_lcnt[l] = c; s_loff[l] = off;
+			off += (c + 7u) & ~7u;
+		}
+		s_lcnt[l + 1u] = 0;      // end marker
+	}
+	__syncthreads();
+	for (uint32_t l = 1; s_lcnt[l] != 0; l++) {
+		const uint32_t cnt = s_lcnt[l], below = s_lcnt[l - 1];
+		const DEP* src = l == 1 ? t.depth : t.gmin + s_loff[l - 1];
+		for (uint32_t gi = tid; gi < cnt; gi += kCrackBlock) {
+			int32_t mv = INT32_MAX;
+			const uint32_t e = min(below, gi * 8u + 8u);
+			for (uint32_t i = gi * 8u; i < e; i++) { const int32_t d = static_cast<int32_t>(src[i]); mv = d < mv ? d : mv; }
+			t.gmin[s_loff[l] + gi] = static_cast<DEP>(mv);
+		}
+		__syncthreads();
 	}
 	__syncthreads();
 	sub(9);
 	const uint32_t first_dead = *s_first_dead;
 	const uint32_t n_eff = min(N, first_dead);
 
+	uint32_t dg_iters = 0;
+	// 't's that return to a branch need a search whose length varies a lot and clusters (runs
+	// of pops): they go to a worklist (in the not yet used seg_x table) that is then dealt out
+	// evenly over the workgroup
+	uint32_t* worklist = t.seg_x;
 	{
 		int32_t sr = S0, m = M0;
 		uint32_t c = C0;
@@ -247,21 +304,31 @@ __device__ __forceinline__ void match_controls(
 			const int32_t before = sr - m;
 			sr += isT ? -1 : 1;
 			m = sr < m ? sr : m;
-			uint32_t val = 0, ptr = kLinkNone;
+			uint32_t val = 0;
 			if (isT && before == 0) c++;
 			if (isT && i < n_eff) {
 				if (before == 0) val = nodes[c];                    // next chain (c < n_nodes: i is before the pad)
-				else {
-					const uint32_t j = static_cast<uint32_t>(prev_smaller<DEP>(t.depth, t.gmin, static_cast<int32_t>(i), before) + 1);
-					const uint32_t pos_j = t.dx[j] + sxe * t.dy[j];
-					const IDX tp = t.lastT[j];
-					if (tp == NONE) val = nodes[0] + pos_j;
-					else { val = pos_j - (t.dx[tp] + sxe * t.dy[tp]); ptr = static_cast<uint32_t>(tp); }
-				}
+				else { worklist[atomicAdd(s_valid_segs, 1u)] = i; continue; }
 			}
-			t.link[i] = (static_cast<unsigned long long>(ptr) << 32) | val;
+			t.link[i] = (static_cast<unsigned long long>(kLinkNone) << 32) | val;
 		}
 	}
+	__syncthreads();
+	const uint32_t n_work = *s_valid_segs - 1u;      // the counter starts at 1 (its later meaning: valid segments)
+	for (uint32_t e = tid; e < n_work; e += kCrackBlock) {
+		const uint32_t i = worklist[1u + e];
+		const int32_t before = static_cast<int32_t>(t.depth[i]) + 1;      // a 't' that pops: depth after = depth before - 1
+		uint32_t val, ptr = kLinkNone;
+		const uint32_t j = static_cast<uint32_t>(prev_smaller<DEP>(t.depth, t.gmin, s_loff, s_lcnt, static_cast<int32_t>(i), before, dg ? &dg_iters : nullptr) + 1);
+		const uint32_t pos_j = t.dx[j] + sxe * t.dy[j];
+		const IDX tp = t.lastT[j];
+		if (tp == NONE) val = nodes[0] + pos_j;
+		else { val = pos_j - (t.dx[tp] + sxe * t.dy[tp]); ptr = static_cast<uint32_t>(tp); }
+		t.link[i] = (static_cast<unsigned long long>(ptr) << 32) | val;
+	}
+	__syncthreads();
+	if (tid == 0) *s_valid_segs = 1u;
+	if (dg) { atomicAdd(dg + 12, static_cast<unsigned long long>(dg_iters)); atomicMax(dg + 13, static_cast<unsigned long long>(dg_iters)); }
 	__syncthreads();
 	sub(10);
 	for (uint32_t i = i0; i < i1; i++) {
@@ -306,7 +373,7 @@ __device__ __forceinline__ void match_controls(
 static inline size_t crack_lds_seg_bytes(uint32_t n) { return (static_cast<size_t>(n) + 2) * 4 * 2; }
 static inline size_t crack_lds_bytes(uint32_t n) {
 	return crack_lds_seg_bytes(n) + static_cast<size_t>(n) * 8 + static_cast<size_t>(n) * 4 * 2
-		+ static_cast<size_t>(n) * 2 * 2 + (static_cast<size_t>(n) / 64 + 2) * 2 + n + 16;
+		+ static_cast<size_t>(n) * 2 * 2 + (static_cast<size_t>(n) / 7 + 48) * 2 + n + 16;
 }
 
 struct TileCarry {
@@ -501,12 +568,13 @@ __device__ __forceinline__ void raster_moves(
 // DIAG builds stamp the phase boundaries (diagnostic only): diag[zi*8 + {A, B, C, D}] cycles
 template <bool DIAG>
 __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsigned long long* __restrict__ diag) {
-	extern __shared__ unsigned long long s_dyn[];
+	extern __shared__ __attribute__((aligned(16))) unsigned long long s_dyn[];
 	__shared__ uint32_t s_scan[4 * kCrackWaves];
 	__shared__ int32_t s_scanmax[kCrackWaves];
 	__shared__ uint8_t s_last_move[kCrackBlock];
 	__shared__ uint8_t s_last_ctrl[kCrackBlock];
 	__shared__ uint32_t s_nnodes, s_ncodes, s_valid_segs, s_err, s_first_dead;
+	__shared__ uint32_t s_loff[14], s_lcnt[14];
 
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 	auto stamp = [&](int slot) {
@@ -638,7 +706,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		uint16_t* p2 = reinterpret_cast<uint16_t*>(p4);
 		lt.depth = reinterpret_cast<int16_t*>(p2); p2 += lcap;
 		lt.lastT = p2; p2 += lcap;
-		lt.gmin = reinterpret_cast<int16_t*>(p2); p2 += lcap / 64 + 2;
+		lt.gmin = reinterpret_cast<int16_t*>(p2); p2 += lcap / 7 + 48;
 		lt.kind = reinterpret_cast<uint8_t*>(p2);
 	}
 	const uint64_t kb = cb / 2u + 4ull * zi;
@@ -688,7 +756,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		// ---- branch matching
 		const uint32_t n_ctl = c.a;
 		if (n_ctl <= lcap) {
-			match_controls<uint16_t, int16_t>(lt, n_ctl, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, rerr, (DIAG && diag) ? diag + static_cast<uint64_t>(zi) * 16 : nullptr);
+			match_controls<uint16_t, int16_t>(lt, n_ctl, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, rerr, (DIAG && diag) ? diag + static_cast<uint64_t>(zi) * 16 : nullptr);
 			// pack seg_y right behind the used part of seg_x: the rest of the LDS becomes the band buffer
 			const uint32_t vs = s_valid_segs;
 			constexpr uint32_t kMoves = 8;
@@ -717,7 +785,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			for (uint32_t i = tid; i < lcap && i < n; i += kCrackBlock) { gt.kind[i] = lt.kind[i]; gt.dx[i] = lt.dx[i]; gt.dy[i] = lt.dy[i]; }
 			__syncthreads();
 			__threadfence_block();
-			match_controls<uint32_t, int32_t>(gt, n, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, rerr);
+			match_controls<uint32_t, int32_t>(gt, n, nodes, n_nodes, sxe, nverts, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, rerr);
 			__threadfence_block();
 		}
 		if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 16 + 5] = n_ctl;
@@ -966,7 +1034,7 @@ __global__ void __launch_bounds__(kBlock) k_check(
 using namespace ckl;
 
 namespace {
-constexpr int kMaxStages = 16;
+constexpr int kMaxStages = 20;
 }
 
 struct ckl_decoder {
@@ -1294,15 +1362,51 @@ struct StageTimer {
 	}
 };
 
+// component ids (ckl_runs.hpp), component -> label, run -> label, paint.  Flat labels: the
+// label table is ready before the components are, so k_run_assign writes the run labels
+// directly; pins need the component ids first (k_label_map_pins looks pixels up).
 template <typename OUT>
-void launch_labels_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays& ra, void* out_device, int has_label, uint64_t label, StageTimer& st) {
+void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays& ra, void* out_device, int has_label, uint64_t label, StageTimer& st) {
 	const Header& h = d.head;
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 	OUT* run_label = reinterpret_cast<OUT*>(d.d_run_label.p);
-	hipLaunchKernelGGL(k_run_labels<OUT>, dim3((d.max_rcap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s,
-		ra, d.d_label_map.p, d.d_comp_off.p, d.d_ncomp_expect.p, has_label ? 1u : 0u, label, run_label);
-	st.done("k_run_labels");
+	const uint64_t nlm = d.total_comp;
+	const bool flat = h.label_format == FLAT;
+	if (flat && nlm) {
+		const uint8_t* keys = d.d_stream.p + d.keys_offset + d.comp_left * static_cast<uint64_t>(d.key_width);
+		const uint8_t* uniq = d.d_stream.p + h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
+		hipLaunchKernelGGL(k_label_map_flat, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+			keys, d.key_width, uniq, h.stored_data_width, d.num_unique, h.is_signed ? 1u : 0u, nlm, d.d_label_map.p);
+	}
+	if (flat) st.done("k_label_map");
+	ResolveScratch rs;
+	rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
+	hipLaunchKernelGGL(k_run_count, dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs);
+	st.done("k_run_count");
+	hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
+	st.done("k_run_rank");
+	RunLabelArgs la;
+	la.label_map = d.d_label_map.p; la.comp_off = d.d_comp_off.p; la.ncomp_expect = d.d_ncomp_expect.p;
+	la.has_label = has_label ? 1u : 0u; la.label = label; la.run_label = run_label;
+	if (flat) {
+		hipLaunchKernelGGL((k_run_assign<OUT, true>), dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
+		st.done("k_run_assign");
+	}
+	else {
+		hipLaunchKernelGGL((k_run_assign<OUT, false>), dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
+		st.done("k_run_assign");
+		if (nlm) hipLaunchKernelGGL(k_fill_u64, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d.d_label_map.p, d.bgcolor, nlm);
+		if (d.n_ccl) hipLaunchKernelGGL(k_label_map_ccids, dim3(static_cast<uint32_t>((d.n_ccl + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+			d.d_ccl_id.p, d.d_ccl_label.p, d.n_ccl, d.comp_left, d.comp_left + nlm, d.d_label_map.p);
+		if (d.pin_total_work) hipLaunchKernelGGL(k_label_map_pins, dim3(static_cast<uint32_t>((d.pin_total_work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+			d.d_pin_index.p, d.d_pin_depth.p, d.d_pin_label.p, d.d_pin_work_off.p, d.n_pins, d.pin_total_work,
+			g, ra, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp_expect.p, d.d_label_map.p);
+		st.done("k_label_map");
+		hipLaunchKernelGGL(k_run_labels<OUT>, dim3((d.max_rcap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s,
+			ra, d.d_label_map.p, d.d_comp_off.p, d.d_ncomp_expect.p, has_label ? 1u : 0u, label, run_label);
+		st.done("k_run_labels");
+	}
 	const uint32_t tiles = static_cast<uint32_t>((d.sxy + kPaintTile - 1) / kPaintTile);
 	const bool fast = h.fortran_order && (h.sx % 4 == 0);
 	if (fast) hipLaunchKernelGGL((k_paint_runs<OUT, true>), dim3(tiles, ns), dim3(kBlock), 0, s, g, ra, run_label, reinterpret_cast<OUT*>(out_device), d.sxy, ns, 1u);
@@ -1359,7 +1463,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		CKL_HIP(hipStreamSynchronize(s));
 		double m[16] = { 0 };
 		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
-		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f | match: depth/lastT=%.0f gmin=%.0f links=%.0f jump=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[8], m[9], m[10], m[11]);
+		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f | match: depth/lastT=%.0f gmin=%.0f links=%.0f jump=%.0f search steps total=%.0f max/thread=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[8], m[9], m[10], m[11], m[12], m[13]);
 	}
 	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, static_cast<unsigned long long*>(nullptr));
 	st.done("k_decode_cracks");
@@ -1386,40 +1490,12 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 			hipLaunchKernelGGL(k_run_union_seams, dim3((words + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, g, ra, rows);
 		}
 		st.done("k_run_union_seams");
-		ResolveScratch rs;
-		rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
-		hipLaunchKernelGGL(k_run_flatten, dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs);
-		st.done("k_run_flatten");
-		hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
-		st.done("k_run_rank");
-		hipLaunchKernelGGL(k_run_assign, dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p);
-		st.done("k_run_assign");
 	}
 
-	// component -> label
-	const uint64_t nlm = d.total_comp;
-	if (h.label_format == FLAT) {
-		if (nlm) {
-			const uint8_t* keys = d.d_stream.p + d.keys_offset + d.comp_left * static_cast<uint64_t>(d.key_width);
-			const uint8_t* uniq = d.d_stream.p + h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
-			hipLaunchKernelGGL(k_label_map_flat, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-				keys, d.key_width, uniq, h.stored_data_width, d.num_unique, h.is_signed ? 1u : 0u, nlm, d.d_label_map.p);
-		}
-	}
-	else {
-		if (nlm) hipLaunchKernelGGL(k_fill_u64, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d.d_label_map.p, d.bgcolor, nlm);
-		if (d.n_ccl) hipLaunchKernelGGL(k_label_map_ccids, dim3(static_cast<uint32_t>((d.n_ccl + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-			d.d_ccl_id.p, d.d_ccl_label.p, d.n_ccl, d.comp_left, d.comp_left + nlm, d.d_label_map.p);
-		if (d.pin_total_work) hipLaunchKernelGGL(k_label_map_pins, dim3(static_cast<uint32_t>((d.pin_total_work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-			d.d_pin_index.p, d.d_pin_depth.p, d.d_pin_label.p, d.d_pin_work_off.p, d.n_pins, d.pin_total_work,
-			g, ra, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp_expect.p, d.d_label_map.p);
-	}
-	st.done("k_label_map");
-
-	if (has_label || h.data_width == 1) launch_labels_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
-	else if (h.data_width == 2) launch_labels_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
-	else if (h.data_width == 4) launch_labels_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
-	else launch_labels_and_paint<uint64_t>(d, g, ra, out_device, has_label, label, st);
+	if (has_label || h.data_width == 1) launch_resolve_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
+	else if (h.data_width == 2) launch_resolve_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
+	else if (h.data_width == 4) launch_resolve_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
+	else launch_resolve_and_paint<uint64_t>(d, g, ra, out_device, has_label, label, st);
 
 	hipLaunchKernelGGL(k_check, dim3((ns + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
 		d.d_crc_acc.p, d.d_crc_expect.p, d.d_ncomp.p, d.d_ncomp_expect.p,
@@ -1469,7 +1545,7 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 			CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
 			const size_t budget = static_cast<size_t>(max_lds > 4096 ? max_lds - 4096 : 0);   // static LDS of the kernel: ~2.4 KiB
 			uint32_t nctl = 5120;
-			if (const char* env = getenv("CKL_LDS_CONTROLS")) nctl = static_cast<uint32_t>(std::max(0, atoi(env)));   // testing: forces the global tables
+			if (const char* env = getenv("CKL_LDS_CONTROLS")) nctl = static_cast<uint32_t>(std::max(0, atoi(env))) & ~63u;   // testing: forces the global tables (multiples of 64: 16-byte aligned tables)
 			while (nctl > 64 && crack_lds_bytes(nctl) > budget) nctl -= 64;
 			if (crack_lds_bytes(nctl) > budget) nctl = 0;
 			if (nctl > 32000) nctl = 32000;

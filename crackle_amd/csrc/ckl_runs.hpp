@@ -298,8 +298,9 @@ struct ResolveScratch {
 	uint32_t nblk;             // blocks per slice = ceil(max run capacity / 256)
 };
 
-// step 1, grid = (nblk, nslices): flatten every run to its root, count the roots per block
-static __global__ void __launch_bounds__(kBlock) k_run_flatten(RunArrays r, ResolveScratch rs) {
+// step 1, grid = (nblk, nslices): count the roots per 256-run block (a root is its own
+// parent once all unions are in: no pointer chasing here)
+static __global__ void __launch_bounds__(kBlock) k_run_count(RunArrays r, ResolveScratch rs) {
 	__shared__ uint32_t s_scan[kWaves];
 	const uint32_t zi = blockIdx.y;
 	const uint32_t n = r.nruns[zi];
@@ -308,13 +309,8 @@ static __global__ void __launch_bounds__(kBlock) k_run_flatten(RunArrays r, Reso
 		if (threadIdx.x == 0) rs.blk_roots[zi * rs.nblk + blockIdx.x] = 0;
 		return;
 	}
-	uint32_t* parent = r.parent + r.rbase[zi];
-	uint32_t is_root = 0;
-	if (i < n) {
-		const uint32_t root = run_find(parent, i);
-		if (root != i) __hip_atomic_store(parent + i, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		is_root = (root == i);
-	}
+	const uint32_t* parent = r.parent + r.rbase[zi];
+	const uint32_t is_root = (i < n && parent[i] == i) ? 1u : 0u;
 	uint32_t v[1] = { is_root }, tot[1];
 	block_excl_add<1>(v, tot, s_scan);
 	if (is_root) rs.run_local[r.rbase[zi] + i] = static_cast<uint16_t>(v[0]);
@@ -346,8 +342,21 @@ static __global__ void __launch_bounds__(kBlock) k_run_rank(RunArrays r, Resolve
 	}
 }
 
-// step 3, grid = (nblk, nslices): component id of every run + its crc contribution
-static __global__ void __launch_bounds__(kBlock) k_run_assign(RunArrays r, ResolveScratch rs, const uint32_t* __restrict__ G, uint32_t n_pixels, uint32_t idbits_in, uint32_t* __restrict__ crc_acc) {
+// component -> label applied in the same pass (flat labels on decode): run_label is typed
+// like the output; has_label: 1 where the label matches
+struct RunLabelArgs {
+	const uint64_t* label_map;
+	const uint64_t* comp_off;
+	const uint32_t* ncomp_expect;
+	uint32_t has_label;
+	uint64_t label;
+	void* run_label;
+};
+
+// step 3, grid = (nblk, nslices): root (a short chain: strip root -> roots of the strips
+// above), component id of every run + its crc contribution [+ its label]
+template <typename OUT, bool LABELS>
+static __global__ void __launch_bounds__(kBlock) k_run_assign(RunArrays r, ResolveScratch rs, const uint32_t* __restrict__ G, uint32_t n_pixels, uint32_t idbits_in, uint32_t* __restrict__ crc_acc, RunLabelArgs la) {
 	__shared__ uint32_t s_scan[kWaves];
 	const uint32_t zi = blockIdx.y;
 	const uint32_t n = r.nruns[zi];
@@ -357,9 +366,18 @@ static __global__ void __launch_bounds__(kBlock) k_run_assign(RunArrays r, Resol
 	const uint32_t idbits = idbits_in ? idbits_in : (n > 1 ? 32u - __clz(n - 1) : 1u);
 	uint32_t part = 0;
 	if (i < n) {
-		const uint32_t root = r.parent[rb + i];
+		const uint32_t* parent = r.parent + rb;
+		uint32_t root = i, p = parent[i];
+		while (p != root) { root = p; p = parent[p]; }
 		const uint32_t cc = rs.blk_roots[zi * rs.nblk + (root >> 8)] + rs.run_local[rb + root];
-		r.run_cc[rb + i] = cc;
+		if (LABELS) {
+			uint64_t v = 0;
+			if (cc < la.ncomp_expect[zi]) v = la.label_map[la.comp_off[zi] + cc];
+			else atomicOr(r.slice_err + zi, ERR_NCOMP);
+			if (la.has_label) v = (v == la.label);
+			static_cast<OUT*>(la.run_label)[rb + i] = static_cast<OUT>(v);
+		}
+		else r.run_cc[rb + i] = cc;
 		const uint32_t a = r.run_start[rb + i];
 		const uint32_t b = (i + 1 < n) ? r.run_start[rb + i + 1] : n_pixels;
 		uint32_t wgt = G[n_pixels - a] ^ G[n_pixels - b];
@@ -373,12 +391,13 @@ static __global__ void __launch_bounds__(kBlock) k_run_assign(RunArrays r, Resol
 	if (threadIdx.x == 0 && part) atomicXor(crc_acc + zi, part);
 }
 
-// the three steps on one stream
+// the three steps on one stream (component ids only)
 static inline void launch_run_resolve(hipStream_t s, uint32_t nslices, const RunArrays& r, const ResolveScratch& rs, const uint32_t* G, uint32_t n_pixels, uint32_t idbits_in, uint32_t* crc_acc, uint32_t* idbits_out) {
 	static_assert(kBlock == 256, "run_local is indexed by root >> 8");
-	hipLaunchKernelGGL(k_run_flatten, dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs);
+	hipLaunchKernelGGL(k_run_count, dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs);
 	hipLaunchKernelGGL(k_run_rank, dim3(nslices), dim3(kBlock), 0, s, r, rs, idbits_in, crc_acc, idbits_out);
-	hipLaunchKernelGGL(k_run_assign, dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs, G, n_pixels, idbits_in, crc_acc);
+	RunLabelArgs none = {};
+	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs, G, n_pixels, idbits_in, crc_acc, none);
 }
 
 // G[k*B + i] = G[k*B] ^ x^(32 k B) * G[i]   (B = 1024; per-block constants from the host)
