@@ -124,11 +124,18 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (never for reported
+  # numbers): CKL_BENCH_REHEARSAL=1 maps the ranks onto the available devices and uses gloo
+  rehearsal = os.environ.get("CKL_BENCH_REHEARSAL") == "1"
+  n_dev = torch.cuda.device_count()
+  dev_index = (local_rank % max(n_dev, 1)) if (world > 1 and rehearsal) else (local_rank if world > 1 else 0)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-  dev_index = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+    if rehearsal:
+      dist.init_process_group(backend="gloo")
+    else:
+      dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{dev_index}"))
   dev = torch.device(f"cuda:{dev_index}")
   torch.cuda.set_device(dev)
   L = _lib.lib()
@@ -149,7 +156,8 @@ def main():
 
   # the stream stays in the library's pinned host buffer (no copy into a Python bytes object)
   backend = ckd.HipBackend(dev_index, zero_copy=True)
-  codec = ckd.ShardedCodec(backend, rank=rank, world=world, device=dev)
+  coll_dev = torch.device("cpu") if (world > 1 and rehearsal) else dev    # gloo: collectives on host tensors
+  codec = ckd.ShardedCodec(backend, rank=rank, world=world, device=coll_dev)
 
   def barrier():
     torch.cuda.synchronize()
@@ -189,7 +197,7 @@ def main():
 
   ok_local = bool(torch.equal(out.view(torch.uint8), vol.view(torch.uint8)))
   # max over ranks of the timed wall clock
-  t = torch.tensor([total_s, sum(enc_ms), sum(dec_ms), 0.0 if ok_local else 1.0], dtype=torch.float64, device=dev)
+  t = torch.tensor([total_s, sum(enc_ms), sum(dec_ms), 0.0 if ok_local else 1.0], dtype=torch.float64, device=coll_dev)
   if world > 1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   total_s, enc_sum_ms, dec_sum_ms, any_bad = (float(v) for v in t.tolist())

@@ -67,7 +67,7 @@ EXPORTS = {
     C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
     C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_zstack": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
-  "ckl_crc32c": (C.c_uint32, [C.c_char_p, C.c_uint64]),
+  "ckl_crc32c": (C.c_uint32, [C.c_void_p, C.c_uint64]),
 }
 
 _lib = None
@@ -132,7 +132,8 @@ class HostStream:
 
 
 def as_pointer(binary):
-  """(address-or-bytes, length) of a stream given as bytes or HostStream, for c_void_p arguments."""
-  if isinstance(binary, HostStream):
+  """(address-or-bytes, length) of a stream given as bytes, HostStream or any object with
+  .ptr / .n (distributed.SharedStream), for c_void_p arguments."""
+  if hasattr(binary, "ptr") and hasattr(binary, "n"):
     return binary.ptr, binary.n
   return binary, len(binary)

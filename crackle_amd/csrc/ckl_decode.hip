@@ -76,6 +76,7 @@ struct CrackArgs {
 	uint32_t lds_controls;       // capacity of the LDS control tables (dynamic LDS is sized for it)
 	uint32_t lds_words;          // dynamic LDS size in 4-byte words
 	uint32_t lds_raster;         // 1: planes are built in LDS bands and stored; 0: zeroed by the host, atomics on HBM
+	uint32_t markov_serial;      // testing: expand markov streams with one thread
 	uint32_t* slice_err;         // [nslices] sticky error bits
 };
 
@@ -565,6 +566,186 @@ __device__ __forceinline__ void raster_moves(
 	else if (cur_word) atomicOr(cur_word, cur_bits);
 }
 
+// ------------------------------------------------------------------------------
+// markov bitstream -> difference codes (markov.hpp:268-313), all threads of the workgroup
+// ------------------------------------------------------------------------------
+// The stream is a raw 2-bit start code followed by codes `0`, `10`, `110`, `111` (LSB first)
+// for the rank of each difference code under the order-N model; rank -> code needs the
+// previous N codes.  Two serial dependencies, both broken here:
+//   1. where codes start: a 3-state automaton over the bits (at a code start / after `1` /
+//      after `11`); every thread simulates its bit range from each state, a block scan
+//      composes the maps, then the ranks are written out by code index;
+//   2. the context recurrence: every thread decodes its chunk of codes speculatively,
+//      warming up over the kMarkovWarm codes before it from an arbitrary context (the
+//      context is the last N codes, so once N decoded codes are right the state is right);
+//      chunks whose assumed start context differs from their predecessor's end context
+//      are re-decoded, round by round, until all agree (at worst one chunk per round:
+//      the serial order; typically one or two rounds).
+struct BitMap3 { uint32_t e, c0, c1, c2; };      // end state per start state (2 bits each), code starts per start state
+__device__ __forceinline__ BitMap3 bitmap3_compose(const BitMap3& f, const BitMap3& g) {      // f first, then g
+	const uint32_t f0 = f.e & 3u, f1 = (f.e >> 2) & 3u, f2 = (f.e >> 4) & 3u;
+	BitMap3 r;
+	r.e = ((g.e >> (2u * f0)) & 3u) | (((g.e >> (2u * f1)) & 3u) << 2) | (((g.e >> (2u * f2)) & 3u) << 4);
+	r.c0 = f.c0 + (f0 == 0 ? g.c0 : (f0 == 1 ? g.c1 : g.c2));
+	r.c1 = f.c1 + (f1 == 0 ? g.c0 : (f1 == 1 ? g.c1 : g.c2));
+	r.c2 = f.c2 + (f2 == 0 ? g.c0 : (f2 == 1 ? g.c1 : g.c2));
+	return r;
+}
+constexpr uint32_t kMarkovWarm = 64;
+
+// lds: [payload words][rank words][model rows or nothing][2 x kCrackBlock context words]
+__device__ __forceinline__ uint32_t markov_lds_need(uint32_t nbytes, uint32_t cap, int order, uint32_t budget, bool& model_in_lds) {
+	const uint32_t pay = ((nbytes + 3u) / 4u + 2u) * 4u;
+	const uint32_t rnk = (cap / 16u + 2u) * 4u;
+	const uint32_t fix = 2u * kCrackBlock * 4u;
+	const uint64_t mdl = 4ull << (2 * order);
+	model_in_lds = order <= 8 && pay + rnk + fix + mdl <= budget;
+	return pay + rnk + fix + (model_in_lds ? static_cast<uint32_t>(mdl) : 0u);
+}
+
+__device__ __forceinline__ void markov_expand_parallel(
+	const uint8_t* __restrict__ s, uint32_t nbytes, int order, const uint8_t* __restrict__ model_g, uint32_t cap,
+	uint32_t* __restrict__ upacked, uint32_t* lds, bool model_in_lds, uint32_t* s_scan, uint32_t* s_total,
+	uint32_t& ncodes_out, uint32_t& err_out
+) {
+	const uint32_t tid = threadIdx.x;
+	const uint32_t pay_words = (nbytes + 3u) / 4u + 2u;
+	uint32_t* pay = lds;
+	uint32_t* ranks = pay + pay_words;
+	const uint32_t rank_words = cap / 16u + 2u;
+	uint32_t* rows_lds = ranks + rank_words;
+	const uint32_t n_rows = 1u << (2 * order);
+	uint32_t* ctx_in = rows_lds + (model_in_lds ? n_rows : 0u);
+	uint32_t* ctx_end = ctx_in + kCrackBlock;
+	const uint32_t* rows = model_in_lds ? rows_lds : reinterpret_cast<const uint32_t*>(model_g);
+
+	// ---- stage the payload (zero padded), clear the ranks, stage the model
+	for (uint32_t w = tid; w < pay_words; w += kCrackBlock) {
+		uint32_t v = 0;
+		for (uint32_t b = 0; b < 4u; b++) { const uint32_t i = w * 4u + b; if (i < nbytes) v |= static_cast<uint32_t>(s[i]) << (8u * b); }
+		pay[w] = v;
+	}
+	for (uint32_t w = tid; w < rank_words; w += kCrackBlock) ranks[w] = 0;
+	if (model_in_lds) for (uint32_t r = tid; r < n_rows; r += kCrackBlock) rows_lds[r] = reinterpret_cast<const uint32_t*>(model_g)[r];
+	__syncthreads();
+	auto bit = [&](uint32_t p) -> uint32_t { return (pay[p >> 5] >> (p & 31u)) & 1u; };      // bits past the end read 0
+
+	// ---- 1. code boundaries
+	const uint32_t B = nbytes * 8u;
+	const uint32_t Q = (B - 2u + kCrackBlock - 1u) / kCrackBlock;
+	const uint32_t lo = min(B, 2u + tid * Q), hi = min(B, lo + Q);
+	BitMap3 m;
+	{
+		uint32_t e[3], c[3];
+		// the three start states in one sweep over the bits (one LDS word per 32 bits)
+		uint32_t st0 = 0, st1 = 1, st2 = 2, n0 = 0, n1 = 0, n2 = 0;
+		uint32_t wc = pay[lo >> 5];
+		for (uint32_t p = lo; p < hi; p++) {
+			if ((p & 31u) == 0u) wc = pay[p >> 5];
+			const uint32_t b = (wc >> (p & 31u)) & 1u;
+			n0 += st0 == 0u ? 1u : 0u; n1 += st1 == 0u ? 1u : 0u; n2 += st2 == 0u ? 1u : 0u;
+			st0 = st0 == 2u ? 0u : (b ? st0 + 1u : 0u);
+			st1 = st1 == 2u ? 0u : (b ? st1 + 1u : 0u);
+			st2 = st2 == 2u ? 0u : (b ? st2 + 1u : 0u);
+		}
+		e[0] = st0; e[1] = st1; e[2] = st2; c[0] = n0; c[1] = n1; c[2] = n2;
+		m.e = e[0] | (e[1] << 2) | (e[2] << 4); m.c0 = c[0]; m.c1 = c[1]; m.c2 = c[2];
+	}
+	// inclusive scan of the maps inside the wavefront, wave totals through LDS
+	const uint32_t lane = tid & (kWave - 1), wave = tid >> 6;
+	BitMap3 inc = m;
+	for (uint32_t d = 1; d < static_cast<uint32_t>(kWave); d <<= 1) {
+		BitMap3 o;
+		o.e = __shfl_up(inc.e, d, kWave); o.c0 = __shfl_up(inc.c0, d, kWave); o.c1 = __shfl_up(inc.c1, d, kWave); o.c2 = __shfl_up(inc.c2, d, kWave);
+		if (lane >= d) inc = bitmap3_compose(o, inc);
+	}
+	if (lane == kWave - 1) { s_scan[wave * 4 + 0] = inc.e; s_scan[wave * 4 + 1] = inc.c0; s_scan[wave * 4 + 2] = inc.c1; s_scan[wave * 4 + 3] = inc.c2; }
+	BitMap3 exc;
+	exc.e = __shfl_up(inc.e, 1, kWave); exc.c0 = __shfl_up(inc.c0, 1, kWave); exc.c1 = __shfl_up(inc.c1, 1, kWave); exc.c2 = __shfl_up(inc.c2, 1, kWave);
+	if (lane == 0) { exc.e = 36u; exc.c0 = exc.c1 = exc.c2 = 0; }      // identity
+	__syncthreads();
+	BitMap3 pre = { 36u, 0, 0, 0 };
+	for (uint32_t w = 0; w < wave; w++) {
+		BitMap3 t = { s_scan[w * 4 + 0], s_scan[w * 4 + 1], s_scan[w * 4 + 2], s_scan[w * 4 + 3] };
+		pre = bitmap3_compose(pre, t);
+	}
+	const BitMap3 before = bitmap3_compose(pre, exc);
+	if (tid == kCrackBlock - 1) *s_total = 1u + bitmap3_compose(before, m).c0;      // + the raw start code
+	// ---- 2. ranks by code index (the stream starts at a code start)
+	{
+		uint32_t st = before.e & 3u;
+		uint32_t k = 1u + before.c0;          // index of the next code to start
+		uint32_t cur = 0;                      // index of the code in progress (valid when it started in my range)
+		bool mine = false;
+		uint32_t p = lo;
+		while (p < hi || (mine && st != 0u)) {
+			const uint32_t b = bit(p);
+			if (st == 0u) {
+				if (p >= hi) break;
+				cur = k++; mine = true;
+			}
+			uint32_t rank = 4u;
+			if (st == 2u) { rank = 2u + b; st = 0u; }
+			else if (b) st++;
+			else { rank = st; st = 0u; }
+			if (rank != 4u && mine) {
+				if (cur < cap) atomicOr(ranks + (cur >> 4), rank << (2u * (cur & 15u)));
+				mine = false;
+			}
+			p++;
+		}
+	}
+	__syncthreads();
+	uint32_t n = *s_total;
+	if (n > cap) { n = cap; err_out |= ERR_CAPACITY; }
+	ncodes_out = n;
+
+	// ---- 3. the context recurrence, speculatively per chunk
+	const int shift = 2 * (order - 1);
+	const uint32_t start = pay[0] & 3u;
+	uint32_t C = (n + kCrackBlock - 1u) / kCrackBlock;
+	C = max(16u, (C + 15u) & ~15u);
+	const uint32_t nchunks = (n + C - 1u) / C;
+	const uint32_t k0 = tid * C, k1 = min(n, k0 + C);
+	const bool have = tid < nchunks;
+	auto decode_chunk = [&](uint32_t ctx) -> uint32_t {      // codes max(k0, 1) .. k1-1 from context ctx; writes the words; returns the end context
+		uint32_t word = (k0 == 0u) ? start : 0u;
+		for (uint32_t k = max(k0, 1u); k < k1; k++) {
+			const uint32_t r = (ranks[k >> 4] >> (2u * (k & 15u))) & 3u;
+			const uint32_t v = (rows[ctx] >> (8u * r)) & 3u;
+			ctx = (ctx >> 2) + (v << shift);
+			word |= v << (2u * (k & 15u));
+			if ((k & 15u) == 15u) { upacked[k >> 4] = word; word = 0; }
+		}
+		if (k1 & 15u) upacked[k1 >> 4] = word;
+		else if (k1 == n) upacked[k1 >> 4] = 0u;
+		return ctx;
+	};
+	uint32_t my_in = start << shift;
+	if (have) {
+		if (k0 > 1u) {
+			const uint32_t kb = k0 > kMarkovWarm ? k0 - kMarkovWarm : 1u;
+			uint32_t ctx = kb == 1u ? (start << shift) : 0u;
+			for (uint32_t k = kb; k < k0; k++) {
+				const uint32_t r = (ranks[k >> 4] >> (2u * (k & 15u))) & 3u;
+				const uint32_t v = (rows[ctx] >> (8u * r)) & 3u;
+				ctx = (ctx >> 2) + (v << shift);
+			}
+			my_in = ctx;
+		}
+		ctx_in[tid] = my_in;
+		ctx_end[tid] = decode_chunk(my_in);
+	}
+	for (uint32_t round = 0; round <= nchunks; round++) {
+		__syncthreads();
+		const uint32_t want = (have && tid > 0u) ? ctx_end[tid - 1] : my_in;
+		const bool bad = have && tid > 0u && want != my_in;
+		if (!__syncthreads_or(bad ? 1 : 0)) break;
+		if (bad) { my_in = want; ctx_end[tid] = decode_chunk(my_in); }
+	}
+	__syncthreads();
+}
+
 // DIAG builds stamp the phase boundaries (diagnostic only): diag[zi*8 + {A, B, C, D}] cycles
 template <bool DIAG>
 __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsigned long long* __restrict__ diag) {
@@ -575,6 +756,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	__shared__ uint8_t s_last_ctrl[kCrackBlock];
 	__shared__ uint32_t s_nnodes, s_ncodes, s_valid_segs, s_err, s_first_dead;
 	__shared__ uint32_t s_loff[14], s_lcnt[14];
+	__shared__ uint32_t s_mk_parallel, s_mk_total, s_index_end;
 
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 	auto stamp = [&](int slot) {
@@ -600,6 +782,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 
 	// ---- phase A: beginning-of-chain index (crackcodes.hpp:283-316), serial ----
 	if (tid == 0) {
+		s_mk_parallel = 0;
 		uint32_t err = 0, nn = 0, ncodes = 0;
 		uint32_t index_end = 0;
 		if (code_len < 4u + a.yw) {
@@ -630,10 +813,15 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 					}
 				}
 			}
-			// ---- markov bitstream -> difference codes, 16 per word (markov.hpp:268-313), serial ----
+			// ---- markov bitstream -> difference codes, 16 per word (markov.hpp:268-313) ----
+			// all threads (markov_expand_parallel) when the slice's tables fit the LDS, else serially here
 			const uint32_t nbytes = code_len - index_end;
+			bool mdl_lds = false;
 			if (a.markov_order == 0) {
 				ncodes = nbytes * 4u;
+			}
+			else if (nbytes > 0 && !a.markov_serial && markov_lds_need(nbytes, cap, a.markov_order, a.lds_words * 4u, mdl_lds) <= a.lds_words * 4u) {
+				s_mk_parallel = 1u + (mdl_lds ? 1u : 0u);
 			}
 			else if (nbytes > 0) {
 				const uint8_t* s = code + index_end;
@@ -673,8 +861,17 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		s_err = err;
 		s_valid_segs = 1;
 		s_first_dead = 0xFFFFFFFFu;
+		s_index_end = index_end;
 	}
 	__syncthreads();
+	if (s_mk_parallel) {
+		uint32_t nc = 0, er = 0;
+		const uint32_t ie = s_index_end;
+		markov_expand_parallel(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), s_mk_parallel == 2u,
+			s_scan, &s_mk_total, nc, er);
+		if (tid == 0) { s_ncodes = nc; if (er) s_err |= er; }
+		__syncthreads();
+	}
 	if (a.markov_order) __threadfence_block();
 	stamp(0);
 	const uint32_t n_codes = s_ncodes;
@@ -1450,6 +1647,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.lds_controls = d.lds_controls;
 	ca.lds_words = static_cast<uint32_t>(crack_lds / 4);
 	ca.lds_raster = lds_raster ? 1u : 0u;
+	ca.markov_serial = getenv("CKL_MARKOV_SERIAL") ? 1u : 0u;
 	ca.planeV = d.d_planes.p; ca.planeH = d.d_planes.p + d.plane_words * ns;
 	ca.row_words = d.row_words; ca.plane_words = d.plane_words;
 	ca.slice_err = d.d_slice_err.p;

@@ -426,13 +426,24 @@ __device__ __forceinline__ uint32_t markov_ctx(const uint8_t* d, uint32_t g, int
 
 // gather_statistics (markov.hpp:193-220): stats[ctx][code]++ for every code of every
 // slice (the first code of a slice is counted in row 0).  grid = nslices.
+// LDS: the workgroup's own histogram (4^order x 4 counters) when it fits (order <= 6),
+// flushed once: the global counters see one atomic per non-zero row entry and workgroup
+// instead of one per run of equal codes.
 __global__ void __launch_bounds__(kBlock) k_markov_hist(
 	const uint8_t* __restrict__ dcode, const uint64_t* __restrict__ cbase, const uint32_t* __restrict__ n_valid,
-	int order, uint32_t* __restrict__ hist
+	int order, uint32_t* __restrict__ hist, uint32_t lds_entries
 ) {
+	extern __shared__ uint32_t s_hist[];
 	const uint32_t zi = blockIdx.x;
 	const uint8_t* d = dcode + cbase[zi];
 	const uint32_t n = n_valid[zi];
+	const uint32_t entries = 4u << (2 * order);
+	const bool local = entries <= lds_entries;
+	if (local) {
+		for (uint32_t i = threadIdx.x; i < entries; i += kBlock) s_hist[i] = 0;
+		__syncthreads();
+	}
+	uint32_t* target = local ? s_hist : hist;
 	constexpr uint32_t kPer = 32;
 	// each thread owns 32 consecutive codes and merges equal (row, code) neighbours
 	// before touching memory: straight crack runs collapse to one atomic
@@ -443,11 +454,15 @@ __global__ void __launch_bounds__(kBlock) k_markov_hist(
 			const uint32_t k = markov_ctx(d, g, order) * 4u + d[g];
 			if (k == key) cnt++;
 			else {
-				if (cnt) atomicAdd(hist + key, cnt);
+				if (cnt) atomicAdd(target + key, cnt);
 				key = k; cnt = 1;
 			}
 		}
-		if (cnt) atomicAdd(hist + key, cnt);
+		if (cnt) atomicAdd(target + key, cnt);
+	}
+	if (local) {
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < entries; i += kBlock) { const uint32_t v = s_hist[i]; if (v) atomicAdd(hist + i, v); }
 	}
 }
 
@@ -727,6 +742,10 @@ struct ckl_encoder {
 	DevBuf<uint32_t> d_slice_err2, d_n_uniq;
 	DevBuf<uint8_t> d_labels_bin;                // the flat label section, assembled on device
 	uint32_t flat_max_rcap = 0;
+	// label planes left by ckl_encoder_stats for the ckl_encoder_run that follows on the same
+	// volume (the sharded encoder: stats -> all-gather -> run with the agreed formats)
+	const void* planes_for = nullptr;
+	int64_t planes_dims[3] = { 0, 0, 0 };
 	std::vector<uint64_t> h_rbase;
 	std::vector<uint32_t> h_rcap;
 	// trail graph (ckl_trail.hpp)
@@ -1091,7 +1110,9 @@ void crack_pass(
 			const size_t rows = static_cast<size_t>(1) << (2 * markov_order);
 			e.d_hist.ensure(rows * 4);
 			CKL_HIP(hipMemsetAsync(e.d_hist.p, 0, rows * 4 * sizeof(uint32_t), s));
-			hipLaunchKernelGGL(k_markov_hist, dim3(ns), dim3(kBlock), 0, s, e.d_dcode.p, e.d_cbase.p, e.d_n_valid.p, markov_order, e.d_hist.p);
+			const uint32_t hist_lds = (rows * 4 <= 16384) ? static_cast<uint32_t>(rows * 4) : 0u;    // order <= 6: 64 KiB
+			if (hist_lds * 4 > 48 * 1024) CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_markov_hist), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(hist_lds * 4)));
+			hipLaunchKernelGGL(k_markov_hist, dim3(ns), dim3(kBlock), hist_lds * sizeof(uint32_t), s, e.d_dcode.p, e.d_cbase.p, e.d_n_valid.p, markov_order, e.d_hist.p, hist_lds);
 			std::vector<uint32_t> hist = download(e.d_hist.p, rows * 4, s);
 			if (hist_out) *hist_out = hist;
 			if (hist_only) {
@@ -1290,7 +1311,10 @@ void encode_typed(
 	HostTimer ht;
 	g_ht = &ht;
 	VolumeStats st;
-	if (voxels > 0) planes_pass<LABEL>(e, labels, sx, sy, sz, &st);
+	const bool planes_cached = ov && voxels > 0 && e.planes_for == static_cast<const void*>(labels)
+		&& e.planes_dims[0] == sx && e.planes_dims[1] == sy && e.planes_dims[2] == sz;
+	e.planes_for = nullptr;       // single use: the caller may change the volume afterwards
+	if (voxels > 0 && !planes_cached) planes_pass<LABEL>(e, labels, sx, sy, sz, &st);
 	ht.mark("planes");
 	int stored_width = byte_width(st.max_label);                     // crackle.hpp:233-235
 	if (ov && ov->force_stored_width) stored_width = ov->force_stored_width;
@@ -1509,10 +1533,22 @@ int ckl_encoder_stats(
 		wait_for_default_stream(e->stream2, e->ev_in);
 		const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
 		VolumeStats st;
-		if (e->dtype_bytes == 1) st = volume_stats<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), voxels);
-		else if (e->dtype_bytes == 2) st = volume_stats<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), voxels);
-		else if (e->dtype_bytes == 4) st = volume_stats<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), voxels);
-		else st = volume_stats<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), voxels);
+		e->planes_for = nullptr;
+		if (voxels > 0) {
+			// the label-plane pass yields max / pairs from the same read and leaves the planes for
+			// the ckl_encoder_run that follows
+			if (e->dtype_bytes == 1) planes_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz, &st);
+			else if (e->dtype_bytes == 2) planes_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz, &st);
+			else if (e->dtype_bytes == 4) planes_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz, &st);
+			else planes_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz, &st);
+			uint64_t f = 0, l = 0;
+			const uint8_t* base = static_cast<const uint8_t*>(labels_device);
+			CKL_HIP(hipMemcpy(&f, base, e->dtype_bytes, hipMemcpyDeviceToHost));
+			CKL_HIP(hipMemcpy(&l, base + (voxels - 1) * e->dtype_bytes, e->dtype_bytes, hipMemcpyDeviceToHost));
+			st.first = f; st.last = l;
+			e->planes_for = labels_device;
+			e->planes_dims[0] = sx; e->planes_dims[1] = sy; e->planes_dims[2] = sz;
+		}
 		if (max_label) *max_label = st.max_label;
 		if (pixel_pairs) *pixel_pairs = st.pairs;
 		if (first_voxel) *first_voxel = st.first;
@@ -1539,7 +1575,9 @@ int ckl_encoder_markov_stats(
 		if (static_cast<uint64_t>(sx) * sy * sz > 0) {
 			const bool perm = crack_format == PERMISSIBLE;
 			const int order = static_cast<int>(markov_model_order);
-			if (e->dtype_bytes == 1) planes_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz, nullptr);
+			const bool cached = e->planes_for == labels_device && e->planes_dims[0] == sx && e->planes_dims[1] == sy && e->planes_dims[2] == sz;
+			if (cached) {}
+			else if (e->dtype_bytes == 1) planes_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz, nullptr);
 			else if (e->dtype_bytes == 2) planes_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz, nullptr);
 			else if (e->dtype_bytes == 4) planes_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz, nullptr);
 			else planes_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz, nullptr);

@@ -65,6 +65,150 @@ def zstack(bufs: Sequence[bytes]) -> bytes:
     L.ckl_free(out)
 
 
+
+_W2DT = {1: "u1", 2: "<u2", 4: "<u4", 8: "<u8"}
+
+
+def _unpack(raw: np.ndarray, width: int, n: int) -> np.ndarray:
+  """n little-endian integers of `width` bytes -> int64 array."""
+  return np.frombuffer(raw, dtype=_W2DT[width], count=n).astype(np.int64)
+
+
+def _pack(values: np.ndarray, width: int) -> np.ndarray:
+  return np.ascontiguousarray(values.astype(_W2DT[width])).view(np.uint8).reshape(-1)
+
+
+def _crc8(data: bytes) -> int:
+  """crc.hpp:23-37: reflected, poly 0xe7, init 0xFF."""
+  crc = 0xFF
+  for b in data:
+    crc ^= b
+    for _ in range(8):
+      crc = ((crc >> 1) ^ 0xE7) if (crc & 1) else (crc >> 1)
+  return crc
+
+
+class _SlabSections:
+  """Views of the sections of one FLAT .ckl stream (header.hpp:284-297, labels.hpp:123-152)."""
+
+  def __init__(self, stream):
+    if isinstance(stream, _lib.HostStream):
+      a = np.frombuffer(stream.view(), dtype=np.uint8)
+    else:
+      a = np.frombuffer(stream, dtype=np.uint8)
+    info = _lib.HeaderInfo()
+    head = bytes(a[:64])
+    if _lib.lib().ckl_header_info_from_bytes(head, len(head), info) != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+    if info.label_format != FLAT or info.format_version != 1:
+      raise RuntimeError("sharded merge needs version-1 FLAT slab streams")
+    self.header = head[:29]
+    sx, sy, sz = int(info.sx), int(info.sy), int(info.sz)
+    self.sz = sz
+    self.stored_width = int(info.stored_data_width)
+    self.comp_width = _byte_width(sx * sy)
+    hb = 29
+    self.zidx = a[hb:hb + 4 * sz]
+    off = hb + 4 * (sz + 1)
+    nlb = int(info.num_label_bytes)
+    lab = a[off:off + nlb]
+    nu = int(np.frombuffer(lab[:8], dtype="<u8")[0])
+    sw, cw = self.stored_width, self.comp_width
+    self.uniq = _unpack(lab[8:8 + nu * sw], sw, nu)
+    self.comp = lab[8 + nu * sw: 8 + nu * sw + sz * cw]
+    ncomp = int(_unpack(self.comp, cw, sz).sum())
+    kw = _byte_width(nu)
+    k0 = 8 + nu * sw + sz * cw
+    self.keys = _unpack(lab[k0:k0 + ncomp * kw], kw, ncomp)
+    order = int(info.markov_model_order)
+    mb = 0 if order == 0 else ((4 ** order) * 5 + 4) // 8      # header.hpp:284-297
+    self.model = a[off + nlb: off + nlb + mb]
+    crack_bytes = int(np.frombuffer(self.zidx, dtype="<u4").astype(np.int64).sum())
+    c0 = off + nlb + mb
+    self.cracks = a[c0:c0 + crack_bytes]
+    self.crcs = a[len(a) - 4 * sz:]
+
+
+class SharedStream:
+  """The merged stream in the node-local shared mapping (rank 0's view): bytes-like through
+  .view() / bytes(); .ptr / .n for the C-ABI."""
+
+  def __init__(self, mm, n: int):
+    self._mm = mm
+    self.n = int(n)
+    self.ptr = C.addressof(C.c_ubyte.from_buffer(mm))
+
+  def __len__(self):
+    return self.n
+
+  def view(self) -> memoryview:
+    return memoryview(self._mm)[:self.n]
+
+  def tobytes(self) -> bytes:
+    return bytes(self.view())
+
+  __bytes__ = tobytes
+
+  def __eq__(self, other):
+    if isinstance(other, (bytes, bytearray, memoryview)):
+      return self.tobytes() == bytes(other)
+    if hasattr(other, "tobytes"):
+      return self.tobytes() == other.tobytes()
+    return NotImplemented
+
+
+class _SharedOutput:
+  """One file in /dev/shm mapped by every rank of the node: each rank writes its slab's
+  sections at their final offsets (the compressed bytes go device ->
+  host on every GPU's own link, not GPU <-> GPU).  Grows geometrically, reused across calls."""
+
+  def __init__(self, rank: int, world: int):
+    import mmap
+    import os
+    self._mmap, self._os = mmap, os
+    self.rank = rank
+    obj = [None]
+    if rank == 0:
+      obj[0] = f"/dev/shm/ckl_amd_{os.getpid()}_{id(self) & 0xFFFF:x}"
+    dist.broadcast_object_list(obj, src=0)
+    self.path = obj[0]
+    self.cap = 0
+    self.mm = None
+
+  def ensure(self, nbytes: int):
+    """Collective: every rank calls it with the same size."""
+    if nbytes <= self.cap:
+      return
+    if self.mm is not None:
+      self.mm.close()
+      self.mm = None
+    cap = max(1 << 20, int(nbytes * 1.5))
+    if self.rank == 0:
+      with open(self.path, "wb") as f:
+        f.truncate(cap)
+    dist.barrier()
+    with open(self.path, "r+b") as f:
+      self.mm = self._mmap.mmap(f.fileno(), cap)
+    self.cap = cap
+    dist.barrier()
+
+  def array(self) -> np.ndarray:
+    return np.frombuffer(self.mm, dtype=np.uint8)
+
+  def close(self):
+    try:
+      if self.mm is not None:
+        self.mm.close()
+        self.mm = None
+      if self.rank == 0 and self._os.path.exists(self.path):
+        self._os.unlink(self.path)
+    except Exception:
+      pass
+
+  def __del__(self):
+    self.close()
+
+
 class HipDecodeSession:
   def __init__(self, binary, z_start: int, z_end: int, device_index: int):
     self._L = _lib.lib()
@@ -204,6 +348,7 @@ class ShardedCodec:
     self.backend = backend
     self.rank, self.world = int(rank), int(world)
     self.device = torch.device(device)
+    self._shared = None     # node-local output mapping of the sharded encoder
 
   # -- encode -------------------------------------------------------------------
   def compress(self, vol, slab_shape, markov_model_order: int = 0, allow_pins: bool = False, fortran_order: bool = True) -> Optional[bytes]:
@@ -214,6 +359,16 @@ class ShardedCodec:
       return be.encode(vol, slab_shape, allow_pins, fortran_order, markov_model_order, None)
     if allow_pins:
       raise NotImplementedError("pins do not shard by z alone (SURVEY.md section 8e); encode on one GPU")
+
+    import os, time
+    prof = os.environ.get("CKL_PROFILE") is not None
+    marks = []
+    t_last = [time.perf_counter()]
+    def mark(name):
+      if prof:
+        now = time.perf_counter()
+        marks.append((name, (now - t_last[0]) * 1e3))
+        t_last[0] = now
 
     sx, sy, sz = slab_shape
     voxels_local = sx * sy * sz
@@ -231,6 +386,7 @@ class ShardedCodec:
     max_label = int(table[:, 1].max())
     crack_format = PERMISSIBLE if tot_pairs < tot_voxels // 2 else IMPERMISSIBLE   # crackle.hpp:50-55
     overrides = dict(crack_format=crack_format, label_format=FLAT, stored_width=_byte_width(max_label))
+    mark("stats+allgather")
 
     # 2. one markov model for all slabs
     order = int(markov_model_order)
@@ -244,22 +400,77 @@ class ShardedCodec:
       else:
         overrides["model"] = stats_to_model(hist).reshape(-1)
 
-    # 3. per-slab streams, gathered to rank 0 and merged
-    slab = bytes(be.encode(vol, slab_shape, False, fortran_order, order, overrides))
-    n_mine = torch.tensor([len(slab)], dtype=torch.int64, device=self.device)
-    sizes = [torch.empty_like(n_mine) for _ in range(self.world)]
-    dist.all_gather(sizes, n_mine)
-    sizes = [int(s.item()) for s in sizes]
-    cap = max(sizes)
-    buf = torch.zeros(cap, dtype=torch.uint8)
-    buf[:len(slab)] = torch.frombuffer(bytearray(slab), dtype=torch.uint8)
-    buf = buf.to(self.device)
-    gathered = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
-    dist.gather(buf, gathered, dst=0)
+    # 3. every rank encodes its slab and places the sections at their final offsets of one
+    #    node-local shared buffer.  Crack codes, z-index entries, component counts and crcs
+    #    are concatenated verbatim (crackle/operations.py:508-548); only the flat label keys
+    #    are re-keyed against the merged, sorted unique-label list (labels.hpp:92-152).
+    slab = be.encode(vol, slab_shape, False, fortran_order, order, overrides)
+    mark("encode")
+    sec = _SlabSections(slab)
+    dev = self.device
+    meta = torch.tensor([len(sec.uniq), len(sec.keys), len(sec.cracks), sec.sz], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(self.world)]
+    dist.all_gather(metas, meta)
+    table = torch.stack(metas).cpu().numpy()
+    max_u = int(table[:, 0].max())
+    mine_u = torch.zeros(max(max_u, 1), dtype=torch.int64, device=dev)
+    mine_u[:len(sec.uniq)] = torch.from_numpy(sec.uniq).to(dev)
+    all_u = [torch.empty_like(mine_u) for _ in range(self.world)]
+    dist.all_gather(all_u, mine_u)
+    merged = torch.unique(torch.cat([all_u[r][:int(table[r, 0])] for r in range(self.world)]))   # sorted
+    remap = torch.searchsorted(merged, mine_u[:len(sec.uniq)])
+    new_keys = remap[torch.from_numpy(sec.keys).to(dev)].cpu().numpy() if len(sec.keys) else np.zeros(0, np.int64)
+    uniq_g = merged.cpu().numpy()
+    mark("labels")
+
+    sw, cw = sec.stored_width, sec.comp_width
+    kw = _byte_width(len(uniq_g))
+    sz_tot = int(table[:, 3].sum())
+    n_keys = int(table[:, 1].sum())
+    label_bytes = 8 + len(uniq_g) * sw + sz_tot * cw + n_keys * kw
+    o_zidx = 29
+    o_labels = o_zidx + 4 * (sz_tot + 1)
+    o_comp = o_labels + 8 + len(uniq_g) * sw
+    o_keys = o_comp + sz_tot * cw
+    o_model = o_labels + label_bytes
+    o_cracks = o_model + len(sec.model)
+    o_tail = o_cracks + int(table[:, 2].sum())
+    total = o_tail + 4 * (sz_tot + 1)
+    z_before = int(table[:self.rank, 3].sum())
+    keys_before = int(table[:self.rank, 1].sum())
+    cracks_before = int(table[:self.rank, 2].sum())
+
+    if self._shared is None:
+      self._shared = _SharedOutput(self.rank, self.world)
+    self._shared.ensure(total)
+    out = self._shared.array()
+    out[o_zidx + 4 * z_before: o_zidx + 4 * (z_before + sec.sz)] = sec.zidx
+    out[o_comp + cw * z_before: o_comp + cw * (z_before + sec.sz)] = sec.comp
+    out[o_keys + kw * keys_before: o_keys + kw * (keys_before + len(new_keys))] = _pack(new_keys, kw)
+    out[o_cracks + cracks_before: o_cracks + cracks_before + len(sec.cracks)] = sec.cracks
+    out[o_tail + 4 + 4 * z_before: o_tail + 4 + 4 * (z_before + sec.sz)] = sec.crcs
+    if self.rank == 0:
+      out[o_labels:o_labels + 8] = np.frombuffer(np.array([len(uniq_g)], dtype="<u8").tobytes(), dtype=np.uint8)
+      out[o_labels + 8:o_comp] = _pack(uniq_g, sw)
+      out[o_model:o_cracks] = sec.model
+      head = bytearray(sec.header)
+      head[15:19] = int(sz_tot).to_bytes(4, "little")
+      head[20:28] = int(label_bytes).to_bytes(8, "little")
+      head[28] = _crc8(bytes(head[5:28]))
+      out[0:29] = np.frombuffer(bytes(head), dtype=np.uint8)
+    mark("place")
+    dist.barrier()
     if self.rank != 0:
       return None
-    slabs = [bytes(gathered[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(self.world)]
-    return zstack(slabs)
+    L = _lib.lib()
+    base = C.addressof(C.c_ubyte.from_buffer(self._shared.mm))
+    out[o_zidx + 4 * sz_tot: o_zidx + 4 * sz_tot + 4] = np.frombuffer(int(L.ckl_crc32c(base + o_zidx, 4 * sz_tot)).to_bytes(4, "little"), dtype=np.uint8)
+    out[o_tail:o_tail + 4] = np.frombuffer(int(L.ckl_crc32c(base + o_labels, label_bytes)).to_bytes(4, "little"), dtype=np.uint8)
+    mark("crc")
+    if prof:
+      import sys
+      print("[ckl sharded compress ms] " + " ".join(f"{n}={v:.2f}" for n, v in marks), file=sys.stderr)
+    return SharedStream(self._shared.mm, total)
 
   # -- decode -------------------------------------------------------------------
   def open_decoder(self, binary: Optional[bytes], slab_shape):

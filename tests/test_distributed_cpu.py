@@ -59,7 +59,7 @@ def _worker(rank, port, kind, order, q):
     session = codec.open_decoder(binary, (sx, sy, szl))
     back = np.zeros_like(slab)
     session.run(back)
-    q.put((rank, binary, bool(np.array_equal(back, slab))))
+    q.put((rank, None if binary is None else bytes(binary), bool(np.array_equal(back, slab))))
   finally:
     dist.destroy_process_group()
 
