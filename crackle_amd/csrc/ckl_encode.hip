@@ -1040,7 +1040,7 @@ void crack_pass(
 			if (const char* env = getenv("CKL_TRAIL_LDS")) clds = static_cast<size_t>(std::max(0, atoi(env)));
 			clds = (std::min(budget, std::max<size_t>(clds, 1024)) / 16) * 16;
 			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_components), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(clds)));
-			hipLaunchKernelGGL(k_trail_components, dim3(ns), dim3(kBlock), clds, s, ta, static_cast<uint32_t>(clds));
+			hipLaunchKernelGGL(k_trail_components, dim3(ns), dim3(kCompBlock), clds, s, ta, static_cast<uint32_t>(clds));
 		}
 		// node tables of k_trail_dfs in LDS: 9 bytes per node + 16 KiB of branch stack when that fits
 		size_t lds = (static_cast<size_t>(max_special) + 256) * 9 + 16384 + 1024;

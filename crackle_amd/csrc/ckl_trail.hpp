@@ -471,15 +471,17 @@ __device__ __forceinline__ void tuf_unite(uint32_t* L, uint32_t a, uint32_t b) {
 	}
 }
 
+constexpr int kCompBlock = 256;      // threads of k_trail_components (one workgroup per slice)
+
 template <bool LDS>
 __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint32_t zi, uint32_t* parent, uint32_t nn, uint32_t* s_scan) {
 	const uint64_t nb = a.nbase[zi];
 	const uint32_t* dart_end = a.dart_end + nb * 4u;
 	unsigned long long* compmin = a.compmin + nb;
-	for (uint32_t j = threadIdx.x; j < nn; j += kBlock) { parent[j] = j; compmin[j] = ~0ull; }
+	for (uint32_t j = threadIdx.x; j < nn; j += kCompBlock) { parent[j] = j; compmin[j] = ~0ull; }
 	__syncthreads();
 	if (!LDS) __threadfence();
-	for (uint32_t d = threadIdx.x; d < nn * 4u; d += kBlock) {
+	for (uint32_t d = threadIdx.x; d < nn * 4u; d += kCompBlock) {
 		const uint32_t e = dart_end[d];
 		if (e == kDartNone) continue;
 		const uint32_t j = d >> 2, j2 = e >> 2;
@@ -489,7 +491,7 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 	if (!LDS) __threadfence();
 	// smallest vertex of every component and a dart that saw it; lanes of a wavefront that
 	// share a root combine first (a slice usually has one giant component)
-	for (uint32_t d0 = 0; d0 < nn * 4u; d0 += kBlock) {
+	for (uint32_t d0 = 0; d0 < nn * 4u; d0 += kCompBlock) {
 		const uint32_t d = d0 + threadIdx.x;
 		uint32_t root = 0xFFFFFFFFu;
 		unsigned long long val = ~0ull;
@@ -517,7 +519,7 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 	// one thread per component root: mark the start vertex; a start inside a segment
 	// becomes a node of degree 2 (right + down) that splits the segment
 	uint32_t* bits = a.start_bits + static_cast<uint64_t>(zi) * a.start_words;
-	for (uint32_t j = threadIdx.x; j < nn; j += kBlock) {
+	for (uint32_t j = threadIdx.x; j < nn; j += kCompBlock) {
 		if (tuf_load<LDS>(parent, j) != j) continue;
 		const unsigned long long m = __hip_atomic_load(compmin + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (m == ~0ull) continue;
@@ -548,7 +550,7 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 	const uint32_t cap = a.kcap[zi];
 	constexpr uint32_t kPer = 8;
 	uint32_t carry = 0, err = 0;
-	for (uint32_t w0 = 0; w0 < a.start_words; w0 += kBlock * kPer) {
+	for (uint32_t w0 = 0; w0 < a.start_words; w0 += kCompBlock * kPer) {
 		uint32_t b[kPer], cnt = 0;
 #pragma unroll
 		for (uint32_t q = 0; q < kPer; q++) {
@@ -557,7 +559,7 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 			cnt += __popc(b[q]);
 		}
 		uint32_t v[1] = { cnt }, tot[1];
-		block_excl_add<1>(v, tot, s_scan);
+		block_excl_add<1, kCompBlock / kWave>(v, tot, s_scan);
 		uint32_t o = carry + v[0];
 #pragma unroll
 		for (uint32_t q = 0; q < kPer; q++) {
@@ -575,9 +577,9 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 }
 
 // grid = nslices; dynamic LDS = lds_bytes (the union-find table of slices that fit)
-static __global__ void __launch_bounds__(kBlock) k_trail_components(TrailArgs a, uint32_t lds_bytes) {
+static __global__ void __launch_bounds__(kCompBlock) k_trail_components(TrailArgs a, uint32_t lds_bytes) {
 	extern __shared__ uint32_t s_trail[];
-	__shared__ uint32_t s_scan[kWaves];
+	__shared__ uint32_t s_scan[kCompBlock / kWave];
 	const uint32_t zi = blockIdx.x;
 	const uint32_t nn = min(a.n_nodes[zi], a.ncap[zi]);
 	if (nn * 4u <= lds_bytes) trail_components_slice<true>(a, zi, s_trail, nn, s_scan);
@@ -662,12 +664,14 @@ __device__ __forceinline__ void trail_dfs_slice(
 	// Every lane carries the same state, so stores need no lane predicate: all lanes write
 	// the same value to the same address (one LDS / memory transaction).
 	uint32_t ni = 0, nch = 0, err = 0;
-	// last: code of the previous symbol's last code point, 4 = nothing emitted yet
+	// last: direction of the previous symbol's last code point as an EDGE BIT number
+	// (0 right, 1 left, 2 down, 3 up), 4 = nothing emitted yet.
 	// 'b' is (UP,DOWN) unless the previous code is DOWN (or there is none), then (LEFT,RIGHT);
 	// 't' is (DOWN,UP) unless the previous code is UP (or there is none), then (RIGHT,LEFT)   (crackcodes.hpp:155-174)
-	constexpr uint32_t kNone = 4u;
+	constexpr uint32_t kNone = 4u, kLeft = 1u, kDown = 2u, kUp = 3u;
 	constexpr uint32_t kB = kItemCtl | TCODE_UP | (TCODE_DOWN << 2), kBalt = kItemCtl | TCODE_LEFT | (TCODE_RIGHT << 2);
 	constexpr uint32_t kT = kItemCtl | TCODE_DOWN | (TCODE_UP << 2), kTalt = kItemCtl | TCODE_RIGHT | (TCODE_LEFT << 2);
+	struct __attribute__((packed, aligned(4))) Item2 { uint32_t a, b; };
 	for (uint32_t si = 0; si < n_starts; si++) {
 		const uint32_t sv = __builtin_amdgcn_readfirstlane(starts[si]);
 		uint32_t j = __builtin_amdgcn_readfirstlane(vert2node[sv]);
@@ -714,7 +718,7 @@ __device__ __forceinline__ void trail_dfs_slice(
 							}
 							if (lo == hi) items[lo] = kItemSeg | tab.get_end(items[lo] & ~kItemMask);
 							const uint32_t e = tab.get_end(items[ni - 1u] & ~kItemMask);
-							lc = trail_code((e & 3u) ^ 1u);
+							lc = (e & 3u) ^ 1u;
 						}
 					}
 					last = __builtin_amdgcn_readfirstlane(lc);
@@ -727,10 +731,10 @@ __device__ __forceinline__ void trail_dfs_slice(
 					prev_t_b = pitem;
 				}
 				else {
-					const bool alt = (last == kNone) || (last == TCODE_UP);
+					const bool alt = (last == kNone) || (last == kUp);
 					items[ni] = alt ? kTalt : kT;
 					ni++;
-					last = alt ? TCODE_LEFT : TCODE_UP;
+					last = alt ? kLeft : kUp;
 					prevt = 1;
 					prev_t_b = pitem;
 				}
@@ -738,33 +742,35 @@ __device__ __forceinline__ void trail_dfs_slice(
 				continue;
 			}
 			pend = 0;
-			if (av & (av - 1u)) {
-				// ---- 'b': more than one edge left, remember the vertex
-				if (sp < lds_stack_cap) s_stack2[l0 ? sp : lds_stack_cap + threadIdx.x] = make_uint2(j, ni);
-				else if (sp < scap) { if (l0) { st_node[sp] = j; st_item[sp] = ni; } }
-				else err |= TRAIL_ERR_CAPACITY;
-				sp++;
-				const bool alt = (last == kNone) || (last == TCODE_DOWN);
-				items[ni] = alt ? kBalt : kB;
-				ni++;
-				rib = (last == kNone) ? 1u : 0u;
-			}
-			prevt = 0;
 			// ---- along the lowest-numbered remaining edge: right, left, down, up
 			const uint32_t k = __ffs(av) - 1;
 			tab.set_adj(j, av & ~(1u << k), l0);
 			const uint32_t e = tab.pick(e_lo, e_hi, k);
-			items[ni] = kItemSeg | (j * 4u + k);
-			ni++;
+			const uint32_t seg = kItemSeg | (j * 4u + k);
+			if (av & (av - 1u)) {
+				// ---- 'b' first: more than one edge left, remember the vertex
+				if (sp < lds_stack_cap) s_stack2[l0 ? sp : lds_stack_cap + threadIdx.x] = make_uint2(j, ni);
+				else if (sp < scap) { if (l0) { st_node[sp] = j; st_item[sp] = ni; } }
+				else err |= TRAIL_ERR_CAPACITY;
+				sp++;
+				const bool alt = (last == kNone) || (last == kDown);
+				Item2 two;
+				two.a = alt ? kBalt : kB; two.b = seg;
+				*reinterpret_cast<Item2*>(items + ni) = two;        // both items in one store
+				ni += 2;
+				rib = (last == kNone) ? 1u : 0u;
+			}
+			else { items[ni] = seg; ni++; }
+			prevt = 0;
 			const uint32_t k2 = e & 3u;
-			last = trail_code(k2 ^ 1u);
+			last = k2 ^ 1u;
 			pend = 1u << k2;
 			j = e >> 2;
 		}
 		// the closing 't' (crackcodes.hpp:436-439)
 		if (prevt) items[prev_t_b] = kItemDead;
 		else {
-			const bool alt = (last == kNone) || (last == TCODE_UP);
+			const bool alt = (last == kNone) || (last == kUp);
 			if (ni < icap) items[ni] = alt ? kTalt : kT;
 			else err |= TRAIL_ERR_CAPACITY;
 			ni++;
