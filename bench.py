@@ -69,7 +69,11 @@ def pmc_traffic(kernel, workload_key):
       t = json.load(f)
     if t.get("workload") != workload_key:
       return None
-    return t["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+    for name, row in t["kernels"].items():
+      # decode kernels are instantiated for the output type: "k_paint_runs<u32, true>"
+      if name == kernel or (name.startswith(kernel + "<") and not name.endswith("false>")):
+        return row.get("hbm_bytes_per_launch")
+    return None
   except (OSError, ValueError, KeyError):
     return None
 

@@ -1025,7 +1025,7 @@ void crack_pass(
 		ta.cbase = e.d_cbase.p; ta.ccap = e.d_ccap.p; ta.cp = e.d_cp.p; ta.slice_err = e.d_slice_err.p;
 
 		ta.dbg = nullptr;
-		if (getenv("CKL_TRAIL_DIAG")) { d_tdbg.ensure(8); CKL_HIP(hipMemsetAsync(d_tdbg.p, 0, 64, s)); ta.dbg = d_tdbg.p; ta_dbg = d_tdbg.p; }
+		if (getenv("CKL_TRAIL_DIAG")) { d_tdbg.ensure(16); CKL_HIP(hipMemsetAsync(d_tdbg.p, 0, 128, s)); ta.dbg = d_tdbg.p; ta_dbg = d_tdbg.p; }
 		ta.graph_blocks = e.graph_blocks; ta.blk_special = e.t_blk_special.p; ta.blk_corner = e.t_blk_corner.p;
 		int max_lds = 0;
 		CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, e.device));
@@ -1061,7 +1061,9 @@ void crack_pass(
 		double sp = 0, co = 0;
 		for (uint32_t zi = 0; zi < ns; zi++) { sp += static_cast<double>(e.count_special[zi]) / ns; co += static_cast<double>(e.count_corner[zi]) / ns; }
 		if (ta_dbg) {
-			std::vector<unsigned long long> g = download(ta_dbg, 8, s);
+			std::vector<unsigned long long> g = download(ta_dbg, 16, s);
+			if (g[11]) fprintf(stderr, "[ckl trail diag, k_trail_dfs] slices=%llu iterations/slice=%.0f cycles/iteration=%.0f clock=%.2f GHz (cycles / 100 MHz ticks)\n",
+				g[11], static_cast<double>(g[8]) / g[11], g[8] ? static_cast<double>(g[9]) / g[8] : 0.0, g[10] ? static_cast<double>(g[9]) / (g[10] * 10.0) : 0.0);
 			fprintf(stderr, "[ckl trail diag, k_trail_segments] waves=%llu iterations/wave mean=%.1f max=%llu cycles/wave mean=%.0f max=%llu cycles/iteration=%.0f active lanes/iteration=%.1f\n",
 				g[4], g[4] ? static_cast<double>(g[0]) / g[4] : 0.0, g[1], g[4] ? static_cast<double>(g[2]) / g[4] : 0.0, g[3],
 				g[0] ? static_cast<double>(g[2]) / g[0] : 0.0, g[0] ? static_cast<double>(g[5]) / g[0] : 0.0);

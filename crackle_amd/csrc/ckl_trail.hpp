@@ -663,7 +663,9 @@ __device__ __forceinline__ void trail_dfs_slice(
 
 	// Every lane carries the same state, so stores need no lane predicate: all lanes write
 	// the same value to the same address (one LDS / memory transaction).
-	uint32_t ni = 0, nch = 0, err = 0;
+	uint32_t ni = 0, nch = 0, err = 0, dbg_iters = 0;
+	const unsigned long long dbg_t0 = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+	const unsigned long long dbg_r0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	// last: direction of the previous symbol's last code point as an EDGE BIT number
 	// (0 right, 1 left, 2 down, 3 up), 4 = nothing emitted yet.
 	// 'b' is (UP,DOWN) unless the previous code is DOWN (or there is none), then (LEFT,RIGHT);
@@ -682,6 +684,7 @@ __device__ __forceinline__ void trail_dfs_slice(
 		uint32_t pend = 0;         // edge of node j consumed by the move that led here
 		for (;;) {
 			if (ni + 4u > icap) { err |= TRAIL_ERR_CAPACITY; break; }
+			dbg_iters++;
 			uint32_t av_raw, e_lo, e_hi;
 			tab.load(j, av_raw, e_lo, e_hi);
 			const uint32_t av = av_raw & ~pend;
@@ -779,6 +782,12 @@ __device__ __forceinline__ void trail_dfs_slice(
 		else err |= TRAIL_ERR_CAPACITY;
 		nch++;
 		if (err) break;
+	}
+	if (l0 && a.dbg) {
+		atomicAdd(a.dbg + 8, static_cast<unsigned long long>(dbg_iters));
+		atomicAdd(a.dbg + 9, __builtin_amdgcn_s_memtime() - dbg_t0);
+		atomicAdd(a.dbg + 10, __builtin_amdgcn_s_memrealtime() - dbg_r0);
+		atomicAdd(a.dbg + 11, 1ull);
 	}
 	if (l0) {
 		a.n_items[zi] = ni < icap ? ni : icap;

@@ -45,7 +45,8 @@ def short(name):
   n = name.split("(")[0]
   for p in ("void ", "ckl::dev::", "ckl::"):
     n = n.replace(p, "")
-  return n.split("<")[0].strip()
+  # keep the template arguments: the encoder and the decoder instantiate some kernels differently
+  return n.replace("unsigned char", "u8").replace("unsigned short", "u16").replace("unsigned int", "u32").replace("unsigned long", "u64").strip()
 
 
 def main():
