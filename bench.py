@@ -36,6 +36,7 @@ def parse_args():
   ap.add_argument("--shape", type=str, default="1024x1024x512", help="per-GPU slab, SXxSYxSZ")
   ap.add_argument("--dtype", type=str, default="uint32")
   ap.add_argument("--markov", type=int, default=0)
+  ap.add_argument("--pins", type=int, default=0, help="allow_pins (parity / rehearsal runs; the metric is quoted on flat labels)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-sample-slices", type=int, default=128)
   return ap.parse_args()
@@ -178,7 +179,7 @@ def main():
     timed = step >= args.warmup
     barrier()
     t0 = time.perf_counter()
-    binary = codec.compress(vol, (sx, sy, sz), markov_model_order=args.markov)   # merged stream on rank 0
+    binary = codec.compress(vol, (sx, sy, sz), markov_model_order=args.markov, allow_pins=bool(args.pins))   # merged stream on rank 0
     barrier()
     t1 = time.perf_counter()
     # decode leg: the stream is made resident first (not timed), then every rank decodes its z-range
@@ -236,7 +237,7 @@ def main():
       "dtype": {1: "u8", 2: "u16", 4: "u32", 8: "u64"}[item],
       "data": "synthetic",
       "config": {
-        "workload": f"{sx}x{sy}x{sz * world} {np_dtype.name} jittered-Voronoi labels (cell 32x32x8), encode+decode, flat labels, markov {args.markov}",
+        "workload": f"{sx}x{sy}x{sz * world} {np_dtype.name} jittered-Voronoi labels (cell 32x32x8), encode+decode, {'pin' if args.pins else 'flat'} labels, markov {args.markov}",
         "per_gpu_slab": f"{sx}x{sy}x{sz}",
         "parallelism": f"z-slab x{world}",
       },

@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(kBlock) k_mapping_runs(
 __global__ void __launch_bounds__(kBlock) k_paint_components(
 	const uint32_t* __restrict__ planeV, uint32_t row_words, uint64_t plane_words, uint32_t sx, uint64_t sxy,
 	const uint32_t* __restrict__ word_base, const uint64_t* __restrict__ rbase, const uint32_t* __restrict__ run_cc,
-	const uint64_t* __restrict__ comp_off, uint32_t* __restrict__ out
+	const uint64_t* __restrict__ comp_off, uint32_t id_base, uint32_t* __restrict__ out
 ) {
 	const uint32_t zi = blockIdx.y;
 	const uint32_t wi = blockIdx.x * kBlock + threadIdx.x;
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(kBlock) k_paint_components(
 	uint32_t b = planeV[zi * plane_words + wi];
 	if (w == 0) b |= 1u;
 	const uint32_t* cc = run_cc + rbase[zi];
-	const uint32_t off = static_cast<uint32_t>(comp_off[zi]);
+	const uint32_t off = static_cast<uint32_t>(comp_off[zi]) + id_base;
 	uint32_t run = word_base[zi * plane_words + wi] - 1u;   // run of the pixel left of this word
 	uint32_t* dst = out + zi * sxy + static_cast<uint64_t>(y) * sx + w * 32u;
 	uint32_t id = 0;
@@ -1397,7 +1397,7 @@ void encode_typed(
 			e.d_cc_volume.ensure(voxels);
 			hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((e.plane_words + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
 				e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
-				e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, e.d_cc_volume.p);
+				e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, 0u, e.d_cc_volume.p);
 			std::vector<uint32_t> cc_host = download(e.d_cc_volume.p, voxels, s2);
 			std::vector<LABEL> labels_host = download(labels, voxels, s2);
 			HT_MARK("pins_d2h");
@@ -1587,6 +1587,45 @@ int ckl_encoder_markov_stats(
 			crack_pass(*e, sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
 		}
 		memcpy(hist, h.data(), h.size() * sizeof(uint32_t));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_encoder_components(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	uint32_t id_base, uint32_t* cc_host, uint32_t* ncomp_host
+) {
+	try {
+		if (!e || !cc_host || !ncomp_host) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		check_dims(sx, sy, sz, e->dtype_bytes, 0);
+		select_device(e->device);
+		wait_for_default_stream(e->stream, e->ev_in);
+		wait_for_default_stream(e->stream2, e->ev_in);
+		const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
+		if (voxels == 0) return CKL_OK;
+		const bool cached = e->planes_for == labels_device && e->planes_dims[0] == sx && e->planes_dims[1] == sy && e->planes_dims[2] == sz;
+		FlatResult fr;
+#define CKL_COMP(T) do { \
+			if (!cached) planes_pass<T>(*e, reinterpret_cast<const T*>(labels_device), sx, sy, sz, nullptr); \
+			flat_enqueue(*e, sx, sy, sz); \
+			flat_collect<T>(*e, reinterpret_cast<const T*>(labels_device), sx, sy, sz, fr); \
+		} while (0)
+		if (e->dtype_bytes == 1) CKL_COMP(uint8_t);
+		else if (e->dtype_bytes == 2) CKL_COMP(uint16_t);
+		else if (e->dtype_bytes == 4) CKL_COMP(uint32_t);
+		else CKL_COMP(uint64_t);
+#undef CKL_COMP
+		if (fr.total + id_base > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
+		hipStream_t s2 = e->stream2;
+		e->d_cc_volume.ensure(voxels);
+		hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((e->plane_words + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
+			e->d_planes.p, e->row_words, e->plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
+			e->d_word_base.p, e->d_rbase.p, e->d_run_cc.p, e->d_comp_off.p, id_base, e->d_cc_volume.p);
+		CKL_HIP(hipMemcpyAsync(cc_host, e->d_cc_volume.p, voxels * sizeof(uint32_t), hipMemcpyDeviceToHost, s2));
+		CKL_HIP(hipStreamSynchronize(s2));
+		for (int64_t z = 0; z < sz; z++) ncomp_host[z] = fr.ncomp[z];
 		return CKL_OK;
 	}
 	catch (const Error& err) { set_last_error(err.what()); return err.status; }

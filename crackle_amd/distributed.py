@@ -324,6 +324,19 @@ class HipBackend:
     finally:
       self._L.ckl_free(out)
 
+  def components(self, vol, shape, id_base: int, cc_out: np.ndarray, ncomp_out: np.ndarray):
+    """Per-voxel component ids of the slab (ids continue from id_base over its slices)
+    written into the host arrays cc_out (uint32, x fastest) / ncomp_out (uint32 per slice)."""
+    e = self._encoder(shape, vol.element_size())
+    rc = self._L.ckl_encoder_components(e, vol.data_ptr(), shape[0], shape[1], shape[2], int(id_base),
+                                        cc_out.ctypes.data, ncomp_out.ctypes.data)
+    if rc != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+
+  def volume_to_host(self, vol, out: np.ndarray):
+    """Copies the slab's labels (x fastest) into the host array `out`."""
+    out[...] = vol.reshape(-1).cpu().numpy().view(out.dtype)
+
   def encoder_timing(self) -> Tuple[float, float]:
     p, k = C.c_float(), C.c_float()
     if self._enc:
@@ -349,6 +362,7 @@ class ShardedCodec:
     self.rank, self.world = int(rank), int(world)
     self.device = torch.device(device)
     self._shared = None     # node-local output mapping of the sharded encoder
+    self._shared_vol = None # node-local labels + component ids of the whole volume (pin encoding)
 
   # -- encode -------------------------------------------------------------------
   def compress(self, vol, slab_shape, markov_model_order: int = 0, allow_pins: bool = False, fortran_order: bool = True) -> Optional[bytes]:
@@ -357,9 +371,6 @@ class ShardedCodec:
     be = self.backend
     if self.world == 1:
       return be.encode(vol, slab_shape, allow_pins, fortran_order, markov_model_order, None)
-    if allow_pins:
-      raise NotImplementedError("pins do not shard by z alone (SURVEY.md section 8e); encode on one GPU")
-
     import os, time
     prof = os.environ.get("CKL_PROFILE") is not None
     marks = []
@@ -385,6 +396,9 @@ class ShardedCodec:
     tot_voxels = int(table[:, 4].sum())
     max_label = int(table[:, 1].max())
     crack_format = PERMISSIBLE if tot_pairs < tot_voxels // 2 else IMPERMISSIBLE   # crackle.hpp:50-55
+    # pins only with the IMPERMISSIBLE crack format and more than one slice (crackle.hpp:50-64)
+    sz_all = int(sum(int(table[r, 4]) for r in range(self.world)) // max(sx * sy, 1))
+    use_pins = bool(allow_pins) and crack_format == IMPERMISSIBLE and sz_all > 1
     overrides = dict(crack_format=crack_format, label_format=FLAT, stored_width=_byte_width(max_label))
     mark("stats+allgather")
 
@@ -424,10 +438,56 @@ class ShardedCodec:
     mark("labels")
 
     sw, cw = sec.stored_width, sec.comp_width
-    kw = _byte_width(len(uniq_g))
     sz_tot = int(table[:, 3].sum())
-    n_keys = int(table[:, 1].sum())
-    label_bytes = 8 + len(uniq_g) * sw + sz_tot * cw + n_keys * kw
+    z_before = int(table[:self.rank, 3].sum())
+    pins_section = None
+    if use_pins:
+      # Pin labels (pins.hpp:348-403, labels.hpp:157-344): candidate pins are z-runs per (x,y)
+      # column over the WHOLE volume and the greedy cover is order sensitive, so the slabs'
+      # labels and component ids (numbered continuously over all slices) are laid side by side
+      # in a second node-local mapping and rank 0 runs the host stage once.
+      ncomp_mine = _unpack(sec.comp, cw, sec.sz)
+      id_base = int(table[:self.rank, 1].sum())
+      sxy = sx * sy
+      item = be.itemsize(vol)
+      vol_bytes = sxy * sz_tot * item
+      cc_off = (vol_bytes + 15) // 16 * 16
+      nc_off = cc_off + sxy * sz_tot * 4
+      if self._shared_vol is None:
+        self._shared_vol = _SharedOutput(self.rank, self.world)
+      self._shared_vol.ensure(nc_off + 4 * sz_tot)
+      big = self._shared_vol.array()
+      lab_all = big[:vol_bytes].view({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[item])
+      cc_all = big[cc_off:cc_off + sxy * sz_tot * 4].view(np.uint32)
+      nc_all = big[nc_off:nc_off + 4 * sz_tot].view(np.uint32)
+      mine = slice(sxy * z_before, sxy * (z_before + sec.sz))
+      be.volume_to_host(vol, lab_all[mine])
+      nc_mine = np.zeros(sec.sz, dtype=np.uint32)
+      cc_mine = np.zeros(sxy * sec.sz, dtype=np.uint32)
+      be.components(vol, slab_shape, id_base, cc_mine, nc_mine)
+      if not np.array_equal(nc_mine.astype(np.int64), ncomp_mine):
+        raise RuntimeError("component counts of the slab stream and of the component pass differ")
+      cc_all[mine] = cc_mine
+      nc_all[z_before:z_before + sec.sz] = nc_mine
+      dist.barrier()
+      if self.rank == 0:
+        L = _lib.lib()
+        out_p, out_n = C.c_void_p(), C.c_uint64()
+        rc = L.ckl_pin_labels_host(lab_all.ctypes.data, item, cc_all.ctypes.data, sx, sy, sz_tot, nc_all.ctypes.data,
+                                   sw, 1, 0, C.byref(out_p), C.byref(out_n))
+        if rc != _lib.CKL_OK:
+          raise RuntimeError(_lib.last_error())
+        pins_section = np.frombuffer(C.string_at(out_p.value, out_n.value), dtype=np.uint8)
+        L.ckl_free(out_p)
+      n_pin = torch.tensor([0 if pins_section is None else len(pins_section)], dtype=torch.int64, device=dev)
+      dist.broadcast(n_pin, src=0)
+      label_bytes = int(n_pin.item())
+      kw = 1
+      mark("pins")
+    else:
+      kw = _byte_width(len(uniq_g))
+      n_keys = int(table[:, 1].sum())
+      label_bytes = 8 + len(uniq_g) * sw + sz_tot * cw + n_keys * kw
     o_zidx = 29
     o_labels = o_zidx + 4 * (sz_tot + 1)
     o_comp = o_labels + 8 + len(uniq_g) * sw
@@ -436,7 +496,6 @@ class ShardedCodec:
     o_cracks = o_model + len(sec.model)
     o_tail = o_cracks + int(table[:, 2].sum())
     total = o_tail + 4 * (sz_tot + 1)
-    z_before = int(table[:self.rank, 3].sum())
     keys_before = int(table[:self.rank, 1].sum())
     cracks_before = int(table[:self.rank, 2].sum())
 
@@ -445,15 +504,23 @@ class ShardedCodec:
     self._shared.ensure(total)
     out = self._shared.array()
     out[o_zidx + 4 * z_before: o_zidx + 4 * (z_before + sec.sz)] = sec.zidx
-    out[o_comp + cw * z_before: o_comp + cw * (z_before + sec.sz)] = sec.comp
-    out[o_keys + kw * keys_before: o_keys + kw * (keys_before + len(new_keys))] = _pack(new_keys, kw)
+    if not use_pins:
+      out[o_comp + cw * z_before: o_comp + cw * (z_before + sec.sz)] = sec.comp
+      out[o_keys + kw * keys_before: o_keys + kw * (keys_before + len(new_keys))] = _pack(new_keys, kw)
     out[o_cracks + cracks_before: o_cracks + cracks_before + len(sec.cracks)] = sec.cracks
     out[o_tail + 4 + 4 * z_before: o_tail + 4 + 4 * (z_before + sec.sz)] = sec.crcs
     if self.rank == 0:
-      out[o_labels:o_labels + 8] = np.frombuffer(np.array([len(uniq_g)], dtype="<u8").tobytes(), dtype=np.uint8)
-      out[o_labels + 8:o_comp] = _pack(uniq_g, sw)
+      if use_pins:
+        out[o_labels:o_labels + label_bytes] = pins_section
+      else:
+        out[o_labels:o_labels + 8] = np.frombuffer(np.array([len(uniq_g)], dtype="<u8").tobytes(), dtype=np.uint8)
+        out[o_labels + 8:o_comp] = _pack(uniq_g, sw)
       out[o_model:o_cracks] = sec.model
       head = bytearray(sec.header)
+      if use_pins:
+        fmt = int.from_bytes(head[5:7], "little")
+        fmt = (fmt & ~(3 << 5)) | (2 << 5)          # label_format = PINS_VARIABLE_WIDTH (header.hpp:216-224)
+        head[5:7] = fmt.to_bytes(2, "little")
       head[15:19] = int(sz_tot).to_bytes(4, "little")
       head[20:28] = int(label_bytes).to_bytes(8, "little")
       head[28] = _crc8(bytes(head[5:28]))

@@ -163,6 +163,15 @@ int ckl_encoder_markov_stats(
 	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
 	int crack_format, uint64_t markov_model_order, uint32_t* hist);
 
+/* Per-voxel component ids of a DEVICE-resident slab, numbered continuously over its slices
+ * from id_base (cc3d::connected_components, src/cc3d.hpp:371-400: 4-connected per slice, ids
+ * in first-raster-pixel order), copied to host memory (cc_host: sx*sy*sz uint32, x fastest;
+ * ncomp_host: sz counts).  The sharded pin encoder (pins::compute, src/pins.hpp:348-403,
+ * needs the whole volume's ids on the host that runs the cover solver) calls it per slab. */
+int ckl_encoder_components(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	uint32_t id_base, uint32_t* cc_host, uint32_t* ncomp_host);
+
 int ckl_encoder_last_timing(const ckl_encoder* e, float* pipeline_ms, float* dominant_kernel_ms);
 void ckl_encoder_destroy(ckl_encoder* e);
 

@@ -73,6 +73,17 @@ class OracleBackend:
     finally:
       self.port._free(out)
 
+  def itemsize(self, vol) -> int:
+    return int(np.asarray(vol).dtype.itemsize)
+
+  def volume_to_host(self, vol, out: np.ndarray):
+    out[...] = np.asfortranarray(vol).ravel(order="F").view(out.dtype)
+
+  def components(self, vol, shape, id_base, cc_out, ncomp_out):
+    cc, per, _ = self.port.connected_components(np.asfortranarray(vol))
+    cc_out[...] = cc.ravel(order="F").astype(np.uint32) + np.uint32(id_base)
+    ncomp_out[...] = per.astype(np.uint32)
+
   def open_decoder(self, binary, z_start, z_end):
     return OracleDecodeSession(self.port, binary, z_start, z_end)
 

@@ -42,7 +42,7 @@ def _volume(kind):
   raise ValueError(kind)
 
 
-def _worker(rank, port, kind, order, q):
+def _worker(rank, port, kind, order, q, pins=False):
   import sys
   sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
   from oracle_backend import OracleBackend
@@ -55,7 +55,7 @@ def _worker(rank, port, kind, order, q):
     szl = sz // WORLD
     slab = np.asfortranarray(vol[:, :, rank * szl:(rank + 1) * szl])
     codec = ckd.ShardedCodec(OracleBackend(), rank=rank, world=WORLD, device="cpu")
-    binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order)
+    binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order, allow_pins=pins)
     session = codec.open_decoder(binary, (sx, sy, szl))
     back = np.zeros_like(slab)
     session.run(back)
@@ -83,6 +83,30 @@ def test_sharded_compress_equals_whole_volume(port, kind, order):
   whole = port.compress(vol, markov_model_order=order)
   assert results[0][0] == whole, "merged slab streams differ from the whole-volume stream"
   assert results[1][0] is None
+  assert results[0][1] and results[1][1], "a rank decoded its z-range wrongly"
+
+
+@pytest.mark.parametrize("kind,order", [("voronoi", 0), ("voronoi", 2), ("wide_labels", 0), ("noise", 0)])
+def test_sharded_pins_equal_whole_volume(port, kind, order):
+  """allow_pins across slabs: columns cross the slab boundary, component ids are numbered over
+  the whole volume and the host cover runs once on rank 0; PERMISSIBLE volumes fall back to
+  flat labels exactly like the reference (crackle.hpp:50-64)."""
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  p = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, p, kind, order, q, True)) for r in range(WORLD)]
+  for pr in procs:
+    pr.start()
+  results = {}
+  for _ in range(WORLD):
+    rank, binary, ok = q.get(timeout=180)
+    results[rank] = (binary, ok)
+  for pr in procs:
+    pr.join(timeout=60)
+    assert pr.exitcode == 0
+  vol = _volume(kind)
+  whole = port.compress(vol, allow_pins=True, markov_model_order=order)
+  assert results[0][0] == whole, "sharded pin stream differs from the whole-volume stream"
   assert results[0][1] and results[1][1], "a rank decoded its z-range wrongly"
 
 

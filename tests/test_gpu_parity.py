@@ -210,3 +210,24 @@ def test_decoder_fallback_paths(env, checker, monkeypatch):
     arr8, _ = SMALL[name]
     got = crackle_amd.decompress(golden()[name])
     assert got.size == arr8.size and (arr8.size == 0 or np.array_equal(got, arr8)), name
+
+
+def test_encoder_components_api(checker):
+  """ckl_encoder_components (per-voxel component ids of a device-resident slab, numbered from
+  id_base) against the oracle's cc3d restatement."""
+  import torch
+  L = _lib.lib()
+  dev = torch.device("cuda:0")
+  for shape, dt in (((96, 80, 7), np.uint32), ((130, 67, 5), np.uint16)):
+    vol = synth.voronoi_labels(shape, dt, seed=51, device=dev, cell=(16, 16, 4))
+    sz, sy, sx = vol.shape
+    enc = C.c_void_p()
+    assert L.ckl_encoder_create(sx, sy, sz, vol.element_size(), 0, C.byref(enc)) == 0
+    cc = np.zeros(sx * sy * sz, dtype=np.uint32)
+    nc = np.zeros(sz, dtype=np.uint32)
+    torch.cuda.synchronize()
+    assert L.ckl_encoder_components(enc, vol.data_ptr(), sx, sy, sz, 1000, cc.ctypes.data, nc.ctypes.data) == 0, _lib.last_error()
+    L.ckl_encoder_destroy(enc)
+    want_cc, want_per, _ = checker.connected_components(synth.as_numpy_f(vol))
+    assert np.array_equal(nc, want_per.astype(np.uint32))
+    assert np.array_equal(cc, want_cc.ravel(order="F").astype(np.uint32) + 1000)
