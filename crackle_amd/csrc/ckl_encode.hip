@@ -251,6 +251,7 @@ enum : uint8_t { CODE_UP = 0, CODE_RIGHT = 1, CODE_DOWN = 2, CODE_LEFT = 3, CODE
 // ------------------------------------------------------------------------------
 struct FinishArgs {
 	int sx, sy, xw, yw;
+	uint32_t z0;               // first slice of this launch
 	uint32_t markov;           // 1: write difference codes to dcode instead of packing
 	const uint64_t* cbase;
 	const uint64_t* kbase;
@@ -280,7 +281,7 @@ __device__ __forceinline__ void put_le_dev(uint8_t* p, uint32_t v, int w) {
 
 __global__ void __launch_bounds__(kBlock) k_finish(FinishArgs a) {
 	__shared__ uint32_t s_scan[kWaves];
-	const uint32_t zi = blockIdx.x;
+	const uint32_t zi = blockIdx.x + a.z0;
 	const int tid = threadIdx.x;
 	const uint32_t nch = a.n_chains[zi], nraw = a.n_raw[zi], nvalid = a.n_valid[zi];
 	const uint8_t* cp = a.cp + a.cbase[zi];
@@ -601,20 +602,6 @@ __global__ void __launch_bounds__(kBlock) k_pad_copy_u64(const uint64_t* __restr
 	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
 	if (i < n_pad) dst[i] = i < n ? src[i] : ~0ull;
 }
-__global__ void __launch_bounds__(kBlock) k_label_keys(
-	const uint64_t* __restrict__ mapping, uint64_t n, const uint64_t* __restrict__ uniq, uint64_t nu, int key_width, uint8_t* __restrict__ keys
-) {
-	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-	if (i >= n) return;
-	const uint64_t v = mapping[i];
-	uint64_t lo = 0, hi = nu;          // last index with uniq[idx] <= v
-	while (lo + 1 < hi) {
-		const uint64_t mid = (lo + hi) >> 1;
-		if (uniq[mid] <= v) lo = mid; else hi = mid;
-	}
-	for (int b = 0; b < key_width; b++) keys[i * key_width + b] = static_cast<uint8_t>((lo >> (8 * b)) & 0xFF);
-}
-
 // sorted[N] -> uniq[U] (first of every run of equal values), U; one workgroup
 __global__ void __launch_bounds__(kBlock) k_unique_sorted(const uint64_t* __restrict__ sorted, uint32_t n, uint64_t* __restrict__ uniq, uint32_t* __restrict__ n_uniq) {
 	__shared__ uint32_t s_scan[kWaves];
@@ -707,11 +694,15 @@ std::vector<uint8_t> encode_pins_host(
 	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor);
 }
 
+constexpr uint32_t kTrailStreams = 8;
+
 struct ckl_encoder {
 	int device = 0;
 	hipStream_t stream = nullptr;      // crack codes
 	hipStream_t stream2 = nullptr;     // labels (components, crcs, label table), concurrent with the crack trail
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr, ev_in = nullptr;
+	hipStream_t trail_stream[kTrailStreams] = {};     // slice groups of the crack trail
+	hipEvent_t ev_fork = nullptr, ev_join[kTrailStreams] = {};
 	float pipeline_ms = 0.f, dominant_ms = 0.f;
 	int64_t max_sx = 0, max_sy = 0, max_sz = 0;
 	int dtype_bytes = 0;
@@ -771,6 +762,9 @@ struct ckl_encoder {
 		if (evk0) (void)hipEventDestroy(evk0);
 		if (evk1) (void)hipEventDestroy(evk1);
 		if (ev_in) (void)hipEventDestroy(ev_in);
+		if (ev_fork) (void)hipEventDestroy(ev_fork);
+		for (auto& ev : ev_join) if (ev) (void)hipEventDestroy(ev);
+		for (auto& st : trail_stream) if (st) (void)hipStreamDestroy(st);
 		if (stream) (void)hipStreamDestroy(stream);
 		if (stream2) (void)hipStreamDestroy(stream2);
 	}
@@ -983,6 +977,33 @@ void crack_pass(
 	e.d_n_chains.ensure(ns); e.d_n_raw.ensure(ns); e.d_n_valid.ensure(ns);
 	e.d_payload_len.ensure(ns); e.d_boc_len.ensure(ns);
 
+	// output buffers sized from the capacities (no round trip to the host before k_finish)
+	const int xw = byte_width(static_cast<uint64_t>(sx) + 1), yw = byte_width(static_cast<uint64_t>(sy) + 1);
+	std::vector<uint64_t> pbase(ns), bbase(ns);
+	uint64_t ptot = 0, btot = 0;
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		// codes <= E + 2 (b + t) <= 5 E + 2; plain: 2 bits / code; markov: at most 3 bits / code (+2)
+		const uint64_t ncodes = ccap[zi];
+		const uint64_t pbytes = markov_order ? (3ull * ncodes + 2 + 7) / 8 : (ncodes + 3) / 4;
+		pbase[zi] = ptot; ptot += ((pbytes + 8 + 3) / 4) * 4;
+		const uint64_t bbytes = 4 + yw + static_cast<uint64_t>(kcap[zi]) * (yw + 2 * xw);
+		bbase[zi] = btot; btot += bbytes;
+	}
+	upload(e.d_pbase, pbase, s); upload(e.d_bbase, bbase, s);
+	e.d_payload.ensure(ptot + 8); e.d_boc.ensure(btot + 8);
+	if (markov_order) CKL_HIP(hipMemsetAsync(e.d_payload.p, 0, ptot + 8, s));
+
+	FinishArgs fa;
+	fa.sx = static_cast<int>(sx); fa.sy = static_cast<int>(sy); fa.xw = xw; fa.yw = yw;
+	fa.markov = markov_order ? 1u : 0u;
+	fa.cbase = e.d_cbase.p; fa.kbase = e.d_kbase.p;
+	fa.n_chains = e.d_n_chains.p; fa.n_raw = e.d_n_raw.p; fa.n_valid = e.d_n_valid.p;
+	fa.cp = e.d_cp.p; fa.chain_node = e.d_chain_node.p; fa.chain_off = e.d_chain_off.p; fa.chain_clen = e.d_chain_clen.p;
+	fa.chain_order = e.d_chain_order.p; fa.chain_dst = e.d_chain_dst.p; fa.chain_vstart = e.d_chain_vstart.p;
+	fa.fcode = e.d_fcode.p; fa.dcode = e.d_dcode.p;
+	fa.pbase = e.d_pbase.p; fa.payload = e.d_payload.p; fa.bbase = e.d_bbase.p; fa.boc = e.d_boc.p;
+	fa.payload_len = e.d_payload_len.p; fa.boc_len = e.d_boc_len.p;
+
 	unsigned long long* ta_dbg = nullptr;
 	DevBuf<unsigned long long> d_tdbg;
 	CKL_HIP(hipEventRecord(e.evk0, s));
@@ -1031,26 +1052,51 @@ void crack_pass(
 		CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, e.device));
 		const size_t budget = static_cast<size_t>(max_lds > 1024 ? max_lds - 1024 : 0);
 		const uint32_t dart_blocks = (4 * max_ncap + kWalkChunk * kWaves - 1) / (kWalkChunk * kWaves);
-		if (any) {
-			hipLaunchKernelGGL(k_trail_nodes, dim3(e.graph_blocks, ns), dim3(kBlock), 0, s, ta);
-			hipLaunchKernelGGL(k_trail_segments, dim3(dart_blocks, ns), dim3(kBlock), 0, s, ta);
-			if (max_cocap) hipLaunchKernelGGL(k_trail_loops, dim3((max_cocap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, ta);
-			// union-find table of k_trail_components in LDS: 4 bytes per node
-			size_t clds = (static_cast<size_t>(max_special) + 1024) * 4;
-			if (const char* env = getenv("CKL_TRAIL_LDS")) clds = static_cast<size_t>(std::max(0, atoi(env)));
-			clds = (std::min(budget, std::max<size_t>(clds, 1024)) / 16) * 16;
-			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_components), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(clds)));
-			hipLaunchKernelGGL(k_trail_components, dim3(ns), dim3(kCompBlock), clds, s, ta, static_cast<uint32_t>(clds));
-		}
+		// union-find table of k_trail_components in LDS: 4 bytes per node
+		size_t clds = (static_cast<size_t>(max_special) + 1024) * 4;
+		if (const char* env = getenv("CKL_TRAIL_LDS")) clds = static_cast<size_t>(std::max(0, atoi(env)));
+		clds = (std::min(budget, std::max<size_t>(clds, 1024)) / 16) * 16;
+		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_components), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(clds)));
 		// node tables of k_trail_dfs in LDS: 9 bytes per node + 16 KiB of branch stack when that fits
 		size_t lds = (static_cast<size_t>(max_special) + 256) * 9 + 16384 + 1024;
 		if (const char* env = getenv("CKL_TRAIL_LDS")) lds = static_cast<size_t>(std::max(0, atoi(env)));   // testing: small values force the global tables
 		lds = std::min(budget, std::max<size_t>(lds, 4096));
 		lds = (lds / 16) * 16;
 		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_dfs), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-		hipLaunchKernelGGL(k_trail_dfs, dim3(ns), dim3(kWave), lds, s, ta, static_cast<uint32_t>(lds));
-		hipLaunchKernelGGL(k_trail_offsets, dim3(ns), dim3(kBlock), 0, s, ta);
-		hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kExpandChunk * kWaves - 1) / (kExpandChunk * kWaves), ns), dim3(kBlock), 0, s, ta);
+
+		// The serial k_trail_dfs keeps 1 wavefront per slice busy for ~2 ms while the chip idles.
+		// Slices are therefore processed in (two) groups on their own streams: while one group is
+		// in its DFS the other runs its parallel stages.
+		uint32_t groups = ns >= 64 ? 2u : 1u;      // more groups only serialise on the shared hardware queue (measured: 2 -> -0.17 ms, 4 and 8 slower)
+		if (const char* env = getenv("CKL_TRAIL_GROUPS")) groups = static_cast<uint32_t>(std::max(1, atoi(env)));
+		groups = std::min<uint32_t>(std::min<uint32_t>(groups, ns), kTrailStreams);
+		if (groups > 1) CKL_HIP(hipEventRecord(e.ev_fork, s));
+		for (uint32_t g = 0; g < groups; g++) {
+			const uint32_t z0 = static_cast<uint32_t>(static_cast<uint64_t>(ns) * g / groups);
+			const uint32_t z1 = static_cast<uint32_t>(static_cast<uint64_t>(ns) * (g + 1) / groups);
+			const uint32_t gn = z1 - z0;
+			if (gn == 0) continue;
+			// group 0 stays on the session's own stream: the runtime multiplexes streams onto few hardware
+			// queues (4 by default), streams created later share one and serialise
+			hipStream_t gs = g == 0 ? s : e.trail_stream[g - 1];
+			if (g > 0) CKL_HIP(hipStreamWaitEvent(gs, e.ev_fork, 0));
+			ta.z0 = z0;
+			fa.z0 = z0;
+			if (any) {
+				hipLaunchKernelGGL(k_trail_nodes, dim3(e.graph_blocks, gn), dim3(kBlock), 0, gs, ta);
+				hipLaunchKernelGGL(k_trail_segments, dim3(dart_blocks, gn), dim3(kBlock), 0, gs, ta);
+				if (max_cocap) hipLaunchKernelGGL(k_trail_loops, dim3((max_cocap + kBlock - 1) / kBlock, gn), dim3(kBlock), 0, gs, ta);
+				hipLaunchKernelGGL(k_trail_components, dim3(gn), dim3(kCompBlock), clds, gs, ta, static_cast<uint32_t>(clds));
+			}
+			hipLaunchKernelGGL(k_trail_dfs, dim3(gn), dim3(kWave), lds, gs, ta, static_cast<uint32_t>(lds));
+			hipLaunchKernelGGL(k_trail_offsets, dim3(gn), dim3(kBlock), 0, gs, ta);
+			hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kExpandChunk * kWaves - 1) / (kExpandChunk * kWaves), gn), dim3(kBlock), 0, gs, ta);
+			hipLaunchKernelGGL(k_finish, dim3(gn), dim3(kBlock), 0, gs, fa);
+			if (g > 0) {
+				CKL_HIP(hipEventRecord(e.ev_join[g], gs));
+				CKL_HIP(hipStreamWaitEvent(s, e.ev_join[g], 0));
+			}
+		}
 	}
 	CKL_HIP(hipEventRecord(e.evk1, s));
 	HT_MARK("c:enqueue");
@@ -1075,33 +1121,6 @@ void crack_pass(
 	if (overlap) overlap();
 	HT_MARK("c:overlap");
 
-	// output buffers sized from the capacities (no round trip to the host before k_finish)
-	const int xw = byte_width(static_cast<uint64_t>(sx) + 1), yw = byte_width(static_cast<uint64_t>(sy) + 1);
-	std::vector<uint64_t> pbase(ns), bbase(ns);
-	uint64_t ptot = 0, btot = 0;
-	for (uint32_t zi = 0; zi < ns; zi++) {
-		// codes <= E + 2 (b + t) <= 5 E + 2; plain: 2 bits / code; markov: at most 3 bits / code (+2)
-		const uint64_t ncodes = ccap[zi];
-		const uint64_t pbytes = markov_order ? (3ull * ncodes + 2 + 7) / 8 : (ncodes + 3) / 4;
-		pbase[zi] = ptot; ptot += ((pbytes + 8 + 3) / 4) * 4;
-		const uint64_t bbytes = 4 + yw + static_cast<uint64_t>(kcap[zi]) * (yw + 2 * xw);
-		bbase[zi] = btot; btot += bbytes;
-	}
-	upload(e.d_pbase, pbase, s); upload(e.d_bbase, bbase, s);
-	e.d_payload.ensure(ptot + 8); e.d_boc.ensure(btot + 8);
-	if (markov_order) CKL_HIP(hipMemsetAsync(e.d_payload.p, 0, ptot + 8, s));
-
-	FinishArgs fa;
-	fa.sx = static_cast<int>(sx); fa.sy = static_cast<int>(sy); fa.xw = xw; fa.yw = yw;
-	fa.markov = markov_order ? 1u : 0u;
-	fa.cbase = e.d_cbase.p; fa.kbase = e.d_kbase.p;
-	fa.n_chains = e.d_n_chains.p; fa.n_raw = e.d_n_raw.p; fa.n_valid = e.d_n_valid.p;
-	fa.cp = e.d_cp.p; fa.chain_node = e.d_chain_node.p; fa.chain_off = e.d_chain_off.p; fa.chain_clen = e.d_chain_clen.p;
-	fa.chain_order = e.d_chain_order.p; fa.chain_dst = e.d_chain_dst.p; fa.chain_vstart = e.d_chain_vstart.p;
-	fa.fcode = e.d_fcode.p; fa.dcode = e.d_dcode.p;
-	fa.pbase = e.d_pbase.p; fa.payload = e.d_payload.p; fa.bbase = e.d_bbase.p; fa.boc = e.d_boc.p;
-	fa.payload_len = e.d_payload_len.p; fa.boc_len = e.d_boc_len.p;
-	hipLaunchKernelGGL(k_finish, dim3(ns), dim3(kBlock), 0, s, fa);
 
 	if (markov_order) {
 		std::vector<uint8_t> model;
@@ -1486,6 +1505,9 @@ int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int 
 		CKL_HIP(hipEventCreate(&e->evk0));
 		CKL_HIP(hipEventCreate(&e->evk1));
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+		CKL_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+		for (auto& ev : e->ev_join) CKL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		for (auto& st : e->trail_stream) CKL_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 		*out = e.release();
 		return CKL_OK;
 	}

@@ -137,35 +137,6 @@ __device__ __forceinline__ void run_unite(uint32_t* L, uint32_t a, uint32_t b) {
 	}
 }
 
-// grid = (ceil(words / 256), nslices): one thread per 32-pixel word of rows y >= 1.
-// A union is issued at the first pixel of every stretch along which the pixel stays
-// up-connected and neither its own run nor the run above changes.
-static __global__ void __launch_bounds__(kBlock) k_run_union(RunGeom g, RunArrays r) {
-	const uint32_t zi = blockIdx.y;
-	const uint32_t wi = blockIdx.x * kBlock + threadIdx.x;
-	if (wi >= g.plane_words) return;
-	const uint32_t y = wi / g.row_words;
-	if (y == 0) return;
-	const uint32_t w = wi - y * g.row_words;
-	const uint32_t up = g.ups(zi, y, w);
-	if (!up) return;
-	const uint32_t prev_bit = w ? (g.ups(zi, y, w - 1) >> 31) : 0u;
-	const uint32_t b_here = g.breaks(zi, y, w);
-	const uint32_t b_up = g.breaks(zi, y - 1, w);
-	uint32_t cand = up & (~((up << 1) | prev_bit) | b_here | b_up);
-	const uint32_t* wb = r.word_base + zi * g.plane_words;
-	const uint32_t base_here = wb[wi], base_up = wb[wi - g.row_words];
-	uint32_t* parent = r.parent + r.rbase[zi];
-	const uint32_t n = r.nruns[zi];
-	for (; cand; cand &= cand - 1u) {
-		const uint32_t bit = __ffs(cand) - 1;
-		const uint32_t m = mask_le(bit);
-		const uint32_t ra = base_here + __popc(b_here & m) - 1u;
-		const uint32_t rb = base_up + __popc(b_up & m) - 1u;
-		if (ra < n && rb < n) run_unite(parent, ra, rb);
-	}
-}
-
 // ---- strip-local union-find in LDS ------------------------------------------------
 // Most unions are local: a strip of rows is united entirely in LDS (parents relative to
 // the strip's first run), flattened there and written out as global parents, so that

@@ -73,6 +73,7 @@ struct TrailArgs {
 	uint32_t sx, sy, inv;
 	uint32_t sxe, sye;
 	uint32_t nverts;
+	uint32_t z0;                 // first slice of this launch (the trail runs in slice groups on several streams)
 	const uint32_t* max_steps;   // [nslices] crack edges of the slice + 1
 	uint32_t graph_blocks;       // workgroups per slice of k_trail_graph / k_trail_nodes
 	const uint32_t* blk_special; // [nslices][graph_blocks] exclusive prefix of the node counts
@@ -255,7 +256,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_count_scan(
 // nodes are numbered in (tile, row, x) order, no atomics
 static __global__ void __launch_bounds__(kBlock) k_trail_nodes(TrailArgs a) {
 	__shared__ uint32_t s_scan[2 * kWaves];
-	const uint32_t zi = blockIdx.y;
+	const uint32_t zi = blockIdx.y + a.z0;
 	const uint32_t tile = blockIdx.x * kGraphTiles + (threadIdx.x >> 5);
 	const uint32_t r = threadIdx.x & 31u;
 	TileRowBits b = { 0, 0, 0, 0 };
@@ -313,7 +314,7 @@ constexpr int kWalkAhead = 3;       // steps a lane may run ahead inside its mic
 // grid = (ceil(4 * max nodes / (kWalkChunk * 4)), nslices)
 static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 	__shared__ uint4 s_res[kWaves][kWalkChunk];       // end, len, minv, minpos
-	const uint32_t zi = blockIdx.y;
+	const uint32_t zi = blockIdx.y + a.z0;
 	const uint32_t lane = threadIdx.x & (kWave - 1);
 	const uint32_t wv = threadIdx.x >> 6;
 	const uint32_t wave = blockIdx.x * kWaves + wv;
@@ -399,7 +400,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 // grid = (ceil(max corners / 256), nslices): a "right+down" corner is the start of a
 // closed loop when following the loop from it never meets a node or a smaller vertex
 static __global__ void __launch_bounds__(kBlock) k_trail_loops(TrailArgs a) {
-	const uint32_t zi = blockIdx.y;
+	const uint32_t zi = blockIdx.y + a.z0;
 	const uint32_t ci = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t nc = min(a.n_corners[zi], a.cocap[zi]);
 	const uint4* adjm = a.adjm + zi * a.adjm_stride;
@@ -580,7 +581,7 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 static __global__ void __launch_bounds__(kCompBlock) k_trail_components(TrailArgs a, uint32_t lds_bytes) {
 	extern __shared__ uint32_t s_trail[];
 	__shared__ uint32_t s_scan[kCompBlock / kWave];
-	const uint32_t zi = blockIdx.x;
+	const uint32_t zi = blockIdx.x + a.z0;
 	const uint32_t nn = min(a.n_nodes[zi], a.ncap[zi]);
 	if (nn * 4u <= lds_bytes) trail_components_slice<true>(a, zi, s_trail, nn, s_scan);
 	else trail_components_slice<false>(a, zi, a.parent + a.nbase[zi], nn, s_scan);
@@ -799,7 +800,7 @@ __device__ __forceinline__ void trail_dfs_slice(
 // grid = nslices, block = one wavefront; dynamic LDS = lds_bytes
 static __global__ void __launch_bounds__(kWave) k_trail_dfs(TrailArgs a, uint32_t lds_bytes) {
 	extern __shared__ uint32_t s_trail[];
-	const uint32_t zi = blockIdx.x;
+	const uint32_t zi = blockIdx.x + a.z0;
 	const uint32_t nn = min(a.n_nodes[zi], a.ncap[zi]);
 	const uint64_t nb = a.nbase[zi];
 	if (a.slice_err[zi]) {
@@ -835,7 +836,7 @@ static __global__ void __launch_bounds__(kWave) k_trail_dfs(TrailArgs a, uint32_
 // grid = nslices: code offset of every item, chain offsets and lengths
 static __global__ void __launch_bounds__(kBlock) k_trail_offsets(TrailArgs a) {
 	__shared__ uint32_t s_scan[kWaves];
-	const uint32_t zi = blockIdx.x;
+	const uint32_t zi = blockIdx.x + a.z0;
 	const uint32_t n = a.n_items[zi];
 	const uint32_t* items = a.items + a.ibase[zi];
 	uint32_t* off = a.item_off + a.ibase[zi];
@@ -889,7 +890,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_offsets(TrailArgs a) {
 // grid = (ceil(max items / (kExpandChunk * 4)), nslices): every item writes its code points;
 // segment items are re-walked, lanes refill from the wavefront's range like k_trail_segments
 static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
-	const uint32_t zi = blockIdx.y;
+	const uint32_t zi = blockIdx.y + a.z0;
 	if (a.slice_err[zi]) return;
 	const uint32_t lane = threadIdx.x & (kWave - 1);
 	const uint32_t wave = blockIdx.x * kWaves + (threadIdx.x >> 6);
