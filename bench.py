@@ -24,6 +24,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The encoder overlaps its crack and label streams; the HIP runtime multiplexes streams onto 4
+# hardware queues by default and torch / RCCL take some: ask for 8 before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 

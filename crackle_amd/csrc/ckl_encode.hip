@@ -1242,7 +1242,7 @@ void flat_enqueue(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz) {
 	ra.word_base = e.d_word_base.p; ra.rbase = e.d_rbase.p; ra.rcap = e.d_rcap.p;
 	ra.parent = e.d_parent.p; ra.run_start = e.d_run_start.p; ra.run_cc = e.d_run_cc.p;
 	ra.nruns = e.d_nruns.p; ra.ncomp = e.d_ncomp.p; ra.slice_err = e.d_slice_err2.p;
-	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kBlock), 0, s, g, ra);
+	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kIndexBlock), 0, s, g, ra);
 	launch_run_union(s, ns, g, ra);
 	ResolveScratch rs;
 	rs.nblk = (max_rcap + kBlock - 1) / kBlock;

@@ -68,9 +68,11 @@ struct RunArrays {
 	uint32_t* slice_err;
 };
 
-// grid = nslices
-static __global__ void __launch_bounds__(kBlock) k_run_index(RunGeom g, RunArrays r) {
-	__shared__ uint32_t s_scan[kWaves];
+constexpr int kIndexBlock = 1024;     // one workgroup per slice: as many threads as a workgroup can have
+
+// grid = nslices, block = kIndexBlock
+static __global__ void __launch_bounds__(kIndexBlock) k_run_index(RunGeom g, RunArrays r) {
+	__shared__ uint32_t s_scan[kIndexBlock / kWave];
 	const uint32_t zi = blockIdx.x;
 	uint32_t* wb = r.word_base + zi * g.plane_words;
 	uint32_t* parent = r.parent + r.rbase[zi];
@@ -79,7 +81,7 @@ static __global__ void __launch_bounds__(kBlock) k_run_index(RunGeom g, RunArray
 	const uint32_t words = static_cast<uint32_t>(g.plane_words);
 	constexpr uint32_t kPer = 4;
 	uint32_t carry = 0, err = 0;
-	for (uint32_t w0 = 0; w0 < words; w0 += kBlock * kPer) {
+	for (uint32_t w0 = 0; w0 < words; w0 += kIndexBlock * kPer) {
 		uint32_t b[kPer], cnt = 0;
 #pragma unroll
 		for (uint32_t j = 0; j < kPer; j++) {
@@ -92,7 +94,7 @@ static __global__ void __launch_bounds__(kBlock) k_run_index(RunGeom g, RunArray
 			cnt += __popc(b[j]);
 		}
 		uint32_t v[1] = { cnt }, tot[1];
-		block_excl_add<1>(v, tot, s_scan);
+		block_excl_add<1, kIndexBlock / kWave>(v, tot, s_scan);
 		uint32_t base = carry + v[0];
 #pragma unroll
 		for (uint32_t j = 0; j < kPer; j++) {
