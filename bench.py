@@ -253,7 +253,7 @@ def main():
       "decode_ms": float(np.mean(dec_ms)),
       "decode_device_pipeline_ms": float(np.mean(dec_pipe_ms)),
       "encode_device_pipeline_ms": float(np.mean(enc_pipe_ms)),
-      "encode_walk_kernel_ms": float(np.mean(enc_kernel_ms)),
+      "encode_dfs_kernel_ms": float(np.mean(enc_kernel_ms)),
       "roofline": {
         "bound": "hbm",
         "kernel": dom + " (decode)",
@@ -270,6 +270,18 @@ def main():
         "decode_stage_ms": stage_ms,
       },
     }
+    # the same figure for the encoder's longest kernel (the serial trail over nodes: one
+    # wavefront per slice, bound by dependent instruction latency, not by bytes)
+    enc_k = float(np.mean(enc_kernel_ms))
+    if enc_k > 0:
+      res["roofline_encode"] = {
+        "bound": "hbm", "kernel": "k_trail_dfs (encode)",
+        "achieved": alg_bytes / (enc_k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg_bytes / (enc_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": pmc_traffic("k_trail_dfs", workload_key),
+        "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": enc_k,
+        "encode_pipeline_frac": alg_bytes / (float(np.mean(enc_pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+      }
     if not args.no_cpu_baseline:
       ns = min(args.cpu_sample_slices, sz)
       slab = synth.as_numpy_f(vol[:ns])

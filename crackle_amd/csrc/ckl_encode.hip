@@ -701,6 +701,8 @@ struct ckl_encoder {
 	hipStream_t stream = nullptr;      // crack codes
 	hipStream_t stream2 = nullptr;     // labels (components, crcs, label table), concurrent with the crack trail
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr, ev_in = nullptr;
+	hipEvent_t evd0 = nullptr, evd1 = nullptr;      // around k_trail_dfs (first slice group)
+	float trail_ms = 0.f;
 	hipStream_t trail_stream[kTrailStreams] = {};     // slice groups of the crack trail
 	hipEvent_t ev_fork = nullptr, ev_join[kTrailStreams] = {};
 	float pipeline_ms = 0.f, dominant_ms = 0.f;
@@ -761,6 +763,8 @@ struct ckl_encoder {
 		if (ev1) (void)hipEventDestroy(ev1);
 		if (evk0) (void)hipEventDestroy(evk0);
 		if (evk1) (void)hipEventDestroy(evk1);
+		if (evd0) (void)hipEventDestroy(evd0);
+		if (evd1) (void)hipEventDestroy(evd1);
 		if (ev_in) (void)hipEventDestroy(ev_in);
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
 		for (auto& ev : ev_join) if (ev) (void)hipEventDestroy(ev);
@@ -1065,9 +1069,9 @@ void crack_pass(
 		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_dfs), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
 
 		// The serial k_trail_dfs keeps 1 wavefront per slice busy for ~2 ms while the chip idles.
-		// Slices are therefore processed in (two) groups on their own streams: while one group is
-		// in its DFS the other runs its parallel stages.
-		uint32_t groups = ns >= 64 ? 2u : 1u;      // more groups only serialise on the shared hardware queue (measured: 2 -> -0.17 ms, 4 and 8 slower)
+		// Slices can be processed in groups on their own streams (CKL_TRAIL_GROUPS): while one
+		// group is in its DFS the others run their parallel stages.
+		uint32_t groups = 1u;      // measured at C2: 2 groups -0.17 ms, 4 and 8 slower (the DFS wavefronts want their SIMDs to themselves); one launch keeps the per-launch accounting simple
 		if (const char* env = getenv("CKL_TRAIL_GROUPS")) groups = static_cast<uint32_t>(std::max(1, atoi(env)));
 		groups = std::min<uint32_t>(std::min<uint32_t>(groups, ns), kTrailStreams);
 		if (groups > 1) CKL_HIP(hipEventRecord(e.ev_fork, s));
@@ -1088,7 +1092,9 @@ void crack_pass(
 				if (max_cocap) hipLaunchKernelGGL(k_trail_loops, dim3((max_cocap + kBlock - 1) / kBlock, gn), dim3(kBlock), 0, gs, ta);
 				hipLaunchKernelGGL(k_trail_components, dim3(gn), dim3(kCompBlock), clds, gs, ta, static_cast<uint32_t>(clds));
 			}
+			if (g == 0) CKL_HIP(hipEventRecord(e.evd0, gs));
 			hipLaunchKernelGGL(k_trail_dfs, dim3(gn), dim3(kWave), lds, gs, ta, static_cast<uint32_t>(lds));
+			if (g == 0) CKL_HIP(hipEventRecord(e.evd1, gs));
 			hipLaunchKernelGGL(k_trail_offsets, dim3(gn), dim3(kBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kExpandChunk * kWaves - 1) / (kExpandChunk * kWaves), gn), dim3(kBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_finish, dim3(gn), dim3(kBlock), 0, gs, fa);
@@ -1471,7 +1477,8 @@ void encode_typed(
 		ht.mark("codes_d2h");
 		CKL_HIP(hipGetLastError());
 		CKL_HIP(hipEventElapsedTime(&e.pipeline_ms, e.ev0, e.ev1));
-		CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evk0, e.evk1));
+		CKL_HIP(hipEventElapsedTime(&e.trail_ms, e.evk0, e.evk1));
+		CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evd0, e.evd1));      // the encoder's longest kernel: k_trail_dfs
 	}
 	catch (...) { host_out_free(o); throw; }
 	*out = o;
@@ -1504,6 +1511,8 @@ int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int 
 		CKL_HIP(hipEventCreate(&e->ev1));
 		CKL_HIP(hipEventCreate(&e->evk0));
 		CKL_HIP(hipEventCreate(&e->evk1));
+		CKL_HIP(hipEventCreate(&e->evd0));
+		CKL_HIP(hipEventCreate(&e->evd1));
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
 		for (auto& ev : e->ev_join) CKL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
