@@ -56,6 +56,8 @@ struct CrackArgs {
 	int xw, yw;
 	int markov_order;
 	const uint8_t* model;        // [4^order][4] rank -> symbol
+	uint32_t* mkscratch;         // markov only: per-slice scratch (payload copy + ranks) for slices whose tables exceed the LDS
+	const uint64_t* mkbase;      // [nslices] word offsets into mkscratch
 	uint32_t* upacked;           // markov only: decoded difference codes, 16 per word (slice base cbase/16 + 2 zi)
 	// control symbol tables in global memory, used when a slice has more control symbols
 	// than the LDS tables hold (slice base cbase/2 + 4 zi, capacity ccap/2 + 4)
@@ -602,18 +604,26 @@ __device__ __forceinline__ uint32_t markov_lds_need(uint32_t nbytes, uint32_t ca
 	model_in_lds = order <= 8 && pay + rnk + fix + mdl <= budget;
 	return pay + rnk + fix + (model_in_lds ? static_cast<uint32_t>(mdl) : 0u);
 }
+// the same with payload and ranks in the global scratch: only the model and the context words
+__device__ __forceinline__ bool markov_model_fits_alone(int order, uint32_t budget) {
+	return order <= 8 && (4ull << (2 * order)) + 2ull * kCrackBlock * 4ull <= budget;
+}
 
+// GLOBAL: the payload copy and the ranks live in a global scratch area (slices too big for the
+// LDS); those words are written by some threads and read by others of the workgroup, so they are
+// read with L1-bypassing loads.
+template <bool GLOBAL>
 __device__ __forceinline__ void markov_expand_parallel(
 	const uint8_t* __restrict__ s, uint32_t nbytes, int order, const uint8_t* __restrict__ model_g, uint32_t cap,
-	uint32_t* __restrict__ upacked, uint32_t* lds, bool model_in_lds, uint32_t* s_scan, uint32_t* s_total,
+	uint32_t* __restrict__ upacked, uint32_t* lds, uint32_t* gscratch, bool model_in_lds, uint32_t* s_scan, uint32_t* s_total,
 	uint32_t& ncodes_out, uint32_t& err_out
 ) {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t pay_words = (nbytes + 3u) / 4u + 2u;
-	uint32_t* pay = lds;
-	uint32_t* ranks = pay + pay_words;
 	const uint32_t rank_words = cap / 16u + 2u;
-	uint32_t* rows_lds = ranks + rank_words;
+	uint32_t* pay = GLOBAL ? gscratch : lds;
+	uint32_t* ranks = pay + pay_words;
+	uint32_t* rows_lds = GLOBAL ? lds : ranks + rank_words;
 	const uint32_t n_rows = 1u << (2 * order);
 	uint32_t* ctx_in = rows_lds + (model_in_lds ? n_rows : 0u);
 	uint32_t* ctx_end = ctx_in + kCrackBlock;
@@ -627,8 +637,10 @@ __device__ __forceinline__ void markov_expand_parallel(
 	}
 	for (uint32_t w = tid; w < rank_words; w += kCrackBlock) ranks[w] = 0;
 	if (model_in_lds) for (uint32_t r = tid; r < n_rows; r += kCrackBlock) rows_lds[r] = reinterpret_cast<const uint32_t*>(model_g)[r];
+	if (GLOBAL) __threadfence();      // the zeroes must be in L2 before another wavefront's atomicOr lands there
 	__syncthreads();
-	auto bit = [&](uint32_t p) -> uint32_t { return (pay[p >> 5] >> (p & 31u)) & 1u; };      // bits past the end read 0
+	auto ldw = [&](const uint32_t* p) -> uint32_t { return GLOBAL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+	auto bit = [&](uint32_t p) -> uint32_t { return (ldw(pay + (p >> 5)) >> (p & 31u)) & 1u; };      // bits past the end read 0
 
 	// ---- 1. code boundaries
 	const uint32_t B = nbytes * 8u;
@@ -639,9 +651,9 @@ __device__ __forceinline__ void markov_expand_parallel(
 		uint32_t e[3], c[3];
 		// the three start states in one sweep over the bits (one LDS word per 32 bits)
 		uint32_t st0 = 0, st1 = 1, st2 = 2, n0 = 0, n1 = 0, n2 = 0;
-		uint32_t wc = pay[lo >> 5];
+		uint32_t wc = ldw(pay + (lo >> 5));
 		for (uint32_t p = lo; p < hi; p++) {
-			if ((p & 31u) == 0u) wc = pay[p >> 5];
+			if ((p & 31u) == 0u) wc = ldw(pay + (p >> 5));
 			const uint32_t b = (wc >> (p & 31u)) & 1u;
 			n0 += st0 == 0u ? 1u : 0u; n1 += st1 == 0u ? 1u : 0u; n2 += st2 == 0u ? 1u : 0u;
 			st0 = st0 == 2u ? 0u : (b ? st0 + 1u : 0u);
@@ -695,6 +707,7 @@ __device__ __forceinline__ void markov_expand_parallel(
 			p++;
 		}
 	}
+	if (GLOBAL) __threadfence();
 	__syncthreads();
 	uint32_t n = *s_total;
 	if (n > cap) { n = cap; err_out |= ERR_CAPACITY; }
@@ -702,7 +715,7 @@ __device__ __forceinline__ void markov_expand_parallel(
 
 	// ---- 3. the context recurrence, speculatively per chunk
 	const int shift = 2 * (order - 1);
-	const uint32_t start = pay[0] & 3u;
+	const uint32_t start = ldw(pay) & 3u;
 	uint32_t C = (n + kCrackBlock - 1u) / kCrackBlock;
 	C = max(16u, (C + 15u) & ~15u);
 	const uint32_t nchunks = (n + C - 1u) / C;
@@ -710,8 +723,11 @@ __device__ __forceinline__ void markov_expand_parallel(
 	const bool have = tid < nchunks;
 	auto decode_chunk = [&](uint32_t ctx) -> uint32_t {      // codes max(k0, 1) .. k1-1 from context ctx; writes the words; returns the end context
 		uint32_t word = (k0 == 0u) ? start : 0u;
-		for (uint32_t k = max(k0, 1u); k < k1; k++) {
-			const uint32_t r = (ranks[k >> 4] >> (2u * (k & 15u))) & 3u;
+		const uint32_t kfirst = max(k0, 1u);
+		uint32_t rw = 0;
+		for (uint32_t k = kfirst; k < k1; k++) {
+			if ((k & 15u) == 0u || k == kfirst) rw = ldw(ranks + (k >> 4));
+			const uint32_t r = (rw >> (2u * (k & 15u))) & 3u;
 			const uint32_t v = (rows[ctx] >> (8u * r)) & 3u;
 			ctx = (ctx >> 2) + (v << shift);
 			word |= v << (2u * (k & 15u));
@@ -726,8 +742,10 @@ __device__ __forceinline__ void markov_expand_parallel(
 		if (k0 > 1u) {
 			const uint32_t kb = k0 > kMarkovWarm ? k0 - kMarkovWarm : 1u;
 			uint32_t ctx = kb == 1u ? (start << shift) : 0u;
+			uint32_t rw = 0;
 			for (uint32_t k = kb; k < k0; k++) {
-				const uint32_t r = (ranks[k >> 4] >> (2u * (k & 15u))) & 3u;
+				if ((k & 15u) == 0u || k == kb) rw = ldw(ranks + (k >> 4));
+				const uint32_t r = (rw >> (2u * (k & 15u))) & 3u;
 				const uint32_t v = (rows[ctx] >> (8u * r)) & 3u;
 				ctx = (ctx >> 2) + (v << shift);
 			}
@@ -823,6 +841,9 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			else if (nbytes > 0 && !a.markov_serial && markov_lds_need(nbytes, cap, a.markov_order, a.lds_words * 4u, mdl_lds) <= a.lds_words * 4u) {
 				s_mk_parallel = 1u + (mdl_lds ? 1u : 0u);
 			}
+			else if (nbytes > 0 && !a.markov_serial && a.mkscratch && a.lds_words * 4u >= 2u * kCrackBlock * 4u) {
+				s_mk_parallel = 3u + (markov_model_fits_alone(a.markov_order, a.lds_words * 4u) ? 1u : 0u);      // payload + ranks in the global scratch
+			}
 			else if (nbytes > 0) {
 				const uint8_t* s = code + index_end;
 				const int shift = 2 * (a.markov_order - 1);
@@ -867,8 +888,10 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	if (s_mk_parallel) {
 		uint32_t nc = 0, er = 0;
 		const uint32_t ie = s_index_end;
-		markov_expand_parallel(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), s_mk_parallel == 2u,
-			s_scan, &s_mk_total, nc, er);
+		const uint32_t mode = s_mk_parallel;
+		uint32_t* gsc = a.mkscratch ? a.mkscratch + a.mkbase[zi] : nullptr;
+		if (mode <= 2u) markov_expand_parallel<false>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 2u, s_scan, &s_mk_total, nc, er);
+		else markov_expand_parallel<true>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 4u, s_scan, &s_mk_total, nc, er);
 		if (tid == 0) { s_ncodes = nc; if (er) s_err |= er; }
 		__syncthreads();
 	}
@@ -1256,6 +1279,8 @@ struct ckl_decoder {
 	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off, d_rbase;
 	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap, d_rcap;
 	DevBuf<uint8_t> d_model, d_ctl_kind;
+	DevBuf<uint32_t> d_mkscratch;
+	DevBuf<uint64_t> d_mkbase;
 	DevBuf<uint32_t> d_upacked, d_ctl_dx, d_ctl_dy, d_ctl_lastT, d_seg_x, d_seg_y, d_nodes;
 	DevBuf<int32_t> d_ctl_depth, d_ctl_gmin;
 	DevBuf<unsigned long long> d_ctl_link;
@@ -1377,7 +1402,15 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	upload(d.d_ncap, ncap, s);
 	upload(d.d_rbase, rbase, s);
 	upload(d.d_rcap, rcap, s);
-	if (h.markov_model_order) d.d_upacked.ensure(ctot / 16 + 2ull * d.nslices + 4);
+	std::vector<uint64_t> mkbase;
+	if (h.markov_model_order) {
+		d.d_upacked.ensure(ctot / 16 + 2ull * d.nslices + 4);
+		mkbase.assign(d.nslices, 0);
+		uint64_t mtot = 0;
+		for (uint32_t zi = 0; zi < d.nslices; zi++) { mkbase[zi] = mtot; mtot += (code_len[zi] + 3ull) / 4 + 2 + ccap[zi] / 16 + 2; }
+		upload(d.d_mkbase, mkbase, s);
+		d.d_mkscratch.ensure(mtot + 4);
+	}
 	{
 		// control symbol tables (global fallback of the LDS tables): a control symbol takes two codes
 		const size_t ktot = ctot / 2 + 4ull * d.nslices + 8;
@@ -1639,6 +1672,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.sx = static_cast<int>(h.sx); ca.sy = static_cast<int>(h.sy);
 	ca.xw = byte_width(static_cast<uint64_t>(h.sx) + 1); ca.yw = byte_width(static_cast<uint64_t>(h.sy) + 1);
 	ca.markov_order = h.markov_model_order;
+	ca.mkscratch = h.markov_model_order ? d.d_mkscratch.p : nullptr; ca.mkbase = d.d_mkbase.p;
 	ca.model = d.d_model.p; ca.upacked = h.markov_model_order ? d.d_upacked.p : nullptr;
 	ca.g_kind = d.d_ctl_kind.p; ca.g_dx = d.d_ctl_dx.p; ca.g_dy = d.d_ctl_dy.p;
 	ca.g_depth = d.d_ctl_depth.p; ca.g_lastT = d.d_ctl_lastT.p; ca.g_link = d.d_ctl_link.p;

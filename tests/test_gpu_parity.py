@@ -231,3 +231,12 @@ def test_encoder_components_api(checker):
     want_cc, want_per, _ = checker.connected_components(synth.as_numpy_f(vol))
     assert np.array_equal(nc, want_per.astype(np.uint32))
     assert np.array_equal(cc, want_cc.ravel(order="F").astype(np.uint32) + 1000)
+
+
+def test_big_slice_markov_uses_global_scratch(checker):
+  """A slice whose markov tables exceed the LDS (2048 x 2048, ~400 k codes) still expands in
+  parallel, with payload and ranks in global scratch."""
+  arr = synth.as_numpy_f(synth.voronoi_labels((2048, 2048, 2), np.uint32, seed=61, cell=(32, 32, 8)))
+  for order in (1, 5):
+    b = checker.compress(arr, parallel=8, markov_model_order=order)
+    assert np.array_equal(crackle_amd.decompress(b), arr), order
