@@ -6,8 +6,10 @@ computed by hand-written HIP kernels behind the C-ABI in include/crackle_amd.h.
 """
 from .headers import CrackleHeader, FormatError, LabelFormat, CrackFormat
 from .codec import compress, decompress, decompress_range, header, labels, num_labels, contains
+from .operations import zstack, zsplit, zshatter
 
 __all__ = [
   "CrackleHeader", "FormatError", "LabelFormat", "CrackFormat",
   "compress", "decompress", "decompress_range", "header", "labels", "num_labels", "contains",
+  "zstack", "zsplit", "zshatter",
 ]

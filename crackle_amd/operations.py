@@ -1,0 +1,56 @@
+"""Stream surgery on .ckl bytes without decoding — the slab merge the sharded encoder is built
+on, exposed with the reference's names (crackle/operations.py:424-662: zstack, zsplit,
+zshatter).  Host only (native: ckl_zstack / ckl_zsplit); FLAT label streams."""
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+from . import _lib
+from .codec import header
+
+
+def _take(out: C.c_void_p, n: C.c_uint64) -> bytes:
+  try:
+    return C.string_at(out.value, n.value)
+  finally:
+    _lib.lib().ckl_free(out)
+
+
+def zstack(images: Sequence[bytes]) -> bytes:
+  """Concatenates the streams of consecutive z-slabs into the stream of the whole volume
+  (crackle/operations.py:424-548); byte-identical to compress() of the whole when the slabs
+  agree on the crack format (automated_test.py:468-487)."""
+  bufs = [bytes(b) for b in images]
+  if not bufs:
+    raise ValueError("zstack needs at least one stream")
+  L = _lib.lib()
+  arr = (C.c_char_p * len(bufs))(*bufs)
+  lens = (C.c_uint64 * len(bufs))(*[len(b) for b in bufs])
+  out, n = C.c_void_p(), C.c_uint64()
+  if L.ckl_zstack(arr, lens, len(bufs), C.byref(out), C.byref(n)) != _lib.CKL_OK:
+    raise ValueError(_lib.last_error())
+  return _take(out, n)
+
+
+def _zrange(binary: bytes, z_start: int, z_end: int) -> bytes:
+  out, n = C.c_void_p(), C.c_uint64()
+  if _lib.lib().ckl_zsplit(binary, len(binary), z_start, z_end, C.byref(out), C.byref(n)) != _lib.CKL_OK:
+    raise ValueError(_lib.last_error())
+  return _take(out, n)
+
+
+def zsplit(binary: bytes, z: int) -> Tuple[bytes, bytes, bytes]:
+  """(before, middle, after) streams around slice z (crackle/operations.py:626-647); empty
+  ranges come back as b''."""
+  head = header(binary)
+  if z < 0 or z >= head.sz:
+    raise ValueError(f"{z} is outside the range 0 to {head.sz}.")
+  before = _zrange(binary, 0, z) if z > 0 else b""
+  middle = _zrange(binary, z, z + 1)
+  after = _zrange(binary, z + 1, head.sz) if z + 1 < head.sz else b""
+  return before, middle, after
+
+
+def zshatter(binary: bytes) -> List[bytes]:
+  """One stream per z-slice (crackle/operations.py:649-662)."""
+  head = header(binary)
+  return [_zrange(binary, z, z + 1) for z in range(head.sz)]

@@ -199,6 +199,11 @@ int ckl_pin_labels_host(
 	int stored_width, int auto_bgcolor, int64_t manual_bgcolor,
 	uint8_t** out, uint64_t* out_len);
 
+/* Native form of crackle.operations.zsplit's range helper (crackle/operations.py:550-623):
+ * the stream of slices [z_start, z_end) of a FLAT stream, without decoding (host only).
+ * *out is released with ckl_free. */
+int ckl_zsplit(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, uint8_t** out, uint64_t* out_len);
+
 /* crc32c (Castagnoli; src/crc.hpp:51-57) of a host buffer — exported for tests. */
 uint32_t ckl_crc32c(const uint8_t* data, uint64_t n);
 
