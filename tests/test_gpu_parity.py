@@ -240,3 +240,23 @@ def test_big_slice_markov_uses_global_scratch(checker):
   for order in (1, 5):
     b = checker.compress(arr, parallel=8, markov_model_order=order)
     assert np.array_equal(crackle_amd.decompress(b), arr), order
+
+
+def test_corrupted_streams_return_an_answer(checker):
+  """Bit flips anywhere behind the header (z-index, labels, model, crack codes, crcs): every
+  decode returns a volume or raises; no fault and no hang (tools/fuzz_decode.py runs more)."""
+  rng = np.random.default_rng(17)
+  vol = synth.as_numpy_f(synth.voronoi_labels((160, 128, 3), np.uint16, seed=81, cell=(16, 16, 3)))
+  streams = [golden()["c0_voronoi_u8"], golden()["c0_voronoi_u8_pins_m5"],
+             checker.compress(vol), checker.compress(vol, markov_model_order=4)]
+  outcomes = 0
+  for t in range(120):
+    b = bytearray(streams[t % len(streams)])
+    for _ in range(int(rng.integers(1, 4))):
+      b[int(rng.integers(29, len(b)))] ^= 1 << int(rng.integers(0, 8))
+    try:
+      crackle_amd.decompress(bytes(b))
+    except (RuntimeError, ValueError, crackle_amd.FormatError):
+      pass
+    outcomes += 1
+  assert outcomes == 120

@@ -1,0 +1,40 @@
+"""GPU robustness aid: decodes corrupted copies of golden / seeded streams; every call must
+return (a volume or an error) — no fault, no hang.  Run under `timeout`."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import crackle_amd
+from crackle_amd import synth
+from util import golden
+from oracle import oracle
+
+
+def main():
+  trials = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+  rng = np.random.default_rng(7)
+  chk = oracle.best()
+  streams = [golden()[k] for k in sorted(golden()) if k.startswith("c0_") or "spur" in k or "checker" in k][:12]
+  vol = synth.as_numpy_f(synth.voronoi_labels((256, 192, 4), np.uint32, seed=71, cell=(16, 16, 4)))
+  streams += [chk.compress(vol, markov_model_order=m) for m in (0, 3)]
+  streams += [chk.compress(synth.random_labels((96, 96, 2), np.uint8, seed=72, high=2), markov_model_order=2)]
+  ok = err = 0
+  for t in range(trials):
+    b = bytearray(streams[t % len(streams)])
+    n = len(b)
+    for _ in range(int(rng.integers(1, 4))):
+      # keep the header intact (its crc8 rejects damage early): hit index, labels, codes, crcs
+      pos = int(rng.integers(29, n))
+      b[pos] ^= 1 << int(rng.integers(0, 8))
+    try:
+      crackle_amd.decompress(bytes(b))
+      ok += 1
+    except (RuntimeError, ValueError, crackle_amd.FormatError):
+      err += 1
+    if t % 50 == 49:
+      print(f"trial {t + 1}: decoded {ok}, rejected {err}", flush=True)
+  print(f"done: {trials} corrupted streams, decoded {ok}, rejected {err}, no faults")
+
+
+if __name__ == "__main__":
+  main()
