@@ -1116,6 +1116,8 @@ void crack_pass(
 			std::vector<unsigned long long> g = download(ta_dbg, 16, s);
 			if (g[11]) fprintf(stderr, "[ckl trail diag, k_trail_dfs] slices=%llu iterations/slice=%.0f cycles/iteration=%.0f clock=%.2f GHz (cycles / 100 MHz ticks)\n",
 				g[11], static_cast<double>(g[8]) / g[11], g[8] ? static_cast<double>(g[9]) / g[8] : 0.0, g[10] ? static_cast<double>(g[9]) / (g[10] * 10.0) : 0.0);
+			fprintf(stderr, "[ckl trail diag, k_trail_components, mean cycles per slice] union=%.0f component minima=%.0f starts/splits=%.0f bitmap scan=%.0f\n",
+				static_cast<double>(g[12]) / ns, static_cast<double>(g[13]) / ns, static_cast<double>(g[14]) / ns, static_cast<double>(g[15]) / ns);
 			fprintf(stderr, "[ckl trail diag, k_trail_segments] waves=%llu iterations/wave mean=%.1f max=%llu cycles/wave mean=%.0f max=%llu cycles/iteration=%.0f active lanes/iteration=%.1f\n",
 				g[4], g[4] ? static_cast<double>(g[0]) / g[4] : 0.0, g[1], g[4] ? static_cast<double>(g[2]) / g[4] : 0.0, g[3],
 				g[0] ? static_cast<double>(g[2]) / g[0] : 0.0, g[0] ? static_cast<double>(g[5]) / g[0] : 0.0);

@@ -472,11 +472,15 @@ __device__ __forceinline__ void tuf_unite(uint32_t* L, uint32_t a, uint32_t b) {
 	}
 }
 
+constexpr uint32_t kStartList = 2048;   // start vertices ranked directly up to this many per slice
 constexpr int kCompBlock = 256;      // threads of k_trail_components (one workgroup per slice)
 
 template <bool LDS>
-__device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint32_t zi, uint32_t* parent, uint32_t nn, uint32_t* s_scan) {
+__device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint32_t zi, uint32_t* parent, uint32_t nn, uint32_t* s_scan, uint32_t* s_nstart) {
 	const uint64_t nb = a.nbase[zi];
+	uint32_t* start_tmp = a.items + a.ibase[zi];      // the item table is not in use yet (capacity >= kStartList)
+	unsigned long long dg_t = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+	auto stamp = [&](int slot) { if (a.dbg && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(a.dbg + slot, now - dg_t); dg_t = now; } };
 	const uint32_t* dart_end = a.dart_end + nb * 4u;
 	unsigned long long* compmin = a.compmin + nb;
 	for (uint32_t j = threadIdx.x; j < nn; j += kCompBlock) { parent[j] = j; compmin[j] = ~0ull; }
@@ -486,19 +490,26 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 		const uint32_t e = dart_end[d];
 		if (e == kDartNone) continue;
 		const uint32_t j = d >> 2, j2 = e >> 2;
-		if (j2 != j && j2 < nn) tuf_unite<LDS>(parent, j, j2);
+		if (j < j2 && j2 < nn) tuf_unite<LDS>(parent, j, j2);      // the dart at the far end names the same segment
 	}
 	__syncthreads();
 	if (!LDS) __threadfence();
+	stamp(12);
 	// smallest vertex of every component and a dart that saw it; lanes of a wavefront that
 	// share a root combine first (a slice usually has one giant component)
-	for (uint32_t d0 = 0; d0 < nn * 4u; d0 += kCompBlock) {
-		const uint32_t d = d0 + threadIdx.x;
+	for (uint32_t j0 = 0; j0 < nn; j0 += kCompBlock) {
+		const uint32_t j = j0 + threadIdx.x;
 		uint32_t root = 0xFFFFFFFFu;
 		unsigned long long val = ~0ull;
-		if (d < nn * 4u && dart_end[d] != kDartNone) {
-			root = tuf_find<LDS>(parent, d >> 2);
-			val = (static_cast<unsigned long long>(a.dart_minv[nb * 4u + d]) << 32) | d;
+		if (j < nn) {
+			// the node's own minimum over its (at most four) segments first
+			for (uint32_t k = 0; k < 4u; k++) {
+				const uint32_t d = j * 4u + k;
+				if (dart_end[d] == kDartNone) continue;
+				const unsigned long long v = (static_cast<unsigned long long>(a.dart_minv[nb * 4u + d]) << 32) | d;
+				val = v < val ? v : val;
+			}
+			if (val != ~0ull) root = tuf_find<LDS>(parent, j);
 		}
 		unsigned long long todo = __ballot(root != 0xFFFFFFFFu);
 		while (todo) {
@@ -517,6 +528,7 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 	}
 	__syncthreads();
 	__threadfence();
+	stamp(13);
 	// one thread per component root: mark the start vertex; a start inside a segment
 	// becomes a node of degree 2 (right + down) that splits the segment
 	uint32_t* bits = a.start_bits + static_cast<uint64_t>(zi) * a.start_words;
@@ -527,6 +539,10 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 		const uint32_t minv = static_cast<uint32_t>(m >> 32);
 		const uint32_t d = static_cast<uint32_t>(m);
 		atomicOr(bits + (minv >> 5), 1u << (minv & 31u));
+		{
+			const uint32_t slot = atomicAdd(s_nstart, 1u);
+			if (slot < kStartList) start_tmp[slot] = minv;
+		}
 		const uint64_t db = nb * 4u;
 		const uint32_t len = a.dart_len[db + d];
 		const uint32_t pos = a.dart_minpos[db + d] >> 2, arr = a.dart_minpos[db + d] & 3u;
@@ -546,9 +562,24 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 	}
 	__syncthreads();
 	__threadfence();
-	// start vertices in ascending order: set bits of the bitmap
+	stamp(14);
+	// start vertices in ascending order.  Usually there are a handful: rank them directly;
+	// a slice with many components (noise) scans the bitmap over the vertices instead.
 	uint32_t* starts = a.starts + nb;
 	const uint32_t cap = a.kcap[zi];
+	const uint32_t n_listed = *s_nstart;
+	if (n_listed <= kStartList) {
+		for (uint32_t i = threadIdx.x; i < n_listed; i += kCompBlock) {
+			const uint32_t v = __hip_atomic_load(start_tmp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			uint32_t rank = 0;
+			for (uint32_t q = 0; q < n_listed; q++) rank += __hip_atomic_load(start_tmp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v ? 1u : 0u;
+			if (rank < cap) starts[rank] = v;
+			else atomicOr(a.slice_err + zi, TRAIL_ERR_CAPACITY);
+		}
+		if (threadIdx.x == 0) a.n_starts[zi] = n_listed < cap ? n_listed : cap;
+		stamp(15);
+		return;
+	}
 	constexpr uint32_t kPer = 8;
 	uint32_t carry = 0, err = 0;
 	for (uint32_t w0 = 0; w0 < a.start_words; w0 += kCompBlock * kPer) {
@@ -575,16 +606,20 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 	}
 	if (threadIdx.x == 0) a.n_starts[zi] = carry < cap ? carry : cap;
 	if (err) atomicOr(a.slice_err + zi, err);
+	stamp(15);
 }
 
 // grid = nslices; dynamic LDS = lds_bytes (the union-find table of slices that fit)
 static __global__ void __launch_bounds__(kCompBlock) k_trail_components(TrailArgs a, uint32_t lds_bytes) {
 	extern __shared__ uint32_t s_trail[];
 	__shared__ uint32_t s_scan[kCompBlock / kWave];
+	__shared__ uint32_t s_nstart;
 	const uint32_t zi = blockIdx.x + a.z0;
 	const uint32_t nn = min(a.n_nodes[zi], a.ncap[zi]);
-	if (nn * 4u <= lds_bytes) trail_components_slice<true>(a, zi, s_trail, nn, s_scan);
-	else trail_components_slice<false>(a, zi, a.parent + a.nbase[zi], nn, s_scan);
+	if (threadIdx.x == 0) s_nstart = 0;
+	__syncthreads();
+	if (nn * 4u <= lds_bytes) trail_components_slice<true>(a, zi, s_trail, nn, s_scan, &s_nstart);
+	else trail_components_slice<false>(a, zi, a.parent + a.nbase[zi], nn, s_scan, &s_nstart);
 }
 
 // ---- the serial trail over nodes ------------------------------------------------
