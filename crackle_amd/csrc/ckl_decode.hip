@@ -56,6 +56,8 @@ struct CrackArgs {
 	int xw, yw;
 	int markov_order;
 	const uint8_t* model;        // [4^order][4] rank -> symbol
+	uint32_t* symbuf;            // slices whose codes span several tiles: symbols of every tile parked between the band passes
+	const uint64_t* symbase;     // [nslices] word offsets into symbuf
 	uint32_t* mkscratch;         // markov only: per-slice scratch (payload copy + ranks) for slices whose tables exceed the LDS
 	const uint64_t* mkbase;      // [nslices] word offsets into mkscratch
 	uint32_t* upacked;           // markov only: decoded difference codes, 16 per word (slice base cbase/16 + 2 zi)
@@ -500,7 +502,7 @@ __device__ __forceinline__ void tile_symbols(
 // moves cross planeV, horizontal moves cross planeH; consecutive moves that land in one
 // plane word are OR-ed into it once.  BAND: the target is the LDS band buffer holding
 // rows [band_y0, band_y0 + band_rows) of both planes; otherwise the planes in HBM.
-template <bool BAND>
+template <bool BAND, bool SKIP = false>
 __device__ __forceinline__ void raster_moves(
 	const WordSyms (&ws)[kCrackWords], uint32_t o_t, uint32_t o_dx, uint32_t o_dy, uint32_t valid_segs,
 	const uint32_t* seg_x, const uint32_t* seg_y, uint32_t sx, uint32_t sy, uint32_t row_words,
@@ -517,6 +519,18 @@ __device__ __forceinline__ void raster_moves(
 #pragma unroll
 	for (uint32_t j = 0; j < kCrackWords; j++) {
 		const WordSyms& w = ws[j];
+		if (SKIP && w.isT == 0u) {
+			// (many-band slices) no jump inside this word: its moves stay within a box known from
+			// four popcounts.  A box inside the grid that misses the band (with the one-row reach
+			// of vertical moves) is skipped whole; everything else takes the exact path below.
+			const uint32_t nr = __popc(w.right()), nl = __popc(w.left()), nd = __popc(w.down()), nu = __popc(w.up());
+			const bool inside = x >= nl && x + nr <= sx && y >= nu && y + nd <= sy;
+			const uint32_t lo = y - nu, hi = y + nd;
+			if (inside && (hi + 1u < band_y0 || lo > band_y0 + band_rows)) {
+				x += nr - nl; y += nd - nu;
+				continue;
+			}
+		}
 		for (uint32_t m = w.ms | w.isT; m; m &= m - 1u) {
 			const uint32_t b = __ffs(m) - 1u;
 			if ((w.isT >> b) & 1u) {
@@ -1024,18 +1038,45 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		const bool single_tile = n_codes < kCrackTile;
 		WordSyms ws[kCrackWords];
 		uint32_t o_a = 0, o_dx = 0, o_dy = 0;
+		// A slice with more codes than one tile needs several bands as well (it is big): its
+		// symbols are derived once per tile and parked in HBM instead of once per tile AND band.
+		uint32_t* sym = a.symbuf + a.symbase[zi];
+		constexpr uint32_t kSymWords = 4u * kCrackWords + 3u;
+		if (have_cracks && !single_tile) {
+			TileCarry c;
+			uint32_t ti = 0;
+			for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
+				tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+				uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
+#pragma unroll
+				for (uint32_t j = 0; j < kCrackWords; j++) {
+					sb[(4u * j + 0u) * kCrackBlock] = ws[j].prevs; sb[(4u * j + 1u) * kCrackBlock] = ws[j].ms;
+					sb[(4u * j + 2u) * kCrackBlock] = ws[j].ctl; sb[(4u * j + 3u) * kCrackBlock] = ws[j].isT;
+				}
+				sb[(4u * kCrackWords + 0u) * kCrackBlock] = o_a; sb[(4u * kCrackWords + 1u) * kCrackBlock] = o_dx; sb[(4u * kCrackWords + 2u) * kCrackBlock] = o_dy;
+			}
+		}
 		for (uint32_t y0 = 0; y0 < sy; y0 += band_rows) {
 			const uint32_t rows = min(band_rows, sy - y0);
 			const uint32_t nw = rows * row_words;
 			for (uint32_t i = tid; i < 2u * band_rows * row_words; i += kCrackBlock) band[i] = 0u;
 			__syncthreads();
-			if (have_cracks) {
+			if (have_cracks && single_tile) {
 				TileCarry c;
-				for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile) {
-					if (!single_tile || y0 == 0) {
-						tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+				if (y0 == 0) tile_symbols<true>(words, wshift, n_codes, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+				raster_moves<true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, nullptr, nullptr, rerr);
+			}
+			else if (have_cracks) {
+				uint32_t ti = 0;
+				for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
+					const uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
+#pragma unroll
+					for (uint32_t j = 0; j < kCrackWords; j++) {
+						ws[j].prevs = sb[(4u * j + 0u) * kCrackBlock]; ws[j].ms = sb[(4u * j + 1u) * kCrackBlock];
+						ws[j].ctl = sb[(4u * j + 2u) * kCrackBlock]; ws[j].isT = sb[(4u * j + 3u) * kCrackBlock];
 					}
-					raster_moves<true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, nullptr, nullptr, rerr);
+					o_a = sb[(4u * kCrackWords + 0u) * kCrackBlock]; o_dx = sb[(4u * kCrackWords + 1u) * kCrackBlock]; o_dy = sb[(4u * kCrackWords + 2u) * kCrackBlock];
+					raster_moves<true, true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, nullptr, nullptr, rerr);
 				}
 			}
 			__syncthreads();
@@ -1279,6 +1320,8 @@ struct ckl_decoder {
 	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off, d_rbase;
 	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap, d_rcap;
 	DevBuf<uint8_t> d_model, d_ctl_kind;
+	DevBuf<uint32_t> d_symbuf;
+	DevBuf<uint64_t> d_symbase;
 	DevBuf<uint32_t> d_mkscratch;
 	DevBuf<uint64_t> d_mkbase;
 	DevBuf<uint32_t> d_upacked, d_ctl_dx, d_ctl_dy, d_ctl_lastT, d_seg_x, d_seg_y, d_nodes;
@@ -1402,6 +1445,18 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	upload(d.d_ncap, ncap, s);
 	upload(d.d_rbase, rbase, s);
 	upload(d.d_rcap, rcap, s);
+	std::vector<uint64_t> symbase(d.nslices, 0);
+	{
+		// symbols of multi-tile slices: (4 words per packed word + 3 counts) per thread and tile
+		uint64_t stot = 0;
+		for (uint32_t zi = 0; zi < d.nslices; zi++) {
+			symbase[zi] = stot;
+			const uint64_t tiles = static_cast<uint64_t>(ccap[zi]) / kCrackTile + 1;
+			if (tiles > 1) stot += tiles * (4 * kCrackWords + 3) * kCrackBlock;
+		}
+		upload(d.d_symbase, symbase, s);
+		d.d_symbuf.ensure(stot + 4);
+	}
 	std::vector<uint64_t> mkbase;
 	if (h.markov_model_order) {
 		d.d_upacked.ensure(ctot / 16 + 2ull * d.nslices + 4);
@@ -1672,6 +1727,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.sx = static_cast<int>(h.sx); ca.sy = static_cast<int>(h.sy);
 	ca.xw = byte_width(static_cast<uint64_t>(h.sx) + 1); ca.yw = byte_width(static_cast<uint64_t>(h.sy) + 1);
 	ca.markov_order = h.markov_model_order;
+	ca.symbuf = d.d_symbuf.p; ca.symbase = d.d_symbase.p;
 	ca.mkscratch = h.markov_model_order ? d.d_mkscratch.p : nullptr; ca.mkbase = d.d_mkbase.p;
 	ca.model = d.d_model.p; ca.upacked = h.markov_model_order ? d.d_upacked.p : nullptr;
 	ca.g_kind = d.d_ctl_kind.p; ca.g_dx = d.d_ctl_dx.p; ca.g_dy = d.d_ctl_dy.p;
