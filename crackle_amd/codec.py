@@ -191,3 +191,98 @@ def decompress(
     head = CrackleHeader.frombytes(binary)
     return np.zeros([0, 0, 0], dtype=bool, order="F" if head.fortran_order else "C")
   return img[:, :, nz[0]:nz[-1] + 1]
+
+
+def _label_stats(binary: bytes, device: int, want_boxes: bool):
+  """One device pass over the stream's runs: (labels, counts, sums[n,3], boxes[n,6]).
+  Label values are the unsigned bit patterns the reference keys its dicts with
+  (fastcrackle.cpp:346-420)."""
+  binary = bytes(binary)
+  head = header(binary)
+  L = _lib.lib()
+  handle = C.c_void_p()
+  rc = L.ckl_decoder_create(binary, len(binary), 0, -1, int(device), C.byref(handle))
+  if rc != _lib.CKL_OK:
+    _raise(rc)
+  try:
+    cap = num_labels(binary)
+    lab = np.zeros((cap,), dtype=np.uint64)
+    cnt = np.zeros((cap,), dtype=np.uint64)
+    sums = np.zeros((cap, 3), dtype=np.uint64)
+    box = np.zeros((cap, 6), dtype=np.uint32) if want_boxes else None
+    n = C.c_uint64()
+    rc = L.ckl_decoder_label_stats(
+      handle, cap, lab.ctypes.data, cnt.ctypes.data, sums.ctypes.data,
+      box.ctypes.data if want_boxes else None, C.byref(n))
+    if rc != _lib.CKL_OK:
+      _raise(rc)
+  finally:
+    L.ckl_decoder_destroy(handle)
+  n = int(n.value)
+  if head.data_width < 8:
+    lab &= np.uint64((1 << (8 * head.data_width)) - 1)
+  return lab[:n], cnt[:n], sums[:n], (box[:n] if want_boxes else None)
+
+
+def _require_label(binary: bytes, label: Optional[int]):
+  if label is not None and not contains(binary, label):
+    raise ValueError(f"Label {label} not contained in image.")
+
+
+def voxel_counts(binary: bytes, label: Optional[int] = None, parallel: int = 0, device: int = 0):
+  """Number of voxels per label (codec.py:949-980, operations.hpp:321-372), computed on the
+  device from the decoded runs; the volume is never materialised.  With ``label`` returns
+  that label's count (the reference narrows the z-range first; the count is the same)."""
+  _require_label(binary, label)
+  head = header(binary)
+  if head.voxels() == 0:
+    vcts = {}
+  elif num_labels(binary) == 1:
+    vcts = {int(labels(binary)[0]): head.voxels()}
+  else:
+    lab, cnt, _, _ = _label_stats(binary, device, False)
+    vcts = {int(l): int(c) for l, c in zip(lab, cnt) if c}
+  if label is not None:
+    return vcts[label]
+  return vcts
+
+
+def centroids(binary: bytes, label: Optional[int] = None, parallel: int = 0, device: int = 0):
+  """Centroid (mean x, y, z as float64) per label (codec.py:982-1006,
+  operations.hpp:422-492: integer coordinate sums divided once)."""
+  _require_label(binary, label)
+  head = header(binary)
+  if head.voxels() == 0:
+    out = {}
+  else:
+    lab, cnt, sums, _ = _label_stats(binary, device, False)
+    out = {
+      int(l): s.astype(np.float64) / np.float64(c)
+      for l, c, s in zip(lab, cnt, sums) if c
+    }
+  if label is not None:
+    return out[label]
+  return out
+
+
+def bounding_boxes(binary: bytes, label: Optional[int] = None, parallel: int = 0, no_slice_conversion: bool = False, device: int = 0):
+  """Axis-aligned bounding box per label (codec.py:1008-1067, operations.hpp:541-618):
+  uint32 [xmin, ymin, zmin, xmax, ymax, zmax] (inclusive), or slices unless
+  ``no_slice_conversion``.  A single-label stream reports [0, 0, 0, sx, sy, sz] like the
+  reference (codec.py:1038-1043)."""
+  _require_label(binary, label)
+  head = header(binary)
+  if head.voxels() == 0:
+    bbxes = {}
+  elif num_labels(binary) == 1:
+    bbxes = {int(labels(binary)[0]): np.array([0, 0, 0, head.sx, head.sy, head.sz], dtype=np.uint32)}
+  else:
+    lab, _, _, box = _label_stats(binary, device, True)
+    bbxes = {int(l): b.copy() for l, b in zip(lab, box)}
+  if no_slice_conversion:
+    return bbxes[label] if label is not None else bbxes
+  if label is not None:
+    bbxes = {label: bbxes[label]}
+  for lbl, b in bbxes.items():
+    bbxes[lbl] = (slice(int(b[0]), int(b[3]) + 1), slice(int(b[1]), int(b[4]) + 1), slice(int(b[2]), int(b[5]) + 1))
+  return bbxes[label] if label is not None else bbxes

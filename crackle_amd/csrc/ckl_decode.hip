@@ -1193,6 +1193,117 @@ __global__ void __launch_bounds__(kBlock) k_run_labels(
 }
 
 // ------------------------------------------------------------------------------
+// per-label statistics over the runs (operations.hpp:321-618: voxel_counts, centroids,
+// bounding_boxes).  The reference walks every pixel of the slice's component image into
+// per-component accumulators and merges those into the per-label maps through label_map.
+// A run is a stretch of one row, so its voxel count, coordinate sums and x extent are closed
+// forms of its end points: one workgroup per slice adds its runs into per-component
+// accumulators in LDS, then merges the components into the label table (a binary search per
+// component) with global atomics.  A slice with more components than the LDS holds merges
+// run by run instead.
+// ------------------------------------------------------------------------------
+struct StatsArgs {
+	const uint64_t* table;     // label values as label_map holds them (sign-extended), ascending as unsigned
+	uint32_t n_table;
+	unsigned long long* acc;   // [n_table][4]: N, sum x, sum y, sum z
+	uint32_t* box;             // [n_table][6]: xmin ymin zmin xmax ymax zmax
+	uint32_t sx, n_pixels;
+	uint32_t z_start;
+	uint32_t lds_comps;        // per-component accumulators the workgroup's LDS holds
+};
+
+constexpr int kStatsBlock = 1024;
+constexpr uint32_t kStatsBytesPerComp = 8 + 8 + 4 * 5;   // sum x, sum y, N, xmin, xmax, ymin, ymax
+
+__device__ __forceinline__ uint32_t stats_find(const StatsArgs& sa, uint64_t v) {
+	uint32_t lo = 0, hi = sa.n_table;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (sa.table[mid] < v) lo = mid + 1; else hi = mid;
+	}
+	return (lo < sa.n_table && sa.table[lo] == v) ? lo : 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ void stats_merge(
+	const StatsArgs& sa, uint32_t idx, uint32_t z, unsigned long long n, unsigned long long sumx, unsigned long long sumy,
+	uint32_t xmin, uint32_t xmax, uint32_t ymin, uint32_t ymax
+) {
+	unsigned long long* acc = sa.acc + 4ull * idx;
+	atomicAdd(acc + 0, n); atomicAdd(acc + 1, sumx); atomicAdd(acc + 2, sumy); atomicAdd(acc + 3, n * z);
+	uint32_t* box = sa.box + 6ull * idx;
+	atomicMin(box + 0, xmin); atomicMin(box + 1, ymin); atomicMin(box + 2, z);
+	atomicMax(box + 3, xmax); atomicMax(box + 4, ymax); atomicMax(box + 5, z);
+}
+
+// grid = nslices, block = kStatsBlock, dynamic LDS = lds_comps * kStatsBytesPerComp
+static __global__ void __launch_bounds__(kStatsBlock) k_run_stats(
+	RunArrays r, const uint64_t* __restrict__ label_map, const uint64_t* __restrict__ comp_off,
+	const uint32_t* __restrict__ ncomp_expect, StatsArgs sa
+) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char s_stats[];
+	const uint32_t zi = blockIdx.x;
+	const uint32_t z = sa.z_start + zi;
+	const uint32_t n = r.nruns[zi];
+	const uint32_t nc = ncomp_expect[zi];
+	const uint64_t rb = r.rbase[zi];
+	const uint64_t* lmap = label_map + comp_off[zi];
+	const bool in_lds = nc <= sa.lds_comps;
+	const uint32_t cap = sa.lds_comps;
+	unsigned long long* s_sumx = reinterpret_cast<unsigned long long*>(s_stats);
+	unsigned long long* s_sumy = s_sumx + cap;
+	uint32_t* s_n = reinterpret_cast<uint32_t*>(s_sumy + cap);
+	uint32_t* s_xmin = s_n + cap;
+	uint32_t* s_xmax = s_xmin + cap;
+	uint32_t* s_ymin = s_xmax + cap;
+	uint32_t* s_ymax = s_ymin + cap;
+	if (in_lds) {
+		for (uint32_t c = threadIdx.x; c < nc; c += kStatsBlock) {
+			s_sumx[c] = 0; s_sumy[c] = 0; s_n[c] = 0;
+			s_xmin[c] = 0xFFFFFFFFu; s_xmax[c] = 0; s_ymin[c] = 0xFFFFFFFFu; s_ymax[c] = 0;
+		}
+		__syncthreads();
+	}
+	for (uint32_t i = threadIdx.x; i < n; i += kStatsBlock) {
+		const uint32_t a = r.run_start[rb + i];
+		const uint32_t b = (i + 1 < n) ? r.run_start[rb + i + 1] : sa.n_pixels;
+		const uint32_t cc = r.run_cc[rb + i];
+		if (b <= a) continue;
+		if (cc >= nc) { atomicOr(r.slice_err + zi, ERR_NCOMP); continue; }
+		const uint32_t y = a / sa.sx;
+		const uint32_t x0 = a - y * sa.sx;
+		const uint32_t len = b - a;
+		const uint32_t x1 = x0 + len - 1;
+		const unsigned long long sumx = (static_cast<unsigned long long>(x0) + x1) * len / 2;
+		const unsigned long long sumy = static_cast<unsigned long long>(y) * len;
+		if (in_lds) {
+			atomicAdd(s_sumx + cc, sumx); atomicAdd(s_sumy + cc, sumy); atomicAdd(s_n + cc, len);
+			atomicMin(s_xmin + cc, x0); atomicMax(s_xmax + cc, x1);
+			atomicMin(s_ymin + cc, y); atomicMax(s_ymax + cc, y);
+		}
+		else {
+			const uint32_t idx = stats_find(sa, lmap[cc]);
+			if (idx == 0xFFFFFFFFu) { atomicOr(r.slice_err + zi, ERR_NCOMP); continue; }   // a label outside the table: inconsistent label section
+			stats_merge(sa, idx, z, len, sumx, sumy, x0, x1, y, y);
+		}
+	}
+	if (!in_lds) return;
+	__syncthreads();
+	for (uint32_t c = threadIdx.x; c < nc; c += kStatsBlock) {
+		if (!s_n[c]) continue;
+		const uint32_t idx = stats_find(sa, lmap[c]);
+		if (idx == 0xFFFFFFFFu) { atomicOr(r.slice_err + zi, ERR_NCOMP); continue; }
+		stats_merge(sa, idx, z, s_n[c], s_sumx[c], s_sumy[c], s_xmin[c], s_xmax[c], s_ymin[c], s_ymax[c]);
+	}
+}
+
+static __global__ void k_stats_init(uint32_t* box, uint32_t n_table) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_table) return;
+	box[6ull * i + 0] = box[6ull * i + 1] = box[6ull * i + 2] = 0xFFFFFFFFu;
+	box[6ull * i + 3] = box[6ull * i + 4] = box[6ull * i + 5] = 0;
+}
+
+// ------------------------------------------------------------------------------
 // paint (crackle.hpp:617-656): out[p] = label of p's run
 // ------------------------------------------------------------------------------
 constexpr uint32_t kPaintTile = 4096;          // pixels per workgroup
@@ -1332,6 +1443,10 @@ struct ckl_decoder {
 	DevBuf<uint32_t> d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_ncomp_expect, d_blk_roots;
 	DevBuf<uint16_t> d_run_local;
 	DevBuf<uint64_t> d_run_label;       // typed on use (1..8 bytes per run)
+	DevBuf<uint64_t> d_stats_table;     // ckl_decoder_label_stats: sorted label values
+	DevBuf<unsigned long long> d_stats_acc;
+	DevBuf<uint32_t> d_stats_box;
+	std::vector<uint64_t> stats_table;
 	DevBuf<uint32_t> d_G, d_crc_acc, d_crc_expect, d_slice_err;
 	DevBuf<uint64_t> d_label_map;
 	DevBuf<uint64_t> d_pin_index, d_pin_depth, d_pin_label, d_pin_work_off, d_ccl_id, d_ccl_label;
@@ -1347,6 +1462,7 @@ struct ckl_decoder {
 	uint32_t row_words = 0;
 	uint64_t plane_words = 0;
 	uint32_t max_rcap = 0;
+	uint32_t max_comp = 1;              // most components of one slice in the range
 	uint32_t idbits = 1, crc_fix = 0;
 	bool check_crc = true;
 
@@ -1545,6 +1661,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	// multiplied in over their `idbits` significant bits only (see k_run_resolve)
 	d.check_crc = h.format_version > 0;
 	d.idbits = 1;
+	d.max_comp = max_comp;
 	while (d.idbits < 32 && (1ull << d.idbits) < max_comp) d.idbits++;
 	d.crc_fix = gf_xpow(32 - d.idbits);
 	{
@@ -1650,20 +1767,57 @@ struct StageTimer {
 // component ids (ckl_runs.hpp), component -> label, run -> label, paint.  Flat labels: the
 // label table is ready before the components are, so k_run_assign writes the run labels
 // directly; pins need the component ids first (k_label_map_pins looks pixels up).
+// component -> label table of a pin stream (labels.hpp:540-650); needs run_cc
+void launch_pin_label_map(ckl_decoder& d, const RunGeom& g, const RunArrays& ra) {
+	hipStream_t s = d.stream;
+	const uint64_t nlm = d.total_comp;
+	if (nlm) hipLaunchKernelGGL(k_fill_u64, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d.d_label_map.p, d.bgcolor, nlm);
+	if (d.n_ccl) hipLaunchKernelGGL(k_label_map_ccids, dim3(static_cast<uint32_t>((d.n_ccl + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+		d.d_ccl_id.p, d.d_ccl_label.p, d.n_ccl, d.comp_left, d.comp_left + nlm, d.d_label_map.p);
+	if (d.pin_total_work) hipLaunchKernelGGL(k_label_map_pins, dim3(static_cast<uint32_t>((d.pin_total_work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+		d.d_pin_index.p, d.d_pin_depth.p, d.d_pin_label.p, d.d_pin_work_off.p, d.n_pins, d.pin_total_work,
+		g, ra, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp_expect.p, d.d_label_map.p);
+}
+
+void launch_flat_label_map(ckl_decoder& d) {
+	const Header& h = d.head;
+	const uint64_t nlm = d.total_comp;
+	if (!nlm) return;
+	const uint8_t* keys = d.d_stream.p + d.keys_offset + d.comp_left * static_cast<uint64_t>(d.key_width);
+	const uint8_t* uniq = d.d_stream.p + h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
+	hipLaunchKernelGGL(k_label_map_flat, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, d.stream,
+		keys, d.key_width, uniq, h.stored_data_width, d.num_unique, h.is_signed ? 1u : 0u, nlm, d.d_label_map.p);
+}
+
+// component ids, component -> label, then the statistics kernel instead of the paint
+void launch_resolve_and_stats(ckl_decoder& d, const RunGeom& g, const RunArrays& ra, StageTimer& st, const StatsArgs& stats) {
+	hipStream_t s = d.stream;
+	const uint32_t ns = d.nslices;
+	ResolveScratch rs;
+	rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
+	hipLaunchKernelGGL(k_run_count, dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs);
+	st.done("k_run_count");
+	hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
+	st.done("k_run_rank");
+	RunLabelArgs none = {};
+	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, none);
+	st.done("k_run_assign");
+	if (d.head.label_format == FLAT) launch_flat_label_map(d);
+	else launch_pin_label_map(d, g, ra);
+	st.done("k_label_map");
+	hipLaunchKernelGGL(k_run_stats, dim3(ns), dim3(kStatsBlock), static_cast<size_t>(stats.lds_comps) * kStatsBytesPerComp, s,
+		ra, d.d_label_map.p, d.d_comp_off.p, d.d_ncomp_expect.p, stats);
+	st.done("k_run_stats");
+}
+
 template <typename OUT>
 void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays& ra, void* out_device, int has_label, uint64_t label, StageTimer& st) {
 	const Header& h = d.head;
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 	OUT* run_label = reinterpret_cast<OUT*>(d.d_run_label.p);
-	const uint64_t nlm = d.total_comp;
 	const bool flat = h.label_format == FLAT;
-	if (flat && nlm) {
-		const uint8_t* keys = d.d_stream.p + d.keys_offset + d.comp_left * static_cast<uint64_t>(d.key_width);
-		const uint8_t* uniq = d.d_stream.p + h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
-		hipLaunchKernelGGL(k_label_map_flat, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-			keys, d.key_width, uniq, h.stored_data_width, d.num_unique, h.is_signed ? 1u : 0u, nlm, d.d_label_map.p);
-	}
+	if (flat) launch_flat_label_map(d);
 	if (flat) st.done("k_label_map");
 	ResolveScratch rs;
 	rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
@@ -1681,12 +1835,7 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	else {
 		hipLaunchKernelGGL((k_run_assign<OUT, false>), dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
 		st.done("k_run_assign");
-		if (nlm) hipLaunchKernelGGL(k_fill_u64, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d.d_label_map.p, d.bgcolor, nlm);
-		if (d.n_ccl) hipLaunchKernelGGL(k_label_map_ccids, dim3(static_cast<uint32_t>((d.n_ccl + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-			d.d_ccl_id.p, d.d_ccl_label.p, d.n_ccl, d.comp_left, d.comp_left + nlm, d.d_label_map.p);
-		if (d.pin_total_work) hipLaunchKernelGGL(k_label_map_pins, dim3(static_cast<uint32_t>((d.pin_total_work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-			d.d_pin_index.p, d.d_pin_depth.p, d.d_pin_label.p, d.d_pin_work_off.p, d.n_pins, d.pin_total_work,
-			g, ra, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp_expect.p, d.d_label_map.p);
+		launch_pin_label_map(d, g, ra);
 		st.done("k_label_map");
 		hipLaunchKernelGGL(k_run_labels<OUT>, dim3((d.max_rcap + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s,
 			ra, d.d_label_map.p, d.d_comp_off.p, d.d_ncomp_expect.p, has_label ? 1u : 0u, label, run_label);
@@ -1699,12 +1848,12 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	st.done("k_paint_runs");
 }
 
-void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label) {
+void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label, const StatsArgs* stats = nullptr) {
 	const Header& h = d.head;
 	if (d.sxy == 0 || d.nslices == 0) return;
 	const int ow = has_label ? 1 : h.data_width;
 	const uint64_t need = d.sxy * d.nslices * static_cast<uint64_t>(ow);
-	if (out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
+	if (!stats && out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 	const bool prof = getenv("CKL_PROFILE") != nullptr;
@@ -1780,7 +1929,8 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		st.done("k_run_union_seams");
 	}
 
-	if (has_label || h.data_width == 1) launch_resolve_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
+	if (stats) launch_resolve_and_stats(d, g, ra, st, *stats);
+	else if (has_label || h.data_width == 1) launch_resolve_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
 	else if (h.data_width == 2) launch_resolve_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
 	else if (h.data_width == 4) launch_resolve_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
 	else launch_resolve_and_paint<uint64_t>(d, g, ra, out_device, has_label, label, st);
@@ -1808,6 +1958,59 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		if (e & (ERR_BOC | ERR_RANGE | ERR_CAPACITY)) throw Error(CKL_ERR_RUNTIME, "crackle: crack code is malformed or corrupted on z=" + z);
 		if (e & ERR_NCOMP) throw Error(CKL_ERR_RUNTIME, "crackle: component count does not match the label section on z=" + z);
 		throw Error(CKL_ERR_CRC, "crackle: crack code crc mismatch on z=" + z);
+	}
+}
+
+// voxel_counts / centroids / bounding_boxes of the decoded z-range (operations.hpp:321-618):
+// one pipeline run up to the run labels, then k_run_stats instead of the paint.
+void decoder_label_stats(ckl_decoder& d, uint64_t capacity, uint64_t* labels, uint64_t* counts, uint64_t* sums, uint32_t* boxes, uint64_t* n_out) {
+	const Header& h = d.head;
+	hipStream_t s = d.stream;
+	if (d.sxy == 0 || d.nslices == 0) { *n_out = 0; return; }
+	if (d.stats_table.empty()) {
+		const int sw = h.stored_data_width;
+		std::vector<uint8_t> raw(static_cast<size_t>(d.num_unique) * sw);
+		const uint64_t at = h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
+		if (!raw.empty()) CKL_HIP(hipMemcpyAsync(raw.data(), d.d_stream.p + at, raw.size(), hipMemcpyDeviceToHost, s));
+		CKL_HIP(hipStreamSynchronize(s));
+		std::vector<uint64_t> t(d.num_unique);
+		for (uint64_t i = 0; i < d.num_unique; i++) t[i] = read_stored(h, raw.data(), i * sw);
+		if (h.label_format != FLAT) t.push_back(d.bgcolor);
+		std::sort(t.begin(), t.end());
+		t.erase(std::unique(t.begin(), t.end()), t.end());
+		d.stats_table.swap(t);
+		upload(d.d_stats_table, d.stats_table, s);
+		CKL_HIP(hipStreamSynchronize(s));
+	}
+	const uint64_t nt = d.stats_table.size();
+	*n_out = nt;
+	if (capacity < nt) throw Error(CKL_ERR_ARG, "crackle_amd: label statistics need room for " + std::to_string(nt) + " labels");
+	d.d_stats_acc.ensure(nt * 4);
+	d.d_stats_box.ensure(nt * 6);
+	CKL_HIP(hipMemsetAsync(d.d_stats_acc.p, 0, nt * 4 * sizeof(unsigned long long), s));
+	hipLaunchKernelGGL(k_stats_init, dim3(static_cast<uint32_t>((nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d.d_stats_box.p, static_cast<uint32_t>(nt));
+	StatsArgs sa;
+	sa.table = d.d_stats_table.p; sa.n_table = static_cast<uint32_t>(nt);
+	sa.acc = d.d_stats_acc.p; sa.box = d.d_stats_box.p;
+	sa.sx = h.sx; sa.n_pixels = static_cast<uint32_t>(d.sxy); sa.z_start = static_cast<uint32_t>(d.z_start);
+	{
+		// per-component accumulators in LDS: all of the fullest slice if the workgroup's LDS allows
+		int max_lds = 0;
+		CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, d.device));
+		uint32_t fit = static_cast<uint32_t>(std::max(0, max_lds - 1024)) / kStatsBytesPerComp;
+		if (const char* env = getenv("CKL_STATS_LDS_COMPS")) fit = std::min<uint32_t>(fit, static_cast<uint32_t>(std::max(0, atoi(env))));   // testing: forces the run-by-run merge
+		sa.lds_comps = std::min<uint32_t>((d.max_comp + 1) & ~1u, fit & ~1u);
+		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_run_stats), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sa.lds_comps * kStatsBytesPerComp)));
+	}
+	decoder_run(d, nullptr, 0, 0, 0, &sa);
+	std::vector<unsigned long long> acc(nt * 4);
+	CKL_HIP(hipMemcpyAsync(acc.data(), d.d_stats_acc.p, acc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	if (boxes) CKL_HIP(hipMemcpyAsync(boxes, d.d_stats_box.p, nt * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipStreamSynchronize(s));
+	for (uint64_t i = 0; i < nt; i++) {
+		if (labels) labels[i] = d.stats_table[i];
+		if (counts) counts[i] = acc[4 * i];
+		if (sums) { sums[3 * i] = acc[4 * i + 1]; sums[3 * i + 1] = acc[4 * i + 2]; sums[3 * i + 2] = acc[4 * i + 3]; }
 	}
 }
 
@@ -1856,6 +2059,18 @@ int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_byte
 		select_device(d->device);
 		wait_for_default_stream(d->stream, d->ev_in);
 		decoder_run(*d, out_device, out_capacity_bytes, has_label, label);
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_decoder_label_stats(ckl_decoder* d, uint64_t capacity, uint64_t* labels, uint64_t* counts, uint64_t* sums, uint32_t* boxes, uint64_t* n_labels) {
+	try {
+		if (!d || !n_labels) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		select_device(d->device);
+		wait_for_default_stream(d->stream, d->ev_in);
+		decoder_label_stats(*d, capacity, labels, counts, sums, boxes, n_labels);
 		return CKL_OK;
 	}
 	catch (const Error& e) { set_last_error(e.what()); return e.status; }

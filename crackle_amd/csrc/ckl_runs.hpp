@@ -11,6 +11,8 @@
 
 #include "ckl_device.hpp"
 
+#include <cstdlib>
+
 namespace ckl {
 namespace dev {
 
@@ -245,6 +247,7 @@ static __global__ void __launch_bounds__(kBlock) k_run_union_seams(RunGeom g, Ru
 }
 
 static inline uint32_t run_strip_rows(uint32_t row_words) {
+	if (const char* env = getenv("CKL_STRIP_ROWS")) { const int v = atoi(env); if (v >= 2) return static_cast<uint32_t>(v); }      // tuning aid
 	const uint32_t r = 2048u / (row_words ? row_words : 1u);
 	return r < 2u ? 2u : r;
 }

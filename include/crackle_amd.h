@@ -115,6 +115,21 @@ int ckl_decoder_create(
 	int device, ckl_decoder** out);
 /* Runs the device pipeline into a DEVICE output buffer and waits for it. */
 int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label);
+/* Per-label statistics of the decoder's z-range without materialising the volume:
+ * replaces crackle::operations::voxel_counts / centroids / bounding_boxes
+ * (src/operations.hpp:321-618, bound by src/fastcrackle.cpp:346-420).  The pipeline runs up
+ * to the run labels; a kernel over the runs accumulates, per label of the stream's label
+ * table (flat: the unique list; pins: the unique list and the background color), the voxel
+ * count, the sums of the x, y and z coordinates (centroid = sums / count) and the inclusive
+ * box [xmin ymin zmin xmax ymax zmax] (z in whole-volume coordinates; a label absent from the
+ * range keeps the reference's initial box: mins 0xFFFFFFFF, maxes 0).
+ * Host outputs, any of which may be NULL: labels[capacity] (values as the decoder paints
+ * them, sign-extended to 64 bits, ascending as unsigned), counts[capacity],
+ * sums[3*capacity], boxes[6*capacity].  *n_labels receives the table size; CKL_ERR_ARG
+ * with *n_labels set when capacity is too small. */
+int ckl_decoder_label_stats(
+	ckl_decoder* d, uint64_t capacity, uint64_t* labels, uint64_t* counts,
+	uint64_t* sums, uint32_t* boxes, uint64_t* n_labels);
 /* Elapsed device time of the last run, from HIP events recorded on the library's
  * own stream around (a) the whole pipeline and (b) the dominant kernel. */
 int ckl_decoder_last_timing(const ckl_decoder* d, float* pipeline_ms, float* dominant_kernel_ms);

@@ -260,3 +260,97 @@ def test_corrupted_streams_return_an_answer(checker):
       pass
     outcomes += 1
   assert outcomes == 120
+
+
+def _numpy_label_stats(arr):
+  """What the reference's per-pixel loops compute (operations.hpp:321-618), with numpy."""
+  arr = np.asarray(arr)
+  mask = (1 << (8 * arr.dtype.itemsize)) - 1
+  flat = arr.ravel(order="F")
+  uniq, inv, cts = np.unique(flat, return_inverse=True, return_counts=True)
+  sx, sy, sz = arr.shape
+  idx = np.arange(flat.size, dtype=np.int64)
+  coords = (idx % sx, (idx // sx) % sy, idx // (sx * sy))
+  # float64 weights are exact here: every sum stays far below 2**53
+  sums = np.stack([np.bincount(inv, weights=c.astype(np.float64), minlength=uniq.size) for c in coords], axis=1)
+  counts, cents, boxes = {}, {}, {}
+  for k, u in enumerate(uniq):
+    key = int(u) & mask
+    counts[key] = int(cts[k])
+    cents[key] = sums[k] / float(cts[k])
+    sel = inv == k
+    boxes[key] = tuple(int(np.min(c[sel])) for c in coords) + tuple(int(np.max(c[sel])) for c in coords)
+  return counts, cents, boxes
+
+
+def test_label_statistics_match_numpy(checker):
+  """voxel_counts / centroids / bounding_boxes (codec.py:949-1067) from the device runs."""
+  cases = [
+    (synth.as_numpy_f(synth.voronoi_labels((96, 80, 12), np.uint16, seed=4, cell=(16, 16, 4))), dict()),
+    (synth.as_numpy_f(synth.voronoi_labels((130, 70, 33), np.uint32, seed=12, cell=(20, 20, 10))), dict(allow_pins=True)),
+    (synth.as_numpy_f(synth.voronoi_labels((64, 64, 10), np.uint64, seed=8, cell=(16, 16, 4), offset=1 << 40)), dict(markov_model_order=3)),
+    (synth.random_labels((50, 41, 3), np.uint32, seed=9, high=200), dict()),
+    (SMALL["c0_voronoi_u8"][0], dict(allow_pins=True, markov_model_order=5)),
+  ]
+  for arr, kw in cases:
+    binary = checker.compress(arr, **kw)
+    counts, cents, boxes = _numpy_label_stats(arr)
+    assert crackle_amd.voxel_counts(binary) == counts
+    got_c = crackle_amd.centroids(binary)
+    assert sorted(got_c) == sorted(cents)
+    for k in cents:
+      assert got_c[k].dtype == np.float64 and np.array_equal(got_c[k], cents[k]), (k, got_c[k], cents[k])
+    got_b = crackle_amd.bounding_boxes(binary, no_slice_conversion=True)
+    assert sorted(got_b) == sorted(boxes)
+    for k in boxes:
+      assert got_b[k].dtype == np.uint32 and tuple(int(v) for v in got_b[k]) == boxes[k], (k, got_b[k], boxes[k])
+    some = next(iter(boxes))
+    x0, y0, z0, x1, y1, z1 = boxes[some]
+    assert crackle_amd.bounding_boxes(binary, label=some) == (slice(x0, x1 + 1), slice(y0, y1 + 1), slice(z0, z1 + 1))
+    assert crackle_amd.voxel_counts(binary, label=some) == counts[some]
+    assert np.array_equal(crackle_amd.centroids(binary, label=some), cents[some])
+  with pytest.raises(ValueError):
+    crackle_amd.voxel_counts(checker.compress(cases[0][0]), label=60000)
+  # the reference's shortcuts for single-label streams (codec.py:968-973, 1038-1043)
+  const = np.full((40, 30, 4), 5, np.uint8, order="F")
+  b = checker.compress(const)
+  assert crackle_amd.voxel_counts(b) == {5: 4800}
+  assert tuple(crackle_amd.bounding_boxes(b, no_slice_conversion=True)[5]) == (0, 0, 0, 40, 30, 4)
+  assert np.array_equal(crackle_amd.centroids(b)[5], [19.5, 14.5, 1.5])
+  empty = checker.compress(np.zeros((0, 0, 0), np.uint8, order="F"))
+  assert crackle_amd.voxel_counts(empty) == {} and crackle_amd.centroids(empty) == {} and crackle_amd.bounding_boxes(empty) == {}
+
+
+def test_label_statistics_run_by_run_merge(checker, monkeypatch):
+  """Slices with more components than the LDS accumulators hold merge run by run."""
+  monkeypatch.setenv("CKL_STATS_LDS_COMPS", "8")
+  arr = synth.as_numpy_f(synth.voronoi_labels((130, 70, 33), np.uint32, seed=12, cell=(20, 20, 10)))
+  counts, cents, boxes = _numpy_label_stats(arr)
+  for kw in (dict(), dict(allow_pins=True)):
+    binary = checker.compress(arr, **kw)
+    assert crackle_amd.voxel_counts(binary) == counts
+    got_b = crackle_amd.bounding_boxes(binary, no_slice_conversion=True)
+    assert {k: tuple(int(v) for v in b) for k, b in got_b.items()} == boxes
+    got_c = crackle_amd.centroids(binary)
+    assert all(np.array_equal(got_c[k], cents[k]) for k in cents)
+
+
+def test_label_statistics_full_size_checksums(checker):
+  """At a large size the statistics are checked through what they must add up to: the
+  counts to the voxel total, the coordinate sums to those of the whole grid, the union of
+  the boxes to the volume."""
+  arr = synth.as_numpy_f(synth.voronoi_labels((512, 512, 64), np.uint32, seed=21, cell=(32, 32, 16)))
+  binary = crackle_amd.compress(arr)
+  sx, sy, sz = arr.shape
+  vc = crackle_amd.voxel_counts(binary)
+  assert sum(vc.values()) == arr.size
+  u, c = np.unique(arr, return_counts=True)
+  assert vc == {int(a): int(b) for a, b in zip(u, c)}
+  cents = crackle_amd.centroids(binary)
+  total = sum(np.asarray(cents[k]) * vc[k] for k in vc)
+  want = np.array([(sx - 1) / 2, (sy - 1) / 2, (sz - 1) / 2]) * arr.size
+  assert np.allclose(total, want, rtol=1e-12)
+  bb = crackle_amd.bounding_boxes(binary, no_slice_conversion=True)
+  lo = np.min([b[:3] for b in bb.values()], axis=0)
+  hi = np.max([b[3:] for b in bb.values()], axis=0)
+  assert tuple(lo) == (0, 0, 0) and tuple(hi) == (sx - 1, sy - 1, sz - 1)
