@@ -1315,6 +1315,100 @@ template <> struct Vec4<uint16_t> { typedef ushort4 type; };
 template <> struct Vec4<uint32_t> { typedef uint4 type; };
 template <> struct Vec4<uint64_t> { typedef ulonglong4 type; };
 
+// the output is written once and not read again by the pipeline: non-temporal stores keep it
+// from displacing the run tables in L2
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename OUT, typename V4>
+__device__ __forceinline__ void store_stream(OUT* dst, const V4& v) {
+	if constexpr (sizeof(V4) == 4) __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(dst));
+	else if constexpr (sizeof(V4) == 8) __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&v), reinterpret_cast<u32x2*>(dst));
+	else if constexpr (sizeof(V4) == 16) __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&v), reinterpret_cast<u32x4*>(dst));
+	else {
+		__builtin_nontemporal_store(reinterpret_cast<const u32x4*>(&v)[0], reinterpret_cast<u32x4*>(dst));
+		__builtin_nontemporal_store(reinterpret_cast<const u32x4*>(&v)[1], reinterpret_cast<u32x4*>(dst) + 1);
+	}
+}
+
+// x-fastest output with sx % 4 == 0: a thread paints groups of 4 consecutive pixels (one plane
+// word each) and stores each group as one vector.  All plane loads of the thread are issued
+// first; the first and the last run of the tile fall out of them, the run labels in between are
+// staged in LDS, then the look-ups and the stores follow: two dependent trips to memory per
+// workgroup.  32-bit pixel arithmetic: a slice has fewer than 2^32 pixels.
+template <typename OUT>
+__device__ __forceinline__ void paint_fast(
+	const RunGeom& g, const uint32_t* __restrict__ wb, OUT* s_lab, uint32_t* s_bounds, const OUT* __restrict__ lab,
+	uint32_t nruns, uint32_t zi, uint32_t p_lo, uint32_t p_hi, uint32_t sxy, OUT* __restrict__ oz, bool no_stage
+) {
+	typedef typename Vec4<OUT>::type V4;
+	constexpr uint32_t kIters = kPaintTile / (kBlock * 4);
+	const uint32_t sx = g.sx;
+	const uint32_t* pv = g.planeV + zi * g.plane_words;
+	const uint32_t inv = g.flip ? 0u : 0xFFFFFFFFu;
+	uint32_t p = p_lo + threadIdx.x * 4u;
+	uint32_t y = p / sx;
+	uint32_t x = p - y * sx;
+	uint32_t pp[kIters], bws[kIters], base[kIters], shs[kIters];
+#pragma unroll
+	for (uint32_t it = 0; it < kIters; it++) {
+		const bool ok = p < sxy;
+		const uint32_t w = x >> 5;
+		const uint32_t at = ok ? y * g.row_words + w : 0u;
+		uint32_t bw = pv[at] ^ inv;          // bit set: a run starts at that pixel (bits past the row end are not looked at: sx % 4 == 0)
+		if (w == 0) bw |= 1u;
+		bws[it] = bw; base[it] = wb[at]; shs[it] = x & 31u;
+		pp[it] = ok ? p : 0xFFFFFFFFu;
+		p += kBlock * 4; x += kBlock * 4;
+		if (x >= sx) {
+			x -= sx; y++;
+			if (x >= sx) { const uint32_t q = x / sx; y += q; x -= q * sx; }
+		}
+	}
+	uint32_t run0[kIters], nibs[kIters];
+#pragma unroll
+	for (uint32_t it = 0; it < kIters; it++) {
+		run0[it] = base[it] + __popc(bws[it] & mask_le(shs[it])) - 1u;
+		nibs[it] = ((bws[it] >> shs[it]) >> 1) & 7u;      // break flags of pixels x+1 .. x+3
+		if (pp[it] == p_lo) s_bounds[0] = run0[it];
+		if (pp[it] + 3u == p_hi) s_bounds[1] = run0[it] + __popc(nibs[it]);
+	}
+	__syncthreads();
+	const uint32_t lo = s_bounds[0], hi = s_bounds[1];
+	const bool staged = (hi - lo) < kPaintStage && hi < nruns && !no_stage;
+	if (staged) {
+		for (uint32_t i = threadIdx.x; i <= hi - lo; i += kBlock) s_lab[i] = lab[lo + i];
+	}
+	__syncthreads();
+	const uint32_t last = nruns ? nruns - 1u : 0u;
+	V4 v[kIters];
+	if (staged) {
+#pragma unroll
+		for (uint32_t it = 0; it < kIters; it++) {
+			uint32_t run = pp[it] != 0xFFFFFFFFu ? run0[it] - lo : 0u;
+			const uint32_t nib = pp[it] != 0xFFFFFFFFu ? nibs[it] : 0u;
+			v[it].x = s_lab[run];
+			run += nib & 1u;        v[it].y = s_lab[run];
+			run += (nib >> 1) & 1u; v[it].z = s_lab[run];
+			run += (nib >> 2) & 1u; v[it].w = s_lab[run];
+		}
+	}
+	else {
+#pragma unroll
+		for (uint32_t it = 0; it < kIters; it++) {
+			uint32_t run = run0[it];
+			const uint32_t nib = nibs[it];
+			v[it].x = lab[run < last ? run : last];
+			run += nib & 1u;        v[it].y = lab[run < last ? run : last];
+			run += (nib >> 1) & 1u; v[it].z = lab[run < last ? run : last];
+			run += (nib >> 2) & 1u; v[it].w = lab[run < last ? run : last];
+		}
+	}
+#pragma unroll
+	for (uint32_t it = 0; it < kIters; it++) {
+		if (pp[it] != 0xFFFFFFFFu) store_stream(oz + pp[it], v[it]);
+	}
+}
+
 // FAST: sx % 4 == 0 and x-fastest output: a thread paints 4 consecutive pixels of one
 // plane word per step and stores them as one vector.  grid = (ceil(sxy / 4096), nslices)
 template <typename OUT, bool FAST>
@@ -1323,22 +1417,27 @@ __global__ void __launch_bounds__(kBlock) k_paint_runs(
 	uint64_t sxy, uint32_t nslices, uint32_t fortran_order
 ) {
 	__shared__ OUT s_lab[kPaintStage];
-	__shared__ uint32_t s_lo, s_hi;
+	__shared__ uint32_t s_bounds[2];
 	const uint32_t zi = blockIdx.y;
 	const uint64_t p_lo = static_cast<uint64_t>(blockIdx.x) * kPaintTile;
 	const uint64_t p_hi = (p_lo + kPaintTile < sxy ? p_lo + kPaintTile : sxy) - 1;   // last pixel of the tile
 	const uint32_t* wb = r.word_base + zi * g.plane_words;
 	const OUT* lab = run_label + r.rbase[zi];
 	const uint32_t nruns = r.nruns[zi];
+	if (FAST) {
+		paint_fast<OUT>(g, wb, s_lab, s_bounds, lab, nruns, zi, static_cast<uint32_t>(p_lo), static_cast<uint32_t>(p_hi), static_cast<uint32_t>(sxy),
+			out + static_cast<uint64_t>(zi) * sxy, (fortran_order & 2u) != 0);
+		return;
+	}
 	auto run_of = [&](uint64_t p) {
 		const uint32_t y = static_cast<uint32_t>(p / g.sx);
 		const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
 		return wb[y * g.row_words + (x >> 5)] + __popc(g.breaks(zi, y, x >> 5) & mask_le(x & 31u)) - 1u;
 	};
-	if (threadIdx.x == 0) s_lo = run_of(p_lo);
-	if (threadIdx.x == 1) s_hi = run_of(p_hi);
+	if (threadIdx.x == 0) s_bounds[0] = run_of(p_lo);
+	if (threadIdx.x == 1) s_bounds[1] = run_of(p_hi);
 	__syncthreads();
-	const uint32_t lo = s_lo, hi = s_hi;
+	const uint32_t lo = s_bounds[0], hi = s_bounds[1];
 	const bool staged = (hi - lo) < kPaintStage && hi < nruns;
 	if (staged) {
 		for (uint32_t i = threadIdx.x; i <= hi - lo; i += kBlock) s_lab[i] = lab[lo + i];
@@ -1348,28 +1447,7 @@ __global__ void __launch_bounds__(kBlock) k_paint_runs(
 		if (staged) return s_lab[run - lo];
 		return run < nruns ? lab[run] : static_cast<OUT>(0);
 	};
-	if (FAST) {
-		typedef typename Vec4<OUT>::type V4;
-		OUT* oz = out + static_cast<uint64_t>(zi) * sxy;
-#pragma unroll
-		for (uint32_t it = 0; it < kPaintTile / (kBlock * 4); it++) {
-			const uint64_t p = p_lo + it * (kBlock * 4) + threadIdx.x * 4u;
-			if (p >= sxy) break;
-			const uint32_t y = static_cast<uint32_t>(p / g.sx);
-			const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
-			const uint32_t bw = g.breaks(zi, y, x >> 5);
-			const uint32_t sh = x & 31u;
-			uint32_t run = wb[y * g.row_words + (x >> 5)] + __popc(bw & mask_le(sh)) - 1u;
-			const uint32_t nib = (bw >> sh) >> 1;      // break flags of pixels x+1 .. x+3
-			V4 v;
-			v.x = label_of(run);
-			run += nib & 1u;        v.y = label_of(run);
-			run += (nib >> 1) & 1u; v.z = label_of(run);
-			run += (nib >> 2) & 1u; v.w = label_of(run);
-			*reinterpret_cast<V4*>(oz + p) = v;
-		}
-	}
-	else {
+	{
 		for (uint32_t i = threadIdx.x; i < kPaintTile; i += kBlock) {
 			const uint64_t p = p_lo + i;
 			if (p >= sxy) break;
@@ -1842,8 +1920,8 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 		st.done("k_run_labels");
 	}
 	const uint32_t tiles = static_cast<uint32_t>((d.sxy + kPaintTile - 1) / kPaintTile);
-	const bool fast = h.fortran_order && (h.sx % 4 == 0);
-	if (fast) hipLaunchKernelGGL((k_paint_runs<OUT, true>), dim3(tiles, ns), dim3(kBlock), 0, s, g, ra, run_label, reinterpret_cast<OUT*>(out_device), d.sxy, ns, 1u);
+	const bool fast = h.fortran_order && (h.sx % 4 == 0) && d.sxy < 0xFFFF0000ull;   // 32-bit pixel arithmetic in the fast path
+	if (fast) hipLaunchKernelGGL((k_paint_runs<OUT, true>), dim3(tiles, ns), dim3(kBlock), 0, s, g, ra, run_label, reinterpret_cast<OUT*>(out_device), d.sxy, ns, getenv("CKL_PAINT_NOSTAGE") ? 3u : 1u);
 	else hipLaunchKernelGGL((k_paint_runs<OUT, false>), dim3(tiles, ns), dim3(kBlock), 0, s, g, ra, run_label, reinterpret_cast<OUT*>(out_device), d.sxy, ns, h.fortran_order ? 1u : 0u);
 	st.done("k_paint_runs");
 }
