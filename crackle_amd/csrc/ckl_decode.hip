@@ -1517,6 +1517,7 @@ struct ckl_decoder {
 	DevBuf<int32_t> d_ctl_depth, d_ctl_gmin;
 	DevBuf<unsigned long long> d_ctl_link;
 	uint32_t lds_controls = 0;          // capacity of k_decode_cracks' LDS control tables
+	size_t lds_bytes = 0;               // dynamic LDS of k_decode_cracks: the tables, or everything the workgroup may have (raster bands)
 	DevBuf<uint32_t> d_planes;          // V then H
 	DevBuf<uint32_t> d_word_base, d_parent, d_run_start, d_run_cc, d_nruns, d_ncomp, d_ncomp_expect, d_blk_roots;
 	DevBuf<uint16_t> d_run_local;
@@ -1878,7 +1879,7 @@ void launch_resolve_and_stats(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
 	st.done("k_run_rank");
 	RunLabelArgs none = {};
-	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, none);
+	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, none);
 	st.done("k_run_assign");
 	if (d.head.label_format == FLAT) launch_flat_label_map(d);
 	else launch_pin_label_map(d, g, ra);
@@ -1907,11 +1908,11 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	la.label_map = d.d_label_map.p; la.comp_off = d.d_comp_off.p; la.ncomp_expect = d.d_ncomp_expect.p;
 	la.has_label = has_label ? 1u : 0u; la.label = label; la.run_label = run_label;
 	if (flat) {
-		hipLaunchKernelGGL((k_run_assign<OUT, true>), dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
+		hipLaunchKernelGGL((k_run_assign<OUT, true>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
 		st.done("k_run_assign");
 	}
 	else {
-		hipLaunchKernelGGL((k_run_assign<OUT, false>), dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
+		hipLaunchKernelGGL((k_run_assign<OUT, false>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
 		st.done("k_run_assign");
 		launch_pin_label_map(d, g, ra);
 		st.done("k_label_map");
@@ -1940,7 +1941,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	StageTimer st(d, s);
 	// k_decode_cracks builds the planes band by band in LDS when at least one row of both
 	// planes fits behind the segment tables; otherwise it ORs bits into zeroed planes in HBM
-	const size_t crack_lds = crack_lds_bytes(d.lds_controls);
+	const size_t crack_lds = d.lds_bytes;
 	const bool lds_raster = !getenv("CKL_NO_LDS_RASTER") &&
 		crack_lds >= crack_lds_seg_bytes(d.lds_controls) + 2ull * d.row_words * sizeof(uint32_t);
 	if (!lds_raster) CKL_HIP(hipMemsetAsync(d.d_planes.p, 0, 2 * d.plane_words * ns * sizeof(uint32_t), s));
@@ -2119,7 +2120,10 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 			if (crack_lds_bytes(nctl) > budget) nctl = 0;
 			if (nctl > 32000) nctl = 32000;
 			d->lds_controls = nctl;
-			const int bytes = static_cast<int>(crack_lds_bytes(nctl));
+			// one workgroup per CU either way: the raster phase takes whatever LDS is left for
+			// its bands (1024x1024 slices: 2 passes instead of 3)
+			d->lds_bytes = getenv("CKL_LDS_CONTROLS") ? crack_lds_bytes(nctl) : std::max(crack_lds_bytes(nctl), budget & ~static_cast<size_t>(15));
+			const int bytes = static_cast<int>(d->lds_bytes);
 			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 		}

@@ -329,37 +329,62 @@ struct RunLabelArgs {
 	void* run_label;
 };
 
-// step 3, grid = (nblk, nslices): root (a short chain: strip root -> roots of the strips
-// above), component id of every run + its crc contribution [+ its label]
+// step 3, grid = (run_assign_blocks(nblk), nslices): root (a short chain: strip root -> roots
+// of the strips above), component id of every run + its crc contribution [+ its label].
+// Every load here depends on the one before it (parent chain -> rank tables -> label), so a
+// thread resolves kAssignRuns runs side by side to keep that many chains in flight.
+constexpr uint32_t kAssignRuns = 4;
+static inline uint32_t run_assign_blocks(uint32_t nblk) { return (nblk + kAssignRuns - 1) / kAssignRuns; }
+
 template <typename OUT, bool LABELS>
 static __global__ void __launch_bounds__(kBlock) k_run_assign(RunArrays r, ResolveScratch rs, const uint32_t* __restrict__ G, uint32_t n_pixels, uint32_t idbits_in, uint32_t* __restrict__ crc_acc, RunLabelArgs la) {
 	__shared__ uint32_t s_scan[kWaves];
 	const uint32_t zi = blockIdx.y;
 	const uint32_t n = r.nruns[zi];
-	if (blockIdx.x * kBlock >= n) return;
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t i0 = blockIdx.x * (kBlock * kAssignRuns) + threadIdx.x;
+	if (blockIdx.x * (kBlock * kAssignRuns) >= n) return;
 	const uint64_t rb = r.rbase[zi];
 	const uint32_t idbits = idbits_in ? idbits_in : (n > 1 ? 32u - __clz(n - 1) : 1u);
+	const uint32_t* parent = r.parent + rb;
+	uint32_t root[kAssignRuns], p[kAssignRuns], a[kAssignRuns], b[kAssignRuns];
+	bool live[kAssignRuns];
+#pragma unroll
+	for (uint32_t k = 0; k < kAssignRuns; k++) {
+		const uint32_t i = i0 + k * kBlock;
+		live[k] = i < n;
+		root[k] = live[k] ? i : 0u;
+		p[k] = live[k] ? parent[i] : 0u;
+		a[k] = live[k] ? r.run_start[rb + i] : 0u;
+		b[k] = (live[k] && i + 1 < n) ? r.run_start[rb + i + 1] : n_pixels;
+	}
+	bool more;
+	do {
+		more = false;
+#pragma unroll
+		for (uint32_t k = 0; k < kAssignRuns; k++) {
+			if (p[k] != root[k]) { root[k] = p[k]; p[k] = parent[p[k]]; more = true; }
+		}
+	} while (more);
+	uint32_t cc[kAssignRuns];
+#pragma unroll
+	for (uint32_t k = 0; k < kAssignRuns; k++) cc[k] = rs.blk_roots[zi * rs.nblk + (root[k] >> 8)] + rs.run_local[rb + root[k]];
 	uint32_t part = 0;
-	if (i < n) {
-		const uint32_t* parent = r.parent + rb;
-		uint32_t root = i, p = parent[i];
-		while (p != root) { root = p; p = parent[p]; }
-		const uint32_t cc = rs.blk_roots[zi * rs.nblk + (root >> 8)] + rs.run_local[rb + root];
+#pragma unroll
+	for (uint32_t k = 0; k < kAssignRuns; k++) {
+		if (!live[k]) continue;
+		const uint32_t i = i0 + k * kBlock;
 		if (LABELS) {
 			uint64_t v = 0;
-			if (cc < la.ncomp_expect[zi]) v = la.label_map[la.comp_off[zi] + cc];
+			if (cc[k] < la.ncomp_expect[zi]) v = la.label_map[la.comp_off[zi] + cc[k]];
 			else atomicOr(r.slice_err + zi, ERR_NCOMP);
 			if (la.has_label) v = (v == la.label);
 			static_cast<OUT*>(la.run_label)[rb + i] = static_cast<OUT>(v);
 		}
-		else r.run_cc[rb + i] = cc;
-		const uint32_t a = r.run_start[rb + i];
-		const uint32_t b = (i + 1 < n) ? r.run_start[rb + i + 1] : n_pixels;
-		uint32_t wgt = G[n_pixels - a] ^ G[n_pixels - b];
+		else r.run_cc[rb + i] = cc[k];
+		uint32_t wgt = G[n_pixels - a[k]] ^ G[n_pixels - b[k]];
 		// sum over set bits j < idbits of c:  wgt * x^(idbits-1-j)
 		for (int j = static_cast<int>(idbits) - 1; j >= 0; j--) {
-			part ^= ((cc >> j) & 1u) ? wgt : 0u;
+			part ^= ((cc[k] >> j) & 1u) ? wgt : 0u;
 			wgt = (wgt >> 1) ^ ((wgt & 1u) ? kCrcPoly : 0u);
 		}
 	}
@@ -373,7 +398,7 @@ static inline void launch_run_resolve(hipStream_t s, uint32_t nslices, const Run
 	hipLaunchKernelGGL(k_run_count, dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs);
 	hipLaunchKernelGGL(k_run_rank, dim3(nslices), dim3(kBlock), 0, s, r, rs, idbits_in, crc_acc, idbits_out);
 	RunLabelArgs none = {};
-	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs, G, n_pixels, idbits_in, crc_acc, none);
+	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(run_assign_blocks(rs.nblk), nslices), dim3(kBlock), 0, s, r, rs, G, n_pixels, idbits_in, crc_acc, none);
 }
 
 // G[k*B + i] = G[k*B] ^ x^(32 k B) * G[i]   (B = 1024; per-block constants from the host)
