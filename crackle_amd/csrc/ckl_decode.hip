@@ -582,6 +582,75 @@ __device__ __forceinline__ void raster_moves(
 	else if (cur_word) atomicOr(cur_word, cur_bits);
 }
 
+// The same for the LDS band buffer (rows [band_y0, band_y0 + band_rows) of both planes, H behind
+// V), written for the instruction count: the loop body runs 128 times per thread and pass and is
+// what k_decode_cracks spends most of its time in.  One predicated ds_or per move, no branches
+// besides the jump at a 't': vertical moves of a trail change the row every time and so hardly
+// ever share a plane word with their predecessor; collecting bits per word is not worth its
+// compares here.
+template <bool SKIP>
+__device__ __forceinline__ void raster_band(
+	const WordSyms (&ws)[kCrackWords], uint32_t o_t, uint32_t o_dx, uint32_t o_dy, uint32_t valid_segs,
+	const uint32_t* seg_x, const uint32_t* seg_y, uint32_t sx, uint32_t sy, uint32_t row_words,
+	uint32_t* band, uint32_t band_y0, uint32_t band_rows, uint32_t& rerr
+) {
+	uint32_t bx = 0, by = 0;
+	uint32_t act = o_t < valid_segs ? 1u : 0u;
+	if (act) { bx = seg_x[o_t]; by = seg_y[o_t]; }
+	uint32_t x = bx + o_dx, y = by + o_dy;
+	const uint32_t h_off = band_rows * row_words;
+	uint32_t bad = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < kCrackWords; j++) {
+		const WordSyms& w = ws[j];
+		if (SKIP && w.isT == 0u) {
+			// (many-band slices) no jump inside this word: its moves stay within a box known from
+			// four popcounts.  A box inside the grid that misses the band (with the one-row reach
+			// of vertical moves) is skipped whole; everything else takes the exact path below.
+			const uint32_t nr = __popc(w.right()), nl = __popc(w.left()), nd = __popc(w.down()), nu = __popc(w.up());
+			const bool inside = x >= nl && x + nr <= sx && y >= nu && y + nd <= sy;
+			const uint32_t lo = y - nu, hi = y + nd;
+			if (inside && (hi + 1u < band_y0 || lo > band_y0 + band_rows)) {
+				x += nr - nl; y += nd - nu;
+				continue;
+			}
+		}
+		const uint32_t prevs = w.prevs, isT = w.isT;
+		for (uint32_t m = w.ms | isT; m; m &= m - 1u) {
+			const uint32_t b = __ffs(m) - 1u;
+			if ((isT >> b) & 1u) {
+				o_t++;
+				act = o_t < valid_segs ? 1u : 0u;
+				if (act) {
+					const uint32_t nbx = seg_x[o_t], nby = seg_y[o_t];
+					x += nbx - bx; y += nby - by;
+					bx = nbx; by = nby;
+				}
+				continue;
+			}
+			// selects are written as masks: the compiler turns ?: on lane-varying conditions into
+			// divergent branches here, which cost more than the arithmetic they guard
+			const uint32_t k = (prevs >> b) & 3u;                 // SYM_U 0, SYM_R 1, SYM_D 2, SYM_L 3
+			const uint32_t hmask = 0u - (k & 1u);                 // all ones: horizontal move
+			const uint32_t neg = ((k >> 1) ^ k ^ 1u) & 1u;        // U or L
+			const uint32_t step = 1u - 2u * neg;                  // +1 / -1
+			const uint32_t nx = x + (step & hmask), ny = y + (step & ~hmask);
+			const uint32_t col = min(x, nx), row = min(y, ny);    // the crossed crack sits at the smaller vertex
+			const uint32_t in_range = static_cast<uint32_t>(max(x, nx) <= sx) & static_cast<uint32_t>(max(y, ny) <= sy);
+			// a move along the outer border crosses no crack of the planes: the coordinate across
+			// the move must be interior (1 .. size-1), the one along it inside (0 .. size-1)
+			const uint32_t across = (row & hmask) | (col & ~hmask), across_n = (sy & hmask) | (sx & ~hmask);
+			const uint32_t along = (col & hmask) | (row & ~hmask), along_n = (sx & hmask) | (sy & ~hmask);
+			const uint32_t ok = static_cast<uint32_t>(across - 1u < across_n - 1u) & static_cast<uint32_t>(along < along_n);
+			const uint32_t rel = row - band_y0;
+			bad |= act & (in_range ^ 1u);
+			if (act & in_range & ok & (rel < band_rows ? 1u : 0u)) atomicOr(band + (h_off & hmask) + rel * row_words + (col >> 5), 1u << (col & 31u));
+			x = nx; y = ny;
+		}
+	}
+	if (bad) rerr |= ERR_RANGE;
+}
+
 // ------------------------------------------------------------------------------
 // markov bitstream -> difference codes (markov.hpp:268-313), all threads of the workgroup
 // ------------------------------------------------------------------------------
@@ -795,6 +864,14 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		if (DIAG && threadIdx.x == 0 && diag) {
 			const unsigned long long now = __builtin_amdgcn_s_memtime();
 			diag[static_cast<uint64_t>(blockIdx.x) * 16 + slot] = now - d_t;
+			d_t = now;
+		}
+	};
+
+	auto stamp_add = [&](int slot) {      // like stamp, accumulating (phases that repeat per band)
+		if (DIAG && threadIdx.x == 0 && diag) {
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			diag[static_cast<uint64_t>(blockIdx.x) * 16 + slot] += now - d_t;
 			d_t = now;
 		}
 	};
@@ -1061,10 +1138,14 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			const uint32_t nw = rows * row_words;
 			for (uint32_t i = tid; i < 2u * band_rows * row_words; i += kCrackBlock) band[i] = 0u;
 			__syncthreads();
+			stamp_add(14);
 			if (have_cracks && single_tile) {
 				TileCarry c;
-				if (y0 == 0) tile_symbols<true>(words, wshift, n_codes, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
-				raster_moves<true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, nullptr, nullptr, rerr);
+				if (y0 == 0) {
+					tile_symbols<true>(words, wshift, n_codes, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+					stamp_add(6);
+				}
+				raster_band<false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
 			}
 			else if (have_cracks) {
 				uint32_t ti = 0;
@@ -1076,15 +1157,17 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 						ws[j].ctl = sb[(4u * j + 2u) * kCrackBlock]; ws[j].isT = sb[(4u * j + 3u) * kCrackBlock];
 					}
 					o_a = sb[(4u * kCrackWords + 0u) * kCrackBlock]; o_dx = sb[(4u * kCrackWords + 1u) * kCrackBlock]; o_dy = sb[(4u * kCrackWords + 2u) * kCrackBlock];
-					raster_moves<true, true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, nullptr, nullptr, rerr);
+					raster_band<true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
 				}
 			}
 			__syncthreads();
+			stamp_add(7);
 			uint32_t* dv = pv + static_cast<uint64_t>(y0) * row_words;
 			uint32_t* dh = ph + static_cast<uint64_t>(y0) * row_words;
 			const uint32_t* bh = band + band_rows * row_words;
 			for (uint32_t i = tid; i < nw; i += kCrackBlock) { dv[i] = band[i]; dh[i] = bh[i]; }
 			__syncthreads();
+			stamp_add(15);
 		}
 	}
 	else if (have_cracks) {
@@ -1979,7 +2062,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		CKL_HIP(hipStreamSynchronize(s));
 		double m[16] = { 0 };
 		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
-		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f | match: depth/lastT=%.0f gmin=%.0f links=%.0f jump=%.0f search steps total=%.0f max/thread=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[8], m[9], m[10], m[11], m[12], m[13]);
+		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f | match: depth/lastT=%.0f gmin=%.0f links=%.0f jump=%.0f search steps total=%.0f max/thread=%.0f | raster: zero=%.0f symbols=%.0f moves=%.0f store=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[6], m[7], m[15]);
 	}
 	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, static_cast<unsigned long long*>(nullptr));
 	st.done("k_decode_cracks");
@@ -1999,7 +2082,8 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		// launch_run_union / launch_run_resolve of ckl_runs.hpp, kernel by kernel for the stage timers
 		const uint32_t rows = run_strip_rows(g.row_words);
 		const uint32_t strips = (g.sy + rows - 1) / rows;
-		hipLaunchKernelGGL(k_run_union_strips, dim3(strips, ns), dim3(kBlock), 0, s, g, ra, rows);
+		const uint32_t sruns = run_strip_runs();
+		hipLaunchKernelGGL(k_run_union_strips, dim3(strips, ns), dim3(kBlock), sruns * sizeof(uint32_t), s, g, ra, rows, sruns);
 		st.done("k_run_union_strips");
 		if (strips > 1) {
 			const uint32_t words = (strips - 1) * g.row_words;

@@ -147,7 +147,7 @@ __device__ __forceinline__ void run_unite(uint32_t* L, uint32_t a, uint32_t b) {
 // the global forest only ever sees trees of depth one plus the few unions across strip
 // seams (k_run_union_seams).  A strip with more runs than the LDS table holds falls back
 // to the global forest for its own rows.
-constexpr uint32_t kStripRuns = 12288;      // LDS table: 48 KiB
+constexpr uint32_t kStripRuns = 3072;       // LDS table: 12 KiB, so that the thread count and not the LDS bounds the workgroups per CU
 
 __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* L, uint32_t a) {
 	uint32_t p = L[a];
@@ -172,8 +172,8 @@ __device__ __forceinline__ void lds_unite(uint32_t* L, uint32_t a, uint32_t b) {
 }
 
 // grid = (strips per slice, nslices); strip_rows rows per strip
-static __global__ void __launch_bounds__(kBlock) k_run_union_strips(RunGeom g, RunArrays r, uint32_t strip_rows) {
-	__shared__ uint32_t s_parent[kStripRuns];
+static __global__ void __launch_bounds__(kBlock) k_run_union_strips(RunGeom g, RunArrays r, uint32_t strip_rows, uint32_t strip_runs) {
+	extern __shared__ uint32_t s_parent[];      // strip_runs entries
 	const uint32_t zi = blockIdx.y;
 	const uint32_t y0 = blockIdx.x * strip_rows;
 	if (y0 >= g.sy) return;
@@ -184,32 +184,43 @@ static __global__ void __launch_bounds__(kBlock) k_run_union_strips(RunGeom g, R
 	const uint32_t base1 = (y1 < g.sy) ? min(wb[static_cast<uint64_t>(y1) * g.row_words], n) : n;
 	const uint32_t nloc = base1 - base0;
 	uint32_t* parent = r.parent + r.rbase[zi];
-	const bool local = nloc <= kStripRuns;
+	const bool local = nloc <= strip_runs;
 	if (local) for (uint32_t j = threadIdx.x; j < nloc; j += kBlock) s_parent[j] = j;
 	else for (uint32_t j = threadIdx.x; j < nloc; j += kBlock) parent[base0 + j] = base0 + j;
 	__syncthreads();
 	if (!local) __threadfence();
 	const uint32_t w_end = (y1 - y0) * g.row_words;
-	for (uint32_t wl = g.row_words + threadIdx.x; wl < w_end; wl += kBlock) {   // rows y0+1 .. y1-1
-		const uint32_t yl = wl / g.row_words;
-		const uint32_t w = wl - yl * g.row_words;
-		const uint32_t y = y0 + yl;
-		const uint32_t up = g.ups(zi, y, w);
-		if (!up) continue;
-		const uint32_t prev_bit = w ? (g.ups(zi, y, w - 1) >> 31) : 0u;
-		const uint32_t b_here = g.breaks(zi, y, w);
-		const uint32_t b_up = g.breaks(zi, y - 1, w);
-		uint32_t cand = up & (~((up << 1) | prev_bit) | b_here | b_up);
-		const uint64_t wi = static_cast<uint64_t>(y) * g.row_words + w;
-		const uint32_t base_here = wb[wi], base_up = wb[wi - g.row_words];
-		for (; cand; cand &= cand - 1u) {
-			const uint32_t bit = __ffs(cand) - 1;
-			const uint32_t m = mask_le(bit);
-			const uint32_t ra = base_here + __popc(b_here & m) - 1u;
-			const uint32_t rb = base_up + __popc(b_up & m) - 1u;
-			if (ra >= base1 || rb >= base1 || rb < base0) continue;      // capacity overflow upstream (flagged there)
-			if (local) lds_unite(s_parent, ra - base0, rb - base0);
-			else run_unite(parent, ra, rb);
+	// the plane words of kUnionBatch steps are loaded before the first union: the unions are a
+	// serial, divergent walk in LDS and would otherwise wait for memory once per word
+	constexpr uint32_t kUnionBatch = 4;
+	for (uint32_t wl0 = g.row_words + threadIdx.x; wl0 < w_end; wl0 += kBlock * kUnionBatch) {   // rows y0+1 .. y1-1
+		uint32_t cand[kUnionBatch], b_here[kUnionBatch], b_up[kUnionBatch], base_here[kUnionBatch], base_up[kUnionBatch];
+#pragma unroll
+		for (uint32_t k = 0; k < kUnionBatch; k++) {
+			const uint32_t wl = wl0 + k * kBlock;
+			const bool in = wl < w_end;
+			const uint32_t yl = in ? wl / g.row_words : 1u;
+			const uint32_t w = in ? wl - yl * g.row_words : 0u;
+			const uint32_t y = y0 + yl;
+			const uint32_t up = in ? g.ups(zi, y, w) : 0u;
+			const uint32_t prev_bit = (in && w) ? (g.ups(zi, y, w - 1) >> 31) : 0u;
+			b_here[k] = g.breaks(zi, y, w);
+			b_up[k] = g.breaks(zi, y - 1, w);
+			cand[k] = up & (~((up << 1) | prev_bit) | b_here[k] | b_up[k]);
+			const uint64_t wi = static_cast<uint64_t>(y) * g.row_words + w;
+			base_here[k] = wb[wi]; base_up[k] = wb[wi - g.row_words];
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < kUnionBatch; k++) {
+			for (uint32_t c = cand[k]; c; c &= c - 1u) {
+				const uint32_t bit = __ffs(c) - 1;
+				const uint32_t m = mask_le(bit);
+				const uint32_t ra = base_here[k] + __popc(b_here[k] & m) - 1u;
+				const uint32_t rb = base_up[k] + __popc(b_up[k] & m) - 1u;
+				if (ra >= base1 || rb >= base1 || rb < base0) continue;      // capacity overflow upstream (flagged there)
+				if (local) lds_unite(s_parent, ra - base0, rb - base0);
+				else run_unite(parent, ra, rb);
+			}
 		}
 	}
 	if (!local) return;
@@ -246,16 +257,23 @@ static __global__ void __launch_bounds__(kBlock) k_run_union_seams(RunGeom g, Ru
 	}
 }
 
+// LDS table of a strip: the smaller, the more workgroups share a CU (the kernel waits on
+// memory and LDS round trips, not on arithmetic); strips with more runs use the global forest
+static inline uint32_t run_strip_runs() {
+	if (const char* env = getenv("CKL_STRIP_RUNS")) { const int v = atoi(env); if (v >= 64 && v <= 16384) return static_cast<uint32_t>(v); }      // tuning aid
+	return kStripRuns;
+}
 static inline uint32_t run_strip_rows(uint32_t row_words) {
 	if (const char* env = getenv("CKL_STRIP_ROWS")) { const int v = atoi(env); if (v >= 2) return static_cast<uint32_t>(v); }      // tuning aid
-	const uint32_t r = 2048u / (row_words ? row_words : 1u);
+	const uint32_t r = 1024u / (row_words ? row_words : 1u);      // 32K pixels per strip: the LDS table covers one run per ~10 pixels
 	return r < 2u ? 2u : r;
 }
 // all unions of every slice on one stream (replaces a single k_run_union launch)
 static inline void launch_run_union(hipStream_t s, uint32_t nslices, const RunGeom& g, const RunArrays& r) {
 	const uint32_t rows = run_strip_rows(g.row_words);
 	const uint32_t strips = (g.sy + rows - 1) / rows;
-	hipLaunchKernelGGL(k_run_union_strips, dim3(strips, nslices), dim3(kBlock), 0, s, g, r, rows);
+	const uint32_t sruns = run_strip_runs();
+	hipLaunchKernelGGL(k_run_union_strips, dim3(strips, nslices), dim3(kBlock), sruns * sizeof(uint32_t), s, g, r, rows, sruns);
 	if (strips > 1) {
 		const uint32_t words = (strips - 1) * g.row_words;
 		hipLaunchKernelGGL(k_run_union_seams, dim3((words + kBlock - 1) / kBlock, nslices), dim3(kBlock), 0, s, g, r, rows);
