@@ -192,11 +192,33 @@ static void crc_tab_init() {
 		}
 	}
 }
-// SSE4.2 crc32 instruction (the same polynomial); three independent streams would be
-// faster still, one is plenty for the label section (< 1 MB) and the z-index
+// SSE4.2 crc32 instruction (the same polynomial).
 #if defined(__x86_64__)
+// The crc32 instruction has a latency of three cycles and a throughput of one per cycle: three
+// independent chains over three thirds of the buffer run at full rate, and the thirds combine
+// through  state(c, M) = c * x^bits(M) + state(0, M)  in GF(2)[x]/P.
 __attribute__((target("sse4.2"))) static uint32_t crc32c_sse42(const uint8_t* data, uint64_t n) {
 	uint64_t crc = 0xFFFFFFFFu;
+	if (n >= 3 * 1024) {
+		const uint64_t words = n / 24;             // 8-byte words per third
+		const uint8_t* pa = data;
+		const uint8_t* pb = data + 8 * words;
+		const uint8_t* pc = data + 16 * words;
+		uint64_t a = crc, b = 0, c = 0;
+		for (uint64_t i = 0; i < words; i++) {
+			uint64_t wa, wb, wc;
+			memcpy(&wa, pa + 8 * i, 8); memcpy(&wb, pb + 8 * i, 8); memcpy(&wc, pc + 8 * i, 8);
+			a = __builtin_ia32_crc32di(a, wa);
+			b = __builtin_ia32_crc32di(b, wb);
+			c = __builtin_ia32_crc32di(c, wc);
+		}
+		const uint32_t shift = gf_xpow(64ull * words);
+		uint32_t st = gf_mul(static_cast<uint32_t>(a), shift) ^ static_cast<uint32_t>(b);
+		st = gf_mul(st, shift) ^ static_cast<uint32_t>(c);
+		crc = st;
+		data += 24 * words;
+		n -= 24 * words;
+	}
 	while (n >= 8) {
 		uint64_t w;
 		memcpy(&w, data, 8);
@@ -209,7 +231,7 @@ __attribute__((target("sse4.2"))) static uint32_t crc32c_sse42(const uint8_t* da
 	return ~c;
 }
 #endif
-// crc32c (src/crc.hpp:39-57 -> crc32_impl(0, ...)): Castagnoli, init/xorout ~0
+
 uint32_t crc32c(const uint8_t* data, uint64_t n) {
 #if defined(__x86_64__)
 	static const bool have_sse42 = __builtin_cpu_supports("sse4.2");

@@ -663,6 +663,39 @@ __global__ void __launch_bounds__(kBlock) k_flat_section(
 	}
 }
 
+// one workgroup: final offset of every slice's codes (exclusive prefix of BOC + payload bytes) and
+// what the host needs of them in one buffer: report = [code_len[nslices] | total lo | total hi | errors]
+__global__ void __launch_bounds__(kBlock) k_code_offsets(
+	const uint32_t* __restrict__ boc_len, const uint32_t* __restrict__ payload_len, const uint32_t* __restrict__ slice_err,
+	uint32_t nslices, uint64_t* __restrict__ out_off, uint32_t* __restrict__ report
+) {
+	__shared__ unsigned long long s_part[kBlock];
+	__shared__ uint32_t s_err;
+	if (threadIdx.x == 0) s_err = 0;
+	const uint32_t per = (nslices + kBlock - 1) / kBlock;
+	const uint32_t z0 = threadIdx.x * per, z1 = min(z0 + per, nslices);
+	unsigned long long sum = 0;
+	uint32_t err = 0;
+	for (uint32_t z = z0; z < z1; z++) { sum += static_cast<unsigned long long>(boc_len[z]) + payload_len[z]; err |= slice_err[z]; }
+	s_part[threadIdx.x] = sum;
+	__syncthreads();
+	if (err) atomicOr(&s_err, err);
+	if (threadIdx.x == 0) {
+		unsigned long long run = 0;
+		for (uint32_t i = 0; i < kBlock; i++) { const unsigned long long v = s_part[i]; s_part[i] = run; run += v; }
+		report[nslices] = static_cast<uint32_t>(run); report[nslices + 1] = static_cast<uint32_t>(run >> 32);
+	}
+	__syncthreads();
+	unsigned long long off = s_part[threadIdx.x];
+	for (uint32_t z = z0; z < z1; z++) {
+		const uint32_t len = boc_len[z] + payload_len[z];
+		out_off[z] = off;
+		report[z] = len;
+		off += len;
+	}
+	if (threadIdx.x == 0) report[nslices + 2] = s_err;
+}
+
 // grid = nslices: copy each slice's BOC index and payload to their final offsets
 __global__ void __launch_bounds__(kBlock) k_gather_codes(
 	const uint8_t* __restrict__ boc, const uint64_t* __restrict__ bbase, const uint32_t* __restrict__ boc_len,
@@ -715,6 +748,8 @@ struct ckl_encoder {
 	DevBuf<uint64_t> d_cbase, d_sbase, d_kbase, d_pbase, d_bbase, d_out_off, d_comp_off;
 	DevBuf<uint32_t> d_ccap, d_scap, d_kcap;
 	DevBuf<uint8_t> d_cp, d_fcode, d_dcode, d_payload, d_boc, d_codes_out, d_model;
+	DevBuf<uint32_t> d_code_report;
+	uint64_t codes_capacity = 0;        // bound of all slices' BOC + payload bytes
 	DevBuf<uint32_t> d_stack_node, d_stack_code;
 	DevBuf<uint32_t> d_chain_node, d_chain_off, d_chain_clen, d_chain_order, d_chain_dst, d_chain_vstart;
 	DevBuf<uint32_t> d_n_chains, d_n_raw, d_n_valid, d_payload_len, d_boc_len;
@@ -995,6 +1030,7 @@ void crack_pass(
 	}
 	upload(e.d_pbase, pbase, s); upload(e.d_bbase, bbase, s);
 	e.d_payload.ensure(ptot + 8); e.d_boc.ensure(btot + 8);
+	e.codes_capacity = ptot + btot;
 	if (markov_order) CKL_HIP(hipMemsetAsync(e.d_payload.p, 0, ptot + 8, s));
 
 	FinishArgs fa;
@@ -1158,26 +1194,25 @@ void crack_pass(
 	}
 	if (!result) { CKL_HIP(hipStreamSynchronize(s)); return; }
 
-	HT_MARK("c:finish_enq");
-	std::vector<uint32_t> plen = download(e.d_payload_len.p, ns, s);
-	HT_MARK("c:finish_wait");
-	std::vector<uint32_t> blen = download(e.d_boc_len.p, ns, s);
-	std::vector<uint32_t> errs = download(e.d_slice_err.p, ns, s);
-	for (uint32_t zi = 0; zi < ns; zi++) {
-		if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack walk scratch overflow on z=" + std::to_string(zi));
-	}
-	std::vector<uint64_t> out_off(ns);
-	uint64_t otot = 0;
-	result->code_len.resize(ns);
-	for (uint32_t zi = 0; zi < ns; zi++) {
-		out_off[zi] = otot;
-		result->code_len[zi] = plen[zi] + blen[zi];
-		otot += result->code_len[zi];
-	}
-	upload(e.d_out_off, out_off, s);
-	e.d_codes_out.ensure(otot + 8);
+	// final offsets on the device, the gather behind them, one small report back (lengths for the
+	// z-index, total, error bits): a single wait before the codes are copied out
+	e.d_out_off.ensure(ns);
+	e.d_code_report.ensure(static_cast<size_t>(ns) + 3);
+	e.d_codes_out.ensure(e.codes_capacity + 8);
+	hipLaunchKernelGGL(k_code_offsets, dim3(1), dim3(kBlock), 0, s, e.d_boc_len.p, e.d_payload_len.p, e.d_slice_err.p, ns, e.d_out_off.p, e.d_code_report.p);
 	hipLaunchKernelGGL(k_gather_codes, dim3(ns), dim3(kBlock), 0, s, e.d_boc.p, e.d_bbase.p, e.d_boc_len.p,
 		e.d_payload.p, e.d_pbase.p, e.d_payload_len.p, e.d_out_off.p, e.d_codes_out.p);
+	HT_MARK("c:finish_enq");
+	std::vector<uint32_t> report = download(e.d_code_report.p, static_cast<size_t>(ns) + 3, s);
+	HT_MARK("c:finish_wait");
+	if (report[ns + 2]) {
+		std::vector<uint32_t> errs = download(e.d_slice_err.p, ns, s);
+		for (uint32_t zi = 0; zi < ns; zi++) {
+			if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack walk scratch overflow on z=" + std::to_string(zi));
+		}
+	}
+	result->code_len.assign(report.begin(), report.begin() + ns);
+	const uint64_t otot = static_cast<uint64_t>(report[ns]) | (static_cast<uint64_t>(report[ns + 1]) << 32);
 	result->total = otot;
 }
 

@@ -67,6 +67,9 @@ def test_crc32c_host(port):
   assert L.ckl_crc32c(b"123456789", 9) == 0xE3069283
   data = bytes(np.random.default_rng(0).integers(0, 256, 100003, dtype=np.uint8))
   assert L.ckl_crc32c(data, len(data)) == port.crc32c(data)
+  # lengths around the switch to three interleaved chains and their remainders
+  for n in (0, 1, 7, 8, 9, 3071, 3072, 3073, 3095, 3096, 24005):
+    assert L.ckl_crc32c(data[:n], n) == port.crc32c(data[:n]), n
 
 
 def test_signed_input_rejected():
