@@ -1446,6 +1446,26 @@ void encode_typed(
 	FlatResult fr;
 	std::vector<uint8_t> pins_binary;      // pin label section (host built)
 	uint64_t label_bytes = 0;
+	const uint64_t off_index = Header::kBytes;
+	const uint64_t off_labels = off_index + 4ull * (sz + 1);
+	// crack code bytes, estimated from the edge and node counts: every edge is one code, a branch
+	// costs a few more; 2 bits per code (markov: at most 3), BOC index of a few chains per slice
+	uint64_t est_code_bytes = 0;
+	{
+		const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
+		const int xw = byte_width(static_cast<uint64_t>(sx) + 1), yw = byte_width(static_cast<uint64_t>(sy) + 1);
+		for (int64_t z = 0; z < sz; z++) {
+			const uint64_t differ = static_cast<uint64_t>(e.count_v[z]) + e.count_h[z];
+			const uint64_t E = permissible ? interior - differ : differ;
+			const uint64_t codes = E + 4ull * (static_cast<uint64_t>(e.count_special[z]) + e.count_corner[z]) + 16;
+			est_code_bytes += (head.markov_model_order ? (3 * codes + 7) / 8 : (codes + 3) / 4) + 8;
+			est_code_bytes += 4 + yw + 64ull * (yw + 2 * xw);
+		}
+	}
+	const uint64_t model_bytes_est = head.markov_model_order ? (1ull << (2 * head.markov_model_order)) : 0;
+	struct HostOut { void* p = nullptr; ~HostOut() { if (p) host_out_free(p); } } early;
+	uint64_t early_cap = 0;
+	uint32_t labels_crc = 0;
 	const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
 	hipStream_t s2 = e.stream2;
 	auto label_side = [&]() {
@@ -1471,6 +1491,16 @@ void encode_typed(
 		else {
 			label_bytes = flat_section(e, N, stored_width, component_width, static_cast<uint32_t>(sz));
 			HT_MARK("label_table");
+			// The output buffer is taken now, sized with an estimate of the crack code bytes, so that
+			// the label section is copied out and checksummed while the trail still runs; a stream
+			// that outgrows the estimate is moved to a larger buffer at assembly.
+			early_cap = off_labels + label_bytes + model_bytes_est + est_code_bytes + 4ull * (sz + 1) + 64;
+			early.p = host_out_alloc(early_cap);
+			uint8_t* eo = static_cast<uint8_t*>(early.p);
+			if (label_bytes) CKL_HIP(hipMemcpyAsync(eo + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToHost, s2));
+			CKL_HIP(hipStreamSynchronize(s2));
+			labels_crc = crc32c(eo + off_labels, label_bytes);
+			HT_MARK("labels_d2h");
 		}
 	};
 
@@ -1487,17 +1517,22 @@ void encode_typed(
 	// assembly (crackle.hpp:171-216), straight into the caller's buffer:
 	// header | z-index + crc | labels | model | crack codes | labels crc | slice crcs
 	head.num_label_bytes = label_bytes;
-	const uint64_t off_index = Header::kBytes;
-	const uint64_t off_labels = off_index + 4ull * (sz + 1);
 	const uint64_t off_model = off_labels + label_bytes;
 	const uint64_t off_codes = off_model + stored_model.size();
 	const uint64_t off_tail = off_codes + cr.total;
 	const uint64_t total = off_tail + 4ull * (sz + 1);
-	uint8_t* o = static_cast<uint8_t*>(host_out_alloc(total));
+	uint8_t* o;
+	if (early.p && total <= early_cap) { o = static_cast<uint8_t*>(early.p); early.p = nullptr; }
+	else {
+		o = static_cast<uint8_t*>(host_out_alloc(total));
+		if (early.p && label_bytes) memcpy(o + off_labels, static_cast<uint8_t*>(early.p) + off_labels, label_bytes);
+	}
 	try {
 		if (cr.total) CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
-		if (head.label_format == PINS_VARIABLE_WIDTH) { if (label_bytes) memcpy(o + off_labels, pins_binary.data(), label_bytes); }
-		else if (label_bytes) CKL_HIP(hipMemcpyAsync(o + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToHost, s2));
+		if (head.label_format == PINS_VARIABLE_WIDTH) {
+			if (label_bytes) memcpy(o + off_labels, pins_binary.data(), label_bytes);
+			labels_crc = crc32c(o + off_labels, label_bytes);
+		}
 		std::vector<uint8_t> hb;
 		head.write(hb);
 		memcpy(o, hb.data(), hb.size());
@@ -1506,8 +1541,7 @@ void encode_typed(
 		put4(off_index + 4ull * sz, crc32c(o + off_index, 4ull * sz));
 		if (!stored_model.empty()) memcpy(o + off_model, stored_model.data(), stored_model.size());
 		for (int64_t z = 0; z < sz; z++) put4(off_tail + 4 + 4ull * z, fr.crcs[z]);
-		CKL_HIP(hipStreamSynchronize(s2));
-		put4(off_tail, crc32c(o + off_labels, label_bytes));
+		put4(off_tail, labels_crc);
 		ht.mark("assembly");
 		CKL_HIP(hipEventRecord(e.ev1, s));
 		CKL_HIP(hipStreamSynchronize(s));
