@@ -1462,6 +1462,7 @@ void encode_typed(
 			est_code_bytes += 4 + yw + 64ull * (yw + 2 * xw);
 		}
 	}
+	if (getenv("CKL_SMALL_ESTIMATE")) est_code_bytes = 0;      // testing: the stream outgrows the early buffer
 	const uint64_t model_bytes_est = head.markov_model_order ? (1ull << (2 * head.markov_model_order)) : 0;
 	struct HostOut { void* p = nullptr; ~HostOut() { if (p) host_out_free(p); } } early;
 	uint64_t early_cap = 0;

@@ -177,7 +177,7 @@ def test_large_slices_and_dense_graphs(checker):
   assert np.array_equal(crackle_amd.decompress(want), bits)
 
 
-@pytest.mark.parametrize("env", [{"CKL_TRAIL_LDS": "4096"}, {"CKL_PLANES_GENERIC": "1"}, {"CKL_NO_OVERLAP": "1"}])
+@pytest.mark.parametrize("env", [{"CKL_TRAIL_LDS": "4096"}, {"CKL_PLANES_GENERIC": "1"}, {"CKL_NO_OVERLAP": "1"}, {"CKL_SMALL_ESTIMATE": "1"}, {"CKL_STRIP_RUNS": "64"}])
 def test_encoder_fallback_paths(env, checker, monkeypatch):
   """The encoder's alternate code paths (node tables / union-find in global memory instead
   of LDS, the generic label-plane kernel, no stream overlap) produce the same bytes."""
@@ -196,7 +196,7 @@ def test_encoder_fallback_paths(env, checker, monkeypatch):
     assert crackle_amd.compress(arr8, **_kw(kw8)) == golden()[name]
 
 
-@pytest.mark.parametrize("env", [{"CKL_MARKOV_SERIAL": "1"}, {"CKL_LDS_CONTROLS": "64"}, {"CKL_NO_LDS_RASTER": "1"}])
+@pytest.mark.parametrize("env", [{"CKL_MARKOV_SERIAL": "1"}, {"CKL_LDS_CONTROLS": "64"}, {"CKL_NO_LDS_RASTER": "1"}, {"CKL_STRIP_RUNS": "64"}, {"CKL_PAINT_NOSTAGE": "1"}])
 def test_decoder_fallback_paths(env, checker, monkeypatch):
   """The decoder's alternate code paths (one-thread markov expansion, control tables in HBM,
   rasterisation with HBM atomics) decode the same volumes."""
