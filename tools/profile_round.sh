@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage: tools/profile_round.sh TAG    (on the GPU box, from the repo root)
+# kernel stats, the two PMC passes and a bench line of the same build -> gpurun_out/<TAG>_*
+set -e
+tag=$1
+root=$PWD
+cd /tmp && export TMPDIR=/tmp
+rm -rf $root/gpurun_out/${tag}_stats $root/gpurun_out/${tag}_fetch $root/gpurun_out/${tag}_write
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o s -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $root/gpurun_out/${tag}_stats.log 2>&1
+echo "stats done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex ckl --output-format csv -d $root/gpurun_out/${tag}_fetch -o f -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $root/gpurun_out/${tag}_fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex ckl --output-format csv -d $root/gpurun_out/${tag}_write -o w -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $root/gpurun_out/${tag}_write.log 2>&1
+echo "write done"
+cd $root
+python3 tools/pmc_summary.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write "1024x1024x512 uint32 markov 0" gpurun_out/${tag}_pmc_traffic.json > gpurun_out/${tag}_pmc.txt
+# the raw traces are tens of MiB: keep the summaries only
+mkdir -p gpurun_out/${tag}
+find gpurun_out/${tag}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}/kernel_stats.csv \;
+rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write
+python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+tail -c 600 gpurun_out/${tag}_bench.json
