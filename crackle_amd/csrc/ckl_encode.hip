@@ -161,46 +161,61 @@ __global__ void __launch_bounds__(kBlock) k_label_planes_fast(
 		uint32_t* pv = planeV + zi * plane_words;
 		uint32_t* ph = planeH + zi * plane_words;
 		const uint32_t word = (x >> 5);
-		for (uint32_t y = y0; y < y1; y++) {
-			Vec cur = prev;
-			LABEL edge = 0;
-			bool have_edge = false;
-			if (active) {
-				cur = *reinterpret_cast<const Vec*>(col + static_cast<uint64_t>(y) * sx);
-				if (lane == 0) {
-					// linear predecessor of the strip's first pixel (previous row / slice when x == 0)
-					const uint64_t lin = slice_off + static_cast<uint64_t>(y) * sx + x;
-					if (lin > 0) { edge = labels[lin - 1]; have_edge = true; }
-				}
-			}
-			LABEL left = __shfl_up(cur.v[P - 1], 1, kWave);
-			bool have_left = true;
-			if (lane == 0) { left = edge; have_left = have_edge; }
-			uint32_t bv = 0, bh = 0;
-			if (active) {
+		// kRowsAhead rows are loaded before the first of them is compared: one 16-byte load per
+		// lane in flight does not cover the memory latency at the occupancy the CU allows
+		constexpr uint32_t kRowsAhead = 4;
+		for (uint32_t yb = y0; yb < y1; yb += kRowsAhead) {
+			Vec rows[kRowsAhead];
+			LABEL edges[kRowsAhead];
+			bool have_edges[kRowsAhead];
 #pragma unroll
-				for (uint32_t i = 0; i < P; i++) {
-					const LABEL l = i ? cur.v[i - 1] : left;
-					const bool differs = cur.v[i] != l;
-					const bool counted = i ? true : have_left;
-					pairs += (counted && !differs) ? 1u : 0u;
-					bv |= ((differs && (x + i) > 0) ? 1u : 0u) << i;
-					bh |= ((y > 0 && cur.v[i] != prev.v[i]) ? 1u : 0u) << i;
-					mx = static_cast<unsigned long long>(cur.v[i]) > mx ? static_cast<unsigned long long>(cur.v[i]) : mx;
+			for (uint32_t r = 0; r < kRowsAhead; r++) {
+				const uint32_t y = yb + r;
+				edges[r] = 0; have_edges[r] = false;
+				if (active && y < y1) {
+					rows[r] = *reinterpret_cast<const Vec*>(col + static_cast<uint64_t>(y) * sx);
+					if (lane == 0) {
+						// linear predecessor of the strip's first pixel (previous row / slice when x == 0)
+						const uint64_t lin = slice_off + static_cast<uint64_t>(y) * sx + x;
+						if (lin > 0) { edges[r] = labels[lin - 1]; have_edges[r] = true; }
+					}
 				}
+				else rows[r] = prev;
 			}
-			nv += __popc(bv); nh += __popc(bh);
-			bv <<= (lane % G) * P; bh <<= (lane % G) * P;
 #pragma unroll
-			for (uint32_t sft = 1; sft < G; sft <<= 1) {
-				bv |= __shfl_xor(bv, sft, kWave);
-				bh |= __shfl_xor(bh, sft, kWave);
+			for (uint32_t r = 0; r < kRowsAhead; r++) {
+				const uint32_t y = yb + r;
+				if (y >= y1) break;
+				const Vec cur = active ? rows[r] : prev;
+				LABEL left = __shfl_up(cur.v[P - 1], 1, kWave);
+				bool have_left = true;
+				if (lane == 0) { left = edges[r]; have_left = have_edges[r]; }
+				uint32_t bv = 0, bh = 0;
+				if (active) {
+#pragma unroll
+					for (uint32_t i = 0; i < P; i++) {
+						const LABEL l = i ? cur.v[i - 1] : left;
+						const bool differs = cur.v[i] != l;
+						const bool counted = i ? true : have_left;
+						pairs += (counted && !differs) ? 1u : 0u;
+						bv |= ((differs && (x + i) > 0) ? 1u : 0u) << i;
+						bh |= ((y > 0 && cur.v[i] != prev.v[i]) ? 1u : 0u) << i;
+						mx = static_cast<unsigned long long>(cur.v[i]) > mx ? static_cast<unsigned long long>(cur.v[i]) : mx;
+					}
+				}
+				nv += __popc(bv); nh += __popc(bh);
+				bv <<= (lane % G) * P; bh <<= (lane % G) * P;
+#pragma unroll
+				for (uint32_t sft = 1; sft < G; sft <<= 1) {
+					bv |= __shfl_xor(bv, sft, kWave);
+					bh |= __shfl_xor(bh, sft, kWave);
+				}
+				if ((lane % G) == 0 && word < row_words && active) {
+					pv[static_cast<uint64_t>(y) * row_words + word] = bv;
+					ph[static_cast<uint64_t>(y) * row_words + word] = bh;
+				}
+				prev = cur;
 			}
-			if ((lane % G) == 0 && word < row_words && active) {
-				pv[static_cast<uint64_t>(y) * row_words + word] = bv;
-				ph[static_cast<uint64_t>(y) * row_words + word] = bh;
-			}
-			prev = cur;
 		}
 	}
 	nv = wave_sum(nv); nh = wave_sum(nh); pairs = wave_sum(pairs);
