@@ -294,8 +294,13 @@ __device__ __forceinline__ void put_le_dev(uint8_t* p, uint32_t v, int w) {
 	for (int i = 0; i < w; i++) p[i] = static_cast<uint8_t>((v >> (8 * i)) & 0xFF);
 }
 
-__global__ void __launch_bounds__(kBlock) k_finish(FinishArgs a) {
-	__shared__ uint32_t s_scan[kWaves];
+// 1024 threads per slice: two workgroups share a CU, and the phases below are rounds of
+// latency-bound byte accesses, so the time goes with the rounds per thread
+constexpr int kFinishBlock = 1024;
+constexpr int kFinishWaves = kFinishBlock / kWave;
+
+__global__ void __launch_bounds__(kFinishBlock) k_finish(FinishArgs a) {
+	__shared__ uint32_t s_scan[kFinishWaves];
 	const uint32_t zi = blockIdx.x + a.z0;
 	const int tid = threadIdx.x;
 	const uint32_t nch = a.n_chains[zi], nraw = a.n_raw[zi], nvalid = a.n_valid[zi];
@@ -362,7 +367,7 @@ __global__ void __launch_bounds__(kBlock) k_finish(FinishArgs a) {
 	// ---- phase 2: compaction of tombstones + scatter of each chain to its sorted place ----
 	constexpr uint32_t kPer = 16;
 	uint32_t carry = 0;
-	for (uint32_t tile = 0; tile < nraw; tile += kBlock * kPer) {
+	for (uint32_t tile = 0; tile < nraw; tile += kFinishBlock * kPer) {
 		const uint32_t i0 = tile + tid * kPer;
 		uint32_t cnt = 0;
 		uint8_t c[kPer];
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(kBlock) k_finish(FinishArgs a) {
 			cnt += (c[k] != CODE_TOMB);
 		}
 		uint32_t v[1] = { cnt }, tot[1];
-		block_excl_add<1>(v, tot, s_scan);
+		block_excl_add<1, kFinishWaves>(v, tot, s_scan);
 		uint32_t g = carry + v[0];
 		if (cnt) {
 			// chain of raw index i0: last chain with ch_off <= i0
@@ -402,26 +407,34 @@ __global__ void __launch_bounds__(kBlock) k_finish(FinishArgs a) {
 	// ---- phase 3: whole-slice mod-4 difference code, then 2-bit packing ----
 	if (a.markov) {
 		uint8_t* dcode = a.dcode + a.cbase[zi];
-		for (uint32_t g = tid; g < nvalid; g += kBlock) {
+		for (uint32_t g = tid; g < nvalid; g += kFinishBlock) {
 			const uint32_t prev = g ? fcode[g - 1] : 0u;
 			dcode[g] = static_cast<uint8_t>((fcode[g] - prev) & 3u);
 		}
 		if (tid == 0) a.payload_len[zi] = 0;
 	}
 	else {
-		uint8_t* out = a.payload + a.pbase[zi];
+		uint8_t* out = a.payload + a.pbase[zi];        // 4-byte aligned
 		const uint32_t nbytes = (nvalid + 3) / 4;
-		for (uint32_t b = tid; b < nbytes; b += kBlock) {
+		const uint32_t nwords = (nvalid + 15) / 16;
+		// 16 codes -> one 32-bit word per thread and step (one 16-byte load, one 4-byte store)
+		for (uint32_t w = tid; w < nwords; w += kFinishBlock) {
+			const uint32_t g0 = w * 16u;
+			uint8_t c[16];
+			if (g0 + 16u <= nvalid) memcpy(c, fcode + g0, 16);
+			else {
+#pragma unroll
+				for (uint32_t j = 0; j < 16; j++) c[j] = g0 + j < nvalid ? fcode[g0 + j] : 0;
+			}
+			uint32_t prev = g0 ? fcode[g0 - 1] : 0u;
 			uint32_t enc = 0;
 #pragma unroll
-			for (uint32_t j = 0; j < 4; j++) {
-				const uint32_t g = b * 4 + j;
-				if (g < nvalid) {
-					const uint32_t prev = g ? fcode[g - 1] : 0u;
-					enc |= ((fcode[g] - prev) & 3u) << (2 * j);
-				}
+			for (uint32_t j = 0; j < 16; j++) {
+				if (g0 + j < nvalid) enc |= ((c[j] - prev) & 3u) << (2 * j);
+				prev = c[j];
 			}
-			out[b] = static_cast<uint8_t>(enc);
+			if (4u * w + 4u <= nbytes) reinterpret_cast<uint32_t*>(out)[w] = enc;
+			else for (uint32_t k = 4u * w; k < nbytes; k++) out[k] = static_cast<uint8_t>(enc >> (8u * (k - 4u * w)));
 		}
 		if (tid == 0) a.payload_len[zi] = nbytes;
 	}
@@ -1148,7 +1161,7 @@ void crack_pass(
 			if (g == 0) CKL_HIP(hipEventRecord(e.evd1, gs));
 			hipLaunchKernelGGL(k_trail_offsets, dim3(gn), dim3(kBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kExpandChunk * kWaves - 1) / (kExpandChunk * kWaves), gn), dim3(kBlock), 0, gs, ta);
-			hipLaunchKernelGGL(k_finish, dim3(gn), dim3(kBlock), 0, gs, fa);
+			hipLaunchKernelGGL(k_finish, dim3(gn), dim3(kFinishBlock), 0, gs, fa);
 			if (g > 0) {
 				CKL_HIP(hipEventRecord(e.ev_join[g], gs));
 				CKL_HIP(hipStreamWaitEvent(s, e.ev_join[g], 0));
