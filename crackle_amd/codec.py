@@ -286,3 +286,21 @@ def bounding_boxes(binary: bytes, label: Optional[int] = None, parallel: int = 0
   for lbl, b in bbxes.items():
     bbxes[lbl] = (slice(int(b[0]), int(b[3]) + 1), slice(int(b[1]), int(b[4]) + 1), slice(int(b[2]), int(b[5]) + 1))
   return bbxes[label] if label is not None else bbxes
+
+
+def reencode(binary: bytes, markov_model_order: int, parallel: int = 0, device: int = 0) -> bytes:
+  """The stream with its crack codes stored under another markov model order
+  (codec.py:877-881 -> reencode_with_markov_order, crackle.hpp:858-984); the label section is
+  untouched.  Runs on the device: crack decoder -> crack planes -> the encoder's trail."""
+  binary = bytes(binary)
+  head = header(binary)
+  if head.markov_model_order == markov_model_order:
+    return binary
+  out, n = C.c_void_p(), C.c_uint64()
+  rc = _lib.lib().ckl_reencode_markov(binary, len(binary), int(markov_model_order), int(device), C.byref(out), C.byref(n))
+  if rc != _lib.CKL_OK:
+    _raise(rc)
+  try:
+    return C.string_at(out.value, n.value)
+  finally:
+    _lib.lib().ckl_free(out)

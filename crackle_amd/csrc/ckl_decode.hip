@@ -2010,12 +2010,12 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	st.done("k_paint_runs");
 }
 
-void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label, const StatsArgs* stats = nullptr) {
+void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label, const StatsArgs* stats = nullptr, bool planes_only = false) {
 	const Header& h = d.head;
 	if (d.sxy == 0 || d.nslices == 0) return;
 	const int ow = has_label ? 1 : h.data_width;
 	const uint64_t need = d.sxy * d.nslices * static_cast<uint64_t>(ow);
-	if (!stats && out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
+	if (!stats && !planes_only && out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 	const bool prof = getenv("CKL_PROFILE") != nullptr;
@@ -2067,6 +2067,18 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, static_cast<unsigned long long*>(nullptr));
 	st.done("k_decode_cracks");
 
+	if (planes_only) {
+		// the crack planes are all the caller wants (ckl_reencode_markov): check what the parser flagged
+		d.n_stages = st.i;
+		std::vector<uint32_t> errs(ns);
+		CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		CKL_HIP(hipStreamSynchronize(s));
+		CKL_HIP(hipGetLastError());
+		for (uint32_t zi = 0; zi < ns; zi++) {
+			if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle: crack code is malformed or corrupted on z=" + std::to_string(d.z_start + zi));
+		}
+		return;
+	}
 	RunGeom g;
 	g.planeV = ca.planeV; g.planeH = ca.planeH; g.row_words = d.row_words; g.plane_words = d.plane_words;
 	g.flip = (h.crack_format == IMPERMISSIBLE) ? 1u : 0u;
@@ -2237,6 +2249,22 @@ int ckl_decoder_label_stats(ckl_decoder* d, uint64_t capacity, uint64_t* labels,
 		select_device(d->device);
 		wait_for_default_stream(d->stream, d->ev_in);
 		decoder_label_stats(*d, capacity, labels, counts, sums, boxes, n_labels);
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_decoder_crack_planes(ckl_decoder* d, const uint32_t** plane_v, const uint32_t** plane_h, uint32_t* row_words, uint64_t* plane_words) {
+	try {
+		if (!d || !plane_v || !plane_h || !row_words || !plane_words) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		select_device(d->device);
+		wait_for_default_stream(d->stream, d->ev_in);
+		*plane_v = nullptr; *plane_h = nullptr; *row_words = d->row_words; *plane_words = d->plane_words;
+		if (d->sxy == 0 || d->nslices == 0) return CKL_OK;
+		decoder_run(*d, nullptr, 0, 0, 0, nullptr, true);
+		*plane_v = d->d_planes.p;
+		*plane_h = d->d_planes.p + d->plane_words * d->nslices;
 		return CKL_OK;
 	}
 	catch (const Error& e) { set_last_error(e.what()); return e.status; }

@@ -232,6 +232,39 @@ __global__ void __launch_bounds__(kBlock) k_label_planes_fast(
 	}
 }
 
+// ckl_reencode_markov: the decoder's crack planes become the encoder's "differs from the
+// neighbour" planes (a crack is a differing pair for IMPERMISSIBLE streams and an equal pair for
+// PERMISSIBLE ones; image-border pairs carry neither) with their per-slice population counts.
+// grid = (ceil(plane_words / 256), nslices); counts: [nslices] v, then [nslices] h, zeroed by the host
+__global__ void __launch_bounds__(kBlock) k_planes_from_cracks(
+	const uint32_t* __restrict__ crackV, const uint32_t* __restrict__ crackH, uint32_t sx, uint32_t sy,
+	uint32_t row_words, uint64_t plane_words, uint32_t permissible,
+	uint32_t* __restrict__ planeV, uint32_t* __restrict__ planeH, uint32_t* __restrict__ counts, uint32_t nslices
+) {
+	__shared__ uint32_t s_red[kWaves];
+	const uint32_t zi = blockIdx.y;
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	uint32_t nv = 0, nh = 0;
+	if (i < plane_words) {
+		const uint32_t y = static_cast<uint32_t>(i / row_words);
+		const uint32_t w = static_cast<uint32_t>(i - static_cast<uint64_t>(y) * row_words);
+		const uint32_t left = sx - w * 32u;
+		const uint32_t in_row = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);           // x < sx
+		const uint32_t mv = in_row & (w == 0 ? 0xFFFFFFFEu : 0xFFFFFFFFu);                   // 1 <= x < sx
+		const uint32_t mh = y >= 1 ? in_row : 0u;                                            // y >= 1
+		const uint64_t at = zi * plane_words + i;
+		const uint32_t inv = permissible ? 0xFFFFFFFFu : 0u;
+		const uint32_t v = (crackV[at] ^ inv) & mv, h = (crackH[at] ^ inv) & mh;
+		planeV[at] = v; planeH[at] = h;
+		nv = __popc(v); nh = __popc(h);
+	}
+	nv = block_sum(nv, s_red); nh = block_sum(nh, s_red);
+	if (threadIdx.x == 0) {
+		if (nv) atomicAdd(counts + zi, nv);
+		if (nh) atomicAdd(counts + nslices + zi, nh);
+	}
+}
+
 // grid = nslices: folds the per-workgroup partials of one slice
 __global__ void __launch_bounds__(kBlock) k_planes_reduce(
 	const uint32_t* __restrict__ partial, const unsigned long long* __restrict__ partial_max, uint32_t nblk,
@@ -1585,6 +1618,89 @@ void encode_typed(
 	*out_len = total;
 }
 
+// reencode_with_markov_order (src/crackle.hpp:858-984).  The reference takes every slice's
+// code apart into symbols and packs them again; here the decoder rasterises the codes into the
+// crack planes and the encoder's trail writes them out again under the new order.  The trail is a
+// function of the crack set alone, so the code points are the ones the reference's own encoder
+// gives for these slices — which is what its reencode reproduces for any stream that encoder
+// (or this one) wrote.  Header, z-index and model are rewritten, label section and crcs copied.
+void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int device, uint8_t** out, uint64_t* out_len) {
+	if (n < Header::kBytesV0) throw Error(CKL_ERR_FORMAT, "crackle: Input too small to be a valid stream. Bytes: " + std::to_string(n));
+	Header head = Header::parse(buf, n);
+	if (markov_order < 0 || markov_order > 13) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order must be in [0, 13] on device");
+	auto copy_out = [&](const uint8_t* p, uint64_t len) {
+		uint8_t* o = static_cast<uint8_t*>(host_out_alloc(len));
+		memcpy(o, p, len);
+		*out = o; *out_len = len;
+	};
+	if (head.markov_model_order == markov_order) { copy_out(buf, n); return; }      // crackle.hpp:887-889
+	if (head.format_version == 0) throw Error(CKL_ERR_ARG, "crackle_amd: reencode of version 0 streams is not supported");
+	const uint64_t sz = head.sz;
+	const uint64_t off_index = head.header_bytes();
+	const uint64_t off_labels = off_index + head.grid_index_bytes();
+	const uint64_t old_codes = off_labels + head.num_label_bytes + head.markov_model_bytes();
+	if (old_codes + 4 * (sz + 1) > n) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_code_offsets: Unable to read past end of buffer.");
+	uint64_t old_tail = old_codes;
+	for (uint64_t z = 0; z < sz; z++) old_tail += rd_le(buf + off_index + 4 * z, 4);
+	if (old_tail + 4 * (sz + 1) > n) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
+
+	struct DecoderGuard { ckl_decoder* d = nullptr; ~DecoderGuard() { if (d) ckl_decoder_destroy(d); } } dec;
+	struct EncoderGuard { ckl_encoder* e = nullptr; ~EncoderGuard() { if (e) ckl_encoder_destroy(e); } } enc;
+	if (ckl_decoder_create(buf, n, 0, -1, device, &dec.d) != CKL_OK) throw Error(CKL_ERR_RUNTIME, ckl_last_error());
+	CrackResult cr;
+	std::vector<uint8_t> model, stored_model;
+	head.markov_model_order = markov_order;
+	if (head.voxels() > 0) {
+		const uint32_t *cv = nullptr, *ch = nullptr;
+		uint32_t row_words = 0;
+		uint64_t plane_words = 0;
+		if (ckl_decoder_crack_planes(dec.d, &cv, &ch, &row_words, &plane_words) != CKL_OK) throw Error(CKL_ERR_RUNTIME, ckl_last_error());
+		if (ckl_encoder_create(head.sx, head.sy, head.sz, 1, device, &enc.e) != CKL_OK) throw Error(CKL_ERR_RUNTIME, ckl_last_error());
+		ckl_encoder& e = *enc.e;
+		hipStream_t s = e.stream;
+		const uint32_t ns = head.sz;
+		const bool permissible = head.crack_format == PERMISSIBLE;
+		e.row_words = row_words;
+		e.plane_words = plane_words;
+		e.d_planes.ensure(2 * plane_words * ns);
+		e.d_count_vh.ensure(4 * static_cast<size_t>(ns));
+		CKL_HIP(hipMemsetAsync(e.d_count_vh.p, 0, 2 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
+		hipLaunchKernelGGL(k_planes_from_cracks, dim3(static_cast<uint32_t>((plane_words + kBlock - 1) / kBlock), ns), dim3(kBlock), 0, s,
+			cv, ch, head.sx, head.sy, row_words, plane_words, permissible ? 1u : 0u,
+			e.d_planes.p, e.d_planes.p + plane_words * ns, e.d_count_vh.p, ns);
+		std::vector<uint32_t> c = download(e.d_count_vh.p, 2 * static_cast<size_t>(ns), s);
+		e.count_v.assign(c.begin(), c.begin() + ns);
+		e.count_h.assign(c.begin() + ns, c.end());
+		graph_pass(e, head.sx, head.sy, head.sz, permissible);
+		crack_pass(e, head.sx, head.sy, head.sz, permissible, markov_order, false, nullptr, nullptr, &model, &cr);
+		if (markov_order > 0) stored_model = markov_model_to_stored(model);
+	}
+	else cr.code_len.assign(sz, 0);
+
+	// assembly (crackle.hpp:935-981)
+	const uint64_t off_model = off_labels + head.num_label_bytes;
+	const uint64_t off_codes = off_model + stored_model.size();
+	const uint64_t off_tail = off_codes + cr.total;
+	const uint64_t total = off_tail + 4 * (sz + 1);
+	uint8_t* o = static_cast<uint8_t*>(host_out_alloc(total));
+	try {
+		if (cr.total) CKL_HIP(hipMemcpyAsync(o + off_codes, enc.e->d_codes_out.p, cr.total, hipMemcpyDeviceToHost, enc.e->stream));
+		std::vector<uint8_t> hb;
+		head.write(hb);
+		memcpy(o, hb.data(), hb.size());
+		auto put4 = [&](uint64_t at, uint32_t v) { for (int b = 0; b < 4; b++) o[at + b] = static_cast<uint8_t>((v >> (8 * b)) & 0xFF); };
+		for (uint64_t z = 0; z < sz; z++) put4(off_index + 4 * z, cr.code_len[z]);
+		put4(off_index + 4 * sz, crc32c(o + off_index, 4 * sz));
+		memcpy(o + off_labels, buf + off_labels, head.num_label_bytes);
+		if (!stored_model.empty()) memcpy(o + off_model, stored_model.data(), stored_model.size());
+		memcpy(o + off_tail, buf + old_tail, 4 * (sz + 1));
+		if (cr.total) CKL_HIP(hipStreamSynchronize(enc.e->stream));
+	}
+	catch (...) { host_out_free(o); throw; }
+	*out = o;
+	*out_len = total;
+}
+
 void check_dims(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int is_signed) {
 	if (is_signed) throw Error(CKL_ERR_ARG, "Signed integer data types are not currently supported.");
 	if (dtype_bytes != 1 && dtype_bytes != 2 && dtype_bytes != 4 && dtype_bytes != 8) throw Error(CKL_ERR_ARG, "crackle_amd: dtype width must be 1, 2, 4 or 8 bytes");
@@ -1648,6 +1764,17 @@ int ckl_encoder_run(
 		if (getenv("CKL_PROFILE")) {
 			fprintf(stderr, "[ckl encoder_run ms] encode=%.2f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count());
 		}
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_reencode_markov(const uint8_t* buf, uint64_t n, int markov_model_order, int device, uint8_t** out, uint64_t* out_len) {
+	try {
+		if (!buf || !out || !out_len) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		select_device(device);
+		reencode_markov(buf, n, markov_model_order, device, out, out_len);
 		return CKL_OK;
 	}
 	catch (const Error& err) { set_last_error(err.what()); return err.status; }

@@ -67,6 +67,13 @@ class CrackleHeader:
   def grid_index_bytes(self):
     return 4 * self.sz if self.format_version == 0 else 4 * (self.sz + 1)
 
+  @property
+  def markov_model_bytes(self):
+    """Stored model size (header.hpp:284-297): 5 bits per context row."""
+    if self.markov_model_order == 0:
+      return 0
+    return ((1 << (2 * self.markov_model_order)) * 5 + 4) // 8
+
   def voxels(self) -> int:
     return self.sx * self.sy * self.sz
 

@@ -22,6 +22,17 @@ def zstack(images: Sequence[bytes]) -> bytes:
   bufs = [bytes(b) for b in images]
   if not bufs:
     raise ValueError("zstack needs at least one stream")
+  # The reference brings every input to markov order 0 first (operations.py:447-457).  Slabs
+  # that share one model (the sharded encoder's, or the parts of one stream) are merged as they
+  # are; otherwise the codes are re-encoded to order 0 on the device, like the reference.
+  heads = [header(b) for b in bufs]
+  def _model(b, h):
+    off = h.header_bytes + h.grid_index_bytes + h.num_label_bytes
+    return b[off:off + h.markov_model_bytes]
+  orders = {h.markov_model_order for h in heads}
+  if orders != {0} and (len(orders) > 1 or len({_model(b, h) for b, h in zip(bufs, heads)}) > 1):
+    from .codec import reencode
+    bufs = [reencode(b, 0) for b in bufs]
   L = _lib.lib()
   arr = (C.c_char_p * len(bufs))(*bufs)
   lens = (C.c_uint64 * len(bufs))(*[len(b) for b in bufs])

@@ -115,6 +115,14 @@ int ckl_decoder_create(
 	int device, ckl_decoder** out);
 /* Runs the device pipeline into a DEVICE output buffer and waits for it. */
 int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label);
+/* Runs only the crack decoder of the session: the two crack bit planes of every slice of the
+ * range (crack_code_to_vcg, src/crackle.hpp:414-425, reduced to the two bits per pixel the
+ * component labelling reads), left in HBM and owned by the decoder.  Plane V bit (x,y): crack
+ * between pixels (x-1,y)|(x,y); plane H bit (x,y): between (x,y-1)|(x,y); rows of *row_words
+ * 32-pixel words, *plane_words words per slice, slices consecutive. */
+int ckl_decoder_crack_planes(
+	ckl_decoder* d, const uint32_t** plane_v_device, const uint32_t** plane_h_device,
+	uint32_t* row_words, uint64_t* plane_words);
 /* Per-label statistics of the decoder's z-range without materialising the volume:
  * replaces crackle::operations::voxel_counts / centroids / bounding_boxes
  * (src/operations.hpp:321-618, bound by src/fastcrackle.cpp:346-420).  The pipeline runs up
@@ -213,6 +221,14 @@ int ckl_pin_labels_host(
 	int64_t sx, int64_t sy, int64_t sz, const uint32_t* ncomp,
 	int stored_width, int auto_bgcolor, int64_t manual_bgcolor,
 	uint8_t** out, uint64_t* out_len);
+
+/* Replaces crackle::reencode_with_markov_order (src/crackle.hpp:858-984, bound as
+ * fastcrackle.reencode_markov, src/fastcrackle.cpp:212-230): the stream with its crack codes
+ * stored under another markov model order.  The crack decoder rasterises the codes on the device
+ * and the encoder's crack trail writes them out again; label section and crcs are copied.
+ * Streams written by the reference encoder or by this library come out byte for byte as the
+ * reference's reencode gives them.  *out (pinned host memory) is released with ckl_free. */
+int ckl_reencode_markov(const uint8_t* buf, uint64_t n, int markov_model_order, int device, uint8_t** out, uint64_t* out_len);
 
 /* Native form of crackle.operations.zsplit's range helper (crackle/operations.py:550-623):
  * the stream of slices [z_start, z_end) of a FLAT stream, without decoding (host only).

@@ -1485,6 +1485,132 @@ int ckl_oracle_slice_vcg(const unsigned char* buf, uint64_t n, int64_t z, uint8_
 	return rc;
 }
 
+/* reencode_with_markov_order (src/crackle.hpp:858-984): every slice's crack code is taken
+ * apart into chains of symbols (crack_code_to_symbols, :394-411), turned back into code points
+ * (symbols_to_codepoints, src/crackcodes.hpp:128-183) and packed again under the new order
+ * (pack_codepoints / markov::gather_statistics + compress); header, z-index and model are
+ * rewritten, label section and the trailing crcs are copied.  Version-0 streams (no crcs)
+ * are not handled here. */
+int ckl_oracle_reencode(
+	const unsigned char* buf, uint64_t n, int markov_order, uint64_t parallel, unsigned char** out, uint64_t* out_len
+) {
+	(void)parallel;
+	dec_ctx_t d;
+	memset(&d, 0, sizeof d);
+	if (n < HEADER_BYTES) FAIL("crackle: Input too small to be a valid stream. Bytes: %llu", (unsigned long long)n);
+	if (header_read(&d.head, buf, n)) return 1;
+	header_t* h = &d.head;
+	if (h->format_version == 0) FAIL("crackle oracle: reencode of version 0 streams is not restated");
+	if (markov_order < 0 || markov_order > 15) FAIL("crackle oracle: markov order out of range");
+	if (h->markov_model_order == markov_order) {   /* :887-889 */
+		*out = (unsigned char*)xmalloc(n ? n : 1);
+		memcpy(*out, buf, n);
+		*out_len = n;
+		return 0;
+	}
+	d.buf = buf; d.n = n;
+	if (header_bytes(h) + grid_index_bytes(h) + h->num_label_bytes + markov_model_bytes(h) + 4 * ((uint64_t)h->sz + 1) > n)
+		FAIL("crackle: get_crack_code_offsets: Unable to read past end of buffer.");
+	d.labels_binary = buf + header_bytes(h) + grid_index_bytes(h);
+	d.order = h->markov_model_order;
+	if (d.order > 0) d.model = mk_from_stored(d.labels_binary + h->num_label_bytes, markov_model_bytes(h), d.order);
+	if (dec_z_index(&d)) { dec_free(&d, 0); return 1; }
+	const uint64_t sz = h->sz;
+	const uint64_t tail = d.z_index[sz];        /* labels crc + slice crcs follow the codes */
+	if (tail + 4 * (sz + 1) > n) { dec_free(&d, 0); FAIL("crackle: Unable to read past end of buffer."); }
+
+	chainset_t* sets = (chainset_t*)xcalloc(sz ? sz : 1, sizeof(chainset_t));
+	int rc = 0;
+	for (uint64_t z = 0; z < sz && !rc; z++) {
+		const unsigned char* code = buf + d.z_index[z];
+		const uint64_t code_len = d.z_index[z + 1] - d.z_index[z];
+		size_t n_nodes; int bad;
+		uint64_t* nodes = read_boc_index(code, code_len, h->sx, h->sy, &n_nodes, &bad);
+		const uint64_t index_size = code_len >= 4 ? 4 + rd(code, 0, 4) : 0;
+		if (bad || index_size > code_len || code_len < 4) { free(nodes); rc = 1; break; }
+		uint8_t* moves; size_t n_moves;
+		if (d.order == 0) {
+			n_moves = (size_t)(code_len - index_size) * 4;
+			moves = (uint8_t*)xmalloc(n_moves + 1);
+			uint8_t last = 0;
+			size_t m = 0;
+			for (uint64_t i = index_size; i < code_len; i++) {
+				for (int j = 0; j < 4; j++) {
+					uint8_t mv = (uint8_t)(((code[i] >> (2 * j)) & 3) + last) & 3;
+					last = mv;
+					moves[m++] = mv;
+				}
+			}
+		}
+		else moves = mk_decode(code + index_size, code_len - index_size, d.model, d.order, &n_moves);
+		unsigned char* symbols = (unsigned char*)xmalloc(n_moves + 1);
+		size_t nc;
+		dchain_t* chains = moves_to_symbols(moves, n_moves, nodes, n_nodes, symbols, &nc);
+		chainset_t* cs = &sets[z];
+		cs->chains = (chain_t*)xcalloc(nc ? nc : 1, sizeof(chain_t));
+		cs->n = cs->cap = nc;
+		for (size_t c = 0; c < nc; c++) {
+			const size_t len = chains[c].end - chains[c].begin;
+			cs->chains[c].node = chains[c].node;
+			cs->chains[c].codes = (uint8_t*)xmalloc(2 * len + 2);
+			cs->chains[c].n = symbols_to_codepoints(symbols + chains[c].begin, len, cs->chains[c].codes);
+		}
+		/* the unordered map of chains is consumed in ascending node order (pack_codepoints :460-464) */
+		qsort(cs->chains, cs->n, sizeof(chain_t), chain_cmp);
+		free(chains); free(symbols); free(moves); free(nodes);
+	}
+	if (rc) {
+		for (uint64_t z = 0; z < sz; z++) chainset_free(&sets[z]);
+		free(sets); dec_free(&d, 0);
+		FAIL("crackle: malformed crack code");
+	}
+
+	bytes_t* codes = (bytes_t*)xcalloc(sz ? sz : 1, sizeof(bytes_t));
+	bytes_t stored = { 0 };
+	if (markov_order > 0) {
+		const size_t rows = (size_t)1 << (2 * markov_order);
+		uint32_t* stats = (uint32_t*)xcalloc(rows * 4, sizeof(uint32_t));
+		for (uint64_t z = 0; z < sz; z++) {
+			size_t nd;
+			uint8_t* dd = slice_diffcodes(&sets[z], &nd);
+			mk_stats_slice(dd, nd, markov_order, stats);
+			free(dd);
+		}
+		uint8_t* model = (uint8_t*)xmalloc(rows * 4);
+		mk_stats_to_model(stats, rows, model);
+		mk_to_stored(model, rows, &stored);
+		for (uint64_t z = 0; z < sz; z++) {
+			size_t nd;
+			uint8_t* dd = slice_diffcodes(&sets[z], &nd);
+			write_boc_index(&sets[z], h->sx, h->sy, &codes[z]);
+			mk_encode(dd, nd, model, markov_order, &codes[z]);
+			free(dd);
+		}
+		free(model); free(stats);
+	}
+	else {
+		for (uint64_t z = 0; z < sz; z++) pack_codepoints(&sets[z], h->sx, h->sy, &codes[z]);
+	}
+
+	bytes_t o = { 0 };
+	header_t nh = *h;
+	nh.markov_model_order = markov_order;
+	header_write(&nh, &o);
+	const size_t zi0 = o.n;
+	for (uint64_t z = 0; z < sz; z++) bput(&o, codes[z].n, 4);
+	bput(&o, ckl_oracle_crc32c(o.p + zi0, 4 * sz), 4);
+	bpush(&o, d.labels_binary, h->num_label_bytes);
+	if (stored.n) bpush(&o, stored.p, stored.n);
+	for (uint64_t z = 0; z < sz; z++) if (codes[z].n) bpush(&o, codes[z].p, codes[z].n);
+	bpush(&o, buf + tail, 4 * (sz + 1));
+	for (uint64_t z = 0; z < sz; z++) { chainset_free(&sets[z]); free(codes[z].p); }
+	free(sets); free(codes); free(stored.p);
+	dec_free(&d, 0);
+	*out = o.p;
+	*out_len = o.n;
+	return 0;
+}
+
 /* lib::max_label / pixel_pairs (src/lib.hpp:224-256) of one slab plus its first and last
  * voxel: what a sharded encoder all-gathers. */
 int ckl_oracle_stats(

@@ -63,6 +63,11 @@ int ckl_oracle_slice_vcg(
 /* mirrors crackle::crc::crc32c (src/crc.hpp:51-57) */
 uint32_t ckl_oracle_crc32c(const uint8_t* data, uint64_t n);
 
+/* reencode_with_markov_order (src/crackle.hpp:858-984); *out is released with ckl_oracle_free */
+int ckl_oracle_reencode(
+	const unsigned char* buf, uint64_t n, int markov_order, uint64_t parallel,
+	unsigned char** out, uint64_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

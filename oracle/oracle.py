@@ -69,6 +69,10 @@ class _Checker:
     f.restype = C.c_uint32
     f.argtypes = [C.c_char_p, C.c_uint64]
     self._crc = f
+    f = getattr(L, prefix + "reencode")
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    self._reencode = f
 
   # -- reference-shaped surface (fastcrackle.compress/decompress semantics) --
   def compress(self, labels, allow_pins=False, fortran_order=None, markov_model_order=0,
@@ -133,6 +137,18 @@ class _Checker:
     if rc != 0:
       raise RuntimeError(self._err().decode())
     return out.reshape((sx, sy), order="F")
+
+  def reencode(self, binary, markov_model_order, parallel=1):
+    """crackle.reencode (codec.py:877-881 -> crackle.hpp:858-984)."""
+    binary = bytes(binary)
+    out, n = C.c_void_p(), C.c_uint64()
+    rc = self._reencode(binary, len(binary), int(markov_model_order), int(parallel), C.byref(out), C.byref(n))
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    try:
+      return C.string_at(out.value, n.value)
+    finally:
+      self._free(out)
 
   def crc32c(self, data):
     data = bytes(data)

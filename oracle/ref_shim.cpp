@@ -15,6 +15,7 @@
 //   crackle::cc3d::connected_components src/cc3d.hpp:371-400
 //   crackle::crack_code_to_vcg    src/crackle.hpp:414-425
 //   crackle::crc::crc32c          src/crc.hpp:51-57
+//   crackle::reencode_with_markov_order src/crackle.hpp:858-984
 
 #include <cstdint>
 #include <cstdlib>
@@ -150,6 +151,25 @@ int ckl_ref_slice_vcg(
 			head.crack_format == crackle::CrackFormat::PERMISSIBLE,
 			model, vcg_out
 		);
+		return 0;
+	}
+	catch (const std::exception& e) {
+		g_err = e.what();
+		return 1;
+	}
+}
+
+// crackle::reencode_with_markov_order  src/crackle.hpp:858-984
+__attribute__((visibility("default")))
+int ckl_ref_reencode(
+	const unsigned char* buf, uint64_t n, int markov_order, uint64_t parallel,
+	unsigned char** out, uint64_t* out_len
+) {
+	try {
+		std::vector<unsigned char> r = crackle::reencode_with_markov_order(buf, n, markov_order, parallel);
+		*out = static_cast<unsigned char*>(malloc(r.size() ? r.size() : 1));
+		memcpy(*out, r.data(), r.size());
+		*out_len = r.size();
 		return 0;
 	}
 	catch (const std::exception& e) {

@@ -354,3 +354,36 @@ def test_label_statistics_full_size_checksums(checker):
   lo = np.min([b[:3] for b in bb.values()], axis=0)
   hi = np.max([b[3:] for b in bb.values()], axis=0)
   assert tuple(lo) == (0, 0, 0) and tuple(hi) == (sx - 1, sy - 1, sz - 1)
+
+
+def test_reencode_on_device(checker):
+  """crackle.reencode (codec.py:877-881): golden fixtures of one volume at two markov orders must
+  turn into each other; seeded volumes are checked against the oracle's restatement of
+  reencode_with_markov_order (crackle.hpp:858-984), flat and pin label sections alike."""
+  g = golden()
+  for m0, m5 in (("c0_voronoi_u8", "c0_voronoi_u8_m5"), ("c0_voronoi_u8_pins", "c0_voronoi_u8_pins_m5"), ("noise_2000", "noise_2000_m5")):
+    assert crackle_amd.reencode(g[m5], 0) == g[m0], m5
+    assert crackle_amd.reencode(g[m0], 5) == g[m5], m0
+    assert crackle_amd.reencode(g[m0], 0) == g[m0]
+  cases = [
+    (synth.as_numpy_f(synth.voronoi_labels((200, 150, 9), np.uint8, seed=5, cell=(16, 16, 4))), dict()),
+    (synth.as_numpy_f(synth.voronoi_labels((333, 257, 5), np.uint16, seed=6, cell=(32, 32, 8))), dict(markov_model_order=4)),
+    (synth.as_numpy_f(synth.voronoi_labels((130, 70, 33), np.uint32, seed=12, cell=(20, 20, 10))), dict(allow_pins=True, markov_model_order=2)),
+    (synth.random_labels((128, 128, 3), np.uint32, seed=9, high=2000), dict()),             # PERMISSIBLE crack format
+    (np.full((40, 30, 4), 5, np.uint8, order="F"), dict()),                                  # no cracks at all
+    (synth.as_numpy_f(synth.voronoi_labels((1100, 1060, 2), np.uint32, seed=17, cell=(8, 8, 2))), dict(markov_model_order=1)),   # multi-tile slices
+  ]
+  for arr, kw in cases:
+    binary = checker.compress(arr, **kw)
+    for order in (0, 1, 3, 6):
+      want = checker.reencode(binary, order)
+      got = crackle_amd.reencode(binary, order)
+      assert got == want, (arr.shape, kw, order)
+      assert np.array_equal(crackle_amd.decompress(got), arr)
+  # zstack of streams with different models re-encodes them to order 0 first (operations.py:447-457)
+  vol = synth.as_numpy_f(synth.voronoi_labels((96, 80, 12), np.uint16, seed=4, cell=(16, 16, 4)))
+  a = checker.compress(np.asfortranarray(vol[:, :, :5]), markov_model_order=3)
+  b = checker.compress(np.asfortranarray(vol[:, :, 5:]), markov_model_order=0)
+  assert crackle_amd.zstack([a, b]) == checker.compress(vol)
+  with pytest.raises(ValueError):
+    crackle_amd.reencode(binary, 14)

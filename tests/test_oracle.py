@@ -131,3 +131,39 @@ def test_live_reference_agrees(port, ref):
   cr, pr, nr = ref.connected_components(arr)
   cp, pp, np_ = port.connected_components(arr)
   assert nr == np_ and np.array_equal(cr, cp) and np.array_equal(pr, pp)
+
+
+def _pairs():
+  """(order-0 golden, order-5 golden) of the same volume and options."""
+  g = golden()
+  return sorted((k[:-3], k) for k in g if k.endswith("_m5") and k[:-3] in g)
+
+
+def test_reencode_between_golden_orders(port):
+  """reencode_with_markov_order (crackle.hpp:858-984): the reference wrote every golden volume
+  at several markov orders, so one fixture re-encoded must give the other, byte for byte."""
+  g = golden()
+  pairs = _pairs()
+  assert len(pairs) >= 3
+  for m0, m5 in pairs:
+    assert port.reencode(g[m5], 0) == g[m0], m5
+    assert port.reencode(g[m0], 5) == g[m5], m0
+    assert port.reencode(g[m0], 0) == g[m0]
+    back = port.reencode(port.reencode(g[m0], 3), 0)
+    assert back == g[m0]
+
+
+def test_reencode_against_live_reference(port, ref):
+  if ref is None:
+    pytest.skip("oracle/_ref not built")
+  g = golden()
+  names = sorted(n for n in g if len(g[n]) >= 29)[::3]
+  for name in names:
+    for order in (0, 2, 5):
+      try:
+        want = ref.reencode(g[name], order)
+      except RuntimeError:
+        with pytest.raises(RuntimeError):
+          port.reencode(g[name], order)
+        continue
+      assert port.reencode(g[name], order) == want, (name, order)
