@@ -7,13 +7,13 @@ computed by hand-written HIP kernels behind the C-ABI in include/crackle_amd.h.
 from .headers import CrackleHeader, FormatError, LabelFormat, CrackFormat
 from .codec import (
   compress, decompress, decompress_range, header, labels, num_labels, contains,
-  voxel_counts, centroids, bounding_boxes, reencode,
+  voxel_counts, centroids, bounding_boxes, reencode, voxel_connectivity_graph,
 )
 from .operations import zstack, zsplit, zshatter
 
 __all__ = [
   "CrackleHeader", "FormatError", "LabelFormat", "CrackFormat",
   "compress", "decompress", "decompress_range", "header", "labels", "num_labels", "contains",
-  "voxel_counts", "centroids", "bounding_boxes", "reencode",
+  "voxel_counts", "centroids", "bounding_boxes", "reencode", "voxel_connectivity_graph",
   "zstack", "zsplit", "zshatter",
 ]

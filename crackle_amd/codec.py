@@ -304,3 +304,18 @@ def reencode(binary: bytes, markov_model_order: int, parallel: int = 0, device: 
     return C.string_at(out.value, n.value)
   finally:
     _lib.lib().ckl_free(out)
+
+
+def voxel_connectivity_graph(binary: bytes, connectivity: int = 6, parallel: int = 0, device: int = 0) -> np.ndarray:
+  """The voxel connectivity graph of the image as a uint8 array, shape (sx, sy, sz), F order
+  (crackle/operations.py:936-954 -> operations.hpp:667-826).
+  bitset (right hand side is LSB): 00-z+z-y+y-x+x"""
+  if connectivity not in (4, 6):
+    raise ValueError(f"Only 4 and 6 connected are supported. Got: {connectivity}")
+  binary = bytes(binary)
+  head = header(binary)
+  vcg = np.zeros((head.sx, head.sy, head.sz), dtype=np.uint8, order="F")
+  rc = _lib.lib().ckl_voxel_connectivity_graph(binary, len(binary), int(connectivity), int(device), vcg.ctypes.data, vcg.nbytes)
+  if rc != _lib.CKL_OK:
+    _raise(rc)
+  return vcg

@@ -1543,6 +1543,47 @@ __global__ void __launch_bounds__(kBlock) k_paint_runs(
 	}
 }
 
+// ------------------------------------------------------------------------------
+// voxel connectivity graph (operations.hpp:667-826): bit0 +x, bit1 -x, bit2 +y, bit3 -y from the
+// crack planes (a pair across the image border is passable for IMPERMISSIBLE streams and not for
+// PERMISSIBLE ones: the reference starts from all-ones / all-zeros and only touches interior
+// pairs); connectivity 6 adds bit4 +z / bit5 -z where the decoded labels of neighbouring slices
+// agree, and marks the first slice's -z and the last slice's +z.
+// grid = (ceil(sxy / 256), nslices); out: x fastest
+// ------------------------------------------------------------------------------
+template <typename LABEL>
+__global__ void __launch_bounds__(kBlock) k_vcg(
+	RunGeom g, const LABEL* __restrict__ labels, uint32_t six, uint32_t fortran_order, uint32_t nslices, uint64_t sxy, uint8_t* __restrict__ out
+) {
+	const uint32_t zi = blockIdx.y;
+	const uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (p >= sxy) return;
+	const uint32_t y = static_cast<uint32_t>(p / g.sx);
+	const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
+	const uint32_t* pv = g.planeV + zi * g.plane_words;
+	const uint32_t* ph = g.planeH + zi * g.plane_words;
+	// plane bit: crack (IMPERMISSIBLE, flip) or connection (PERMISSIBLE)
+	auto joined = [&](const uint32_t* plane, uint32_t px, uint32_t py) -> uint32_t {
+		const uint32_t bit = (plane[static_cast<uint64_t>(py) * g.row_words + (px >> 5)] >> (px & 31u)) & 1u;
+		return g.flip ? (bit ^ 1u) : bit;
+	};
+	const uint32_t border = g.flip ? 1u : 0u;
+	uint32_t v = 0;
+	v |= (x + 1 < g.sx ? joined(pv, x + 1, y) : border) << 0;
+	v |= (x >= 1 ? joined(pv, x, y) : border) << 1;
+	v |= (y + 1 < g.sy ? joined(ph, x, y + 1) : border) << 2;
+	v |= (y >= 1 ? joined(ph, x, y) : border) << 3;
+	if (six && nslices > 1) {
+		auto at = [&](uint32_t z) -> LABEL {
+			return fortran_order ? labels[static_cast<uint64_t>(z) * sxy + p] : labels[z + static_cast<uint64_t>(nslices) * (y + static_cast<uint64_t>(g.sy) * x)];
+		};
+		const LABEL me = at(zi);
+		if (zi + 1 < nslices ? at(zi + 1) == me : true) v |= 0x10u;
+		if (zi >= 1 ? at(zi - 1) == me : true) v |= 0x20u;
+	}
+	out[static_cast<uint64_t>(zi) * sxy + p] = static_cast<uint8_t>(v);
+}
+
 // compares the accumulated raw crc with the stored per-slice crc32c and the computed
 // component counts with the label section; grid = ceil(nslices / 256)
 __global__ void __launch_bounds__(kBlock) k_check(
@@ -2189,6 +2230,37 @@ void decoder_label_stats(ckl_decoder& d, uint64_t capacity, uint64_t* labels, ui
 	}
 }
 
+// voxel_connectivity_graph of the decoder's range into a device buffer of sx*sy*slices bytes
+void decoder_vcg(ckl_decoder& d, uint8_t* out_device, uint64_t capacity, int connectivity) {
+	const Header& h = d.head;
+	if (connectivity != 4 && connectivity != 6) throw Error(CKL_ERR_ARG, "crackle: voxel_connectivity_graph: only connectivity 4 and 6 are currently supported.");
+	if (d.sxy == 0 || d.nslices == 0) return;
+	const uint64_t need = d.sxy * d.nslices;
+	if (!out_device || capacity < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
+	hipStream_t s = d.stream;
+	const bool six = connectivity == 6 && d.nslices > 1;
+	DevBuf<uint8_t> labels;
+	if (six) {
+		// the z bits compare decoded labels: the whole pipeline runs into a scratch volume first
+		labels.ensure(need * h.data_width);
+		decoder_run(d, labels.p, need * h.data_width, 0, 0);
+	}
+	else decoder_run(d, nullptr, 0, 0, 0, nullptr, true);
+	RunGeom g;
+	g.planeV = d.d_planes.p; g.planeH = d.d_planes.p + d.plane_words * d.nslices;
+	g.row_words = d.row_words; g.plane_words = d.plane_words;
+	g.flip = (h.crack_format == IMPERMISSIBLE) ? 1u : 0u;
+	g.sx = h.sx; g.sy = h.sy;
+	const dim3 grid(static_cast<uint32_t>((d.sxy + kBlock - 1) / kBlock), d.nslices);
+	const uint32_t f = h.fortran_order ? 1u : 0u;
+	if (h.data_width == 1) hipLaunchKernelGGL(k_vcg<uint8_t>, grid, dim3(kBlock), 0, s, g, reinterpret_cast<const uint8_t*>(labels.p), six ? 1u : 0u, f, d.nslices, d.sxy, out_device);
+	else if (h.data_width == 2) hipLaunchKernelGGL(k_vcg<uint16_t>, grid, dim3(kBlock), 0, s, g, reinterpret_cast<const uint16_t*>(labels.p), six ? 1u : 0u, f, d.nslices, d.sxy, out_device);
+	else if (h.data_width == 4) hipLaunchKernelGGL(k_vcg<uint32_t>, grid, dim3(kBlock), 0, s, g, reinterpret_cast<const uint32_t*>(labels.p), six ? 1u : 0u, f, d.nslices, d.sxy, out_device);
+	else hipLaunchKernelGGL(k_vcg<uint64_t>, grid, dim3(kBlock), 0, s, g, reinterpret_cast<const uint64_t*>(labels.p), six ? 1u : 0u, f, d.nslices, d.sxy, out_device);
+	CKL_HIP(hipStreamSynchronize(s));
+	CKL_HIP(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
@@ -2269,6 +2341,39 @@ int ckl_decoder_crack_planes(ckl_decoder* d, const uint32_t** plane_v, const uin
 	}
 	catch (const Error& e) { set_last_error(e.what()); return e.status; }
 	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_decoder_vcg(ckl_decoder* d, uint8_t* out_device, uint64_t out_capacity_bytes, int connectivity) {
+	try {
+		if (!d) throw Error(CKL_ERR_ARG, "crackle_amd: null decoder");
+		select_device(d->device);
+		wait_for_default_stream(d->stream, d->ev_in);
+		decoder_vcg(*d, out_device, out_capacity_bytes, connectivity);
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_voxel_connectivity_graph(const uint8_t* buf, uint64_t n, int connectivity, int device, uint8_t* out_host, uint64_t out_capacity_bytes) {
+	ckl_decoder* d = nullptr;
+	int rc = ckl_decoder_create(buf, n, 0, -1, device, &d);
+	if (rc != CKL_OK) return rc;
+	try {
+		const uint64_t need = d->sxy * d->nslices;
+		if (need) {
+			if (!out_host || out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
+			DevBuf<uint8_t> tmp;
+			tmp.ensure(need);
+			decoder_vcg(*d, tmp.p, need, connectivity);
+			CKL_HIP(hipMemcpy(out_host, tmp.p, need, hipMemcpyDeviceToHost));
+		}
+		else if (connectivity != 4 && connectivity != 6) throw Error(CKL_ERR_ARG, "crackle: voxel_connectivity_graph: only connectivity 4 and 6 are currently supported.");
+		ckl_decoder_destroy(d);
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); ckl_decoder_destroy(d); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); ckl_decoder_destroy(d); return CKL_ERR_RUNTIME; }
 }
 
 int ckl_decoder_last_timing(const ckl_decoder* d, float* pipeline_ms, float* dominant_kernel_ms) {

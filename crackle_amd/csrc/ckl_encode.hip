@@ -1179,6 +1179,7 @@ void crack_pass(
 			if (gn == 0) continue;
 			// group 0 stays on the session's own stream: the runtime multiplexes streams onto few hardware
 			// queues (4 by default), streams created later share one and serialise
+			if (g > 0 && !e.trail_stream[g - 1]) CKL_HIP(hipStreamCreateWithFlags(&e.trail_stream[g - 1], hipStreamNonBlocking));      // only when slice groups are asked for
 			hipStream_t gs = g == 0 ? s : e.trail_stream[g - 1];
 			if (g > 0) CKL_HIP(hipStreamWaitEvent(gs, e.ev_fork, 0));
 			ta.z0 = z0;
@@ -1644,9 +1645,18 @@ void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int devic
 	for (uint64_t z = 0; z < sz; z++) old_tail += rd_le(buf + off_index + 4 * z, 4);
 	if (old_tail + 4 * (sz + 1) > n) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
 
+	const bool prof = getenv("CKL_PROFILE") != nullptr;
+	auto t_prev = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (!prof) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[ckl reencode host ms] %s=%.2f\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+		t_prev = now;
+	};
 	struct DecoderGuard { ckl_decoder* d = nullptr; ~DecoderGuard() { if (d) ckl_decoder_destroy(d); } } dec;
 	struct EncoderGuard { ckl_encoder* e = nullptr; ~EncoderGuard() { if (e) ckl_encoder_destroy(e); } } enc;
 	if (ckl_decoder_create(buf, n, 0, -1, device, &dec.d) != CKL_OK) throw Error(CKL_ERR_RUNTIME, ckl_last_error());
+	lap("decoder_create");
 	CrackResult cr;
 	std::vector<uint8_t> model, stored_model;
 	head.markov_model_order = markov_order;
@@ -1655,7 +1665,9 @@ void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int devic
 		uint32_t row_words = 0;
 		uint64_t plane_words = 0;
 		if (ckl_decoder_crack_planes(dec.d, &cv, &ch, &row_words, &plane_words) != CKL_OK) throw Error(CKL_ERR_RUNTIME, ckl_last_error());
+		lap("crack_planes");
 		if (ckl_encoder_create(head.sx, head.sy, head.sz, 1, device, &enc.e) != CKL_OK) throw Error(CKL_ERR_RUNTIME, ckl_last_error());
+		lap("encoder_create");
 		ckl_encoder& e = *enc.e;
 		hipStream_t s = e.stream;
 		const uint32_t ns = head.sz;
@@ -1671,8 +1683,11 @@ void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int devic
 		std::vector<uint32_t> c = download(e.d_count_vh.p, 2 * static_cast<size_t>(ns), s);
 		e.count_v.assign(c.begin(), c.begin() + ns);
 		e.count_h.assign(c.begin() + ns, c.end());
+		lap("planes");
 		graph_pass(e, head.sx, head.sy, head.sz, permissible);
+		lap("graph");
 		crack_pass(e, head.sx, head.sy, head.sz, permissible, markov_order, false, nullptr, nullptr, &model, &cr);
+		lap("cracks");
 		if (markov_order > 0) stored_model = markov_model_to_stored(model);
 	}
 	else cr.code_len.assign(sz, 0);
@@ -1695,6 +1710,7 @@ void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int devic
 		if (!stored_model.empty()) memcpy(o + off_model, stored_model.data(), stored_model.size());
 		memcpy(o + off_tail, buf + old_tail, 4 * (sz + 1));
 		if (cr.total) CKL_HIP(hipStreamSynchronize(enc.e->stream));
+		lap("assembly");
 	}
 	catch (...) { host_out_free(o); throw; }
 	*out = o;
@@ -1732,7 +1748,6 @@ int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int 
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
 		for (auto& ev : e->ev_join) CKL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-		for (auto& st : e->trail_stream) CKL_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 		*out = e.release();
 		return CKL_OK;
 	}

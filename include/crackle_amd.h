@@ -123,6 +123,15 @@ int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_byte
 int ckl_decoder_crack_planes(
 	ckl_decoder* d, const uint32_t** plane_v_device, const uint32_t** plane_h_device,
 	uint32_t* row_words, uint64_t* plane_words);
+/* Replaces crackle::operations::voxel_connectivity_graph (src/operations.hpp:667-826, bound at
+ * src/fastcrackle.cpp:538-565): one byte per voxel of the decoder's z-range, x fastest, bit0 +x,
+ * bit1 -x, bit2 +y, bit3 -y (from the crack planes), and for connectivity 6 bit4 +z / bit5 -z
+ * where neighbouring slices carry the same label (first slice -z and last slice +z always set).
+ * ckl_decoder_vcg writes into a DEVICE buffer; ckl_voxel_connectivity_graph is the one-shot
+ * form over the whole volume with a HOST buffer of sx*sy*sz bytes. */
+int ckl_decoder_vcg(ckl_decoder* d, uint8_t* out_device, uint64_t out_capacity_bytes, int connectivity);
+int ckl_voxel_connectivity_graph(const uint8_t* buf, uint64_t n, int connectivity, int device, uint8_t* out_host, uint64_t out_capacity_bytes);
+
 /* Per-label statistics of the decoder's z-range without materialising the volume:
  * replaces crackle::operations::voxel_counts / centroids / bounding_boxes
  * (src/operations.hpp:321-618, bound by src/fastcrackle.cpp:346-420).  The pipeline runs up

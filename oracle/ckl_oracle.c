@@ -1485,6 +1485,49 @@ int ckl_oracle_slice_vcg(const unsigned char* buf, uint64_t n, int64_t z, uint8_
 	return rc;
 }
 
+/* operations::voxel_connectivity_graph (src/operations.hpp:667-826), whole volume: the four
+ * in-plane bits of every voxel are the slice's voxel connectivity graph as the crack decoder
+ * leaves it (crack_code_to_vcg; bit0 +x, bit1 -x, bit2 +y, bit3 -y), connectivity 6 adds bit4
+ * (+z) / bit5 (-z) between voxels of equal label in neighbouring slices and marks the first
+ * slice's -z and the last slice's +z as passable.  vcg: sx*sy*sz bytes, x fastest. */
+int ckl_oracle_voxel_connectivity_graph(
+	const unsigned char* buf, uint64_t n, int connectivity, uint64_t parallel, uint8_t* vcg
+) {
+	if (connectivity != 4 && connectivity != 6) FAIL("crackle: voxel_connectivity_graph: only connectivity 4 and 6 are currently supported.");
+	header_t h;
+	if (header_read(&h, buf, n)) return 1;
+	const uint64_t sxy = (uint64_t)h.sx * h.sy;
+	if (sxy * h.sz == 0) return 0;
+	for (uint64_t z = 0; z < h.sz; z++) {
+		if (ckl_oracle_slice_vcg(buf, n, (int64_t)z, vcg + z * sxy)) return 1;
+	}
+	if (h.sz == 1 || connectivity == 4) return 0;     /* :757-759 */
+	/* the reference compares label_map[ccl] of neighbouring slices: the decoded labels */
+	uint8_t* lab = (uint8_t*)xmalloc(sxy * h.sz * (uint64_t)h.data_width);
+	if (ckl_oracle_decompress(buf, n, lab, 0, -1, parallel, 0, 0)) { free(lab); return 1; }
+	const int w = h.data_width;
+	for (uint64_t z = 1; z < h.sz; z++) {
+		for (uint64_t y = 0; y < h.sy; y++) {
+			for (uint64_t x = 0; x < h.sx; x++) {
+				const uint64_t loc = x + (uint64_t)h.sx * y;
+				/* decompress honours the stream's memory order */
+				const uint64_t top = h.fortran_order ? loc + (z - 1) * sxy : (z - 1) + (uint64_t)h.sz * (y + (uint64_t)h.sy * x);
+				const uint64_t bot = h.fortran_order ? loc + z * sxy : z + (uint64_t)h.sz * (y + (uint64_t)h.sy * x);
+				if (memcmp(lab + top * w, lab + bot * w, (size_t)w) == 0) {
+					vcg[loc + (z - 1) * sxy] |= 0x10;
+					vcg[loc + z * sxy] |= 0x20;
+				}
+			}
+		}
+	}
+	for (uint64_t loc = 0; loc < sxy; loc++) {        /* :812-821 */
+		vcg[loc] |= 0x20;
+		vcg[loc + (h.sz - 1) * sxy] |= 0x10;
+	}
+	free(lab);
+	return 0;
+}
+
 /* reencode_with_markov_order (src/crackle.hpp:858-984): every slice's crack code is taken
  * apart into chains of symbols (crack_code_to_symbols, :394-411), turned back into code points
  * (symbols_to_codepoints, src/crackcodes.hpp:128-183) and packed again under the new order

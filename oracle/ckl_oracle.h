@@ -63,6 +63,10 @@ int ckl_oracle_slice_vcg(
 /* mirrors crackle::crc::crc32c (src/crc.hpp:51-57) */
 uint32_t ckl_oracle_crc32c(const uint8_t* data, uint64_t n);
 
+/* operations::voxel_connectivity_graph (src/operations.hpp:667-826), whole volume; vcg: sx*sy*sz bytes */
+int ckl_oracle_voxel_connectivity_graph(
+	const unsigned char* buf, uint64_t n, int connectivity, uint64_t parallel, uint8_t* vcg);
+
 /* reencode_with_markov_order (src/crackle.hpp:858-984); *out is released with ckl_oracle_free */
 int ckl_oracle_reencode(
 	const unsigned char* buf, uint64_t n, int markov_order, uint64_t parallel,

@@ -69,6 +69,10 @@ class _Checker:
     f.restype = C.c_uint32
     f.argtypes = [C.c_char_p, C.c_uint64]
     self._crc = f
+    f = getattr(L, prefix + "voxel_connectivity_graph")
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p]
+    self._vcg3d = f
     f = getattr(L, prefix + "reencode")
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -137,6 +141,17 @@ class _Checker:
     if rc != 0:
       raise RuntimeError(self._err().decode())
     return out.reshape((sx, sy), order="F")
+
+  def voxel_connectivity_graph(self, binary, connectivity=6, parallel=1):
+    """crackle.voxel_connectivity_graph (operations.py:936-954): uint8 (sx, sy, sz), F order."""
+    import numpy as np
+    binary = bytes(binary)
+    sx, sy, sz = (int.from_bytes(binary[o:o + 4], "little") for o in (7, 11, 15))
+    out = np.zeros((sx, sy, sz), dtype=np.uint8, order="F")
+    rc = self._vcg3d(binary, len(binary), int(connectivity), int(parallel), out.ctypes.data)
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    return out
 
   def reencode(self, binary, markov_model_order, parallel=1):
     """crackle.reencode (codec.py:877-881 -> crackle.hpp:858-984)."""

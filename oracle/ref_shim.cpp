@@ -16,6 +16,7 @@
 //   crackle::crack_code_to_vcg    src/crackle.hpp:414-425
 //   crackle::crc::crc32c          src/crc.hpp:51-57
 //   crackle::reencode_with_markov_order src/crackle.hpp:858-984
+//   crackle::operations::voxel_connectivity_graph src/operations.hpp:667-826
 
 #include <cstdint>
 #include <cstdlib>
@@ -26,6 +27,7 @@
 #include <limits>
 
 #include "crackle.hpp"
+#include "operations.hpp"
 
 static thread_local std::string g_err;
 
@@ -151,6 +153,25 @@ int ckl_ref_slice_vcg(
 			head.crack_format == crackle::CrackFormat::PERMISSIBLE,
 			model, vcg_out
 		);
+		return 0;
+	}
+	catch (const std::exception& e) {
+		g_err = e.what();
+		return 1;
+	}
+}
+
+// crackle::operations::voxel_connectivity_graph  src/operations.hpp:667-826
+// vcg_out: sx*sy*sz bytes (whole volume, x fastest)
+__attribute__((visibility("default")))
+int ckl_ref_voxel_connectivity_graph(
+	const unsigned char* buf, uint64_t n, int connectivity, uint64_t parallel, uint8_t* vcg_out
+) {
+	try {
+		crackle::CrackleHeader head(buf);
+		uint8_t* vcg = crackle::operations::voxel_connectivity_graph(buf, n, 0, -1, parallel, connectivity);
+		memcpy(vcg_out, vcg, static_cast<size_t>(head.sx) * head.sy * head.sz);
+		delete[] vcg;
 		return 0;
 	}
 	catch (const std::exception& e) {

@@ -387,3 +387,28 @@ def test_reencode_on_device(checker):
   assert crackle_amd.zstack([a, b]) == checker.compress(vol)
   with pytest.raises(ValueError):
     crackle_amd.reencode(binary, 14)
+
+
+def test_voxel_connectivity_graph(checker):
+  """crackle.voxel_connectivity_graph (operations.py:936-954) against the oracle's restatement of
+  operations.hpp:667-826: golden streams (flat, pins, markov, C order, PERMISSIBLE noise, single
+  slices) and seeded volumes, connectivity 4 and 6."""
+  g = golden()
+  names = [n for n in sorted(g) if len(g[n]) >= 29 and SMALL.get(n, (np.zeros(0),))[0].size][::4]
+  names += ["c0_voronoi_u8_c", "noise_2000", "c0_voronoi_u8_pins_m5"]
+  for name in names:
+    for conn in (4, 6):
+      want = checker.voxel_connectivity_graph(g[name], conn)
+      got = crackle_amd.voxel_connectivity_graph(g[name], conn)
+      assert got.dtype == np.uint8 and got.shape == want.shape and got.flags.f_contiguous
+      assert np.array_equal(got, want), (name, conn, int((got != want).sum()))
+  for shape, dt, kw in [((200, 150, 9), np.uint8, dict()), ((333, 257, 5), np.uint16, dict(markov_model_order=4)), ((130, 70, 33), np.uint64, dict(allow_pins=True))]:
+    arr = synth.as_numpy_f(synth.voronoi_labels(shape, dt, seed=5, cell=(16, 16, 4)))
+    binary = checker.compress(arr, **kw)
+    for conn in (4, 6):
+      assert np.array_equal(crackle_amd.voxel_connectivity_graph(binary, conn), checker.voxel_connectivity_graph(binary, conn)), (shape, conn)
+  # the +z bit is what numpy says about the labels
+  v6 = crackle_amd.voxel_connectivity_graph(binary, 6)
+  assert np.array_equal((v6[:, :, :-1] & 0x10) != 0, arr[:, :, :-1] == arr[:, :, 1:])
+  with pytest.raises(ValueError):
+    crackle_amd.voxel_connectivity_graph(binary, 8)

@@ -167,3 +167,42 @@ def test_reencode_against_live_reference(port, ref):
           port.reencode(g[name], order)
         continue
       assert port.reencode(g[name], order) == want, (name, order)
+
+
+def _numpy_vcg(arr, border):
+  """Connectivity of equal neighbours: what operations.hpp:667-826 yields for a stream whose
+  cracks sit exactly at label changes; `border` is the bit given to pairs across the image edge
+  in x / y (1 for IMPERMISSIBLE streams, 0 for PERMISSIBLE ones)."""
+  sx, sy, sz = arr.shape
+  v = np.zeros(arr.shape, dtype=np.uint8)
+  eqx = arr[1:, :, :] == arr[:-1, :, :]
+  eqy = arr[:, 1:, :] == arr[:, :-1, :]
+  v[:-1, :, :] |= eqx.astype(np.uint8) << 0
+  v[-1, :, :] |= border << 0
+  v[1:, :, :] |= eqx.astype(np.uint8) << 1
+  v[0, :, :] |= border << 1
+  v[:, :-1, :] |= eqy.astype(np.uint8) << 2
+  v[:, -1, :] |= border << 2
+  v[:, 1:, :] |= eqy.astype(np.uint8) << 3
+  v[:, 0, :] |= border << 3
+  if sz > 1:
+    eqz = arr[:, :, 1:] == arr[:, :, :-1]
+    v[:, :, :-1] |= eqz.astype(np.uint8) << 4
+    v[:, :, 1:] |= eqz.astype(np.uint8) << 5
+    v[:, :, -1] |= 1 << 4
+    v[:, :, 0] |= 1 << 5
+  return v
+
+
+def test_voxel_connectivity_graph_restatement(port, ref):
+  g = golden()
+  for name in ("c0_voronoi_u8", "c0_voronoi_u8_m5", "c0_voronoi_u8_pins", "c0_voronoi_u8_c", "noise_2000"):
+    arr = np.asarray(SMALL[name][0])
+    crack_format = (int.from_bytes(g[name][5:7], "little") >> 4) & 1
+    got = port.voxel_connectivity_graph(g[name], 6)
+    assert np.array_equal(got, _numpy_vcg(arr, 0 if crack_format else 1)), name
+    assert np.array_equal(port.voxel_connectivity_graph(g[name], 4), got & 0x0F)
+    if ref is not None:
+      assert np.array_equal(ref.voxel_connectivity_graph(g[name], 6), got), name
+  with pytest.raises(RuntimeError):
+    port.voxel_connectivity_graph(g["c0_voronoi_u8"], 8)
