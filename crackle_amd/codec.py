@@ -319,3 +319,27 @@ def voxel_connectivity_graph(binary: bytes, connectivity: int = 6, parallel: int
   if rc != _lib.CKL_OK:
     _raise(rc)
   return vcg
+
+
+def crack_crcs(binary: bytes) -> Optional[np.ndarray]:
+  """The stored per-slice crc32c of the component images (codec.py:215-223)."""
+  head = header(binary)
+  if head.format_version == 0:
+    return None
+  crcl = head.sz * 4
+  return np.frombuffer(bytes(binary)[-crcl:] if crcl else b"", dtype=np.uint32)
+
+
+def structure_equal(binary1: bytes, binary2: bytes, parallel: int = 0, device: int = 0) -> bool:
+  """Whether two streams partition the volume the same way, whatever the labels
+  (crackle/operations.py:996-1021): same shape, same stored crcs of the component images, same
+  4-connected voxel connectivity graph (computed on the device)."""
+  h1, h2 = header(binary1), header(binary2)
+  if h1.sx != h2.sx or h1.sy != h2.sy or h1.sz != h2.sz:
+    return False
+  if h1.format_version > 0 and h2.format_version > 0:
+    if not np.all(crack_crcs(binary1) == crack_crcs(binary2)):
+      return False
+  vcg1 = voxel_connectivity_graph(binary1, connectivity=4, parallel=parallel, device=device)
+  vcg2 = voxel_connectivity_graph(binary2, connectivity=4, parallel=parallel, device=device)
+  return bool(np.all(vcg1 == vcg2))

@@ -412,3 +412,19 @@ def test_voxel_connectivity_graph(checker):
   assert np.array_equal((v6[:, :, :-1] & 0x10) != 0, arr[:, :, :-1] == arr[:, :, 1:])
   with pytest.raises(ValueError):
     crackle_amd.voxel_connectivity_graph(binary, 8)
+
+
+def test_structure_equal(checker):
+  """structure_equal (operations.py:996-1021): encodings of one partition agree whatever the
+  labels, markov order or label format; a moved boundary does not."""
+  arr = synth.as_numpy_f(synth.voronoi_labels((96, 80, 12), np.uint16, seed=4, cell=(16, 16, 4)))
+  a = checker.compress(arr)
+  relabelled = checker.compress((arr.astype(np.uint32) * 7 + 3).astype(np.uint32))
+  assert crackle_amd.structure_equal(a, checker.compress(arr, markov_model_order=3))
+  assert crackle_amd.structure_equal(a, checker.compress(arr, allow_pins=True))
+  assert crackle_amd.structure_equal(a, relabelled)
+  moved = arr.copy(order="F")
+  moved[10:14, 20:23, 5] = moved[9, 19, 5] + 1
+  assert not crackle_amd.structure_equal(a, checker.compress(moved))
+  assert not crackle_amd.structure_equal(a, checker.compress(np.asfortranarray(arr[:, :, :6])))
+  assert crackle_amd.crack_crcs(a).dtype == np.uint32 and crackle_amd.crack_crcs(a).size == 12

@@ -18,7 +18,8 @@ def main():
   vol = synth.as_numpy_f(synth.voronoi_labels((256, 192, 4), np.uint32, seed=71, cell=(16, 16, 4)))
   streams += [chk.compress(vol, markov_model_order=m) for m in (0, 3)]
   streams += [chk.compress(synth.random_labels((96, 96, 2), np.uint8, seed=72, high=2), markov_model_order=2)]
-  ok = err = 0
+  ok = err = ok2 = err2 = 0
+  wide = len(sys.argv) > 2 and sys.argv[2] == "wide"
   for t in range(trials):
     b = bytearray(streams[t % len(streams)])
     n = len(b)
@@ -31,9 +32,19 @@ def main():
       ok += 1
     except (RuntimeError, ValueError, crackle_amd.FormatError):
       err += 1
+    if wide:
+      # the consumers of the decode path must come back as well (an answer or an error)
+      for fn in (lambda: crackle_amd.voxel_counts(bytes(b)), lambda: crackle_amd.bounding_boxes(bytes(b)),
+                 lambda: crackle_amd.voxel_connectivity_graph(bytes(b), 6),
+                 lambda: crackle_amd.reencode(bytes(b), 1 if crackle_amd.header(bytes(b)).markov_model_order != 1 else 0)):
+        try:
+          fn()
+          ok2 += 1
+        except (RuntimeError, ValueError, KeyError, crackle_amd.FormatError):
+          err2 += 1
     if t % 50 == 49:
       print(f"trial {t + 1}: decoded {ok}, rejected {err}", flush=True)
-  print(f"done: {trials} corrupted streams, decoded {ok}, rejected {err}, no faults")
+  print(f"done: {trials} corrupted streams, decoded {ok}, rejected {err}, no faults" + (f"; statistics / vcg / reencode calls: {ok2} answered, {err2} rejected" if wide else ""))
 
 
 if __name__ == "__main__":
