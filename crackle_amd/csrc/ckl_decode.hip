@@ -1998,7 +1998,7 @@ void launch_resolve_and_stats(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	const uint32_t ns = d.nslices;
 	ResolveScratch rs;
 	rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
-	hipLaunchKernelGGL(k_run_count, dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs);
+	hipLaunchKernelGGL(k_run_count, dim3(run_count_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs);
 	st.done("k_run_count");
 	hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
 	st.done("k_run_rank");
@@ -2024,7 +2024,7 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	if (flat) st.done("k_label_map");
 	ResolveScratch rs;
 	rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
-	hipLaunchKernelGGL(k_run_count, dim3(rs.nblk, ns), dim3(kBlock), 0, s, ra, rs);
+	hipLaunchKernelGGL(k_run_count, dim3(run_count_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs);
 	st.done("k_run_count");
 	hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
 	st.done("k_run_rank");

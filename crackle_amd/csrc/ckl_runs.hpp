@@ -72,9 +72,13 @@ struct RunArrays {
 
 constexpr int kIndexBlock = 1024;     // one workgroup per slice: as many threads as a workgroup can have
 
-// grid = nslices, block = kIndexBlock
+// grid = nslices, block = kIndexBlock.  The first pixels of a step's runs are collected in LDS
+// and written out as one contiguous stretch (each thread owns a variable number of them: written
+// straight from the threads they would land a few bytes per cache line and store instruction).
+constexpr uint32_t kIndexStage = 8192;     // runs of one step (4096 plane words) staged in LDS; denser steps write directly
 static __global__ void __launch_bounds__(kIndexBlock) k_run_index(RunGeom g, RunArrays r) {
 	__shared__ uint32_t s_scan[kIndexBlock / kWave];
+	__shared__ uint32_t s_runs[kIndexStage];
 	const uint32_t zi = blockIdx.x;
 	uint32_t* wb = r.word_base + zi * g.plane_words;
 	uint32_t* parent = r.parent + r.rbase[zi];
@@ -97,20 +101,32 @@ static __global__ void __launch_bounds__(kIndexBlock) k_run_index(RunGeom g, Run
 		}
 		uint32_t v[1] = { cnt }, tot[1];
 		block_excl_add<1, kIndexBlock / kWave>(v, tot, s_scan);
-		uint32_t base = carry + v[0];
+		const bool staged = tot[0] <= kIndexStage;
+		uint32_t local = v[0];
 #pragma unroll
 		for (uint32_t j = 0; j < kPer; j++) {
 			const uint32_t wi = w0 + threadIdx.x * kPer + j;
 			if (wi >= words) break;
-			wb[wi] = base;
+			wb[wi] = carry + local;
 			const uint32_t y = wi / g.row_words;
 			const uint32_t x0 = (wi - y * g.row_words) * 32u;
 			for (uint32_t m = b[j]; m; m &= m - 1u) {
 				const uint32_t bit = __ffs(m) - 1;
-				if (base < cap) { run_start[base] = y * g.sx + x0 + bit; parent[base] = base; }
+				const uint32_t start = y * g.sx + x0 + bit;
+				if (staged) s_runs[local] = start;
+				else if (carry + local < cap) { run_start[carry + local] = start; parent[carry + local] = carry + local; }
 				else err = ERR_CAPACITY;
-				base++;
+				local++;
 			}
+		}
+		if (staged) {
+			__syncthreads();
+			for (uint32_t i = threadIdx.x; i < tot[0]; i += kIndexBlock) {
+				const uint32_t at = carry + i;
+				if (at < cap) { run_start[at] = s_runs[i]; parent[at] = at; }
+				else err = ERR_CAPACITY;
+			}
+			__syncthreads();
 		}
 		carry += tot[0];
 	}
@@ -292,23 +308,35 @@ struct ResolveScratch {
 	uint32_t nblk;             // blocks per slice = ceil(max run capacity / 256)
 };
 
-// step 1, grid = (nblk, nslices): count the roots per 256-run block (a root is its own
-// parent once all unions are in: no pointer chasing here)
+// step 1, grid = (run_count_blocks(nblk), nslices): count the roots per 256-run block (a root is
+// its own parent once all unions are in: no pointer chasing here); a workgroup takes
+// kCountBlocks blocks at once (their loads and scans share one trip to memory and one barrier pair)
+constexpr uint32_t kCountBlocks = 4;
+static inline uint32_t run_count_blocks(uint32_t nblk) { return (nblk + kCountBlocks - 1) / kCountBlocks; }
 static __global__ void __launch_bounds__(kBlock) k_run_count(RunArrays r, ResolveScratch rs) {
-	__shared__ uint32_t s_scan[kWaves];
+	__shared__ uint32_t s_scan[kCountBlocks * kWaves];
 	const uint32_t zi = blockIdx.y;
 	const uint32_t n = r.nruns[zi];
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (blockIdx.x * kBlock >= n) {
-		if (threadIdx.x == 0) rs.blk_roots[zi * rs.nblk + blockIdx.x] = 0;
+	const uint32_t b0 = blockIdx.x * kCountBlocks;
+	if (b0 * kBlock >= n) {
+		if (threadIdx.x < kCountBlocks && b0 + threadIdx.x < rs.nblk) rs.blk_roots[zi * rs.nblk + b0 + threadIdx.x] = 0;
 		return;
 	}
 	const uint32_t* parent = r.parent + r.rbase[zi];
-	const uint32_t is_root = (i < n && parent[i] == i) ? 1u : 0u;
-	uint32_t v[1] = { is_root }, tot[1];
-	block_excl_add<1>(v, tot, s_scan);
-	if (is_root) rs.run_local[r.rbase[zi] + i] = static_cast<uint16_t>(v[0]);
-	if (threadIdx.x == 0) rs.blk_roots[zi * rs.nblk + blockIdx.x] = tot[0];
+	uint32_t v[kCountBlocks], tot[kCountBlocks], is_root[kCountBlocks];
+#pragma unroll
+	for (uint32_t k = 0; k < kCountBlocks; k++) {
+		const uint32_t i = (b0 + k) * kBlock + threadIdx.x;
+		is_root[k] = (i < n && parent[i] == i) ? 1u : 0u;
+		v[k] = is_root[k];
+	}
+	block_excl_add<kCountBlocks>(v, tot, s_scan);
+#pragma unroll
+	for (uint32_t k = 0; k < kCountBlocks; k++) {
+		const uint32_t i = (b0 + k) * kBlock + threadIdx.x;
+		if (is_root[k]) rs.run_local[r.rbase[zi] + i] = static_cast<uint16_t>(v[k]);
+		if (threadIdx.x == 0 && b0 + k < rs.nblk) rs.blk_roots[zi * rs.nblk + b0 + k] = tot[k];
+	}
 }
 
 // step 2, grid = nslices: exclusive prefix of the per-block root counts -> component count
@@ -413,7 +441,7 @@ static __global__ void __launch_bounds__(kBlock) k_run_assign(RunArrays r, Resol
 // the three steps on one stream (component ids only)
 static inline void launch_run_resolve(hipStream_t s, uint32_t nslices, const RunArrays& r, const ResolveScratch& rs, const uint32_t* G, uint32_t n_pixels, uint32_t idbits_in, uint32_t* crc_acc, uint32_t* idbits_out) {
 	static_assert(kBlock == 256, "run_local is indexed by root >> 8");
-	hipLaunchKernelGGL(k_run_count, dim3(rs.nblk, nslices), dim3(kBlock), 0, s, r, rs);
+	hipLaunchKernelGGL(k_run_count, dim3(run_count_blocks(rs.nblk), nslices), dim3(kBlock), 0, s, r, rs);
 	hipLaunchKernelGGL(k_run_rank, dim3(nslices), dim3(kBlock), 0, s, r, rs, idbits_in, crc_acc, idbits_out);
 	RunLabelArgs none = {};
 	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(run_assign_blocks(rs.nblk), nslices), dim3(kBlock), 0, s, r, rs, G, n_pixels, idbits_in, crc_acc, none);
