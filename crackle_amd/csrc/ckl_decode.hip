@@ -582,14 +582,15 @@ __device__ __forceinline__ void raster_moves(
 	else if (cur_word) atomicOr(cur_word, cur_bits);
 }
 
-// The same for the LDS band buffer (rows [band_y0, band_y0 + band_rows) of both planes, H behind
-// V), written for the instruction count: the loop body runs 128 times per thread and pass and is
-// what k_decode_cracks spends most of its time in.  One predicated ds_or per move, no branches
-// besides the jump at a 't': vertical moves of a trail change the row every time and so hardly
-// ever share a plane word with their predecessor; collecting bits per word is not worth its
-// compares here.
-template <bool SKIP>
-__device__ __forceinline__ void raster_band(
+// The same for the LDS band buffer, one plane per pass: HORIZ rasterises the horizontal moves
+// into rows [band_y0, band_y0 + band_rows) of plane H, otherwise the vertical moves into plane V.
+// Written for the instruction count (the loop body is what k_decode_cracks spends most of its
+// time in): a pass only visits the moves of its orientation; the vertex of a move is the
+// segment's offset plus the displacement before it, which inside a word is four popcounts, so
+// the moves of the other orientation never have to be stepped through.  One ds_or per move:
+// vertical moves change the row every time and hardly ever share a plane word.
+template <bool HORIZ, bool SKIP>
+__device__ __forceinline__ void raster_plane(
 	const WordSyms (&ws)[kCrackWords], uint32_t o_t, uint32_t o_dx, uint32_t o_dy, uint32_t valid_segs,
 	const uint32_t* seg_x, const uint32_t* seg_y, uint32_t sx, uint32_t sy, uint32_t row_words,
 	uint32_t* band, uint32_t band_y0, uint32_t band_rows, uint32_t& rerr
@@ -597,56 +598,56 @@ __device__ __forceinline__ void raster_band(
 	uint32_t bx = 0, by = 0;
 	uint32_t act = o_t < valid_segs ? 1u : 0u;
 	if (act) { bx = seg_x[o_t]; by = seg_y[o_t]; }
-	uint32_t x = bx + o_dx, y = by + o_dy;
-	const uint32_t h_off = band_rows * row_words;
+	uint32_t dx = o_dx, dy = o_dy;        // displacement of the whole stream before the current word
 	uint32_t bad = 0;
 #pragma unroll
 	for (uint32_t j = 0; j < kCrackWords; j++) {
 		const WordSyms& w = ws[j];
-		if (SKIP && w.isT == 0u) {
+		const uint32_t mR = w.right(), mL = w.left(), mD = w.down(), mU = w.up(), isT = w.isT;
+		const uint32_t nr = __popc(mR), nl = __popc(mL), nd = __popc(mD), nu = __popc(mU);
+		bool skip = isT == 0u && !act;        // a cut-off segment stays silent until the next jump
+		if (SKIP && isT == 0u && act) {
 			// (many-band slices) no jump inside this word: its moves stay within a box known from
-			// four popcounts.  A box inside the grid that misses the band (with the one-row reach
-			// of vertical moves) is skipped whole; everything else takes the exact path below.
-			const uint32_t nr = __popc(w.right()), nl = __popc(w.left()), nd = __popc(w.down()), nu = __popc(w.up());
+			// the four popcounts.  A box inside the grid (no range error possible) that misses the
+			// band, with the one-row reach of vertical moves, is skipped whole.
+			const uint32_t x = bx + dx, y = by + dy;
 			const bool inside = x >= nl && x + nr <= sx && y >= nu && y + nd <= sy;
-			const uint32_t lo = y - nu, hi = y + nd;
-			if (inside && (hi + 1u < band_y0 || lo > band_y0 + band_rows)) {
-				x += nr - nl; y += nd - nu;
-				continue;
-			}
+			skip = inside && (y + nd + 1u < band_y0 || y - nu > band_y0 + band_rows);
 		}
-		const uint32_t prevs = w.prevs, isT = w.isT;
-		for (uint32_t m = w.ms | isT; m; m &= m - 1u) {
-			const uint32_t b = __ffs(m) - 1u;
-			if ((isT >> b) & 1u) {
-				o_t++;
-				act = o_t < valid_segs ? 1u : 0u;
-				if (act) {
-					const uint32_t nbx = seg_x[o_t], nby = seg_y[o_t];
-					x += nbx - bx; y += nby - by;
-					bx = nbx; by = nby;
+		if (!skip) {
+			for (uint32_t m = (HORIZ ? (mR | mL) : (mD | mU)) | isT; m; m &= m - 1u) {
+				const uint32_t b = __ffs(m) - 1u;
+				if ((isT >> b) & 1u) {
+					o_t++;
+					act = o_t < valid_segs ? 1u : 0u;
+					if (act) { bx = seg_x[o_t]; by = seg_y[o_t]; }
+					continue;
 				}
-				continue;
+				const uint32_t below = (1u << b) - 1u;
+				const uint32_t x = bx + dx + __popc(mR & below) - __popc(mL & below);
+				const uint32_t y = by + dy + __popc(mD & below) - __popc(mU & below);
+				uint32_t in_range, ok, row, col;
+				if (HORIZ) {
+					const uint32_t neg = (mL >> b) & 1u;                 // left
+					const uint32_t nx = x + 1u - 2u * neg;
+					col = x - neg; row = y;                                // the crossed crack sits at the smaller vertex
+					in_range = static_cast<uint32_t>(max(x, nx) <= sx) & static_cast<uint32_t>(y <= sy);
+					// a move along the outer border crosses no crack of the planes
+					ok = static_cast<uint32_t>(row - 1u < sy - 1u) & static_cast<uint32_t>(col < sx);
+				}
+				else {
+					const uint32_t neg = (mU >> b) & 1u;                 // up
+					const uint32_t ny = y + 1u - 2u * neg;
+					col = x; row = y - neg;
+					in_range = static_cast<uint32_t>(x <= sx) & static_cast<uint32_t>(max(y, ny) <= sy);
+					ok = static_cast<uint32_t>(col - 1u < sx - 1u) & static_cast<uint32_t>(row < sy);
+				}
+				const uint32_t rel = row - band_y0;
+				bad |= act & (in_range ^ 1u);
+				if (act & in_range & ok & (rel < band_rows ? 1u : 0u)) atomicOr(band + rel * row_words + (col >> 5), 1u << (col & 31u));
 			}
-			// selects are written as masks: the compiler turns ?: on lane-varying conditions into
-			// divergent branches here, which cost more than the arithmetic they guard
-			const uint32_t k = (prevs >> b) & 3u;                 // SYM_U 0, SYM_R 1, SYM_D 2, SYM_L 3
-			const uint32_t hmask = 0u - (k & 1u);                 // all ones: horizontal move
-			const uint32_t neg = ((k >> 1) ^ k ^ 1u) & 1u;        // U or L
-			const uint32_t step = 1u - 2u * neg;                  // +1 / -1
-			const uint32_t nx = x + (step & hmask), ny = y + (step & ~hmask);
-			const uint32_t col = min(x, nx), row = min(y, ny);    // the crossed crack sits at the smaller vertex
-			const uint32_t in_range = static_cast<uint32_t>(max(x, nx) <= sx) & static_cast<uint32_t>(max(y, ny) <= sy);
-			// a move along the outer border crosses no crack of the planes: the coordinate across
-			// the move must be interior (1 .. size-1), the one along it inside (0 .. size-1)
-			const uint32_t across = (row & hmask) | (col & ~hmask), across_n = (sy & hmask) | (sx & ~hmask);
-			const uint32_t along = (col & hmask) | (row & ~hmask), along_n = (sx & hmask) | (sy & ~hmask);
-			const uint32_t ok = static_cast<uint32_t>(across - 1u < across_n - 1u) & static_cast<uint32_t>(along < along_n);
-			const uint32_t rel = row - band_y0;
-			bad |= act & (in_range ^ 1u);
-			if (act & in_range & ok & (rel < band_rows ? 1u : 0u)) atomicOr(band + (h_off & hmask) + rel * row_words + (col >> 5), 1u << (col & 31u));
-			x = nx; y = ny;
 		}
+		dx += nr - nl; dy += nd - nu;
 	}
 	if (bad) rerr |= ERR_RANGE;
 }
@@ -1110,7 +1111,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		// stores: no memset of the planes, no atomics on HBM.
 		uint32_t* band = reinterpret_cast<uint32_t*>(s_dyn) + band_off_words;
 		const uint32_t band_words = a.lds_words - band_off_words;
-		uint32_t band_rows = band_words / (2u * row_words);      // >= 1 (checked by the host)
+		uint32_t band_rows = band_words / row_words;              // one plane per pass; >= 1 (checked by the host)
 		if (band_rows > sy) band_rows = sy;
 		const bool single_tile = n_codes < kCrackTile;
 		WordSyms ws[kCrackWords];
@@ -1133,41 +1134,45 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 				sb[(4u * kCrackWords + 0u) * kCrackBlock] = o_a; sb[(4u * kCrackWords + 1u) * kCrackBlock] = o_dx; sb[(4u * kCrackWords + 2u) * kCrackBlock] = o_dy;
 			}
 		}
-		for (uint32_t y0 = 0; y0 < sy; y0 += band_rows) {
-			const uint32_t rows = min(band_rows, sy - y0);
-			const uint32_t nw = rows * row_words;
-			for (uint32_t i = tid; i < 2u * band_rows * row_words; i += kCrackBlock) band[i] = 0u;
-			__syncthreads();
-			stamp_add(14);
-			if (have_cracks && single_tile) {
-				TileCarry c;
-				if (y0 == 0) {
-					tile_symbols<true>(words, wshift, n_codes, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
-					stamp_add(6);
-				}
-				raster_band<false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
-			}
-			else if (have_cracks) {
-				uint32_t ti = 0;
-				for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
-					const uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
-#pragma unroll
-					for (uint32_t j = 0; j < kCrackWords; j++) {
-						ws[j].prevs = sb[(4u * j + 0u) * kCrackBlock]; ws[j].ms = sb[(4u * j + 1u) * kCrackBlock];
-						ws[j].ctl = sb[(4u * j + 2u) * kCrackBlock]; ws[j].isT = sb[(4u * j + 3u) * kCrackBlock];
+		bool have_syms = false;
+		for (uint32_t plane = 0; plane < 2u; plane++) {      // 0: plane V (vertical moves), 1: plane H
+			for (uint32_t y0 = 0; y0 < sy; y0 += band_rows) {
+				const uint32_t rows = min(band_rows, sy - y0);
+				const uint32_t nw = rows * row_words;
+				for (uint32_t i = tid; i < band_rows * row_words; i += kCrackBlock) band[i] = 0u;
+				__syncthreads();
+				stamp_add(14);
+				if (have_cracks && single_tile) {
+					TileCarry c;
+					if (!have_syms) {
+						tile_symbols<true>(words, wshift, n_codes, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+						have_syms = true;
+						stamp_add(6);
 					}
-					o_a = sb[(4u * kCrackWords + 0u) * kCrackBlock]; o_dx = sb[(4u * kCrackWords + 1u) * kCrackBlock]; o_dy = sb[(4u * kCrackWords + 2u) * kCrackBlock];
-					raster_band<true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
+					if (plane == 0u) raster_plane<false, false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
+					else raster_plane<true, false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
 				}
+				else if (have_cracks) {
+					uint32_t ti = 0;
+					for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
+						const uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
+#pragma unroll
+						for (uint32_t j = 0; j < kCrackWords; j++) {
+							ws[j].prevs = sb[(4u * j + 0u) * kCrackBlock]; ws[j].ms = sb[(4u * j + 1u) * kCrackBlock];
+							ws[j].ctl = sb[(4u * j + 2u) * kCrackBlock]; ws[j].isT = sb[(4u * j + 3u) * kCrackBlock];
+						}
+						o_a = sb[(4u * kCrackWords + 0u) * kCrackBlock]; o_dx = sb[(4u * kCrackWords + 1u) * kCrackBlock]; o_dy = sb[(4u * kCrackWords + 2u) * kCrackBlock];
+						if (plane == 0u) raster_plane<false, true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
+						else raster_plane<true, true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
+					}
+				}
+				__syncthreads();
+				stamp_add(7);
+				uint32_t* dst = (plane == 0u ? pv : ph) + static_cast<uint64_t>(y0) * row_words;
+				for (uint32_t i = tid; i < nw; i += kCrackBlock) dst[i] = band[i];
+				__syncthreads();
+				stamp_add(15);
 			}
-			__syncthreads();
-			stamp_add(7);
-			uint32_t* dv = pv + static_cast<uint64_t>(y0) * row_words;
-			uint32_t* dh = ph + static_cast<uint64_t>(y0) * row_words;
-			const uint32_t* bh = band + band_rows * row_words;
-			for (uint32_t i = tid; i < nw; i += kCrackBlock) { dv[i] = band[i]; dh[i] = bh[i]; }
-			__syncthreads();
-			stamp_add(15);
 		}
 	}
 	else if (have_cracks) {
