@@ -165,7 +165,7 @@ def main():
   # the stream stays in the library's pinned host buffer (no copy into a Python bytes object)
   backend = ckd.HipBackend(dev_index, zero_copy=True)
   coll_dev = torch.device("cpu") if (world > 1 and rehearsal) else dev    # gloo: collectives on host tensors
-  codec = ckd.ShardedCodec(backend, rank=rank, world=world, device=coll_dev)
+  codec = ckd.ShardedCodec(backend, rank=rank, world=world, device=coll_dev, compute_device=dev)
 
   def barrier():
     torch.cuda.synchronize()

@@ -76,6 +76,7 @@ EXPORTS = {
   "ckl_decoder_crack_planes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
   "ckl_zsplit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_crc32c": (C.c_uint32, [C.c_void_p, C.c_uint64]),
+  "ckl_crc32c_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint64]),
 }
 
 _lib = None

@@ -415,4 +415,10 @@ void ckl_free(void* p) { host_out_free(p); }
 
 uint32_t ckl_crc32c(const uint8_t* data, uint64_t n) { return crc32c(data, n); }
 
+// crc32c(A || B) from crc32c(A), crc32c(B) and len(B): appending len(B) bytes multiplies the
+// register by x^(8 len(B)); the init / final inversions of the two finished values cancel
+uint32_t ckl_crc32c_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+	return gf_mul(crc_a, gf_xpow(8ull * len_b)) ^ crc_b;
+}
+
 }  // extern "C"

@@ -119,7 +119,9 @@ class _SlabSections:
     ncomp = int(_unpack(self.comp, cw, sz).sum())
     kw = _byte_width(nu)
     k0 = 8 + nu * sw + sz * cw
-    self.keys = _unpack(lab[k0:k0 + ncomp * kw], kw, ncomp)
+    self.key_width = kw
+    self.n_keys = ncomp
+    self.keys_raw = lab[k0:k0 + ncomp * kw]        # re-keyed on the device, never unpacked here
     order = int(info.markov_model_order)
     mb = 0 if order == 0 else ((4 ** order) * 5 + 4) // 8      # header.hpp:284-297
     self.model = a[off + nlb: off + nlb + mb]
@@ -357,10 +359,13 @@ class HipBackend:
 class ShardedCodec:
   """Sharded compress / decode over the default process group (or single process)."""
 
-  def __init__(self, backend, rank: int = 0, world: int = 1, device="cpu"):
+  def __init__(self, backend, rank: int = 0, world: int = 1, device="cpu", compute_device=None):
+    """device: where the tensors of the collectives live (cuda for RCCL, cpu for gloo);
+    compute_device: where the small tensor work of the label merge runs (default: device)."""
     self.backend = backend
     self.rank, self.world = int(rank), int(world)
     self.device = torch.device(device)
+    self.compute_device = torch.device(compute_device) if compute_device is not None else self.device
     self._shared = None     # node-local output mapping of the sharded encoder
     self._shared_vol = None # node-local labels + component ids of the whole volume (pin encoding)
 
@@ -421,8 +426,9 @@ class ShardedCodec:
     slab = be.encode(vol, slab_shape, False, fortran_order, order, overrides)
     mark("encode")
     sec = _SlabSections(slab)
+    mark("sections")
     dev = self.device
-    meta = torch.tensor([len(sec.uniq), len(sec.keys), len(sec.cracks), sec.sz], dtype=torch.int64, device=dev)
+    meta = torch.tensor([len(sec.uniq), sec.n_keys, len(sec.cracks), sec.sz], dtype=torch.int64, device=dev)
     metas = [torch.empty_like(meta) for _ in range(self.world)]
     dist.all_gather(metas, meta)
     table = torch.stack(metas).cpu().numpy()
@@ -431,10 +437,22 @@ class ShardedCodec:
     mine_u[:len(sec.uniq)] = torch.from_numpy(sec.uniq).to(dev)
     all_u = [torch.empty_like(mine_u) for _ in range(self.world)]
     dist.all_gather(all_u, mine_u)
-    merged = torch.unique(torch.cat([all_u[r][:int(table[r, 0])] for r in range(self.world)]))   # sorted
-    remap = torch.searchsorted(merged, mine_u[:len(sec.uniq)])
-    new_keys = remap[torch.from_numpy(sec.keys).to(dev)].cpu().numpy() if len(sec.keys) else np.zeros(0, np.int64)
-    uniq_g = merged.cpu().numpy()
+    mark("gathers")
+    cdev = self.compute_device
+    merged = torch.unique(torch.cat([all_u[r][:int(table[r, 0])].to(cdev) for r in range(self.world)]))   # sorted
+    n_merged = int(merged.numel())
+    kw = _byte_width(n_merged)
+    packed_dev = None
+    if not use_pins and sec.n_keys:
+      # keys -> positions in the merged list, packed at their new width, all on `dev`: the only
+      # host work is the copy of the packed bytes into the shared buffer
+      signed = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
+      remap = torch.searchsorted(merged, mine_u[:len(sec.uniq)].to(cdev))
+      raw = torch.from_numpy(np.array(sec.keys_raw, copy=True)).to(cdev)
+      old = raw.view(signed[sec.key_width]).to(torch.int64)
+      if sec.key_width in (2, 4):
+        old &= (1 << (8 * sec.key_width)) - 1
+      packed_dev = remap[old].to(signed[kw]).contiguous().view(torch.uint8)      # collected after the host copies below
     mark("labels")
 
     sw, cw = sec.stored_width, sec.comp_width
@@ -485,12 +503,11 @@ class ShardedCodec:
       kw = 1
       mark("pins")
     else:
-      kw = _byte_width(len(uniq_g))
       n_keys = int(table[:, 1].sum())
-      label_bytes = 8 + len(uniq_g) * sw + sz_tot * cw + n_keys * kw
+      label_bytes = 8 + n_merged * sw + sz_tot * cw + n_keys * kw
     o_zidx = 29
     o_labels = o_zidx + 4 * (sz_tot + 1)
-    o_comp = o_labels + 8 + len(uniq_g) * sw
+    o_comp = o_labels + 8 + n_merged * sw
     o_keys = o_comp + sz_tot * cw
     o_model = o_labels + label_bytes
     o_cracks = o_model + len(sec.model)
@@ -501,18 +518,29 @@ class ShardedCodec:
 
     if self._shared is None:
       self._shared = _SharedOutput(self.rank, self.world)
-    self._shared.ensure(total)
+    o_part = (total + 63) // 64 * 64            # behind the stream: every rank's partial crcs of the label section
+    self._shared.ensure(o_part + 16 * self.world)
     out = self._shared.array()
+    L = _lib.lib()
+    base = C.addressof(C.c_ubyte.from_buffer(self._shared.mm))
+    # the big host copies first: the re-keying above is still running on the device
     out[o_zidx + 4 * z_before: o_zidx + 4 * (z_before + sec.sz)] = sec.zidx
-    if not use_pins:
-      out[o_comp + cw * z_before: o_comp + cw * (z_before + sec.sz)] = sec.comp
-      out[o_keys + kw * keys_before: o_keys + kw * (keys_before + len(new_keys))] = _pack(new_keys, kw)
     out[o_cracks + cracks_before: o_cracks + cracks_before + len(sec.cracks)] = sec.cracks
     out[o_tail + 4 + 4 * z_before: o_tail + 4 + 4 * (z_before + sec.sz)] = sec.crcs
+    if not use_pins:
+      packed_keys = packed_dev.cpu().numpy() if packed_dev is not None else np.zeros(0, np.uint8)
+      c_at, c_len = o_comp + cw * z_before, cw * sec.sz
+      k_at, k_len = o_keys + kw * keys_before, len(packed_keys)
+      out[c_at:c_at + c_len] = sec.comp
+      out[k_at:k_at + k_len] = packed_keys
+      # the label section's crc32c is put together from the ranks' own parts (ckl_crc32c_combine)
+      part = np.array([L.ckl_crc32c(base + c_at, c_len), c_len, L.ckl_crc32c(base + k_at, k_len), k_len], dtype="<u4")
+      out[o_part + 16 * self.rank: o_part + 16 * (self.rank + 1)] = part.view(np.uint8)
     if self.rank == 0:
       if use_pins:
         out[o_labels:o_labels + label_bytes] = pins_section
       else:
+        uniq_g = merged.cpu().numpy()
         out[o_labels:o_labels + 8] = np.frombuffer(np.array([len(uniq_g)], dtype="<u8").tobytes(), dtype=np.uint8)
         out[o_labels + 8:o_comp] = _pack(uniq_g, sw)
       out[o_model:o_cracks] = sec.model
@@ -529,10 +557,16 @@ class ShardedCodec:
     dist.barrier()
     if self.rank != 0:
       return None
-    L = _lib.lib()
-    base = C.addressof(C.c_ubyte.from_buffer(self._shared.mm))
     out[o_zidx + 4 * sz_tot: o_zidx + 4 * sz_tot + 4] = np.frombuffer(int(L.ckl_crc32c(base + o_zidx, 4 * sz_tot)).to_bytes(4, "little"), dtype=np.uint8)
-    out[o_tail:o_tail + 4] = np.frombuffer(int(L.ckl_crc32c(base + o_labels, label_bytes)).to_bytes(4, "little"), dtype=np.uint8)
+    if use_pins:
+      labels_crc = int(L.ckl_crc32c(base + o_labels, label_bytes))
+    else:
+      parts = np.frombuffer(bytes(out[o_part:o_part + 16 * self.world]), dtype="<u4").reshape(self.world, 4)
+      labels_crc = int(L.ckl_crc32c(base + o_labels, o_comp - o_labels))        # count + unique labels
+      for col in (0, 2):                                                          # component counts, then keys, in rank order
+        for r in range(self.world):
+          labels_crc = int(L.ckl_crc32c_combine(labels_crc, int(parts[r, col]), int(parts[r, col + 1])))
+    out[o_tail:o_tail + 4] = np.frombuffer(labels_crc.to_bytes(4, "little"), dtype=np.uint8)
     mark("crc")
     if prof:
       import sys

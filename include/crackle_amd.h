@@ -246,6 +246,9 @@ int ckl_zsplit(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, u
 
 /* crc32c (Castagnoli; src/crc.hpp:51-57) of a host buffer — exported for tests. */
 uint32_t ckl_crc32c(const uint8_t* data, uint64_t n);
+/* crc32c(A || B) from crc32c(A), crc32c(B) and the byte length of B: lets the ranks of a sharded
+ * encode checksum their own parts of the merged label section. */
+uint32_t ckl_crc32c_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 
 #ifdef __cplusplus
 }
