@@ -75,6 +75,10 @@ EXPORTS = {
   "ckl_reencode_markov": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_decoder_crack_planes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
   "ckl_zsplit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+  "ckl_encoder_defer_codes": (C.c_int, [C.c_void_p, C.c_int]),
+  "ckl_encoder_codes_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+  "ckl_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
+  "ckl_host_unregister": (C.c_int, [C.c_void_p]),
   "ckl_crc32c": (C.c_uint32, [C.c_void_p, C.c_uint64]),
   "ckl_crc32c_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint64]),
 }

@@ -413,6 +413,20 @@ int ckl_header_info_from_bytes(const uint8_t* buf, uint64_t n, ckl_header_info* 
 
 void ckl_free(void* p) { host_out_free(p); }
 
+int ckl_host_register(void* p, uint64_t bytes) {
+	if (!p || !bytes) { set_last_error("crackle_amd: null argument"); return CKL_ERR_ARG; }
+	if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		set_last_error("crackle_amd: hipHostRegister failed");
+		return CKL_ERR_RUNTIME;
+	}
+	return CKL_OK;
+}
+int ckl_host_unregister(void* p) {
+	if (p && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+	return CKL_OK;
+}
+
 uint32_t ckl_crc32c(const uint8_t* data, uint64_t n) { return crc32c(data, n); }
 
 // crc32c(A || B) from crc32c(A), crc32c(B) and len(B): appending len(B) bytes multiplies the

@@ -811,6 +811,8 @@ struct ckl_encoder {
 	DevBuf<uint8_t> d_cp, d_fcode, d_dcode, d_payload, d_boc, d_codes_out, d_model;
 	DevBuf<uint32_t> d_code_report;
 	uint64_t codes_capacity = 0;        // bound of all slices' BOC + payload bytes
+	bool defer_codes = false;           // ckl_encoder_defer_codes: the codes stay in d_codes_out for ckl_encoder_codes_to_host
+	uint64_t last_codes_total = 0;      // bytes of the last run's crack codes
 	DevBuf<uint32_t> d_stack_node, d_stack_code;
 	DevBuf<uint32_t> d_chain_node, d_chain_off, d_chain_clen, d_chain_order, d_chain_dst, d_chain_vstart;
 	DevBuf<uint32_t> d_n_chains, d_n_raw, d_n_valid, d_payload_len, d_boc_len;
@@ -1591,7 +1593,8 @@ void encode_typed(
 		if (early.p && label_bytes) memcpy(o + off_labels, static_cast<uint8_t*>(early.p) + off_labels, label_bytes);
 	}
 	try {
-		if (cr.total) CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
+		e.last_codes_total = cr.total;
+		if (cr.total && !e.defer_codes) CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
 		if (head.label_format == PINS_VARIABLE_WIDTH) {
 			if (label_bytes) memcpy(o + off_labels, pins_binary.data(), label_bytes);
 			labels_crc = crc32c(o + off_labels, label_bytes);
@@ -1790,6 +1793,27 @@ int ckl_reencode_markov(const uint8_t* buf, uint64_t n, int markov_model_order, 
 		if (!buf || !out || !out_len) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
 		select_device(device);
 		reencode_markov(buf, n, markov_model_order, device, out, out_len);
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_encoder_defer_codes(ckl_encoder* e, int defer) {
+	if (!e) { set_last_error("crackle_amd: null encoder"); return CKL_ERR_ARG; }
+	e->defer_codes = defer != 0;
+	return CKL_OK;
+}
+
+int ckl_encoder_codes_to_host(ckl_encoder* e, uint8_t* dst_host, uint64_t capacity, uint64_t* n_bytes) {
+	try {
+		if (!e || !n_bytes) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		*n_bytes = e->last_codes_total;
+		if (e->last_codes_total == 0) return CKL_OK;
+		if (!dst_host || capacity < e->last_codes_total) throw Error(CKL_ERR_ARG, "crackle_amd: code buffer too small: need " + std::to_string(e->last_codes_total) + " bytes");
+		select_device(e->device);
+		CKL_HIP(hipMemcpyAsync(dst_host, e->d_codes_out.p, e->last_codes_total, hipMemcpyDeviceToHost, e->stream));
+		CKL_HIP(hipStreamSynchronize(e->stream));
 		return CKL_OK;
 	}
 	catch (const Error& err) { set_last_error(err.what()); return err.status; }

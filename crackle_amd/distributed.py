@@ -164,11 +164,14 @@ class _SharedOutput:
   sections at their final offsets (the compressed bytes go device ->
   host on every GPU's own link, not GPU <-> GPU).  Grows geometrically, reused across calls."""
 
-  def __init__(self, rank: int, world: int):
+  def __init__(self, rank: int, world: int, register: bool = False):
     import mmap
     import os
     self._mmap, self._os = mmap, os
     self.rank = rank
+    self.register = bool(register)
+    self.registered = False
+    self._reg_base = None
     obj = [None]
     if rank == 0:
       obj[0] = f"/dev/shm/ckl_amd_{os.getpid()}_{id(self) & 0xFFFF:x}"
@@ -182,6 +185,7 @@ class _SharedOutput:
     if nbytes <= self.cap:
       return
     if self.mm is not None:
+      self._unregister()
       self.mm.close()
       self.mm = None
     cap = max(1 << 20, int(nbytes * 1.5))
@@ -192,14 +196,26 @@ class _SharedOutput:
     with open(self.path, "r+b") as f:
       self.mm = self._mmap.mmap(f.fileno(), cap)
     self.cap = cap
+    if self.register:
+      # page-locked: the ranks' crack codes come straight from their GPUs into the mapping
+      base = C.addressof(C.c_ubyte.from_buffer(self.mm))
+      self.registered = _lib.lib().ckl_host_register(base, cap) == _lib.CKL_OK
+      self._reg_base = base if self.registered else None
     dist.barrier()
 
   def array(self) -> np.ndarray:
     return np.frombuffer(self.mm, dtype=np.uint8)
 
+  def _unregister(self):
+    if self._reg_base is not None:
+      _lib.lib().ckl_host_unregister(self._reg_base)
+      self._reg_base = None
+      self.registered = False
+
   def close(self):
     try:
       if self.mm is not None:
+        self._unregister()
         self.mm.close()
         self.mm = None
       if self.rank == 0 and self._os.path.exists(self.path):
@@ -339,6 +355,18 @@ class HipBackend:
     """Copies the slab's labels (x fastest) into the host array `out`."""
     out[...] = vol.reshape(-1).cpu().numpy().view(out.dtype)
 
+  def defer_codes(self, shape, itemsize: int, defer: bool):
+    """Following encodes of this shape leave the crack codes in HBM for codes_to_host."""
+    self._L.ckl_encoder_defer_codes(self._encoder(shape, itemsize), int(bool(defer)))
+
+  def codes_to_host(self, dst_ptr: int, capacity: int) -> int:
+    """Copies the last encode's crack codes (slice order) to host address dst_ptr."""
+    n = C.c_uint64()
+    rc = self._L.ckl_encoder_codes_to_host(self._enc, dst_ptr, capacity, C.byref(n))
+    if rc != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+    return int(n.value)
+
   def encoder_timing(self) -> Tuple[float, float]:
     p, k = C.c_float(), C.c_float()
     if self._enc:
@@ -423,7 +451,14 @@ class ShardedCodec:
     #    node-local shared buffer.  Crack codes, z-index entries, component counts and crcs
     #    are concatenated verbatim (crackle/operations.py:508-548); only the flat label keys
     #    are re-keyed against the merged, sorted unique-label list (labels.hpp:92-152).
-    slab = be.encode(vol, slab_shape, False, fortran_order, order, overrides)
+    direct = hasattr(be, "codes_to_host")      # the crack codes go from HBM straight to their place in the shared buffer
+    if direct:
+      be.defer_codes(slab_shape, be.itemsize(vol), True)
+    try:
+      slab = be.encode(vol, slab_shape, False, fortran_order, order, overrides)
+    finally:
+      if direct:
+        be.defer_codes(slab_shape, be.itemsize(vol), False)
     mark("encode")
     sec = _SlabSections(slab)
     mark("sections")
@@ -517,7 +552,7 @@ class ShardedCodec:
     cracks_before = int(table[:self.rank, 2].sum())
 
     if self._shared is None:
-      self._shared = _SharedOutput(self.rank, self.world)
+      self._shared = _SharedOutput(self.rank, self.world, register=direct)
     o_part = (total + 63) // 64 * 64            # behind the stream: every rank's partial crcs of the label section
     self._shared.ensure(o_part + 16 * self.world)
     out = self._shared.array()
@@ -525,7 +560,12 @@ class ShardedCodec:
     base = C.addressof(C.c_ubyte.from_buffer(self._shared.mm))
     # the big host copies first: the re-keying above is still running on the device
     out[o_zidx + 4 * z_before: o_zidx + 4 * (z_before + sec.sz)] = sec.zidx
-    out[o_cracks + cracks_before: o_cracks + cracks_before + len(sec.cracks)] = sec.cracks
+    if direct:
+      got = be.codes_to_host(base + o_cracks + cracks_before, len(sec.cracks))
+      if got != len(sec.cracks):
+        raise RuntimeError("crack code bytes of the slab stream and of the encoder session differ")
+    else:
+      out[o_cracks + cracks_before: o_cracks + cracks_before + len(sec.cracks)] = sec.cracks
     out[o_tail + 4 + 4 * z_before: o_tail + 4 + 4 * (z_before + sec.sz)] = sec.crcs
     if not use_pins:
       packed_keys = packed_dev.cpu().numpy() if packed_dev is not None else np.zeros(0, np.uint8)

@@ -180,6 +180,17 @@ int ckl_encoder_run(
 	const ckl_encode_overrides* overrides,
 	uint8_t** out, uint64_t* out_len);
 
+/* Sharded encoders place every slab's crack codes at an offset of a shared buffer that is only
+ * known once all slabs are encoded.  With defer != 0 the following runs leave the crack codes in
+ * HBM (the code region of the returned stream is then unspecified; everything else is as usual)
+ * and ckl_encoder_codes_to_host copies them, contiguous in slice order, to where they belong:
+ * one transfer over the GPU's own link instead of a transfer and a host copy. */
+int ckl_encoder_defer_codes(ckl_encoder* e, int defer);
+int ckl_encoder_codes_to_host(ckl_encoder* e, uint8_t* dst_host, uint64_t capacity, uint64_t* n_bytes);
+/* Page-locks / releases a host range for device transfers (e.g. a shared mapping). */
+int ckl_host_register(void* p, uint64_t bytes);
+int ckl_host_unregister(void* p);
+
 /* Whole-volume reductions of the encode path, exposed so that sharded encoders can
  * all-reduce them (lib.hpp:224-256): max label, count of equal linear neighbours
  * inside this slab, and the slab's first and last voxel (for the pair that straddles
