@@ -9,25 +9,28 @@
 //   labels::decode_flat / decode_condensed_pins      src/labels.hpp:453-617
 //   the paint loop                                   src/crackle.hpp:617-656
 //
-// Kernels (block = 256 threads):
-//   k_decode_cracks   one workgroup per slice: BOC index, 2-bit unpack + mod-4 prefix
-//                     sum (undo the difference code), control-pair detection, symbol
-//                     compaction and displacement prefix sums (block scans), branch
-//                     matching of the control symbols 64 at a time by one wavefront
-//                     (ballot / shuffle pointer jumping, stack in LDS), then parallel
-//                     rasterisation of every move into two bit planes.
+// Kernels:
+//   k_decode_cracks   one workgroup of 1024 per slice: BOC index, 2-bit unpack + mod-4 prefix
+//                     sum (undo the difference code; markov streams are expanded by the whole
+//                     workgroup first), 16 codes per word bit-parallel symbol derivation,
+//                     branch matching of the control symbols (clamped depth scan, previous
+//                     smaller value through a min tree, pointer jumping), then the two crack
+//                     planes rasterised in LDS, one plane per pass, and stored.
 //   k_run_index       horizontal runs of each slice from the vertical-crack plane:
 //                     exclusive prefix sum of break counts per 32-pixel word.
-//   k_run_union       union-find over RUNS (not pixels): vertically adjacent runs that
-//                     are connected through the horizontal-crack plane are united.
+//   k_run_union_*     union-find over RUNS (not pixels): vertically adjacent runs that are
+//                     connected through the horizontal-crack plane are united, strip by
+//                     strip in LDS, the seams between strips on the global forest.
 //   k_run_count/rank/assign  roots ranked in raster order = the reference's component ids
 //                     (cc3d.hpp:114-144); crc32c of the (never materialised) component
 //                     image accumulated per run from a geometric-sum table; flat labels
 //                     are applied to the runs in the same pass.
 //   k_label_map_*     component -> label tables (flat keys / pins)
-//   k_run_labels      run -> label
+//   k_run_labels      run -> label (pins)
 //   k_paint_runs      streams the output: per 4 pixels one plane word, a popcount and a
-//                     look-up in an LDS-staged run->label table; 16-byte stores.
+//                     look-up in an LDS-staged run->label table; 16-byte streaming stores.
+//   k_run_stats       per-label voxel counts, coordinate sums and boxes from the runs
+//   k_vcg             voxel connectivity graph from the planes (+ labels for the z bits)
 #include "ckl_common.hpp"
 #include "ckl_runs.hpp"
 
@@ -498,39 +501,24 @@ __device__ __forceinline__ void tile_symbols(
 	c.a += t3[0]; c.dx += t3[1]; c.dy += t3[2];
 }
 
-// Rasterises the moves of one thread's 128 positions (crackcodes.hpp:706-862).  Vertical
-// moves cross planeV, horizontal moves cross planeH; consecutive moves that land in one
-// plane word are OR-ed into it once.  BAND: the target is the LDS band buffer holding
-// rows [band_y0, band_y0 + band_rows) of both planes; otherwise the planes in HBM.
-template <bool BAND, bool SKIP = false>
-__device__ __forceinline__ void raster_moves(
+// Rasterises the moves of one thread's 128 positions (crackcodes.hpp:706-862) straight into the
+// planes in HBM (zeroed by the host): the fallback when not even one plane row fits the LDS band
+// buffer.  Vertical moves cross planeV, horizontal moves cross planeH; consecutive moves that
+// land in one plane word are OR-ed into it once (an atomic on HBM is expensive).
+__device__ __forceinline__ void raster_moves_hbm(
 	const WordSyms (&ws)[kCrackWords], uint32_t o_t, uint32_t o_dx, uint32_t o_dy, uint32_t valid_segs,
 	const uint32_t* seg_x, const uint32_t* seg_y, uint32_t sx, uint32_t sy, uint32_t row_words,
-	uint32_t* band, uint32_t band_y0, uint32_t band_rows, uint32_t* pv, uint32_t* ph, uint32_t& rerr
+	uint32_t* pv, uint32_t* ph, uint32_t& rerr
 ) {
 	uint32_t bx = 0, by = 0;
 	bool act = o_t < valid_segs;
 	if (act) { bx = seg_x[o_t]; by = seg_y[o_t]; }
 	uint32_t x = bx + o_dx, y = by + o_dy;
-	constexpr uint32_t kNoWord = 0xFFFFFFFFu;
-	uint32_t cur_idx = kNoWord, cur_bits = 0;
+	uint32_t cur_bits = 0;
 	uint32_t* cur_word = nullptr;
-	const uint32_t h_off = band_rows * row_words;
 #pragma unroll
 	for (uint32_t j = 0; j < kCrackWords; j++) {
 		const WordSyms& w = ws[j];
-		if (SKIP && w.isT == 0u) {
-			// (many-band slices) no jump inside this word: its moves stay within a box known from
-			// four popcounts.  A box inside the grid that misses the band (with the one-row reach
-			// of vertical moves) is skipped whole; everything else takes the exact path below.
-			const uint32_t nr = __popc(w.right()), nl = __popc(w.left()), nd = __popc(w.down()), nu = __popc(w.up());
-			const bool inside = x >= nl && x + nr <= sx && y >= nu && y + nd <= sy;
-			const uint32_t lo = y - nu, hi = y + nd;
-			if (inside && (hi + 1u < band_y0 || lo > band_y0 + band_rows)) {
-				x += nr - nl; y += nd - nu;
-				continue;
-			}
-		}
 		for (uint32_t m = w.ms | w.isT; m; m &= m - 1u) {
 			const uint32_t b = __ffs(m) - 1u;
 			if ((w.isT >> b) & 1u) {
@@ -551,20 +539,9 @@ __device__ __forceinline__ void raster_moves(
 				if (x > sx || y > sy || nx > sx || ny > sy) rerr |= ERR_RANGE;
 				else {
 					const bool horiz = k & 1u;
+					// a move along the outer border crosses no crack of the planes
 					const bool ok = horiz ? (row - 1u < sy - 1u && col < sx) : (col - 1u < sx - 1u && row < sy);
-					if (BAND) {
-						const uint32_t rel = row - band_y0;
-						if (ok && rel < band_rows) {
-							const uint32_t idx = (horiz ? h_off : 0u) + rel * row_words + (col >> 5);
-							if (idx != cur_idx) {
-								if (cur_idx != kNoWord) atomicOr(band + cur_idx, cur_bits);
-								cur_idx = idx;
-								cur_bits = 0;
-							}
-							cur_bits |= 1u << (col & 31u);
-						}
-					}
-					else if (ok) {
+					if (ok) {
 						uint32_t* word = (horiz ? ph : pv) + static_cast<uint64_t>(row) * row_words + (col >> 5);
 						if (word != cur_word) {
 							if (cur_word) atomicOr(cur_word, cur_bits);
@@ -578,11 +555,10 @@ __device__ __forceinline__ void raster_moves(
 			x = nx; y = ny;
 		}
 	}
-	if (BAND) { if (cur_idx != kNoWord) atomicOr(band + cur_idx, cur_bits); }
-	else if (cur_word) atomicOr(cur_word, cur_bits);
+	if (cur_word) atomicOr(cur_word, cur_bits);
 }
 
-// The same for the LDS band buffer, one plane per pass: HORIZ rasterises the horizontal moves
+// The LDS band buffer variant, one plane per pass: HORIZ rasterises the horizontal moves
 // into rows [band_y0, band_y0 + band_rows) of plane H, otherwise the vertical moves into plane V.
 // Written for the instruction count (the loop body is what k_decode_cracks spends most of its
 // time in): a pass only visits the moves of its orientation; the vertex of a move is the
@@ -1182,7 +1158,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			WordSyms ws[kCrackWords];
 			uint32_t o_a, o_dx, o_dy;
 			tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
-			raster_moves<false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, nullptr, 0u, 0u, pv, ph, rerr);
+			raster_moves_hbm(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, pv, ph, rerr);
 			__syncthreads();
 		}
 	}
