@@ -8,13 +8,13 @@ from .headers import CrackleHeader, FormatError, LabelFormat, CrackFormat
 from .codec import (
   compress, decompress, decompress_range, header, labels, num_labels, contains,
   voxel_counts, centroids, bounding_boxes, reencode, voxel_connectivity_graph,
-  crack_crcs, structure_equal,
+  crack_crcs, structure_equal, labels_crc, check, ok,
 )
 from .operations import zstack, zsplit, zshatter
 
 __all__ = [
   "CrackleHeader", "FormatError", "LabelFormat", "CrackFormat",
   "compress", "decompress", "decompress_range", "header", "labels", "num_labels", "contains",
-  "voxel_counts", "centroids", "bounding_boxes", "reencode", "voxel_connectivity_graph", "crack_crcs", "structure_equal",
+  "voxel_counts", "centroids", "bounding_boxes", "reencode", "voxel_connectivity_graph", "crack_crcs", "structure_equal", "labels_crc", "check", "ok",
   "zstack", "zsplit", "zshatter",
 ]

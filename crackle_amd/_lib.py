@@ -70,6 +70,7 @@ EXPORTS = {
     C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
     C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_zstack": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+  "ckl_decoder_check": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
   "ckl_decoder_vcg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
   "ckl_voxel_connectivity_graph": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
   "ckl_reencode_markov": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),

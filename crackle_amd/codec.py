@@ -343,3 +343,74 @@ def structure_equal(binary1: bytes, binary2: bytes, parallel: int = 0, device: i
   vcg1 = voxel_connectivity_graph(binary1, connectivity=4, parallel=parallel, device=device)
   vcg2 = voxel_connectivity_graph(binary2, connectivity=4, parallel=parallel, device=device)
   return bool(np.all(vcg1 == vcg2))
+
+
+def labels_crc(binary: bytes) -> Optional[int]:
+  """The stored crc32c of the label section (codec.py:205-213)."""
+  head = header(binary)
+  if head.format_version == 0:
+    return None
+  crcl = head.sz * 4 + 4
+  return int.from_bytes(bytes(binary)[-crcl:len(binary) - crcl + 4], "little")
+
+
+def check(binary: bytes, device: int = 0) -> dict:
+  """Test for file corruption, reporting which sections are damaged (codec.py:900-948): header
+  (crc8), crack index (its crc32c and that it stays inside the stream), label section (crc32c)
+  and the z of every slice whose crack code does not decode, whose component count disagrees
+  with the label section or whose component-image crc32c differs.  The slices are verified on
+  the device by the decode pipeline up to the component ids; no volume is produced."""
+  binary = bytes(binary)
+  sections = {"header": None, "crack_index": None, "labels": None, "z": None}
+  try:
+    head = header(binary)
+  except FormatError:
+    sections["header"] = False
+    return sections
+  sections["header"] = True
+  L = _lib.lib()
+  hb, gib = head.header_bytes, head.grid_index_bytes
+  if len(binary) < hb + gib:
+    sections["crack_index"] = False
+    return sections
+  zidx = np.frombuffer(binary, dtype="<u4", offset=hb, count=head.sz)
+  if head.format_version > 0:
+    stored = int.from_bytes(binary[hb + 4 * head.sz: hb + 4 * head.sz + 4], "little")
+    if stored != int(L.ckl_crc32c(binary[hb:hb + 4 * head.sz], 4 * head.sz)):
+      sections["crack_index"] = False
+      return sections
+  # the reference's offsets leave the markov model out here (codec.py:277-281); kept
+  if hb + gib + head.num_label_bytes + int(zidx.astype(np.uint64).sum()) >= len(binary):
+    sections["crack_index"] = False
+    return sections
+  sections["crack_index"] = True
+  if head.format_version == 0:
+    return sections
+  lab = binary[hb + gib: hb + gib + head.num_label_bytes]
+  sections["labels"] = labels_crc(binary) == int(L.ckl_crc32c(lab, len(lab)))
+  sections["z"] = []
+  if head.voxels() == 0:
+    return sections
+  handle = C.c_void_p()
+  rc = L.ckl_decoder_create(binary, len(binary), 0, -1, int(device), C.byref(handle))
+  if rc != _lib.CKL_OK:
+    # the stream's layout cannot even be parsed: every slice is unreadable
+    sections["z"] = list(range(head.sz))
+    return sections
+  try:
+    errs = np.zeros(head.sz, dtype=np.uint32)
+    rc = L.ckl_decoder_check(handle, errs.ctypes.data, errs.size)
+    if rc != _lib.CKL_OK:
+      _raise(rc)
+  finally:
+    L.ckl_decoder_destroy(handle)
+  sections["z"] = [int(z) for z in np.flatnonzero(errs)]
+  return sections
+
+
+def ok(binary: bytes, device: int = 0) -> bool:
+  """Whether the stream is intact as a whole (codec.py:883-898)."""
+  report = check(binary, device=device)
+  if report["header"] is False or report["crack_index"] is False or report["labels"] is False:
+    return False
+  return not (report["z"] is not None and len(report["z"]) > 0)

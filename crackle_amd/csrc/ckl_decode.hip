@@ -1974,7 +1974,7 @@ void launch_flat_label_map(ckl_decoder& d) {
 }
 
 // component ids, component -> label, then the statistics kernel instead of the paint
-void launch_resolve_and_stats(ckl_decoder& d, const RunGeom& g, const RunArrays& ra, StageTimer& st, const StatsArgs& stats) {
+void launch_resolve_and_stats(ckl_decoder& d, const RunGeom& g, const RunArrays& ra, StageTimer& st, const StatsArgs* stats) {
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 	ResolveScratch rs;
@@ -1989,8 +1989,9 @@ void launch_resolve_and_stats(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	if (d.head.label_format == FLAT) launch_flat_label_map(d);
 	else launch_pin_label_map(d, g, ra);
 	st.done("k_label_map");
-	hipLaunchKernelGGL(k_run_stats, dim3(ns), dim3(kStatsBlock), static_cast<size_t>(stats.lds_comps) * kStatsBytesPerComp, s,
-		ra, d.d_label_map.p, d.d_comp_off.p, d.d_ncomp_expect.p, stats);
+	if (!stats) return;      // integrity check only: component counts and crcs are in, k_check follows
+	hipLaunchKernelGGL(k_run_stats, dim3(ns), dim3(kStatsBlock), static_cast<size_t>(stats->lds_comps) * kStatsBytesPerComp, s,
+		ra, d.d_label_map.p, d.d_comp_off.p, d.d_ncomp_expect.p, *stats);
 	st.done("k_run_stats");
 }
 
@@ -2032,12 +2033,12 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	st.done("k_paint_runs");
 }
 
-void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label, const StatsArgs* stats = nullptr, bool planes_only = false) {
+void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label, const StatsArgs* stats = nullptr, bool planes_only = false, uint32_t* errs_out = nullptr) {
 	const Header& h = d.head;
 	if (d.sxy == 0 || d.nslices == 0) return;
 	const int ow = has_label ? 1 : h.data_width;
 	const uint64_t need = d.sxy * d.nslices * static_cast<uint64_t>(ow);
-	if (!stats && !planes_only && out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
+	if (!stats && !planes_only && !errs_out && out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 	const bool prof = getenv("CKL_PROFILE") != nullptr;
@@ -2126,7 +2127,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		st.done("k_run_union_seams");
 	}
 
-	if (stats) launch_resolve_and_stats(d, g, ra, st, *stats);
+	if (stats || errs_out) launch_resolve_and_stats(d, g, ra, st, stats);
 	else if (has_label || h.data_width == 1) launch_resolve_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
 	else if (h.data_width == 2) launch_resolve_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
 	else if (h.data_width == 4) launch_resolve_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
@@ -2148,6 +2149,10 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	CKL_HIP(hipGetLastError());
 	CKL_HIP(hipEventElapsedTime(&d.pipeline_ms, d.ev[0], d.ev[d.n_stages]));
 	for (int i = 0; i < d.n_stages; i++) CKL_HIP(hipEventElapsedTime(&d.stage_ms[i], d.ev[i], d.ev[i + 1]));
+	if (errs_out) {      // the caller wants the per-slice verdicts, not an exception
+		for (uint32_t zi = 0; zi < ns; zi++) errs_out[zi] = errs[zi];
+		return;
+	}
 	for (uint32_t zi = 0; zi < ns; zi++) {
 		const uint32_t e = errs[zi];
 		if (!e) continue;
@@ -2318,6 +2323,20 @@ int ckl_decoder_crack_planes(ckl_decoder* d, const uint32_t** plane_v, const uin
 		decoder_run(*d, nullptr, 0, 0, 0, nullptr, true);
 		*plane_v = d->d_planes.p;
 		*plane_h = d->d_planes.p + d->plane_words * d->nslices;
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_decoder_check(ckl_decoder* d, uint32_t* slice_errors, uint64_t capacity) {
+	try {
+		if (!d || !slice_errors) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		if (capacity < d->nslices) throw Error(CKL_ERR_ARG, "crackle_amd: room for " + std::to_string(d->nslices) + " slice verdicts needed");
+		select_device(d->device);
+		wait_for_default_stream(d->stream, d->ev_in);
+		if (d->sxy == 0 || d->nslices == 0) return CKL_OK;
+		decoder_run(*d, nullptr, 0, 0, 0, nullptr, false, slice_errors);
 		return CKL_OK;
 	}
 	catch (const Error& e) { set_last_error(e.what()); return e.status; }

@@ -123,6 +123,15 @@ int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_byte
 int ckl_decoder_crack_planes(
 	ckl_decoder* d, const uint32_t** plane_v_device, const uint32_t** plane_h_device,
 	uint32_t* row_words, uint64_t* plane_words);
+/* Integrity check of the decoder's z-range without producing the volume (the per-slice part of
+ * crackle.check, crackle/codec.py:900-948, which decodes slice by slice and notes the failures):
+ * the pipeline runs up to the component ids; slice_errors[i] receives 0 or a combination of
+ * CKL_SLICE_* bits for slice z_start + i. */
+#define CKL_SLICE_BAD_CODE 0x7u        /* crack code malformed: index, range or capacity */
+#define CKL_SLICE_BAD_COMPONENTS 0x8u  /* component count differs from the label section */
+#define CKL_SLICE_BAD_CRC 0x10u        /* crc32c of the component image differs from the stored one */
+int ckl_decoder_check(ckl_decoder* d, uint32_t* slice_errors, uint64_t capacity);
+
 /* Replaces crackle::operations::voxel_connectivity_graph (src/operations.hpp:667-826, bound at
  * src/fastcrackle.cpp:538-565): one byte per voxel of the decoder's z-range, x fastest, bit0 +x,
  * bit1 -x, bit2 +y, bit3 -y (from the crack planes), and for connectivity 6 bit4 +z / bit5 -z

@@ -428,3 +428,28 @@ def test_structure_equal(checker):
   assert not crackle_amd.structure_equal(a, checker.compress(moved))
   assert not crackle_amd.structure_equal(a, checker.compress(np.asfortranarray(arr[:, :, :6])))
   assert crackle_amd.crack_crcs(a).dtype == np.uint32 and crackle_amd.crack_crcs(a).size == 12
+
+
+def test_check_and_ok(checker):
+  """crackle.check / crackle.ok (codec.py:883-948): damage is attributed to the section it hits."""
+  arr = synth.as_numpy_f(synth.voronoi_labels((96, 80, 12), np.uint16, seed=4, cell=(16, 16, 4)))
+  for kw in (dict(), dict(markov_model_order=3), dict(allow_pins=True)):
+    good = checker.compress(arr, **kw)
+    assert crackle_amd.ok(good)
+    assert crackle_amd.check(good) == {"header": True, "crack_index": True, "labels": True, "z": []}
+    head = crackle_amd.header(good)
+    b = bytearray(good); b[8] ^= 1
+    assert crackle_amd.check(bytes(b))["header"] is False and not crackle_amd.ok(bytes(b))
+    b = bytearray(good); b[29] ^= 1                                   # first z-index entry
+    assert crackle_amd.check(bytes(b))["crack_index"] is False
+    b = bytearray(good); b[29 + 4 * 13 + 9] ^= 0x10                   # inside the label section
+    rep = crackle_amd.check(bytes(b))
+    assert rep["labels"] is False and not crackle_amd.ok(bytes(b))
+    b = bytearray(good); b[-4 * 5 + 1] ^= 0x40                        # stored crc of slice 7
+    assert crackle_amd.check(bytes(b))["z"] == [7]
+    # a flipped bit in the crack codes of slice 3
+    zidx = np.frombuffer(good, dtype="<u4", offset=29, count=12).astype(np.int64)
+    start = 29 + 4 * 13 + head.num_label_bytes + head.markov_model_bytes + int(zidx[:3].sum())
+    b = bytearray(good); b[start + int(zidx[3]) // 2] ^= 0x04
+    rep = crackle_amd.check(bytes(b))
+    assert rep["header"] and rep["crack_index"] and rep["labels"] and rep["z"] == [3], rep
