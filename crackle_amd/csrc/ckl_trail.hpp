@@ -486,11 +486,22 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 	for (uint32_t j = threadIdx.x; j < nn; j += kCompBlock) { parent[j] = j; compmin[j] = ~0ull; }
 	__syncthreads();
 	if (!LDS) __threadfence();
-	for (uint32_t d = threadIdx.x; d < nn * 4u; d += kCompBlock) {
-		const uint32_t e = dart_end[d];
-		if (e == kDartNone) continue;
-		const uint32_t j = d >> 2, j2 = e >> 2;
-		if (j < j2 && j2 < nn) tuf_unite<LDS>(parent, j, j2);      // the dart at the far end names the same segment
+	// the dart ends of kUniteBatch steps are loaded before the first union: the unions are dependent
+	// round trips to the table and would otherwise wait for memory once per step
+	constexpr uint32_t kUniteBatch = 8;
+	for (uint32_t d0 = threadIdx.x; d0 < nn * 4u; d0 += kCompBlock * kUniteBatch) {
+		uint32_t e[kUniteBatch];
+#pragma unroll
+		for (uint32_t k = 0; k < kUniteBatch; k++) {
+			const uint32_t d = d0 + k * kCompBlock;
+			e[k] = d < nn * 4u ? dart_end[d] : kDartNone;
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < kUniteBatch; k++) {
+			if (e[k] == kDartNone) continue;
+			const uint32_t j = (d0 + k * kCompBlock) >> 2, j2 = e[k] >> 2;
+			if (j < j2 && j2 < nn) tuf_unite<LDS>(parent, j, j2);      // the dart at the far end names the same segment
+		}
 	}
 	__syncthreads();
 	if (!LDS) __threadfence();
@@ -502,11 +513,14 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 		uint32_t root = 0xFFFFFFFFu;
 		unsigned long long val = ~0ull;
 		if (j < nn) {
-			// the node's own minimum over its (at most four) segments first
+			// the node's own minimum over its (at most four) segments first (one 16-byte load each)
+			const uint4 e4 = *reinterpret_cast<const uint4*>(dart_end + j * 4u);
+			const uint4 m4 = *reinterpret_cast<const uint4*>(a.dart_minv + nb * 4u + j * 4u);
+			const uint32_t ee[4] = { e4.x, e4.y, e4.z, e4.w }, mm[4] = { m4.x, m4.y, m4.z, m4.w };
+#pragma unroll
 			for (uint32_t k = 0; k < 4u; k++) {
-				const uint32_t d = j * 4u + k;
-				if (dart_end[d] == kDartNone) continue;
-				const unsigned long long v = (static_cast<unsigned long long>(a.dart_minv[nb * 4u + d]) << 32) | d;
+				if (ee[k] == kDartNone) continue;
+				const unsigned long long v = (static_cast<unsigned long long>(mm[k]) << 32) | (j * 4u + k);
 				val = v < val ? v : val;
 			}
 			if (val != ~0ull) root = tuf_find<LDS>(parent, j);
