@@ -24,11 +24,15 @@ class HeaderInfo(C.Structure):
   ]
 
 
+MERGE_UNIQUE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
+
+
 class EncodeOverrides(C.Structure):
   _fields_ = [
     ("force_crack_format", C.c_int32), ("force_label_format", C.c_int32),
     ("force_stored_width", C.c_int32), ("has_model", C.c_int32),
     ("model", C.c_void_p),
+    ("merge_unique", MERGE_UNIQUE_FN), ("merge_ctx", C.c_void_p),
   ]
 
 

@@ -1398,7 +1398,7 @@ void flat_collect(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, i
 // The flat label section (labels.hpp:92-152) on device: sort + unique of the component
 // labels, keys by binary search, everything packed at its byte width into e.d_labels_bin.
 // Returns the section size; num_unique comes back for the header arithmetic only.
-uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int component_width, uint32_t ns) {
+uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int component_width, uint32_t ns, const ckl_encode_overrides* ov = nullptr) {
 	hipStream_t s = e.stream2;
 	if (N > 0x7FFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
 	e.d_n_uniq.ensure(1);
@@ -1414,9 +1414,28 @@ uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int componen
 		hipLaunchKernelGGL(k_bitonic_local, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 	}
 	hipLaunchKernelGGL(k_unique_sorted, dim3(1), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(N), e.d_uniq.p, e.d_n_uniq.p);
+	uint64_t uniq_bound = N;      // entries of the unique list the section kernel may have to write
+	if (ov && ov->merge_unique) {
+		// sharded encode: the keys are written against the unique labels of all slabs.  The caller
+		// exchanges the lists now, under the crack trail that is still running on the other stream.
+		const uint32_t n_local = download(e.d_n_uniq.p, 1, s)[0];
+		std::vector<uint64_t> local = download(e.d_uniq.p, n_local, s);
+		const uint64_t* merged = nullptr;
+		uint64_t n_merged = 0;
+		if (ov->merge_unique(ov->merge_ctx, local.data(), n_local, &merged, &n_merged) != 0 || (!merged && n_merged))
+			throw Error(CKL_ERR_RUNTIME, "crackle_amd: the merge_unique callback failed");
+		if (n_merged < n_local || n_merged > 0xFFFFFFFFull) throw Error(CKL_ERR_ARG, "crackle_amd: merge_unique returned a list that cannot contain the slab's labels");
+		e.d_uniq.ensure(n_merged + 1);
+		if (n_merged) CKL_HIP(hipMemcpyAsync(e.d_uniq.p, merged, n_merged * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+		const uint32_t nm = static_cast<uint32_t>(n_merged);
+		CKL_HIP(hipMemcpyAsync(e.d_n_uniq.p, &nm, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+		CKL_HIP(hipStreamSynchronize(s));      // `nm` and the caller's list may go away
+		e.d_labels_bin.ensure(8 + n_merged * static_cast<uint64_t>(stored_width) + static_cast<uint64_t>(ns) * component_width + N * 4 + 16);
+		uniq_bound = std::max<uint64_t>(uniq_bound, n_merged);
+	}
 	// worst case: every component has its own label and 4-byte keys
 	e.d_labels_bin.ensure(8 + N * static_cast<uint64_t>(stored_width) + static_cast<uint64_t>(ns) * component_width + N * 4 + 16);
-	const uint64_t work = std::max<uint64_t>(std::max<uint64_t>(N, ns), 1);
+	const uint64_t work = std::max<uint64_t>(std::max<uint64_t>(uniq_bound, ns), 1);
 	hipLaunchKernelGGL(k_flat_section, dim3(static_cast<uint32_t>((work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
 		e.d_uniq.p, e.d_n_uniq.p, stored_width, e.d_ncomp.p, ns, component_width, e.d_mapping.p, static_cast<uint32_t>(N), e.d_labels_bin.p);
 	HT_MARK("l:enqueue");
@@ -1554,7 +1573,7 @@ void encode_typed(
 			HT_MARK("pins_host");
 		}
 		else {
-			label_bytes = flat_section(e, N, stored_width, component_width, static_cast<uint32_t>(sz));
+			label_bytes = flat_section(e, N, stored_width, component_width, static_cast<uint32_t>(sz), ov);
 			HT_MARK("label_table");
 			// The output buffer is taken now, sized with an estimate of the crack code bytes, so that
 			// the label section is copied out and checksummed while the trail still runs; a stream

@@ -273,6 +273,7 @@ class HipDecodeSession:
 
 class HipBackend:
   """Device-resident volumes: torch tensors of shape (sz, sy, sx) on the rank's GPU."""
+  merges_unique_in_encode = True      # encode() accepts overrides["merge_unique"]
 
   def __init__(self, device_index: int = 0, zero_copy: bool = False):
     self.device_index = int(device_index)
@@ -326,15 +327,35 @@ class HipBackend:
       if model is not None:
         keep = np.ascontiguousarray(model, dtype=np.uint8)
         ov.model = keep.ctypes.data
+      merge = overrides.get("merge_unique")
+      if merge is not None:
+        # merge(local uint64 array) -> sorted uint64 array of all slabs' labels; runs while the
+        # crack trail executes (ckl_encode_overrides.merge_unique)
+        state = {"merged": None, "error": None}
+        def _cb(ctx, local_ptr, n_local, merged_out, n_out):
+          try:
+            local = np.ctypeslib.as_array(local_ptr, shape=(int(n_local),)).copy() if n_local else np.zeros(0, np.uint64)
+            state["merged"] = np.ascontiguousarray(merge(local), dtype=np.uint64)
+            merged_out[0] = state["merged"].ctypes.data
+            n_out[0] = state["merged"].size
+            return 0
+          except BaseException as exc:      # must not propagate through the C frames
+            state["error"] = exc
+            return 1
+        cb = _lib.MERGE_UNIQUE_FN(_cb)
+        ov.merge_unique = cb
+        keep = (keep, cb, state)
       ov_ptr = C.byref(ov)
     out, n = C.c_void_p(), C.c_uint64()
     rc = self._L.ckl_encoder_run(
       e, vol.data_ptr(), shape[0], shape[1], shape[2],
       int(bool(allow_pins)), int(fortran_order), int(markov_model_order), 0, 1, 0,
       ov_ptr, C.byref(out), C.byref(n))
-    del keep
     if rc != _lib.CKL_OK:
+      if isinstance(keep, tuple) and keep[2]["error"] is not None:
+        raise keep[2]["error"]
       raise RuntimeError(_lib.last_error())
+    del keep
     if self.zero_copy:
       return _lib.HostStream(out.value, n.value)
     try:
@@ -451,6 +472,25 @@ class ShardedCodec:
     #    node-local shared buffer.  Crack codes, z-index entries, component counts and crcs
     #    are concatenated verbatim (crackle/operations.py:508-548); only the flat label keys
     #    are re-keyed against the merged, sorted unique-label list (labels.hpp:92-152).
+    import os as _os
+    early_merge = bool(getattr(be, "merges_unique_in_encode", False)) and not _os.environ.get("CKL_SHARDED_LEGACY")
+    if early_merge:
+      # the slabs' unique labels are exchanged from inside the encode, under the crack trail: the
+      # label sections then share one unique list and one key width and concatenate as they are
+      cdev0 = self.compute_device
+      def _merge_unique(local: np.ndarray) -> np.ndarray:
+        mine_n = torch.tensor([local.size], dtype=torch.int64, device=self.device)
+        sizes = [torch.empty_like(mine_n) for _ in range(self.world)]
+        dist.all_gather(sizes, mine_n)
+        sizes = [int(t.item()) for t in sizes]
+        pad = torch.zeros(max(max(sizes), 1), dtype=torch.int64, device=self.device)
+        pad[:local.size] = torch.from_numpy(local.view(np.int64)).to(self.device)
+        everyone = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(everyone, pad)
+        m = torch.unique(torch.cat([everyone[r][:sizes[r]].to(cdev0) for r in range(self.world)]))      # ascending as int64
+        m = torch.cat([m[m >= 0], m[m < 0]])                                                            # ascending as uint64
+        return m.cpu().numpy().view(np.uint64)
+      overrides["merge_unique"] = _merge_unique
     direct = hasattr(be, "codes_to_host")      # the crack codes go from HBM straight to their place in the shared buffer
     if direct:
       be.defer_codes(slab_shape, be.itemsize(vol), True)
@@ -467,18 +507,27 @@ class ShardedCodec:
     metas = [torch.empty_like(meta) for _ in range(self.world)]
     dist.all_gather(metas, meta)
     table = torch.stack(metas).cpu().numpy()
-    max_u = int(table[:, 0].max())
-    mine_u = torch.zeros(max(max_u, 1), dtype=torch.int64, device=dev)
-    mine_u[:len(sec.uniq)] = torch.from_numpy(sec.uniq).to(dev)
-    all_u = [torch.empty_like(mine_u) for _ in range(self.world)]
-    dist.all_gather(all_u, mine_u)
-    mark("gathers")
-    cdev = self.compute_device
-    merged = torch.unique(torch.cat([all_u[r][:int(table[r, 0])].to(cdev) for r in range(self.world)]))   # sorted
-    n_merged = int(merged.numel())
-    kw = _byte_width(n_merged)
     packed_dev = None
-    if not use_pins and sec.n_keys:
+    cdev = self.compute_device
+    if early_merge:
+      # every slab's section already holds the merged list and keys of the final width
+      mark("gathers")
+      merged = None
+      n_merged = len(sec.uniq)
+      kw = sec.key_width
+      if int(table[:, 0].min()) != int(table[:, 0].max()):
+        raise RuntimeError("the slabs' label sections disagree on the merged unique list")
+    else:
+      max_u = int(table[:, 0].max())
+      mine_u = torch.zeros(max(max_u, 1), dtype=torch.int64, device=dev)
+      mine_u[:len(sec.uniq)] = torch.from_numpy(sec.uniq).to(dev)
+      all_u = [torch.empty_like(mine_u) for _ in range(self.world)]
+      dist.all_gather(all_u, mine_u)
+      mark("gathers")
+      merged = torch.unique(torch.cat([all_u[r][:int(table[r, 0])].to(cdev) for r in range(self.world)]))   # sorted
+      n_merged = int(merged.numel())
+      kw = _byte_width(n_merged)
+    if not early_merge and not use_pins and sec.n_keys:
       # keys -> positions in the merged list, packed at their new width, all on `dev`: the only
       # host work is the copy of the packed bytes into the shared buffer
       signed = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
@@ -568,7 +617,10 @@ class ShardedCodec:
       out[o_cracks + cracks_before: o_cracks + cracks_before + len(sec.cracks)] = sec.cracks
     out[o_tail + 4 + 4 * z_before: o_tail + 4 + 4 * (z_before + sec.sz)] = sec.crcs
     if not use_pins:
-      packed_keys = packed_dev.cpu().numpy() if packed_dev is not None else np.zeros(0, np.uint8)
+      if early_merge:
+        packed_keys = sec.keys_raw
+      else:
+        packed_keys = packed_dev.cpu().numpy() if packed_dev is not None else np.zeros(0, np.uint8)
       c_at, c_len = o_comp + cw * z_before, cw * sec.sz
       k_at, k_len = o_keys + kw * keys_before, len(packed_keys)
       out[c_at:c_at + c_len] = sec.comp
@@ -580,7 +632,7 @@ class ShardedCodec:
       if use_pins:
         out[o_labels:o_labels + label_bytes] = pins_section
       else:
-        uniq_g = merged.cpu().numpy()
+        uniq_g = sec.uniq if early_merge else merged.cpu().numpy()
         out[o_labels:o_labels + 8] = np.frombuffer(np.array([len(uniq_g)], dtype="<u8").tobytes(), dtype=np.uint8)
         out[o_labels + 8:o_comp] = _pack(uniq_g, sw)
       out[o_model:o_cracks] = sec.model
