@@ -482,7 +482,7 @@ class ShardedCodec:
         mine_n = torch.tensor([local.size], dtype=torch.int64, device=self.device)
         sizes = [torch.empty_like(mine_n) for _ in range(self.world)]
         dist.all_gather(sizes, mine_n)
-        sizes = [int(t.item()) for t in sizes]
+        sizes = [int(v) for v in torch.cat(sizes).cpu().tolist()]      # one transfer, not one per rank
         pad = torch.zeros(max(max(sizes), 1), dtype=torch.int64, device=self.device)
         pad[:local.size] = torch.from_numpy(local.view(np.int64)).to(self.device)
         everyone = [torch.empty_like(pad) for _ in range(self.world)]
