@@ -663,31 +663,51 @@ __global__ void __launch_bounds__(kBlock) k_pad_copy_u64(const uint64_t* __restr
 	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
 	if (i < n_pad) dst[i] = i < n ? src[i] : ~0ull;
 }
-// sorted[N] -> uniq[U] (first of every run of equal values), U; one workgroup
-__global__ void __launch_bounds__(kBlock) k_unique_sorted(const uint64_t* __restrict__ sorted, uint32_t n, uint64_t* __restrict__ uniq, uint32_t* __restrict__ n_uniq) {
+// sorted[N] -> uniq[U] (first of every run of equal values), U: heads counted per 2048-item
+// block, block counts scanned by one workgroup, heads scattered.
+constexpr uint32_t kUniqPer = 8, kUniqItems = kBlock * kUniqPer;
+__device__ __forceinline__ uint32_t unique_heads(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t i0, uint64_t (&v)[kUniqPer]) {
+	uint32_t flag = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < kUniqPer; q++) {
+		const uint32_t i = i0 + q;
+		v[q] = i < n ? sorted[i] : 0;
+		const uint64_t prev = q ? v[q - 1] : ((i > 0 && i < n) ? sorted[i - 1] : 0);
+		flag |= ((i < n && (i == 0 || v[q] != prev)) ? 1u : 0u) << q;
+	}
+	return flag;
+}
+// grid = ceil(n / 2048)
+__global__ void __launch_bounds__(kBlock) k_unique_count(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t* __restrict__ blk_count) {
+	__shared__ uint32_t s_red[kWaves];
+	uint64_t v[kUniqPer];
+	const uint32_t flag = unique_heads(sorted, n, blockIdx.x * kUniqItems + threadIdx.x * kUniqPer, v);
+	const uint32_t tot = block_sum(static_cast<uint32_t>(__popc(flag)), s_red);
+	if (threadIdx.x == 0) blk_count[blockIdx.x] = tot;
+}
+// one workgroup: exclusive prefix of the block counts (in place) and the total
+__global__ void __launch_bounds__(kBlock) k_unique_scan(uint32_t* __restrict__ blk_count, uint32_t nblk, uint32_t* __restrict__ n_uniq) {
 	__shared__ uint32_t s_scan[kWaves];
-	constexpr uint32_t kPer = 8;
 	uint32_t carry = 0;
-	for (uint32_t i0 = 0; i0 < n; i0 += kBlock * kPer) {
-		uint64_t v[kPer];
-		uint32_t flag = 0, cnt = 0;
-#pragma unroll
-		for (uint32_t q = 0; q < kPer; q++) {
-			const uint32_t i = i0 + threadIdx.x * kPer + q;
-			v[q] = i < n ? sorted[i] : 0;
-			const uint64_t prev = q ? v[q - 1] : ((i > 0 && i < n) ? sorted[i - 1] : 0);
-			const bool first = i < n && (i == 0 || v[q] != prev);
-			flag |= (first ? 1u : 0u) << q;
-			cnt += first ? 1u : 0u;
-		}
-		uint32_t c[1] = { cnt }, tot[1];
+	for (uint32_t b0 = 0; b0 < nblk; b0 += kBlock) {
+		const uint32_t b = b0 + threadIdx.x;
+		uint32_t c[1] = { b < nblk ? blk_count[b] : 0u }, tot[1];
 		block_excl_add<1>(c, tot, s_scan);
-		uint32_t o = carry + c[0];
-#pragma unroll
-		for (uint32_t q = 0; q < kPer; q++) if ((flag >> q) & 1u) uniq[o++] = v[q];
+		if (b < nblk) blk_count[b] = carry + c[0];
 		carry += tot[0];
 	}
 	if (threadIdx.x == 0) *n_uniq = carry;
+}
+// grid = ceil(n / 2048)
+__global__ void __launch_bounds__(kBlock) k_unique_scatter(const uint64_t* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ blk_base, uint64_t* __restrict__ uniq) {
+	__shared__ uint32_t s_scan[kWaves];
+	uint64_t v[kUniqPer];
+	const uint32_t flag = unique_heads(sorted, n, blockIdx.x * kUniqItems + threadIdx.x * kUniqPer, v);
+	uint32_t c[1] = { static_cast<uint32_t>(__popc(flag)) }, tot[1];
+	block_excl_add<1>(c, tot, s_scan);
+	uint32_t o = blk_base[blockIdx.x] + c[0];
+#pragma unroll
+	for (uint32_t q = 0; q < kUniqPer; q++) if ((flag >> q) & 1u) uniq[o++] = v[q];
 }
 
 // The flat label section (labels.hpp:123-152) assembled on device:
@@ -830,7 +850,7 @@ struct ckl_encoder {
 	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq;
 	DevBuf<uint8_t> d_keys;
 	DevBuf<uint32_t> d_cc_volume;                // global component id of every voxel (pin encoding only)
-	DevBuf<uint32_t> d_slice_err2, d_n_uniq;
+	DevBuf<uint32_t> d_slice_err2, d_n_uniq, d_uniq_blk;
 	DevBuf<uint8_t> d_labels_bin;                // the flat label section, assembled on device
 	uint32_t flat_max_rcap = 0;
 	// label planes left by ckl_encoder_stats for the ckl_encoder_run that follows on the same
@@ -1413,7 +1433,13 @@ uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int componen
 		for (; j >= 2048; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3(blocks), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 		hipLaunchKernelGGL(k_bitonic_local, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 	}
-	hipLaunchKernelGGL(k_unique_sorted, dim3(1), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(N), e.d_uniq.p, e.d_n_uniq.p);
+	{
+		const uint32_t ub = static_cast<uint32_t>((N + kUniqItems - 1) / kUniqItems);
+		e.d_uniq_blk.ensure(ub + 1);
+		hipLaunchKernelGGL(k_unique_count, dim3(ub), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(N), e.d_uniq_blk.p);
+		hipLaunchKernelGGL(k_unique_scan, dim3(1), dim3(kBlock), 0, s, e.d_uniq_blk.p, ub, e.d_n_uniq.p);
+		hipLaunchKernelGGL(k_unique_scatter, dim3(ub), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(N), e.d_uniq_blk.p, e.d_uniq.p);
+	}
 	uint64_t uniq_bound = N;      // entries of the unique list the section kernel may have to write
 	if (ov && ov->merge_unique) {
 		// sharded encode: the keys are written against the unique labels of all slabs.  The caller
