@@ -72,6 +72,18 @@ def test_crc32c_host(port):
     assert L.ckl_crc32c(data[:n], n) == port.crc32c(data[:n]), n
 
 
+def test_crc32c_combine_host(port):
+  """ckl_crc32c_combine: the label-section crc of a sharded encode is put together from the
+  ranks' parts."""
+  L = _lib.lib()
+  rng = np.random.default_rng(5)
+  parts = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (0, 1, 17, 4096, 100003, 0, 5)]
+  crc = L.ckl_crc32c(parts[0], len(parts[0]))
+  for p in parts[1:]:
+    crc = L.ckl_crc32c_combine(crc, L.ckl_crc32c(p, len(p)), len(p))
+  assert crc == port.crc32c(b"".join(parts))
+
+
 def test_signed_input_rejected():
   with pytest.raises(TypeError):
     crackle_amd.compress(np.zeros((4, 4, 4), dtype=np.int32))
