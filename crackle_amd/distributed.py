@@ -473,12 +473,14 @@ class ShardedCodec:
     #    are concatenated verbatim (crackle/operations.py:508-548); only the flat label keys
     #    are re-keyed against the merged, sorted unique-label list (labels.hpp:92-152).
     import os as _os
-    early_merge = bool(getattr(be, "merges_unique_in_encode", False)) and not _os.environ.get("CKL_SHARDED_LEGACY")
+    early_merge = bool(getattr(be, "merges_unique_in_encode", False)) and not _os.environ.get("CKL_SHARDED_LEGACY") and not getattr(self, "_legacy_merge", False)
     if early_merge:
       # the slabs' unique labels are exchanged from inside the encode, under the crack trail: the
       # label sections then share one unique list and one key width and concatenate as they are
       cdev0 = self.compute_device
       def _merge_unique(local: np.ndarray) -> np.ndarray:
+        if _os.environ.get("CKL_TEST_MERGE_FAIL"):      # testing: exercises the fallback below
+          raise RuntimeError("forced failure of the in-encode merge")
         mine_n = torch.tensor([local.size], dtype=torch.int64, device=self.device)
         sizes = [torch.empty_like(mine_n) for _ in range(self.world)]
         dist.all_gather(sizes, mine_n)
@@ -495,7 +497,19 @@ class ShardedCodec:
     if direct:
       be.defer_codes(slab_shape, be.itemsize(vol), True)
     try:
-      slab = be.encode(vol, slab_shape, False, fortran_order, order, overrides)
+      try:
+        slab = be.encode(vol, slab_shape, False, fortran_order, order, overrides)
+      except Exception as exc:
+        if not early_merge:
+          raise
+        # insurance: should the exchange from inside the encode fail on this installation (it
+        # would on every rank alike), this and all later calls merge after the encode instead
+        import sys as _sys
+        print(f"crackle_amd: merging unique labels inside the encode failed ({exc!r}); falling back to the merge after the encode", file=_sys.stderr)
+        self._legacy_merge = True
+        early_merge = False
+        overrides.pop("merge_unique", None)
+        slab = be.encode(vol, slab_shape, False, fortran_order, order, overrides)
     finally:
       if direct:
         be.defer_codes(slab_shape, be.itemsize(vol), False)

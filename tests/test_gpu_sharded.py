@@ -62,8 +62,14 @@ def _worker(rank, port, kind, order, pins, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,order,pins", [("voronoi", 0, False), ("voronoi", 3, False), ("wide", 0, False), ("noise", 0, False), ("voronoi", 0, True)])
-def test_sharded_hip_backend_equals_whole_volume(checker, kind, order, pins):
+@pytest.mark.parametrize("kind,order,pins,env", [
+  ("voronoi", 0, False, None), ("voronoi", 3, False, None), ("wide", 0, False, None), ("noise", 0, False, None), ("voronoi", 0, True, None),
+  ("wide", 0, False, "CKL_SHARDED_LEGACY"),      # unique labels exchanged after the slab encode
+  ("voronoi", 0, False, "CKL_TEST_MERGE_FAIL"),  # the in-encode exchange fails on every rank: fallback
+])
+def test_sharded_hip_backend_equals_whole_volume(checker, kind, order, pins, env, monkeypatch):
+  if env:
+    monkeypatch.setenv(env, "1")      # inherited by the spawned ranks
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
   port = _free_port()
