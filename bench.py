@@ -1,48 +1,131 @@
 #!/usr/bin/env python3
 """Throughput of the crackle encode+decode hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
 A "step" is one pass of the hot path over one batch of synthetic input: encode the
 label volume resident in HBM into .ckl bytes, then decode those bytes (resident in
 HBM) back into a label volume in HBM.  At N=1 the workload is BASELINE.json
-configs[2]: 1024x1024x512 uint32.  At N>1 every rank holds one such z-slab of a
-1024x1024x(512*N) volume (weak scaling): format-deciding reductions and the gather
-of per-slab streams go over RCCL, rank 0 merges them into one .ckl, every rank
-decodes its own z-range.
+configs[2]: 1024x1024x512 uint32.
+
+N>1: one process per GPU.  Under `torch.distributed.run` (RANK / WORLD_SIZE in the
+environment) this process is one rank; started plainly with --gpus N it spawns the N
+rank processes itself — before anything touches the GPU — and relays rank 0's line.
+  weak scaling (default): every rank holds one --shape slab of a volume N times as deep;
+  strong scaling: --shape is the whole volume, its slices are dealt out over the ranks
+  (BASELINE.json configs[3] is `--scaling strong --shape 1024x1024x1024 --dtype uint64`).
+Format-deciding reductions and the small per-slab tables go over RCCL (backend "nccl"),
+every rank writes its slab's sections at their final offsets of one node-local buffer,
+every rank decodes its own z-range.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The encoder overlaps its crack and label streams; the HIP runtime multiplexes streams onto 4
-# hardware queues by default and torch / RCCL take some: ask for 8 before the runtime starts.
+# The encoder overlaps its crack and label streams and the decoder pipelines z-chunks; the
+# HIP runtime multiplexes streams onto 4 hardware queues by default and torch / RCCL take
+# some: ask for 8 before the runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def parse_args():
+def parse_args(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=10)
   ap.add_argument("--warmup", type=int, default=3)
-  ap.add_argument("--shape", type=str, default="1024x1024x512", help="per-GPU slab, SXxSYxSZ")
+  ap.add_argument("--shape", type=str, default="1024x1024x512", help="SXxSYxSZ: per-GPU slab (weak) or whole volume (strong)")
   ap.add_argument("--dtype", type=str, default="uint32")
+  ap.add_argument("--scaling", type=str, default="weak", choices=("weak", "strong"))
   ap.add_argument("--markov", type=int, default=0)
   ap.add_argument("--pins", type=int, default=0, help="allow_pins (parity / rehearsal runs; the metric is quoted on flat labels)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-sample-slices", type=int, default=128)
-  return ap.parse_args()
+  return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------
+# multi-rank launcher (no GPU call may precede it: the children are fresh processes)
+# ------------------------------------------------------------------------------------
+def _free_port():
+  import socket
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+  """`python bench.py --gpus N` without a launcher: start N rank processes of this script
+  and relay rank 0's JSON line.  Returns the exit code."""
+  n = args.gpus
+  rehearsal = os.environ.get("CKL_BENCH_REHEARSAL", "")
+  if not rehearsal:
+    import torch   # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < n:
+      print(f"bench.py: --gpus {n} asked for but only {have} GPU(s) are visible", file=sys.stderr)
+      return 2
+  env = dict(os.environ)
+  env["MASTER_ADDR"] = "127.0.0.1"
+  env["MASTER_PORT"] = str(_free_port())
+  env["WORLD_SIZE"] = str(n)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  procs = []
+  for r in range(n):
+    e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+    out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e, stdout=out))
+  line0, _ = procs[0].communicate()
+  rcs = [p.wait() for p in procs]
+  text = (line0 or b"").decode("utf-8", "replace")
+  sys.stdout.write(text)
+  sys.stdout.flush()
+  if any(rcs):
+    print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    return 1
+  try:
+    res = json.loads(text.strip().splitlines()[-1])
+  except (ValueError, IndexError):
+    print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+    return 1
+  if res.get("n_gpus") != n:
+    print(f"bench.py: the line reports n_gpus={res.get('n_gpus')}, --gpus was {n}", file=sys.stderr)
+    return 1
+  return 0
+
+
+def dry_run(args, world, rank):
+  """CKL_BENCH_REHEARSAL=dry: rendezvous, barriers and the max-over-ranks reduction of the
+  real run over gloo, no compute — covers the launcher on a box without GPUs."""
+  import torch
+  import torch.distributed as dist
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+  t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+  if world > 1:
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  if rank == 0:
+    print(json.dumps({"metric": metric_name(args), "value": None, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+                      "warmup": args.warmup, "dry_run": True, "max_over_ranks": float(t.item()), "scaling": args.scaling}), flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------
+def metric_name(args):
+  sx, sy, sz = (int(v) for v in args.shape.lower().split("x"))
+  return f"voxels/s encode+decode, {sx}x{sy}x{sz} {args.dtype}; bit-exact .ckl bytes"
 
 
 def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=5):
@@ -63,31 +146,53 @@ def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=5):
   return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
-def pmc_traffic(kernel, workload_key):
-  """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass
-  (profiles/pmc_traffic.json, produced by tools/pmc_summary.py from the same workload);
-  None when no counters were collected for this workload."""
-  path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-  try:
-    with open(path) as f:
-      t = json.load(f)
+def pmc_traffic(kernels, workload_key):
+  """HBM bytes per launch, summed over `kernels` (name prefixes), from the committed rocprofv3
+  --pmc passes of this workload (profiles/r02_pmc_traffic.json, written by tools/pmc_summary.py:
+  separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the guide prescribes for gfx950).
+  None when no counters were collected for this workload or a kernel is missing from them."""
+  for fn in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+    path = os.path.join(ROOT, "profiles", fn)
+    try:
+      with open(path) as f:
+        t = json.load(f)
+    except (OSError, ValueError):
+      continue
     if t.get("workload") != workload_key:
-      return None
-    for name, row in t["kernels"].items():
-      # decode kernels are instantiated for the output type: "k_paint_runs<u32, true>"
-      if name == kernel or (name.startswith(kernel + "<") and not name.endswith("false>")):
-        return row.get("hbm_bytes_per_launch")
-    return None
-  except (OSError, ValueError, KeyError):
-    return None
+      continue
+    total, per = 0.0, {}
+    for want in kernels:
+      got = None
+      for name, row in t.get("kernels", {}).items():
+        base = name.split("<")[0]
+        if base == want and not name.endswith("false>"):
+          got = (got or 0.0) + float(row.get("hbm_bytes_per_launch", 0.0))
+      if got is None:
+        return None, {}
+      per[want] = got
+      total += got
+    return total, per
+  return None, {}
 
 
-def cpu_baseline(vol_np_slab, markov, hip_bytes_for_slab=None):
+def cpu_model():
+  try:
+    with open("/proc/cpuinfo") as f:
+      for line in f:
+        if line.lower().startswith("model name"):
+          return line.split(":", 1)[1].strip()
+  except OSError:
+    pass
+  return "unknown"
+
+
+def cpu_baseline(np, vol_np_slab, markov, hip_bytes_for_slab=None):
   """Times the CPU checker (the compiled reference when oracle/_ref travelled here,
   else the C restatement) on a bounded z-slab of the same workload."""
   from oracle import oracle
   chk = oracle.best()
   cores = os.cpu_count() or 1
+  nz = vol_np_slab.shape[2]
   best_e, best_d, binary = None, None, None
   for _ in range(2):
     t = time.perf_counter()
@@ -101,41 +206,73 @@ def cpu_baseline(vol_np_slab, markov, hip_bytes_for_slab=None):
   ok = bool(np.array_equal(out.reshape(vol_np_slab.shape, order="F"), vol_np_slab))
   vox = vol_np_slab.size
   # one-thread row on a quarter of the sample
-  q = np.asfortranarray(vol_np_slab[:, :, :max(1, vol_np_slab.shape[2] // 4)])
+  q = np.asfortranarray(vol_np_slab[:, :, :max(1, nz // 4)])
   t = time.perf_counter()
   b1 = chk.compress(q, markov_model_order=markov, parallel=1)
   chk.decompress(b1, parallel=1)
   t1 = time.perf_counter() - t
+  # the reference's pool never runs more threads than slices (src/crackle.hpp:66-69, 570-573)
+  threads = min(cores, nz)
   res = {
     "value": vox / (best_e + best_d),
     "unit": "voxels/s",
-    "cores": cores,
+    "cores": threads,
+    "host_cores": cores,
+    "cpu_model": cpu_model(),
     "kind": chk.kind,
-    "sample": f"{vol_np_slab.shape[0]}x{vol_np_slab.shape[1]}x{vol_np_slab.shape[2]} {vol_np_slab.dtype} z-slab of the same synthetic volume, encode+decode, parallel={cores}, best of 2",
+    "sample": f"{vol_np_slab.shape[0]}x{vol_np_slab.shape[1]}x{nz} {vol_np_slab.dtype} z-slab of the same synthetic volume, encode+decode, parallel={cores} asked, {threads} threads effective (one per slice), best of 2",
     "encode_voxels_per_s": vox / best_e,
     "decode_voxels_per_s": vox / best_d,
     "single_thread_voxels_per_s": q.size / t1,
     "roundtrip_ok": ok,
   }
   if hip_bytes_for_slab is not None:
-    res["hip_bytes_equal_cpu_bytes_on_sample"] = bool(hip_bytes_for_slab == binary)
+    res["hip_bytes_equal_cpu_bytes_on_sample"] = bool(bytes(hip_bytes_for_slab) == bytes(binary))
   return res
+
+
+def reference_manifest(name):
+  """sha256 / length of the reference encoder's bytes for a full-size configuration
+  (tests/golden/manifest_xl.json, written here by tests/gen_golden.py --xl)."""
+  try:
+    with open(os.path.join(ROOT, "tests", "golden", "manifest_xl.json")) as f:
+      return json.load(f).get(name)
+  except (OSError, ValueError):
+    return None
+
+
+DECODE_KERNELS_FOR_TRAFFIC = None   # filled from the stage names of the run
 
 
 def main():
   args = parse_args()
+  world_env = os.environ.get("WORLD_SIZE")
+  if world_env is None and args.gpus > 1:
+    sys.exit(spawn_ranks(args))
+  world = int(world_env or "1")
+  if world != args.gpus:
+    print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    sys.exit(2)
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  rehearsal_mode = os.environ.get("CKL_BENCH_REHEARSAL", "")
+  if rehearsal_mode == "dry":
+    return dry_run(args, world, rank)
+
+  import hashlib
+  import numpy as np
   import torch
   import torch.distributed as dist
   from crackle_amd import _lib, synth
   from crackle_amd import distributed as ckd
 
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  rank = int(os.environ.get("RANK", "0"))
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (never for reported
   # numbers): CKL_BENCH_REHEARSAL=1 maps the ranks onto the available devices and uses gloo
-  rehearsal = os.environ.get("CKL_BENCH_REHEARSAL") == "1"
+  rehearsal = rehearsal_mode == "1"
   n_dev = torch.cuda.device_count()
+  if world > 1 and not rehearsal and n_dev < world:
+    print(f"bench.py: {world} ranks but {n_dev} GPU(s)", file=sys.stderr)
+    sys.exit(2)
   dev_index = (local_rank % max(n_dev, 1)) if (world > 1 and rehearsal) else (local_rank if world > 1 else 0)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -149,15 +286,23 @@ def main():
   L = _lib.lib()
   assert L.ckl_device_count() > dev_index, "no HIP device for this rank"
 
-  sx, sy, sz = (int(v) for v in args.shape.lower().split("x"))
+  sx, sy, sz_arg = (int(v) for v in args.shape.lower().split("x"))
   np_dtype = np.dtype(args.dtype)
+  if args.scaling == "strong":
+    if sz_arg % world:
+      print(f"bench.py: strong scaling needs the slice count {sz_arg} to divide over {world} ranks", file=sys.stderr)
+      sys.exit(2)
+    sz = sz_arg // world
+  else:
+    sz = sz_arg
+  sz_total = sz * world
   voxels_local = sx * sy * sz
   voxels_total = voxels_local * world
 
   # synthetic connectomics-style labels, generated on device;
   # rank r holds slices [r*sz, (r+1)*sz) of one global volume
   offset = (1 << 40) if np_dtype.itemsize == 8 else 0
-  vol = synth.voronoi_labels((sx, sy, sz * world), np_dtype, seed=2, device=dev, offset=offset,
+  vol = synth.voronoi_labels((sx, sy, sz_total), np_dtype, seed=2, device=dev, offset=offset,
                              z_range=(rank * sz, (rank + 1) * sz)) if world > 1 else \
         synth.voronoi_labels((sx, sy, sz), np_dtype, seed=2, device=dev, offset=offset)
   torch.cuda.synchronize()
@@ -174,9 +319,8 @@ def main():
     torch.cuda.synchronize()
 
   out = torch.empty_like(vol)
-  enc_ms, dec_ms, dec_kernel_ms, dec_pipe_ms, enc_pipe_ms, enc_kernel_ms = [], [], [], [], [], []
+  enc_ms, dec_ms, open_ms, dec_pipe_ms, enc_pipe_ms, enc_kernel_ms = [], [], [], [], [], []
   binary = None
-  dec_stages = []
   total_s = 0.0
   for step in range(args.warmup + args.steps):
     timed = step >= args.warmup
@@ -185,7 +329,9 @@ def main():
     binary = codec.compress(vol, (sx, sy, sz), markov_model_order=args.markov, allow_pins=bool(args.pins))   # merged stream on rank 0
     barrier()
     t1 = time.perf_counter()
-    # decode leg: the stream is made resident first (not timed), then every rank decodes its z-range
+    # decode leg.  Set-up (stream upload over PCIe, header / z-index / label-section parse,
+    # descriptors, scratch) is timed on its own: `value` counts the path from bytes resident in
+    # HBM to labels resident in HBM, decode_total_ms includes the set-up.
     session = codec.open_decoder(binary, (sx, sy, sz))
     barrier()
     t2 = time.perf_counter()
@@ -194,16 +340,33 @@ def main():
     t3 = time.perf_counter()
     if timed:
       enc_ms.append((t1 - t0) * 1e3)
+      open_ms.append((t2 - t1) * 1e3)
       dec_ms.append((t3 - t2) * 1e3)
       total_s += (t1 - t0) + (t3 - t2)
-      p, k = session.timing()
-      dec_pipe_ms.append(p); dec_kernel_ms.append(k)
-      dec_stages.append(session.stages())
+      p, _ = session.timing()
+      dec_pipe_ms.append(p)
       p, k = backend.encoder_timing()
       enc_pipe_ms.append(p); enc_kernel_ms.append(k)
     session.close()
 
   ok_local = bool(torch.equal(out.view(torch.uint8), vol.view(torch.uint8)))
+
+  # one more decode with the z-chunks serialised on one stream, for the per-kernel table:
+  # HIP events between the kernels on the decoder's own stream (ckl_decoder_stage_timing)
+  stage_ms = {}
+  if rank == 0 or world > 1:
+    os.environ["CKL_DECODE_CHUNKS"] = "1"
+    session = codec.open_decoder(binary, (sx, sy, sz))
+    acc = {}
+    for _ in range(3):
+      session.run(out)
+      for n, ms in session.stages():
+        acc.setdefault(n, []).append(ms)
+    serial_pipe = session.timing()[0]
+    session.close()
+    del os.environ["CKL_DECODE_CHUNKS"]
+    stage_ms = {n: float(np.mean(v[1:])) for n, v in acc.items()}
+
   # max over ranks of the timed wall clock
   t = torch.tensor([total_s, sum(enc_ms), sum(dec_ms), 0.0 if ok_local else 1.0], dtype=torch.float64, device=coll_dev)
   if world > 1:
@@ -215,19 +378,18 @@ def main():
     ms_per_step = total_s * 1e3 / K
     ckl_len = len(binary)
     item = np_dtype.itemsize
-    # roofline of the dominant decode kernel: algorithmic bytes per launch =
-    # label bytes written + stream bytes read, this rank's slab
+    # algorithmic bytes of one decode of this rank's slab = label bytes written + stream bytes
+    # read (4 B/voxel @u32 plus ~1 % for the stream)
     alg_bytes = voxels_local * item + ckl_len / world
-    # per-stage means over the timed steps; the dominant decode kernel is the slowest stage
-    stage_names = [n for n, _ in dec_stages[0]]
-    stage_ms = {n: float(np.mean([dict(s)[n] for s in dec_stages])) for n in stage_names}
-    dom = max(stage_ms, key=stage_ms.get)
-    k_ms = stage_ms[dom]
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    pipe_ms = float(np.mean(dec_pipe_ms))
+    achieved = alg_bytes / (pipe_ms * 1e-3) / 1e9
     copy_gbs = measured_copy_bandwidth(torch, dev)
     workload_key = f"{sx}x{sy}x{sz} {np_dtype.name} markov {args.markov}"
+    kernels = [n for n in stage_ms if n.startswith("k_")]
+    traffic, traffic_per = pmc_traffic(kernels, workload_key)
+    dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
     res = {
-      "metric": "voxels/s encode+decode, 1024x1024x512 uint32; bit-exact .ckl bytes",
+      "metric": metric_name(args),
       "value": voxels_total * K / total_s,
       "unit": "voxels/s",
       "n_gpus": world,
@@ -235,12 +397,12 @@ def main():
       "warmup": args.warmup,
       "ms_per_step": ms_per_step,
       "higher_is_better": True,
-      "scaling": "weak",
+      "scaling": args.scaling,
       "vs_baseline": None,
       "dtype": {1: "u8", 2: "u16", 4: "u32", 8: "u64"}[item],
       "data": "synthetic",
       "config": {
-        "workload": f"{sx}x{sy}x{sz * world} {np_dtype.name} jittered-Voronoi labels (cell 32x32x8), encode+decode, {'pin' if args.pins else 'flat'} labels, markov {args.markov}",
+        "workload": f"{sx}x{sy}x{sz_total} {np_dtype.name} jittered-Voronoi labels (cell 32x32x8), encode+decode, {'pin' if args.pins else 'flat'} labels, markov {args.markov}",
         "per_gpu_slab": f"{sx}x{sy}x{sz}",
         "parallelism": f"z-slab x{world}",
       },
@@ -251,41 +413,63 @@ def main():
       "decode_voxels_per_s": voxels_total * K / (dec_sum_ms * 1e-3),
       "encode_ms": float(np.mean(enc_ms)),
       "decode_ms": float(np.mean(dec_ms)),
-      "decode_device_pipeline_ms": float(np.mean(dec_pipe_ms)),
+      "decoder_create_ms": float(np.mean(open_ms)),
+      "decode_total_ms": float(np.mean(open_ms)) + float(np.mean(dec_ms)),
+      "decode_device_pipeline_ms": pipe_ms,
       "encode_device_pipeline_ms": float(np.mean(enc_pipe_ms)),
       "encode_dfs_kernel_ms": float(np.mean(enc_kernel_ms)),
+      # the decode direction as one unit (north_star states its target for it): every kernel of one
+      # decode, first launch to last completion, HIP events on the decoder's streams
       "roofline": {
         "bound": "hbm",
-        "kernel": dom + " (decode)",
+        "kernel": "decode pipeline: " + " + ".join(kernels),
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": pmc_traffic(dom, workload_key),
+        "traffic": traffic,
         "measured_copy_GBs": copy_gbs,
         "frac_of_measured_copy": achieved / copy_gbs,
         "algorithmic_bytes_per_launch": alg_bytes,
-        "kernel_ms": k_ms,
-        "decode_pipeline_frac": alg_bytes / (float(np.mean(dec_pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "kernel_ms": pipe_ms,
+        "serialized_pipeline_ms": serial_pipe,
         "decode_stage_ms": stage_ms,
+        "decode_stage_traffic": traffic_per,
+        "slowest_stage": None if dom is None else {
+          "kernel": dom, "kernel_ms": stage_ms[dom],
+          "achieved": alg_bytes / (stage_ms[dom] * 1e-3) / 1e9,
+          "frac": alg_bytes / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        },
       },
     }
     # the same figure for the encoder's longest kernel (the serial trail over nodes: one
     # wavefront per slice, bound by dependent instruction latency, not by bytes)
     enc_k = float(np.mean(enc_kernel_ms))
     if enc_k > 0:
+      etraffic, _ = pmc_traffic(["k_trail_dfs"], workload_key)
       res["roofline_encode"] = {
         "bound": "hbm", "kernel": "k_trail_dfs (encode)",
         "achieved": alg_bytes / (enc_k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": alg_bytes / (enc_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": pmc_traffic("k_trail_dfs", workload_key),
+        "traffic": etraffic,
         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": enc_k,
         "encode_pipeline_frac": alg_bytes / (float(np.mean(enc_pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
       }
+    # bytes against the reference encoder's own output at full size (sha256 of the whole stream)
+    if world == 1 and not args.pins:
+      name = f"c2_{sx}x{sy}x{sz}_u32" if (np_dtype.itemsize == 4 and args.markov == 0) else None
+      ref = reference_manifest(name) if name else None
+      if ref is not None:
+        sha = hashlib.sha256(bytes(binary.view()) if hasattr(binary, "view") else bytes(binary)).hexdigest()
+        res["bytes_match_reference"] = bool(sha == ref["sha256"] and ckl_len == ref["length"])
+        res["reference_sha256"] = ref["sha256"]
     if not args.no_cpu_baseline:
       ns = min(args.cpu_sample_slices, sz)
-      slab = synth.as_numpy_f(vol[:ns])
-      res["cpu_baseline"] = cpu_baseline(np.asfortranarray(slab), args.markov)
+      slab = np.asfortranarray(synth.as_numpy_f(vol[:ns]))
+      hip_slab = None
+      if world == 1:
+        hip_slab = ckd.HipBackend(dev_index).encode(vol[:ns].contiguous(), (sx, sy, ns), False, True, args.markov, None)
+      res["cpu_baseline"] = cpu_baseline(np, slab, args.markov, hip_slab)
     print(json.dumps(res), flush=True)
 
   if world > 1:

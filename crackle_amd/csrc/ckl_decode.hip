@@ -33,6 +33,7 @@
 //   k_vcg             voxel connectivity graph from the planes (+ labels for the z bits)
 #include "ckl_common.hpp"
 #include "ckl_runs.hpp"
+#include "ckl_strips.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -84,6 +85,7 @@ struct CrackArgs {
 	uint32_t lds_words;          // dynamic LDS size in 4-byte words
 	uint32_t lds_raster;         // 1: planes are built in LDS bands and stored; 0: zeroed by the host, atomics on HBM
 	uint32_t markov_serial;      // testing: expand markov streams with one thread
+	uint32_t zbase;              // first slice of this launch (z-chunked launches)
 	uint32_t* slice_err;         // [nslices] sticky error bits
 };
 
@@ -853,7 +855,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		}
 	};
 
-	const uint32_t zi = blockIdx.x;
+	const uint32_t zi = blockIdx.x + a.zbase;
 	const uint32_t tid = threadIdx.x;
 	const uint8_t* code = a.stream + a.code_off[zi];
 	const uint32_t code_len = a.code_len[zi];
@@ -1524,6 +1526,139 @@ __global__ void __launch_bounds__(kBlock) k_paint_runs(
 	}
 }
 
+// the groups of 4 pixels of one tile: labels from the staged table (STAGED) or straight from HBM
+template <typename OUT, bool STAGED>
+__device__ __forceinline__ void paint_tile_groups(
+	const OUT* s_lab, const OUT* __restrict__ lab, const uint32_t* s_b, const uint16_t* s_wb, OUT* __restrict__ oz,
+	uint32_t ngroups, uint32_t gpr, uint32_t gpr_shift, uint32_t rw, uint32_t sx, uint32_t lo, uint32_t cap
+) {
+	typedef typename Vec4<OUT>::type V4;
+	const uint32_t t = threadIdx.x;
+	const uint32_t last = cap - 1u;
+	for (uint32_t g0 = 0; g0 < ngroups; g0 += kBlock * 4u) {
+		V4 val[4];
+		uint32_t at[4];
+#pragma unroll
+		for (uint32_t u = 0; u < 4; u++) {
+			const uint32_t gi = g0 + u * kBlock + t;
+			at[u] = 0xFFFFFFFFu;
+			if (gi >= ngroups) continue;
+			const uint32_t row = gpr_shift != 0xFFFFFFFFu ? gi >> gpr_shift : gi / gpr;
+			const uint32_t x = (gi - row * gpr) << 2;
+			const uint32_t wl = row * rw + (x >> 5);
+			const uint32_t bw = s_b[wl], sh = x & 31u;
+			uint32_t run = s_wb[wl] + __popc(bw & mask_le(sh)) - 1u;
+			const uint32_t nib = ((bw >> sh) >> 1) & 7u;
+			at[u] = row * sx + x;
+			if (STAGED) {
+				val[u].x = s_lab[run];
+				run += nib & 1u;        val[u].y = s_lab[run];
+				run += (nib >> 1) & 1u; val[u].z = s_lab[run];
+				run += (nib >> 2) & 1u; val[u].w = s_lab[run];
+			}
+			else {
+				run += lo;
+				val[u].x = lab[run < last ? run : last];
+				run += nib & 1u;        val[u].y = lab[run < last ? run : last];
+				run += (nib >> 1) & 1u; val[u].z = lab[run < last ? run : last];
+				run += (nib >> 2) & 1u; val[u].w = lab[run < last ? run : last];
+			}
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < 4; u++) if (at[u] != 0xFFFFFFFFu) store_stream(oz + at[u], val[u]);
+	}
+}
+
+// The strip path's paint (ckl_strips.hpp): a tile is a few whole rows of one strip.  Its plane
+// words and the run prefix over them are built in LDS, the tile's run labels (one contiguous
+// stretch of run_label, starting at row_run[first row]) are staged next to them, then every
+// thread paints groups of 4 pixels with 16-byte streaming stores.  sx % 4 == 0, x fastest.
+// grid = (nstrips * tiles_per_strip, slices of the launch)
+template <typename OUT>
+__global__ void __launch_bounds__(kBlock) k_paint_strips(
+	RunGeom g, StripArrays sa, const OUT* __restrict__ run_label, OUT* __restrict__ out,
+	uint32_t sxy, uint32_t tile_rows, uint32_t tiles_per_strip, uint32_t gpr_shift
+) {
+	__shared__ OUT s_lab[kPaintStage];
+	__shared__ uint32_t s_b[kStripWords];
+	__shared__ uint16_t s_wb[kStripWords];
+	__shared__ uint32_t s_scan[kWaves];
+	const uint32_t zi = blockIdx.y + sa.zbase;
+	const uint32_t k = blockIdx.x / tiles_per_strip, tt = blockIdx.x - k * tiles_per_strip;
+	const uint32_t y1s = min((k + 1u) * sa.strip_rows, g.sy);
+	const uint32_t ya = k * sa.strip_rows + tt * tile_rows;
+	if (ya >= y1s) return;
+	const uint32_t yb = min(ya + tile_rows, y1s);
+	const uint32_t rw = g.row_words, sx = g.sx;
+	const uint32_t nw = (yb - ya) * rw;
+	const uint32_t t = threadIdx.x;
+	const uint32_t lo = sa.row_run[static_cast<uint64_t>(zi) * g.sy + ya];
+	uint32_t b[4], cnt = 0;
+	{
+		uint32_t yy = (t * 4u) / rw, ww = t * 4u - yy * rw;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {
+			b[j] = t * 4u + j < nw ? g.breaks(zi, ya + yy, ww) : 0u;
+			cnt += __popc(b[j]);
+			if (++ww == rw) { ww = 0; yy++; }
+		}
+	}
+	uint32_t v[1] = { cnt }, tot[1];
+	block_excl_add<1>(v, tot, s_scan);
+	{
+		uint32_t local = v[0];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {
+			const uint32_t wl = t * 4u + j;
+			if (wl < nw) { s_b[wl] = b[j]; s_wb[wl] = static_cast<uint16_t>(local); }
+			local += __popc(b[j]);
+		}
+	}
+	const uint32_t n_runs = tot[0];
+	const uint32_t cap = sa.rcap[zi];
+	const OUT* lab = run_label + sa.rbase[zi];
+	const bool staged = n_runs <= kPaintStage;
+	if (staged) {
+		for (uint32_t i = t; i < n_runs; i += kBlock) { const uint32_t at = lo + i; s_lab[i] = lab[at < cap ? at : cap - 1u]; }
+	}
+	__syncthreads();
+	const uint32_t gpr = sx >> 2;      // groups of 4 pixels per row
+	const uint32_t ngroups = (yb - ya) * gpr;
+	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(ya) * sx;
+	if (staged) paint_tile_groups<OUT, true>(s_lab, lab, s_b, s_wb, oz, ngroups, gpr, gpr_shift, rw, sx, lo, cap);
+	else paint_tile_groups<OUT, false>(s_lab, lab, s_b, s_wb, oz, ngroups, gpr, gpr_shift, rw, sx, lo, cap);
+}
+
+// condensed pins on the strip path (labels.hpp:600-614): one thread per (pin, slice) pair
+__global__ void __launch_bounds__(kBlock) k_label_map_pins_strips(
+	const uint64_t* __restrict__ pin_index, const uint64_t* __restrict__ pin_depth, const uint64_t* __restrict__ pin_label,
+	const uint64_t* __restrict__ pin_work_off, uint64_t n_pins, uint64_t total_work,
+	RunGeom g, StripArrays sa, uint64_t sxy,
+	int64_t z_start, int64_t z_end, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ ncomp_expect,
+	uint64_t* __restrict__ label_map
+) {
+	const uint64_t w = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (w >= total_work) return;
+	uint64_t lo = 0, hi = n_pins;
+	while (lo + 1 < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (pin_work_off[mid] <= w) lo = mid; else hi = mid;
+	}
+	const uint64_t j = lo;
+	const int64_t pin_z = static_cast<int64_t>(pin_index[j] / sxy);
+	const uint64_t loc = pin_index[j] - static_cast<uint64_t>(pin_z) * sxy;
+	const int64_t zs = pin_z > z_start ? pin_z : z_start;
+	const int64_t z = zs + static_cast<int64_t>(w - pin_work_off[j]);
+	int64_t ze = pin_z + static_cast<int64_t>(pin_depth[j]) + 1;
+	if (ze > z_end) ze = z_end;
+	if (z >= ze) return;
+	const uint32_t zi = static_cast<uint32_t>(z - z_start);
+	const uint32_t y = static_cast<uint32_t>(loc / g.sx);
+	const uint32_t x = static_cast<uint32_t>(loc - static_cast<uint64_t>(y) * g.sx);
+	const uint32_t cc = strip_component_of_pixel(g, sa, zi, x, y);
+	if (cc < ncomp_expect[zi]) label_map[comp_off[zi] + cc] = pin_label[j];
+}
+
 // ------------------------------------------------------------------------------
 // voxel connectivity graph (operations.hpp:667-826): bit0 +x, bit1 -x, bit2 +y, bit3 -y from the
 // crack planes (a pair across the image border is passable for IMPERMISSIBLE streams and not for
@@ -1596,7 +1731,7 @@ struct ckl_decoder {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	// stage boundaries: ev[i] .. ev[i+1] brackets stage i of the last run
-	hipEvent_t ev[kMaxStages + 1] = {};
+	hipEvent_t ev[kMaxStages + 2] = {};      // [kMaxStages + 1]: end of the pipeline
 	hipEvent_t ev_in = nullptr;
 	const char* stage_name[kMaxStages] = {};
 	float stage_ms[kMaxStages] = {};
@@ -1634,6 +1769,17 @@ struct ckl_decoder {
 	DevBuf<uint32_t> d_G, d_crc_acc, d_crc_expect, d_slice_err;
 	DevBuf<uint64_t> d_label_map;
 	DevBuf<uint64_t> d_pin_index, d_pin_depth, d_pin_label, d_pin_work_off, d_ccl_id, d_ccl_label;
+	// strip path (ckl_strips.hpp); its per-run arrays reuse d_run_local (run_lid), d_parent (sc_w),
+	// d_run_cc (sc_cc) and d_run_label of the general pipeline
+	DevBuf<uint32_t> d_cursor, d_row_run, d_strip_base, d_strip_nruns, d_strip_nsc, d_overflow;
+	DevBuf<uint16_t> d_seam_first, d_seam_last;
+	bool strip_ok = false;              // shape / layout qualify for the strip path
+	bool use_general = false;           // a run overflowed the strip path's LDS tables: stay on the general pipeline
+	uint32_t strip_rows = 0, nstrips = 0;
+	static constexpr int kMaxChunks = 8;
+	hipStream_t chunk_stream[kMaxChunks] = {};
+	hipEvent_t chunk_done[kMaxChunks] = {};
+	hipEvent_t ev_fork = nullptr;
 
 	// label section layout
 	uint64_t total_comp = 0;            // components in [z_start, z_end)
@@ -1653,6 +1799,9 @@ struct ckl_decoder {
 	~ckl_decoder() {
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
 		if (ev_in) (void)hipEventDestroy(ev_in);
+		if (ev_fork) (void)hipEventDestroy(ev_fork);
+		for (auto& e : chunk_done) if (e) (void)hipEventDestroy(e);
+		for (auto& cs : chunk_stream) if (cs) (void)hipStreamDestroy(cs);
 		if (stream) (void)hipStreamDestroy(stream);
 	}
 };
@@ -1789,7 +1938,22 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	d.row_words = (h.sx + 31) / 32;
 	d.plane_words = static_cast<uint64_t>(d.row_words) * h.sy;
 	d.d_planes.ensure(2 * d.plane_words * d.nslices);
-	d.d_word_base.ensure(d.plane_words * d.nslices);
+	{
+		// strip path: x-fastest output in groups of 4 pixels, strips of <= 1024 plane words
+		d.strip_rows = std::max<uint32_t>(1u, kStripWords / d.row_words);
+		d.nstrips = (h.sy + d.strip_rows - 1) / d.strip_rows;
+		d.strip_ok = h.fortran_order && (h.sx % 4 == 0) && d.row_words <= kStripWords && d.nstrips <= kMaxStrips &&
+			d.sxy < 0xFFFF0000ull && !getenv("CKL_DECODE_GENERAL");
+		if (d.strip_ok) {
+			const size_t nst = static_cast<size_t>(d.nstrips) * d.nslices;
+			d.d_cursor.ensure(d.nslices);
+			d.d_row_run.ensure(static_cast<size_t>(h.sy) * d.nslices);
+			d.d_strip_base.ensure(nst); d.d_strip_nruns.ensure(nst); d.d_strip_nsc.ensure(nst);
+			d.d_seam_first.ensure(nst * d.row_words); d.d_seam_last.ensure(nst * d.row_words);
+			d.d_overflow.ensure(1);
+		}
+		else d.d_word_base.ensure(d.plane_words * d.nslices);
+	}
 	d.d_nruns.ensure(d.nslices);
 	d.d_ncomp.ensure(d.nslices);
 	d.d_slice_err.ensure(d.nslices);
@@ -1939,9 +2103,10 @@ struct StageTimer {
 	ckl_decoder& d;
 	hipStream_t s;
 	int i = 0;
+	bool on = true;      // off: z-chunks overlap on several streams, only the whole pipeline is timed
 	StageTimer(ckl_decoder& dec, hipStream_t st) : d(dec), s(st) { CKL_HIP(hipEventRecord(d.ev[0], s)); }
 	void done(const char* name) {
-		if (i >= kMaxStages) return;
+		if (!on || i >= kMaxStages) return;
 		d.stage_name[i] = name;
 		CKL_HIP(hipEventRecord(d.ev[i + 1], s));
 		i++;
@@ -1952,13 +2117,18 @@ struct StageTimer {
 // label table is ready before the components are, so k_run_assign writes the run labels
 // directly; pins need the component ids first (k_label_map_pins looks pixels up).
 // component -> label table of a pin stream (labels.hpp:540-650); needs run_cc
-void launch_pin_label_map(ckl_decoder& d, const RunGeom& g, const RunArrays& ra) {
+void launch_pin_label_map(ckl_decoder& d, const RunGeom& g, const RunArrays& ra, const StripArrays* sa = nullptr) {
 	hipStream_t s = d.stream;
 	const uint64_t nlm = d.total_comp;
 	if (nlm) hipLaunchKernelGGL(k_fill_u64, dim3(static_cast<uint32_t>((nlm + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d.d_label_map.p, d.bgcolor, nlm);
 	if (d.n_ccl) hipLaunchKernelGGL(k_label_map_ccids, dim3(static_cast<uint32_t>((d.n_ccl + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
 		d.d_ccl_id.p, d.d_ccl_label.p, d.n_ccl, d.comp_left, d.comp_left + nlm, d.d_label_map.p);
-	if (d.pin_total_work) hipLaunchKernelGGL(k_label_map_pins, dim3(static_cast<uint32_t>((d.pin_total_work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+	if (!d.pin_total_work) return;
+	const dim3 grid(static_cast<uint32_t>((d.pin_total_work + kBlock - 1) / kBlock));
+	if (sa) hipLaunchKernelGGL(k_label_map_pins_strips, grid, dim3(kBlock), 0, s,
+		d.d_pin_index.p, d.d_pin_depth.p, d.d_pin_label.p, d.d_pin_work_off.p, d.n_pins, d.pin_total_work,
+		g, *sa, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp_expect.p, d.d_label_map.p);
+	else hipLaunchKernelGGL(k_label_map_pins, grid, dim3(kBlock), 0, s,
 		d.d_pin_index.p, d.d_pin_depth.p, d.d_pin_label.p, d.d_pin_work_off.p, d.n_pins, d.pin_total_work,
 		g, ra, d.sxy, d.z_start, d.z_end, d.d_comp_off.p, d.d_ncomp_expect.p, d.d_label_map.p);
 }
@@ -2033,6 +2203,166 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	st.done("k_paint_runs");
 }
 
+// ---- the strip path (ckl_strips.hpp): planes -> labels in three kernels per z-chunk ----
+struct StripPlan {
+	StripArrays sa;
+	ResolveArgs ra;
+	uint32_t tile_rows, tiles_per_strip, gpr_shift;
+	size_t resolve_lds;
+};
+
+template <typename OUT>
+StripPlan strip_plan(ckl_decoder& d, int has_label, uint64_t label) {
+	const Header& h = d.head;
+	StripPlan p;
+	StripArrays& sa = p.sa;
+	sa.rbase = d.d_rbase.p; sa.rcap = d.d_rcap.p; sa.cursor = d.d_cursor.p;
+	sa.run_lid = d.d_run_local.p; sa.row_run = d.d_row_run.p;
+	sa.strip_base = d.d_strip_base.p; sa.strip_nruns = d.d_strip_nruns.p; sa.strip_nsc = d.d_strip_nsc.p;
+	sa.seam_first = d.d_seam_first.p; sa.seam_last = d.d_seam_last.p;
+	sa.sc_w = d.d_parent.p; sa.sc_cc = d.d_run_cc.p;
+	sa.slice_err = d.d_slice_err.p; sa.overflow = d.d_overflow.p;
+	sa.nstrips = d.nstrips; sa.strip_rows = d.strip_rows; sa.zbase = 0;
+	ResolveArgs& ra = p.ra;
+	ra.idbits = d.idbits; ra.crc_fix = d.crc_fix; ra.check_crc = d.check_crc ? 1u : 0u;
+	ra.crc_expect = d.d_crc_expect.p; ra.ncomp_expect = d.d_ncomp_expect.p; ra.comp_off = d.d_comp_off.p;
+	ra.label_map = d.d_label_map.p; ra.has_label = has_label ? 1u : 0u; ra.label = label;
+	ra.run_label = d.d_run_label.p;
+	ra.cap = kResolveCap;
+	if (const char* env = getenv("CKL_RESOLVE_CAP")) ra.cap = std::min<uint32_t>(kResolveCap, static_cast<uint32_t>(std::max(1, atoi(env))));   // testing: forces the overflow path
+	p.resolve_lds = static_cast<size_t>(kResolveCap) * std::max<size_t>(4, sizeof(OUT));
+	p.tile_rows = std::min<uint32_t>(d.strip_rows, std::max<uint32_t>(1u, kPaintTile / h.sx));
+	p.tiles_per_strip = (d.strip_rows + p.tile_rows - 1) / p.tile_rows;
+	const uint32_t gpr = h.sx / 4;
+	p.gpr_shift = (gpr & (gpr - 1)) == 0 ? static_cast<uint32_t>(__builtin_ctz(gpr)) : 0xFFFFFFFFu;
+	return p;
+}
+
+template <typename OUT>
+void set_strip_attributes() {
+	const int bytes = static_cast<int>(static_cast<size_t>(kResolveCap) * std::max<size_t>(4, sizeof(OUT)));
+	CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slice_resolve<OUT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+	CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slice_resolve<OUT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+	CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_labels<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+}
+
+void launch_cracks(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t z0, uint32_t n, size_t crack_lds) {
+	ca.zbase = z0;
+	hipLaunchKernelGGL(k_decode_cracks<false>, dim3(n), dim3(kCrackBlock), crack_lds, s, ca, static_cast<unsigned long long*>(nullptr));
+}
+
+// strips + resolve of slices [z0, z0 + n); flat labels also paint
+template <typename OUT>
+void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p, uint32_t z0, uint32_t n, void* out_device, bool flat, bool paint, StageTimer* st) {
+	p.sa.zbase = z0;
+	hipLaunchKernelGGL(k_strip_ccl, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.d_G.p, static_cast<uint32_t>(d.sxy));
+	if (st) st->done("k_strip_ccl");
+	if (flat) hipLaunchKernelGGL((k_slice_resolve<OUT, true>), dim3(n), dim3(kResolveBlock), p.resolve_lds, s, g, p.sa, p.ra, d.d_ncomp.p);
+	else hipLaunchKernelGGL((k_slice_resolve<OUT, false>), dim3(n), dim3(kResolveBlock), p.resolve_lds, s, g, p.sa, p.ra, d.d_ncomp.p);
+	if (st) st->done("k_slice_resolve");
+	if (!paint) return;
+	hipLaunchKernelGGL(k_paint_strips<OUT>, dim3(d.nstrips * p.tiles_per_strip, n), dim3(kBlock), 0, s,
+		g, p.sa, reinterpret_cast<const OUT*>(d.d_run_label.p), reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), p.tile_rows, p.tiles_per_strip, p.gpr_shift);
+	if (st) st->done("k_paint_strips");
+}
+
+// number of z-chunks the strip path pipelines over its streams
+uint32_t decode_chunks(const ckl_decoder& d) {
+	uint32_t want = 4;
+	if (const char* env = getenv("CKL_DECODE_CHUNKS")) want = static_cast<uint32_t>(std::max(1, atoi(env)));
+	want = std::min<uint32_t>(want, ckl_decoder::kMaxChunks);
+	// a chunk should still fill the chip: at least 64 Mi voxels and 64 slices each
+	const uint64_t by_size = std::max<uint64_t>(1, d.sxy * d.nslices >> 26);
+	const uint64_t by_slices = std::max<uint32_t>(1u, d.nslices / 64u);
+	if (!getenv("CKL_DECODE_CHUNKS")) want = static_cast<uint32_t>(std::min<uint64_t>(want, std::min(by_size, by_slices)));
+	return std::max<uint32_t>(1u, std::min(want, d.nslices));
+}
+
+template <typename OUT>
+void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const RunGeom& g, const RunArrays& ra_legacy, void* out_device, int has_label, uint64_t label, StageTimer& st) {
+	const Header& h = d.head;
+	hipStream_t s = d.stream;
+	const uint32_t ns = d.nslices;
+	const bool flat = h.label_format == FLAT;
+	StripPlan p = strip_plan<OUT>(d, has_label, label);
+	CKL_HIP(hipMemsetAsync(d.d_cursor.p, 0, ns * sizeof(uint32_t), s));
+	CKL_HIP(hipMemsetAsync(d.d_overflow.p, 0, sizeof(uint32_t), s));
+	if (flat) launch_flat_label_map(d);
+	st.done("k_label_map");
+	const uint32_t chunks = decode_chunks(d);
+	if (chunks <= 1) {
+		launch_cracks(d, s, ca, 0, ns, crack_lds);
+		st.done("k_decode_cracks");
+		launch_strips<OUT>(d, s, g, p, 0, ns, out_device, flat, flat, &st);
+	}
+	else {
+		// z-chunks on their own streams: the instruction-bound crack and strip kernels of one chunk
+		// run beside the bandwidth-bound paint of another
+		st.on = false;
+		if (!d.ev_fork) CKL_HIP(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
+		CKL_HIP(hipEventRecord(d.ev_fork, s));
+		const uint32_t per = (ns + chunks - 1) / chunks;
+		for (uint32_t c = 0; c < chunks; c++) {
+			const uint32_t z0 = c * per;
+			if (z0 >= ns) break;
+			const uint32_t n = std::min(per, ns - z0);
+			if (!d.chunk_stream[c]) CKL_HIP(hipStreamCreateWithFlags(&d.chunk_stream[c], hipStreamNonBlocking));
+			if (!d.chunk_done[c]) CKL_HIP(hipEventCreateWithFlags(&d.chunk_done[c], hipEventDisableTiming));
+			hipStream_t cs = d.chunk_stream[c];
+			CKL_HIP(hipStreamWaitEvent(cs, d.ev_fork, 0));
+			launch_cracks(d, cs, ca, z0, n, crack_lds);
+			launch_strips<OUT>(d, cs, g, p, z0, n, out_device, flat, flat, nullptr);
+			CKL_HIP(hipEventRecord(d.chunk_done[c], cs));
+			CKL_HIP(hipStreamWaitEvent(s, d.chunk_done[c], 0));
+		}
+	}
+	if (!flat) {
+		// pins: the label table needs the component ids of every slice a pin pierces
+		launch_pin_label_map(d, g, ra_legacy, &p.sa);
+		st.done("k_label_map_pins");
+		p.sa.zbase = 0;
+		hipLaunchKernelGGL(k_strip_labels<OUT>, dim3(ns), dim3(kResolveBlock), p.resolve_lds, s, p.sa, p.ra);
+		st.done("k_strip_labels");
+		hipLaunchKernelGGL(k_paint_strips<OUT>, dim3(d.nstrips * p.tiles_per_strip, ns), dim3(kBlock), 0, s,
+			g, p.sa, reinterpret_cast<const OUT*>(d.d_run_label.p), reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), p.tile_rows, p.tiles_per_strip, p.gpr_shift);
+		st.done("k_paint_strips");
+	}
+}
+
+// the general run pipeline (ckl_runs.hpp) from planes that are already in HBM
+void general_pipeline(ckl_decoder& d, const RunGeom& g, RunArrays& ra, void* out_device, int has_label, uint64_t label, const StatsArgs* stats, bool check_only, StageTimer& st) {
+	const Header& h = d.head;
+	hipStream_t s = d.stream;
+	const uint32_t ns = d.nslices;
+	d.d_word_base.ensure(d.plane_words * ns);
+	ra.word_base = d.d_word_base.p;
+	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kIndexBlock), 0, s, g, ra);
+	st.done("k_run_index");
+	{
+		// launch_run_union / launch_run_resolve of ckl_runs.hpp, kernel by kernel for the stage timers
+		const uint32_t rows = run_strip_rows(g.row_words);
+		const uint32_t strips = (g.sy + rows - 1) / rows;
+		const uint32_t sruns = run_strip_runs();
+		hipLaunchKernelGGL(k_run_union_strips, dim3(strips, ns), dim3(kBlock), sruns * sizeof(uint32_t), s, g, ra, rows, sruns);
+		st.done("k_run_union_strips");
+		if (strips > 1) {
+			const uint32_t words = (strips - 1) * g.row_words;
+			hipLaunchKernelGGL(k_run_union_seams, dim3((words + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, g, ra, rows);
+		}
+		st.done("k_run_union_seams");
+	}
+	if (stats || check_only) launch_resolve_and_stats(d, g, ra, st, stats);
+	else if (has_label || h.data_width == 1) launch_resolve_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
+	else if (h.data_width == 2) launch_resolve_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
+	else if (h.data_width == 4) launch_resolve_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
+	else launch_resolve_and_paint<uint64_t>(d, g, ra, out_device, has_label, label, st);
+
+	hipLaunchKernelGGL(k_check, dim3((ns + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+		d.d_crc_acc.p, d.d_crc_expect.p, d.d_ncomp.p, d.d_ncomp_expect.p,
+		d.check_crc ? 1u : 0u, d.crc_fix, ns, d.d_slice_err.p);
+	st.done("k_check");
+}
+
 void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label, const StatsArgs* stats = nullptr, bool planes_only = false, uint32_t* errs_out = nullptr) {
 	const Header& h = d.head;
 	if (d.sxy == 0 || d.nslices == 0) return;
@@ -2072,36 +2402,11 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.lds_words = static_cast<uint32_t>(crack_lds / 4);
 	ca.lds_raster = lds_raster ? 1u : 0u;
 	ca.markov_serial = getenv("CKL_MARKOV_SERIAL") ? 1u : 0u;
+	ca.zbase = 0;
 	ca.planeV = d.d_planes.p; ca.planeH = d.d_planes.p + d.plane_words * ns;
 	ca.row_words = d.row_words; ca.plane_words = d.plane_words;
 	ca.slice_err = d.d_slice_err.p;
-	if (getenv("CKL_DECODE_DIAG")) {
-		DevBuf<unsigned long long> d_diag;
-		d_diag.ensure(static_cast<size_t>(ns) * 16);
-		CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 128, s));
-		hipLaunchKernelGGL(k_decode_cracks<true>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, d_diag.p);
-		std::vector<unsigned long long> dg(static_cast<size_t>(ns) * 16);
-		CKL_HIP(hipMemcpyAsync(dg.data(), d_diag.p, dg.size() * 8, hipMemcpyDeviceToHost, s));
-		CKL_HIP(hipStreamSynchronize(s));
-		double m[16] = { 0 };
-		for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
-		fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f | match: depth/lastT=%.0f gmin=%.0f links=%.0f jump=%.0f search steps total=%.0f max/thread=%.0f | raster: zero=%.0f symbols=%.0f moves=%.0f store=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[6], m[7], m[15]);
-	}
-	else hipLaunchKernelGGL(k_decode_cracks<false>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, static_cast<unsigned long long*>(nullptr));
-	st.done("k_decode_cracks");
 
-	if (planes_only) {
-		// the crack planes are all the caller wants (ckl_reencode_markov): check what the parser flagged
-		d.n_stages = st.i;
-		std::vector<uint32_t> errs(ns);
-		CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-		CKL_HIP(hipStreamSynchronize(s));
-		CKL_HIP(hipGetLastError());
-		for (uint32_t zi = 0; zi < ns; zi++) {
-			if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle: crack code is malformed or corrupted on z=" + std::to_string(d.z_start + zi));
-		}
-		return;
-	}
 	RunGeom g;
 	g.planeV = ca.planeV; g.planeH = ca.planeH; g.row_words = d.row_words; g.plane_words = d.plane_words;
 	g.flip = (h.crack_format == IMPERMISSIBLE) ? 1u : 0u;
@@ -2111,43 +2416,73 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ra.parent = d.d_parent.p; ra.run_start = d.d_run_start.p; ra.run_cc = d.d_run_cc.p;
 	ra.nruns = d.d_nruns.p; ra.ncomp = d.d_ncomp.p; ra.slice_err = d.d_slice_err.p;
 
-	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kIndexBlock), 0, s, g, ra);
-	st.done("k_run_index");
-	{
-		// launch_run_union / launch_run_resolve of ckl_runs.hpp, kernel by kernel for the stage timers
-		const uint32_t rows = run_strip_rows(g.row_words);
-		const uint32_t strips = (g.sy + rows - 1) / rows;
-		const uint32_t sruns = run_strip_runs();
-		hipLaunchKernelGGL(k_run_union_strips, dim3(strips, ns), dim3(kBlock), sruns * sizeof(uint32_t), s, g, ra, rows, sruns);
-		st.done("k_run_union_strips");
-		if (strips > 1) {
-			const uint32_t words = (strips - 1) * g.row_words;
-			hipLaunchKernelGGL(k_run_union_seams, dim3((words + kBlock - 1) / kBlock, ns), dim3(kBlock), 0, s, g, ra, rows);
-		}
-		st.done("k_run_union_seams");
+	const bool paint = !stats && !planes_only && !errs_out;
+	const bool strips = paint && d.strip_ok && !d.use_general && !getenv("CKL_DECODE_DIAG");
+	if (strips) {
+		// planes -> strips -> labels, z-chunk by z-chunk (ckl_strips.hpp)
+		if (has_label || h.data_width == 1) strip_pipeline<uint8_t>(d, ca, crack_lds, g, ra, out_device, has_label, label, st);
+		else if (h.data_width == 2) strip_pipeline<uint16_t>(d, ca, crack_lds, g, ra, out_device, has_label, label, st);
+		else if (h.data_width == 4) strip_pipeline<uint32_t>(d, ca, crack_lds, g, ra, out_device, has_label, label, st);
+		else strip_pipeline<uint64_t>(d, ca, crack_lds, g, ra, out_device, has_label, label, st);
 	}
+	else {
+		if (getenv("CKL_DECODE_DIAG")) {
+			DevBuf<unsigned long long> d_diag;
+			d_diag.ensure(static_cast<size_t>(ns) * 16);
+			CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 128, s));
+			hipLaunchKernelGGL(k_decode_cracks<true>, dim3(ns), dim3(kCrackBlock), crack_lds, s, ca, d_diag.p);
+			std::vector<unsigned long long> dg(static_cast<size_t>(ns) * 16);
+			CKL_HIP(hipMemcpyAsync(dg.data(), d_diag.p, dg.size() * 8, hipMemcpyDeviceToHost, s));
+			CKL_HIP(hipStreamSynchronize(s));
+			double m[16] = { 0 };
+			for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
+			fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols)=%.0f C(match)=%.0f D(raster)=%.0f  codes=%.0f controls=%.0f | match: depth/lastT=%.0f gmin=%.0f links=%.0f jump=%.0f search steps total=%.0f max/thread=%.0f | raster: zero=%.0f symbols=%.0f moves=%.0f store=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[6], m[7], m[15]);
+		}
+		else launch_cracks(d, s, ca, 0, ns, crack_lds);
+		st.done("k_decode_cracks");
 
-	if (stats || errs_out) launch_resolve_and_stats(d, g, ra, st, stats);
-	else if (has_label || h.data_width == 1) launch_resolve_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
-	else if (h.data_width == 2) launch_resolve_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
-	else if (h.data_width == 4) launch_resolve_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
-	else launch_resolve_and_paint<uint64_t>(d, g, ra, out_device, has_label, label, st);
-
-	hipLaunchKernelGGL(k_check, dim3((ns + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-		d.d_crc_acc.p, d.d_crc_expect.p, d.d_ncomp.p, d.d_ncomp_expect.p,
-		d.check_crc ? 1u : 0u, d.crc_fix, ns, d.d_slice_err.p);
-	st.done("k_check");
+		if (planes_only) {
+			// the crack planes are all the caller wants (ckl_reencode_markov): check what the parser flagged
+			d.n_stages = st.i;
+			std::vector<uint32_t> errs(ns);
+			CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+			CKL_HIP(hipStreamSynchronize(s));
+			CKL_HIP(hipGetLastError());
+			for (uint32_t zi = 0; zi < ns; zi++) {
+				if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle: crack code is malformed or corrupted on z=" + std::to_string(d.z_start + zi));
+			}
+			return;
+		}
+		general_pipeline(d, g, ra, out_device, has_label, label, stats, errs_out != nullptr, st);
+	}
 	d.n_stages = st.i;
+	CKL_HIP(hipEventRecord(d.ev[kMaxStages + 1], s));      // end of the pipeline (all chunk streams joined)
 
 	auto h1 = std::chrono::steady_clock::now();
 	std::vector<uint32_t> errs(ns);
+	uint32_t overflow = 0;
 	CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	if (strips) CKL_HIP(hipMemcpyAsync(&overflow, d.d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	CKL_HIP(hipStreamSynchronize(s));
+	CKL_HIP(hipGetLastError());
+	if (strips && overflow) {
+		// a strip or a slice has more runs / strip components than the LDS tables of the strip path
+		// hold (dense, noisy labels): the general pipeline takes over from the planes, for this and
+		// all later runs of the session
+		d.use_general = true;
+		StageTimer st2(d, s);
+		st2.on = st.on;
+		general_pipeline(d, g, ra, out_device, has_label, label, nullptr, false, st2);
+		d.n_stages = st2.i;
+		CKL_HIP(hipEventRecord(d.ev[kMaxStages + 1], s));
+		CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		CKL_HIP(hipStreamSynchronize(s));
+		CKL_HIP(hipGetLastError());
+	}
 	auto h2 = std::chrono::steady_clock::now();
 	if (prof) fprintf(stderr, "[ckl decode host ms] enqueue=%.2f wait=%.2f\n",
 		std::chrono::duration<double, std::milli>(h1 - h0).count(), std::chrono::duration<double, std::milli>(h2 - h1).count());
-	CKL_HIP(hipGetLastError());
-	CKL_HIP(hipEventElapsedTime(&d.pipeline_ms, d.ev[0], d.ev[d.n_stages]));
+	CKL_HIP(hipEventElapsedTime(&d.pipeline_ms, d.ev[0], d.ev[kMaxStages + 1]));
 	for (int i = 0; i < d.n_stages; i++) CKL_HIP(hipEventElapsedTime(&d.stage_ms[i], d.ev[i], d.ev[i + 1]));
 	if (errs_out) {      // the caller wants the per-slice verdicts, not an exception
 		for (uint32_t zi = 0; zi < ns; zi++) errs_out[zi] = errs[zi];
@@ -2280,6 +2615,7 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 			const int bytes = static_cast<int>(d->lds_bytes);
 			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+			set_strip_attributes<uint8_t>(); set_strip_attributes<uint16_t>(); set_strip_attributes<uint32_t>(); set_strip_attributes<uint64_t>();
 		}
 		decoder_build(*d, buf, n, z_start, z_end);
 		*out = d.release();

@@ -5,7 +5,8 @@ into oracle/_ref by `make -C oracle ref`).  Runs only in the build container, wh
   tests/golden/golden.npz      exact .ckl bytes for every small case
   tests/golden/manifest.json   sha256/length/section hashes for larger generated cases
 
-usage: python tests/gen_golden.py
+usage: python tests/gen_golden.py [--xl]
+  --xl  writes tests/golden/manifest_xl.json (full-size BASELINE.json configurations)
 """
 import hashlib
 import json
@@ -42,9 +43,33 @@ def sections(binary: bytes):
   return out
 
 
+def manifest_entry(arr, b):
+  return {
+    "length": len(b),
+    "sha256": hashlib.sha256(b).hexdigest(),
+    "input_sha256": hashlib.sha256(np.asfortranarray(arr).tobytes(order="F")).hexdigest(),
+    "sections": {k: hashlib.sha256(v).hexdigest() for k, v in sections(b).items()},
+  }
+
+
+def main_xl(ref):
+  """Full-size BASELINE.json configurations (minutes of CPU time, gigabytes of memory)."""
+  manifest = {}
+  for name, (thunk, kw) in golden_cases.xl_cases().items():
+    arr = thunk()
+    b = ref.compress(arr, parallel=8, **kw)
+    manifest[name] = manifest_entry(arr, b)
+    print(name, len(b), manifest[name]["sha256"], flush=True)
+    del arr, b
+  with open(os.path.join(HERE, "golden", "manifest_xl.json"), "w") as f:
+    json.dump(manifest, f, indent=1, sort_keys=True)
+
+
 def main():
   ref = oracle.ref()
   assert ref is not None, "build oracle/_ref first (make -C oracle ref)"
+  if "--xl" in sys.argv:
+    return main_xl(ref)
   blobs = {}
   for name, (arr, kw) in golden_cases.small_cases().items():
     blobs[name] = np.frombuffer(ref.compress(arr, parallel=2, **kw), dtype=np.uint8)
@@ -53,12 +78,7 @@ def main():
   for name, (thunk, kw) in golden_cases.large_cases().items():
     arr = thunk()
     b = ref.compress(arr, parallel=4, **kw)
-    manifest[name] = {
-      "length": len(b),
-      "sha256": hashlib.sha256(b).hexdigest(),
-      "input_sha256": hashlib.sha256(np.asfortranarray(arr).tobytes(order="F")).hexdigest(),
-      "sections": {k: hashlib.sha256(v).hexdigest() for k, v in sections(b).items()},
-    }
+    manifest[name] = manifest_entry(arr, b)
   with open(os.path.join(HERE, "golden", "manifest.json"), "w") as f:
     json.dump(manifest, f, indent=1, sort_keys=True)
   print("small:", len(blobs), "cases,", sum(v.size for v in blobs.values()), "bytes; large:", len(manifest))

@@ -170,3 +170,24 @@ def large_cases():
     v[1].setdefault("allow_pins", False)
     v[1].setdefault("markov_model_order", 0)
   return cases
+
+
+def xl_cases():
+  """BASELINE.json configurations at (or near) their full per-GPU size; expected = sha256
+  manifest written by `python tests/gen_golden.py --xl` (tests/golden/manifest_xl.json).
+  name -> (generator thunk, kwargs, slab description used by bench.py / the GPU tests)"""
+  def vor(shape, dt, seed, **kw):
+    return lambda: synth.as_numpy_f(synth.voronoi_labels(shape, dt, seed=seed, cell=(32, 32, 8), **kw))
+  cases = {
+    # C2: the bench workload itself (bench.py asserts this sha on its own output)
+    "c2_1024x1024x512_u32": (vor((1024, 1024, 512), np.uint32, 2), dict()),
+    # C3: one 16-slice slab of the uint64 volume (stored width 8)
+    "c3_1024x1024x16_u64": (vor((1024, 1024, 16), np.uint64, 2, offset=1 << 40), dict()),
+    # C4: 2048-wide slices, pins + markov order 5
+    "c4_2048x2048x8_u32_pins_m5": (vor((2048, 2048, 8), np.uint32, 2), dict(allow_pins=True, markov_model_order=5)),
+    "c4_2048x2048x8_u32_m5": (vor((2048, 2048, 8), np.uint32, 2), dict(markov_model_order=5)),
+  }
+  for v in cases.values():
+    v[1].setdefault("allow_pins", False)
+    v[1].setdefault("markov_model_order", 0)
+  return cases
