@@ -1374,6 +1374,7 @@ static __global__ void k_stats_init(uint32_t* box, uint32_t n_table) {
 // ------------------------------------------------------------------------------
 constexpr uint32_t kPaintTile = 4096;          // pixels per workgroup
 constexpr uint32_t kPaintStage = 3072;         // run labels staged in LDS per workgroup
+constexpr uint32_t kPaintTable = 512;          // strip path: labels of a strip's components fetched ahead of knowing how many there are
 
 template <typename OUT> struct Vec4;
 template <> struct Vec4<uint8_t> { typedef uchar4 type; };
@@ -1527,7 +1528,7 @@ __global__ void __launch_bounds__(kBlock) k_paint_runs(
 }
 
 // the groups of 4 pixels of one tile: labels from the staged table (STAGED) or straight from HBM
-template <typename OUT, bool STAGED>
+template <typename OUT, bool STAGED, uint32_t U = 4>
 __device__ __forceinline__ void paint_tile_groups(
 	const OUT* s_lab, const OUT* __restrict__ lab, const uint32_t* s_b, const uint16_t* s_wb, OUT* __restrict__ oz,
 	uint32_t ngroups, uint32_t gpr, uint32_t gpr_shift, uint32_t rw, uint32_t sx, uint32_t lo, uint32_t cap
@@ -1535,11 +1536,11 @@ __device__ __forceinline__ void paint_tile_groups(
 	typedef typename Vec4<OUT>::type V4;
 	const uint32_t t = threadIdx.x;
 	const uint32_t last = cap - 1u;
-	for (uint32_t g0 = 0; g0 < ngroups; g0 += kBlock * 4u) {
-		V4 val[4];
-		uint32_t at[4];
+	for (uint32_t g0 = 0; g0 < ngroups; g0 += kBlock * U) {
+		V4 val[U];
+		uint32_t at[U];
 #pragma unroll
-		for (uint32_t u = 0; u < 4; u++) {
+		for (uint32_t u = 0; u < U; u++) {
 			const uint32_t gi = g0 + u * kBlock + t;
 			at[u] = 0xFFFFFFFFu;
 			if (gi >= ngroups) continue;
@@ -1565,46 +1566,86 @@ __device__ __forceinline__ void paint_tile_groups(
 			}
 		}
 #pragma unroll
-		for (uint32_t u = 0; u < 4; u++) if (at[u] != 0xFFFFFFFFu) store_stream(oz + at[u], val[u]);
+		for (uint32_t u = 0; u < U; u++) if (at[u] != 0xFFFFFFFFu) store_stream(oz + at[u], val[u]);
 	}
 }
 
-// The strip path's paint (ckl_strips.hpp): a tile is a few whole rows of one strip.  Its plane
-// words and the run prefix over them are built in LDS, the tile's run labels (one contiguous
-// stretch of run_label, starting at row_run[first row]) are staged next to them, then every
-// thread paints groups of 4 pixels with 16-byte streaming stores.  sx % 4 == 0, x fastest.
-// grid = (nstrips * tiles_per_strip, slices of the launch)
-template <typename OUT>
+// The strip path's paint (ckl_strips.hpp): one workgroup per strip.  The strip's plane words and
+// the run prefix over them are built in LDS, the label of every run of the strip is staged next
+// to them (run -> strip component -> label: two small dependent loads per run, issued for all
+// runs at once and never inside a branch), then every thread paints pairs of adjacent 4-pixel
+// groups with plain 16-byte stores.  sx % 4 == 0, x fastest.  grid = (nstrips, slices of the launch)
+// What was measured at C2 (0.41 ms for the general pipeline's k_paint_runs):
+//  * store pattern (tools/micro/store_bw.hip, 2 GiB): one 128 KiB chunk per workgroup 5.9 TB/s,
+//    112 KiB 5.5, 16 KiB chunks 6.0 - 6.5, a grid-stride loop 4.5; non-temporal stores cost 3 - 10 %;
+//  * one workgroup per 16 KiB tile of a strip (three dependent loads in front of two store sweeps):
+//    0.64 ms, the prologue is not amortised;
+//  * a persistent workgroup that loads two strips ahead of its stores: 0.50 ms (hipcc can only wait
+//    for the prefetched words with vmcnt(0), i.e. for all of the workgroup's stores).
+template <typename OUT, bool DIAG>
 __global__ void __launch_bounds__(kBlock) k_paint_strips(
-	RunGeom g, StripArrays sa, const OUT* __restrict__ run_label, OUT* __restrict__ out,
-	uint32_t sxy, uint32_t tile_rows, uint32_t tiles_per_strip, uint32_t gpr_shift
+	RunGeom g, StripArrays sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag
 ) {
-	__shared__ OUT s_lab[kPaintStage];
+	typedef typename Vec4<OUT>::type V4;
+	__shared__ OUT s_lab[kStripCap];
+	__shared__ OUT s_tab[kPaintTable];      // labels of the strip's first components
 	__shared__ uint32_t s_b[kStripWords];
 	__shared__ uint16_t s_wb[kStripWords];
 	__shared__ uint32_t s_scan[kWaves];
+	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+	auto stamp = [&](int slot) {
+		if (DIAG && threadIdx.x == 0) {
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			atomicAdd(diag + slot, now - d_t);
+			d_t = now;
+		}
+	};
 	const uint32_t zi = blockIdx.y + sa.zbase;
-	const uint32_t k = blockIdx.x / tiles_per_strip, tt = blockIdx.x - k * tiles_per_strip;
-	const uint32_t y1s = min((k + 1u) * sa.strip_rows, g.sy);
-	const uint32_t ya = k * sa.strip_rows + tt * tile_rows;
-	if (ya >= y1s) return;
-	const uint32_t yb = min(ya + tile_rows, y1s);
+	const uint32_t k = blockIdx.x;
+	const uint32_t si = zi * sa.nstrips + k;
+	const uint32_t y0 = k * sa.strip_rows;
+	const uint32_t y1 = min(y0 + sa.strip_rows, g.sy);
 	const uint32_t rw = g.row_words, sx = g.sx;
-	const uint32_t nw = (yb - ya) * rw;
+	const uint32_t nw = (y1 - y0) * rw;
 	const uint32_t t = threadIdx.x;
-	const uint32_t lo = sa.row_run[static_cast<uint64_t>(zi) * g.sy + ya];
-	uint32_t b[4], cnt = 0;
+	const uint64_t slot = (sa.ablate & 0x2000u) ? 0ull : static_cast<uint64_t>(si) * sa.cap;
+	// ONE trip to memory in front of the stores: plane words, strip component of every run and the
+	// first kPaintTable labels of the strip's components are all requested at once, none inside a
+	// branch (a load inside a branch is waited for there): words past the strip read word 0, runs
+	// past the slot its last entry.  How many runs the strip has is only known after the scan; what
+	// lies behind the last run is not used.  (With the labels fetched through the components in a
+	// second, dependent trip the kernel took 0.42 instead of 0.35 ms at C2.)
+	uint32_t b[4], lid[kStripRunsPerThread];
+	const OUT* lab = static_cast<const OUT*>(sa.sc_label) + slot;
+	OUT tab[kPaintTable / kBlock];
 	{
-		uint32_t yy = (t * 4u) / rw, ww = t * 4u - yy * rw;
+		const uint32_t* pv = (sa.ablate & 0x6000u) ? g.planeV : g.planeV + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) { const uint32_t wl = t * 4u + j; b[j] = pv[wl < nw ? wl : 0u]; }
+		const uint16_t* lp = sa.run_lid + ((sa.ablate & 0x8000u) ? 0ull : slot);
+#pragma unroll
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) { const uint32_t j = t + i * kBlock; lid[i] = lp[j < sa.cap ? j : sa.cap - 1u]; }
+#pragma unroll
+		for (uint32_t i = 0; i < kPaintTable / kBlock; i++) { const uint32_t j = t + i * kBlock; tab[i] = lab[j < sa.cap ? j : sa.cap - 1u]; }
+	}
+	const uint32_t nsc = (sa.ablate & 0x2000u) ? 1u : sa.strip_nsc[si];
+	uint32_t cnt = 0;
+	{
+		const uint32_t yy = (t * 4u) / rw;
+		uint32_t ww = t * 4u - yy * rw;
 #pragma unroll
 		for (uint32_t j = 0; j < 4; j++) {
-			b[j] = t * 4u + j < nw ? g.breaks(zi, ya + yy, ww) : 0u;
+			b[j] = t * 4u + j < nw ? g.breaks_of(b[j], ww) : 0u;
 			cnt += __popc(b[j]);
-			if (++ww == rw) { ww = 0; yy++; }
+			if (++ww == rw) ww = 0;
 		}
 	}
+#pragma unroll
+	for (uint32_t i = 0; i < kPaintTable / kBlock; i++) s_tab[t + i * kBlock] = tab[i];
 	uint32_t v[1] = { cnt }, tot[1];
-	block_excl_add<1>(v, tot, s_scan);
+	block_excl_add<1>(v, tot, s_scan);      // its barriers also publish s_tab
+	const uint32_t nloc = tot[0];
+	if (nloc > sa.cap) return;      // uniform; flagged by k_strip_ccl, the general pipeline repaints
 	{
 		uint32_t local = v[0];
 #pragma unroll
@@ -1614,19 +1655,64 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 			local += __popc(b[j]);
 		}
 	}
-	const uint32_t n_runs = tot[0];
-	const uint32_t cap = sa.rcap[zi];
-	const OUT* lab = run_label + sa.rbase[zi];
-	const bool staged = n_runs <= kPaintStage;
-	if (staged) {
-		for (uint32_t i = t; i < n_runs; i += kBlock) { const uint32_t at = lo + i; s_lab[i] = lab[at < cap ? at : cap - 1u]; }
+	stamp(0);
+	// the labels of my runs through their strip components
+	if (nsc <= kPaintTable) {      // uniform
+#pragma unroll
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
+			const uint32_t j = t + i * kBlock;
+			if (j < nloc) s_lab[j] = s_tab[lid[i] < kPaintTable ? lid[i] : 0u];
+		}
+	}
+	else {      // more strip components than the table holds: through memory
+		OUT lv[kStripRunsPerThread];
+#pragma unroll
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) lv[i] = lab[lid[i] < sa.cap ? lid[i] : 0u];
+#pragma unroll
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
+			const uint32_t j = t + i * kBlock;
+			if (j < nloc) s_lab[j] = lv[i];
+		}
 	}
 	__syncthreads();
-	const uint32_t gpr = sx >> 2;      // groups of 4 pixels per row
-	const uint32_t ngroups = (yb - ya) * gpr;
-	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(ya) * sx;
-	if (staged) paint_tile_groups<OUT, true>(s_lab, lab, s_b, s_wb, oz, ngroups, gpr, gpr_shift, rw, sx, lo, cap);
-	else paint_tile_groups<OUT, false>(s_lab, lab, s_b, s_wb, oz, ngroups, gpr, gpr_shift, rw, sx, lo, cap);
+	stamp(1);
+	// groups of 4 pixels
+	const uint32_t ngroups = ((y1 - y0) * sx) >> 2;
+	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(y0) * sx;
+	const bool nt = (sa.ablate & 0x800u) != 0, adjacent = (sa.ablate & 0x1000u) != 0;
+	constexpr uint32_t U = 4;
+	for (uint32_t g0 = 0; g0 < ngroups; g0 += kBlock * U) {
+		V4 val[U];
+		uint32_t at[U];
+#pragma unroll
+		for (uint32_t u = 0; u < U; u++) {
+			const uint32_t gi = adjacent ? g0 + t * U + u : g0 + u * kBlock + t;
+			at[u] = 0xFFFFFFFFu;
+			if (gi >= ngroups) continue;
+			const uint32_t p = gi << 2;
+			const uint32_t row = p / sx;
+			const uint32_t x = p - row * sx;
+			const uint32_t wl = row * rw + (x >> 5);
+			const uint32_t bw = s_b[wl], sh = x & 31u;
+			uint32_t run = s_wb[wl] + __popc(bw & mask_le(sh)) - 1u;
+			const uint32_t nib = ((bw >> sh) >> 1) & 7u;
+			at[u] = p;
+			if (sa.ablate & 0x400u) { val[u].x = val[u].y = val[u].z = val[u].w = static_cast<OUT>(run); continue; }
+			val[u].x = s_lab[run];
+			run += nib & 1u;        val[u].y = s_lab[run];
+			run += (nib >> 1) & 1u; val[u].z = s_lab[run];
+			run += (nib >> 2) & 1u; val[u].w = s_lab[run];
+		}
+		if (nt) {
+#pragma unroll
+			for (uint32_t u = 0; u < U; u++) if (at[u] != 0xFFFFFFFFu) store_stream(oz + at[u], val[u]);
+		}
+		else {
+#pragma unroll
+			for (uint32_t u = 0; u < U; u++) if (at[u] != 0xFFFFFFFFu) *reinterpret_cast<V4*>(oz + at[u]) = val[u];
+		}
+	}
+	stamp(2);
 }
 
 // condensed pins on the strip path (labels.hpp:600-614): one thread per (pin, slice) pair
@@ -1729,6 +1815,7 @@ constexpr int kMaxStages = 20;
 
 struct ckl_decoder {
 	int device = 0;
+	int n_cus = 256;
 	hipStream_t stream = nullptr;
 	// stage boundaries: ev[i] .. ev[i+1] brackets stage i of the last run
 	hipEvent_t ev[kMaxStages + 2] = {};      // [kMaxStages + 1]: end of the pipeline
@@ -1769,13 +1856,15 @@ struct ckl_decoder {
 	DevBuf<uint32_t> d_G, d_crc_acc, d_crc_expect, d_slice_err;
 	DevBuf<uint64_t> d_label_map;
 	DevBuf<uint64_t> d_pin_index, d_pin_depth, d_pin_label, d_pin_work_off, d_ccl_id, d_ccl_label;
-	// strip path (ckl_strips.hpp); its per-run arrays reuse d_run_local (run_lid), d_parent (sc_w),
-	// d_run_cc (sc_cc) and d_run_label of the general pipeline
-	DevBuf<uint32_t> d_cursor, d_row_run, d_strip_base, d_strip_nruns, d_strip_nsc, d_overflow;
-	DevBuf<uint16_t> d_seam_first, d_seam_last;
+	// strip path (ckl_strips.hpp): one slot of strip_cap entries per strip
+	DevBuf<uint32_t> d_strip_nruns, d_strip_nsc, d_overflow, d_sc_w, d_sc_cc;
+	DevBuf<uint16_t> d_seam_first, d_seam_last, d_row_run, d_run_lid;
+	DevBuf<uint64_t> d_sc_label;        // typed on use
+	DevBuf<unsigned long long> d_diag;
 	bool strip_ok = false;              // shape / layout qualify for the strip path
 	bool use_general = false;           // a run overflowed the strip path's LDS tables: stay on the general pipeline
-	uint32_t strip_rows = 0, nstrips = 0;
+	uint32_t strip_rows = 0, nstrips = 0, strip_cap = 0;
+	uint64_t rtot = 0;                  // entries of the general pipeline's per-run arrays (allocated when it runs)
 	static constexpr int kMaxChunks = 8;
 	hipStream_t chunk_stream[kMaxChunks] = {};
 	hipEvent_t chunk_done[kMaxChunks] = {};
@@ -1867,6 +1956,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	std::vector<uint64_t> code_off(d.nslices), cbase(d.nslices), nbase(d.nslices), rbase(d.nslices);
 	std::vector<uint32_t> code_len(d.nslices), ccap(d.nslices), ncap(d.nslices), rcap(d.nslices);
 	uint64_t ctot = 0, ntot = 0, rtot = 0;
+	double est_codes = 0;      // markov: ~1.4 bits per code on typical streams
 	d.max_rcap = 0;
 	for (uint32_t zi = 0; zi < d.nslices; zi++) {
 		const uint64_t z = static_cast<uint64_t>(zs) + zi;
@@ -1882,6 +1972,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		// runs: one per row plus one per vertical crack move (IMPERMISSIBLE), else up to one per pixel
 		const uint64_t runs_cap = permissible ? d.sxy : std::min<uint64_t>(d.sxy, static_cast<uint64_t>(h.sy) + cap);
 		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cap); ctot += cap;
+		est_codes += h.markov_model_order ? payload * 8 / 1.4 : payload * 4.0;
 		nbase[zi] = ntot; ncap[zi] = static_cast<uint32_t>(nodes_cap); ntot += nodes_cap;
 		rbase[zi] = rtot; rcap[zi] = static_cast<uint32_t>(runs_cap); rtot += runs_cap;
 		d.max_rcap = std::max<uint32_t>(d.max_rcap, static_cast<uint32_t>(runs_cap));
@@ -1923,12 +2014,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		d.d_seg_x.ensure(ktot); d.d_seg_y.ensure(ktot); d.d_ctl_gmin.ensure(ktot);
 	}
 	d.d_nodes.ensure(ntot);
-	d.d_parent.ensure(rtot);
-	d.d_run_start.ensure(rtot);
-	d.d_run_cc.ensure(rtot);
-	d.d_run_local.ensure(rtot);
-	d.d_blk_roots.ensure(static_cast<size_t>((d.max_rcap + kBlock - 1) / kBlock) * d.nslices);
-	d.d_run_label.ensure(rtot);
+	d.rtot = rtot;      // the general pipeline's per-run arrays are allocated when it runs
 
 	if (h.markov_model_order) {
 		std::vector<uint8_t> model = markov_model_from_stored(buf + hb + gib + h.num_label_bytes, h.markov_model_bytes(), h.markov_model_order);
@@ -1940,21 +2026,31 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	d.d_planes.ensure(2 * d.plane_words * d.nslices);
 	{
 		// strip path: x-fastest output in groups of 4 pixels, strips of <= 1024 plane words
+		// strips of <= 1024 plane words, and few enough rows that the runs expected from the length of
+		// the crack codes (one per row plus one per vertical move, about half of the moves) fill ~0.7
+		// of the strip kernels' LDS tables; a strip that still overflows falls back (ckl_strips.hpp)
 		d.strip_rows = std::max<uint32_t>(1u, kStripWords / d.row_words);
+		if (!permissible && d.nslices) {
+			const double runs_per_row = 1.0 + 0.5 * est_codes / (static_cast<double>(d.nslices) * h.sy);
+			const uint32_t fit = static_cast<uint32_t>(0.7 * kStripCap / runs_per_row);
+			d.strip_rows = std::max<uint32_t>(1u, std::min(d.strip_rows, fit));
+		}
+		if (const char* env = getenv("CKL_CCL_ROWS")) d.strip_rows = std::max<uint32_t>(1u, std::min<uint32_t>(kStripWords / d.row_words, static_cast<uint32_t>(std::max(1, atoi(env)))));
 		d.nstrips = (h.sy + d.strip_rows - 1) / d.strip_rows;
 		d.strip_ok = h.fortran_order && (h.sx % 4 == 0) && d.row_words <= kStripWords && d.nstrips <= kMaxStrips &&
 			d.sxy < 0xFFFF0000ull && !getenv("CKL_DECODE_GENERAL");
 		if (d.strip_ok) {
 			const size_t nst = static_cast<size_t>(d.nstrips) * d.nslices;
-			d.d_cursor.ensure(d.nslices);
+			d.strip_cap = static_cast<uint32_t>(std::min<uint64_t>(kStripCap, static_cast<uint64_t>(d.strip_rows) * h.sx));
 			d.d_row_run.ensure(static_cast<size_t>(h.sy) * d.nslices);
-			d.d_strip_base.ensure(nst); d.d_strip_nruns.ensure(nst); d.d_strip_nsc.ensure(nst);
+			d.d_strip_nruns.ensure(nst); d.d_strip_nsc.ensure(nst);
 			d.d_seam_first.ensure(nst * d.row_words); d.d_seam_last.ensure(nst * d.row_words);
+			d.d_run_lid.ensure(nst * d.strip_cap); d.d_sc_w.ensure(nst * d.strip_cap);
+			d.d_sc_label.ensure(nst * d.strip_cap);
+			if (h.label_format != FLAT) d.d_sc_cc.ensure(nst * d.strip_cap);
 			d.d_overflow.ensure(1);
 		}
-		else d.d_word_base.ensure(d.plane_words * d.nslices);
 	}
-	d.d_nruns.ensure(d.nslices);
 	d.d_ncomp.ensure(d.nslices);
 	d.d_slice_err.ensure(d.nslices);
 	d.d_crc_acc.ensure(d.nslices);
@@ -2207,43 +2303,25 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 struct StripPlan {
 	StripArrays sa;
 	ResolveArgs ra;
-	uint32_t tile_rows, tiles_per_strip, gpr_shift;
-	size_t resolve_lds;
 };
 
-template <typename OUT>
 StripPlan strip_plan(ckl_decoder& d, int has_label, uint64_t label) {
-	const Header& h = d.head;
 	StripPlan p;
 	StripArrays& sa = p.sa;
-	sa.rbase = d.d_rbase.p; sa.rcap = d.d_rcap.p; sa.cursor = d.d_cursor.p;
-	sa.run_lid = d.d_run_local.p; sa.row_run = d.d_row_run.p;
-	sa.strip_base = d.d_strip_base.p; sa.strip_nruns = d.d_strip_nruns.p; sa.strip_nsc = d.d_strip_nsc.p;
+	sa.run_lid = d.d_run_lid.p; sa.sc_w = d.d_sc_w.p; sa.sc_cc = d.d_sc_cc.p; sa.sc_label = d.d_sc_label.p;
+	sa.strip_nruns = d.d_strip_nruns.p; sa.strip_nsc = d.d_strip_nsc.p; sa.row_run = d.d_row_run.p;
 	sa.seam_first = d.d_seam_first.p; sa.seam_last = d.d_seam_last.p;
-	sa.sc_w = d.d_parent.p; sa.sc_cc = d.d_run_cc.p;
 	sa.slice_err = d.d_slice_err.p; sa.overflow = d.d_overflow.p;
-	sa.nstrips = d.nstrips; sa.strip_rows = d.strip_rows; sa.zbase = 0;
+	sa.nstrips = d.nstrips; sa.strip_rows = d.strip_rows; sa.cap = d.strip_cap; sa.zbase = 0;
+	sa.ablate = 0;
+	if (const char* env = getenv("CKL_ABLATE")) sa.ablate = static_cast<uint32_t>(strtoul(env, nullptr, 0));
 	ResolveArgs& ra = p.ra;
 	ra.idbits = d.idbits; ra.crc_fix = d.crc_fix; ra.check_crc = d.check_crc ? 1u : 0u;
 	ra.crc_expect = d.d_crc_expect.p; ra.ncomp_expect = d.d_ncomp_expect.p; ra.comp_off = d.d_comp_off.p;
 	ra.label_map = d.d_label_map.p; ra.has_label = has_label ? 1u : 0u; ra.label = label;
-	ra.run_label = d.d_run_label.p;
 	ra.cap = kResolveCap;
 	if (const char* env = getenv("CKL_RESOLVE_CAP")) ra.cap = std::min<uint32_t>(kResolveCap, static_cast<uint32_t>(std::max(1, atoi(env))));   // testing: forces the overflow path
-	p.resolve_lds = static_cast<size_t>(kResolveCap) * std::max<size_t>(4, sizeof(OUT));
-	p.tile_rows = std::min<uint32_t>(d.strip_rows, std::max<uint32_t>(1u, kPaintTile / h.sx));
-	p.tiles_per_strip = (d.strip_rows + p.tile_rows - 1) / p.tile_rows;
-	const uint32_t gpr = h.sx / 4;
-	p.gpr_shift = (gpr & (gpr - 1)) == 0 ? static_cast<uint32_t>(__builtin_ctz(gpr)) : 0xFFFFFFFFu;
 	return p;
-}
-
-template <typename OUT>
-void set_strip_attributes() {
-	const int bytes = static_cast<int>(static_cast<size_t>(kResolveCap) * std::max<size_t>(4, sizeof(OUT)));
-	CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slice_resolve<OUT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-	CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slice_resolve<OUT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-	CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_labels<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
 
 void launch_cracks(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t z0, uint32_t n, size_t crack_lds) {
@@ -2251,24 +2329,35 @@ void launch_cracks(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t z0, uin
 	hipLaunchKernelGGL(k_decode_cracks<false>, dim3(n), dim3(kCrackBlock), crack_lds, s, ca, static_cast<unsigned long long*>(nullptr));
 }
 
+template <typename OUT>
+void launch_paint_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, const StripPlan& p, uint32_t n, void* out_device, unsigned long long* diag) {
+	const dim3 grid(d.nstrips, n);
+	if (diag) hipLaunchKernelGGL((k_paint_strips<OUT, true>), grid, dim3(kBlock), 0, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), diag + 16);
+	else hipLaunchKernelGGL((k_paint_strips<OUT, false>), grid, dim3(kBlock), 0, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), diag);
+}
+
 // strips + resolve of slices [z0, z0 + n); flat labels also paint
 template <typename OUT>
-void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p, uint32_t z0, uint32_t n, void* out_device, bool flat, bool paint, StageTimer* st) {
+void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p, uint32_t z0, uint32_t n, void* out_device, bool flat, StageTimer* st, unsigned long long* diag) {
 	p.sa.zbase = z0;
-	hipLaunchKernelGGL(k_strip_ccl, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.d_G.p, static_cast<uint32_t>(d.sxy));
+	const uint32_t npx = static_cast<uint32_t>(d.sxy);
+	if (diag) hipLaunchKernelGGL(k_strip_ccl<true>, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.d_G.p, npx, diag);
+	else hipLaunchKernelGGL(k_strip_ccl<false>, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.d_G.p, npx, diag);
 	if (st) st->done("k_strip_ccl");
-	if (flat) hipLaunchKernelGGL((k_slice_resolve<OUT, true>), dim3(n), dim3(kResolveBlock), p.resolve_lds, s, g, p.sa, p.ra, d.d_ncomp.p);
-	else hipLaunchKernelGGL((k_slice_resolve<OUT, false>), dim3(n), dim3(kResolveBlock), p.resolve_lds, s, g, p.sa, p.ra, d.d_ncomp.p);
+	if (flat) {
+		if (diag) hipLaunchKernelGGL((k_slice_resolve<OUT, true, true>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, diag + 8);
+		else hipLaunchKernelGGL((k_slice_resolve<OUT, true, false>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, diag);
+	}
+	else hipLaunchKernelGGL((k_slice_resolve<OUT, false, false>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, static_cast<unsigned long long*>(nullptr));
 	if (st) st->done("k_slice_resolve");
-	if (!paint) return;
-	hipLaunchKernelGGL(k_paint_strips<OUT>, dim3(d.nstrips * p.tiles_per_strip, n), dim3(kBlock), 0, s,
-		g, p.sa, reinterpret_cast<const OUT*>(d.d_run_label.p), reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), p.tile_rows, p.tiles_per_strip, p.gpr_shift);
+	if (!flat) return;
+	launch_paint_strips<OUT>(d, s, g, p, n, out_device, diag);
 	if (st) st->done("k_paint_strips");
 }
 
 // number of z-chunks the strip path pipelines over its streams
 uint32_t decode_chunks(const ckl_decoder& d) {
-	uint32_t want = 4;
+	uint32_t want = 1;      // measured at C2: 4 chunks on 4 streams 1.39 ms against 1.22 ms on one stream
 	if (const char* env = getenv("CKL_DECODE_CHUNKS")) want = static_cast<uint32_t>(std::max(1, atoi(env)));
 	want = std::min<uint32_t>(want, ckl_decoder::kMaxChunks);
 	// a chunk should still fill the chip: at least 64 Mi voxels and 64 slices each
@@ -2284,16 +2373,29 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 	const bool flat = h.label_format == FLAT;
-	StripPlan p = strip_plan<OUT>(d, has_label, label);
-	CKL_HIP(hipMemsetAsync(d.d_cursor.p, 0, ns * sizeof(uint32_t), s));
+	StripPlan p = strip_plan(d, has_label, label);
 	CKL_HIP(hipMemsetAsync(d.d_overflow.p, 0, sizeof(uint32_t), s));
 	if (flat) launch_flat_label_map(d);
 	st.done("k_label_map");
 	const uint32_t chunks = decode_chunks(d);
-	if (chunks <= 1) {
+	unsigned long long* diag = nullptr;
+	if (getenv("CKL_STRIP_DIAG")) {      // cycle stamps of the strip kernels (adds a sync and a print)
+		d.d_diag.ensure(32);
+		CKL_HIP(hipMemsetAsync(d.d_diag.p, 0, 32 * sizeof(unsigned long long), s));
+		diag = d.d_diag.p;
+	}
+	if (chunks <= 1 || diag) {
 		launch_cracks(d, s, ca, 0, ns, crack_lds);
 		st.done("k_decode_cracks");
-		launch_strips<OUT>(d, s, g, p, 0, ns, out_device, flat, flat, &st);
+		launch_strips<OUT>(d, s, g, p, 0, ns, out_device, flat, &st, diag);
+		if (diag) {
+			unsigned long long hd[32];
+			CKL_HIP(hipMemcpyAsync(hd, diag, sizeof(hd), hipMemcpyDeviceToHost, s));
+			CKL_HIP(hipStreamSynchronize(s));
+			const double nst = static_cast<double>(d.nstrips) * ns;
+			fprintf(stderr, "[ckl strip diag, mean cycles per workgroup] k_strip_ccl: load+scan=%.0f starts=%.0f unions=%.0f roots+ids=%.0f weights=%.0f | k_slice_resolve: tables=%.0f seams=%.0f rank=%.0f labels+crc=%.0f | k_paint_strips: words+scan=%.0f labels=%.0f paint=%.0f\n",
+				hd[0] / nst, hd[1] / nst, hd[2] / nst, hd[3] / nst, hd[4] / nst, hd[8] / double(ns), hd[9] / double(ns), hd[10] / double(ns), hd[11] / double(ns), hd[16] / nst, hd[17] / nst, hd[18] / nst);
+		}
 	}
 	else {
 		// z-chunks on their own streams: the instruction-bound crack and strip kernels of one chunk
@@ -2311,7 +2413,7 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 			hipStream_t cs = d.chunk_stream[c];
 			CKL_HIP(hipStreamWaitEvent(cs, d.ev_fork, 0));
 			launch_cracks(d, cs, ca, z0, n, crack_lds);
-			launch_strips<OUT>(d, cs, g, p, z0, n, out_device, flat, flat, nullptr);
+			launch_strips<OUT>(d, cs, g, p, z0, n, out_device, flat, nullptr, nullptr);
 			CKL_HIP(hipEventRecord(d.chunk_done[c], cs));
 			CKL_HIP(hipStreamWaitEvent(s, d.chunk_done[c], 0));
 		}
@@ -2321,10 +2423,9 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 		launch_pin_label_map(d, g, ra_legacy, &p.sa);
 		st.done("k_label_map_pins");
 		p.sa.zbase = 0;
-		hipLaunchKernelGGL(k_strip_labels<OUT>, dim3(ns), dim3(kResolveBlock), p.resolve_lds, s, p.sa, p.ra);
+		hipLaunchKernelGGL(k_strip_labels<OUT>, dim3(d.nstrips, ns), dim3(kBlock), 0, s, p.sa, p.ra);
 		st.done("k_strip_labels");
-		hipLaunchKernelGGL(k_paint_strips<OUT>, dim3(d.nstrips * p.tiles_per_strip, ns), dim3(kBlock), 0, s,
-			g, p.sa, reinterpret_cast<const OUT*>(d.d_run_label.p), reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), p.tile_rows, p.tiles_per_strip, p.gpr_shift);
+		launch_paint_strips<OUT>(d, s, g, p, ns, out_device, nullptr);
 		st.done("k_paint_strips");
 	}
 }
@@ -2334,8 +2435,12 @@ void general_pipeline(ckl_decoder& d, const RunGeom& g, RunArrays& ra, void* out
 	const Header& h = d.head;
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
+	// per-run arrays of the general pipeline (a session on the strip path never needs them)
 	d.d_word_base.ensure(d.plane_words * ns);
-	ra.word_base = d.d_word_base.p;
+	d.d_parent.ensure(d.rtot); d.d_run_start.ensure(d.rtot); d.d_run_cc.ensure(d.rtot); d.d_run_local.ensure(d.rtot);
+	d.d_run_label.ensure(d.rtot); d.d_nruns.ensure(ns);
+	d.d_blk_roots.ensure(static_cast<size_t>((d.max_rcap + kBlock - 1) / kBlock) * ns);
+	ra.word_base = d.d_word_base.p; ra.parent = d.d_parent.p; ra.run_start = d.d_run_start.p; ra.run_cc = d.d_run_cc.p; ra.nruns = d.d_nruns.p;
 	hipLaunchKernelGGL(k_run_index, dim3(ns), dim3(kIndexBlock), 0, s, g, ra);
 	st.done("k_run_index");
 	{
@@ -2595,6 +2700,7 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 		select_device(device);
 		std::unique_ptr<ckl_decoder> d(new ckl_decoder());
 		d->device = device;
+		CKL_HIP(hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, device));
 		CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
 		for (auto& e : d->ev) CKL_HIP(hipEventCreate(&e));
 		CKL_HIP(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
@@ -2615,7 +2721,6 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 			const int bytes = static_cast<int>(d->lds_bytes);
 			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-			set_strip_attributes<uint8_t>(); set_strip_attributes<uint16_t>(); set_strip_attributes<uint32_t>(); set_strip_attributes<uint64_t>();
 		}
 		decoder_build(*d, buf, n, z_start, z_end);
 		*out = d.release();

@@ -55,6 +55,15 @@ struct RunGeom {
 		const uint32_t h = planeH[zi * plane_words + static_cast<uint64_t>(y) * row_words + w];
 		return (flip ? ~h : h) & valid_mask(w);
 	}
+	// the same from a plane word that is already loaded (the strip kernels issue all their loads
+	// first, unconditionally, and interpret the words afterwards: a load inside a branch is
+	// waited for inside the branch)
+	__device__ __forceinline__ uint32_t breaks_of(uint32_t v, uint32_t w) const {
+		uint32_t b = flip ? v : ~v;
+		if (w == 0) b |= 1u;
+		return b & valid_mask(w);
+	}
+	__device__ __forceinline__ uint32_t ups_of(uint32_t h, uint32_t w) const { return (flip ? ~h : h) & valid_mask(w); }
 };
 __device__ __forceinline__ uint32_t mask_le(uint32_t bit) { return bit >= 31u ? 0xFFFFFFFFu : ((2u << bit) - 1u); }
 

@@ -12,10 +12,10 @@
 //   k_slice_resolve  one workgroup per slice: union-find over the strip components (a few thousand
 //                    per slice instead of ~50 k runs) across the strip seams, ranks the roots in
 //                    raster order of their first pixel = the reference's component ids, checks count
-//                    and crc32c, maps ids to labels and writes the label of every run.
-//   k_paint_strips   4096-pixel tiles of whole rows: the tile's plane words and their run prefix
-//                    are built in LDS (no per-word table in HBM), the run labels are staged, 16-byte
-//                    streaming stores.
+//                    and crc32c, maps ids to labels: one label per strip component.
+//   k_paint_strips   one workgroup per strip: the strip's plane words and their run prefix are built
+//                    in LDS (no per-word table in HBM), the label of every run is staged there
+//                    (run -> strip component -> label), then 16-byte streaming stores.
 //
 // A strip with more runs than the LDS tables hold, or a slice with more strip components than
 // k_slice_resolve's table, raises `overflow`: the host then runs the general run pipeline of
@@ -28,7 +28,7 @@ namespace ckl {
 namespace dev {
 
 constexpr uint32_t kStripWords = 1024;      // plane words per strip: 4 per thread
-constexpr uint32_t kStripCap = 3072;        // runs per strip held in LDS
+constexpr uint32_t kStripCap = 2560;        // runs per strip held in LDS (the host sizes the strips for ~0.7 of it)
 constexpr uint32_t kStripRunsPerThread = kStripCap / kBlock;
 constexpr uint32_t kStripBitmapWords = kStripCap / 32;
 constexpr uint32_t kStripOverflow = 0xFFFFFFFFu;
@@ -65,117 +65,143 @@ __device__ __forceinline__ void sm_unite(uint32_t* L, uint32_t a, uint32_t b) {
 }
 
 struct StripArrays {
-	const uint64_t* rbase;     // [nslices] base of the slice in the per-run arrays
-	const uint32_t* rcap;      // [nslices] capacity
-	uint32_t* cursor;          // [nslices] runs handed out to strips so far (zeroed per decode)
-	uint16_t* run_lid;         // [runs] strip-local component of the run
-	uint32_t* row_run;         // [nslices][sy] slice-relative index of the first run of each row
-	uint32_t* strip_base;      // [nslices][nstrips] slice-relative index of the strip's first run
-	uint32_t* strip_nruns;     // [nslices][nstrips] (kStripOverflow: the strip did not fit)
-	uint32_t* strip_nsc;       // [nslices][nstrips] strip components
-	uint16_t* seam_first;      // [nslices][nstrips][row_words] runs of the strip before each word of its first row
+	// per strip (index si = slice * nstrips + strip); the per-run and per-strip-component arrays
+	// give every strip a fixed slot of `cap` entries, so that no kernel waits for another's counts
+	uint16_t* run_lid;         // [strips][cap] strip-local component of each run
+	uint32_t* sc_w;            // [strips][cap] per strip component: XOR of its runs' crc weights
+	uint32_t* sc_cc;           // [strips][cap] per strip component: component id of the slice (pins)
+	void* sc_label;            // [strips][cap] per strip component: label, typed like the output
+	uint32_t* strip_nruns;     // [strips] (kStripOverflow: the strip did not fit)
+	uint32_t* strip_nsc;       // [strips] strip components
+	uint16_t* row_run;         // [nslices][sy] runs of the strip before each row (pins look pixels up)
+	uint16_t* seam_first;      // [strips][row_words] runs of the strip before each word of its first row
 	uint16_t* seam_last;       // ... of its last row
-	uint32_t* sc_w;            // [runs] per strip component (at strip_base + local id): XOR of crc weights
-	uint32_t* sc_cc;           // [runs] per strip component: component id of the slice
 	uint32_t* slice_err;
 	uint32_t* overflow;        // one word
 	uint32_t nstrips, strip_rows;
+	uint32_t cap;              // slot size: min(kStripCap, pixels of a strip)
 	uint32_t zbase;            // first slice of this launch (z-chunked launches)
+	uint32_t ablate;           // tuning aid (CKL_ABLATE): skips parts of the strip kernels, results are wrong
 };
 
-// grid = (nstrips, slices of the launch), block = kBlock
-static __global__ void __launch_bounds__(kBlock) k_strip_ccl(RunGeom g, StripArrays sa, const uint32_t* __restrict__ G, uint32_t n_pixels) {
+// grid = (nstrips, slices of the launch), block = kBlock.  The kernel waits on LDS round trips
+// (union-find), so what counts is the number of resident wavefronts: <= 72 registers and 22 KiB of
+// LDS keep seven workgroups on a CU.  (A persistent variant that fetched the next strip's words
+// while working on the current one needed 113 registers and was slower: 0.36 against 0.29 ms.)
+template <bool DIAG>
+static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, StripArrays sa, const uint32_t* __restrict__ G, uint32_t n_pixels, unsigned long long* __restrict__ diag) {
 	__shared__ uint32_t s_parent[kStripCap];          // union-find, then the crc weights per strip component
 	__shared__ uint32_t s_b[kStripWords];             // break words of the strip
 	__shared__ uint16_t s_wb[kStripWords];            // runs before each word
-	__shared__ uint16_t s_start[kStripCap];           // first pixel of each run, relative to the strip
-	__shared__ uint16_t s_lid[kStripCap];
+	__shared__ uint16_t s_pool[kStripCap];            // first pixel of each run (relative to the strip), later its strip component
 	__shared__ uint32_t s_bm[kStripBitmapWords], s_bmbase[kStripBitmapWords];
 	__shared__ uint32_t s_scan[kWaves];
 	__shared__ uint32_t s_misc[2];
+	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+	auto stamp = [&](int slot) {
+		if (DIAG && threadIdx.x == 0) {
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			atomicAdd(diag + slot, now - d_t);
+			d_t = now;
+		}
+	};
+	const uint32_t rw = g.row_words;
+	const uint32_t t = threadIdx.x;
 	const uint32_t zi = blockIdx.y + sa.zbase;
 	const uint32_t k = blockIdx.x;
 	const uint32_t si = zi * sa.nstrips + k;
 	const uint32_t y0 = k * sa.strip_rows;
 	const uint32_t y1 = min(y0 + sa.strip_rows, g.sy);
-	const uint32_t rw = g.row_words;
 	const uint32_t nw = (y1 - y0) * rw;
-	const uint32_t t = threadIdx.x;
-	const uint64_t rb = sa.rbase[zi];
-
-	// ---- runs of the strip
-	uint32_t b[4], yl[4], w[4], cnt = 0;
+	const uint64_t slot = static_cast<uint64_t>(si) * sa.cap;
+	// ---- plane words: every load is issued at once, none sits in a branch (a load inside a branch
+	// is waited for there); words past the strip read word 0
+	uint32_t b[4], up[4], upl[4], cnt = 0;
 	{
-		uint32_t yy = (t * 4u) / rw, ww = t * 4u - yy * rw;
+		const uint32_t* pv = g.planeV + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+		const uint32_t* ph = g.planeH + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
 #pragma unroll
 		for (uint32_t j = 0; j < 4; j++) {
 			const uint32_t wl = t * 4u + j;
-			yl[j] = yy; w[j] = ww;
-			b[j] = wl < nw ? g.breaks(zi, y0 + yy, ww) : 0u;
-			cnt += __popc(b[j]);
-			if (++ww == rw) { ww = 0; yy++; }
+			const uint32_t at = wl < nw ? wl : 0u;
+			b[j] = pv[at];
+			up[j] = ph[at];
 		}
+		upl[0] = ph[(t * 4u < nw && t) ? t * 4u - 1u : 0u];
 	}
-	// the H words of rows 1.. are requested before the scan's barriers
-	uint32_t up[4], upl[4];
+	// word t*4+j of the strip sits at word w[j] of its row
+	uint32_t w[4];
+	{
+		const uint32_t yy = (t * 4u) / rw;
+		uint32_t ww = t * 4u - yy * rw;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) { w[j] = ww; if (++ww == rw) ww = 0; }
+	}
+	upl[0] = (w[0] && t * 4u >= rw && t * 4u < nw) ? g.ups_of(upl[0], w[0] - 1u) : 0u;
 #pragma unroll
 	for (uint32_t j = 0; j < 4; j++) {
 		const uint32_t wl = t * 4u + j;
-		const bool in = wl >= rw && wl < nw;
-		up[j] = in ? g.ups(zi, y0 + yl[j], w[j]) : 0u;
-		upl[j] = (in && w[j]) ? (j ? 0u : g.ups(zi, y0 + yl[j], w[j] - 1u)) : 0u;
+		b[j] = wl < nw ? g.breaks_of(b[j], w[j]) : 0u;
+		up[j] = (wl >= rw && wl < nw) ? g.ups_of(up[j], w[j]) : 0u;      // rows 1.. of the strip: connections to the row above
+		cnt += __popc(b[j]);
 	}
 #pragma unroll
-	for (uint32_t j = 1; j < 4; j++) if (w[j]) upl[j] = up[j - 1];      // same row: the word before is my own
+	for (uint32_t j = 1; j < 4; j++) upl[j] = w[j] ? up[j - 1] : 0u;      // same row: the word before is my own
 	uint32_t v[1] = { cnt }, tot[1];
 	block_excl_add<1>(v, tot, s_scan);
 	const uint32_t nloc = tot[0];
-	if (nloc > kStripCap) {      // uniform: the general pipeline takes over (host)
-		if (t == 0) { sa.strip_nruns[si] = kStripOverflow; sa.strip_nsc[si] = 0; sa.strip_base[si] = 0; atomicOr(sa.overflow, 1u); }
+	if (nloc > sa.cap) {      // uniform: the general pipeline takes over (host)
+		if (t == 0) { sa.strip_nruns[si] = kStripOverflow; sa.strip_nsc[si] = 0; atomicOr(sa.overflow, 1u); }
 		return;
 	}
-	if (t == 0) {
-		uint32_t base = atomicAdd(sa.cursor + zi, nloc);
-		if (base + nloc > sa.rcap[zi]) { atomicOr(sa.slice_err + zi, ERR_CAPACITY); base = kStripOverflow; }
-		s_misc[0] = base;
-	}
+	stamp(0);
 	{
 		uint32_t local = v[0];
-		const uint32_t p_strip = 0;
+		uint32_t px = ((t * 4u) / rw) * g.sx;      // first pixel of my first word's row, relative to the strip
 #pragma unroll
 		for (uint32_t j = 0; j < 4; j++) {
 			const uint32_t wl = t * 4u + j;
+			if (j && w[j] == 0) px += g.sx;
 			if (wl < nw) {
 				s_b[wl] = b[j];
 				s_wb[wl] = static_cast<uint16_t>(local);
-				const uint32_t px = p_strip + yl[j] * g.sx + w[j] * 32u;
-				for (uint32_t m = b[j]; m; m &= m - 1u) s_start[local++] = static_cast<uint16_t>(px + (__ffs(m) - 1u));
+				for (uint32_t m = b[j]; m; m &= m - 1u) s_pool[local++] = static_cast<uint16_t>(px + w[j] * 32u + (__ffs(m) - 1u));
 			}
 		}
 	}
 	for (uint32_t j = t; j < nloc; j += kBlock) s_parent[j] = j;
-	for (uint32_t j = t; j < kStripBitmapWords; j += kBlock) s_bm[j] = 0u;
+	if (t < kStripBitmapWords) s_bm[t] = 0u;
 	__syncthreads();
-	const uint32_t base = s_misc[0];
-	if (base == kStripOverflow) {      // capacity of the slice exceeded (malformed stream): flagged, nothing written
-		if (t == 0) { sa.strip_nruns[si] = 0; sa.strip_nsc[si] = 0; sa.strip_base[si] = 0; }
-		return;
+	stamp(1);
+	// the crc weights of my runs are requested now and collected after the unions
+	uint32_t gv[kStripRunsPerThread];
+	{
+		const uint32_t p0 = y0 * g.sx;
+#pragma unroll
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
+			const uint32_t j = t + i * kBlock;
+			gv[i] = G[(sa.ablate & 4u) ? j : n_pixels - (p0 + s_pool[j < nloc ? j : 0u])];
+		}
 	}
 	// per-row and seam tables
+	{
+		uint32_t yy = (t * 4u) / rw;
 #pragma unroll
-	for (uint32_t j = 0; j < 4; j++) {
-		const uint32_t wl = t * 4u + j;
-		if (wl >= nw) break;
-		const uint32_t wbv = s_wb[wl];
-		if (w[j] == 0) sa.row_run[static_cast<uint64_t>(zi) * g.sy + y0 + yl[j]] = base + wbv;
-		if (wl < rw) sa.seam_first[static_cast<uint64_t>(si) * rw + wl] = static_cast<uint16_t>(wbv);
-		if (wl + rw >= nw) sa.seam_last[static_cast<uint64_t>(si) * rw + (wl + rw - nw)] = static_cast<uint16_t>(wbv);
+		for (uint32_t j = 0; j < 4; j++) {
+			const uint32_t wl = t * 4u + j;
+			if (j && w[j] == 0) yy++;
+			if (wl >= nw) break;
+			const uint16_t wbv = s_wb[wl];
+			if (w[j] == 0) sa.row_run[static_cast<uint64_t>(zi) * g.sy + y0 + yy] = wbv;
+			if (wl < rw) sa.seam_first[static_cast<uint64_t>(si) * rw + wl] = wbv;
+			if (wl + rw >= nw) sa.seam_last[static_cast<uint64_t>(si) * rw + (wl + rw - nw)] = wbv;
+		}
 	}
 	// ---- unions between vertically adjacent runs of the strip (first contact of each pair)
 #pragma unroll
 	for (uint32_t j = 0; j < 4; j++) {
 		const uint32_t wl = t * 4u + j;
-		if (!up[j]) continue;
+		if (!up[j] || (sa.ablate & 1u)) continue;
 		const uint32_t b_here = b[j], b_up = s_b[wl - rw];
 		const uint32_t base_here = s_wb[wl], base_up = s_wb[wl - rw];
 		for (uint32_t c = up[j] & (~((up[j] << 1) | (upl[j] >> 31)) | b_here | b_up); c; c &= c - 1u) {
@@ -183,7 +209,8 @@ static __global__ void __launch_bounds__(kBlock) k_strip_ccl(RunGeom g, StripArr
 			sm_unite(s_parent, base_here + __popc(b_here & m) - 1u, base_up + __popc(b_up & m) - 1u);
 		}
 	}
-	__syncthreads();
+	__syncthreads();      // also: every s_pool[] start has been read, the pool now takes the strip components
+	stamp(2);
 	// ---- roots -> strip-local component ids in run order
 	uint32_t root[kStripRunsPerThread];
 #pragma unroll
@@ -194,7 +221,7 @@ static __global__ void __launch_bounds__(kBlock) k_strip_ccl(RunGeom g, StripArr
 	}
 	__syncthreads();
 	if (t < kWave) {
-		static_assert(kStripBitmapWords <= 2 * kWave, "two words per lane");
+		static_assert(kStripBitmapWords <= 2 * kWave, "two bitmap words per lane");
 		const uint32_t c0 = t < kStripBitmapWords ? __popc(s_bm[t]) : 0u;
 		const uint32_t c1 = t + kWave < kStripBitmapWords ? __popc(s_bm[t + kWave]) : 0u;
 		const uint32_t i0 = wave_incl_add(c0);
@@ -206,50 +233,34 @@ static __global__ void __launch_bounds__(kBlock) k_strip_ccl(RunGeom g, StripArr
 	}
 	__syncthreads();
 	const uint32_t nsc = s_misc[1];
-	uint16_t* lid_out = sa.run_lid + rb + base;
+	uint16_t* lid_out = sa.run_lid + slot;
 #pragma unroll
 	for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 		const uint32_t j = t + i * kBlock;
 		if (j >= nloc) break;
 		const uint32_t r = root[i];
 		const uint32_t lid = s_bmbase[r >> 5] + __popc(s_bm[r >> 5] & ((1u << (r & 31u)) - 1u));
-		s_lid[j] = static_cast<uint16_t>(lid);
+		s_pool[j] = static_cast<uint16_t>(lid);
 		lid_out[j] = static_cast<uint16_t>(lid);
 	}
 	for (uint32_t j = t; j < nsc; j += kBlock) s_parent[j] = 0u;      // every find is done: the table becomes the weights
 	__syncthreads();
+	stamp(3);
 	// ---- crc weights: run j covering [a_j, a_j+1) adds G[n - a_j] ^ G[n - a_j+1] to its component
-	{
-		const uint32_t p0 = y0 * g.sx;
-		uint32_t gv[kStripRunsPerThread];
 #pragma unroll
-		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
-			const uint32_t j = t + i * kBlock;
-			gv[i] = j < nloc ? G[n_pixels - (p0 + s_start[j])] : 0u;
-		}
-#pragma unroll
-		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
-			const uint32_t j = t + i * kBlock;
-			if (j >= nloc) break;
-			atomicXor(s_parent + s_lid[j], gv[i]);
-			if (j) atomicXor(s_parent + s_lid[j - 1], gv[i]);
-		}
-		if (t == 0 && nloc) atomicXor(s_parent + s_lid[nloc - 1], G[n_pixels - y1 * g.sx]);
+	for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
+		const uint32_t j = t + i * kBlock;
+		if (j >= nloc || (sa.ablate & 2u)) break;
+		atomicXor(s_parent + s_pool[j], gv[i]);
+		if (j) atomicXor(s_parent + s_pool[j - 1], gv[i]);
 	}
+	if (t == 0 && nloc) atomicXor(s_parent + s_pool[nloc - 1], G[n_pixels - y1 * g.sx]);
 	__syncthreads();
-	uint32_t* w_out = sa.sc_w + rb + base;
+	uint32_t* w_out = sa.sc_w + slot;
 	for (uint32_t j = t; j < nsc; j += kBlock) w_out[j] = s_parent[j];
-	if (t == 0) { sa.strip_base[si] = base; sa.strip_nruns[si] = nloc; sa.strip_nsc[si] = nsc; }
+	if (t == 0) { sa.strip_nruns[si] = nloc; sa.strip_nsc[si] = nsc; }
+	stamp(4);
 }
-
-// The dynamic LDS of the resolve kernels seen as ids (uint32) and as labels (OUT): one extern
-// array per element type, all at the same address (a pointer cast from the uint32 view loses the
-// LDS address space in hipcc 7.2 and ends in an illegal instruction).
-template <typename T> struct DynLds;
-template <> struct DynLds<uint8_t> { static __device__ __forceinline__ uint8_t* get() { extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_u8[]; return s_dyn_u8; } };
-template <> struct DynLds<uint16_t> { static __device__ __forceinline__ uint16_t* get() { extern __shared__ __attribute__((aligned(16))) uint16_t s_dyn_u16[]; return s_dyn_u16; } };
-template <> struct DynLds<uint32_t> { static __device__ __forceinline__ uint32_t* get() { extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn_u32[]; return s_dyn_u32; } };
-template <> struct DynLds<uint64_t> { static __device__ __forceinline__ uint64_t* get() { extern __shared__ __attribute__((aligned(16))) uint64_t s_dyn_u64[]; return s_dyn_u64; } };
 
 // what k_slice_resolve needs besides the strips
 struct ResolveArgs {
@@ -257,59 +268,66 @@ struct ResolveArgs {
 	const uint32_t* crc_expect;      // [nslices] raw
 	const uint32_t* ncomp_expect;    // [nslices]
 	const uint64_t* comp_off;        // [nslices] first entry of the slice in label_map
-	const uint64_t* label_map;       // component -> label (LABELS)
+	const uint64_t* label_map;       // component -> label
 	uint32_t has_label;
 	uint64_t label;
-	void* run_label;                 // [runs] typed like the output (LABELS)
-	uint32_t cap;                    // strip components the dynamic LDS holds
+	uint32_t cap;                    // strip components the LDS table holds (<= kResolveCap)
 };
 
-// component -> label -> every run of the slice (shared by the flat path, inside k_slice_resolve,
-// and the pin path, where the label table only exists after the component ids)
-template <typename OUT>
-__device__ __forceinline__ void strip_run_labels(const StripArrays& sa, uint64_t rb, const uint32_t* s_sbase, const uint32_t* s_nruns, const uint32_t* s_scbase, const OUT* s_lab, OUT* __restrict__ run_label) {
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-	for (uint32_t s = wave; s < sa.nstrips; s += kResolveBlock / kWave) {
-		const uint32_t nr = s_nruns[s];
-		const uint16_t* lid = sa.run_lid + rb + s_sbase[s];
-		OUT* dst = run_label + rb + s_sbase[s];
-		const uint32_t scb = s_scbase[s];
-		for (uint32_t j0 = 0; j0 < nr; j0 += 4 * kWave) {
-			uint32_t l[4];
-#pragma unroll
-			for (uint32_t u = 0; u < 4; u++) { const uint32_t j = j0 + u * kWave + lane; l[u] = j < nr ? lid[j] : 0u; }
-#pragma unroll
-			for (uint32_t u = 0; u < 4; u++) { const uint32_t j = j0 + u * kWave + lane; if (j < nr) dst[j] = s_lab[scb + l[u]]; }
-		}
-	}
-}
-
-// grid = slices of the launch, block = kResolveBlock, dynamic LDS = cap * max(4, sizeof(OUT))
-// LABELS: flat labels (label_map is ready): run labels are written here.  Otherwise the component
-// id of every strip component goes to sc_cc (pins: the label table needs them first).
-template <typename OUT, bool LABELS>
-static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom g, StripArrays sa, ResolveArgs ra, uint32_t* __restrict__ ncomp_out) {
-	uint32_t* s_tab = DynLds<uint32_t>::get();
-	__shared__ uint32_t s_sbase[kMaxStrips], s_nruns[kMaxStrips], s_scbase[kMaxStrips + 1];
+// grid = slices of the launch, block = kResolveBlock
+// LABELS: flat labels (label_map is ready): the label of every strip component is written here.
+// Otherwise its component id goes to sc_cc (pins: the label table needs the ids first).
+template <typename OUT, bool LABELS, bool DIAG>
+static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom g, StripArrays sa, ResolveArgs ra, uint32_t* __restrict__ ncomp_out, unsigned long long* __restrict__ diag) {
+	__shared__ uint32_t s_tab[kResolveCap];
+	__shared__ uint32_t s_scbase[kMaxStrips + 1];
 	__shared__ uint32_t s_scan[kResolveBlock / kWave];
 	__shared__ uint32_t s_flag;
 	constexpr int NW = kResolveBlock / kWave;
+	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+	auto stamp = [&](int slot) {
+		if (DIAG && threadIdx.x == 0) {
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			atomicAdd(diag + slot, now - d_t);
+			d_t = now;
+		}
+	};
 	const uint32_t zi = blockIdx.x + sa.zbase;
 	const uint32_t t = threadIdx.x;
 	const uint32_t ns = sa.nstrips;
 	const uint32_t rw = g.row_words;
-	const uint64_t rb = sa.rbase[zi];
+	const uint32_t si0 = zi * ns;
+	// ---- the seam words of this thread are requested first: they depend on nothing
+	const uint32_t items = (ns - 1u) * rw;
+	constexpr uint32_t kSeamPer = 2;      // seam words per thread and round
+	uint32_t q_up[kSeamPer], q_prev[kSeamPer], q_bh[kSeamPer], q_bu[kSeamPer], q_wh[kSeamPer], q_wu[kSeamPer];
+	auto seam_load = [&](uint32_t it0) {
+		// all loads issued, none in a branch (seam words past the end read the first seam instead)
+#pragma unroll
+		for (uint32_t u = 0; u < kSeamPer; u++) {
+			const uint32_t it_raw = it0 + u * kResolveBlock + t;
+			const uint32_t it = it_raw < items ? it_raw : 0u;
+			const uint32_t seam = it / rw, w = it - seam * rw;
+			const uint32_t k = seam + 1u, y = k * sa.strip_rows;
+			const uint64_t at = zi * g.plane_words + static_cast<uint64_t>(y) * rw + w;
+			const uint32_t h = g.planeH[at], hp = g.planeH[w ? at - 1u : at];
+			const uint32_t vh = g.planeV[at], vu = g.planeV[at - rw];
+			q_wh[u] = sa.seam_first[static_cast<uint64_t>(si0 + k) * rw + w];
+			q_wu[u] = sa.seam_last[static_cast<uint64_t>(si0 + k - 1u) * rw + w];
+			q_up[u] = it_raw < items ? g.ups_of(h, w) : 0u;
+			q_prev[u] = w ? (g.ups_of(hp, w - 1u) >> 31) : 0u;
+			q_bh[u] = g.breaks_of(vh, w); q_bu[u] = g.breaks_of(vu, w);
+		}
+	};
+	if (items) seam_load(0);
 	// ---- strip tables
 	uint32_t my_nsc = 0;
 	if (t == 0) s_flag = 0;
 	__syncthreads();
 	if (t < ns) {
-		const uint32_t si = zi * ns + t;
-		const uint32_t nr = sa.strip_nruns[si];
+		const uint32_t nr = sa.strip_nruns[si0 + t];
 		if (nr == kStripOverflow) s_flag = 1;
-		s_nruns[t] = nr == kStripOverflow ? 0u : nr;
-		s_sbase[t] = sa.strip_base[si];
-		my_nsc = sa.strip_nsc[si];
+		my_nsc = sa.strip_nsc[si0 + t];
 	}
 	uint32_t v[1] = { my_nsc }, tot[1];
 	block_excl_add<1, NW>(v, tot, s_scan);
@@ -325,28 +343,29 @@ static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom 
 	const uint32_t i0 = min(total, t * per), i1 = min(total, i0 + per);
 	for (uint32_t i = t; i < total; i += kResolveBlock) s_tab[i] = i;
 	__syncthreads();
+	stamp(0);
 	// ---- unions across the strip seams
-	const uint32_t items = (ns - 1u) * rw;
-	for (uint32_t it = t; it < items; it += kResolveBlock) {
-		const uint32_t seam = it / rw, w = it - seam * rw;
-		const uint32_t k = seam + 1u, y = k * sa.strip_rows;
-		const uint32_t up = g.ups(zi, y, w);
-		if (!up) continue;
-		const uint32_t prev_bit = w ? (g.ups(zi, y, w - 1u) >> 31) : 0u;
-		const uint32_t b_here = g.breaks(zi, y, w), b_up = g.breaks(zi, y - 1u, w);
-		const uint32_t wbh = sa.seam_first[(static_cast<uint64_t>(zi) * ns + k) * rw + w];
-		const uint32_t wbu = sa.seam_last[(static_cast<uint64_t>(zi) * ns + k - 1u) * rw + w];
-		const uint16_t* lid_h = sa.run_lid + rb + s_sbase[k];
-		const uint16_t* lid_u = sa.run_lid + rb + s_sbase[k - 1u];
-		for (uint32_t c = up & (~((up << 1) | prev_bit) | b_here | b_up); c; c &= c - 1u) {
-			const uint32_t m = mask_le(__ffs(c) - 1u);
-			const uint32_t jh = wbh + __popc(b_here & m) - 1u, ju = wbu + __popc(b_up & m) - 1u;
-			if (jh >= s_nruns[k] || ju >= s_nruns[k - 1u]) continue;      // a strip that hit the slice capacity (flagged there)
-			const uint32_t a = s_scbase[k] + lid_h[jh], bb = s_scbase[k - 1u] + lid_u[ju];
-			if (a < total && bb < total) sm_unite(s_tab, a, bb);
+	for (uint32_t it0 = 0; it0 < items; it0 += kSeamPer * kResolveBlock) {
+		if (it0) seam_load(it0);
+#pragma unroll
+		for (uint32_t u = 0; u < kSeamPer; u++) {
+			if (!q_up[u]) continue;
+			const uint32_t it = it0 + u * kResolveBlock + t;
+			const uint32_t k = it / rw + 1u;
+			const uint16_t* lid_h = sa.run_lid + static_cast<uint64_t>(si0 + k) * sa.cap;
+			const uint16_t* lid_u = sa.run_lid + static_cast<uint64_t>(si0 + k - 1u) * sa.cap;
+			const uint32_t nsc_h = s_scbase[k + 1u] - s_scbase[k], nsc_u = s_scbase[k] - s_scbase[k - 1u];
+			for (uint32_t c = q_up[u] & (~((q_up[u] << 1) | q_prev[u]) | q_bh[u] | q_bu[u]); c; c &= c - 1u) {
+				const uint32_t m = mask_le(__ffs(c) - 1u);
+				const uint32_t jh = q_wh[u] + __popc(q_bh[u] & m) - 1u, ju = q_wu[u] + __popc(q_bu[u] & m) - 1u;
+				if (jh >= sa.cap || ju >= sa.cap) continue;
+				const uint32_t lh = lid_h[jh], lu = lid_u[ju];
+				if (lh < nsc_h && lu < nsc_u) sm_unite(s_tab, s_scbase[k] + lh, s_scbase[k - 1u] + lu);
+			}
 		}
 	}
 	__syncthreads();
+	stamp(1);
 	// ---- roots ranked in index order = raster order of the components' first pixels
 	uint32_t root[kResolvePer], nroot = 0;
 #pragma unroll
@@ -354,6 +373,26 @@ static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom 
 		const uint32_t i = i0 + q;
 		root[q] = i < i1 ? sm_find(s_tab, i) : 0u;
 		nroot += (i < i1 && root[q] == i) ? 1u : 0u;
+	}
+	// the crc weights are requested before the scan's barriers
+	uint32_t wgt[kResolvePer];
+	uint64_t gi[kResolvePer];
+	{
+		uint32_t s = 0;
+		if (i0 < i1) {      // strip of my first entry
+			uint32_t lo = 0, hi = ns;
+			while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_scbase[mid] <= i0) lo = mid; else hi = mid; }
+			s = lo;
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < kResolvePer; q++) {
+			const uint32_t i = i0 + q;
+			wgt[q] = 0; gi[q] = 0;
+			if (i >= i1) continue;
+			while (s + 1 < ns && s_scbase[s + 1] <= i) s++;
+			gi[q] = static_cast<uint64_t>(si0 + s) * sa.cap + (i - s_scbase[s]);
+			wgt[q] = sa.sc_w[gi[q]];
+		}
 	}
 	uint32_t v2[1] = { nroot }, tot2[1];
 	block_excl_add<1, NW>(v2, tot2, s_scan);      // its barriers also end every find
@@ -366,37 +405,31 @@ static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom 
 		}
 	}
 	__syncthreads();
+	stamp(2);
 	const uint32_t ncomp = tot2[0];
 	const uint32_t nexp = ra.ncomp_expect[zi];
-	// ---- ids, crc32c of the component image, labels
-	uint32_t cc[kResolvePer], part = 0;
-	{
-		uint32_t s = 0;
-		if (i0 < i1) {      // strip of my first entry
-			uint32_t lo = 0, hi = ns;
-			while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_scbase[mid] <= i0) lo = mid; else hi = mid; }
-			s = lo;
-		}
+	const uint64_t coff = ra.comp_off[zi];
+	// ---- ids, labels, crc32c of the component image
+	uint32_t part = 0;
 #pragma unroll
-		for (uint32_t q = 0; q < kResolvePer; q++) {
-			const uint32_t i = i0 + q;
-			cc[q] = 0;
-			if (i >= i1) continue;
-			cc[q] = s_tab[root[q]];
-			while (s + 1 < ns && s_scbase[s + 1] <= i) s++;
-			const uint64_t gi = rb + s_sbase[s] + (i - s_scbase[s]);
-			uint32_t wgt = sa.sc_w[gi];
-			if (!LABELS) sa.sc_cc[gi] = cc[q];
-			// sum over set bits j < idbits of the id:  wgt * x^(idbits-1-j)
-			for (int j = static_cast<int>(ra.idbits) - 1; j >= 0; j--) {
-				part ^= ((cc[q] >> j) & 1u) ? wgt : 0u;
-				wgt = (wgt >> 1) ^ ((wgt & 1u) ? kCrcPoly : 0u);
-			}
+	for (uint32_t q = 0; q < kResolvePer; q++) {
+		const uint32_t i = i0 + q;
+		if (i >= i1) continue;
+		const uint32_t cc = s_tab[root[q]];
+		if (LABELS) {
+			uint64_t val = cc < nexp ? ra.label_map[coff + cc] : 0ull;
+			if (ra.has_label) val = (val == ra.label);
+			static_cast<OUT*>(sa.sc_label)[gi[q]] = static_cast<OUT>(val);
+		}
+		else sa.sc_cc[gi[q]] = cc;
+		// sum over set bits j < idbits of the id:  wgt * x^(idbits-1-j)
+		uint32_t wg = wgt[q];
+		for (int j = static_cast<int>(ra.idbits) - 1; j >= 0; j--) {
+			part ^= ((cc >> j) & 1u) ? wg : 0u;
+			wg = (wg >> 1) ^ ((wg & 1u) ? kCrcPoly : 0u);
 		}
 	}
-	// block xor (NW wavefronts)
 	part = wave_xor(part);
-	__syncthreads();      // every s_tab[root] has been read
 	if ((t & (kWave - 1)) == 0) s_scan[t >> 6] = part;
 	__syncthreads();
 	if (t == 0) {
@@ -408,62 +441,26 @@ static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom 
 		if (e) atomicOr(sa.slice_err + zi, e);
 		ncomp_out[zi] = ncomp;
 	}
-	if (!LABELS) return;
-	OUT* s_lab = DynLds<OUT>::get();
-	OUT mine[kResolvePer];
-#pragma unroll
-	for (uint32_t q = 0; q < kResolvePer; q++) {
-		uint64_t val = 0;
-		if (i0 + q < i1 && cc[q] < nexp) val = ra.label_map[ra.comp_off[zi] + cc[q]];
-		if (ra.has_label) val = (val == ra.label);
-		mine[q] = static_cast<OUT>(val);
-	}
-	if (sizeof(OUT) > 4) __syncthreads();      // wider than the ids they replace: all ids are in registers by now (barrier above), kept for symmetry
-#pragma unroll
-	for (uint32_t q = 0; q < kResolvePer; q++) if (i0 + q < i1) s_lab[i0 + q] = mine[q];
-	__syncthreads();
-	strip_run_labels<OUT>(sa, rb, s_sbase, s_nruns, s_scbase, s_lab, static_cast<OUT*>(ra.run_label));
+	stamp(3);
 }
 
-// pins: labels of the runs once label_map has been filled from the component ids
-// grid = slices of the launch, block = kResolveBlock, dynamic LDS = cap * sizeof(OUT)
+// pins: labels of the strip components once label_map has been filled from their component ids
+// grid = (nstrips, slices of the launch), block = kBlock
 template <typename OUT>
-static __global__ void __launch_bounds__(kResolveBlock) k_strip_labels(StripArrays sa, ResolveArgs ra) {
-	__shared__ uint32_t s_sbase[kMaxStrips], s_nruns[kMaxStrips], s_scbase[kMaxStrips + 1];
-	__shared__ uint32_t s_scan[kResolveBlock / kWave];
-	constexpr int NW = kResolveBlock / kWave;
-	const uint32_t zi = blockIdx.x + sa.zbase;
-	const uint32_t t = threadIdx.x;
-	const uint32_t ns = sa.nstrips;
-	const uint64_t rb = sa.rbase[zi];
-	uint32_t my_nsc = 0;
-	if (t < ns) {
-		const uint32_t si = zi * ns + t;
-		const uint32_t nr = sa.strip_nruns[si];
-		s_nruns[t] = nr == kStripOverflow ? 0u : nr;
-		s_sbase[t] = sa.strip_base[si];
-		my_nsc = nr == kStripOverflow ? 0u : sa.strip_nsc[si];
-	}
-	uint32_t v[1] = { my_nsc }, tot[1];
-	block_excl_add<1, NW>(v, tot, s_scan);
-	if (t < ns) s_scbase[t] = v[0];
-	if (t == 0) s_scbase[ns] = tot[0];
-	__syncthreads();
-	if (tot[0] > ra.cap) return;      // flagged by k_slice_resolve
-	OUT* s_lab = DynLds<OUT>::get();
+static __global__ void __launch_bounds__(kBlock) k_strip_labels(StripArrays sa, ResolveArgs ra) {
+	const uint32_t zi = blockIdx.y + sa.zbase;
+	const uint32_t si = zi * sa.nstrips + blockIdx.x;
+	if (sa.strip_nruns[si] == kStripOverflow) return;
+	const uint32_t n = min(sa.strip_nsc[si], sa.cap);
 	const uint32_t nexp = ra.ncomp_expect[zi];
-	for (uint32_t s = t >> 6; s < ns; s += NW) {
-		const uint32_t n = s_scbase[s + 1] - s_scbase[s];
-		for (uint32_t j = t & (kWave - 1); j < n; j += kWave) {
-			const uint32_t c = sa.sc_cc[rb + s_sbase[s] + j];
-			uint64_t val = 0;
-			if (c < nexp) val = ra.label_map[ra.comp_off[zi] + c];
-			if (ra.has_label) val = (val == ra.label);
-			s_lab[s_scbase[s] + j] = static_cast<OUT>(val);
-		}
+	const uint64_t coff = ra.comp_off[zi];
+	const uint64_t slot = static_cast<uint64_t>(si) * sa.cap;
+	for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+		const uint32_t c = sa.sc_cc[slot + j];
+		uint64_t val = c < nexp ? ra.label_map[coff + c] : 0ull;
+		if (ra.has_label) val = (val == ra.label);
+		static_cast<OUT*>(sa.sc_label)[slot + j] = static_cast<OUT>(val);
 	}
-	__syncthreads();
-	strip_run_labels<OUT>(sa, rb, s_sbase, s_nruns, s_scbase, s_lab, static_cast<OUT*>(ra.run_label));
 }
 
 // component id of the run that holds pixel (x, y) — pin decoding (labels.hpp:600-614)
@@ -476,10 +473,10 @@ __device__ __forceinline__ uint32_t strip_component_of_pixel(const RunGeom& g, c
 	const uint32_t wx = x >> 5;
 	for (uint32_t w = 0; w < wx; w++) run += __popc(g.breaks(zi, y, w));
 	run += __popc(g.breaks(zi, y, wx) & mask_le(x & 31u)) - 1u;
-	const uint32_t sb = sa.strip_base[si];
-	if (run < sb || run - sb >= nr) return 0xFFFFFFFFu;
-	const uint64_t rb = sa.rbase[zi];
-	return sa.sc_cc[rb + sb + sa.run_lid[rb + run]];
+	if (run >= nr || run >= sa.cap) return 0xFFFFFFFFu;
+	const uint64_t slot = static_cast<uint64_t>(si) * sa.cap;
+	const uint32_t lid = sa.run_lid[slot + run];
+	return lid < sa.cap ? sa.sc_cc[slot + lid] : 0xFFFFFFFFu;
 }
 
 }  // namespace dev

