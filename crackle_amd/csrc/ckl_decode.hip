@@ -86,7 +86,8 @@ struct CrackArgs {
 	uint32_t lds_raster;         // 1: planes are built in LDS bands and stored; 0: zeroed by the host, atomics on HBM
 	uint32_t markov_serial;      // testing: expand markov streams with one thread
 	uint32_t zbase;              // first slice of this launch (z-chunked launches)
-	uint32_t* slice_err;         // [nslices] sticky error bits
+	uint32_t* slice_err;         // [nslices] sticky error bits, cleared by this kernel (it is the first of every decode)
+	uint32_t* overflow;          // strip path: its overflow word, cleared here as well (or null)
 };
 
 __device__ __forceinline__ uint32_t rd_le_dev(const uint8_t* p, int w) {
@@ -573,10 +574,13 @@ __device__ __forceinline__ void raster_plane(
 	const uint32_t* seg_x, const uint32_t* seg_y, uint32_t sx, uint32_t sy, uint32_t row_words,
 	uint32_t* band, uint32_t band_y0, uint32_t band_rows, uint32_t& rerr
 ) {
-	uint32_t bx = 0, by = 0;
 	uint32_t act = o_t < valid_segs ? 1u : 0u;
-	if (act) { bx = seg_x[o_t]; by = seg_y[o_t]; }
 	uint32_t dx = o_dx, dy = o_dy;        // displacement of the whole stream before the current word
+	// vertex before the current word = segment offset + that displacement.  The offsets are added in
+	// where they are loaded (start and jumps), so that the wait for those loads sits there and not in
+	// front of every move, where it would also wait for the previous move's ds_or.
+	uint32_t xb = dx, yb = dy;
+	if (act) { xb += seg_x[o_t]; yb += seg_y[o_t]; }
 	uint32_t bad = 0;
 #pragma unroll
 	for (uint32_t j = 0; j < kCrackWords; j++) {
@@ -588,9 +592,8 @@ __device__ __forceinline__ void raster_plane(
 			// (many-band slices) no jump inside this word: its moves stay within a box known from
 			// the four popcounts.  A box inside the grid (no range error possible) that misses the
 			// band, with the one-row reach of vertical moves, is skipped whole.
-			const uint32_t x = bx + dx, y = by + dy;
-			const bool inside = x >= nl && x + nr <= sx && y >= nu && y + nd <= sy;
-			skip = inside && (y + nd + 1u < band_y0 || y - nu > band_y0 + band_rows);
+			const bool inside = xb >= nl && xb + nr <= sx && yb >= nu && yb + nd <= sy;
+			skip = inside && (yb + nd + 1u < band_y0 || yb - nu > band_y0 + band_rows);
 		}
 		if (!skip) {
 			for (uint32_t m = (HORIZ ? (mR | mL) : (mD | mU)) | isT; m; m &= m - 1u) {
@@ -598,34 +601,41 @@ __device__ __forceinline__ void raster_plane(
 				if ((isT >> b) & 1u) {
 					o_t++;
 					act = o_t < valid_segs ? 1u : 0u;
-					if (act) { bx = seg_x[o_t]; by = seg_y[o_t]; }
+					if (act) { xb = seg_x[o_t] + dx; yb = seg_y[o_t] + dy; }
 					continue;
 				}
 				const uint32_t below = (1u << b) - 1u;
-				const uint32_t x = bx + dx + __popc(mR & below) - __popc(mL & below);
-				const uint32_t y = by + dy + __popc(mD & below) - __popc(mU & below);
-				uint32_t in_range, ok, row, col;
+				const uint32_t x = xb + __popc(mR & below) - __popc(mL & below);
+				const uint32_t y = yb + __popc(mD & below) - __popc(mU & below);
+				// the crossed crack sits at the smaller vertex; a move along the outer border crosses no
+				// crack of the planes (never in a stream of the reference's encoder), a move that leaves
+				// the vertex grid is an error: both fail `ok` and are told apart on the side
+				uint32_t ok, row, col, neg;
 				if (HORIZ) {
-					const uint32_t neg = (mL >> b) & 1u;                 // left
-					const uint32_t nx = x + 1u - 2u * neg;
-					col = x - neg; row = y;                                // the crossed crack sits at the smaller vertex
-					in_range = static_cast<uint32_t>(max(x, nx) <= sx) & static_cast<uint32_t>(y <= sy);
-					// a move along the outer border crosses no crack of the planes
+					neg = (mL >> b) & 1u;                 // left
+					col = x - neg; row = y;
 					ok = static_cast<uint32_t>(row - 1u < sy - 1u) & static_cast<uint32_t>(col < sx);
 				}
 				else {
-					const uint32_t neg = (mU >> b) & 1u;                 // up
-					const uint32_t ny = y + 1u - 2u * neg;
+					neg = (mU >> b) & 1u;                 // up
 					col = x; row = y - neg;
-					in_range = static_cast<uint32_t>(x <= sx) & static_cast<uint32_t>(max(y, ny) <= sy);
 					ok = static_cast<uint32_t>(col - 1u < sx - 1u) & static_cast<uint32_t>(row < sy);
 				}
-				const uint32_t rel = row - band_y0;
-				bad |= act & (in_range ^ 1u);
-				if (act & in_range & ok & (rel < band_rows ? 1u : 0u)) atomicOr(band + rel * row_words + (col >> 5), 1u << (col & 31u));
+				if (act & ok) {
+					const uint32_t rel = row - band_y0;
+					if (rel < band_rows) atomicOr(band + rel * row_words + (col >> 5), 1u << (col & 31u));
+				}
+				else if (act) {
+					const uint32_t far = HORIZ ? x + 1u - 2u * neg : y + 1u - 2u * neg;      // the vertex moved to
+					const uint32_t in_range = HORIZ
+						? static_cast<uint32_t>(max(x, far) <= sx) & static_cast<uint32_t>(y <= sy)
+						: static_cast<uint32_t>(x <= sx) & static_cast<uint32_t>(max(y, far) <= sy);
+					bad |= in_range ^ 1u;
+				}
 			}
 		}
 		dx += nr - nl; dy += nd - nu;
+		xb += nr - nl; yb += nd - nu;
 	}
 	if (bad) rerr |= ERR_RANGE;
 }
@@ -1006,8 +1016,8 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	uint32_t* ph = a.planeH + zi * a.plane_words;
 	const uint32_t row_words = a.row_words;
 	uint32_t rerr = 0;
-	const uint32_t* seg_x = lt.seg_x;
-	const uint32_t* seg_y = lt.seg_y;
+	bool segs_in_lds = true;                       // segment offsets: LDS (seg_x at word 0, seg_y at word seg_y_words) or the HBM tables
+	uint32_t seg_y_words = lcap + 2u;
 	uint32_t band_off_words = 2u * (lcap + 2u);   // LDS words in front of the raster band buffer
 	const bool have_cracks = n_nodes > 0 && n_codes > 0;
 
@@ -1057,7 +1067,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			if (vs <= kMoves * kCrackBlock) {
 #pragma unroll
 				for (uint32_t k = 0; k < kMoves; k++) { const uint32_t i = tid + k * kCrackBlock; if (i < vs) lt.seg_x[vs + i] = tmp[k]; }
-				seg_y = lt.seg_x + vs;
+				seg_y_words = vs;
 				band_off_words = 2u * vs;
 			}
 			__syncthreads();
@@ -1068,7 +1078,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			gt.kind = a.g_kind + kb; gt.dx = a.g_dx + kb; gt.dy = a.g_dy + kb; gt.depth = a.g_depth + kb;
 			gt.lastT = a.g_lastT + kb; gt.link = a.g_link + kb; gt.seg_x = a.g_seg_x + kb; gt.seg_y = a.g_seg_y + kb;
 			gt.gmin = a.g_gmin + kb;
-			seg_x = gt.seg_x; seg_y = gt.seg_y;
+			segs_in_lds = false;
 			band_off_words = 0;
 			uint32_t n = n_ctl;
 			if (n + 2u >= kcap) { n = kcap - 3u; rerr |= ERR_CAPACITY; }
@@ -1082,93 +1092,103 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		stamp(2);
 	}
 
-	// ---- pass 1: rasterise
+	// ---- pass 1: rasterise.  The segment offsets sit in LDS or, for slices with more control symbols
+	// than its tables hold, in HBM: one instantiation per address space (through one pointer of
+	// either kind they would be flat loads, and every wait for one also waits for all LDS traffic).
 	const uint32_t valid_segs = s_valid_segs;
-	if (a.lds_raster) {
-		// Both planes are built band by band in LDS (ds_or) and streamed out with plain
-		// stores: no memset of the planes, no atomics on HBM.
-		uint32_t* band = reinterpret_cast<uint32_t*>(s_dyn) + band_off_words;
-		const uint32_t band_words = a.lds_words - band_off_words;
-		uint32_t band_rows = band_words / row_words;              // one plane per pass; >= 1 (checked by the host)
-		if (band_rows > sy) band_rows = sy;
-		const bool single_tile = n_codes < kCrackTile;
-		WordSyms ws[kCrackWords];
-		uint32_t o_a = 0, o_dx = 0, o_dy = 0;
-		// A slice with more codes than one tile needs several bands as well (it is big): its
-		// symbols are derived once per tile and parked in HBM instead of once per tile AND band.
-		uint32_t* sym = a.symbuf + a.symbase[zi];
-		constexpr uint32_t kSymWords = 4u * kCrackWords + 3u;
-		if (have_cracks && !single_tile) {
-			TileCarry c;
-			uint32_t ti = 0;
-			for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
-				tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
-				uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
-#pragma unroll
-				for (uint32_t j = 0; j < kCrackWords; j++) {
-					sb[(4u * j + 0u) * kCrackBlock] = ws[j].prevs; sb[(4u * j + 1u) * kCrackBlock] = ws[j].ms;
-					sb[(4u * j + 2u) * kCrackBlock] = ws[j].ctl; sb[(4u * j + 3u) * kCrackBlock] = ws[j].isT;
-				}
-				sb[(4u * kCrackWords + 0u) * kCrackBlock] = o_a; sb[(4u * kCrackWords + 1u) * kCrackBlock] = o_dx; sb[(4u * kCrackWords + 2u) * kCrackBlock] = o_dy;
-			}
-		}
-		bool have_syms = false;
-		for (uint32_t plane = 0; plane < 2u; plane++) {      // 0: plane V (vertical moves), 1: plane H
-			for (uint32_t y0 = 0; y0 < sy; y0 += band_rows) {
-				const uint32_t rows = min(band_rows, sy - y0);
-				const uint32_t nw = rows * row_words;
-				for (uint32_t i = tid; i < band_rows * row_words; i += kCrackBlock) band[i] = 0u;
-				__syncthreads();
-				stamp_add(14);
-				if (have_cracks && single_tile) {
-					TileCarry c;
-					if (!have_syms) {
-						tile_symbols<true>(words, wshift, n_codes, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
-						have_syms = true;
-						stamp_add(6);
-					}
-					if (plane == 0u) raster_plane<false, false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
-					else raster_plane<true, false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
-				}
-				else if (have_cracks) {
-					uint32_t ti = 0;
-					for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
-						const uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
-#pragma unroll
-						for (uint32_t j = 0; j < kCrackWords; j++) {
-							ws[j].prevs = sb[(4u * j + 0u) * kCrackBlock]; ws[j].ms = sb[(4u * j + 1u) * kCrackBlock];
-							ws[j].ctl = sb[(4u * j + 2u) * kCrackBlock]; ws[j].isT = sb[(4u * j + 3u) * kCrackBlock];
-						}
-						o_a = sb[(4u * kCrackWords + 0u) * kCrackBlock]; o_dx = sb[(4u * kCrackWords + 1u) * kCrackBlock]; o_dy = sb[(4u * kCrackWords + 2u) * kCrackBlock];
-						if (plane == 0u) raster_plane<false, true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
-						else raster_plane<true, true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
-					}
-				}
-				__syncthreads();
-				stamp_add(7);
-				uint32_t* dst = (plane == 0u ? pv : ph) + static_cast<uint64_t>(y0) * row_words;
-				for (uint32_t i = tid; i < nw; i += kCrackBlock) dst[i] = band[i];
-				__syncthreads();
-				stamp_add(15);
-			}
-		}
-	}
-	else if (have_cracks) {
-		// planes were zeroed by the host; bits go straight to HBM
-		TileCarry c;
-		for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile) {
+	auto rasterise = [&](const uint32_t* seg_x, const uint32_t* seg_y) {
+		if (a.lds_raster) {
+			// Both planes are built band by band in LDS (ds_or) and streamed out with plain
+			// stores: no memset of the planes, no atomics on HBM.
+			uint32_t* band = reinterpret_cast<uint32_t*>(s_dyn) + band_off_words;
+			const uint32_t band_words = a.lds_words - band_off_words;
+			uint32_t band_rows = band_words / row_words;              // one plane per pass; >= 1 (checked by the host)
+			if (band_rows > sy) band_rows = sy;
+			const bool single_tile = n_codes < kCrackTile;
 			WordSyms ws[kCrackWords];
-			uint32_t o_a, o_dx, o_dy;
-			tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
-			raster_moves_hbm(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, pv, ph, rerr);
-			__syncthreads();
+			uint32_t o_a = 0, o_dx = 0, o_dy = 0;
+			// A slice with more codes than one tile needs several bands as well (it is big): its
+			// symbols are derived once per tile and parked in HBM instead of once per tile AND band.
+			uint32_t* sym = a.symbuf + a.symbase[zi];
+			constexpr uint32_t kSymWords = 4u * kCrackWords + 3u;
+			if (have_cracks && !single_tile) {
+				TileCarry c;
+				uint32_t ti = 0;
+				for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
+					tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+					uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
+	#pragma unroll
+					for (uint32_t j = 0; j < kCrackWords; j++) {
+						sb[(4u * j + 0u) * kCrackBlock] = ws[j].prevs; sb[(4u * j + 1u) * kCrackBlock] = ws[j].ms;
+						sb[(4u * j + 2u) * kCrackBlock] = ws[j].ctl; sb[(4u * j + 3u) * kCrackBlock] = ws[j].isT;
+					}
+					sb[(4u * kCrackWords + 0u) * kCrackBlock] = o_a; sb[(4u * kCrackWords + 1u) * kCrackBlock] = o_dx; sb[(4u * kCrackWords + 2u) * kCrackBlock] = o_dy;
+				}
+			}
+			bool have_syms = false;
+			for (uint32_t plane = 0; plane < 2u; plane++) {      // 0: plane V (vertical moves), 1: plane H
+				for (uint32_t y0 = 0; y0 < sy; y0 += band_rows) {
+					const uint32_t rows = min(band_rows, sy - y0);
+					const uint32_t nw = rows * row_words;
+					for (uint32_t i = tid; i < band_rows * row_words; i += kCrackBlock) band[i] = 0u;
+					__syncthreads();
+					stamp_add(14);
+					if (have_cracks && single_tile) {
+						TileCarry c;
+						if (!have_syms) {
+							tile_symbols<true>(words, wshift, n_codes, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+							have_syms = true;
+							stamp_add(6);
+						}
+						if (plane == 0u) raster_plane<false, false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
+						else raster_plane<true, false>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
+					}
+					else if (have_cracks) {
+						uint32_t ti = 0;
+						for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
+							const uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
+	#pragma unroll
+							for (uint32_t j = 0; j < kCrackWords; j++) {
+								ws[j].prevs = sb[(4u * j + 0u) * kCrackBlock]; ws[j].ms = sb[(4u * j + 1u) * kCrackBlock];
+								ws[j].ctl = sb[(4u * j + 2u) * kCrackBlock]; ws[j].isT = sb[(4u * j + 3u) * kCrackBlock];
+							}
+							o_a = sb[(4u * kCrackWords + 0u) * kCrackBlock]; o_dx = sb[(4u * kCrackWords + 1u) * kCrackBlock]; o_dy = sb[(4u * kCrackWords + 2u) * kCrackBlock];
+							if (plane == 0u) raster_plane<false, true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
+							else raster_plane<true, true>(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, band, y0, band_rows, rerr);
+						}
+					}
+					__syncthreads();
+					stamp_add(7);
+					uint32_t* dst = (plane == 0u ? pv : ph) + static_cast<uint64_t>(y0) * row_words;
+					for (uint32_t i = tid; i < nw; i += kCrackBlock) dst[i] = band[i];
+					__syncthreads();
+					stamp_add(15);
+				}
+			}
 		}
-	}
+		else if (have_cracks) {
+			// planes were zeroed by the host; bits go straight to HBM
+			TileCarry c;
+			for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile) {
+				WordSyms ws[kCrackWords];
+				uint32_t o_a, o_dx, o_dy;
+				tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+				raster_moves_hbm(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, pv, ph, rerr);
+				__syncthreads();
+			}
+		}
+
+	};
+	if (segs_in_lds) rasterise(reinterpret_cast<const uint32_t*>(s_dyn), reinterpret_cast<const uint32_t*>(s_dyn) + seg_y_words);
+	else rasterise(a.g_seg_x + kb, a.g_seg_y + kb);
 
 	if (rerr) atomicOr(&s_err, rerr);
 	__syncthreads();
 	stamp(3);
-	if (tid == 0 && s_err) atomicOr(a.slice_err + zi, s_err);
+	if (tid == 0) {
+		a.slice_err[zi] = s_err;      // later kernels of the decode OR their bits in
+		if (a.overflow && blockIdx.x == 0 && a.zbase == 0) *a.overflow = 0u;
+	}
 	if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 16 + 4] = n_codes;
 }
 
@@ -1374,7 +1394,7 @@ static __global__ void k_stats_init(uint32_t* box, uint32_t n_table) {
 // ------------------------------------------------------------------------------
 constexpr uint32_t kPaintTile = 4096;          // pixels per workgroup
 constexpr uint32_t kPaintStage = 3072;         // run labels staged in LDS per workgroup
-constexpr uint32_t kPaintTable = 512;          // strip path: labels of a strip's components fetched ahead of knowing how many there are
+constexpr uint32_t kPaintTable = 512;          // strip path: labels of a strip's components staged in LDS
 
 template <typename OUT> struct Vec4;
 template <> struct Vec4<uint8_t> { typedef uchar4 type; };
@@ -1587,8 +1607,8 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	RunGeom g, StripArrays sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag
 ) {
 	typedef typename Vec4<OUT>::type V4;
-	__shared__ OUT s_lab[kStripCap];
-	__shared__ OUT s_tab[kPaintTable];      // labels of the strip's first components
+	__shared__ OUT s_lab[kStripCap];          // label of every run
+	__shared__ OUT s_tab[kPaintTable];        // labels of the strip's components (a strip with more reads them from memory)
 	__shared__ uint32_t s_b[kStripWords];
 	__shared__ uint16_t s_wb[kStripWords];
 	__shared__ uint32_t s_scan[kWaves];
@@ -1609,26 +1629,32 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	const uint32_t nw = (y1 - y0) * rw;
 	const uint32_t t = threadIdx.x;
 	const uint64_t slot = (sa.ablate & 0x2000u) ? 0ull : static_cast<uint64_t>(si) * sa.cap;
-	// ONE trip to memory in front of the stores: plane words, strip component of every run and the
-	// first kPaintTable labels of the strip's components are all requested at once, none inside a
-	// branch (a load inside a branch is waited for there): words past the strip read word 0, runs
-	// past the slot its last entry.  How many runs the strip has is only known after the scan; what
-	// lies behind the last run is not used.  (With the labels fetched through the components in a
-	// second, dependent trip the kernel took 0.42 instead of 0.35 ms at C2.)
-	uint32_t b[4], lid[kStripRunsPerThread];
-	const OUT* lab = static_cast<const OUT*>(sa.sc_label) + slot;
-	OUT tab[kPaintTable / kBlock];
+	// Two trips to memory in front of the stores, and as few bytes as possible: beside the stores
+	// every byte read costs several bytes' worth of store time (C2: 0.41 ms with every load of the
+	// strip, 0.34 ms with the loads pointed at one cached line; one trip or two made no difference).
+	// First the plane words and the strip's counts, then exactly the strip components of its runs
+	// (one byte each while there are at most 256) and exactly the labels of its components.  No
+	// load sits in a branch of its own (it would be waited for there): lanes past the end read entry 0.
+	uint32_t b[4];
 	{
 		const uint32_t* pv = (sa.ablate & 0x6000u) ? g.planeV : g.planeV + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
 #pragma unroll
 		for (uint32_t j = 0; j < 4; j++) { const uint32_t wl = t * 4u + j; b[j] = pv[wl < nw ? wl : 0u]; }
+	}
+	const uint32_t nr = sa.strip_nruns[si];
+	const uint32_t nsc = min(sa.strip_nsc[si], sa.cap);
+	if (nr > sa.cap) return;      // uniform (kStripOverflow): flagged by k_strip_ccl, the general pipeline repaints
+	uint32_t lid[kStripRunsPerThread];
+	const OUT* lab = static_cast<const OUT*>(sa.sc_label) + slot;
+	{
 		const uint16_t* lp = sa.run_lid + ((sa.ablate & 0x8000u) ? 0ull : slot);
 #pragma unroll
-		for (uint32_t i = 0; i < kStripRunsPerThread; i++) { const uint32_t j = t + i * kBlock; lid[i] = lp[j < sa.cap ? j : sa.cap - 1u]; }
-#pragma unroll
-		for (uint32_t i = 0; i < kPaintTable / kBlock; i++) { const uint32_t j = t + i * kBlock; tab[i] = lab[j < sa.cap ? j : sa.cap - 1u]; }
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
+			const uint32_t j = t + i * kBlock;
+			if (i * kBlock < nr) lid[i] = strip_lid(lp, nsc, j < nr ? j : 0u);      // uniform condition
+		}
+		if (nsc <= kPaintTable) for (uint32_t j = t; j < nsc; j += kBlock) s_tab[j] = lab[j];
 	}
-	const uint32_t nsc = (sa.ablate & 0x2000u) ? 1u : sa.strip_nsc[si];
 	uint32_t cnt = 0;
 	{
 		const uint32_t yy = (t * 4u) / rw;
@@ -1640,12 +1666,9 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 			if (++ww == rw) ww = 0;
 		}
 	}
-#pragma unroll
-	for (uint32_t i = 0; i < kPaintTable / kBlock; i++) s_tab[t + i * kBlock] = tab[i];
 	uint32_t v[1] = { cnt }, tot[1];
-	block_excl_add<1>(v, tot, s_scan);      // its barriers also publish s_tab
-	const uint32_t nloc = tot[0];
-	if (nloc > sa.cap) return;      // uniform; flagged by k_strip_ccl, the general pipeline repaints
+	block_excl_add<1>(v, tot, s_scan);      // its barriers also publish the component labels
+	if (tot[0] != nr) return;      // uniform; cannot happen: the same plane words gave k_strip_ccl its count
 	{
 		uint32_t local = v[0];
 #pragma unroll
@@ -1661,17 +1684,17 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 #pragma unroll
 		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 			const uint32_t j = t + i * kBlock;
-			if (j < nloc) s_lab[j] = s_tab[lid[i] < kPaintTable ? lid[i] : 0u];
+			if (j < nr) s_lab[j] = s_tab[lid[i] < nsc ? lid[i] : 0u];
 		}
 	}
-	else {      // more strip components than the table holds: through memory
+	else {
 		OUT lv[kStripRunsPerThread];
 #pragma unroll
-		for (uint32_t i = 0; i < kStripRunsPerThread; i++) lv[i] = lab[lid[i] < sa.cap ? lid[i] : 0u];
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) lv[i] = lab[(i * kBlock < nr && lid[i] < nsc) ? lid[i] : 0u];
 #pragma unroll
 		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 			const uint32_t j = t + i * kBlock;
-			if (j < nloc) s_lab[j] = lv[i];
+			if (j < nr) s_lab[j] = lv[i];
 		}
 	}
 	__syncthreads();
@@ -1679,7 +1702,8 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	// groups of 4 pixels
 	const uint32_t ngroups = ((y1 - y0) * sx) >> 2;
 	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(y0) * sx;
-	const bool nt = (sa.ablate & 0x800u) != 0, adjacent = (sa.ablate & 0x1000u) != 0;
+	// non-temporal stores: 0.39 against 0.41 ms at C2 (they lose 3 - 10 % in a kernel that only stores)
+	const bool nt = (sa.ablate & 0x800u) == 0, adjacent = (sa.ablate & 0x1000u) != 0;
 	constexpr uint32_t U = 4;
 	for (uint32_t g0 = 0; g0 < ngroups; g0 += kBlock * U) {
 		V4 val[U];
@@ -2319,6 +2343,13 @@ StripPlan strip_plan(ckl_decoder& d, int has_label, uint64_t label) {
 	ra.idbits = d.idbits; ra.crc_fix = d.crc_fix; ra.check_crc = d.check_crc ? 1u : 0u;
 	ra.crc_expect = d.d_crc_expect.p; ra.ncomp_expect = d.d_ncomp_expect.p; ra.comp_off = d.d_comp_off.p;
 	ra.label_map = d.d_label_map.p; ra.has_label = has_label ? 1u : 0u; ra.label = label;
+	{
+		const Header& h = d.head;
+		ra.keys = d.d_stream.p + d.keys_offset + d.comp_left * static_cast<uint64_t>(d.key_width);
+		ra.uniq = d.d_stream.p + h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
+		ra.key_width = static_cast<uint32_t>(d.key_width); ra.stored_width = static_cast<uint32_t>(h.stored_data_width);
+		ra.is_signed = h.is_signed ? 1u : 0u; ra.num_unique = d.num_unique;
+	}
 	ra.cap = kResolveCap;
 	if (const char* env = getenv("CKL_RESOLVE_CAP")) ra.cap = std::min<uint32_t>(kResolveCap, static_cast<uint32_t>(std::max(1, atoi(env))));   // testing: forces the overflow path
 	return p;
@@ -2374,10 +2405,8 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 	const uint32_t ns = d.nslices;
 	const bool flat = h.label_format == FLAT;
 	StripPlan p = strip_plan(d, has_label, label);
-	CKL_HIP(hipMemsetAsync(d.d_overflow.p, 0, sizeof(uint32_t), s));
-	if (flat) launch_flat_label_map(d);
-	st.done("k_label_map");
 	const uint32_t chunks = decode_chunks(d);
+	if (chunks > 1) CKL_HIP(hipMemsetAsync(d.d_overflow.p, 0, sizeof(uint32_t), s));      // one chunk: the crack kernel clears it
 	unsigned long long* diag = nullptr;
 	if (getenv("CKL_STRIP_DIAG")) {      // cycle stamps of the strip kernels (adds a sync and a print)
 		d.d_diag.ensure(32);
@@ -2385,7 +2414,9 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 		diag = d.d_diag.p;
 	}
 	if (chunks <= 1 || diag) {
-		launch_cracks(d, s, ca, 0, ns, crack_lds);
+		CrackArgs ca1 = ca;
+		if (chunks <= 1) ca1.overflow = d.d_overflow.p;
+		launch_cracks(d, s, ca1, 0, ns, crack_lds);
 		st.done("k_decode_cracks");
 		launch_strips<OUT>(d, s, g, p, 0, ns, out_device, flat, &st, diag);
 		if (diag) {
@@ -2486,8 +2517,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	const bool lds_raster = !getenv("CKL_NO_LDS_RASTER") &&
 		crack_lds >= crack_lds_seg_bytes(d.lds_controls) + 2ull * d.row_words * sizeof(uint32_t);
 	if (!lds_raster) CKL_HIP(hipMemsetAsync(d.d_planes.p, 0, 2 * d.plane_words * ns * sizeof(uint32_t), s));
-	CKL_HIP(hipMemsetAsync(d.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
-	st.done("memset");
+	if (!lds_raster) st.done("memset");
 
 	CrackArgs ca;
 	ca.stream = d.d_stream.p;
@@ -2511,6 +2541,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ca.planeV = d.d_planes.p; ca.planeH = d.d_planes.p + d.plane_words * ns;
 	ca.row_words = d.row_words; ca.plane_words = d.plane_words;
 	ca.slice_err = d.d_slice_err.p;
+	ca.overflow = nullptr;
 
 	RunGeom g;
 	g.planeV = ca.planeV; g.planeH = ca.planeH; g.row_words = d.row_words; g.plane_words = d.plane_words;

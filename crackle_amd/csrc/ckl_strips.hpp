@@ -84,6 +84,11 @@ struct StripArrays {
 	uint32_t ablate;           // tuning aid (CKL_ABLATE): skips parts of the strip kernels, results are wrong
 };
 
+// strip component of run j of a strip with nsc components: stored in one byte while nsc <= 256
+__device__ __forceinline__ uint32_t strip_lid(const uint16_t* slot_lids, uint32_t nsc, uint32_t j) {
+	return nsc <= 256u ? reinterpret_cast<const uint8_t*>(slot_lids)[j] : slot_lids[j];
+}
+
 // grid = (nstrips, slices of the launch), block = kBlock.  The kernel waits on LDS round trips
 // (union-find), so what counts is the number of resident wavefronts: <= 72 registers and 22 KiB of
 // LDS keep seven workgroups on a CU.  (A persistent variant that fetched the next strip's words
@@ -233,7 +238,10 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 	}
 	__syncthreads();
 	const uint32_t nsc = s_misc[1];
+	// one byte per run while the strip has at most 256 components (strip_lid): the paint kernel reads
+	// them beside its stores, where every byte read costs several bytes' worth of store time
 	uint16_t* lid_out = sa.run_lid + slot;
+	const bool narrow = nsc <= 256u;
 #pragma unroll
 	for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 		const uint32_t j = t + i * kBlock;
@@ -241,7 +249,8 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 		const uint32_t r = root[i];
 		const uint32_t lid = s_bmbase[r >> 5] + __popc(s_bm[r >> 5] & ((1u << (r & 31u)) - 1u));
 		s_pool[j] = static_cast<uint16_t>(lid);
-		lid_out[j] = static_cast<uint16_t>(lid);
+		if (narrow) reinterpret_cast<uint8_t*>(lid_out)[j] = static_cast<uint8_t>(lid);
+		else lid_out[j] = static_cast<uint16_t>(lid);
 	}
 	for (uint32_t j = t; j < nsc; j += kBlock) s_parent[j] = 0u;      // every find is done: the table becomes the weights
 	__syncthreads();
@@ -268,7 +277,12 @@ struct ResolveArgs {
 	const uint32_t* crc_expect;      // [nslices] raw
 	const uint32_t* ncomp_expect;    // [nslices]
 	const uint64_t* comp_off;        // [nslices] first entry of the slice in label_map
-	const uint64_t* label_map;       // component -> label
+	const uint64_t* label_map;       // component -> label (pins: built from the component ids)
+	// flat labels (labels.hpp:453-506): label = uniq[key[component]], read straight from the stream
+	const uint8_t* keys;             // key of the first component of the decoded range
+	const uint8_t* uniq;
+	uint32_t key_width, stored_width, is_signed;
+	uint64_t num_unique;
 	uint32_t has_label;
 	uint64_t label;
 	uint32_t cap;                    // strip components the LDS table holds (<= kResolveCap)
@@ -359,7 +373,7 @@ static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom 
 				const uint32_t m = mask_le(__ffs(c) - 1u);
 				const uint32_t jh = q_wh[u] + __popc(q_bh[u] & m) - 1u, ju = q_wu[u] + __popc(q_bu[u] & m) - 1u;
 				if (jh >= sa.cap || ju >= sa.cap) continue;
-				const uint32_t lh = lid_h[jh], lu = lid_u[ju];
+				const uint32_t lh = strip_lid(lid_h, nsc_h, jh), lu = strip_lid(lid_u, nsc_u, ju);
 				if (lh < nsc_h && lu < nsc_u) sm_unite(s_tab, s_scbase[k] + lh, s_scbase[k - 1u] + lu);
 			}
 		}
@@ -417,7 +431,17 @@ static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom 
 		if (i >= i1) continue;
 		const uint32_t cc = s_tab[root[q]];
 		if (LABELS) {
-			uint64_t val = cc < nexp ? ra.label_map[coff + cc] : 0ull;
+			uint64_t val = 0;
+			if (cc < nexp) {
+				const uint8_t* kp = ra.keys + (coff + cc) * ra.key_width;
+				uint64_t key = 0;
+				for (uint32_t bt = 0; bt < ra.key_width; bt++) key |= static_cast<uint64_t>(kp[bt]) << (8u * bt);
+				if (key < ra.num_unique) {
+					const uint8_t* up = ra.uniq + key * ra.stored_width;
+					for (uint32_t bt = 0; bt < ra.stored_width; bt++) val |= static_cast<uint64_t>(up[bt]) << (8u * bt);
+					if (ra.is_signed && ra.stored_width < 8u && (val >> (8u * ra.stored_width - 1u))) val |= ~0ull << (8u * ra.stored_width);
+				}
+			}
 			if (ra.has_label) val = (val == ra.label);
 			static_cast<OUT*>(sa.sc_label)[gi[q]] = static_cast<OUT>(val);
 		}
@@ -475,7 +499,7 @@ __device__ __forceinline__ uint32_t strip_component_of_pixel(const RunGeom& g, c
 	run += __popc(g.breaks(zi, y, wx) & mask_le(x & 31u)) - 1u;
 	if (run >= nr || run >= sa.cap) return 0xFFFFFFFFu;
 	const uint64_t slot = static_cast<uint64_t>(si) * sa.cap;
-	const uint32_t lid = sa.run_lid[slot + run];
+	const uint32_t lid = strip_lid(sa.run_lid + slot, sa.strip_nsc[si], run);
 	return lid < sa.cap ? sa.sc_cc[slot + lid] : 0xFFFFFFFFu;
 }
 
