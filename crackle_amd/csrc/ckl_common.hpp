@@ -106,6 +106,15 @@ struct Header {
 		return byte_width(v);
 	}
 	uint64_t voxels() const { return static_cast<uint64_t>(sx) * sy * sz; }
+	// True when header, z-index, label section, markov model and the crc tail fit into n bytes.
+	// The fields come from an untrusted stream (the crc8 is trivially forged): nothing is summed
+	// that could wrap — the fixed parts are at most a few times 2^34, num_label_bytes is compared by
+	// subtraction.  After this every offset below num_label_bytes / n is safe to add.
+	bool layout_fits(uint64_t n) const {
+		const uint64_t tail = format_version == 0 ? 0 : 4ull * (static_cast<uint64_t>(sz) + 1);
+		const uint64_t fixed = header_bytes() + grid_index_bytes() + markov_model_bytes() + tail;
+		return fixed <= n && num_label_bytes <= n - fixed;
+	}
 };
 
 // ---- device buffers -------------------------------------------------------------

@@ -1953,7 +1953,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 
 	const uint64_t hb = h.header_bytes(), gib = h.grid_index_bytes();
 	const uint64_t tail = h.format_version == 0 ? 0 : 4ull * (static_cast<uint64_t>(h.sz) + 1);
-	if (hb + gib + h.num_label_bytes + h.markov_model_bytes() + tail > n) {
+	if (!h.layout_fits(n)) {      // no sum of untrusted fields that could wrap
 		throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_code_offsets: Unable to read past end of buffer.");
 	}
 	// z-index (crackle.hpp:262-313)
@@ -1967,7 +1967,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	std::vector<uint64_t> z_index(static_cast<size_t>(h.sz) + 1);
 	z_index[0] = hb + gib + h.num_label_bytes + h.markov_model_bytes();
 	for (uint64_t z = 0; z < h.sz; z++) z_index[z + 1] = z_index[z] + rd_le(buf + hb + 4 * z, 4);
-	if (z_index[h.sz] + tail > n) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
+	if (z_index[h.sz] > n || tail > n - z_index[h.sz]) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
 
 	hipStream_t s = d.stream;
 	// the whole stream goes to HBM once
@@ -2089,7 +2089,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		if (nlb < 8) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
 		d.num_unique = rd_le(lb, 8);
 		d.uniq_offset = 8;
-		if (d.num_unique > nlb / sw) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+		if (d.num_unique > (nlb - 8) / sw) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
 		offset = 8 + static_cast<uint64_t>(sw) * d.num_unique;
 	}
 	else if (h.label_format == PINS_VARIABLE_WIDTH) {
@@ -2097,13 +2097,13 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		d.bgcolor = read_stored(h, lb, 0);
 		d.num_unique = rd_le(lb + sw, 8);
 		d.uniq_offset = static_cast<uint64_t>(sw) + 8;
-		if (d.num_unique > nlb / sw) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+		if (d.num_unique > (nlb - 8 - static_cast<uint64_t>(sw)) / sw) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
 		offset = 8 + static_cast<uint64_t>(sw) * (d.num_unique + 1);
 	}
 	else {
 		throw Error(CKL_ERR_RUNTIME, "crackle: Unsupported label format. Got: " + std::to_string(h.label_format));
 	}
-	if (offset + static_cast<uint64_t>(component_width) * h.sz > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+	if (offset > nlb || static_cast<uint64_t>(component_width) * h.sz > nlb - offset) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
 	std::vector<uint64_t> comp_prefix(static_cast<size_t>(h.sz) + 1, 0);
 	for (uint64_t z = 0; z < h.sz; z++) {
 		comp_prefix[z + 1] = comp_prefix[z] + rd_le(lb + offset + z * component_width, component_width);
@@ -2170,7 +2170,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	if (h.label_format == FLAT) {
 		d.key_width = byte_width(d.num_unique);
 		d.keys_offset = hb + gib + offset;
-		if (offset + comp_prefix[h.sz] * static_cast<uint64_t>(d.key_width) > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+		if (offset > nlb || comp_prefix[h.sz] > (nlb - offset) / static_cast<uint64_t>(d.key_width)) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
 	}
 	else {
 		if (offset + 1 > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");

@@ -810,6 +810,8 @@ std::vector<uint8_t> encode_pins_host(
 
 constexpr uint32_t kTrailStreams = 8;
 
+struct VolumeStats { uint64_t max_label = 0, pairs = 0, first = 0, last = 0; };
+
 struct ckl_encoder {
 	int device = 0;
 	hipStream_t stream = nullptr;      // crack codes
@@ -856,6 +858,7 @@ struct ckl_encoder {
 	// label planes left by ckl_encoder_stats for the ckl_encoder_run that follows on the same
 	// volume (the sharded encoder: stats -> all-gather -> run with the agreed formats)
 	const void* planes_for = nullptr;
+	VolumeStats planes_stats;          // max / pairs of the volume the cached planes were built from
 	int64_t planes_dims[3] = { 0, 0, 0 };
 	std::vector<uint64_t> h_rbase;
 	std::vector<uint32_t> h_rcap;
@@ -907,7 +910,6 @@ std::vector<T> download(const T* p, size_t n, hipStream_t s) {
 	return h;
 }
 
-struct VolumeStats { uint64_t max_label = 0, pairs = 0, first = 0, last = 0; };
 
 template <typename LABEL>
 VolumeStats volume_stats(ckl_encoder& e, const LABEL* labels, uint64_t voxels) {
@@ -1488,6 +1490,7 @@ void encode_typed(
 		&& e.planes_dims[0] == sx && e.planes_dims[1] == sy && e.planes_dims[2] == sz;
 	e.planes_for = nullptr;       // single use: the caller may change the volume afterwards
 	if (voxels > 0 && !planes_cached) planes_pass<LABEL>(e, labels, sx, sy, sz, &st);
+	else if (planes_cached) st = e.planes_stats;      // overrides that force nothing still decide from the volume
 	ht.mark("planes");
 	int stored_width = byte_width(st.max_label);                     // crackle.hpp:233-235
 	if (ov && ov->force_stored_width) stored_width = ov->force_stored_width;
@@ -1687,11 +1690,11 @@ void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int devic
 	const uint64_t sz = head.sz;
 	const uint64_t off_index = head.header_bytes();
 	const uint64_t off_labels = off_index + head.grid_index_bytes();
+	if (!head.layout_fits(n)) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_code_offsets: Unable to read past end of buffer.");      // no sum of untrusted fields that could wrap
 	const uint64_t old_codes = off_labels + head.num_label_bytes + head.markov_model_bytes();
-	if (old_codes + 4 * (sz + 1) > n) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_code_offsets: Unable to read past end of buffer.");
 	uint64_t old_tail = old_codes;
 	for (uint64_t z = 0; z < sz; z++) old_tail += rd_le(buf + off_index + 4 * z, 4);
-	if (old_tail + 4 * (sz + 1) > n) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
+	if (old_tail > n || 4 * (sz + 1) > n - old_tail) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
 
 	const bool prof = getenv("CKL_PROFILE") != nullptr;
 	auto t_prev = std::chrono::steady_clock::now();
@@ -1891,6 +1894,7 @@ int ckl_encoder_stats(
 			CKL_HIP(hipMemcpy(&l, base + (voxels - 1) * e->dtype_bytes, e->dtype_bytes, hipMemcpyDeviceToHost));
 			st.first = f; st.last = l;
 			e->planes_for = labels_device;
+			e->planes_stats = st;
 			e->planes_dims[0] = sx; e->planes_dims[1] = sy; e->planes_dims[2] = sz;
 		}
 		if (max_label) *max_label = st.max_label;

@@ -40,14 +40,14 @@ Slab parse_slab(const uint8_t* buf, uint64_t n) {
 	if (h.voxels() == 0) throw Error(CKL_ERR_ARG, "crackle_amd: zstack of an empty slab");
 	const uint64_t hb = h.header_bytes(), gib = h.grid_index_bytes();
 	const uint64_t tail = 4ull * (static_cast<uint64_t>(h.sz) + 1);
-	if (hb + gib + h.num_label_bytes + h.markov_model_bytes() + tail > n) throw Error(CKL_ERR_RUNTIME, "crackle: Unable to read past end of buffer.");
+	if (!h.layout_fits(n)) throw Error(CKL_ERR_RUNTIME, "crackle: Unable to read past end of buffer.");      // no sum of untrusted fields that could wrap
 	s.z_index = buf + hb;
 	s.labels = buf + hb + gib;
 	const int sw = h.stored_data_width;
 	const int cw = byte_width(static_cast<uint64_t>(h.sx) * h.sy);
 	if (h.num_label_bytes < 8) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
 	s.num_unique = rd_le(s.labels, 8);
-	if (8 + s.num_unique * sw + static_cast<uint64_t>(cw) * h.sz > h.num_label_bytes) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+	if (static_cast<uint64_t>(cw) * h.sz > h.num_label_bytes - 8 || s.num_unique > (h.num_label_bytes - 8 - static_cast<uint64_t>(cw) * h.sz) / sw) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
 	s.uniq.resize(s.num_unique);
 	for (uint64_t i = 0; i < s.num_unique; i++) s.uniq[i] = rd_le(s.labels + 8 + i * sw, sw);
 	s.comp = s.labels + 8 + s.num_unique * sw;
@@ -55,7 +55,7 @@ Slab parse_slab(const uint8_t* buf, uint64_t n) {
 	for (uint64_t z = 0; z < h.sz; z++) s.total_comp += rd_le(s.comp + z * cw, cw);
 	s.keys = s.comp + static_cast<uint64_t>(cw) * h.sz;
 	const int kw = byte_width(s.num_unique);
-	if (static_cast<uint64_t>(s.keys - s.labels) + s.total_comp * kw > h.num_label_bytes) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
+	if (s.total_comp > (h.num_label_bytes - static_cast<uint64_t>(s.keys - s.labels)) / kw) throw Error(CKL_ERR_RUNTIME, "crackle: label section is malformed or corrupted.");
 	s.model = s.labels + h.num_label_bytes;
 	s.cracks = s.model + h.markov_model_bytes();
 	uint64_t cb = 0;

@@ -174,7 +174,10 @@ class _SharedOutput:
     self._reg_base = None
     obj = [None]
     if rank == 0:
-      obj[0] = f"/dev/shm/ckl_amd_{os.getpid()}_{id(self) & 0xFFFF:x}"
+      # a name nobody else has (two mappings of one codec, or two codecs, must never share a file)
+      import tempfile
+      fd, obj[0] = tempfile.mkstemp(prefix="ckl_amd_", dir="/dev/shm")
+      os.close(fd)
     dist.broadcast_object_list(obj, src=0)
     self.path = obj[0]
     self.cap = 0
@@ -439,10 +442,12 @@ class ShardedCodec:
     voxels_local = sx * sy * sz
     # 1. whole-volume reductions: pixel_pairs (linear, crosses slab boundaries) and max label
     mx, pairs, first, last = be.stats(vol, slab_shape)
-    mine = torch.tensor([pairs, mx, first, last, voxels_local], dtype=torch.int64, device=self.device)
+    # uint64 labels travel as their int64 bit patterns (labels >= 2^63 do not fit torch.int64 as values)
+    mine_np = np.array([pairs, mx, first, last, voxels_local], dtype=np.uint64).view(np.int64)
+    mine = torch.from_numpy(mine_np).to(self.device)
     everyone = [torch.empty_like(mine) for _ in range(self.world)]
     dist.all_gather(everyone, mine)
-    table = torch.stack(everyone).cpu().numpy().astype(np.uint64)
+    table = torch.stack(everyone).cpu().numpy().view(np.uint64)
     tot_pairs = int(table[:, 0].sum())
     nonempty = [r for r in range(self.world) if table[r, 4] > 0]
     for a, b in zip(nonempty[:-1], nonempty[1:]):
@@ -538,14 +543,18 @@ class ShardedCodec:
       all_u = [torch.empty_like(mine_u) for _ in range(self.world)]
       dist.all_gather(all_u, mine_u)
       mark("gathers")
-      merged = torch.unique(torch.cat([all_u[r][:int(table[r, 0])].to(cdev) for r in range(self.world)]))   # sorted
+      # labels are uint64 bit patterns in int64 tensors: flipping the sign bit maps the unsigned
+      # order onto the signed one (labels >= 2^63 must sort last, labels.hpp:92-121)
+      sign = torch.tensor(-(1 << 63), dtype=torch.int64, device=cdev)
+      merged_t = torch.unique(torch.cat([all_u[r][:int(table[r, 0])].to(cdev) for r in range(self.world)]) ^ sign)   # sorted as unsigned
+      merged = merged_t ^ sign
       n_merged = int(merged.numel())
       kw = _byte_width(n_merged)
     if not early_merge and not use_pins and sec.n_keys:
       # keys -> positions in the merged list, packed at their new width, all on `dev`: the only
       # host work is the copy of the packed bytes into the shared buffer
       signed = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
-      remap = torch.searchsorted(merged, mine_u[:len(sec.uniq)].to(cdev))
+      remap = torch.searchsorted(merged_t, mine_u[:len(sec.uniq)].to(cdev) ^ sign)
       raw = torch.from_numpy(np.array(sec.keys_raw, copy=True)).to(cdev)
       old = raw.view(signed[sec.key_width]).to(torch.int64)
       if sec.key_width in (2, 4):
@@ -646,7 +655,7 @@ class ShardedCodec:
       if use_pins:
         out[o_labels:o_labels + label_bytes] = pins_section
       else:
-        uniq_g = sec.uniq if early_merge else merged.cpu().numpy()
+        uniq_g = sec.uniq if early_merge else merged.cpu().numpy()      # int64 bit patterns, ascending as uint64
         out[o_labels:o_labels + 8] = np.frombuffer(np.array([len(uniq_g)], dtype="<u8").tobytes(), dtype=np.uint8)
         out[o_labels + 8:o_comp] = _pack(uniq_g, sw)
       out[o_model:o_cracks] = sec.model

@@ -158,3 +158,31 @@ def test_zstack_rejects_mismatched_slabs(port):
   b = port.compress(np.ones((8, 9, 2), np.uint8, order="F"))
   with pytest.raises(RuntimeError):
     _zstack([a, b])
+
+
+def _forge(stream: bytes, num_label_bytes: int) -> bytes:
+  """The stream with a forged num_label_bytes and a matching crc8 (crc.hpp:23-37: the header's
+  own checksum is no protection against a hostile stream)."""
+  b = bytearray(stream)
+  b[20:28] = int(num_label_bytes & (2**64 - 1)).to_bytes(8, "little")
+  crc = 0xFF
+  for x in b[5:28]:
+    crc ^= x
+    for _ in range(8):
+      crc = ((crc >> 1) ^ 0xE7) if (crc & 1) else (crc >> 1)
+  b[28] = crc
+  return bytes(b)
+
+
+@pytest.mark.parametrize("nlb", [2**64 - 1, 2**64 - 29, 2**64 - 200, 2**63, 2**40, 10**6])
+def test_forged_label_section_length_is_refused_by_the_host_parsers(nlb):
+  """Offsets taken from the header must not be summed until each is known to lie inside the
+  buffer: a num_label_bytes close to 2^64 made the old `a + b + c > n` checks wrap."""
+  import crackle_amd.operations as ops
+  good = golden()["c0_voronoi_u8"]
+  bad = _forge(good, nlb)
+  assert crackle_amd.header(bad).num_label_bytes == nlb      # the forged header itself parses
+  with pytest.raises(ValueError, match="past end of buffer|malformed"):
+    ops.zstack([bad, good])
+  with pytest.raises(ValueError, match="past end of buffer|malformed"):
+    ops.zsplit(bad, 3)

@@ -39,6 +39,13 @@ def _volume(kind):
     return synth.random_labels((48, 40, 6), np.uint32, seed=3, high=2000)
   if kind == "constant":
     return np.full((40, 30, 4), 5, np.uint8, order="F")
+  if kind == "u64":
+    # C3's label type: stored width 8, labels above 2^40 and two above 2^63 (one per slab):
+    # nothing on the way may treat them as signed values
+    v = synth.as_numpy_f(synth.voronoi_labels((64, 48, 8), np.uint64, seed=8, cell=(16, 16, 4), offset=1 << 40)).copy(order="F")
+    v[5:11, 7:12, 1] = (1 << 63) + 5
+    v[20:26, 30:33, 6] = (1 << 64) - 1
+    return v
   raise ValueError(kind)
 
 
@@ -64,7 +71,7 @@ def _worker(rank, port, kind, order, q, pins=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,order", [("voronoi", 0), ("voronoi", 3), ("wide_labels", 0), ("noise", 2), ("constant", 4)])
+@pytest.mark.parametrize("kind,order", [("voronoi", 0), ("voronoi", 3), ("wide_labels", 0), ("noise", 2), ("constant", 4), ("u64", 0), ("u64", 5)])
 def test_sharded_compress_equals_whole_volume(port, kind, order):
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
@@ -86,7 +93,7 @@ def test_sharded_compress_equals_whole_volume(port, kind, order):
   assert results[0][1] and results[1][1], "a rank decoded its z-range wrongly"
 
 
-@pytest.mark.parametrize("kind,order", [("voronoi", 0), ("voronoi", 2), ("wide_labels", 0), ("noise", 0)])
+@pytest.mark.parametrize("kind,order", [("voronoi", 0), ("voronoi", 2), ("wide_labels", 0), ("noise", 0), ("u64", 5)])
 def test_sharded_pins_equal_whole_volume(port, kind, order):
   """allow_pins across slabs: columns cross the slab boundary, component ids are numbered over
   the whole volume and the host cover runs once on rank 0; PERMISSIBLE volumes fall back to

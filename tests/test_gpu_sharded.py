@@ -34,6 +34,15 @@ def _volume(kind):
     return v
   if kind == "noise":
     return synth.random_labels((96, 80, 6), np.uint32, seed=43, high=2000)
+  if kind == "u64":
+    # C3's label type: stored width 8, labels above 2^40 and two above 2^63, one per slab
+    v = synth.as_numpy_f(synth.voronoi_labels((1024, 64, 8), np.uint64, seed=44, cell=(32, 32, 4), offset=1 << 40)).copy(order="F")
+    v[5:11, 7:12, 1] = (1 << 63) + 5
+    v[200:260, 30:33, 6] = (1 << 64) - 1
+    return v
+  if kind == "c4":
+    # C4's slice shape: 2048 x 2048 (x_width = y_width = 2, component_width = 4)
+    return synth.as_numpy_f(synth.voronoi_labels((2048, 2048, 4), np.uint32, seed=45, cell=(32, 32, 8)))
   raise ValueError(kind)
 
 
@@ -48,7 +57,8 @@ def _worker(rank, port, kind, order, pins, q):
     sx, sy, sz = vol.shape
     szl = sz // WORLD
     dev = torch.device("cuda", 0)
-    slab = torch.from_numpy(np.ascontiguousarray(vol[:, :, rank * szl:(rank + 1) * szl].transpose(2, 1, 0)).view(np.int32)).to(dev)
+    signed = {1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[vol.dtype.itemsize]
+    slab = torch.from_numpy(np.ascontiguousarray(vol[:, :, rank * szl:(rank + 1) * szl].transpose(2, 1, 0)).view(signed)).to(dev)
     codec = ckd.ShardedCodec(ckd.HipBackend(0, zero_copy=True), rank=rank, world=WORLD, device="cpu", compute_device=dev)
     binary = None
     for _ in range(2):      # the second call reuses the shared mapping
@@ -66,6 +76,8 @@ def _worker(rank, port, kind, order, pins, q):
   ("voronoi", 0, False, None), ("voronoi", 3, False, None), ("wide", 0, False, None), ("noise", 0, False, None), ("voronoi", 0, True, None),
   ("wide", 0, False, "CKL_SHARDED_LEGACY"),      # unique labels exchanged after the slab encode
   ("voronoi", 0, False, "CKL_TEST_MERGE_FAIL"),  # the in-encode exchange fails on every rank: fallback
+  ("u64", 0, False, None), ("u64", 5, False, "CKL_SHARDED_LEGACY"), ("u64", 5, True, None),      # BASELINE.json configs[3]: uint64 labels
+  ("voronoi", 5, True, None), ("c4", 5, True, None), ("c4", 5, False, None),                       # configs[4]: pins + markov order 5, 2048 x 2048
 ])
 def test_sharded_hip_backend_equals_whole_volume(checker, kind, order, pins, env, monkeypatch):
   if env:
