@@ -51,7 +51,35 @@ def build(force=False, verbose=True):
     if verbose:
       print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+  build_fastcrackle(force=force, verbose=verbose)
   return LIB
+
+
+def fastcrackle_path():
+  import sysconfig
+  return os.path.join(HERE, "fastcrackle" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_fastcrackle(force=False, verbose=True):
+  """crackle_amd/fastcrackle*.so: the reference's pybind11 module (src/fastcrackle.cpp:641-669,
+  same names and positional arguments) on top of the C-ABI; host code only (g++), linked against
+  libcrackle_amd.so next to it ($ORIGIN rpath)."""
+  import sysconfig
+  import pybind11
+  src = os.path.join(CSRC, "fastcrackle.cpp")
+  out = fastcrackle_path()
+  deps = [src, os.path.normpath(os.path.join(CSRC, "..", "..", "include", "crackle_amd.h")), LIB]
+  if not (force or _stale(out, deps)):
+    return out
+  cmd = [
+    os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+    f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
+    src, "-o", out, f"-L{HERE}", "-lcrackle_amd", "-Wl,-rpath,$ORIGIN",
+  ]
+  if verbose:
+    print(" ".join(cmd), flush=True)
+  subprocess.run(cmd, check=True)
+  return out
 
 
 if __name__ == "__main__":

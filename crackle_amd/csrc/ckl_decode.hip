@@ -2828,8 +2828,12 @@ int ckl_decoder_vcg(ckl_decoder* d, uint8_t* out_device, uint64_t out_capacity_b
 }
 
 int ckl_voxel_connectivity_graph(const uint8_t* buf, uint64_t n, int connectivity, int device, uint8_t* out_host, uint64_t out_capacity_bytes) {
+	return ckl_voxel_connectivity_graph_range(buf, n, 0, -1, connectivity, device, out_host, out_capacity_bytes);
+}
+
+int ckl_voxel_connectivity_graph_range(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, int connectivity, int device, uint8_t* out_host, uint64_t out_capacity_bytes) {
 	ckl_decoder* d = nullptr;
-	int rc = ckl_decoder_create(buf, n, 0, -1, device, &d);
+	int rc = ckl_decoder_create(buf, n, z_start, z_end, device, &d);
 	if (rc != CKL_OK) return rc;
 	try {
 		const uint64_t need = d->sxy * d->nslices;

@@ -137,9 +137,11 @@ int ckl_decoder_check(ckl_decoder* d, uint32_t* slice_errors, uint64_t capacity)
  * bit1 -x, bit2 +y, bit3 -y (from the crack planes), and for connectivity 6 bit4 +z / bit5 -z
  * where neighbouring slices carry the same label (first slice -z and last slice +z always set).
  * ckl_decoder_vcg writes into a DEVICE buffer; ckl_voxel_connectivity_graph is the one-shot
- * form over the whole volume with a HOST buffer of sx*sy*sz bytes. */
+ * form over the whole volume with a HOST buffer of sx*sy*sz bytes, ckl_voxel_connectivity_graph_range
+ * the same for slices [z_start, z_end) (z_end < 0: to the end), like the reference's binding. */
 int ckl_decoder_vcg(ckl_decoder* d, uint8_t* out_device, uint64_t out_capacity_bytes, int connectivity);
 int ckl_voxel_connectivity_graph(const uint8_t* buf, uint64_t n, int connectivity, int device, uint8_t* out_host, uint64_t out_capacity_bytes);
+int ckl_voxel_connectivity_graph_range(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, int connectivity, int device, uint8_t* out_host, uint64_t out_capacity_bytes);
 
 /* Per-label statistics of the decoder's z-range without materialising the volume:
  * replaces crackle::operations::voxel_counts / centroids / bounding_boxes
