@@ -31,6 +31,7 @@ constexpr uint32_t kStripWords = 1024;      // plane words per strip: 4 per thre
 constexpr uint32_t kStripCap = 2560;        // runs per strip held in LDS (the host sizes the strips for ~0.7 of it)
 constexpr uint32_t kStripRunsPerThread = kStripCap / kBlock;
 constexpr uint32_t kStripBitmapWords = kStripCap / 32;
+constexpr uint32_t kStripEdgeCap = kStripWords + kStripCap / 2;      // 32-bit words of the break words + the 16-bit run pool
 constexpr uint32_t kStripOverflow = 0xFFFFFFFFu;
 constexpr int kResolveBlock = 1024;
 constexpr uint32_t kResolveCap = 12288;     // strip components per slice held in LDS
@@ -96,9 +97,10 @@ __device__ __forceinline__ uint32_t strip_lid(const uint16_t* slot_lids, uint32_
 template <bool DIAG>
 static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, StripArrays sa, const uint32_t* __restrict__ G, uint32_t n_pixels, unsigned long long* __restrict__ diag) {
 	__shared__ uint32_t s_parent[kStripCap];          // union-find, then the crc weights per strip component
-	__shared__ uint32_t s_b[kStripWords];             // break words of the strip
+	__shared__ uint32_t s_mem[kStripEdgeCap];         // s_b | s_pool, and over both of them the edge list of the unions
 	__shared__ uint16_t s_wb[kStripWords];            // runs before each word
-	__shared__ uint16_t s_pool[kStripCap];            // first pixel of each run (relative to the strip), later its strip component
+	uint32_t* s_b = s_mem;                                                        // break words of the strip
+	uint16_t* s_pool = reinterpret_cast<uint16_t*>(s_mem + kStripWords);          // first pixel of each run (relative to the strip), later its strip component
 	__shared__ uint32_t s_bm[kStripBitmapWords], s_bmbase[kStripBitmapWords];
 	__shared__ uint32_t s_scan[kWaves];
 	__shared__ uint32_t s_misc[2];
@@ -202,19 +204,46 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 			if (wl + rw >= nw) sa.seam_last[static_cast<uint64_t>(si) * rw + (wl + rw - nw)] = wbv;
 		}
 	}
-	// ---- unions between vertically adjacent runs of the strip (first contact of each pair)
+	// ---- unions between vertically adjacent runs of the strip (first contact of each pair).
+	// The contacts are spread unevenly over the words (0 .. 6 each): they are first written out as a
+	// list of (run, run above) pairs, over the break words and the run pool, which nobody needs any
+	// more, and then dealt out evenly, so that a wavefront does not wait for its busiest lane.
+	{
+		uint32_t c[4], b_up[4], base_up[4], base_here[4], n_e = 0;
 #pragma unroll
-	for (uint32_t j = 0; j < 4; j++) {
-		const uint32_t wl = t * 4u + j;
-		if (!up[j] || (sa.ablate & 1u)) continue;
-		const uint32_t b_here = b[j], b_up = s_b[wl - rw];
-		const uint32_t base_here = s_wb[wl], base_up = s_wb[wl - rw];
-		for (uint32_t c = up[j] & (~((up[j] << 1) | (upl[j] >> 31)) | b_here | b_up); c; c &= c - 1u) {
-			const uint32_t m = mask_le(__ffs(c) - 1u);
-			sm_unite(s_parent, base_here + __popc(b_here & m) - 1u, base_up + __popc(b_up & m) - 1u);
+		for (uint32_t j = 0; j < 4; j++) {
+			const uint32_t wl = t * 4u + j;
+			const uint32_t above = up[j] ? wl - rw : 0u;
+			b_up[j] = s_b[above]; base_up[j] = s_wb[above]; base_here[j] = s_wb[wl < nw ? wl : 0u];
+			c[j] = (sa.ablate & 1u) ? 0u : up[j] & (~((up[j] << 1) | (upl[j] >> 31)) | b[j] | b_up[j]);
+			n_e += __popc(c[j]);
+		}
+		uint32_t ve[1] = { n_e }, te[1];
+		block_excl_add<1>(ve, te, s_scan);      // its barriers: every read of s_b / s_pool is done
+		const uint32_t n_edges = te[0];
+		if (n_edges <= kStripEdgeCap) {      // uniform
+			uint32_t at = ve[0];
+#pragma unroll
+			for (uint32_t j = 0; j < 4; j++) {
+				for (uint32_t cc = c[j]; cc; cc &= cc - 1u) {
+					const uint32_t m = mask_le(__ffs(cc) - 1u);
+					s_mem[at++] = (base_here[j] + __popc(b[j] & m) - 1u) | ((base_up[j] + __popc(b_up[j] & m) - 1u) << 16);
+				}
+			}
+			__syncthreads();
+			for (uint32_t e = t; e < n_edges; e += kBlock) { const uint32_t pr = s_mem[e]; sm_unite(s_parent, pr & 0xFFFFu, pr >> 16); }
+		}
+		else {
+#pragma unroll
+			for (uint32_t j = 0; j < 4; j++) {
+				for (uint32_t cc = c[j]; cc; cc &= cc - 1u) {
+					const uint32_t m = mask_le(__ffs(cc) - 1u);
+					sm_unite(s_parent, base_here[j] + __popc(b[j] & m) - 1u, base_up[j] + __popc(b_up[j] & m) - 1u);
+				}
+			}
 		}
 	}
-	__syncthreads();      // also: every s_pool[] start has been read, the pool now takes the strip components
+	__syncthreads();      // the pool now takes the strip components
 	stamp(2);
 	// ---- roots -> strip-local component ids in run order
 	uint32_t root[kStripRunsPerThread];

@@ -73,10 +73,11 @@ py::array decompress(const py::buffer buffer, int64_t z_start, int64_t z_end, si
 	const std::vector<py::ssize_t> shape = { static_cast<py::ssize_t>(voxels) };
 	py::array arr(unsigned_dtype(width), shape);
 	if (voxels == 0) return arr;
+	void* dst = arr.mutable_data();
 	int rc;
 	{
 		py::gil_scoped_release nogil;
-		rc = ckl_decompress(s.p, s.n, arr.mutable_data(), voxels * width, CKL_MEM_HOST, zs, ze, label.has_value() ? 1 : 0, label.value_or(0), device());
+		rc = ckl_decompress(s.p, s.n, dst, voxels * width, CKL_MEM_HOST, zs, ze, label.has_value() ? 1 : 0, label.value_or(0), device());
 	}
 	check(rc);
 	return arr;
@@ -92,10 +93,13 @@ py::bytes compress(
 	const int64_t sz = labels.ndim() < 3 ? 1 : labels.shape(2);
 	uint8_t* out = nullptr;
 	uint64_t n = 0;
+	const void* data = labels.data();
+	const int width = static_cast<int>(labels.dtype().itemsize());
+	const int is_signed = labels.dtype().kind() == 'i' ? 1 : 0;
 	int rc;
 	{
-		py::gil_scoped_release nogil;
-		rc = ckl_compress(labels.data(), CKL_MEM_HOST, static_cast<int>(labels.dtype().itemsize()), labels.dtype().kind() == 'i' ? 1 : 0,
+		py::gil_scoped_release nogil;      // nothing below touches a Python object
+		rc = ckl_compress(data, CKL_MEM_HOST, width, is_signed,
 			sx, sy, sz, allow_pins ? 1 : 0, fortran_order ? 1 : 0, markov_model_order, optimize_pins ? 1 : 0, auto_bgcolor ? 1 : 0, manual_bgcolor,
 			device(), &out, &n);
 	}
