@@ -85,6 +85,8 @@ EXPORTS = {
   "ckl_encoder_codes_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
   "ckl_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
   "ckl_host_unregister": (C.c_int, [C.c_void_p]),
+  "ckl_array_equal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_int)]),
+  "ckl_mode_pooling_2x2x1": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_crc32c": (C.c_uint32, [C.c_void_p, C.c_uint64]),
   "ckl_crc32c_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint64]),
 }

@@ -1827,6 +1827,46 @@ __global__ void __launch_bounds__(kBlock) k_check(
 	if (e) atomicOr(slice_err + zi, e);
 }
 
+// ------------------------------------------------------------------------------
+// array_equal (operations.hpp:1039-1184) and mode_pooling_2x2x1 (operations.hpp:1201-1304)
+// ------------------------------------------------------------------------------
+// one flag: do two device buffers differ anywhere (16 bytes per thread and step, tail by bytes)
+__global__ void __launch_bounds__(kBlock) k_buffers_differ(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t n, uint32_t* __restrict__ differ) {
+	const uint64_t nv = n / 16;
+	uint32_t bad = 0;
+	for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < nv; i += static_cast<uint64_t>(gridDim.x) * kBlock) {
+		const uint4 x = reinterpret_cast<const uint4*>(a)[i], y = reinterpret_cast<const uint4*>(b)[i];
+		bad |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 15u)) bad |= a[nv * 16 + threadIdx.x] ^ b[nv * 16 + threadIdx.x];
+	if (bad) atomicOr(differ, 1u);
+}
+
+// the reference's 2 x 2 pooling rule (operations.hpp:1254-1290): a == b -> a, a == c -> a, b == c -> b,
+// else d; the last column / row of an odd-sized slice is copied.  in: x fastest, one slice after the other
+template <typename LABEL>
+__global__ void __launch_bounds__(kBlock) k_mode_pool_2x2(const LABEL* __restrict__ in, LABEL* __restrict__ out, uint32_t sx, uint32_t sy, uint32_t nslices) {
+	const uint32_t osx = (sx + 1u) >> 1, osy = (sy + 1u) >> 1;
+	const uint64_t osxy = static_cast<uint64_t>(osx) * osy, sxy = static_cast<uint64_t>(sx) * sy;
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	if (i >= osxy * nslices) return;
+	const uint32_t z = static_cast<uint32_t>(i / osxy);
+	const uint32_t r = static_cast<uint32_t>(i - z * osxy);
+	const uint32_t oy = r / osx, ox = r - oy * osx;
+	const LABEL* src = in + z * sxy;
+	const uint32_t x = 2u * ox, y = 2u * oy;
+	const bool has_x = x + 1u < sx, has_y = y + 1u < sy;
+	const LABEL a = src[x + static_cast<uint64_t>(sx) * y];
+	LABEL v = a;
+	if (has_x && has_y) {
+		const LABEL b = src[x + 1u + static_cast<uint64_t>(sx) * y];
+		const LABEL c = src[x + static_cast<uint64_t>(sx) * (y + 1u)];
+		const LABEL dd = src[x + 1u + static_cast<uint64_t>(sx) * (y + 1u)];
+		v = (a == b) ? a : (a == c) ? a : (b == c) ? b : dd;
+	}
+	out[i] = v;
+}
+
 }  // namespace ckl
 
 // ------------------------------------------------------------------------------
@@ -1887,6 +1927,9 @@ struct ckl_decoder {
 	DevBuf<uint64_t> d_sc_label;        // typed on use
 	DevBuf<unsigned long long> d_diag;
 	bool strip_ok = false;              // shape / layout qualify for the strip path
+	const uint64_t* foreign_label_map = nullptr;   // array_equal: component -> label table of ANOTHER stream (same component counts)
+	int paint_width = 0;                // array_equal: bytes per painted voxel when it is not this stream's data width
+	std::vector<uint32_t> ncomp_expect_host;       // components per slice of the range, as the label section states them
 	bool use_general = false;           // a run overflowed the strip path's LDS tables: stay on the general pipeline
 	uint32_t strip_rows = 0, nstrips = 0, strip_cap = 0;
 	uint64_t rtot = 0;                  // entries of the general pipeline's per-run arrays (allocated when it runs)
@@ -2124,6 +2167,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	}
 	upload(d.d_comp_off, comp_off, s);
 	upload(d.d_ncomp_expect, ncomp_expect, s);
+	d.ncomp_expect_host = ncomp_expect;
 	d.d_label_map.ensure(d.total_comp + 1);
 
 	// crc machinery: geometric-sum table G[m] = x^32 + ... + x^(32 m), component ids are
@@ -2292,8 +2336,9 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	hipStream_t s = d.stream;
 	const uint32_t ns = d.nslices;
 	OUT* run_label = reinterpret_cast<OUT*>(d.d_run_label.p);
-	const bool flat = h.label_format == FLAT;
-	if (flat) launch_flat_label_map(d);
+	const bool foreign = d.foreign_label_map != nullptr;      // the table of another stream: nothing to build
+	const bool flat = h.label_format == FLAT || foreign;
+	if (flat && !foreign) launch_flat_label_map(d);
 	if (flat) st.done("k_label_map");
 	ResolveScratch rs;
 	rs.run_local = d.d_run_local.p; rs.blk_roots = d.d_blk_roots.p; rs.nblk = (d.max_rcap + kBlock - 1) / kBlock;
@@ -2302,7 +2347,7 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
 	st.done("k_run_rank");
 	RunLabelArgs la;
-	la.label_map = d.d_label_map.p; la.comp_off = d.d_comp_off.p; la.ncomp_expect = d.d_ncomp_expect.p;
+	la.label_map = foreign ? d.foreign_label_map : d.d_label_map.p; la.comp_off = d.d_comp_off.p; la.ncomp_expect = d.d_ncomp_expect.p;
 	la.has_label = has_label ? 1u : 0u; la.label = label; la.run_label = run_label;
 	if (flat) {
 		hipLaunchKernelGGL((k_run_assign<OUT, true>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
@@ -2489,10 +2534,13 @@ void general_pipeline(ckl_decoder& d, const RunGeom& g, RunArrays& ra, void* out
 		st.done("k_run_union_seams");
 	}
 	if (stats || check_only) launch_resolve_and_stats(d, g, ra, st, stats);
-	else if (has_label || h.data_width == 1) launch_resolve_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
-	else if (h.data_width == 2) launch_resolve_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
-	else if (h.data_width == 4) launch_resolve_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
-	else launch_resolve_and_paint<uint64_t>(d, g, ra, out_device, has_label, label, st);
+	else {
+		const int dw = d.paint_width ? d.paint_width : h.data_width;
+		if (has_label || dw == 1) launch_resolve_and_paint<uint8_t>(d, g, ra, out_device, has_label, label, st);
+		else if (dw == 2) launch_resolve_and_paint<uint16_t>(d, g, ra, out_device, has_label, label, st);
+		else if (dw == 4) launch_resolve_and_paint<uint32_t>(d, g, ra, out_device, has_label, label, st);
+		else launch_resolve_and_paint<uint64_t>(d, g, ra, out_device, has_label, label, st);
+	}
 
 	hipLaunchKernelGGL(k_check, dim3((ns + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
 		d.d_crc_acc.p, d.d_crc_expect.p, d.d_ncomp.p, d.d_ncomp_expect.p,
@@ -2503,7 +2551,7 @@ void general_pipeline(ckl_decoder& d, const RunGeom& g, RunArrays& ra, void* out
 void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label, const StatsArgs* stats = nullptr, bool planes_only = false, uint32_t* errs_out = nullptr) {
 	const Header& h = d.head;
 	if (d.sxy == 0 || d.nslices == 0) return;
-	const int ow = has_label ? 1 : h.data_width;
+	const int ow = has_label ? 1 : (d.paint_width ? d.paint_width : h.data_width);
 	const uint64_t need = d.sxy * d.nslices * static_cast<uint64_t>(ow);
 	if (!stats && !planes_only && !errs_out && out_capacity_bytes < need) throw Error(CKL_ERR_ARG, "crackle_amd: output buffer too small: need " + std::to_string(need) + " bytes");
 	hipStream_t s = d.stream;
@@ -2554,7 +2602,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ra.nruns = d.d_nruns.p; ra.ncomp = d.d_ncomp.p; ra.slice_err = d.d_slice_err.p;
 
 	const bool paint = !stats && !planes_only && !errs_out;
-	const bool strips = paint && d.strip_ok && !d.use_general && !getenv("CKL_DECODE_DIAG");
+	const bool strips = paint && d.strip_ok && !d.use_general && !d.foreign_label_map && !d.paint_width && !getenv("CKL_DECODE_DIAG");
 	if (strips) {
 		// planes -> strips -> labels, z-chunk by z-chunk (ckl_strips.hpp)
 		if (has_label || h.data_width == 1) strip_pipeline<uint8_t>(d, ca, crack_lds, g, ra, out_device, has_label, label, st);
@@ -2870,6 +2918,115 @@ int ckl_decoder_stage_timing(const ckl_decoder* d, int index, const char** name,
 }
 
 void ckl_decoder_destroy(ckl_decoder* d) { delete d; }
+
+int ckl_array_equal(const uint8_t* buf1, uint64_t n1, const uint8_t* buf2, uint64_t n2, int device, int* equal) {
+	ckl_decoder *d1 = nullptr, *d2 = nullptr;
+	try {
+		if (!buf1 || !buf2 || !equal) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		*equal = 0;
+		const Header h1 = Header::parse(buf1, n1), h2 = Header::parse(buf2, n2);
+		// operations.hpp:1049-1062; get_voxels -> get_szr (:54-87) throws for a stream without slices
+		if (h1.sz == 0 || h2.sz == 0) throw Error(CKL_ERR_RUNTIME, "crackle: Invalid range: 0 - 0");
+		if (h1.voxels() == 0 || h2.voxels() == 0) { *equal = h1.voxels() == h2.voxels(); return CKL_OK; }
+		if (h1.sx != h2.sx || h1.sy != h2.sy || h1.sz != h2.sz) return CKL_OK;
+		int rc = ckl_decoder_create(buf1, n1, 0, -1, device, &d1);
+		if (rc == CKL_OK) rc = ckl_decoder_create(buf2, n2, 0, -1, device, &d2);
+		if (rc != CKL_OK) { ckl_decoder_destroy(d1); ckl_decoder_destroy(d2); return rc; }
+		// the reference compares the component counts its CCL finds (:1146-1149); those of a valid
+		// stream are the counts its label section states
+		if (d1->ncomp_expect_host != d2->ncomp_expect_host) { ckl_decoder_destroy(d1); ckl_decoder_destroy(d2); return CKL_OK; }
+		// label_map1[ccl1] against label_map1[ccl2] (:1160-1171; yes, label_map1 on both sides): the
+		// first stream is decoded as it is, the second one's components are painted through the FIRST
+		// stream's component -> label table.  Both x fastest, whatever the headers say.
+		d1->use_general = true; d2->use_general = true;      // the general pipeline keeps the component -> label table
+		d1->head.fortran_order = true; d2->head.fortran_order = true;
+		const uint64_t bytes = d1->sxy * d1->nslices * static_cast<uint64_t>(h1.data_width);
+		DevBuf<uint8_t> a, b;
+		DevBuf<uint32_t> flag;
+		a.ensure(bytes); b.ensure(bytes); flag.ensure(1);
+		decoder_run(*d1, a.p, bytes, 0, 0);
+		d2->foreign_label_map = d1->d_label_map.p;
+		d2->paint_width = h1.data_width;
+		CKL_HIP(hipStreamSynchronize(d1->stream));
+		decoder_run(*d2, b.p, bytes, 0, 0);
+		hipStream_t s = d2->stream;
+		CKL_HIP(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
+		hipLaunchKernelGGL(k_buffers_differ, dim3(2048), dim3(kBlock), 0, s, a.p, b.p, bytes, flag.p);
+		uint32_t differ = 0;
+		CKL_HIP(hipMemcpyAsync(&differ, flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		CKL_HIP(hipStreamSynchronize(s));
+		CKL_HIP(hipGetLastError());
+		*equal = differ ? 0 : 1;
+		ckl_decoder_destroy(d1); ckl_decoder_destroy(d2);
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); ckl_decoder_destroy(d1); ckl_decoder_destroy(d2); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); ckl_decoder_destroy(d1); ckl_decoder_destroy(d2); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_mode_pooling_2x2x1(
+	const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, int device,
+	uint8_t** out, uint64_t* out_len, uint64_t** lengths, uint64_t* count
+) {
+	ckl_decoder* d = nullptr;
+	ckl_encoder* e = nullptr;
+	uint64_t* lens = nullptr;
+	try {
+		if (!buf || !out || !out_len || !lengths || !count) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		*out = nullptr; *out_len = 0; *lengths = nullptr; *count = 0;
+		const Header h = Header::parse(buf, n);
+		{
+			// get_szr (operations.hpp:54-72): an empty range is an error, an empty slice is not (:1213-1215)
+			int64_t zs = std::max<int64_t>(std::min<int64_t>(z_start, static_cast<int64_t>(static_cast<uint32_t>(h.sz - 1u))), 0);
+			int64_t ze = z_end < 0 ? static_cast<int64_t>(h.sz) : z_end;
+			ze = std::max<int64_t>(std::min<int64_t>(ze, static_cast<int64_t>(h.sz)), 0);
+			if (zs >= ze) throw Error(CKL_ERR_RUNTIME, "crackle: Invalid range: " + std::to_string(zs) + " - " + std::to_string(ze));
+		}
+		if (static_cast<uint64_t>(h.sx) * h.sy == 0) return CKL_OK;
+		int rc = ckl_decoder_create(buf, n, z_start < 0 ? 0 : z_start, z_end, device, &d);
+		if (rc != CKL_OK) return rc;
+		d->head.fortran_order = true;      // the pooling walks x fastest (operations.hpp:1241-1249)
+		d->use_general = d->use_general || !(h.fortran_order);      // a C-order stream was laid out for the general pipeline
+		const uint32_t sx = h.sx, sy = h.sy, nz = d->nslices;
+		const uint32_t osx = (sx + 1u) >> 1, osy = (sy + 1u) >> 1;
+		const int w = h.data_width;
+		const uint64_t vox = d->sxy * nz, ovox = static_cast<uint64_t>(osx) * osy * nz;
+		DevBuf<uint8_t> full, pooled;
+		full.ensure(vox * w); pooled.ensure(ovox * w);
+		decoder_run(*d, full.p, vox * w, 0, 0);
+		hipStream_t s = d->stream;
+		const dim3 grid(static_cast<uint32_t>((ovox + kBlock - 1) / kBlock));
+		if (w == 1) hipLaunchKernelGGL(k_mode_pool_2x2<uint8_t>, grid, dim3(kBlock), 0, s, full.p, pooled.p, sx, sy, nz);
+		else if (w == 2) hipLaunchKernelGGL(k_mode_pool_2x2<uint16_t>, grid, dim3(kBlock), 0, s, reinterpret_cast<const uint16_t*>(full.p), reinterpret_cast<uint16_t*>(pooled.p), sx, sy, nz);
+		else if (w == 4) hipLaunchKernelGGL(k_mode_pool_2x2<uint32_t>, grid, dim3(kBlock), 0, s, reinterpret_cast<const uint32_t*>(full.p), reinterpret_cast<uint32_t*>(pooled.p), sx, sy, nz);
+		else hipLaunchKernelGGL(k_mode_pool_2x2<uint64_t>, grid, dim3(kBlock), 0, s, reinterpret_cast<const uint64_t*>(full.p), reinterpret_cast<uint64_t*>(pooled.p), sx, sy, nz);
+		CKL_HIP(hipStreamSynchronize(s));
+		CKL_HIP(hipGetLastError());
+		// every pooled slice becomes a stream of its own: crackle::compress<LABEL>(oimg, osx, osy, 1) with
+		// its defaults (operations.hpp:1294-1297; LABEL is the unsigned type of the data width)
+		rc = ckl_encoder_create(osx, osy, 1, w, device, &e);
+		if (rc != CKL_OK) { ckl_decoder_destroy(d); return rc; }
+		std::vector<uint8_t> all;
+		lens = static_cast<uint64_t*>(host_out_alloc(sizeof(uint64_t) * (nz ? nz : 1)));
+		for (uint32_t z = 0; z < nz; z++) {
+			uint8_t* one = nullptr; uint64_t len = 0;
+			rc = ckl_encoder_run(e, pooled.p + static_cast<uint64_t>(z) * osx * osy * w, osx, osy, 1, 0, 1, 0, 0, 1, 0, nullptr, &one, &len);
+			if (rc != CKL_OK) { host_out_free(lens); ckl_encoder_destroy(e); ckl_decoder_destroy(d); return rc; }
+			all.insert(all.end(), one, one + len);
+			lens[z] = len;
+			ckl_free(one);
+		}
+		ckl_encoder_destroy(e); e = nullptr;
+		ckl_decoder_destroy(d); d = nullptr;
+		uint8_t* o = static_cast<uint8_t*>(host_out_alloc(all.size() ? all.size() : 1));
+		memcpy(o, all.data(), all.size());
+		*out = o; *out_len = all.size(); *lengths = lens; *count = nz;
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); if (lens) host_out_free(lens); if (e) ckl_encoder_destroy(e); ckl_decoder_destroy(d); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); if (lens) host_out_free(lens); if (e) ckl_encoder_destroy(e); ckl_decoder_destroy(d); return CKL_ERR_RUNTIME; }
+}
+
 
 int ckl_decompress(
 	const uint8_t* buf, uint64_t n, void* out, uint64_t out_capacity_bytes, int out_mem,

@@ -7,7 +7,8 @@
 // CRACKLE_AMD_DEVICE (default 0).  No CPU fallback: without a HIP device every call raises.
 //
 // Functions: decompress (ref :84-128), compress (:163-210), reencode_markov (:212-227),
-// voxel_counts / centroids / bounding_boxes (:346-426), voxel_connectivity_graph (:538-565).
+// voxel_counts / centroids / bounding_boxes (:346-426), voxel_connectivity_graph (:538-565),
+// array_equal (:594-618), mode_pooling_2x2x1 (:620-639).
 #include <pybind11/pybind11.h>
 #include <pybind11/numpy.h>
 #include <pybind11/stl.h>
@@ -189,6 +190,31 @@ py::array voxel_connectivity_graph(const py::buffer buffer, int64_t z_start, int
 	return arr;
 }
 
+bool array_equal(const py::buffer buffer1, const py::buffer buffer2, size_t /*parallel*/) {
+	Stream a(buffer1), b(buffer2);
+	if (a.p == b.p) return true;      // src/fastcrackle.cpp:609-611
+	int eq = 0;
+	check(ckl_array_equal(a.p, a.n, b.p, b.n, device(), &eq));
+	return eq != 0;
+}
+
+py::list mode_pooling_2x2x1(const py::buffer buffer, int64_t z_start, int64_t z_end, size_t /*parallel*/) {
+	Stream s(buffer);
+	uint8_t* out = nullptr;
+	uint64_t n = 0, count = 0;
+	uint64_t* lens = nullptr;
+	check(ckl_mode_pooling_2x2x1(s.p, s.n, z_start, z_end, device(), &out, &n, &lens, &count));
+	py::list result;
+	uint64_t at = 0;
+	for (uint64_t i = 0; i < count; i++) {
+		result.append(py::bytes(reinterpret_cast<const char*>(out + at), lens[i]));
+		at += lens[i];
+	}
+	if (out) ckl_free(out);
+	if (lens) ckl_free(lens);
+	return result;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(fastcrackle, m) {
@@ -205,6 +231,10 @@ PYBIND11_MODULE(fastcrackle, m) {
 	m.def("centroids", &centroids, "Compute the centroid for each label in the dataset.",
 		py::arg("buffer"), py::arg("z_start") = 0, py::arg("z_end") = -1, py::arg("parallel") = 1);
 	m.def("bounding_boxes", &bounding_boxes, "Compute the bounding box for each label in the dataset.",
+		py::arg("buffer"), py::arg("z_start") = 0, py::arg("z_end") = -1, py::arg("parallel") = 1);
+	m.def("array_equal", &array_equal, "Check if two crackle arrays are equal regardless of encoding.",
+		py::arg("buffer1"), py::arg("buffer2"), py::arg("parallel") = 1);
+	m.def("mode_pooling_2x2x1", &mode_pooling_2x2x1, "Return an array of downsampled crackle binaries in z order.",
 		py::arg("buffer"), py::arg("z_start") = 0, py::arg("z_end") = -1, py::arg("parallel") = 1);
 	m.def("voxel_connectivity_graph", &voxel_connectivity_graph, "Extract the voxel connectivity graph from the image.",
 		py::arg("buffer"), py::arg("z_start") = 0, py::arg("z_end") = -1, py::arg("parallel") = 1, py::arg("connectivity") = 4);

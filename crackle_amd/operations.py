@@ -4,8 +4,10 @@ zshatter).  Host only (native: ckl_zstack / ckl_zsplit); FLAT label streams."""
 import ctypes as C
 from typing import List, Sequence, Tuple
 
+import numpy as np
+
 from . import _lib
-from .codec import header
+from .codec import header, labels, num_labels
 
 
 def _take(out: C.c_void_p, n: C.c_uint64) -> bytes:
@@ -65,3 +67,49 @@ def zshatter(binary: bytes) -> List[bytes]:
   """One stream per z-slice (crackle/operations.py:649-662)."""
   head = header(binary)
   return [_zrange(binary, z, z + 1) for z in range(head.sz)]
+
+
+def array_equal(binary1: bytes, binary2: bytes, parallel: int = 0, device: int = 0) -> bool:
+  """Do the two streams hold the same array, whatever their encoding (crackle/operations.py:966-994:
+  shapes, number of labels and label sets are compared on the host, then
+  fastcrackle.array_equal = src/operations.hpp:1039-1184 -> ckl_array_equal)."""
+  b1, b2 = bytes(binary1), bytes(binary2)
+  h1, h2 = header(b1), header(b2)
+  if h1.sx != h2.sx or h1.sy != h2.sy or h1.sz != h2.sz:
+    return False
+  if num_labels(b1) != num_labels(b2):
+    return False
+  if np.any(labels(b1) != labels(b2)):
+    return False
+  eq = C.c_int(0)
+  if _lib.lib().ckl_array_equal(b1, len(b1), b2, len(b2), int(device), C.byref(eq)) != _lib.CKL_OK:
+    raise RuntimeError(_lib.last_error())
+  return bool(eq.value)
+
+
+def _mode_pooling_slices(binary: bytes, z_start: int = 0, z_end: int = -1, device: int = 0) -> List[bytes]:
+  """fastcrackle.mode_pooling_2x2x1 (src/fastcrackle.cpp:620-639): one pooled stream per slice."""
+  b = bytes(binary)
+  out, n, lens, cnt = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+  L = _lib.lib()
+  if L.ckl_mode_pooling_2x2x1(b, len(b), int(z_start), int(z_end), int(device), C.byref(out), C.byref(n), C.byref(lens), C.byref(cnt)) != _lib.CKL_OK:
+    raise RuntimeError(_lib.last_error())
+  try:
+    sizes = list((C.c_uint64 * cnt.value).from_address(lens.value)) if cnt.value else []
+    blob = C.string_at(out.value, n.value) if n.value else b""
+  finally:
+    if out.value:
+      L.ckl_free(out)
+    if lens.value:
+      L.ckl_free(lens)
+  res, at = [], 0
+  for m in sizes:
+    res.append(blob[at:at + m])
+    at += m
+  return res
+
+
+def mode_pooling_2x2x1(binary: bytes, parallel: int = 0, device: int = 0) -> bytes:
+  """Downsamples a segmentation 2 x 2 x 1 by the reference's pooling rule
+  (crackle/operations.py:1023-1026: the per-slice streams of fastcrackle.mode_pooling_2x2x1, stacked)."""
+  return zstack(_mode_pooling_slices(binary, 0, -1, device))

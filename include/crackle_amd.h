@@ -143,6 +143,22 @@ int ckl_decoder_vcg(ckl_decoder* d, uint8_t* out_device, uint64_t out_capacity_b
 int ckl_voxel_connectivity_graph(const uint8_t* buf, uint64_t n, int connectivity, int device, uint8_t* out_host, uint64_t out_capacity_bytes);
 int ckl_voxel_connectivity_graph_range(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, int connectivity, int device, uint8_t* out_host, uint64_t out_capacity_bytes);
 
+/* Replaces crackle::operations::array_equal (src/operations.hpp:1039-1184, bound at
+ * src/fastcrackle.cpp:594-618): *equal = 1 when both streams have the same shape, the same number
+ * of components in every slice and label_map1[components1] == label_map1[components2] everywhere
+ * — the FIRST stream's component -> label table on both sides, as the reference has it (:1163-1164);
+ * crackle/operations.py:976-994 compares the label sets before it calls this. */
+int ckl_array_equal(const uint8_t* buf1, uint64_t n1, const uint8_t* buf2, uint64_t n2, int device, int* equal);
+
+/* Replaces crackle::operations::mode_pooling_2x2x1 (src/operations.hpp:1201-1304, bound at
+ * src/fastcrackle.cpp:620-639): slices [z_start, z_end) are decoded, pooled 2 x 2 in x and y by the
+ * reference's rule (a == b ? a : a == c ? a : b == c ? b : d) and every pooled slice is encoded as
+ * a one-slice stream of its own.  *out holds the streams one after the other (release with
+ * ckl_free), *lengths their `*count` lengths (release with ckl_free as well). */
+int ckl_mode_pooling_2x2x1(
+	const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, int device,
+	uint8_t** out, uint64_t* out_len, uint64_t** lengths, uint64_t* count);
+
 /* Per-label statistics of the decoder's z-range without materialising the volume:
  * replaces crackle::operations::voxel_counts / centroids / bounding_boxes
  * (src/operations.hpp:321-618, bound by src/fastcrackle.cpp:346-420).  The pipeline runs up

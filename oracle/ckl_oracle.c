@@ -1194,6 +1194,8 @@ typedef struct {
 	uint64_t bgcolor;
 	uint64_t n_pins; uint64_t* pin_label; uint64_t* pin_index; uint64_t* pin_depth;
 	uint64_t n_ccl; uint64_t* ccl_label; uint64_t* ccl_id;
+	/* captures for array_equal: per-voxel component ids, component counts and component -> label tables */
+	uint32_t* cap_cc; uint64_t* cap_N; uint64_t** cap_lmap;
 	atomic_int failed;
 	char err[256];
 } dec_ctx_t;
@@ -1204,6 +1206,12 @@ static uint64_t read_stored(const dec_ctx_t* d, uint64_t offset) {
 	uint64_t v = rd(d->labels_binary, offset, w);
 	if (d->head.is_signed && w < 8 && (v >> (8 * w - 1))) v |= ~0ull << (8 * w);
 	return v;
+}
+static uint64_t load_label(const void* in, int width, uint64_t idx) {
+	if (width == 1) return ((const uint8_t*)in)[idx];
+	if (width == 2) return ((const uint16_t*)in)[idx];
+	if (width == 4) return ((const uint32_t*)in)[idx];
+	return ((const uint64_t*)in)[idx];
 }
 static void store_out(void* out, int width, uint64_t idx, uint64_t v) {
 	if (width == 1) ((uint8_t*)out)[idx] = (uint8_t)v;
@@ -1270,6 +1278,13 @@ static void dec_slice_task(int64_t zi, size_t tid, void* c) {
 				if (id < N) label_map[id] = d->pin_label[j];
 			}
 		}
+	}
+
+	if (d->cap_cc) {
+		memcpy(d->cap_cc + (uint64_t)zi * (uint64_t)sxy, cc, (size_t)sxy * 4);
+		d->cap_N[zi] = N;
+		d->cap_lmap[zi] = label_map;      /* ownership moves to the caller */
+		return;
 	}
 
 	/* paint (src/crackle.hpp:617-656) */
@@ -1407,6 +1422,12 @@ static void dec_free(dec_ctx_t* d, size_t threads) {
 	free(d->vcg); free(d->cc); free(d->ids); free(d->ren);
 }
 
+static int dec_run(
+	dec_ctx_t* dp, const unsigned char* buf, uint64_t n, void* out,
+	int64_t z_start, int64_t z_end, uint64_t parallel,
+	int has_label, uint64_t label
+);
+
 int ckl_oracle_decompress(
 	const unsigned char* buf, uint64_t n, void* out,
 	int64_t z_start, int64_t z_end, uint64_t parallel,
@@ -1414,6 +1435,16 @@ int ckl_oracle_decompress(
 ) {
 	dec_ctx_t d;
 	memset(&d, 0, sizeof d);
+	return dec_run(&d, buf, n, out, z_start, z_end, parallel, has_label, label);
+}
+
+/* the decoder proper; with dp->cap_* set the slices are captured instead of painted */
+static int dec_run(
+	dec_ctx_t* dp, const unsigned char* buf, uint64_t n, void* out,
+	int64_t z_start, int64_t z_end, uint64_t parallel,
+	int has_label, uint64_t label
+) {
+	dec_ctx_t d = *dp;
 	if (n < HEADER_BYTES_V0) FAIL("crackle: Input too small to be a valid stream. Bytes: %llu", (unsigned long long)n);
 	if (header_read(&d.head, buf, n)) return 1;
 	const header_t* h = &d.head;
@@ -1464,6 +1495,116 @@ int ckl_oracle_decompress(
 	}
 	dec_free(&d, threads);
 	return rc;
+}
+
+/* operations::get_szr (src/operations.hpp:54-72): slices of the clamped range; an empty range is an error */
+static int get_szr(const header_t* h, int64_t z_start, int64_t z_end, int64_t* zs_out, int64_t* szr) {
+	int64_t zs = z_start, ze = z_end;
+	const int64_t last = (int64_t)(uint32_t)(h->sz - 1u);      /* header.sz - 1 in 32-bit unsigned arithmetic */
+	if (zs > last) zs = last;
+	if (zs < 0) zs = 0;
+	ze = ze < 0 ? (int64_t)h->sz : ze;
+	if (ze > (int64_t)h->sz) ze = h->sz;
+	if (ze < 0) ze = 0;
+	if (zs >= ze) FAIL("crackle: Invalid range: %lld - %lld", (long long)zs, (long long)ze);
+	*zs_out = zs; *szr = ze - zs;
+	return 0;
+}
+
+/* operations::array_equal (src/operations.hpp:1039-1184), quirk included: label_map1 on both sides */
+int ckl_oracle_array_equal(const unsigned char* buf1, uint64_t n1, const unsigned char* buf2, uint64_t n2, uint64_t parallel, int* equal) {
+	header_t h1, h2;
+	*equal = 0;
+	if (n1 < HEADER_BYTES_V0 || n2 < HEADER_BYTES_V0) FAIL("crackle: Input too small to be a valid stream.");
+	if (header_read(&h1, buf1, n1) || header_read(&h2, buf2, n2)) return 1;
+	int64_t zs1, zs2, szr1, szr2;
+	if (get_szr(&h1, 0, -1, &zs1, &szr1) || get_szr(&h2, 0, -1, &zs2, &szr2)) return 1;      /* get_voxels throws for sz = 0 */
+	const uint64_t v1 = (uint64_t)h1.sx * h1.sy * (uint64_t)szr1, v2 = (uint64_t)h2.sx * h2.sy * (uint64_t)szr2;
+	if (v1 == 0 || v2 == 0) { *equal = v1 == v2; return 0; }                       /* :1049-1054 */
+	if (h1.sx != h2.sx || h1.sy != h2.sy || h1.sz != h2.sz) return 0;              /* :1056-1062 */
+	const uint64_t sxy = (uint64_t)h1.sx * h1.sy, sz = h1.sz;
+	dec_ctx_t d[2];
+	int rc = 0;
+	for (int k = 0; k < 2 && !rc; k++) {
+		memset(&d[k], 0, sizeof d[k]);
+		d[k].cap_cc = (uint32_t*)xmalloc(sxy * sz * 4);
+		d[k].cap_N = (uint64_t*)xcalloc(sz, sizeof(uint64_t));
+		d[k].cap_lmap = (uint64_t**)xcalloc(sz, sizeof(uint64_t*));
+		rc = dec_run(&d[k], k ? buf2 : buf1, k ? n2 : n1, NULL, 0, -1, parallel, 0, 0);
+	}
+	if (!rc) {
+		int eq = 1;
+		for (uint64_t z = 0; z < sz && eq; z++) {
+			if (d[0].cap_N[z] != d[1].cap_N[z]) { eq = 0; break; }                     /* :1146-1149 */
+			const uint64_t* lm1 = d[0].cap_lmap[z];
+			const uint32_t* c1 = d[0].cap_cc + z * sxy;
+			const uint32_t* c2 = d[1].cap_cc + z * sxy;
+			for (uint64_t i = 0; i < sxy; i++) {
+				if (lm1[c1[i]] != lm1[c2[i]]) { eq = 0; break; }                         /* :1160-1171 */
+			}
+		}
+		*equal = eq;
+	}
+	for (int k = 0; k < 2; k++) {
+		if (d[k].cap_lmap) for (uint64_t z = 0; z < sz; z++) free(d[k].cap_lmap[z]);
+		free(d[k].cap_lmap); free(d[k].cap_N); free(d[k].cap_cc);
+	}
+	return rc;
+}
+
+/* operations::mode_pooling_2x2x1 (src/operations.hpp:1201-1340): *out holds the per-slice streams one
+ * after the other (release with ckl_oracle_free), lens_out their lengths (room for sz entries) */
+int ckl_oracle_mode_pooling(
+	const unsigned char* buf, uint64_t n, int64_t z_start, int64_t z_end, uint64_t parallel,
+	unsigned char** out, uint64_t* out_len, uint64_t* lens_out, uint64_t* count
+) {
+	header_t h;
+	*out = NULL; *out_len = 0; *count = 0;
+	if (n < HEADER_BYTES_V0) FAIL("crackle: Input too small to be a valid stream.");
+	if (header_read(&h, buf, n)) return 1;
+	int64_t zs, szr;
+	if (get_szr(&h, z_start, z_end, &zs, &szr)) return 1;
+	const int64_t ze = zs + szr;
+	const uint64_t sx = h.sx, sy = h.sy;
+	if (sx * sy == 0) return 0;      /* voxels == 0: no streams (:1213-1215) */
+	const int w = h.data_width;
+	/* decoded in the stream's own order; VOX() below addresses voxel (x, y) of slice zi in either */
+	unsigned char* vol = (unsigned char*)xmalloc(sx * sy * (uint64_t)szr * (uint64_t)w);
+	int rc = ckl_oracle_decompress(buf, n, vol, zs, ze, parallel, 0, 0);
+	if (rc) { free(vol); return rc; }
+	const uint64_t osx = (sx + 1) >> 1, osy = (sy + 1) >> 1, osxy = osx * osy;
+	unsigned char* oimg = (unsigned char*)xmalloc(osxy * (uint64_t)w);
+	unsigned char* all = NULL;
+	uint64_t total = 0;
+	for (int64_t zi = 0; zi < szr && !rc; zi++) {
+		for (uint64_t oy = 0; oy < osy; oy++) {
+			for (uint64_t ox = 0; ox < osx; ox++) {
+				const uint64_t x = 2 * ox, y = 2 * oy;
+#define VOX(X, Y) load_label(vol, w, h.fortran_order ? ((X) + sx * ((Y) + sy * (uint64_t)zi)) : ((uint64_t)zi + (uint64_t)szr * ((Y) + sy * (X))))
+				uint64_t v = VOX(x, y);
+				if (x + 1 < sx && y + 1 < sy) {
+					const uint64_t a = v, b = VOX(x + 1, y), c = VOX(x, y + 1), dd = VOX(x + 1, y + 1);
+					v = (a == b) ? a : (a == c) ? a : (b == c) ? b : dd;                  /* :1262-1273 */
+				}
+#undef VOX
+				store_out(oimg, w, ox + osx * oy, v);
+			}
+		}
+		unsigned char* one = NULL; uint64_t len = 0;
+		rc = ckl_oracle_compress(oimg, w, 0, (int64_t)osx, (int64_t)osy, 1, 0, 1, 0, 0, 1, 0, 1, &one, &len);      /* :1294-1297 */
+		if (!rc) {
+			all = (unsigned char*)xrealloc(all, total + len + 1);
+			memcpy(all + total, one, len);
+			total += len;
+			lens_out[zi] = len;
+			free(one);
+		}
+	}
+	free(oimg); free(vol);
+	if (rc) { free(all); return rc; }
+	*out = all ? all : (unsigned char*)xmalloc(1);
+	*out_len = total; *count = (uint64_t)szr;
+	return 0;
 }
 
 int ckl_oracle_slice_vcg(const unsigned char* buf, uint64_t n, int64_t z, uint8_t* vcg_out) {

@@ -72,6 +72,14 @@ int ckl_oracle_reencode(
 	const unsigned char* buf, uint64_t n, int markov_order, uint64_t parallel,
 	unsigned char** out, uint64_t* out_len);
 
+/* operations::array_equal (src/operations.hpp:1039-1184) */
+int ckl_oracle_array_equal(const unsigned char* buf1, uint64_t n1, const unsigned char* buf2, uint64_t n2, uint64_t parallel, int* equal);
+
+/* operations::mode_pooling_2x2x1 (src/operations.hpp:1201-1340): per-slice streams one after the other */
+int ckl_oracle_mode_pooling(
+	const unsigned char* buf, uint64_t n, int64_t z_start, int64_t z_end, uint64_t parallel,
+	unsigned char** out, uint64_t* out_len, uint64_t* lens_out, uint64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,14 @@ class _Checker:
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p]
     self._vcg3d = f
+    f = getattr(L, prefix + "array_equal")
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
+    self._array_equal = f
+    f = getattr(L, prefix + "mode_pooling")
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64)]
+    self._mode_pooling = f
     f = getattr(L, prefix + "reencode")
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -164,6 +172,36 @@ class _Checker:
       return C.string_at(out.value, n.value)
     finally:
       self._free(out)
+
+  def array_equal(self, binary1, binary2, parallel=1):
+    """fastcrackle.array_equal (operations.hpp:1039-1184), without the host-side pre-checks of
+    crackle/operations.py:976-992."""
+    b1, b2 = bytes(binary1), bytes(binary2)
+    eq = C.c_int(0)
+    rc = self._array_equal(b1, len(b1), b2, len(b2), int(parallel), C.byref(eq))
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    return bool(eq.value)
+
+  def mode_pooling_2x2x1(self, binary, z_start=0, z_end=-1, parallel=1):
+    """fastcrackle.mode_pooling_2x2x1 (operations.hpp:1201-1340): list of per-slice streams."""
+    binary = bytes(binary)
+    sz = int.from_bytes(binary[15:19], "little")
+    lens = np.zeros(max(sz, 1), dtype=np.uint64)
+    out, n, cnt = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    rc = self._mode_pooling(binary, len(binary), int(z_start), int(z_end), int(parallel), C.byref(out), C.byref(n), lens.ctypes.data, C.byref(cnt))
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    try:
+      blob = C.string_at(out.value, n.value) if n.value else b""
+    finally:
+      if out.value:
+        self._free(out)
+    res, at = [], 0
+    for m in lens[:cnt.value]:
+      res.append(blob[at:at + int(m)])
+      at += int(m)
+    return res
 
   def crc32c(self, data):
     data = bytes(data)

@@ -17,6 +17,8 @@
 //   crackle::crc::crc32c          src/crc.hpp:51-57
 //   crackle::reencode_with_markov_order src/crackle.hpp:858-984
 //   crackle::operations::voxel_connectivity_graph src/operations.hpp:667-826
+//   crackle::operations::array_equal src/operations.hpp:1039-1184
+//   crackle::operations::mode_pooling_2x2x1 src/operations.hpp:1201-1340
 
 #include <cstdint>
 #include <cstdlib>
@@ -191,6 +193,47 @@ int ckl_ref_reencode(
 		*out = static_cast<unsigned char*>(malloc(r.size() ? r.size() : 1));
 		memcpy(*out, r.data(), r.size());
 		*out_len = r.size();
+		return 0;
+	}
+	catch (const std::exception& e) {
+		g_err = e.what();
+		return 1;
+	}
+}
+
+// crackle::operations::array_equal  src/operations.hpp:1039-1184
+__attribute__((visibility("default")))
+int ckl_ref_array_equal(const unsigned char* buf1, uint64_t n1, const unsigned char* buf2, uint64_t n2, uint64_t parallel, int* equal) {
+	try {
+		*equal = crackle::operations::array_equal(buf1, n1, buf2, n2, parallel) ? 1 : 0;
+		return 0;
+	}
+	catch (const std::exception& e) {
+		g_err = e.what();
+		return 1;
+	}
+}
+
+// crackle::operations::mode_pooling_2x2x1  src/operations.hpp:1201-1340
+// *out: the per-slice streams one after the other, lens_out[i] their lengths (room for sz entries)
+__attribute__((visibility("default")))
+int ckl_ref_mode_pooling(
+	const unsigned char* buf, uint64_t n, int64_t z_start, int64_t z_end, uint64_t parallel,
+	unsigned char** out, uint64_t* out_len, uint64_t* lens_out, uint64_t* count
+) {
+	try {
+		auto bins = crackle::operations::mode_pooling_2x2x1(buf, n, z_start, z_end, parallel);
+		uint64_t total = 0;
+		for (const auto& b : bins) total += b.size();
+		*out = static_cast<unsigned char*>(malloc(total ? total : 1));
+		uint64_t at = 0;
+		for (size_t i = 0; i < bins.size(); i++) {
+			memcpy(*out + at, bins[i].data(), bins[i].size());
+			at += bins[i].size();
+			lens_out[i] = bins[i].size();
+		}
+		*out_len = total;
+		*count = bins.size();
 		return 0;
 	}
 	catch (const std::exception& e) {

@@ -453,3 +453,52 @@ def test_check_and_ok(checker):
     b = bytearray(good); b[start + int(zidx[3]) // 2] ^= 0x04
     rep = crackle_amd.check(bytes(b))
     assert rep["header"] and rep["crack_index"] and rep["labels"] and rep["z"] == [3], rep
+
+
+def test_array_equal_on_device(checker):
+  """ckl_array_equal against the oracle's restatement of operations::array_equal
+  (src/operations.hpp:1039-1184, pinned to the compiled reference in tests/test_oracle.py),
+  the reference's quirk included."""
+  from crackle_amd import operations as ops
+  L = _lib.lib()
+  arr, _ = SMALL["c0_voronoi_u8"]
+  g = golden()
+  same = [g["c0_voronoi_u8"], g["c0_voronoi_u8_m5"], g["c0_voronoi_u8_pins"], g["c0_voronoi_u8_pins_m5"], g["c0_voronoi_u8_c"]]
+  other = arr.copy(order="F"); other[10:14, 20:25, 3] = 251
+  relabel = np.asfortranarray(((arr.astype(np.uint16) * 7 + 3) % 251).astype(np.uint8))
+  moved = np.asfortranarray(np.roll(arr, 1, axis=0))
+  cases = same + [checker.compress(other), checker.compress(relabel), checker.compress(moved), checker.compress(arr[:, :, :8].copy(order="F"))]
+  def raw(a, b):
+    eq = C.c_int(0)
+    rc = L.ckl_array_equal(a, len(a), b, len(b), 0, C.byref(eq))
+    assert rc == 0, _lib.last_error()
+    return bool(eq.value)
+  for a in cases[:7]:
+    for b in cases:
+      assert raw(a, b) == checker.array_equal(a, b)
+  assert ops.array_equal(same[0], same[3]) and ops.array_equal(same[4], same[1])
+  assert not ops.array_equal(same[0], cases[5]) and not ops.array_equal(same[0], cases[6])
+  big = synth.as_numpy_f(synth.voronoi_labels((320, 288, 5), np.uint32, seed=61, cell=(16, 16, 4)))
+  b0, b5 = checker.compress(big), checker.compress(big, markov_model_order=5, allow_pins=True)
+  assert ops.array_equal(b0, b5)
+  big2 = big.copy(order="F"); big2[100, 100, 2] += 1
+  assert not ops.array_equal(b0, checker.compress(big2))
+
+
+def test_mode_pooling_on_device(checker):
+  """ckl_mode_pooling_2x2x1 against the oracle's restatement of operations::mode_pooling_2x2x1
+  (src/operations.hpp:1201-1340): the per-slice streams byte for byte, and the stacked result."""
+  from crackle_amd import operations as ops
+  for name in ("c0_voronoi_u8", "c0_voronoi_u8_pins_m5", "c0_voronoi_u8_c", "rand_17x13x5_uint32_F_m0_p0", "rand_17x13x5_uint64_C_m2_p1", "rand_254x257x2_m0", "single_voxel", "row_33", "col_29"):
+    b = golden()[name]
+    want = checker.mode_pooling_2x2x1(b)
+    got = ops._mode_pooling_slices(b)
+    assert got == want, name
+  b = golden()["c0_voronoi_u8"]
+  assert ops._mode_pooling_slices(b, 2, 5) == checker.mode_pooling_2x2x1(b, 2, 5)
+  arr, _ = SMALL["c0_voronoi_u8"]
+  small = crackle_amd.decompress(ops.mode_pooling_2x2x1(b))
+  assert small.shape == (32, 32, 16)
+  a, bb, c, d = arr[0::2, 0::2], arr[1::2, 0::2], arr[0::2, 1::2], arr[1::2, 1::2]
+  want = np.where(a == bb, a, np.where(a == c, a, np.where(bb == c, bb, d)))
+  assert np.array_equal(small, want)

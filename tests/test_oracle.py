@@ -206,3 +206,50 @@ def test_voxel_connectivity_graph_restatement(port, ref):
       assert np.array_equal(ref.voxel_connectivity_graph(g[name], 6), got), name
   with pytest.raises(RuntimeError):
     port.voxel_connectivity_graph(g["c0_voronoi_u8"], 8)
+
+
+def _streams_for_ops(checker):
+  import golden_cases
+  from util import golden
+  small = golden_cases.small_cases()
+  arr, _ = small["c0_voronoi_u8"]
+  g = golden()
+  return arr, g
+
+
+def test_array_equal_restatement_against_the_live_reference(port, ref):
+  """operations::array_equal (src/operations.hpp:1039-1184): same array under different encodings,
+  different arrays, and the reference's own quirk — label_map1 on both sides (:1163-1164), so two
+  streams of one structure compare equal whatever the second one's labels are."""
+  if ref is None:
+    pytest.skip("compiled reference not available")
+  arr, g = _streams_for_ops(port)
+  same = [g["c0_voronoi_u8"], g["c0_voronoi_u8_m5"], g["c0_voronoi_u8_pins"], g["c0_voronoi_u8_pins_m5"], g["c0_voronoi_u8_c"]]
+  other = arr.copy(order="F"); other[10:14, 20:25, 3] = 251
+  relabel = ((arr.astype(np.uint16) * 7 + 3) % 251).astype(np.uint8)      # same structure unless two labels collide
+  moved = np.roll(arr, 1, axis=0)
+  cases = same + [ref.compress(other), ref.compress(np.asfortranarray(relabel)), ref.compress(np.asfortranarray(moved)), ref.compress(arr[:, :, :8].copy(order="F")), g["empty_000"]]
+  def call(chk, a, b):
+    try:
+      return chk.array_equal(a, b)
+    except RuntimeError as exc:
+      return str(exc)
+  for a in cases[:6] + [g["empty_000"]]:
+    for b in cases:
+      assert call(port, a, b) == call(ref, a, b)
+  assert ref.array_equal(same[0], same[2]) and not ref.array_equal(same[0], cases[5])
+
+
+def test_mode_pooling_restatement_against_the_live_reference(port, ref):
+  if ref is None:
+    pytest.skip("compiled reference not available")
+  import golden_cases
+  from util import golden
+  small = golden_cases.small_cases()
+  for name in ("c0_voronoi_u8", "c0_voronoi_u8_pins_m5", "c0_voronoi_u8_c", "rand_17x13x5_uint32_F_m0_p0", "rand_17x13x5_uint64_C_m2_p1", "rand_254x257x2_m0", "single_voxel", "row_33"):
+    b = golden()[name]
+    want = ref.mode_pooling_2x2x1(b)
+    got = port.mode_pooling_2x2x1(b)
+    assert got == want, name
+    if int.from_bytes(b[15:19], "little") >= 3:      # (the reference indexes out of bounds when the range is clamped)
+      assert port.mode_pooling_2x2x1(b, 1, 3) == ref.mode_pooling_2x2x1(b, 1, 3), name
