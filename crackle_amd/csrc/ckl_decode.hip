@@ -38,6 +38,7 @@
 #include <algorithm>
 #include <chrono>
 #include <memory>
+#include <mutex>
 
 namespace ckl {
 
@@ -1918,7 +1919,8 @@ struct ckl_decoder {
 	DevBuf<unsigned long long> d_stats_acc;
 	DevBuf<uint32_t> d_stats_box;
 	std::vector<uint64_t> stats_table;
-	DevBuf<uint32_t> d_G, d_crc_acc, d_crc_expect, d_slice_err;
+	std::shared_ptr<DevBuf<uint32_t>> G;      // geometric-sum table of the slice size, shared by the sessions of a device (geom_table)
+	DevBuf<uint32_t> d_crc_acc, d_crc_expect, d_slice_err;
 	DevBuf<uint64_t> d_label_map;
 	DevBuf<uint64_t> d_pin_index, d_pin_depth, d_pin_label, d_pin_work_off, d_ccl_id, d_ccl_label;
 	// strip path (ckl_strips.hpp): one slot of strip_cap entries per strip
@@ -1969,6 +1971,46 @@ template <typename T>
 void upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t s) {
 	d.ensure(h.size());
 	if (!h.empty()) CKL_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+// G[m] = x^32 + ... + x^(32 m) for m <= pixels of a slice (ckl_runs.hpp): 4 bytes per pixel, built by
+// one kernel launch and a stream sync.  Sessions are created per call by the one-shot API, so the
+// tables are kept per (device, slice size) for the life of the process, the four most recent ones.
+std::shared_ptr<DevBuf<uint32_t>> geom_table(int device, uint64_t sxy, hipStream_t s) {
+	static std::mutex mu;
+	typedef std::vector<std::pair<std::pair<int, uint64_t>, std::shared_ptr<DevBuf<uint32_t>>>> Cache;
+	static Cache& cache = *new Cache();      // never destroyed: no HIP calls from static destructors at exit
+	std::lock_guard<std::mutex> lock(mu);
+	for (size_t i = 0; i < cache.size(); i++) {
+		if (cache[i].first == std::make_pair(device, sxy)) {
+			auto hit = cache[i];
+			cache.erase(cache.begin() + i);
+			cache.push_back(hit);      // most recently used last
+			return hit.second;
+		}
+	}
+	const uint32_t npx = static_cast<uint32_t>(sxy);
+	const uint32_t B = 1024, nblk = npx / B + 1;
+	std::vector<uint32_t> g_base(B), blk_g(nblk), blk_x(nblk);
+	const uint32_t X = gf_xpow(32);
+	g_base[0] = 0;
+	for (uint32_t i = 1; i < B; i++) g_base[i] = gf_mul(X, g_base[i - 1] ^ 0x80000000u);
+	const uint32_t gB = gf_mul(X, g_base[B - 1] ^ 0x80000000u);   // G[B]
+	const uint32_t XB = gf_xpow(32ull * B);
+	blk_g[0] = 0; blk_x[0] = 0x80000000u;
+	for (uint32_t k = 1; k < nblk; k++) {
+		blk_g[k] = blk_g[k - 1] ^ gf_mul(blk_x[k - 1], gB);
+		blk_x[k] = gf_mul(blk_x[k - 1], XB);
+	}
+	DevBuf<uint32_t> t_base, t_g, t_x;
+	upload(t_base, g_base, s); upload(t_g, blk_g, s); upload(t_x, blk_x, s);
+	auto tab = std::make_shared<DevBuf<uint32_t>>();
+	tab->ensure(static_cast<size_t>(npx) + 1);
+	hipLaunchKernelGGL(k_build_geom_table, dim3(npx / kBlock + 1), dim3(kBlock), 0, s, t_base.p, t_g.p, t_x.p, npx, tab->p);
+	CKL_HIP(hipStreamSynchronize(s));
+	if (cache.size() >= 4) cache.erase(cache.begin());
+	cache.push_back({ { device, sxy }, tab });
+	return tab;
 }
 
 uint64_t read_stored(const Header& h, const uint8_t* lb, uint64_t offset) {
@@ -2177,26 +2219,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	d.max_comp = max_comp;
 	while (d.idbits < 32 && (1ull << d.idbits) < max_comp) d.idbits++;
 	d.crc_fix = gf_xpow(32 - d.idbits);
-	{
-		const uint32_t npx = static_cast<uint32_t>(d.sxy);
-		const uint32_t B = 1024, nblk = npx / B + 1;
-		std::vector<uint32_t> g_base(B), blk_g(nblk), blk_x(nblk);
-		const uint32_t X = gf_xpow(32);
-		g_base[0] = 0;
-		for (uint32_t i = 1; i < B; i++) g_base[i] = gf_mul(X, g_base[i - 1] ^ 0x80000000u);
-		const uint32_t gB = gf_mul(X, g_base[B - 1] ^ 0x80000000u);   // G[B]
-		const uint32_t XB = gf_xpow(32ull * B);
-		blk_g[0] = 0; blk_x[0] = 0x80000000u;
-		for (uint32_t k = 1; k < nblk; k++) {
-			blk_g[k] = blk_g[k - 1] ^ gf_mul(blk_x[k - 1], gB);
-			blk_x[k] = gf_mul(blk_x[k - 1], XB);
-		}
-		DevBuf<uint32_t> t_base, t_g, t_x;
-		upload(t_base, g_base, s); upload(t_g, blk_g, s); upload(t_x, blk_x, s);
-		d.d_G.ensure(static_cast<size_t>(npx) + 1);
-		hipLaunchKernelGGL(k_build_geom_table, dim3(npx / kBlock + 1), dim3(kBlock), 0, s, t_base.p, t_g.p, t_x.p, npx, d.d_G.p);
-		CKL_HIP(hipStreamSynchronize(s));
-	}
+	d.G = geom_table(d.device, d.sxy, s);
 	if (d.check_crc) {
 		// stored = ~(x^(32 n) * 0xFFFFFFFF ^ raw)  =>  raw = ~stored ^ init_term
 		const uint32_t init_term = gf_mul(0xFFFFFFFFu, gf_xpow(32ull * d.sxy));
@@ -2319,7 +2342,7 @@ void launch_resolve_and_stats(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	hipLaunchKernelGGL(k_run_rank, dim3(ns), dim3(kBlock), 0, s, ra, rs, d.idbits, d.d_crc_acc.p, static_cast<uint32_t*>(nullptr));
 	st.done("k_run_rank");
 	RunLabelArgs none = {};
-	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, none);
+	hipLaunchKernelGGL((k_run_assign<uint8_t, false>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.G->p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, none);
 	st.done("k_run_assign");
 	if (d.head.label_format == FLAT) launch_flat_label_map(d);
 	else launch_pin_label_map(d, g, ra);
@@ -2350,11 +2373,11 @@ void launch_resolve_and_paint(ckl_decoder& d, const RunGeom& g, const RunArrays&
 	la.label_map = foreign ? d.foreign_label_map : d.d_label_map.p; la.comp_off = d.d_comp_off.p; la.ncomp_expect = d.d_ncomp_expect.p;
 	la.has_label = has_label ? 1u : 0u; la.label = label; la.run_label = run_label;
 	if (flat) {
-		hipLaunchKernelGGL((k_run_assign<OUT, true>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
+		hipLaunchKernelGGL((k_run_assign<OUT, true>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.G->p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
 		st.done("k_run_assign");
 	}
 	else {
-		hipLaunchKernelGGL((k_run_assign<OUT, false>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.d_G.p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
+		hipLaunchKernelGGL((k_run_assign<OUT, false>), dim3(run_assign_blocks(rs.nblk), ns), dim3(kBlock), 0, s, ra, rs, d.G->p, static_cast<uint32_t>(d.sxy), d.idbits, d.d_crc_acc.p, la);
 		st.done("k_run_assign");
 		launch_pin_label_map(d, g, ra);
 		st.done("k_label_map");
@@ -2418,8 +2441,8 @@ template <typename OUT>
 void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p, uint32_t z0, uint32_t n, void* out_device, bool flat, StageTimer* st, unsigned long long* diag) {
 	p.sa.zbase = z0;
 	const uint32_t npx = static_cast<uint32_t>(d.sxy);
-	if (diag) hipLaunchKernelGGL(k_strip_ccl<true>, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.d_G.p, npx, diag);
-	else hipLaunchKernelGGL(k_strip_ccl<false>, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.d_G.p, npx, diag);
+	if (diag) hipLaunchKernelGGL(k_strip_ccl<true>, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.G->p, npx, diag);
+	else hipLaunchKernelGGL(k_strip_ccl<false>, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.G->p, npx, diag);
 	if (st) st->done("k_strip_ccl");
 	if (flat) {
 		if (diag) hipLaunchKernelGGL((k_slice_resolve<OUT, true, true>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, diag + 8);
