@@ -174,20 +174,25 @@ __device__ __forceinline__ void run_unite(uint32_t* L, uint32_t a, uint32_t b) {
 // to the global forest for its own rows.
 constexpr uint32_t kStripRuns = 3072;       // LDS table: 12 KiB, so that the thread count and not the LDS bounds the workgroups per CU
 
-__device__ __forceinline__ uint32_t lds_find(volatile uint32_t* L, uint32_t a) {
-	uint32_t p = L[a];
+// union-find in LDS with relaxed workgroup-scope atomics instead of volatile accesses: hipcc keeps
+// volatile accesses on flat pointers (the address-space inference skips them), which costs a
+// flat instruction per access and miscompiles on the dynamic LDS base (ROCm 7.2)
+__device__ __forceinline__ uint32_t sm_load(const uint32_t* L, uint32_t i) { return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void sm_store(uint32_t* L, uint32_t i, uint32_t v) { __hip_atomic_store(L + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t sm_find(uint32_t* L, uint32_t a) {
+	uint32_t p = sm_load(L, a);
 	while (p != a) {
-		const uint32_t gp = L[p];
-		if (gp != p) L[a] = gp;     // path halving; a racing writer only ever stores an ancestor
+		const uint32_t gp = sm_load(L, p);
+		if (gp != p) sm_store(L, a, gp);     // path halving; a racing writer only ever stores an ancestor
 		a = p;
 		p = gp;
 	}
 	return a;
 }
-__device__ __forceinline__ void lds_unite(uint32_t* L, uint32_t a, uint32_t b) {
+__device__ __forceinline__ void sm_unite(uint32_t* L, uint32_t a, uint32_t b) {
 	for (;;) {
-		a = lds_find(L, a);
-		b = lds_find(L, b);
+		a = sm_find(L, a);
+		b = sm_find(L, b);
 		if (a == b) return;
 		if (a > b) { const uint32_t t = a; a = b; b = t; }
 		const uint32_t old = atomicMin(L + b, a);
@@ -195,6 +200,9 @@ __device__ __forceinline__ void lds_unite(uint32_t* L, uint32_t a, uint32_t b) {
 		b = old;
 	}
 }
+
+__device__ __forceinline__ uint32_t lds_find(uint32_t* L, uint32_t a) { return sm_find(L, a); }
+__device__ __forceinline__ void lds_unite(uint32_t* L, uint32_t a, uint32_t b) { sm_unite(L, a, b); }
 
 // grid = (strips per slice, nslices); strip_rows rows per strip
 static __global__ void __launch_bounds__(kBlock) k_run_union_strips(RunGeom g, RunArrays r, uint32_t strip_rows, uint32_t strip_runs) {

@@ -38,33 +38,6 @@ constexpr uint32_t kResolveCap = 12288;     // strip components per slice held i
 constexpr uint32_t kResolvePer = kResolveCap / kResolveBlock;
 constexpr uint32_t kMaxStrips = 1024;
 
-// union-find in LDS with relaxed workgroup-scope atomics instead of volatile accesses: hipcc keeps
-// volatile accesses on flat pointers (the address-space inference skips them), which costs a
-// flat instruction per access and miscompiles on the dynamic LDS base (ROCm 7.2)
-__device__ __forceinline__ uint32_t sm_load(const uint32_t* L, uint32_t i) { return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void sm_store(uint32_t* L, uint32_t i, uint32_t v) { __hip_atomic_store(L + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint32_t sm_find(uint32_t* L, uint32_t a) {
-	uint32_t p = sm_load(L, a);
-	while (p != a) {
-		const uint32_t gp = sm_load(L, p);
-		if (gp != p) sm_store(L, a, gp);     // path halving; a racing writer only ever stores an ancestor
-		a = p;
-		p = gp;
-	}
-	return a;
-}
-__device__ __forceinline__ void sm_unite(uint32_t* L, uint32_t a, uint32_t b) {
-	for (;;) {
-		a = sm_find(L, a);
-		b = sm_find(L, b);
-		if (a == b) return;
-		if (a > b) { const uint32_t t = a; a = b; b = t; }
-		const uint32_t old = atomicMin(L + b, a);
-		if (old == b) return;
-		b = old;
-	}
-}
-
 struct StripArrays {
 	// per strip (index si = slice * nstrips + strip); the per-run and per-strip-component arrays
 	// give every strip a fixed slot of `cap` entries, so that no kernel waits for another's counts

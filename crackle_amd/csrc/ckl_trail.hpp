@@ -445,7 +445,9 @@ static __global__ void __launch_bounds__(kBlock) k_trail_loops(TrailArgs a) {
 // in LDS or, for slices with too many nodes, in global memory
 template <bool LDS>
 __device__ __forceinline__ uint32_t tuf_load(uint32_t* L, uint32_t i) {
-	if (LDS) return reinterpret_cast<volatile uint32_t*>(L)[i];
+	// LDS: a relaxed workgroup-scope atomic load, not a volatile one (hipcc keeps volatile accesses on
+	// flat pointers: a flat instruction per access, and every wait for one waits for all memory traffic)
+	if (LDS) return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool LDS>
