@@ -164,8 +164,7 @@ def pmc_traffic(kernels, workload_key):
     for want in kernels:
       got = None
       for name, row in t.get("kernels", {}).items():
-        base = name.split("<")[0]
-        if base == want and not name.endswith("false>"):
+        if name.split("<")[0] == want:      # the instantiations of a template that ran (names carry their arguments)
           got = (got or 0.0) + float(row.get("hbm_bytes_per_launch", 0.0))
       if got is None:
         return None, {}
