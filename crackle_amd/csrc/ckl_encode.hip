@@ -13,6 +13,7 @@
 #include "ckl_common.hpp"
 #include "ckl_runs.hpp"
 #include "ckl_trail.hpp"
+#include "ckl_pins_dev.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -799,14 +800,6 @@ __global__ void __launch_bounds__(kBlock) k_gather_codes(
 // ------------------------------------------------------------------------------
 using namespace ckl;
 
-namespace ckl {
-// ckl_pins.hip
-template <typename LABEL>
-std::vector<uint8_t> encode_pins_host(
-	const LABEL* labels, const uint32_t* cc, int64_t sx, int64_t sy, int64_t sz,
-	const std::vector<uint32_t>& ncomp, uint64_t n_total,
-	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor);
-}
 
 constexpr uint32_t kTrailStreams = 8;
 
@@ -852,6 +845,9 @@ struct ckl_encoder {
 	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq;
 	DevBuf<uint8_t> d_keys;
 	DevBuf<uint32_t> d_cc_volume;                // global component id of every voxel (pin encoding only)
+	DevBuf<uint32_t> d_pin_kept, d_pin_u32;      // pin passes (ckl_pins_dev.hpp): kept-run bits, per-component depths
+	DevBuf<uint8_t> d_pin_tables;                // per-row label tables of k_pin_dedup
+	DevBuf<uint64_t> d_pin_u64;                  // per-component keys
 	DevBuf<uint32_t> d_slice_err2, d_n_uniq, d_uniq_blk;
 	DevBuf<uint8_t> d_labels_bin;                // the flat label section, assembled on device
 	uint32_t flat_max_rcap = 0;
@@ -1417,6 +1413,89 @@ void flat_collect(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, i
 	out.total = total;
 }
 
+// extract_columns / compute_multiverse / the component -> pin choice of find_suboptimal_pins
+// (src/pins.hpp:95-198, 300-346) as device passes over the resident label volume and
+// e.d_cc_volume (ckl_pins_dev.hpp); only per-component facts and the chosen pins are copied out.
+template <typename LABEL>
+PinCandidates pin_candidates_device(ckl_encoder& e, const LABEL* labels, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N) {
+	hipStream_t s = e.stream2;
+	PinVolume v;
+	v.sx = static_cast<uint32_t>(sx_); v.sy = static_cast<uint32_t>(sy_); v.sz = static_cast<uint32_t>(sz_);
+	v.sxy = static_cast<uint64_t>(v.sx) * v.sy;
+	const uint64_t voxels = v.sxy * v.sz;
+	const uint64_t kept_words = (voxels + 31) / 32;
+	e.d_pin_kept.ensure(kept_words);
+	CKL_HIP(hipMemsetAsync(e.d_pin_kept.p, 0, kept_words * sizeof(uint32_t), s));
+	v.cc = e.d_cc_volume.p; v.kept = e.d_pin_kept.p;
+
+	uint32_t cap = 16;
+	while (cap < 2u * v.sz) cap <<= 1;
+	const uint64_t slots = 2ull * cap * v.sy;
+	e.d_pin_tables.ensure(slots * sizeof(PinSlot));
+	CKL_HIP(hipMemsetAsync(e.d_pin_tables.p, 0, slots * sizeof(PinSlot), s));
+	hipLaunchKernelGGL(k_pin_dedup<LABEL>, dim3((v.sy + kPinRowBlock - 1) / kPinRowBlock), dim3(kPinRowBlock), 0, s,
+		labels, v, reinterpret_cast<PinSlot*>(e.d_pin_tables.p), cap);
+
+	e.d_pin_u64.ensure(4 * N + 1);
+	e.d_pin_u32.ensure(N + 1);
+	PinComponentArrays a;
+	a.first_any = reinterpret_cast<unsigned long long*>(e.d_pin_u64.p);
+	a.first_kept = a.first_any + N;
+	a.best = a.first_kept + N;
+	unsigned long long* choice = a.best + N;
+	a.first_depth = e.d_pin_u32.p;
+	CKL_HIP(hipMemsetAsync(a.first_any, 0xFF, 2 * N * sizeof(uint64_t), s));
+	CKL_HIP(hipMemsetAsync(a.best, 0, N * sizeof(uint64_t), s));
+	CKL_HIP(hipMemsetAsync(a.first_depth, 0, N * sizeof(uint32_t), s));
+	const dim3 cgrid((v.sx + kPinBlock - 1) / kPinBlock, v.sy);
+	hipLaunchKernelGGL((k_pin_columns<LABEL, 0>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
+	hipLaunchKernelGGL((k_pin_columns<LABEL, 1>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
+	hipLaunchKernelGGL((k_pin_columns<LABEL, 2>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
+	hipLaunchKernelGGL(k_pin_choice, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s, a, N, choice);
+
+	PinCandidates pc;
+	pc.comp_label = download(e.d_mapping.p, N, s);
+	pc.comp_first = download(reinterpret_cast<const uint64_t*>(a.first_any), N, s);
+	std::vector<uint64_t> chosen = download(reinterpret_cast<const uint64_t*>(choice), N, s);
+
+	// the distinct chosen runs, in traversal order
+	std::vector<uint64_t> keys;
+	keys.reserve(N);
+	for (uint64_t k : chosen) if (k != kPinNoKey) keys.push_back(k);
+	std::sort(keys.begin(), keys.end());
+	keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+	if (keys.size() >= kPinNone) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many pins");
+	const uint32_t P = static_cast<uint32_t>(keys.size());
+	pc.comp_pin.assign(N, kPinNone);
+	for (uint64_t c = 0; c < N; c++) {
+		if (chosen[c] == kPinNoKey) continue;
+		pc.comp_pin[c] = static_cast<uint32_t>(std::lower_bound(keys.begin(), keys.end(), chosen[c]) - keys.begin());
+	}
+	pc.pin_x.resize(P); pc.pin_y.resize(P); pc.pin_zs.resize(P);
+	for (uint32_t i = 0; i < P; i++) {
+		const uint64_t col = keys[i] / v.sz;
+		pc.pin_zs[i] = static_cast<uint32_t>(keys[i] % v.sz);
+		pc.pin_x[i] = static_cast<uint32_t>(col % v.sx);
+		pc.pin_y[i] = static_cast<uint32_t>(col / v.sx);
+	}
+	pc.pin_ids_off.assign(P + 1, 0);
+	if (P) {
+		DevBuf<uint64_t> d_keys, d_off;
+		DevBuf<uint32_t> d_ze, d_ids;
+		upload(d_keys, keys, s);
+		d_ze.ensure(P);
+		const dim3 pgrid((P + kPinBlock - 1) / kPinBlock);
+		hipLaunchKernelGGL(k_pin_extent<LABEL>, pgrid, dim3(kPinBlock), 0, s, labels, v, reinterpret_cast<const unsigned long long*>(d_keys.p), P, d_ze.p);
+		pc.pin_ze = download(d_ze.p, P, s);
+		for (uint32_t i = 0; i < P; i++) pc.pin_ids_off[i + 1] = pc.pin_ids_off[i] + (pc.pin_ze[i] - pc.pin_zs[i] + 1u);
+		upload(d_off, pc.pin_ids_off, s);
+		d_ids.ensure(pc.pin_ids_off[P]);
+		hipLaunchKernelGGL(k_pin_ids, pgrid, dim3(kPinBlock), 0, s, v, reinterpret_cast<const unsigned long long*>(d_keys.p), d_ze.p, d_off.p, P, d_ids.p);
+		pc.pin_ids = download(d_ids.p, pc.pin_ids_off[P], s);
+	}
+	return pc;
+}
+
 // The flat label section (labels.hpp:92-152) on device: sort + unique of the component
 // labels, keys by binary search, everything packed at its byte width into e.d_labels_bin.
 // Returns the section size; num_unique comes back for the header arithmetic only.
@@ -1593,11 +1672,9 @@ void encode_typed(
 			hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((e.plane_words + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
 				e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
 				e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, 0u, e.d_cc_volume.p);
-			std::vector<uint32_t> cc_host = download(e.d_cc_volume.p, voxels, s2);
-			std::vector<LABEL> labels_host = download(labels, voxels, s2);
-			HT_MARK("pins_d2h");
-			pins_binary = encode_pins_host<LABEL>(labels_host.data(), cc_host.data(), sx, sy, sz, fr.ncomp, N,
-				head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
+			const PinCandidates pc = pin_candidates_device<LABEL>(e, labels, sx, sy, sz, N);
+			HT_MARK("pins_device");
+			pins_binary = pins_cover_host(pc, sx, sy, sz, fr.ncomp, N, head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
 			label_bytes = pins_binary.size();
 			HT_MARK("pins_host");
 		}

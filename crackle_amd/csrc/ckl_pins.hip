@@ -11,9 +11,11 @@
 // insertion, backward-shift erase, 80 % load, growth in old-slot order), written so that
 // slot order is identical; the libstdc++ container is simply used as is.
 //
-// Per-voxel work (component labelling, crc32c) stays on the device (ckl_encode.hip); this
-// file consumes the label volume and the global component-id volume on the host.
-#include "ckl_common.hpp"
+// Per-voxel work (component labelling, crc32c, the column runs and their dedup, the
+// component -> pin choice) runs on the device (ckl_encode.hip, ckl_pins_dev.hpp); this file
+// consumes the per-component facts of ckl_pins.hpp.  pin_candidates_host restates the device
+// passes with the reference's own loops for the CPU tests and the sharded whole-volume stage.
+#include "ckl_pins.hpp"
 
 #include <algorithm>
 #include <thread>
@@ -94,10 +96,12 @@ public:
 		info[idx] = 0;
 		num--;
 	}
-	// first occupied slot in slot order (begin())
-	bool first(size_t& slot) const {
+	// first occupied slot in slot order (begin()).  `cursor` carries the search start between
+	// calls of a phase that only erases: backward-shift deletion never moves an entry in front
+	// of the first occupied slot.
+	bool first(size_t& slot, size_t& cursor) const {
 		if (!mask || !num) return false;
-		for (size_t i = 0; i < nbuf; i++) if (info[i]) { slot = i; return true; }
+		for (size_t i = cursor; i < nbuf; i++) if (info[i]) { slot = i; cursor = i; return true; }
 		return false;
 	}
 
@@ -162,37 +166,34 @@ private:
 	}
 };
 
-// candidate pin: a maximal z-run of one label in one (x, y) column (src/pins.hpp:51-93);
-// its component ids are cc[x, y, z_s .. z_e], looked up on demand
-struct CandidatePin {
-	uint32_t x, y, z_s, z_e;
-};
-
 }  // namespace
 
+// ---- host statement of the device passes (src/pins.hpp:95-163 with the choice rule of 325-340) ----
 template <typename LABEL>
-std::vector<uint8_t> encode_pins_host(
-	const LABEL* labels, const uint32_t* cc /* global component ids */,
-	int64_t sx, int64_t sy, int64_t sz,
-	const std::vector<uint32_t>& ncomp, uint64_t n_total,
-	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor
-) {
-	const uint64_t sxy = static_cast<uint64_t>(sx) * sy, voxels = sxy * sz;
-
-	// ---- extract_columns (src/pins.hpp:126-163) with add_pin's dedup (95-124) ----
-	RhTable pinsets;                                  // label -> index into pvecs, reference slot order
-	std::vector<std::vector<CandidatePin>> pvecs;
-	auto pinset_of = [&](uint64_t label) -> std::vector<CandidatePin>& {
+PinCandidates pin_candidates_host(const LABEL* labels, const uint32_t* cc, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N) {
+	const uint64_t sx = static_cast<uint64_t>(sx_), sy = static_cast<uint64_t>(sy_), sz = static_cast<uint64_t>(sz_);
+	const uint64_t sxy = sx * sy, voxels = sxy * sz;
+	struct Cand { uint32_t x, y, z_s, z_e; };
+	RhTable pinsets;                                  // label -> index into pvecs
+	std::vector<std::vector<Cand>> pvecs;
+	PinCandidates pc;
+	pc.comp_label.assign(N, 0);
+	pc.comp_first.assign(N, kPinNoKey);
+	pc.comp_pin.assign(N, kPinNone);
+	for (uint64_t i = 0; i < voxels; i++) {
+		if (cc[i] >= N) throw Error(CKL_ERR_ARG, "crackle_amd: component id out of range");
+		pc.comp_label[cc[i]] = static_cast<uint64_t>(labels[i]);
+	}
+	auto add_pin = [&](uint64_t label, uint64_t z_start, uint64_t x, uint64_t y, uint64_t z) {
+		uint64_t& cf = pc.comp_first[cc[x + sx * y + sxy * z_start]];
+		cf = std::min(cf, pin_key(x, y, z_start, sx, sz));
 		bool found;
 		const size_t s = pinsets.insert(label, static_cast<uint32_t>(pvecs.size()), found);
 		if (!found) pvecs.emplace_back();
-		return pvecs[pinsets.vals[s]];
-	};
-	auto add_pin = [&](uint64_t label, uint64_t z_start, uint64_t x, uint64_t y, uint64_t z) {
-		std::vector<CandidatePin>& v = pinset_of(label);
-		const CandidatePin np{ static_cast<uint32_t>(x), static_cast<uint32_t>(y), static_cast<uint32_t>(z_start), static_cast<uint32_t>(z) };
+		std::vector<Cand>& v = pvecs[pinsets.vals[s]];
+		const Cand np{ static_cast<uint32_t>(x), static_cast<uint32_t>(y), static_cast<uint32_t>(z_start), static_cast<uint32_t>(z) };
 		if (v.empty()) { v.push_back(np); return; }
-		CandidatePin& last = v.back();
+		Cand& last = v.back();
 		if (static_cast<uint64_t>(last.x) == x - 1 && static_cast<uint64_t>(last.y) == y) {
 			if (last.z_s <= z_start && last.z_e >= z) return;
 			else if (last.z_s >= z_start && last.z_e <= z) last = np;
@@ -200,12 +201,12 @@ std::vector<uint8_t> encode_pins_host(
 		}
 		else v.push_back(np);
 	};
-	for (uint64_t y = 0; y < static_cast<uint64_t>(sy); y++) {
-		for (uint64_t x = 0; x < static_cast<uint64_t>(sx); x++) {
-			const uint64_t loc = x + static_cast<uint64_t>(sx) * y;
+	for (uint64_t y = 0; y < sy; y++) {
+		for (uint64_t x = 0; x < sx; x++) {
+			const uint64_t loc = x + sx * y;
 			LABEL label = labels[loc];
 			uint64_t z_start = 0, z = 1;
-			for (; z < static_cast<uint64_t>(sz); z++) {
+			for (; z < sz; z++) {
 				const LABEL cur = labels[loc + sxy * z];
 				if (label != cur) {
 					add_pin(label, z_start, x, y, z - 1);
@@ -217,75 +218,99 @@ std::vector<uint8_t> encode_pins_host(
 			add_pin(label, z_start, x, y, z - 1);
 		}
 	}
-
-	// ---- compute_multiverse (src/pins.hpp:165-198): per label the flat set of its
-	// component ids, inserted in linear voxel order at every change of component id ----
-	std::vector<RhTable> universe(pvecs.size());
-	{
-		bool f; size_t s;
-		uint32_t last = cc[0];
-		if (pinsets.find(labels[0], s)) universe[pinsets.vals[s]].insert(cc[0], 0, f);
-		for (uint64_t i = 1; i < voxels; i++) {
-			if (cc[i] != last) {
-				if (pinsets.find(labels[i], s)) universe[pinsets.vals[s]].insert(cc[i], 0, f);
-				last = cc[i];
+	// the pin drawn for a component: first candidate holding it, then the last deeper one
+	std::vector<uint32_t> first_depth(N, 0);
+	std::vector<const Cand*> pick(N, nullptr);
+	for (const std::vector<Cand>& pv : pvecs) {
+		for (const Cand& p : pv) {
+			const uint64_t base = p.x + sx * p.y;
+			const uint32_t depth = p.z_e - p.z_s;
+			for (uint32_t z = p.z_s; z <= p.z_e; z++) {
+				const uint32_t c = cc[base + sxy * z];
+				if (!pick[c]) { pick[c] = &p; first_depth[c] = depth; }
+				else if (depth > first_depth[c]) pick[c] = &p;
 			}
 		}
-		if (pinsets.find(labels[voxels - 1], s)) universe[pinsets.vals[s]].insert(cc[voxels - 1], 0, f);
+	}
+	std::vector<std::pair<uint64_t, uint32_t>> order;      // (key of the picked pin, component)
+	order.reserve(N);
+	for (uint64_t c = 0; c < N; c++) if (pick[c]) order.emplace_back(pin_key(pick[c]->x, pick[c]->y, pick[c]->z_s, sx, sz), static_cast<uint32_t>(c));
+	std::sort(order.begin(), order.end());
+	pc.pin_ids_off.push_back(0);
+	for (size_t i = 0; i < order.size(); i++) {
+		const Cand& p = *pick[order[i].second];
+		if (i == 0 || order[i].first != order[i - 1].first) {
+			pc.pin_x.push_back(p.x); pc.pin_y.push_back(p.y); pc.pin_zs.push_back(p.z_s); pc.pin_ze.push_back(p.z_e);
+			const uint64_t base = p.x + sx * p.y;
+			for (uint32_t z = p.z_s; z <= p.z_e; z++) pc.pin_ids.push_back(cc[base + sxy * z]);
+			pc.pin_ids_off.push_back(pc.pin_ids.size());
+		}
+		pc.comp_pin[order[i].second] = static_cast<uint32_t>(pc.pin_x.size() - 1);
+	}
+	return pc;
+}
+
+template PinCandidates pin_candidates_host<uint8_t>(const uint8_t*, const uint32_t*, int64_t, int64_t, int64_t, uint64_t);
+template PinCandidates pin_candidates_host<uint16_t>(const uint16_t*, const uint32_t*, int64_t, int64_t, int64_t, uint64_t);
+template PinCandidates pin_candidates_host<uint32_t>(const uint32_t*, const uint32_t*, int64_t, int64_t, int64_t, uint64_t);
+template PinCandidates pin_candidates_host<uint64_t>(const uint64_t*, const uint32_t*, int64_t, int64_t, int64_t, uint64_t);
+
+std::vector<uint8_t> pins_cover_host(
+	const PinCandidates& pc, int64_t sx, int64_t sy, int64_t sz,
+	const std::vector<uint32_t>& ncomp, uint64_t n_total,
+	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor
+) {
+	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
+	const uint64_t N = pc.comp_label.size();
+	const size_t P = pc.pin_x.size();
+	if (pc.comp_first.size() != N || pc.comp_pin.size() != N || pc.pin_ids_off.size() != P + 1) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
+
+	// ---- pinsets (src/pins.hpp:126-163): a robin-hood node map keyed by label; its slot order
+	// depends on the order the labels were first seen, i.e. on their first column run ----
+	RhTable pinsets;                                  // label -> label index
+	size_t n_labels = 0;
+	{
+		std::vector<std::pair<uint64_t, uint32_t>> order;
+		order.reserve(N);
+		for (uint64_t c = 0; c < N; c++) if (pc.comp_first[c] != kPinNoKey) order.emplace_back(pc.comp_first[c], static_cast<uint32_t>(c));
+		std::sort(order.begin(), order.end());
+		for (const auto& o : order) {
+			bool found;
+			pinsets.insert(pc.comp_label[o.second], static_cast<uint32_t>(n_labels), found);
+			if (!found) n_labels++;
+		}
+	}
+
+	// ---- compute_multiverse (src/pins.hpp:165-198): per label the flat set of its component
+	// ids, inserted in linear voxel order = ascending id ----
+	std::vector<RhTable> universe(n_labels);
+	for (uint64_t c = 0; c < N; c++) {
+		size_t s; bool f;
+		if (!pinsets.find(pc.comp_label[c], s)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: component of a label without column runs");
+		universe[pinsets.vals[s]].insert(c, 0, f);
 	}
 
 	// ---- find_suboptimal_pins per label (src/pins.hpp:300-346).  Labels are independent:
 	// solved on a thread pool, stored by label index ----
-	std::vector<std::vector<CandidatePin>> chosen(pvecs.size());
+	std::vector<std::vector<uint32_t>> chosen(n_labels);      // pin indices, in the order taken
 	auto solve = [&](size_t li) {
-		const std::vector<CandidatePin>& pv = pvecs[li];
 		RhTable& uni = universe[li];
-		// component -> candidate pins that contain it, in pin order (CSR over this label's components)
-		RhTable c2p;
-		std::vector<uint32_t> counts;
-		for (size_t i = 0; i < pv.size(); i++) {
-			const uint64_t base = pv[i].x + static_cast<uint64_t>(sx) * pv[i].y;
-			for (uint32_t z = pv[i].z_s; z <= pv[i].z_e; z++) {
-				bool f;
-				const size_t s = c2p.insert(cc[base + sxy * z], static_cast<uint32_t>(counts.size()), f);
-				if (!f) counts.push_back(0);
-				counts[c2p.vals[s]]++;
-			}
-		}
-		std::vector<uint32_t> start(counts.size() + 1, 0);
-		for (size_t k = 0; k < counts.size(); k++) start[k + 1] = start[k] + counts[k];
-		std::vector<uint32_t> fill(start.begin(), start.end() - 1), members(start.back());
-		for (size_t i = 0; i < pv.size(); i++) {
-			const uint64_t base = pv[i].x + static_cast<uint64_t>(sx) * pv[i].y;
-			for (uint32_t z = pv[i].z_s; z <= pv[i].z_e; z++) {
-				size_t s;
-				c2p.find(cc[base + sxy * z], s);
-				members[fill[c2p.vals[s]]++] = static_cast<uint32_t>(i);
-			}
-		}
-		std::vector<CandidatePin>& out = chosen[li];
-		while (!pv.empty() && uni.num) {
+		std::vector<uint32_t>& out = chosen[li];
+		size_t cursor = 0;
+		while (uni.num) {
 			size_t us;
-			if (!uni.first(us)) break;
+			if (!uni.first(us, cursor)) break;
 			const uint64_t picked = uni.keys[us];
-			size_t cs;
-			if (!c2p.find(picked, cs)) { uni.erase(picked); continue; }   // cannot happen: every component lies on a column run
-			const uint32_t l = c2p.vals[cs];
-			const CandidatePin* max_pin = &pv[members[start[l]]];
-			const int max_depth = static_cast<int>(max_pin->z_e - max_pin->z_s);   // never updated
-			for (uint32_t m = start[l] + 1; m < start[l + 1]; m++) {
-				const CandidatePin* cur = &pv[members[m]];
-				if (static_cast<int>(cur->z_e - cur->z_s) > max_depth) max_pin = cur;
-			}
-			const uint64_t base = max_pin->x + static_cast<uint64_t>(sx) * max_pin->y;
-			for (uint32_t z = max_pin->z_s; z <= max_pin->z_e; z++) uni.erase(cc[base + sxy * z]);
-			out.push_back(*max_pin);
+			const uint32_t p = pc.comp_pin[picked];
+			if (p == kPinNone) { uni.erase(picked); continue; }   // cannot happen: every component lies on a kept column run
+			for (uint64_t k = pc.pin_ids_off[p]; k < pc.pin_ids_off[p + 1]; k++) uni.erase(pc.pin_ids[k]);
+			out.push_back(p);
 		}
 	};
 	{
-		const size_t nl = pvecs.size();
+		const size_t nl = n_labels;
 		size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
-		nthreads = std::min(nthreads, std::max<size_t>(1, nl / 16));
+		nthreads = std::min(nthreads, std::max<size_t>(1, nl / 64));
 		if (nthreads <= 1) {
 			for (size_t li = 0; li < nl; li++) solve(li);
 		}
@@ -311,9 +336,10 @@ std::vector<uint8_t> encode_pins_host(
 		if (!pinsets.info[slot]) continue;
 		all_pins[pinsets.keys[slot]] = pinsets.vals[slot];
 	}
-	auto total_depth = [](const std::vector<CandidatePin>& v) {
+	auto depth_of = [&](uint32_t p) { return static_cast<uint64_t>(pc.pin_ze[p] - pc.pin_zs[p]); };
+	auto total_depth = [&](const std::vector<uint32_t>& v) {
 		uint64_t d = 0;
-		for (const CandidatePin& p : v) d += p.z_e - p.z_s;
+		for (uint32_t p : v) d += depth_of(p);
 		return d;
 	};
 	uint64_t bgcolor = (manual_bgcolor != 0) ? 1 : 0;   // Q1: compress_helper takes `const bool manual_bgcolor`
@@ -321,7 +347,7 @@ std::vector<uint8_t> encode_pins_host(
 		bgcolor = 0;
 		uint64_t max_pins = 0, max_pins_depth = static_cast<uint64_t>(sz);
 		for (const auto& kv : all_pins) {
-			const std::vector<CandidatePin>& v = chosen[kv.second];
+			const std::vector<uint32_t>& v = chosen[kv.second];
 			if (v.size() > max_pins) {
 				bgcolor = kv.first;
 				max_pins = v.size();
@@ -341,9 +367,9 @@ std::vector<uint8_t> encode_pins_host(
 	std::vector<uint64_t> all_labels;
 	all_labels.reserve(all_pins.size());
 	for (const auto& kv : all_pins) {
-		const std::vector<CandidatePin>& v = chosen[kv.second];
+		const std::vector<uint32_t>& v = chosen[kv.second];
 		max_pins = std::max<uint64_t>(max_pins, v.size());
-		for (const CandidatePin& p : v) max_depth = std::max<uint64_t>(max_depth, p.z_e - p.z_s);
+		for (uint32_t p : v) max_depth = std::max<uint64_t>(max_depth, depth_of(p));
 		all_labels.push_back(kv.first);
 	}
 	std::sort(all_labels.begin(), all_labels.end());
@@ -363,14 +389,13 @@ std::vector<uint8_t> encode_pins_host(
 	for (int64_t z = 0; z < sz; z++) put_le(bin, ncomp[z], component_width);
 	bin.push_back(combined);
 
-	struct Sorted { uint64_t idx, depth; const CandidatePin* pin; };
+	struct Sorted { uint64_t idx, depth; uint32_t pin; };
 	for (uint64_t label : all_labels) {
-		const std::vector<CandidatePin>& v = chosen[all_pins[label]];
+		const std::vector<uint32_t>& v = chosen[all_pins[label]];
 		std::vector<Sorted> sp;
 		sp.reserve(v.size());
-		for (const CandidatePin& p : v) {
-			sp.push_back({ static_cast<uint64_t>(p.x) + static_cast<uint64_t>(sx) * (static_cast<uint64_t>(p.y) + static_cast<uint64_t>(sy) * p.z_s),
-				static_cast<uint64_t>(p.z_e - p.z_s), &p });
+		for (uint32_t p : v) {
+			sp.push_back({ static_cast<uint64_t>(pc.pin_x[p]) + static_cast<uint64_t>(sx) * (static_cast<uint64_t>(pc.pin_y[p]) + static_cast<uint64_t>(sy) * pc.pin_zs[p]), depth_of(p), p });
 		}
 		std::sort(sp.begin(), sp.end(), [](const Sorted& a, const Sorted& b) { return a.idx < b.idx; });
 		uint64_t n_pin_repr = 0;
@@ -388,8 +413,7 @@ std::vector<uint8_t> encode_pins_host(
 		std::vector<uint32_t> ids;
 		for (const Sorted& s : sp) {
 			if (s.depth >= cc_efficient_threshold) continue;
-			const uint64_t base = s.pin->x + static_cast<uint64_t>(sx) * s.pin->y;
-			for (uint32_t z = s.pin->z_s; z <= s.pin->z_e; z++) ids.push_back(cc[base + sxy * z]);
+			for (uint64_t k = pc.pin_ids_off[s.pin]; k < pc.pin_ids_off[s.pin + 1]; k++) ids.push_back(pc.pin_ids[k]);
 		}
 		std::sort(ids.begin(), ids.end());
 		put_le(bin, ids.size(), num_pins_width);
@@ -397,11 +421,6 @@ std::vector<uint8_t> encode_pins_host(
 	}
 	return bin;
 }
-
-template std::vector<uint8_t> encode_pins_host<uint8_t>(const uint8_t*, const uint32_t*, int64_t, int64_t, int64_t, const std::vector<uint32_t>&, uint64_t, int, int, bool, int64_t);
-template std::vector<uint8_t> encode_pins_host<uint16_t>(const uint16_t*, const uint32_t*, int64_t, int64_t, int64_t, const std::vector<uint32_t>&, uint64_t, int, int, bool, int64_t);
-template std::vector<uint8_t> encode_pins_host<uint32_t>(const uint32_t*, const uint32_t*, int64_t, int64_t, int64_t, const std::vector<uint32_t>&, uint64_t, int, int, bool, int64_t);
-template std::vector<uint8_t> encode_pins_host<uint64_t>(const uint64_t*, const uint32_t*, int64_t, int64_t, int64_t, const std::vector<uint32_t>&, uint64_t, int, int, bool, int64_t);
 
 }  // namespace ckl
 
@@ -421,14 +440,13 @@ extern "C" int ckl_pin_labels_host(
 		for (uint32_t c : nc) total += c;
 		Header h;
 		h.sx = static_cast<uint32_t>(sx); h.sy = static_cast<uint32_t>(sy); h.sz = static_cast<uint32_t>(sz);
-		std::vector<uint8_t> bin;
-#define CKL_PINS(T) bin = encode_pins_host<T>(static_cast<const T*>(labels), cc, sx, sy, sz, nc, total, h.pin_index_width(), stored_width, auto_bgcolor != 0, manual_bgcolor)
-		if (dtype_bytes == 1) CKL_PINS(uint8_t);
-		else if (dtype_bytes == 2) CKL_PINS(uint16_t);
-		else if (dtype_bytes == 4) CKL_PINS(uint32_t);
-		else if (dtype_bytes == 8) CKL_PINS(uint64_t);
+		PinCandidates pc;
+		if (dtype_bytes == 1) pc = pin_candidates_host<uint8_t>(static_cast<const uint8_t*>(labels), cc, sx, sy, sz, total);
+		else if (dtype_bytes == 2) pc = pin_candidates_host<uint16_t>(static_cast<const uint16_t*>(labels), cc, sx, sy, sz, total);
+		else if (dtype_bytes == 4) pc = pin_candidates_host<uint32_t>(static_cast<const uint32_t*>(labels), cc, sx, sy, sz, total);
+		else if (dtype_bytes == 8) pc = pin_candidates_host<uint64_t>(static_cast<const uint64_t*>(labels), cc, sx, sy, sz, total);
 		else throw Error(CKL_ERR_ARG, "crackle_amd: dtype width must be 1, 2, 4 or 8 bytes");
-#undef CKL_PINS
+		const std::vector<uint8_t> bin = pins_cover_host(pc, sx, sy, sz, nc, total, h.pin_index_width(), stored_width, auto_bgcolor != 0, manual_bgcolor);
 		uint8_t* p = static_cast<uint8_t*>(malloc(bin.size() ? bin.size() : 1));
 		if (!p) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
 		memcpy(p, bin.data(), bin.size());

@@ -1,0 +1,52 @@
+// Pin label encoding: what the device hands to the host cover (ckl_pins.hip).
+//
+// pins::compute (src/pins.hpp:348-403) walks the label volume and the component-id volume
+// three times on one core (extract_columns, compute_multiverse, the component -> pins index
+// of find_suboptimal_pins).  Here those walks are device passes (ckl_pins_dev.hpp) and only
+// per-component facts cross PCIe:
+//
+//   * the label of every component (component ids ascend in first-appearance order, which is
+//     the insertion order of compute_multiverse, src/pins.hpp:165-198);
+//   * the first column run of every component in extract_columns' traversal order
+//     (y, x, z_start) — the order the labels enter `pinsets`;
+//   * the pin find_suboptimal_pins takes when the component is drawn from the universe
+//     (src/pins.hpp:325-340).  Candidate pins are never removed, only components are, so
+//     that choice is a function of the component alone: with the candidate pins containing
+//     it in vector order p0, p1, ..., it is the LAST p_i deeper than p0, or p0
+//     (`max_depth` is never updated);
+//   * for every pin so chosen its column, z-range and the component ids along it.
+#pragma once
+#include "ckl_common.hpp"
+
+#include <vector>
+
+namespace ckl {
+
+constexpr uint64_t kPinNoKey = ~0ull;
+constexpr uint32_t kPinNone = 0xFFFFFFFFu;
+
+// order of extract_columns (src/pins.hpp:126-163): rows, then columns, then z
+inline uint64_t pin_key(uint64_t x, uint64_t y, uint64_t z_s, uint64_t sx, uint64_t sz) { return (y * sx + x) * sz + z_s; }
+
+struct PinCandidates {
+	std::vector<uint64_t> comp_label;     // [N] label of component c
+	std::vector<uint64_t> comp_first;     // [N] smallest pin_key of a column run starting inside c (kPinNoKey: none)
+	std::vector<uint32_t> comp_pin;       // [N] pin taken when c is drawn (index below; kPinNone cannot happen)
+	std::vector<uint32_t> pin_x, pin_y, pin_zs, pin_ze;
+	std::vector<uint64_t> pin_ids_off;    // [P + 1]
+	std::vector<uint32_t> pin_ids;        // component ids along each pin, z ascending
+};
+
+// The order-sensitive part (cover, background colour, section bytes) on the host.
+std::vector<uint8_t> pins_cover_host(
+	const PinCandidates& pc, int64_t sx, int64_t sy, int64_t sz,
+	const std::vector<uint32_t>& ncomp, uint64_t n_total,
+	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor);
+
+// PinCandidates from host volumes with the reference's own loops (add_pin vectors): the
+// CPU statement the device passes are tested against, and the sharded codec's whole-volume
+// stage (ckl_pin_labels_host).
+template <typename LABEL>
+PinCandidates pin_candidates_host(const LABEL* labels, const uint32_t* cc, int64_t sx, int64_t sy, int64_t sz, uint64_t n_total);
+
+}  // namespace ckl
