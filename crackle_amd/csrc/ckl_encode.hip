@@ -1428,13 +1428,26 @@ PinCandidates pin_candidates_device(ckl_encoder& e, const LABEL* labels, int64_t
 	CKL_HIP(hipMemsetAsync(e.d_pin_kept.p, 0, kept_words * sizeof(uint32_t), s));
 	v.cc = e.d_cc_volume.p; v.kept = e.d_pin_kept.p;
 
-	uint32_t cap = 16;
-	while (cap < 2u * v.sz) cap <<= 1;
-	const uint64_t slots = 2ull * cap * v.sy;
-	e.d_pin_tables.ensure(slots * sizeof(PinSlot));
-	CKL_HIP(hipMemsetAsync(e.d_pin_tables.p, 0, slots * sizeof(PinSlot), s));
-	hipLaunchKernelGGL(k_pin_dedup<LABEL>, dim3((v.sy + kPinRowBlock - 1) / kPinRowBlock), dim3(kPinRowBlock), 0, s,
-		labels, v, reinterpret_cast<PinSlot*>(e.d_pin_tables.p), cap);
+	const bool by_thread = getenv("CKL_PINS_ROW_THREADS") != nullptr;      // testing: the general kernel on small volumes
+	if (v.sz <= 1024u && !by_thread) {
+		// a wavefront per row, label tables in registers
+		const dim3 wgrid((v.sy + kPinWaves - 1) / kPinWaves), wblock(64 * kPinWaves);
+		if (v.sz <= 64u) hipLaunchKernelGGL((k_pin_dedup_wave<LABEL, 1>), wgrid, wblock, 0, s, labels, v);
+		else if (v.sz <= 128u) hipLaunchKernelGGL((k_pin_dedup_wave<LABEL, 2>), wgrid, wblock, 0, s, labels, v);
+		else if (v.sz <= 256u) hipLaunchKernelGGL((k_pin_dedup_wave<LABEL, 4>), wgrid, wblock, 0, s, labels, v);
+		else if (v.sz <= 512u) hipLaunchKernelGGL((k_pin_dedup_wave<LABEL, 8>), wgrid, wblock, 0, s, labels, v);
+		else hipLaunchKernelGGL((k_pin_dedup_wave<LABEL, 16>), wgrid, wblock, 0, s, labels, v);
+	}
+	else {
+		// taller volumes: a thread per row with its label tables in global memory
+		uint32_t cap = 16;
+		while (cap < 2u * v.sz) cap <<= 1;
+		const uint64_t slots = 2ull * cap * v.sy;
+		e.d_pin_tables.ensure(slots * sizeof(PinSlot));
+		CKL_HIP(hipMemsetAsync(e.d_pin_tables.p, 0, slots * sizeof(PinSlot), s));
+		hipLaunchKernelGGL(k_pin_dedup<LABEL>, dim3((v.sy + kPinRowBlock - 1) / kPinRowBlock), dim3(kPinRowBlock), 0, s,
+			labels, v, reinterpret_cast<PinSlot*>(e.d_pin_tables.p), cap);
+	}
 
 	e.d_pin_u64.ensure(4 * N + 1);
 	e.d_pin_u32.ensure(N + 1);

@@ -116,6 +116,110 @@ __global__ void __launch_bounds__(kPinRowBlock) k_pin_dedup(const LABEL* __restr
 	}
 }
 
+// ---- k_pin_dedup, one wavefront per row (sz <= 64 * K) ----
+// Lane l holds the labels of slices 64 k + l of the current column (loaded one column ahead);
+// a ballot of "the label changes above me" gives the column's runs, which the wave then walks
+// uniformly.  The two label tables live in registers, one entry per lane and k: a lookup is a
+// compare + ballot, an append a predicated move.  No LDS, no hashing, no dependent memory
+// round trip per run; the only stores are the kept-bit atomics of lane 0.
+template <typename LABEL>
+__device__ __forceinline__ LABEL wave_read(LABEL v, uint32_t lane) {
+	if constexpr (sizeof(LABEL) == 8) {
+		const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), lane);
+		const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32), lane);
+		return static_cast<LABEL>((static_cast<uint64_t>(hi) << 32) | lo);
+	}
+	else return static_cast<LABEL>(__builtin_amdgcn_readlane(static_cast<uint32_t>(v), lane));
+}
+
+constexpr uint32_t kPinWaves = 4;      // rows per workgroup
+
+// grid = ceil(sy / 4) x 256
+template <typename LABEL, int K>
+__global__ void __launch_bounds__(64 * kPinWaves) k_pin_dedup_wave(const LABEL* __restrict__ labels, PinVolume v) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t y = blockIdx.x * kPinWaves + (threadIdx.x >> 6);
+	if (y >= v.sy) return;
+	const uint64_t row = static_cast<uint64_t>(y) * v.sx;
+	LABEL lab[K], nlab[K];
+	LABEL cur_lab[K], prev_lab[K];
+	uint32_t cur_zz[K], prev_zz[K];      // z_s | z_e << 16
+	uint32_t n_prev = 0;
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		nlab[k] = labels[row + v.sxy * min(static_cast<uint32_t>(k) * 64u + lane, v.sz - 1u)];
+		cur_lab[k] = prev_lab[k] = 0; cur_zz[k] = prev_zz[k] = 0;
+	}
+	for (uint32_t x = 0; x < v.sx; x++) {
+		const uint64_t col = row + x;
+#pragma unroll
+		for (int k = 0; k < K; k++) lab[k] = nlab[k];
+		{
+			const uint64_t ncol = row + min(x + 1u, v.sx - 1u);
+#pragma unroll
+			for (int k = 0; k < K; k++) nlab[k] = labels[ncol + v.sxy * min(static_cast<uint32_t>(k) * 64u + lane, v.sz - 1u)];
+		}
+		uint32_t n_cur = 0, z_s = 0;
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			const uint32_t z = static_cast<uint32_t>(k) * 64u + lane;
+			// label of the slice above: the next lane, or lane 0 of the next register
+			LABEL up = __shfl_down(lab[k], 1);
+			if (k + 1 < K) { const LABEL first_up = wave_read(lab[k + 1 < K ? k + 1 : k], 0); if (lane == 63u) up = first_up; }
+			const bool ends = z < v.sz && (z == v.sz - 1u || up != lab[k]);
+			unsigned long long m = __ballot(ends);
+			while (m) {
+				const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
+				m &= m - 1ull;
+				const uint32_t z_e = static_cast<uint32_t>(k) * 64u + b;
+				const LABEL L = wave_read(lab[k], b);
+				const uint32_t zz = z_s | (z_e << 16);
+				// an earlier run of this column is L's last pin: plain append, it becomes the last
+				bool in_cur = false;
+#pragma unroll
+				for (int j = 0; j < K; j++) {
+					if (static_cast<uint32_t>(j) * 64u < n_cur) {
+						const bool hit = static_cast<uint32_t>(j) * 64u + lane < n_cur && cur_lab[j] == L;
+						if (__ballot(hit)) { in_cur = true; if (hit) cur_zz[j] = zz; }
+					}
+				}
+				bool keep = true;
+				if (!in_cur) {
+#pragma unroll
+					for (int j = 0; j < K; j++) {
+						if (static_cast<uint32_t>(j) * 64u < n_prev) {
+							const bool hit = static_cast<uint32_t>(j) * 64u + lane < n_prev && prev_lab[j] == L;
+							const unsigned long long hm = __ballot(hit);
+							if (hm) {
+								const uint32_t lzz = __builtin_amdgcn_readlane(prev_zz[j], static_cast<uint32_t>(__ffsll(static_cast<long long>(hm))) - 1u);
+								const uint32_t lz_s = lzz & 0xFFFFu, lz_e = lzz >> 16;
+								if (lz_s <= z_s && lz_e >= z_e) keep = false;                 // covered by the neighbour: dropped
+								else if (lz_s >= z_s && lz_e <= z_e && lane == 0) {             // covers the neighbour: takes its place
+									const uint64_t bit = col - 1u + v.sxy * lz_s;
+									atomicAnd(v.kept + (bit >> 5), ~(1u << (bit & 31u)));
+								}
+							}
+						}
+					}
+					if (keep) {
+#pragma unroll
+						for (int j = 0; j < K; j++) if (n_cur == static_cast<uint32_t>(j) * 64u + lane) { cur_lab[j] = L; cur_zz[j] = zz; }
+						n_cur++;
+					}
+				}
+				if (keep && lane == 0) {
+					const uint64_t bit = col + v.sxy * z_s;
+					atomicOr(v.kept + (bit >> 5), 1u << (bit & 31u));
+				}
+				z_s = z_e + 1u;
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < K; k++) { prev_lab[k] = cur_lab[k]; prev_zz[k] = cur_zz[k]; }
+		n_prev = n_cur;
+	}
+}
+
 struct PinComponentArrays {
 	unsigned long long* first_any;      // [N] smallest key of a run starting in the component
 	unsigned long long* first_kept;     // [N] smallest key of a kept run containing it
