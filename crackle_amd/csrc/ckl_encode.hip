@@ -596,33 +596,24 @@ __global__ void __launch_bounds__(kBlock) k_mapping_runs(
 }
 
 // Global component id of every voxel (cc3d.hpp:371-400 numbers components continuously
-// across slices) for the pin encoder: one thread per 32-pixel word of a row, ids read from
-// the run tables.  grid = (ceil(plane_words / 256), nslices)
+// across slices) for the pin encoder: one thread per pixel, its run found by a popcount in
+// the row's break word, ids read from the run tables.  grid = (ceil(sxy / 256), nslices)
 __global__ void __launch_bounds__(kBlock) k_paint_components(
 	const uint32_t* __restrict__ planeV, uint32_t row_words, uint64_t plane_words, uint32_t sx, uint64_t sxy,
 	const uint32_t* __restrict__ word_base, const uint64_t* __restrict__ rbase, const uint32_t* __restrict__ run_cc,
 	const uint64_t* __restrict__ comp_off, uint32_t id_base, uint32_t* __restrict__ out
 ) {
 	const uint32_t zi = blockIdx.y;
-	const uint32_t wi = blockIdx.x * kBlock + threadIdx.x;
-	if (wi >= plane_words) return;
-	const uint32_t y = wi / row_words, w = wi - y * row_words;
-	const uint32_t left = sx - w * 32u;
-	const uint32_t valid = left >= 32u ? 32u : left;
-	uint32_t b = planeV[zi * plane_words + wi];
+	const uint32_t px = blockIdx.x * kBlock + threadIdx.x;
+	if (px >= sxy) return;
+	const uint32_t y = px / sx, x = px - y * sx;
+	const uint32_t w = x >> 5, bit = x & 31u;
+	const uint64_t wi = zi * plane_words + static_cast<uint64_t>(y) * row_words + w;
+	uint32_t b = planeV[wi];
 	if (w == 0) b |= 1u;
-	const uint32_t* cc = run_cc + rbase[zi];
-	const uint32_t off = static_cast<uint32_t>(comp_off[zi]) + id_base;
-	uint32_t run = word_base[zi * plane_words + wi] - 1u;   // run of the pixel left of this word
-	uint32_t* dst = out + zi * sxy + static_cast<uint64_t>(y) * sx + w * 32u;
-	uint32_t id = 0;
-	for (uint32_t i = 0; i < valid; i++) {
-		if (i == 0 || ((b >> i) & 1u)) {
-			run += (b >> i) & 1u;
-			id = cc[run] + off;
-		}
-		dst[i] = id;
-	}
+	// word_base counts the runs that start before this word; bit i set = a run starts at pixel i
+	const uint32_t run = word_base[wi] - 1u + __popc(b & (0xFFFFFFFFu >> (31u - bit)));
+	out[zi * sxy + px] = run_cc[rbase[zi] + run] + static_cast<uint32_t>(comp_off[zi]) + id_base;
 }
 
 // ------------------------------------------------------------------------------
@@ -1462,7 +1453,8 @@ PinCandidates pin_candidates_device(ckl_encoder& e, const LABEL* labels, int64_t
 	CKL_HIP(hipMemsetAsync(a.first_depth, 0, N * sizeof(uint32_t), s));
 	const dim3 cgrid((v.sx + kPinBlock - 1) / kPinBlock, v.sy);
 	hipLaunchKernelGGL((k_pin_columns<LABEL, 0>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
-	hipLaunchKernelGGL((k_pin_columns<LABEL, 1>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
+	hipLaunchKernelGGL((k_pin_extent<LABEL, true>), dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s,
+		labels, v, a.first_kept, static_cast<uint32_t>(N), a.first_depth);
 	hipLaunchKernelGGL((k_pin_columns<LABEL, 2>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
 	hipLaunchKernelGGL(k_pin_choice, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s, a, N, choice);
 
@@ -1498,7 +1490,7 @@ PinCandidates pin_candidates_device(ckl_encoder& e, const LABEL* labels, int64_t
 		upload(d_keys, keys, s);
 		d_ze.ensure(P);
 		const dim3 pgrid((P + kPinBlock - 1) / kPinBlock);
-		hipLaunchKernelGGL(k_pin_extent<LABEL>, pgrid, dim3(kPinBlock), 0, s, labels, v, reinterpret_cast<const unsigned long long*>(d_keys.p), P, d_ze.p);
+		hipLaunchKernelGGL((k_pin_extent<LABEL, false>), pgrid, dim3(kPinBlock), 0, s, labels, v, reinterpret_cast<const unsigned long long*>(d_keys.p), P, d_ze.p);
 		pc.pin_ze = download(d_ze.p, P, s);
 		for (uint32_t i = 0; i < P; i++) pc.pin_ids_off[i + 1] = pc.pin_ids_off[i] + (pc.pin_ze[i] - pc.pin_zs[i] + 1u);
 		upload(d_off, pc.pin_ids_off, s);
@@ -1682,7 +1674,7 @@ void encode_typed(
 			// device passes above; the order-sensitive cover runs on the host (ckl_pins.hip)
 			if (N > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
 			e.d_cc_volume.ensure(voxels);
-			hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((e.plane_words + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
+			hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((static_cast<uint64_t>(sx) * sy + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
 				e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
 				e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, 0u, e.d_cc_volume.p);
 			const PinCandidates pc = pin_candidates_device<LABEL>(e, labels, sx, sy, sz, N);
@@ -2056,7 +2048,7 @@ int ckl_encoder_components(
 		if (fr.total + id_base > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
 		hipStream_t s2 = e->stream2;
 		e->d_cc_volume.ensure(voxels);
-		hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((e->plane_words + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
+		hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((static_cast<uint64_t>(sx) * sy + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
 			e->d_planes.p, e->row_words, e->plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
 			e->d_word_base.p, e->d_rbase.p, e->d_run_cc.p, e->d_comp_off.p, id_base, e->d_cc_volume.p);
 		CKL_HIP(hipMemcpyAsync(cc_host, e->d_cc_volume.p, voxels * sizeof(uint32_t), hipMemcpyDeviceToHost, s2));

@@ -10,14 +10,14 @@
 //                  thread per row walks x with two generation-stamped open-addressing tables
 //                  (labels of column x-1 / x, no clearing) and marks the kept runs in a bit
 //                  volume at (x, y, z_start).
-//   k_pin_first    per component: first column run (any) and first KEPT run containing it, in
-//                  traversal order (y, x, z_start)            — atomicMin on 64-bit keys
-//   k_pin_depth    depth of that first kept run
-//   k_pin_best     last kept run deeper than the first        — atomicMax
+//   k_pin_columns<0>  per component: first column run (any) and first KEPT run containing it,
+//                  in traversal order (y, x, z_start)         — atomicMin on 64-bit keys
+//   k_pin_extent<depth>  depth of that first kept run (one thread per component)
+//   k_pin_columns<2>  last kept run deeper than the first     — atomicMax
 //   k_pin_choice   the run find_suboptimal_pins takes per component (src/pins.hpp:325-340)
 //   k_pin_extent / k_pin_ids   z-range and component ids of the distinct chosen runs
 //
-// The three per-column passes read labels + ids + kept bits coalesced along x
+// The two per-column passes read labels + ids + kept bits coalesced along x
 // (~9 B per voxel each); the dedup pass is latency bound (sx * runs-per-column dependent
 // steps per row) and reads the volume once through L2.
 #pragma once
@@ -227,7 +227,8 @@ struct PinComponentArrays {
 	unsigned long long* best;           // [N] 1 + largest key of a kept run deeper than the first (0: none)
 };
 
-// One thread per (x, y) column walks z; `pass` 0: firsts, 1: depth of the first, 2: last deeper.
+// One thread per (x, y) column walks z; PASS 0: firsts, 2: last kept run deeper than the first
+// (the depth of the first comes from k_pin_extent in between).
 // grid = ceil(sx / 256) x sy
 template <typename LABEL, int PASS>
 __global__ void __launch_bounds__(kPinBlock) k_pin_columns(const LABEL* __restrict__ labels, PinVolume v, PinComponentArrays a) {
@@ -255,7 +256,6 @@ __global__ void __launch_bounds__(kPinBlock) k_pin_columns(const LABEL* __restri
 			for (uint32_t zz = z_s; zz <= z_e; zz++) {
 				const uint32_t c = v.cc[col + v.sxy * zz];
 				if (PASS == 0) { if (key < a.first_kept[c]) atomicMin(a.first_kept + c, key); }
-				else if (PASS == 1) { if (a.first_kept[c] == key) a.first_depth[c] = depth; }
 				else { if (depth > a.first_depth[c] && key + 1ull > a.best[c]) atomicMax(a.best + c, key + 1ull); }
 			}
 		}
@@ -271,18 +271,20 @@ __global__ void __launch_bounds__(kPinBlock) k_pin_choice(PinComponentArrays a, 
 	choice[c] = b ? b - 1ull : a.first_kept[c];
 }
 
-// z-range of the distinct chosen runs: one thread per run
-template <typename LABEL>
-__global__ void __launch_bounds__(kPinBlock) k_pin_extent(const LABEL* __restrict__ labels, PinVolume v, const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ z_e_out) {
+// z-range of a run given by its key, one thread per key: the last slice (the distinct chosen
+// runs) or the depth (the first kept run of every component; a component without one keeps 0)
+template <typename LABEL, bool DEPTH>
+__global__ void __launch_bounds__(kPinBlock) k_pin_extent(const LABEL* __restrict__ labels, PinVolume v, const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ out) {
 	const uint32_t i = blockIdx.x * kPinBlock + threadIdx.x;
 	if (i >= n) return;
 	const unsigned long long key = keys[i];
+	if (key == kPinNoKey) return;
 	const uint32_t z_s = static_cast<uint32_t>(key % v.sz);
 	const uint64_t col = key / v.sz;
 	const LABEL label = labels[col + v.sxy * z_s];
 	uint32_t z = z_s + 1u;
 	while (z < v.sz && labels[col + v.sxy * z] == label) z++;
-	z_e_out[i] = z - 1u;
+	out[i] = DEPTH ? z - 1u - z_s : z - 1u;
 }
 
 __global__ void __launch_bounds__(kPinBlock) k_pin_ids(PinVolume v, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ z_e, const uint64_t* __restrict__ off, uint32_t n, uint32_t* __restrict__ ids) {
