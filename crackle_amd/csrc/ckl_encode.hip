@@ -1406,9 +1406,12 @@ void flat_collect(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, i
 
 // extract_columns / compute_multiverse / the component -> pin choice of find_suboptimal_pins
 // (src/pins.hpp:95-198, 300-346) as device passes over the resident label volume and
-// e.d_cc_volume (ckl_pins_dev.hpp); only per-component facts and the chosen pins are copied out.
+// the component id volume (ckl_pins_dev.hpp); only per-component facts and the chosen pins are copied out.
 template <typename LABEL>
-PinCandidates pin_candidates_device(ckl_encoder& e, const LABEL* labels, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N) {
+PinCandidates pin_candidates_device(
+	ckl_encoder& e, const LABEL* labels, const uint32_t* cc /* device: component id of every voxel */,
+	const uint64_t* comp_label /* device: label of every component */, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N
+) {
 	hipStream_t s = e.stream2;
 	PinVolume v;
 	v.sx = static_cast<uint32_t>(sx_); v.sy = static_cast<uint32_t>(sy_); v.sz = static_cast<uint32_t>(sz_);
@@ -1417,7 +1420,7 @@ PinCandidates pin_candidates_device(ckl_encoder& e, const LABEL* labels, int64_t
 	const uint64_t kept_words = (voxels + 31) / 32;
 	e.d_pin_kept.ensure(kept_words);
 	CKL_HIP(hipMemsetAsync(e.d_pin_kept.p, 0, kept_words * sizeof(uint32_t), s));
-	v.cc = e.d_cc_volume.p; v.kept = e.d_pin_kept.p;
+	v.cc = cc; v.kept = e.d_pin_kept.p;
 
 	const bool by_thread = getenv("CKL_PINS_ROW_THREADS") != nullptr;      // testing: the general kernel on small volumes
 	if (v.sz <= 1024u && !by_thread) {
@@ -1459,7 +1462,7 @@ PinCandidates pin_candidates_device(ckl_encoder& e, const LABEL* labels, int64_t
 	hipLaunchKernelGGL(k_pin_choice, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s, a, N, choice);
 
 	PinCandidates pc;
-	pc.comp_label = download(e.d_mapping.p, N, s);
+	pc.comp_label = download(comp_label, N, s);
 	pc.comp_first = download(reinterpret_cast<const uint64_t*>(a.first_any), N, s);
 	std::vector<uint64_t> chosen = download(reinterpret_cast<const uint64_t*>(choice), N, s);
 
@@ -1677,7 +1680,7 @@ void encode_typed(
 			hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((static_cast<uint64_t>(sx) * sy + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
 				e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
 				e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, 0u, e.d_cc_volume.p);
-			const PinCandidates pc = pin_candidates_device<LABEL>(e, labels, sx, sy, sz, N);
+			const PinCandidates pc = pin_candidates_device<LABEL>(e, labels, e.d_cc_volume.p, e.d_mapping.p, sx, sy, sz, N);
 			HT_MARK("pins_device");
 			pins_binary = pins_cover_host(pc, sx, sy, sz, fr.ncomp, N, head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
 			label_bytes = pins_binary.size();
@@ -2021,39 +2024,111 @@ int ckl_encoder_markov_stats(
 	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
 }
 
+// shared by ckl_encoder_components / ckl_encoder_components_device: components of the slab, ids
+// painted into cc_device (null: the session's own volume); returns where they are
+static uint32_t* encoder_components(ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz, uint32_t id_base, uint32_t* cc_device, uint32_t* ncomp_host) {
+	check_dims(sx, sy, sz, e->dtype_bytes, 0);
+	select_device(e->device);
+	wait_for_default_stream(e->stream, e->ev_in);
+	wait_for_default_stream(e->stream2, e->ev_in);
+	const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
+	if (voxels == 0) return cc_device;
+	const bool cached = e->planes_for == labels_device && e->planes_dims[0] == sx && e->planes_dims[1] == sy && e->planes_dims[2] == sz;
+	FlatResult fr;
+#define CKL_COMP(T) do { \
+		if (!cached) planes_pass<T>(*e, reinterpret_cast<const T*>(labels_device), sx, sy, sz, nullptr); \
+		flat_enqueue(*e, sx, sy, sz); \
+		flat_collect<T>(*e, reinterpret_cast<const T*>(labels_device), sx, sy, sz, fr); \
+	} while (0)
+	if (e->dtype_bytes == 1) CKL_COMP(uint8_t);
+	else if (e->dtype_bytes == 2) CKL_COMP(uint16_t);
+	else if (e->dtype_bytes == 4) CKL_COMP(uint32_t);
+	else CKL_COMP(uint64_t);
+#undef CKL_COMP
+	if (fr.total + id_base > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
+	hipStream_t s2 = e->stream2;
+	if (!cc_device) { e->d_cc_volume.ensure(voxels); cc_device = e->d_cc_volume.p; }
+	hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((static_cast<uint64_t>(sx) * sy + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
+		e->d_planes.p, e->row_words, e->plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
+		e->d_word_base.p, e->d_rbase.p, e->d_run_cc.p, e->d_comp_off.p, id_base, cc_device);
+	for (int64_t z = 0; z < sz; z++) ncomp_host[z] = fr.ncomp[z];
+	return cc_device;
+}
+
 int ckl_encoder_components(
 	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
 	uint32_t id_base, uint32_t* cc_host, uint32_t* ncomp_host
 ) {
 	try {
 		if (!e || !cc_host || !ncomp_host) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
-		check_dims(sx, sy, sz, e->dtype_bytes, 0);
-		select_device(e->device);
-		wait_for_default_stream(e->stream, e->ev_in);
-		wait_for_default_stream(e->stream2, e->ev_in);
+		const uint32_t* cc = encoder_components(e, labels_device, sx, sy, sz, id_base, nullptr, ncomp_host);
 		const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
-		if (voxels == 0) return CKL_OK;
-		const bool cached = e->planes_for == labels_device && e->planes_dims[0] == sx && e->planes_dims[1] == sy && e->planes_dims[2] == sz;
-		FlatResult fr;
-#define CKL_COMP(T) do { \
-			if (!cached) planes_pass<T>(*e, reinterpret_cast<const T*>(labels_device), sx, sy, sz, nullptr); \
-			flat_enqueue(*e, sx, sy, sz); \
-			flat_collect<T>(*e, reinterpret_cast<const T*>(labels_device), sx, sy, sz, fr); \
+		if (voxels) CKL_HIP(hipMemcpyAsync(cc_host, cc, voxels * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream2));
+		CKL_HIP(hipStreamSynchronize(e->stream2));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_encoder_components_device(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	uint32_t id_base, uint32_t* cc_device, uint32_t* ncomp_host
+) {
+	try {
+		if (!e || !cc_device || !ncomp_host) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		encoder_components(e, labels_device, sx, sy, sz, id_base, cc_device, ncomp_host);
+		CKL_HIP(hipStreamSynchronize(e->stream2));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_encoder_pin_labels(
+	ckl_encoder* e, const void* labels_device, const uint32_t* cc_device,
+	int64_t sx, int64_t sy, int64_t sz, const uint32_t* ncomp_host,
+	int stored_width, int auto_bgcolor, int64_t manual_bgcolor,
+	uint8_t** out, uint64_t* out_len
+) {
+	try {
+		if (!e || !labels_device || !cc_device || !ncomp_host || !out || !out_len) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		if (sx <= 0 || sy <= 0 || sz <= 0) throw Error(CKL_ERR_ARG, "crackle_amd: empty volume");
+		if (sx > 0xFFFFFFFFll || sy > 0xFFFFFFFFll || sz > 0xFFFFFFFFll) throw Error(CKL_ERR_ARG, "crackle_amd: dimensions must fit 32 bits");
+		if (stored_width != 1 && stored_width != 2 && stored_width != 4 && stored_width != 8) throw Error(CKL_ERR_ARG, "crackle_amd: stored width must be 1, 2, 4 or 8 bytes");
+		select_device(e->device);
+		wait_for_default_stream(e->stream2, e->ev_in);
+		std::vector<uint32_t> nc(ncomp_host, ncomp_host + sz);
+		uint64_t N = 0;
+		for (uint32_t c : nc) N += c;
+		if (N == 0 || N > 0xFFFFFFFFull) throw Error(CKL_ERR_ARG, "crackle_amd: component counts out of range");
+		Header h;
+		h.sx = static_cast<uint32_t>(sx); h.sy = static_cast<uint32_t>(sy); h.sz = static_cast<uint32_t>(sz);
+		hipStream_t s = e->stream2;
+		const uint64_t voxels = static_cast<uint64_t>(sx) * sy * sz;
+		// label of every component, read where the id changes along x (every component has such a voxel)
+		e->d_mapping.ensure(N + 1);
+		e->d_slice_err2.ensure(1);
+		CKL_HIP(hipMemsetAsync(e->d_mapping.p, 0, N * sizeof(uint64_t), s));
+		CKL_HIP(hipMemsetAsync(e->d_slice_err2.p, 0, sizeof(uint32_t), s));
+		PinCandidates pc;
+		const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((voxels + kPinBlock - 1) / kPinBlock, 0x7FFFFFFFull));
+#define CKL_PINS(T) do { \
+			hipLaunchKernelGGL(k_pin_component_labels<T>, dim3(blocks), dim3(kPinBlock), 0, s, reinterpret_cast<const T*>(labels_device), cc_device, voxels, static_cast<uint32_t>(sx), N, \
+				reinterpret_cast<unsigned long long*>(e->d_mapping.p), e->d_slice_err2.p); \
+			if (download(e->d_slice_err2.p, 1, s)[0]) throw Error(CKL_ERR_ARG, "crackle_amd: component id out of range"); \
+			pc = pin_candidates_device<T>(*e, reinterpret_cast<const T*>(labels_device), cc_device, e->d_mapping.p, sx, sy, sz, N); \
 		} while (0)
-		if (e->dtype_bytes == 1) CKL_COMP(uint8_t);
-		else if (e->dtype_bytes == 2) CKL_COMP(uint16_t);
-		else if (e->dtype_bytes == 4) CKL_COMP(uint32_t);
-		else CKL_COMP(uint64_t);
-#undef CKL_COMP
-		if (fr.total + id_base > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
-		hipStream_t s2 = e->stream2;
-		e->d_cc_volume.ensure(voxels);
-		hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((static_cast<uint64_t>(sx) * sy + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
-			e->d_planes.p, e->row_words, e->plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
-			e->d_word_base.p, e->d_rbase.p, e->d_run_cc.p, e->d_comp_off.p, id_base, e->d_cc_volume.p);
-		CKL_HIP(hipMemcpyAsync(cc_host, e->d_cc_volume.p, voxels * sizeof(uint32_t), hipMemcpyDeviceToHost, s2));
-		CKL_HIP(hipStreamSynchronize(s2));
-		for (int64_t z = 0; z < sz; z++) ncomp_host[z] = fr.ncomp[z];
+		if (e->dtype_bytes == 1) CKL_PINS(uint8_t);
+		else if (e->dtype_bytes == 2) CKL_PINS(uint16_t);
+		else if (e->dtype_bytes == 4) CKL_PINS(uint32_t);
+		else CKL_PINS(uint64_t);
+#undef CKL_PINS
+		const std::vector<uint8_t> bin = pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor != 0, manual_bgcolor);
+		uint8_t* p = static_cast<uint8_t*>(host_out_alloc(bin.size() ? bin.size() : 1));
+		memcpy(p, bin.data(), bin.size());
+		*out = p;
+		*out_len = bin.size();
 		return CKL_OK;
 	}
 	catch (const Error& err) { set_last_error(err.what()); return err.status; }

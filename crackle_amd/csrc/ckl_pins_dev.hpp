@@ -271,6 +271,20 @@ __global__ void __launch_bounds__(kPinBlock) k_pin_choice(PinComponentArrays a, 
 	choice[c] = b ? b - 1ull : a.first_kept[c];
 }
 
+// label of every component from the two volumes (the sharded encoder's whole-volume stage has no
+// run tables): read where the id changes along x.  Grid-stride over the voxels.
+template <typename LABEL>
+__global__ void __launch_bounds__(kPinBlock) k_pin_component_labels(
+	const LABEL* __restrict__ labels, const uint32_t* __restrict__ cc, uint64_t voxels, uint32_t sx, uint64_t n,
+	unsigned long long* __restrict__ comp_label, uint32_t* __restrict__ err
+) {
+	for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kPinBlock + threadIdx.x; i < voxels; i += static_cast<uint64_t>(gridDim.x) * kPinBlock) {
+		const uint32_t c = cc[i];
+		if (c >= n) { *err = 1u; continue; }
+		if (i % sx == 0 || cc[i - 1] != c) comp_label[c] = static_cast<unsigned long long>(labels[i]);
+	}
+}
+
 // z-range of a run given by its key, one thread per key: the last slice (the distinct chosen
 // runs) or the depth (the first kept run of every component; a component without one keeps 0)
 template <typename LABEL, bool DEPTH>

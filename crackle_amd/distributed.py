@@ -379,6 +379,33 @@ class HipBackend:
     """Copies the slab's labels (x fastest) into the host array `out`."""
     out[...] = vol.reshape(-1).cpu().numpy().view(out.dtype)
 
+  def components_device(self, vol, shape, id_base: int, cc_out: torch.Tensor) -> np.ndarray:
+    """Per-voxel component ids of the slab written into the device tensor cc_out (int32 bit
+    patterns of uint32 ids, x fastest); returns the component count of every slice."""
+    e = self._encoder(shape, vol.element_size())
+    nc = np.zeros(max(int(shape[2]), 1), dtype=np.uint32)
+    rc = self._L.ckl_encoder_components_device(e, vol.data_ptr(), shape[0], shape[1], shape[2], int(id_base),
+                                               cc_out.data_ptr(), nc.ctypes.data)
+    if rc != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+    return nc[:int(shape[2])]
+
+  def pin_labels_device(self, labels_all: torch.Tensor, cc_all: torch.Tensor, shape_all, ncomp_all: np.ndarray, stored_width: int) -> np.ndarray:
+    """The pin label section of the whole volume from labels and global component ids resident on
+    this rank's GPU (ckl_encoder_pin_labels); uses the slab session's stream and scratch."""
+    if self._enc is None:
+      raise RuntimeError("pin_labels_device follows an encode of this backend")
+    nc = np.ascontiguousarray(ncomp_all, dtype=np.uint32)
+    out_p, out_n = C.c_void_p(), C.c_uint64()
+    rc = self._L.ckl_encoder_pin_labels(self._enc, labels_all.data_ptr(), cc_all.data_ptr(), shape_all[0], shape_all[1], shape_all[2],
+                                        nc.ctypes.data, int(stored_width), 1, 0, C.byref(out_p), C.byref(out_n))
+    if rc != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+    try:
+      return np.frombuffer(C.string_at(out_p.value, out_n.value), dtype=np.uint8)
+    finally:
+      self._L.ckl_free(out_p)
+
   def defer_codes(self, shape, itemsize: int, defer: bool):
     """Following encodes of this shape leave the crack codes in HBM for codes_to_host."""
     self._L.ckl_encoder_defer_codes(self._encoder(shape, itemsize), int(bool(defer)))
@@ -566,11 +593,36 @@ class ShardedCodec:
     sz_tot = int(table[:, 3].sum())
     z_before = int(table[:self.rank, 3].sum())
     pins_section = None
-    if use_pins:
+    if use_pins and hasattr(be, "pin_labels_device"):
       # Pin labels (pins.hpp:348-403, labels.hpp:157-344): candidate pins are z-runs per (x,y)
-      # column over the WHOLE volume and the greedy cover is order sensitive, so the slabs'
-      # labels and component ids (numbered continuously over all slices) are laid side by side
-      # in a second node-local mapping and rank 0 runs the host stage once.
+      # column over the WHOLE volume and the greedy cover is order sensitive.  The slabs' labels
+      # and component ids (numbered continuously over all slices) are collected in rank 0's HBM
+      # — device to device over the collective backend when it carries device tensors (RCCL) —
+      # and rank 0 runs the pin passes there (ckl_encoder_pin_labels); nothing volumetric
+      # touches the host.
+      ncomp_mine = _unpack(sec.comp, cw, sec.sz)
+      id_base = int(table[:self.rank, 1].sum())
+      sxy = sx * sy
+      cc_mine = torch.empty(max(sxy * sec.sz, 1), dtype=torch.int32, device=vol.device)
+      nc_mine = be.components_device(vol, slab_shape, id_base, cc_mine)
+      if not np.array_equal(nc_mine.astype(np.int64), ncomp_mine):
+        raise RuntimeError("component counts of the slab stream and of the component pass differ")
+      counts = [int(table[r, 3]) * sxy for r in range(self.world)]
+      lab_all = self._collect_on_root(vol.reshape(-1), counts)
+      cc_all = self._collect_on_root(cc_mine[:sxy * sec.sz], counts)
+      max_sz = max(int(table[:, 3].max()), 1)
+      nc_pad = torch.zeros(max_sz, dtype=torch.int64, device=dev)
+      nc_pad[:sec.sz] = torch.from_numpy(nc_mine.astype(np.int64)).to(dev)
+      nc_every = [torch.empty_like(nc_pad) for _ in range(self.world)]
+      dist.all_gather(nc_every, nc_pad)
+      if self.rank == 0:
+        nc_all = np.concatenate([nc_every[r][:int(table[r, 3])].cpu().numpy() for r in range(self.world)]).astype(np.uint32)
+        pins_section = be.pin_labels_device(lab_all, cc_all, (sx, sy, sz_tot), nc_all, sw)
+        del lab_all, cc_all
+    elif use_pins:
+      # backends without a device stage (the CPU orchestration tests): the slabs' labels and
+      # component ids are laid side by side in a second node-local mapping and rank 0 runs the
+      # host statement of the stage once.
       ncomp_mine = _unpack(sec.comp, cw, sec.sz)
       id_base = int(table[:self.rank, 1].sum())
       sxy = sx * sy
@@ -604,6 +656,7 @@ class ShardedCodec:
           raise RuntimeError(_lib.last_error())
         pins_section = np.frombuffer(C.string_at(out_p.value, out_n.value), dtype=np.uint8)
         L.ckl_free(out_p)
+    if use_pins:
       n_pin = torch.tensor([0 if pins_section is None else len(pins_section)], dtype=torch.int64, device=dev)
       dist.broadcast(n_pin, src=0)
       label_bytes = int(n_pin.item())
@@ -687,6 +740,30 @@ class ShardedCodec:
       import sys
       print("[ckl sharded compress ms] " + " ".join(f"{n}={v:.2f}" for n, v in marks), file=sys.stderr)
     return SharedStream(self._shared.mm, total)
+
+  def _collect_on_root(self, mine: torch.Tensor, counts):
+    """Concatenates every rank's 1-D device tensor (counts[r] elements, rank order) in rank 0's
+    device memory with point-to-point transfers: device to device when the process group carries
+    device tensors (RCCL over xGMI), through host staging otherwise (gloo).  None off rank 0."""
+    direct = self.device.type == mine.device.type
+    if self.rank != 0:
+      if counts[self.rank]:
+        dist.send(mine.contiguous() if direct else mine.to(self.device), dst=0)
+      return None
+    whole = torch.empty(max(sum(counts), 1), dtype=mine.dtype, device=mine.device)
+    whole[:counts[0]] = mine
+    off = counts[0]
+    for r in range(1, self.world):
+      if not counts[r]:
+        continue
+      if direct:
+        dist.recv(whole[off:off + counts[r]], src=r)
+      else:
+        stage = torch.empty(counts[r], dtype=mine.dtype, device=self.device)
+        dist.recv(stage, src=r)
+        whole[off:off + counts[r]] = stage.to(mine.device)
+      off += counts[r]
+    return whole
 
   # -- decode -------------------------------------------------------------------
   def open_decoder(self, binary: Optional[bytes], slab_shape):

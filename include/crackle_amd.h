@@ -250,6 +250,25 @@ int ckl_encoder_components(
 	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
 	uint32_t id_base, uint32_t* cc_host, uint32_t* ncomp_host);
 
+/* As ckl_encoder_components, the ids staying on the device (cc_device: sx*sy*sz uint32). */
+int ckl_encoder_components_device(
+	ckl_encoder* e, const void* labels_device, int64_t sx, int64_t sy, int64_t sz,
+	uint32_t id_base, uint32_t* cc_device, uint32_t* ncomp_host);
+
+/* The pin label section (pins::compute, src/pins.hpp:348-403 + labels::encode_condensed_pins,
+ * src/labels.hpp:157-344) of a WHOLE volume whose labels (the session's dtype) and global
+ * component ids are resident on the session's device; ncomp_host holds the component count of
+ * each of the sz slices.  What ckl_encoder_run does for allow_pins after labelling components,
+ * as a stage of its own for the sharded encoder: rank 0 collects the slabs' labels and ids
+ * (ckl_encoder_components_device) in its HBM and calls this once.  Column runs, their dedup and
+ * the component -> pin choice run on the device, the ordered cover on the host.  *out is
+ * released with ckl_free. */
+int ckl_encoder_pin_labels(
+	ckl_encoder* e, const void* labels_device, const uint32_t* cc_device,
+	int64_t sx, int64_t sy, int64_t sz, const uint32_t* ncomp_host,
+	int stored_width, int auto_bgcolor, int64_t manual_bgcolor,
+	uint8_t** out, uint64_t* out_len);
+
 int ckl_encoder_last_timing(const ckl_encoder* e, float* pipeline_ms, float* dominant_kernel_ms);
 void ckl_encoder_destroy(ckl_encoder* e);
 
@@ -268,9 +287,10 @@ int ckl_zstack(
  * labels::encode_condensed_pins (src/labels.hpp:157-344).  `labels` (dtype_bytes wide)
  * and `cc` (global component id of every voxel, as crackle::cc3d::connected_components
  * numbers them, src/cc3d.hpp:371-400) are HOST pointers in Fortran order; `ncomp` holds
- * the component count of each of the sz slices.  ckl_encoder_run calls this stage itself
- * after labelling components on the device; it is exported so that the order-sensitive
- * host logic can be tested without a GPU.  *out is released with ckl_free. */
+ * the component count of each of the sz slices.  ckl_encoder_run and ckl_encoder_pin_labels
+ * find the candidate pins on the device and share the ordered cover with this function, which
+ * finds them with the reference's own loops; it is exported so that the order-sensitive host
+ * logic can be tested without a GPU.  *out is released with ckl_free. */
 int ckl_pin_labels_host(
 	const void* labels, int dtype_bytes, const uint32_t* cc,
 	int64_t sx, int64_t sy, int64_t sz, const uint32_t* ncomp,

@@ -96,3 +96,49 @@ def test_thread_per_row_dedup_equals_oracle(name, checker, monkeypatch):
   monkeypatch.setenv("CKL_PINS_ROW_THREADS", "1")
   arr = CASES[name]()
   assert crackle_amd.compress(arr, allow_pins=1) == checker.compress(arr, allow_pins=True)
+
+
+def test_whole_volume_pin_stage_on_device(checker):
+  """ckl_encoder_components_device + ckl_encoder_pin_labels (the sharded encoder's whole-volume
+  stage on rank 0): ids of two slabs painted into one device volume, the section computed from
+  device-resident labels and ids equals the label section of the oracle's stream; ids out of
+  range are refused."""
+  import ctypes as C
+  import torch
+  from crackle_amd import _lib
+  from crackle_amd.headers import CrackleHeader
+  L = _lib.lib()
+  dev = torch.device("cuda:0")
+  for name in ("blocks_3labels", "voronoi_modulus", "blocks_u64"):
+    arr = CASES[name]()
+    sx, sy, sz = arr.shape
+    signed = {1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[arr.dtype.itemsize]
+    vol = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 1, 0)).view(signed)).to(dev)
+    half = sz // 2
+    cc = torch.zeros(sx * sy * sz, dtype=torch.int32, device=dev)
+    nc = np.zeros(sz, dtype=np.uint32)
+    base = 0
+    for z0, z1 in ((0, half), (half, sz)):
+      enc = C.c_void_p()
+      assert L.ckl_encoder_create(sx, sy, z1 - z0, arr.dtype.itemsize, 0, C.byref(enc)) == 0
+      slab = vol[z0:z1].contiguous()
+      part = np.zeros(z1 - z0, dtype=np.uint32)
+      torch.cuda.synchronize()
+      assert L.ckl_encoder_components_device(enc, slab.data_ptr(), sx, sy, z1 - z0, base, cc[sx * sy * z0:].data_ptr(), part.ctypes.data) == 0, _lib.last_error()
+      nc[z0:z1] = part
+      base += int(part.sum())
+      if z1 != sz:
+        L.ckl_encoder_destroy(enc)
+    want = checker.compress(arr, allow_pins=True)
+    out, n = C.c_void_p(), C.c_uint64()
+    h = CrackleHeader.frombytes(want)
+    sw = int(h.stored_data_width)
+    first = 29 + 4 * (sz + 1)
+    want_section = want[first:first + h.num_label_bytes]
+    assert L.ckl_encoder_pin_labels(enc, vol.data_ptr(), cc.data_ptr(), sx, sy, sz, nc.ctypes.data, sw, 1, 0, C.byref(out), C.byref(n)) == 0, _lib.last_error()
+    got = C.string_at(out.value, n.value)
+    L.ckl_free(out)
+    assert got == want_section, name
+    cc[7] = base + 5      # an id no slice accounts for
+    assert L.ckl_encoder_pin_labels(enc, vol.data_ptr(), cc.data_ptr(), sx, sy, sz, nc.ctypes.data, sw, 1, 0, C.byref(out), C.byref(n)) != 0
+    L.ckl_encoder_destroy(enc)
