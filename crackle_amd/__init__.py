@@ -10,11 +10,11 @@ from .codec import (
   voxel_counts, centroids, bounding_boxes, reencode, voxel_connectivity_graph,
   crack_crcs, structure_equal, labels_crc, check, ok,
 )
-from .operations import zstack, zsplit, zshatter, array_equal, mode_pooling_2x2x1
+from .operations import zstack, zsplit, zshatter, array_equal, mode_pooling_2x2x1, point_cloud
 
 __all__ = [
   "CrackleHeader", "FormatError", "LabelFormat", "CrackFormat",
   "compress", "decompress", "decompress_range", "header", "labels", "num_labels", "contains",
   "voxel_counts", "centroids", "bounding_boxes", "reencode", "voxel_connectivity_graph", "crack_crcs", "structure_equal", "labels_crc", "check", "ok",
-  "zstack", "zsplit", "zshatter", "array_equal", "mode_pooling_2x2x1",
+  "zstack", "zsplit", "zshatter", "array_equal", "mode_pooling_2x2x1", "point_cloud",
 ]

@@ -83,6 +83,9 @@ EXPORTS = {
   "ckl_decoder_vcg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
   "ckl_voxel_connectivity_graph": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
   "ckl_voxel_connectivity_graph_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
+  "ckl_point_cloud": (C.c_int, [
+    C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
+    C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_reencode_markov": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_decoder_crack_planes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
   "ckl_zsplit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),

@@ -1,0 +1,211 @@
+// Point clouds: the contour tracer of crackle::dual_graph (src/dual_graph.hpp:133-275) behind
+// operations::point_cloud (src/operations.hpp:183-262), on the crack planes the decoder leaves.
+//
+// The reference traces one slice on one core: a raster scan finds the next start pixel
+// (VCGGraph::next_contour), a wall follower walks the boundary loop through it and sets a
+// visited bit on every pixel it passes; what a later start sees depends on those bits, so the
+// order of discovery is part of the result.  Slices are independent, the walk inside a slice is
+// not: here a slice is one wavefront.  The scan for the next start is 64 pixels wide (ballot);
+// the walk itself is wave-uniform code — the compiler keeps it on the scalar unit, one
+// scalar-cache load of the pixel's direction mask per step — with the visited bits of the
+// whole slice in LDS (one bit per pixel; slices above ~1.2 M pixels keep them in HBM).
+//
+//   k_contour_dirs     passable directions of every pixel from the crack planes, border cleared
+//                      (dual_graph.hpp:139-150), as a mask in rotational order R, D, L, U
+//   k_trace_contours   the scan + walk of extract_contours_helper; per kept contour: where its
+//                      nodes lie, how many, where the smallest node sits (the rotation of
+//                      dual_graph.hpp:203-211) and that node
+//   k_contour_components   component of every contour (merge_contours_via_vcg_coloring looks up
+//                      cc_labels[contour[0]], dual_graph.hpp:229) through the run tables
+//   k_contour_emit     (x, y, z) uint16 triples of the contours in the order the host planned
+//                      (operations.hpp:229-257)
+#pragma once
+#include "ckl_device.hpp"
+#include "ckl_runs.hpp"
+
+namespace ckl {
+namespace dev {
+
+constexpr uint32_t kDirR = 1u, kDirD = 2u, kDirL = 4u, kDirU = 8u;
+
+// grid = (ceil(sxy / 256), nslices)
+__global__ void __launch_bounds__(256) k_contour_dirs(RunGeom g, uint64_t sxy, uint64_t stride, uint8_t* __restrict__ out) {
+	const uint32_t zi = blockIdx.y;
+	const uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+	if (p >= sxy) return;
+	const uint32_t y = static_cast<uint32_t>(p / g.sx);
+	const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
+	const uint32_t* pv = g.planeV + zi * g.plane_words;
+	const uint32_t* ph = g.planeH + zi * g.plane_words;
+	auto joined = [&](const uint32_t* plane, uint32_t px, uint32_t py) -> uint32_t {
+		const uint32_t bit = (plane[static_cast<uint64_t>(py) * g.row_words + (px >> 5)] >> (px & 31u)) & 1u;
+		return g.flip ? (bit ^ 1u) : bit;
+	};
+	uint32_t m = 0;
+	if (x + 1 < g.sx && joined(pv, x + 1, y)) m |= kDirR;
+	if (y + 1 < g.sy && joined(ph, x, y + 1)) m |= kDirD;
+	if (x >= 1 && joined(pv, x, y)) m |= kDirL;
+	if (y >= 1 && joined(ph, x, y)) m |= kDirU;
+	out[static_cast<uint64_t>(zi) * stride + p] = static_cast<uint8_t>(m);
+}
+
+struct ContourArgs {
+	const uint8_t* dirs;       // [nslices][dirs_stride], dirs_stride a multiple of 4 (the walk reads aligned words)
+	uint32_t* visited;         // [nslices][vis_words] (only when the bits do not fit the LDS; zeroed)
+	uint32_t* raw;             // [nslices][raw_cap] contour nodes as walked
+	uint4* table;              // [nslices][tab_cap]: offset into raw, length, position of the smallest node, that node
+	uint32_t* counts;          // [nslices][4]: contours, nodes, flags (1 raw overflow, 2 table overflow, 4 walk did not close), steps
+	uint32_t sx, sy;
+	uint32_t sxy;
+	uint32_t raw_cap, tab_cap, vis_words;
+	uint64_t dirs_stride;
+};
+
+constexpr uint32_t kContourRawOverflow = 1u, kContourTableOverflow = 2u, kContourOpenWalk = 4u;
+
+// compute_next_move (dual_graph.hpp:66-131) on rotational direction indices (0 R, 1 D, 2 L, 3 U):
+// first the turn towards the followed wall (clockwise: +1), then straight on, the other turn, back
+__device__ __forceinline__ uint32_t contour_next_move(uint32_t turn, uint32_t last, uint32_t allowed) {
+	const uint32_t a = (last + turn) & 3u, c = (last - turn) & 3u, d = (last + 2u) & 3u;
+	if ((allowed >> a) & 1u) return a;
+	if ((allowed >> last) & 1u) return last;
+	if ((allowed >> c) & 1u) return c;
+	if ((allowed >> d) & 1u) return d;
+	return 4u;
+}
+
+// One wavefront per slice.  grid = nslices, block = 64, dynamic LDS = vis_words * 4 when LDSVIS.
+template <bool LDSVIS>
+__global__ void __launch_bounds__(64) k_trace_contours(ContourArgs a) {
+	extern __shared__ uint32_t s_vis[];
+	const uint32_t zi = blockIdx.x;
+	const uint32_t lane = threadIdx.x;
+	const uint8_t* __restrict__ dirs = a.dirs + static_cast<uint64_t>(zi) * a.dirs_stride;
+	const uint32_t* __restrict__ dirs4 = reinterpret_cast<const uint32_t*>(dirs);
+	// the direction mask of a pixel through an aligned word: a scalar load when the index is uniform
+	auto dir_of = [&](uint32_t v) -> uint32_t { return (dirs4[v >> 2] >> ((v & 3u) * 8u)) & 15u; };
+	uint32_t* vis = LDSVIS ? s_vis : a.visited + static_cast<uint64_t>(zi) * a.vis_words;
+	uint32_t* __restrict__ raw = a.raw + static_cast<uint64_t>(zi) * a.raw_cap;
+	uint4* __restrict__ table = a.table + static_cast<uint64_t>(zi) * a.tab_cap;
+	if (LDSVIS) {
+		for (uint32_t i = lane; i < a.vis_words; i += 64u) s_vis[i] = 0u;
+		__syncthreads();
+	}
+	const uint32_t sxy = a.sxy, sx = a.sx;
+	auto delta = [&](uint32_t move) -> uint32_t { return move == 0u ? 1u : move == 1u ? sx : move == 2u ? 0xFFFFFFFFu : 0u - sx; };
+	uint32_t n_contours = 0, tail = 0, flags = 0, total_steps = 0;
+	const uint32_t step_cap = 4u * sxy + 8u;      // a closed walk passes every (pixel, heading) at most once
+
+	uint32_t pos = 0;
+	while (pos < sxy && !flags) {
+		// ---- VCGGraph::next_contour (dual_graph.hpp:40-61), 64 pixels at a time ----
+		const uint32_t p = pos + lane;
+		bool cand = false;
+		if (p < sxy) {
+			const uint32_t m0 = dirs[p];
+			const bool v0 = (vis[p >> 5] >> (p & 31u)) & 1u;
+			cand = !v0 && (m0 & (kDirR | kDirL)) != (kDirR | kDirL);             // (vcg & 0b110011) < 0b11
+			const uint32_t x = p % sx;
+			if (!cand && x + 1u < sx) {
+				const uint32_t q = p + 1u;
+				const bool v1 = (vis[q >> 5] >> (q & 31u)) & 1u;
+				cand = !v1 && (dirs[q] & kDirL) == 0u;                              // (vcg[idx+1] & 0b11110010) == 0
+			}
+		}
+		const unsigned long long found = __ballot(cand);
+		if (!found) { pos += 64u; continue; }
+		const uint32_t start = pos + static_cast<uint32_t>(__ffsll(static_cast<long long>(found))) - 1u;
+
+		// ---- the walk (dual_graph.hpp:161-199): wave-uniform ----
+		uint32_t node = start;
+		const uint32_t m_start = dir_of(node);
+		const bool start_visited = (vis[node >> 5] >> (node & 31u)) & 1u;
+		uint32_t already = start_visited ? 1u : 0u;
+		uint32_t n = 0, mn = start, mn_pos = 0;
+		auto push = [&](uint32_t v) {
+			if (tail + n < a.raw_cap) { if (lane == 0) raw[tail + n] = v; }
+			else flags |= kContourRawOverflow;
+			if (v < mn) { mn = v; mn_pos = n; }
+			n++;
+		};
+		auto visit = [&](uint32_t v) -> uint32_t {      // sets the visited bit, returns what it was
+			const uint32_t w = vis[v >> 5], bit = 1u << (v & 31u);
+			if (lane == 0) vis[v >> 5] = w | bit;
+			if (!LDSVIS) __threadfence_block();
+			return (w & bit) ? 1u : 0u;
+		};
+		if (m_start == 0u) {
+			visit(node);
+			push(node);
+		}
+		else {
+			push(start);
+			// counterclockwise for |x, clockwise for x| (dual_graph.hpp:177)
+			const bool clockwise = (m_start & kDirR) == 0u || (start_visited && m_start == (kDirU | kDirD));
+			const uint32_t turn = clockwise ? 1u : 3u;
+			const uint32_t ending = contour_next_move(turn, 3u /* UP */, m_start);
+			uint32_t next = ending, steps = 0;
+			do {
+				node += delta(next);
+				push(node);
+				already += visit(node);
+				next = contour_next_move(turn, next, node < sxy ? dir_of(node) : 0u);
+				if (++steps > step_cap || next > 3u || node >= sxy) { flags |= kContourOpenWalk; break; }
+			} while (!(node == start && next == ending) && !(flags & kContourRawOverflow));
+			total_steps += steps;
+		}
+		pos = start + 1u;
+		if (flags) break;
+		if (n == 0u || n == already) continue;      // nothing new on this loop (dual_graph.hpp:199-201)
+		if (n_contours < a.tab_cap) { if (lane == 0) table[n_contours] = make_uint4(tail, n, mn_pos, mn); }
+		else { flags |= kContourTableOverflow; break; }
+		n_contours++;
+		tail += n;
+	}
+	if (lane == 0) {
+		uint32_t* c = a.counts + 4u * zi;
+		c[0] = n_contours; c[1] = tail; c[2] = flags; c[3] = total_steps;
+	}
+}
+
+// component (within its slice) of every contour: the run of its smallest node.
+// grid = (ceil(tab_cap / 256), nslices)
+__global__ void __launch_bounds__(256) k_contour_components(
+	RunGeom g, RunArrays r, const uint4* __restrict__ table, const uint32_t* __restrict__ counts, uint32_t tab_cap, uint32_t* __restrict__ comp
+) {
+	const uint32_t zi = blockIdx.y;
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= counts[4u * zi]) return;
+	const uint32_t node = table[static_cast<uint64_t>(zi) * tab_cap + i].w;
+	const uint32_t y = node / g.sx, x = node - y * g.sx;
+	const uint32_t w = x >> 5;
+	const uint32_t b = g.breaks(zi, y, w);
+	const uint32_t run = r.word_base[zi * g.plane_words + static_cast<uint64_t>(y) * g.row_words + w] - 1u + __popc(b & mask_le(x & 31u));
+	comp[static_cast<uint64_t>(zi) * tab_cap + i] = r.run_cc[r.rbase[zi] + run];
+}
+
+struct ContourJob {
+	uint64_t src;       // first node of the contour in the raw array (all slices)
+	uint64_t dst;       // first point of the contour in the output
+	uint32_t len, rot;  // nodes, position of the node that comes first
+	uint32_t z, pad;
+};
+
+// grid = ceil(jobs / 4), block = 256: one wavefront per contour
+__global__ void __launch_bounds__(256) k_contour_emit(const ContourJob* __restrict__ jobs, uint64_t n_jobs, const uint32_t* __restrict__ raw, uint32_t sx, uint16_t* __restrict__ out) {
+	const uint64_t j = static_cast<uint64_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
+	if (j >= n_jobs) return;
+	const ContourJob job = jobs[j];
+	for (uint32_t i = threadIdx.x & 63u; i < job.len; i += 64u) {
+		uint32_t k = i + job.rot;
+		if (k >= job.len) k -= job.len;
+		const uint32_t loc = raw[job.src + k];
+		const uint16_t y = static_cast<uint16_t>(loc / sx);                       // 16-bit truncation as operations.hpp:246-247
+		const uint16_t x = static_cast<uint16_t>(loc - sx * y);
+		uint16_t* q = out + 3u * (job.dst + i);
+		q[0] = x; q[1] = y; q[2] = static_cast<uint16_t>(job.z);
+	}
+}
+
+}  // namespace dev
+}  // namespace ckl

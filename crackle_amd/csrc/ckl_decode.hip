@@ -34,8 +34,10 @@
 #include "ckl_common.hpp"
 #include "ckl_runs.hpp"
 #include "ckl_strips.hpp"
+#include "ckl_contours.hpp"
 
 #include <algorithm>
+#include <deque>
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -2790,6 +2792,230 @@ void decoder_vcg(ckl_decoder& d, uint8_t* out_device, uint64_t capacity, int con
 	CKL_HIP(hipGetLastError());
 }
 
+// operations::point_cloud (src/operations.hpp:183-262): contours of every component of the decoder's
+// range (ckl_contours.hpp), grouped by label.  The pipeline runs up to the run tables and the
+// component -> label map (the integrity check's mode), then per z-chunk: direction masks, the
+// per-slice tracer, the contours' components; the host orders the contours of each component
+// (dual_graph.hpp:223-241), groups components by label in (z, component) order and plans the
+// output, which k_contour_emit writes on the device.
+struct PointCloud {
+	std::vector<uint64_t> labels;      // ascending
+	std::vector<uint64_t> offsets;     // [labels + 1], in points
+	uint16_t* points = nullptr;        // host_out_alloc, 3 uint16 per point
+};
+
+void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bool has_sel, bool skip_background, PointCloud& out) {
+	const Header& h = d.head;
+	hipStream_t s = d.stream;
+	const uint32_t ns = d.nslices;
+	out.offsets.assign(1, 0);
+	if (d.sxy == 0 || ns == 0) return;
+	if (d.sxy >= 0xFFFFFFF0ull / 4) throw Error(CKL_ERR_ARG, "crackle_amd: point_cloud: slices of this size are not supported");
+	{
+		std::vector<uint32_t> errs(ns);
+		decoder_run(d, nullptr, 0, 0, 0, nullptr, false, errs.data());
+		for (uint32_t zi = 0; zi < ns; zi++) {
+			if (!errs[zi]) continue;
+			const std::string z = std::to_string(d.z_start + zi);
+			if (errs[zi] & (ERR_BOC | ERR_RANGE | ERR_CAPACITY)) throw Error(CKL_ERR_RUNTIME, "crackle: crack code is malformed or corrupted on z=" + z);
+			if (errs[zi] & ERR_NCOMP) throw Error(CKL_ERR_RUNTIME, "crackle: component count does not match the label section on z=" + z);
+			throw Error(CKL_ERR_CRC, "crackle: crack code crc mismatch on z=" + z);
+		}
+	}
+	RunGeom g;
+	g.planeV = d.d_planes.p; g.planeH = d.d_planes.p + d.plane_words * ns;
+	g.row_words = d.row_words; g.plane_words = d.plane_words;
+	g.flip = (h.crack_format == IMPERMISSIBLE) ? 1u : 0u;
+	g.sx = h.sx; g.sy = h.sy;
+	RunArrays ra;
+	ra.word_base = d.d_word_base.p; ra.rbase = d.d_rbase.p; ra.rcap = d.d_rcap.p;
+	ra.parent = d.d_parent.p; ra.run_start = d.d_run_start.p; ra.run_cc = d.d_run_cc.p;
+	ra.nruns = d.d_nruns.p; ra.ncomp = d.d_ncomp.p; ra.slice_err = d.d_slice_err.p;
+
+	// component -> label, as point_cloud<LABEL> holds it: the unsigned type of the data width
+	std::vector<uint64_t> label_map(d.total_comp);
+	if (d.total_comp) CKL_HIP(hipMemcpyAsync(label_map.data(), d.d_label_map.p, d.total_comp * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipStreamSynchronize(s));
+	const uint64_t lmask = h.data_width >= 8 ? ~0ull : ((1ull << (8 * h.data_width)) - 1);
+	for (uint64_t& v : label_map) v &= lmask;
+	std::vector<uint64_t> comp_off(ns + 1, 0);
+	for (uint32_t zi = 0; zi < ns; zi++) comp_off[zi + 1] = comp_off[zi] + d.ncomp_expect_host[zi];
+	std::vector<uint64_t> selected;
+	if (has_sel) { selected.assign(sel, sel + n_sel); std::sort(selected.begin(), selected.end()); }
+	auto takes = [&](uint64_t label) {
+		if (skip_background && label == 0) return false;
+		return !has_sel || std::binary_search(selected.begin(), selected.end(), label);
+	};
+
+	const uint32_t sxy = static_cast<uint32_t>(d.sxy);
+	const uint64_t dirs_stride = (d.sxy + 3) & ~3ull;
+	const uint32_t vis_words = (sxy + 31) / 32;
+	int max_lds = 0;
+	CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, d.device));
+	const bool lds_vis = !getenv("CKL_CONTOUR_HBM_VISITED") && static_cast<uint64_t>(vis_words) * 4 + 256 <= static_cast<uint64_t>(std::max(0, max_lds));
+	if (lds_vis) CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_contours<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(vis_words * 4)));
+
+	// contours of all slices: per slice the kept ones in discovery order
+	struct Kept { uint32_t zi, offset, len, rot, first, comp; };
+	std::vector<Kept> kept;
+	// per z-chunk device buffers, kept until the emit; first try with room for the usual volume,
+	// a chunk that overflows is traced again with the bounds of the worst case
+	struct Chunk { uint32_t z0, n; uint32_t raw_cap; std::unique_ptr<DevBuf<uint32_t>> raw; };
+	std::vector<Chunk> chunks;
+	const uint64_t budget = 3ull << 30;
+	uint32_t raw_cap0 = static_cast<uint32_t>(std::min<uint64_t>(d.sxy / 2 + 4096, 8ull * d.sxy + 16));
+	uint32_t tab_cap0 = static_cast<uint32_t>(std::min<uint64_t>(d.sxy / 32 + 1024, d.sxy + 1));
+	if (const char* env = getenv("CKL_CONTOUR_SMALL")) { raw_cap0 = std::max(16, atoi(env)); tab_cap0 = std::max(2, atoi(env) / 8); }      // testing: forces the second pass
+	DevBuf<uint8_t> d_dirs;
+	DevBuf<uint32_t> d_vis, d_counts, d_comp;
+	DevBuf<uint4> d_table;
+	uint32_t z0 = 0;
+	while (z0 < ns) {
+		uint32_t raw_cap = raw_cap0, tab_cap = tab_cap0;
+		for (int attempt = 0; ; attempt++) {
+			const uint64_t per_slice = dirs_stride + 4ull * raw_cap + 16ull * tab_cap + 4ull * tab_cap + (lds_vis ? 0 : 4ull * vis_words) + 16;
+			const uint32_t nz = static_cast<uint32_t>(std::min<uint64_t>(ns - z0, std::max<uint64_t>(1, budget / per_slice)));
+			RunGeom gz = g;
+			gz.planeV = g.planeV + static_cast<uint64_t>(z0) * d.plane_words;
+			gz.planeH = g.planeH + static_cast<uint64_t>(z0) * d.plane_words;
+			RunArrays rz = ra;
+			rz.word_base = ra.word_base + static_cast<uint64_t>(z0) * d.plane_words;
+			rz.rbase = ra.rbase + z0;
+			d_dirs.ensure(dirs_stride * nz);
+			std::unique_ptr<DevBuf<uint32_t>> raw(new DevBuf<uint32_t>());
+			raw->ensure(static_cast<uint64_t>(raw_cap) * nz);
+			d_table.ensure(static_cast<uint64_t>(tab_cap) * nz);
+			d_comp.ensure(static_cast<uint64_t>(tab_cap) * nz);
+			d_counts.ensure(4ull * nz);
+			if (!lds_vis) {
+				d_vis.ensure(static_cast<uint64_t>(vis_words) * nz);
+				CKL_HIP(hipMemsetAsync(d_vis.p, 0, static_cast<uint64_t>(vis_words) * nz * sizeof(uint32_t), s));
+			}
+			hipLaunchKernelGGL(k_contour_dirs, dim3(static_cast<uint32_t>((d.sxy + 255) / 256), nz), dim3(256), 0, s, gz, d.sxy, dirs_stride, d_dirs.p);
+			ContourArgs ca;
+			ca.dirs = d_dirs.p; ca.visited = d_vis.p; ca.raw = raw->p; ca.table = d_table.p; ca.counts = d_counts.p;
+			ca.sx = h.sx; ca.sy = h.sy; ca.sxy = sxy; ca.raw_cap = raw_cap; ca.tab_cap = tab_cap; ca.vis_words = vis_words; ca.dirs_stride = dirs_stride;
+			if (lds_vis) hipLaunchKernelGGL(k_trace_contours<true>, dim3(nz), dim3(64), vis_words * 4, s, ca);
+			else hipLaunchKernelGGL(k_trace_contours<false>, dim3(nz), dim3(64), 0, s, ca);
+			hipLaunchKernelGGL(k_contour_components, dim3((tab_cap + 255) / 256, nz), dim3(256), 0, s, gz, rz, d_table.p, d_counts.p, tab_cap, d_comp.p);
+			std::vector<uint32_t> counts(4ull * nz);
+			CKL_HIP(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+			CKL_HIP(hipStreamSynchronize(s));
+			CKL_HIP(hipGetLastError());
+			uint32_t flags = 0;
+			for (uint32_t i = 0; i < nz; i++) flags |= counts[4 * i + 2];
+			if (flags & kContourOpenWalk) throw Error(CKL_ERR_RUNTIME, "crackle_amd: point_cloud: a contour walk did not close");
+			if (flags) {
+				if (attempt) throw Error(CKL_ERR_RUNTIME, "crackle_amd: point_cloud: contour buffers overflow");
+				raw_cap = static_cast<uint32_t>(8ull * d.sxy + 16);
+				tab_cap = sxy + 1;
+				continue;
+			}
+			std::vector<uint4> table(static_cast<uint64_t>(tab_cap) * nz);
+			std::vector<uint32_t> comp(static_cast<uint64_t>(tab_cap) * nz);
+			for (uint32_t i = 0; i < nz; i++) {
+				const uint32_t nc = counts[4 * i];
+				if (!nc) continue;
+				CKL_HIP(hipMemcpyAsync(table.data() + static_cast<uint64_t>(i) * tab_cap, d_table.p + static_cast<uint64_t>(i) * tab_cap, nc * sizeof(uint4), hipMemcpyDeviceToHost, s));
+				CKL_HIP(hipMemcpyAsync(comp.data() + static_cast<uint64_t>(i) * tab_cap, d_comp.p + static_cast<uint64_t>(i) * tab_cap, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+			}
+			CKL_HIP(hipStreamSynchronize(s));
+			for (uint32_t i = 0; i < nz; i++) {
+				for (uint32_t k = 0; k < counts[4 * i]; k++) {
+					const uint4 t = table[static_cast<uint64_t>(i) * tab_cap + k];
+					kept.push_back({ z0 + i, t.x, t.y, t.z, t.w, comp[static_cast<uint64_t>(i) * tab_cap + k] });
+				}
+			}
+			chunks.push_back({ z0, nz, raw_cap, std::move(raw) });
+			z0 += nz;
+			break;
+		}
+	}
+
+	// merge_contours_via_vcg_coloring (dual_graph.hpp:213-243): a contour whose first node lies before
+	// the component's current first node goes to the front, any other to the back
+	std::vector<uint64_t> comp_n(d.total_comp, 0);                // contours per component
+	for (const Kept& k : kept) {
+		if (k.comp >= d.ncomp_expect_host[k.zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: point_cloud: component out of range");
+		comp_n[comp_off[k.zi] + k.comp]++;
+	}
+	std::vector<uint64_t> comp_at(d.total_comp + 1, 0);
+	for (uint64_t c = 0; c < d.total_comp; c++) comp_at[c + 1] = comp_at[c] + comp_n[c];
+	std::vector<uint32_t> order(kept.size());                    // per component: its contours in merged order
+	{
+		std::vector<std::deque<uint32_t>> lists;                    // only for components with more than one contour
+		std::vector<int64_t> list_of(d.total_comp, -1);
+		for (uint32_t i = 0; i < kept.size(); i++) {
+			const uint64_t c = comp_off[kept[i].zi] + kept[i].comp;
+			if (comp_n[c] == 1) { order[comp_at[c]] = i; continue; }
+			if (list_of[c] < 0) { list_of[c] = static_cast<int64_t>(lists.size()); lists.emplace_back(); }
+			std::deque<uint32_t>& l = lists[list_of[c]];
+			if (!l.empty() && kept[l.front()].first > kept[i].first) l.push_front(i);
+			else l.push_back(i);
+		}
+		for (uint64_t c = 0; c < d.total_comp; c++) {
+			if (list_of[c] < 0) continue;
+			uint64_t at = comp_at[c];
+			for (uint32_t i : lists[list_of[c]]) order[at++] = i;
+		}
+	}
+
+	// operations.hpp:229-257: components in (z, index) order append to their label's points
+	std::vector<uint64_t> keys;
+	for (uint64_t c = 0; c < d.total_comp; c++) if (takes(label_map[c])) keys.push_back(label_map[c]);
+	std::sort(keys.begin(), keys.end());
+	keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+	std::vector<uint64_t> off(keys.size() + 1, 0);
+	std::vector<int64_t> key_of(d.total_comp, -1);
+	for (uint64_t c = 0; c < d.total_comp; c++) {
+		if (!takes(label_map[c])) continue;
+		const uint64_t k = static_cast<uint64_t>(std::lower_bound(keys.begin(), keys.end(), label_map[c]) - keys.begin());
+		key_of[c] = static_cast<int64_t>(k);
+		for (uint64_t j = comp_at[c]; j < comp_at[c + 1]; j++) off[k + 1] += kept[order[j]].len;
+	}
+	for (size_t k = 0; k < keys.size(); k++) off[k + 1] += off[k];
+	const uint64_t total_points = off[keys.size()];
+	out.labels = keys;
+	out.offsets = off;
+	out.points = static_cast<uint16_t*>(host_out_alloc(std::max<uint64_t>(total_points * 6, 2)));
+	if (!total_points) return;
+
+	DevBuf<uint16_t> d_points;
+	d_points.ensure(total_points * 3);
+	std::vector<uint64_t> fill(off.begin(), off.end() - 1);
+	std::vector<std::vector<ContourJob>> jobs(chunks.size());
+	{
+		std::vector<uint32_t> chunk_of(ns);
+		for (size_t ci = 0; ci < chunks.size(); ci++) for (uint32_t i = 0; i < chunks[ci].n; i++) chunk_of[chunks[ci].z0 + i] = static_cast<uint32_t>(ci);
+		for (uint32_t zi = 0; zi < ns; zi++) {
+			const Chunk& ch = chunks[chunk_of[zi]];
+			for (uint64_t c = comp_off[zi]; c < comp_off[zi + 1]; c++) {
+				if (key_of[c] < 0) continue;
+				for (uint64_t j = comp_at[c]; j < comp_at[c + 1]; j++) {
+					const Kept& k = kept[order[j]];
+					ContourJob job;
+					job.src = static_cast<uint64_t>(zi - ch.z0) * ch.raw_cap + k.offset;
+					job.dst = fill[key_of[c]];
+					job.len = k.len; job.rot = k.rot; job.z = static_cast<uint32_t>(d.z_start + zi); job.pad = 0;
+					fill[key_of[c]] += k.len;
+					jobs[chunk_of[zi]].push_back(job);
+				}
+			}
+		}
+	}
+	DevBuf<ContourJob> d_jobs;
+	for (size_t ci = 0; ci < chunks.size(); ci++) {
+		if (jobs[ci].empty()) continue;
+		upload(d_jobs, jobs[ci], s);
+		const uint64_t nj = jobs[ci].size();
+		hipLaunchKernelGGL(k_contour_emit, dim3(static_cast<uint32_t>((nj + 3) / 4)), dim3(256), 0, s, d_jobs.p, nj, chunks[ci].raw->p, h.sx, d_points.p);
+		CKL_HIP(hipStreamSynchronize(s));      // the job list is reused by the next chunk
+	}
+	CKL_HIP(hipMemcpyAsync(out.points, d_points.p, total_points * 6, hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipStreamSynchronize(s));
+	CKL_HIP(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
@@ -2922,6 +3148,42 @@ int ckl_voxel_connectivity_graph_range(const uint8_t* buf, uint64_t n, int64_t z
 	}
 	catch (const Error& e) { set_last_error(e.what()); ckl_decoder_destroy(d); return e.status; }
 	catch (const std::exception& e) { set_last_error(e.what()); ckl_decoder_destroy(d); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_point_cloud(
+	const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end,
+	const uint64_t* labels, uint64_t n_labels, int has_labels, int skip_background, int device,
+	uint64_t** labels_out, uint64_t** offsets_out, uint16_t** points_out, uint64_t* n_out
+) {
+	ckl_decoder* d = nullptr;
+	uint64_t* lo = nullptr; uint64_t* oo = nullptr;
+	PointCloud pc;
+	try {
+		if (!buf || !labels_out || !offsets_out || !points_out || !n_out || (has_labels && n_labels && !labels)) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		*labels_out = nullptr; *offsets_out = nullptr; *points_out = nullptr; *n_out = 0;
+		Header h = Header::parse(buf, n);
+		// operations::get_szr (src/operations.hpp:54-72): the clamped range must hold a slice
+		int64_t zs = z_start, ze = z_end;
+		const int64_t last = static_cast<int64_t>(static_cast<uint32_t>(h.sz - 1u));
+		zs = std::max<int64_t>(std::min(zs, last), 0);
+		ze = ze < 0 ? static_cast<int64_t>(h.sz) : ze;
+		ze = std::max<int64_t>(std::min<int64_t>(ze, h.sz), 0);
+		if (zs >= ze) throw Error(CKL_ERR_RUNTIME, "crackle: Invalid range: " + std::to_string(zs) + " - " + std::to_string(ze));
+		const int rc = ckl_decoder_create(buf, n, zs, ze, device, &d);
+		if (rc != CKL_OK) return rc;
+		decoder_point_cloud(*d, labels, n_labels, has_labels != 0, skip_background != 0, pc);
+		const uint64_t k = pc.labels.size();
+		lo = static_cast<uint64_t*>(host_out_alloc(std::max<uint64_t>(k, 1) * 8));
+		oo = static_cast<uint64_t*>(host_out_alloc((k + 1) * 8));
+		if (k) memcpy(lo, pc.labels.data(), k * 8);
+		memcpy(oo, pc.offsets.data(), (k + 1) * 8);
+		if (!pc.points) pc.points = static_cast<uint16_t*>(host_out_alloc(2));
+		*labels_out = lo; *offsets_out = oo; *points_out = pc.points; *n_out = k;
+		ckl_decoder_destroy(d);
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); if (pc.points) host_out_free(pc.points); if (lo) host_out_free(lo); if (oo) host_out_free(oo); if (d) ckl_decoder_destroy(d); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); if (pc.points) host_out_free(pc.points); if (lo) host_out_free(lo); if (oo) host_out_free(oo); if (d) ckl_decoder_destroy(d); return CKL_ERR_RUNTIME; }
 }
 
 int ckl_decoder_last_timing(const ckl_decoder* d, float* pipeline_ms, float* dominant_kernel_ms) {

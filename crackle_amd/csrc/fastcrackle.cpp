@@ -8,7 +8,7 @@
 //
 // Functions: decompress (ref :84-128), compress (:163-210), reencode_markov (:212-227),
 // voxel_counts / centroids / bounding_boxes (:346-426), voxel_connectivity_graph (:538-565),
-// array_equal (:594-618), mode_pooling_2x2x1 (:620-639).
+// array_equal (:594-618), mode_pooling_2x2x1 (:620-639), point_cloud (:315-345).
 #include <pybind11/pybind11.h>
 #include <pybind11/numpy.h>
 #include <pybind11/stl.h>
@@ -215,6 +215,26 @@ py::list mode_pooling_2x2x1(const py::buffer buffer, int64_t z_start, int64_t z_
 	return result;
 }
 
+// src/fastcrackle.cpp:315-345: dict label -> flat uint16 array of (x, y, z) triples
+py::dict point_cloud(const py::buffer buffer, int64_t z_start, int64_t z_end, const std::optional<std::vector<uint64_t>> labels, bool skip_background, size_t /*parallel*/) {
+	Stream s(buffer);
+	uint64_t* lab = nullptr; uint64_t* off = nullptr; uint16_t* pts = nullptr;
+	uint64_t n = 0;
+	check(ckl_point_cloud(s.p, s.n, z_start, z_end, labels ? labels->data() : nullptr, labels ? labels->size() : 0, labels ? 1 : 0,
+		skip_background ? 1 : 0, device(), &lab, &off, &pts, &n));
+	py::dict result;
+	for (uint64_t i = 0; i < n; i++) {
+		const uint64_t count = 3 * (off[i + 1] - off[i]);
+		py::array_t<uint16_t> arr(static_cast<py::ssize_t>(count));
+		if (count) std::memcpy(arr.mutable_data(), pts + 3 * off[i], count * sizeof(uint16_t));
+		result[py::int_(lab[i])] = arr;
+	}
+	if (lab) ckl_free(lab);
+	if (off) ckl_free(off);
+	if (pts) ckl_free(pts);
+	return result;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(fastcrackle, m) {
@@ -236,6 +256,8 @@ PYBIND11_MODULE(fastcrackle, m) {
 		py::arg("buffer1"), py::arg("buffer2"), py::arg("parallel") = 1);
 	m.def("mode_pooling_2x2x1", &mode_pooling_2x2x1, "Return an array of downsampled crackle binaries in z order.",
 		py::arg("buffer"), py::arg("z_start") = 0, py::arg("z_end") = -1, py::arg("parallel") = 1);
+	m.def("point_cloud", &point_cloud, "Extract one or more point clouds without decompressing.",
+		py::arg("buffer"), py::arg("z_start") = 0, py::arg("z_end") = -1, py::arg("labels") = py::none(), py::arg("skip_background") = false, py::arg("parallel") = 1);
 	m.def("voxel_connectivity_graph", &voxel_connectivity_graph, "Extract the voxel connectivity graph from the image.",
 		py::arg("buffer"), py::arg("z_start") = 0, py::arg("z_end") = -1, py::arg("parallel") = 1, py::arg("connectivity") = 4);
 }

@@ -2,12 +2,12 @@
 on, exposed with the reference's names (crackle/operations.py:424-662: zstack, zsplit,
 zshatter).  Host only (native: ckl_zstack / ckl_zsplit); FLAT label streams."""
 import ctypes as C
-from typing import List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
 from . import _lib
-from .codec import header, labels, num_labels
+from .codec import contains, header, labels, num_labels
 
 
 def _take(out: C.c_void_p, n: C.c_uint64) -> bytes:
@@ -113,3 +113,65 @@ def mode_pooling_2x2x1(binary: bytes, parallel: int = 0, device: int = 0) -> byt
   """Downsamples a segmentation 2 x 2 x 1 by the reference's pooling rule
   (crackle/operations.py:1023-1026: the per-slice streams of fastcrackle.mode_pooling_2x2x1, stacked)."""
   return zstack(_mode_pooling_slices(binary, 0, -1, device))
+
+
+def _point_cloud_raw(binary: bytes, z_start: int, z_end: int, label_list, skip_background: bool, device: int) -> Dict[int, np.ndarray]:
+  """fastcrackle.point_cloud (src/fastcrackle.cpp:315-345 -> ckl_point_cloud): dict label -> flat
+  uint16 array of (x, y, z) triples."""
+  b = bytes(binary)
+  sel = None if label_list is None else np.ascontiguousarray(label_list, dtype=np.uint64)
+  lab_p, off_p, pts_p, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+  L = _lib.lib()
+  rc = L.ckl_point_cloud(b, len(b), int(z_start), int(z_end), None if sel is None else sel.ctypes.data,
+                         0 if sel is None else sel.size, int(sel is not None), int(bool(skip_background)), int(device),
+                         C.byref(lab_p), C.byref(off_p), C.byref(pts_p), C.byref(n))
+  if rc != _lib.CKL_OK:
+    raise RuntimeError(_lib.last_error())
+  try:
+    k = int(n.value)
+    if k == 0:
+      return {}
+    labs = np.frombuffer(C.string_at(lab_p.value, 8 * k), dtype=np.uint64)
+    offs = np.frombuffer(C.string_at(off_p.value, 8 * (k + 1)), dtype=np.uint64)
+    pts = np.frombuffer(C.string_at(pts_p.value, 6 * int(offs[k])), dtype=np.uint16) if int(offs[k]) else np.zeros(0, np.uint16)
+    return {int(labs[i]): pts[3 * int(offs[i]):3 * int(offs[i + 1])].copy() for i in range(k)}
+  finally:
+    for p in (lab_p, off_p, pts_p):
+      if p.value:
+        L.ckl_free(p)
+
+
+def point_cloud(
+  binary: bytes, label: Optional[Union[int, List[int]]] = None, parallel: int = 0,
+  z_start: int = -1, z_end: int = -1, skip_background: bool = True, device: int = 0,
+) -> Union[np.ndarray, Dict[int, np.ndarray]]:
+  """Surface point clouds of the labels without decompressing the image (crackle/codec.py:804-872).
+
+  Without `label`: dict label -> (N, 3) uint16 array of (x, y, z).  With an int: that label's
+  array; with a list: the dict restricted to those labels.  A label the image does not contain
+  raises ValueError.  The reference narrows an unspecified z-range to the slices that hold the
+  labels (z_range_for_label); slices without them contribute no points, so the whole range is
+  traced here instead.  Points come in the order the reference gives with parallel = 1."""
+  scalar_input = False
+  if isinstance(label, (int, np.integer)):
+    scalar_input = True
+    label = [int(label)]
+  head = header(binary)
+  if isinstance(label, (list, tuple)):
+    for lbl in label:
+      if not contains(binary, lbl):
+        raise ValueError(f"Label {lbl} not contained in image.")
+  if z_start == -1:
+    z_start = 0
+  if z_end == -1:
+    z_end = head.sz
+  ptc = _point_cloud_raw(binary, z_start, z_end, label, skip_background, device)
+  if len(ptc) == 0:
+    if label:
+      return np.zeros([0, 3], dtype=np.uint16, order="C")
+    return {}
+  for lbl, pts in ptc.items():
+    ptc[lbl] = np.asarray(pts, dtype=np.uint16, order="C").reshape([len(pts) // 3, 3], order="C")
+  if scalar_input:
+    return ptc[label[0]]
+  return ptc

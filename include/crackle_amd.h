@@ -297,6 +297,22 @@ int ckl_pin_labels_host(
 	int stored_width, int auto_bgcolor, int64_t manual_bgcolor,
 	uint8_t** out, uint64_t* out_len);
 
+/* Replaces crackle::operations::point_cloud (src/operations.hpp:183-262, bound as
+ * fastcrackle.point_cloud, src/fastcrackle.cpp:315-345) with dual_graph::extract_contours
+ * (src/dual_graph.hpp:133-275): the boundary contours of every 2D component of slices
+ * [z_start, z_end) (clamped like operations::get_szr; an empty range is an error), as (x, y, z)
+ * uint16 triples per label.  `labels` (when has_labels) restricts the output to those labels,
+ * skip_background drops label 0.  The labels that own points come back ascending (the reference
+ * returns an unordered_map), offsets_out[i] .. offsets_out[i+1] are label i's points in
+ * points_out (3 uint16 each), in the order the reference appends them with parallel = 1: slices
+ * ascending, components in index order, each component's contours merged as the reference merges
+ * them.  The crack codes are decoded and the contours traced on the device (one wavefront per
+ * slice).  Release the three arrays with ckl_free. */
+int ckl_point_cloud(
+	const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end,
+	const uint64_t* labels, uint64_t n_labels, int has_labels, int skip_background, int device,
+	uint64_t** labels_out, uint64_t** offsets_out, uint16_t** points_out, uint64_t* n_out);
+
 /* Replaces crackle::reencode_with_markov_order (src/crackle.hpp:858-984, bound as
  * fastcrackle.reencode_markov, src/fastcrackle.cpp:212-230): the stream with its crack codes
  * stored under another markov model order.  The crack decoder rasterises the codes on the device

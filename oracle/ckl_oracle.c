@@ -1607,6 +1607,209 @@ int ckl_oracle_mode_pooling(
 	return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * point clouds: dual_graph::extract_contours (src/dual_graph.hpp:133-275) + operations::point_cloud
+ * (src/operations.hpp:183-262)
+ * ------------------------------------------------------------------------------------------ */
+enum { DG_RIGHT = 1, DG_LEFT = 2, DG_DOWN = 4, DG_UP = 8, DG_VISITED = 16 };
+
+/* compute_next_move (src/dual_graph.hpp:66-131): turn order relative to the last move */
+static uint8_t dg_next_move(int clockwise, uint8_t last, uint8_t allowed) {
+	static const uint8_t cw[4][4] = {
+		{ DG_DOWN, DG_RIGHT, DG_UP, DG_LEFT },      /* last = RIGHT */
+		{ DG_UP, DG_LEFT, DG_DOWN, DG_RIGHT },      /* last = LEFT */
+		{ DG_RIGHT, DG_UP, DG_LEFT, DG_DOWN },      /* last = UP */
+		{ DG_LEFT, DG_DOWN, DG_RIGHT, DG_UP },      /* otherwise (DOWN) */
+	};
+	static const uint8_t ccw[4][4] = {
+		{ DG_UP, DG_RIGHT, DG_DOWN, DG_LEFT },
+		{ DG_DOWN, DG_LEFT, DG_UP, DG_RIGHT },
+		{ DG_LEFT, DG_UP, DG_RIGHT, DG_DOWN },
+		{ DG_RIGHT, DG_DOWN, DG_LEFT, DG_UP },
+	};
+	const int row = last == DG_RIGHT ? 0 : last == DG_LEFT ? 1 : last == DG_UP ? 2 : 3;
+	const uint8_t* pref = clockwise ? cw[row] : ccw[row];
+	for (int k = 0; k < 4; k++) if (allowed & pref[k]) return pref[k];
+	return 0;
+}
+
+typedef struct { uint32_t* v; uint64_t n, cap; } u32vec_t;
+static void u32vec_push(u32vec_t* a, uint32_t x) {
+	if (a->n == a->cap) { a->cap = a->cap ? 2 * a->cap : 64; a->v = (uint32_t*)xrealloc(a->v, a->cap * 4); }
+	a->v[a->n++] = x;
+}
+
+/* extract_contours_helper + merge_contours_via_vcg_coloring: merged[c] receives the contour nodes
+ * of component c (vcg is modified: border bits cleared, visited bits set) */
+static void dg_extract_contours(uint8_t* vcg, const uint32_t* cc, uint64_t N, int64_t sx, int64_t sy, u32vec_t* merged) {
+	for (int64_t i = 0; i < sx; i++) {                                                 /* :139-143 */
+		vcg[i] &= (uint8_t)~DG_UP;
+		vcg[i + sx * (sy - 1)] &= (uint8_t)~DG_DOWN;
+	}
+	for (int64_t i = 0; i < sy; i++) {
+		vcg[sx * i] &= (uint8_t)~DG_LEFT;
+		vcg[sx - 1 + sx * i] &= (uint8_t)~DG_RIGHT;
+	}
+	int64_t move_amt[9] = { 0 };
+	move_amt[DG_RIGHT] = 1; move_amt[DG_LEFT] = -1; move_amt[DG_DOWN] = sx; move_amt[DG_UP] = -sx;
+	u32vec_t cur = { 0 };
+	int64_t start = 0, y = 0;
+	(void)N;
+	for (;;) {
+		/* VCGGraph::next_contour (:40-61) */
+		int found = 0;
+		int64_t x = start - sx * y;
+		for (; y < sy; y++) {
+			for (; x < sx; x++, start++) {
+				if ((vcg[start] & 0x33) < 3 || (x < sx - 1 && (vcg[start + 1] & 0xF2) == 0)) { found = 1; break; }
+			}
+			if (found) break;
+			x = 0;
+		}
+		if (!found) break;
+		cur.n = 0;
+		int64_t node = start;
+		uint8_t allowed = vcg[node] & 15;
+		uint64_t already = (vcg[node] >> 4) > 0;
+		if (allowed == 0) {
+			vcg[node] |= DG_VISITED;
+			u32vec_push(&cur, (uint32_t)node);
+		}
+		else {
+			u32vec_push(&cur, (uint32_t)start);
+			const int clockwise = ((vcg[start] & 1) == 0) || (vcg[start] == 0x1C);       /* :177 */
+			const uint8_t ending = dg_next_move(clockwise, DG_UP, allowed);
+			uint8_t next = ending;
+			do {
+				node += move_amt[next];
+				u32vec_push(&cur, (uint32_t)node);
+				already += (vcg[node] >> 4) > 0;
+				vcg[node] |= DG_VISITED;
+				allowed = vcg[node] & 15;
+				next = dg_next_move(clockwise, next, allowed);
+			} while (!(node == start && next == ending));
+		}
+		start++;
+		if (cur.n == 0 || cur.n == already) continue;
+		/* rotate: the smallest node first (:203-211), then merge by component (:223-241) */
+		uint64_t at = 0;
+		for (uint64_t i = 1; i < cur.n; i++) if (cur.v[i] < cur.v[at]) at = i;
+		u32vec_t* m = &merged[cc[cur.v[at]]];
+		const int front = m->n > 0 && m->v[0] > cur.v[at];
+		const uint64_t old = m->n;
+		while (m->cap < old + cur.n) { m->cap = m->cap ? 2 * m->cap : 64; m->v = (uint32_t*)xrealloc(m->v, m->cap * 4); }
+		if (front) memmove(m->v + cur.n, m->v, old * 4);
+		uint32_t* dst = front ? m->v : m->v + old;
+		memcpy(dst, cur.v + at, (cur.n - at) * 4);
+		memcpy(dst + (cur.n - at), cur.v, at * 4);
+		m->n = old + cur.n;
+	}
+	free(cur.v);
+}
+
+static int cmp_u64(const void* a, const void* b) {
+	const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+	return x < y ? -1 : x > y;
+}
+
+/* operations::point_cloud with parallel = 1 (slices in order): the labels that own points, ascending,
+ * and for each the (x, y, z) uint16 triples in the order the reference appends them.
+ * labels_out[n_out], offsets_out[n_out + 1] (in points), points_out[3 * offsets_out[n_out]];
+ * release each with ckl_oracle_free. */
+int ckl_oracle_point_cloud(
+	const unsigned char* buf, uint64_t n, int64_t z_start, int64_t z_end,
+	const uint64_t* labels, uint64_t n_labels, int has_labels, int skip_background,
+	uint64_t** labels_out, uint64_t** offsets_out, uint16_t** points_out, uint64_t* n_out
+) {
+	header_t h;
+	*labels_out = NULL; *offsets_out = NULL; *points_out = NULL; *n_out = 0;
+	if (n < HEADER_BYTES_V0) FAIL("crackle: Input too small to be a valid stream.");
+	if (header_read(&h, buf, n)) return 1;
+	int64_t zs, szr;
+	if (get_szr(&h, z_start, z_end, &zs, &szr)) return 1;
+	const uint64_t sx = h.sx, sy = h.sy, sxy = sx * sy;
+	if (sxy == 0) return 0;
+	dec_ctx_t d;
+	memset(&d, 0, sizeof d);
+	d.cap_cc = (uint32_t*)xmalloc(sxy * (uint64_t)szr * 4);
+	d.cap_N = (uint64_t*)xcalloc((size_t)szr, sizeof(uint64_t));
+	d.cap_lmap = (uint64_t**)xcalloc((size_t)szr, sizeof(uint64_t*));
+	int rc = dec_run(&d, buf, n, NULL, zs, zs + szr, 1, 0, 0);
+	uint8_t* vcg = (uint8_t*)xmalloc(sxy);
+	/* per slice and component: the merged contour */
+	u32vec_t** per = (u32vec_t**)xcalloc((size_t)szr, sizeof(u32vec_t*));
+	for (int64_t zi = 0; zi < szr && !rc; zi++) {
+		rc = ckl_oracle_slice_vcg(buf, n, zs + zi, vcg);
+		if (rc) break;
+		per[zi] = (u32vec_t*)xcalloc((size_t)d.cap_N[zi] + 1, sizeof(u32vec_t));
+		dg_extract_contours(vcg, d.cap_cc + (uint64_t)zi * sxy, d.cap_N[zi], (int64_t)sx, (int64_t)sy, per[zi]);
+	}
+	if (!rc) {
+		/* the labels with points, ascending */
+		uint64_t total_comp = 0;
+		for (int64_t zi = 0; zi < szr; zi++) total_comp += d.cap_N[zi];
+		uint64_t* keys = (uint64_t*)xmalloc((total_comp + 1) * 8);
+		uint64_t nk = 0;
+		/* point_cloud<LABEL> holds the labels as the unsigned type of the data width (:274-300) */
+		const uint64_t lmask = h.data_width >= 8 ? ~0ull : ((1ull << (8 * h.data_width)) - 1);
+		for (int64_t zi = 0; zi < szr; zi++) {
+			for (uint64_t c = 0; c < d.cap_N[zi]; c++) {
+				const uint64_t L = d.cap_lmap[zi][c] & lmask;
+				int sel = 1;
+				if (skip_background && L == 0) sel = 0;
+				if (sel && has_labels) {
+					sel = 0;
+					for (uint64_t k = 0; k < n_labels; k++) if (labels[k] == L) { sel = 1; break; }
+				}
+				/* ptc[current_label] creates the entry even when the component has no contour nodes */
+				if (sel) keys[nk++] = L;
+			}
+		}
+		qsort(keys, nk, 8, cmp_u64);
+		uint64_t nu = 0;
+		for (uint64_t i = 0; i < nk; i++) if (i == 0 || keys[i] != keys[i - 1]) keys[nu++] = keys[i];
+		uint64_t* off = (uint64_t*)xcalloc(nu + 2, 8);
+		for (int pass = 0; pass < 2; pass++) {
+			uint64_t* fill = NULL;
+			uint16_t* pts = NULL;
+			if (pass == 1) {
+				uint64_t run = 0;
+				for (uint64_t i = 0; i <= nu; i++) { const uint64_t c = off[i]; off[i] = run; run += c; }
+				fill = (uint64_t*)xmalloc((nu + 1) * 8);
+				memcpy(fill, off, (nu + 1) * 8);
+				pts = (uint16_t*)xmalloc((off[nu] * 3 + 1) * 2);
+				*points_out = pts;
+			}
+			for (int64_t zi = 0; zi < szr; zi++) {
+				for (uint64_t c = 0; c < d.cap_N[zi]; c++) {
+					const uint64_t L = d.cap_lmap[zi][c] & lmask;
+					if (skip_background && L == 0) continue;
+					uint64_t lo = 0, hi = nu;
+					while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (keys[mid] < L) lo = mid + 1; else hi = mid; }
+					if (lo == nu || keys[lo] != L) continue;      /* not selected */
+					const u32vec_t* m = &per[zi][c];
+					if (pass == 0) { off[lo] += m->n; continue; }
+					for (uint64_t k = 0; k < m->n; k++) {
+						const uint32_t loc = m->v[k];
+						const uint16_t yy = (uint16_t)(loc / h.sx);                          /* :246-247: 16-bit truncation */
+						const uint16_t xx = (uint16_t)(loc - h.sx * yy);
+						uint16_t* q = pts + 3 * fill[lo]++;
+						q[0] = xx; q[1] = yy; q[2] = (uint16_t)(zs + zi);
+					}
+				}
+			}
+			free(fill);
+		}
+		*labels_out = keys; *offsets_out = off; *n_out = nu;
+	}
+	for (int64_t zi = 0; zi < szr; zi++) {
+		if (per[zi]) { for (uint64_t c = 0; c <= d.cap_N[zi]; c++) free(per[zi][c].v); free(per[zi]); }
+		if (d.cap_lmap) free(d.cap_lmap[zi]);
+	}
+	free(per); free(vcg); free(d.cap_lmap); free(d.cap_N); free(d.cap_cc);
+	return rc;
+}
+
 int ckl_oracle_slice_vcg(const unsigned char* buf, uint64_t n, int64_t z, uint8_t* vcg_out) {
 	dec_ctx_t d;
 	memset(&d, 0, sizeof d);

@@ -75,6 +75,13 @@ int ckl_oracle_reencode(
 /* operations::array_equal (src/operations.hpp:1039-1184) */
 int ckl_oracle_array_equal(const unsigned char* buf1, uint64_t n1, const unsigned char* buf2, uint64_t n2, uint64_t parallel, int* equal);
 
+/* operations::point_cloud (src/operations.hpp:183-262) with dual_graph::extract_contours
+ * (src/dual_graph.hpp:133-275), parallel = 1: labels ascending, offsets in points, (x, y, z) uint16 */
+int ckl_oracle_point_cloud(
+	const unsigned char* buf, uint64_t n, int64_t z_start, int64_t z_end,
+	const uint64_t* labels, uint64_t n_labels, int has_labels, int skip_background,
+	uint64_t** labels_out, uint64_t** offsets_out, uint16_t** points_out, uint64_t* n_out);
+
 /* operations::mode_pooling_2x2x1 (src/operations.hpp:1201-1340): per-slice streams one after the other */
 int ckl_oracle_mode_pooling(
 	const unsigned char* buf, uint64_t n, int64_t z_start, int64_t z_end, uint64_t parallel,

@@ -81,6 +81,11 @@ class _Checker:
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64)]
     self._mode_pooling = f
+    f = getattr(L, prefix + "point_cloud")
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
+                  C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    self._point_cloud = f
     f = getattr(L, prefix + "reencode")
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -202,6 +207,30 @@ class _Checker:
       res.append(blob[at:at + int(m)])
       at += int(m)
     return res
+
+  def point_cloud(self, binary, z_start=0, z_end=-1, labels=None, skip_background=False):
+    """fastcrackle.point_cloud (operations.hpp:183-262, dual_graph.hpp:133-275) with parallel = 1:
+    dict label -> flat uint16 array of (x, y, z) triples, in the reference's append order."""
+    binary = bytes(binary)
+    sel = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
+    lab_p, off_p, pts_p, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    rc = self._point_cloud(binary, len(binary), int(z_start), int(z_end), None if sel is None else sel.ctypes.data,
+                           0 if sel is None else sel.size, int(sel is not None), int(bool(skip_background)),
+                           C.byref(lab_p), C.byref(off_p), C.byref(pts_p), C.byref(n))
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    try:
+      k = int(n.value)
+      if k == 0:
+        return {}
+      labs = np.frombuffer(C.string_at(lab_p.value, 8 * k), dtype=np.uint64)
+      offs = np.frombuffer(C.string_at(off_p.value, 8 * (k + 1)), dtype=np.uint64)
+      pts = np.frombuffer(C.string_at(pts_p.value, 6 * int(offs[k])), dtype=np.uint16)
+      return {int(labs[i]): pts[3 * int(offs[i]):3 * int(offs[i + 1])].copy() for i in range(k)}
+    finally:
+      for p in (lab_p, off_p, pts_p):
+        if p.value:
+          self._free(p)
 
   def crc32c(self, data):
     data = bytes(data)

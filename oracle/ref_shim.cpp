@@ -19,6 +19,7 @@
 //   crackle::operations::voxel_connectivity_graph src/operations.hpp:667-826
 //   crackle::operations::array_equal src/operations.hpp:1039-1184
 //   crackle::operations::mode_pooling_2x2x1 src/operations.hpp:1201-1340
+//   crackle::operations::point_cloud src/operations.hpp:183-262 (dual_graph.hpp:133-275)
 
 #include <cstdint>
 #include <cstdlib>
@@ -234,6 +235,44 @@ int ckl_ref_mode_pooling(
 		}
 		*out_len = total;
 		*count = bins.size();
+		return 0;
+	}
+	catch (const std::exception& e) {
+		g_err = e.what();
+		return 1;
+	}
+}
+
+// crackle::operations::point_cloud  src/operations.hpp:183-262 (the binding, src/fastcrackle.cpp:315-345,
+// passes z_start, z_end, labels, skip_background, parallel).  Labels ascending, offsets in points.
+__attribute__((visibility("default")))
+int ckl_ref_point_cloud(
+	const unsigned char* buf, uint64_t n, int64_t z_start, int64_t z_end,
+	const uint64_t* labels, uint64_t n_labels, int has_labels, int skip_background,
+	uint64_t** labels_out, uint64_t** offsets_out, uint16_t** points_out, uint64_t* n_out
+) {
+	try {
+		std::optional<std::vector<uint64_t>> sel = std::nullopt;
+		if (has_labels) sel = std::vector<uint64_t>(labels, labels + n_labels);
+		auto ptc = crackle::operations::point_cloud(buf, n, z_start, z_end, sel, skip_background != 0, 1);
+		std::vector<uint64_t> keys;
+		for (const auto& kv : ptc) keys.push_back(kv.first);
+		std::sort(keys.begin(), keys.end());
+		uint64_t total = 0;
+		for (uint64_t k : keys) total += ptc[k].size();
+		*labels_out = static_cast<uint64_t*>(malloc((keys.size() + 1) * 8));
+		*offsets_out = static_cast<uint64_t*>(malloc((keys.size() + 2) * 8));
+		*points_out = static_cast<uint16_t*>(malloc((total + 1) * 2));
+		uint64_t at = 0;
+		for (size_t i = 0; i < keys.size(); i++) {
+			const auto& v = ptc[keys[i]];
+			(*labels_out)[i] = keys[i];
+			(*offsets_out)[i] = at / 3;
+			memcpy(*points_out + at, v.data(), v.size() * 2);
+			at += v.size();
+		}
+		(*offsets_out)[keys.size()] = at / 3;
+		*n_out = keys.size();
 		return 0;
 	}
 	catch (const std::exception& e) {

@@ -5,8 +5,10 @@ into oracle/_ref by `make -C oracle ref`).  Runs only in the build container, wh
   tests/golden/golden.npz      exact .ckl bytes for every small case
   tests/golden/manifest.json   sha256/length/section hashes for larger generated cases
 
-usage: python tests/gen_golden.py [--xl]
-  --xl  writes tests/golden/manifest_xl.json (full-size BASELINE.json configurations)
+usage: python tests/gen_golden.py [--xl | --ops]
+  --xl   writes tests/golden/manifest_xl.json (full-size BASELINE.json configurations)
+  --ops  writes tests/golden/point_cloud.json (the reference's point_cloud on the small golden
+         streams: per stream and argument set a sha256 over labels, offsets and points)
 """
 import hashlib
 import json
@@ -65,11 +67,43 @@ def main_xl(ref):
     json.dump(manifest, f, indent=1, sort_keys=True)
 
 
+def point_cloud_digest(ptc) -> str:
+  """sha256 over the labels (ascending) and each label's flat uint16 (x, y, z) triples."""
+  h = hashlib.sha256()
+  for k in sorted(ptc):
+    h.update(int(k).to_bytes(8, "little"))
+    h.update(int(ptc[k].size).to_bytes(8, "little"))
+    h.update(np.ascontiguousarray(ptc[k], dtype="<u2").tobytes())
+  return h.hexdigest()
+
+
+POINT_CLOUD_ARGS = {"all": (0, -1, None, False), "skip0": (0, -1, None, True), "z1": (1, 2, None, False)}
+
+
+def main_ops(ref):
+  with np.load(os.path.join(HERE, "golden", "golden.npz")) as z:
+    streams = {k: z[k].tobytes() for k in z.files}
+  out = {}
+  for name in sorted(streams):
+    entry = {}
+    for tag, (z0, z1, labels, skip) in POINT_CLOUD_ARGS.items():
+      try:
+        entry[tag] = point_cloud_digest(ref.point_cloud(streams[name], z0, z1, labels, skip))
+      except RuntimeError as exc:
+        entry[tag] = "error: " + str(exc)
+    out[name] = entry
+  with open(os.path.join(HERE, "golden", "point_cloud.json"), "w") as f:
+    json.dump(out, f, indent=1, sort_keys=True)
+  print("point_cloud:", len(out), "streams")
+
+
 def main():
   ref = oracle.ref()
   assert ref is not None, "build oracle/_ref first (make -C oracle ref)"
   if "--xl" in sys.argv:
     return main_xl(ref)
+  if "--ops" in sys.argv:
+    return main_ops(ref)
   blobs = {}
   for name, (arr, kw) in golden_cases.small_cases().items():
     blobs[name] = np.frombuffer(ref.compress(arr, parallel=2, **kw), dtype=np.uint8)

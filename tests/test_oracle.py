@@ -1,6 +1,8 @@
 """Pins the oracle (oracle/ckl_oracle.c) to the reference: known-answer vectors from
 SURVEY.md Appendix C, the committed golden fixtures (bytes produced by the reference
 itself, tests/gen_golden.py), and — where oracle/_ref exists — the live reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -253,3 +255,50 @@ def test_mode_pooling_restatement_against_the_live_reference(port, ref):
     assert got == want, name
     if int.from_bytes(b[15:19], "little") >= 3:      # (the reference indexes out of bounds when the range is clamped)
       assert port.mode_pooling_2x2x1(b, 1, 3) == ref.mode_pooling_2x2x1(b, 1, 3), name
+
+
+def _point_cloud_call(chk, b, z0, z1, labels, skip):
+  try:
+    return chk.point_cloud(b, z0, z1, labels, skip)
+  except RuntimeError as exc:
+    return "error: " + str(exc)
+
+
+def test_point_cloud_restatement_against_the_reference_fixture(port):
+  """operations::point_cloud + dual_graph::extract_contours (src/operations.hpp:183-262,
+  src/dual_graph.hpp:133-275): the C restatement against tests/golden/point_cloud.json, written by
+  tests/gen_golden.py --ops from the compiled reference (every small golden stream, three argument
+  sets; the empty stream's error text included)."""
+  import json
+  from gen_golden import POINT_CLOUD_ARGS, point_cloud_digest
+  from util import golden
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "point_cloud.json")) as f:
+    want = json.load(f)
+  g = golden()
+  assert sorted(want) == sorted(g)
+  for name in sorted(g):
+    for tag, (z0, z1, labels, skip) in POINT_CLOUD_ARGS.items():
+      got = _point_cloud_call(port, g[name], z0, z1, labels, skip)
+      got = got if isinstance(got, str) else point_cloud_digest(got)
+      assert got == want[name][tag], (name, tag)
+
+
+def test_point_cloud_restatement_against_the_live_reference(port, ref):
+  """Thin structures, holes, nested components, noise, label selections and z-ranges."""
+  if ref is None:
+    pytest.skip("compiled reference not available")
+  import test_gpu_point_cloud as cases
+  for name in sorted(cases.VOLUMES):
+    arr = cases.VOLUMES[name]()
+    for kw in (dict(), dict(allow_pins=True, markov_model_order=2)):
+      b = ref.compress(arr, **kw)
+      some = [int(v) for v in np.unique(arr)[:3]] + [123456]
+      for z0, z1, labels, skip in ((0, -1, None, False), (0, -1, None, True), (1, 3, None, False), (0, -1, some, False), (2, 2, None, False)):
+        a, c = _point_cloud_call(ref, b, z0, z1, labels, skip), _point_cloud_call(port, b, z0, z1, labels, skip)
+        assert type(a) is type(c), (name, z0, z1)
+        if isinstance(a, str):
+          assert a == c
+          continue
+        assert sorted(a) == sorted(c), (name, kw, z0, z1)
+        for k in a:
+          assert np.array_equal(a[k], c[k]), (name, kw, z0, z1, k)
