@@ -28,40 +28,54 @@ namespace dev {
 
 constexpr uint32_t kDirR = 1u, kDirD = 2u, kDirL = 4u, kDirU = 8u;
 
-// grid = (ceil(sxy / 256), nslices)
-__global__ void __launch_bounds__(256) k_contour_dirs(RunGeom g, uint64_t sxy, uint64_t stride, uint8_t* __restrict__ out) {
+// grid = (ceil(sxy / 256), nslices).  Also the two candidate bitmaps of the start scan (one bit
+// per pixel, cand_words per slice, zeroed beforehand): A = a wall on the left or right side,
+// B = a wall on the right side and a pixel beyond it.
+__global__ void __launch_bounds__(256) k_contour_dirs(RunGeom g, uint64_t sxy, uint64_t stride, uint8_t* __restrict__ out, uint32_t cand_words, uint32_t* __restrict__ cand_a, uint32_t* __restrict__ cand_b) {
 	const uint32_t zi = blockIdx.y;
 	const uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
-	if (p >= sxy) return;
-	const uint32_t y = static_cast<uint32_t>(p / g.sx);
-	const uint32_t x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
-	const uint32_t* pv = g.planeV + zi * g.plane_words;
-	const uint32_t* ph = g.planeH + zi * g.plane_words;
-	auto joined = [&](const uint32_t* plane, uint32_t px, uint32_t py) -> uint32_t {
-		const uint32_t bit = (plane[static_cast<uint64_t>(py) * g.row_words + (px >> 5)] >> (px & 31u)) & 1u;
-		return g.flip ? (bit ^ 1u) : bit;
-	};
-	uint32_t m = 0;
-	if (x + 1 < g.sx && joined(pv, x + 1, y)) m |= kDirR;
-	if (y + 1 < g.sy && joined(ph, x, y + 1)) m |= kDirD;
-	if (x >= 1 && joined(pv, x, y)) m |= kDirL;
-	if (y >= 1 && joined(ph, x, y)) m |= kDirU;
-	out[static_cast<uint64_t>(zi) * stride + p] = static_cast<uint8_t>(m);
+	uint32_t m = kDirR | kDirL, x = 0;
+	if (p < sxy) {
+		const uint32_t y = static_cast<uint32_t>(p / g.sx);
+		x = static_cast<uint32_t>(p - static_cast<uint64_t>(y) * g.sx);
+		const uint32_t* pv = g.planeV + zi * g.plane_words;
+		const uint32_t* ph = g.planeH + zi * g.plane_words;
+		auto joined = [&](const uint32_t* plane, uint32_t px, uint32_t py) -> uint32_t {
+			const uint32_t bit = (plane[static_cast<uint64_t>(py) * g.row_words + (px >> 5)] >> (px & 31u)) & 1u;
+			return g.flip ? (bit ^ 1u) : bit;
+		};
+		m = 0;
+		if (x + 1 < g.sx && joined(pv, x + 1, y)) m |= kDirR;
+		if (y + 1 < g.sy && joined(ph, x, y + 1)) m |= kDirD;
+		if (x >= 1 && joined(pv, x, y)) m |= kDirL;
+		if (y >= 1 && joined(ph, x, y)) m |= kDirU;
+		out[static_cast<uint64_t>(zi) * stride + p] = static_cast<uint8_t>(m);
+	}
+	const unsigned long long ba = __ballot(p < sxy && (m & (kDirR | kDirL)) != (kDirR | kDirL));
+	const unsigned long long bb = __ballot(p < sxy && (m & kDirR) == 0u && x + 1 < g.sx);
+	if ((threadIdx.x & 63u) == 0 && p < sxy) {
+		const uint64_t w = static_cast<uint64_t>(zi) * cand_words + (p >> 5);
+		cand_a[w] = static_cast<uint32_t>(ba); cand_a[w + 1] = static_cast<uint32_t>(ba >> 32);
+		cand_b[w] = static_cast<uint32_t>(bb); cand_b[w + 1] = static_cast<uint32_t>(bb >> 32);
+	}
 }
 
 struct ContourArgs {
 	const uint8_t* dirs;       // [nslices][dirs_stride], dirs_stride a multiple of 4 (the walk reads aligned words)
+	const uint32_t* cand_a;    // [nslices][cand_words] start candidates (k_contour_dirs); cand_words covers a scan window past the end
+	const uint32_t* cand_b;
 	uint32_t* visited;         // [nslices][vis_words] (only when the bits do not fit the LDS; zeroed)
 	uint32_t* raw;             // [nslices][raw_cap] contour nodes as walked
 	uint4* table;              // [nslices][tab_cap]: offset into raw, length, position of the smallest node, that node
 	uint32_t* counts;          // [nslices][4]: contours, nodes, flags (1 raw overflow, 2 table overflow, 4 walk did not close), steps
 	uint32_t sx, sy;
 	uint32_t sxy;
-	uint32_t raw_cap, tab_cap, vis_words;
+	uint32_t raw_cap, tab_cap, vis_words, cand_words;
 	uint64_t dirs_stride;
 };
 
 constexpr uint32_t kContourRawOverflow = 1u, kContourTableOverflow = 2u, kContourOpenWalk = 4u;
+constexpr uint32_t kContourWindow = 64u;      // words of the candidate bitmaps one scan step looks at (2048 pixels)
 
 // compute_next_move (dual_graph.hpp:66-131) on rotational direction indices (0 R, 1 D, 2 L, 3 U):
 // first the turn towards the followed wall (clockwise: +1), then straight on, the other turn, back
@@ -74,16 +88,20 @@ __device__ __forceinline__ uint32_t contour_next_move(uint32_t turn, uint32_t la
 	return 4u;
 }
 
+// the direction masks are written by an earlier launch: read through the constant address space,
+// a wave-uniform index becomes a scalar load (its own counter, no wait behind the node stores)
+typedef const __attribute__((address_space(4))) uint32_t* contour_const_words;
+
 // One wavefront per slice.  grid = nslices, block = 64, dynamic LDS = vis_words * 4 when LDSVIS.
 template <bool LDSVIS>
 __global__ void __launch_bounds__(64) k_trace_contours(ContourArgs a) {
 	extern __shared__ uint32_t s_vis[];
 	const uint32_t zi = blockIdx.x;
 	const uint32_t lane = threadIdx.x;
-	const uint8_t* __restrict__ dirs = a.dirs + static_cast<uint64_t>(zi) * a.dirs_stride;
-	const uint32_t* __restrict__ dirs4 = reinterpret_cast<const uint32_t*>(dirs);
-	// the direction mask of a pixel through an aligned word: a scalar load when the index is uniform
+	const contour_const_words dirs4 = (contour_const_words)(reinterpret_cast<uintptr_t>(a.dirs + static_cast<uint64_t>(zi) * a.dirs_stride));
 	auto dir_of = [&](uint32_t v) -> uint32_t { return (dirs4[v >> 2] >> ((v & 3u) * 8u)) & 15u; };
+	const uint32_t* __restrict__ cand_a = a.cand_a + static_cast<uint64_t>(zi) * a.cand_words;
+	const uint32_t* __restrict__ cand_b = a.cand_b + static_cast<uint64_t>(zi) * a.cand_words;
 	uint32_t* vis = LDSVIS ? s_vis : a.visited + static_cast<uint64_t>(zi) * a.vis_words;
 	uint32_t* __restrict__ raw = a.raw + static_cast<uint64_t>(zi) * a.raw_cap;
 	uint4* __restrict__ table = a.table + static_cast<uint64_t>(zi) * a.tab_cap;
@@ -91,30 +109,31 @@ __global__ void __launch_bounds__(64) k_trace_contours(ContourArgs a) {
 		for (uint32_t i = lane; i < a.vis_words; i += 64u) s_vis[i] = 0u;
 		__syncthreads();
 	}
-	const uint32_t sxy = a.sxy, sx = a.sx;
+	const uint32_t sxy = a.sxy, sx = a.sx, vis_words = a.vis_words;
 	auto delta = [&](uint32_t move) -> uint32_t { return move == 0u ? 1u : move == 1u ? sx : move == 2u ? 0xFFFFFFFFu : 0u - sx; };
 	uint32_t n_contours = 0, tail = 0, flags = 0, total_steps = 0;
 	const uint32_t step_cap = 4u * sxy + 8u;      // a closed walk passes every (pixel, heading) at most once
 
 	uint32_t pos = 0;
+	uint32_t win = 0xFFFFFFFFu, a_w = 0, b_w = 0;      // this lane's words of the current candidate window
 	while (pos < sxy && !flags) {
-		// ---- VCGGraph::next_contour (dual_graph.hpp:40-61), 64 pixels at a time ----
-		const uint32_t p = pos + lane;
-		bool cand = false;
-		if (p < sxy) {
-			const uint32_t m0 = dirs[p];
-			const bool v0 = (vis[p >> 5] >> (p & 31u)) & 1u;
-			cand = !v0 && (m0 & (kDirR | kDirL)) != (kDirR | kDirL);             // (vcg & 0b110011) < 0b11
-			const uint32_t x = p % sx;
-			if (!cand && x + 1u < sx) {
-				const uint32_t q = p + 1u;
-				const bool v1 = (vis[q >> 5] >> (q & 31u)) & 1u;
-				cand = !v1 && (dirs[q] & kDirL) == 0u;                              // (vcg[idx+1] & 0b11110010) == 0
-			}
-		}
-		const unsigned long long found = __ballot(cand);
-		if (!found) { pos += 64u; continue; }
-		const uint32_t start = pos + static_cast<uint32_t>(__ffsll(static_cast<long long>(found))) - 1u;
+		// ---- VCGGraph::next_contour (dual_graph.hpp:40-61): the first pixel at or after pos that is
+		// unvisited with a wall at its left or right, or whose right neighbour is unvisited behind a
+		// wall — 64 words of the candidate bitmaps against the visited bits per step ----
+		const uint32_t wbase = (pos >> 5) & ~(kContourWindow - 1u);
+		if (wbase != win) { win = wbase; a_w = cand_a[wbase + lane]; b_w = cand_b[wbase + lane]; }
+		const uint32_t w = wbase + lane;
+		const uint32_t v0 = w < vis_words ? vis[w] : 0xFFFFFFFFu;
+		const uint32_t v1 = w + 1u < vis_words ? vis[w + 1u] : 0xFFFFFFFFu;
+		uint32_t fire = (a_w & ~v0) | (b_w & ~((v0 >> 1) | (v1 << 31)));
+		const uint32_t pw = pos >> 5;
+		if (w < pw) fire = 0u;
+		else if (w == pw) fire &= 0xFFFFFFFFu << (pos & 31u);
+		const unsigned long long found = __ballot(fire != 0u);
+		if (!found) { pos = (wbase + kContourWindow) << 5; continue; }
+		const uint32_t fl = static_cast<uint32_t>(__ffsll(static_cast<long long>(found))) - 1u;
+		const uint32_t fw = __builtin_amdgcn_readlane(fire, fl);
+		const uint32_t start = ((wbase + fl) << 5) + static_cast<uint32_t>(__ffs(static_cast<int>(fw))) - 1u;
 
 		// ---- the walk (dual_graph.hpp:161-199): wave-uniform ----
 		uint32_t node = start;
@@ -145,13 +164,21 @@ __global__ void __launch_bounds__(64) k_trace_contours(ContourArgs a) {
 			const uint32_t turn = clockwise ? 1u : 3u;
 			const uint32_t ending = contour_next_move(turn, 3u /* UP */, m_start);
 			uint32_t next = ending, steps = 0;
+			uint32_t seen = 0;      // lane 0: visited pixels met on the way
 			do {
 				node += delta(next);
+				if (node >= sxy) { flags |= kContourOpenWalk; break; }
+				const uint32_t m = dir_of(node);      // issued before the visited bit is touched: the two latencies overlap
 				push(node);
-				already += visit(node);
-				next = contour_next_move(turn, next, node < sxy ? dir_of(node) : 0u);
-				if (++steps > step_cap || next > 3u || node >= sxy) { flags |= kContourOpenWalk; break; }
+				if (LDSVIS) {
+					// nothing on the walk depends on the old bit: lane 0 swaps it in and counts
+					if (lane == 0) seen += (atomicOr(&vis[node >> 5], 1u << (node & 31u)) >> (node & 31u)) & 1u;
+				}
+				else already += visit(node);
+				next = contour_next_move(turn, next, m);
+				if (++steps > step_cap || next > 3u) { flags |= kContourOpenWalk; break; }
 			} while (!(node == start && next == ending) && !(flags & kContourRawOverflow));
+			already += __builtin_amdgcn_readfirstlane(seen);
 			total_steps += steps;
 		}
 		pos = start + 1u;

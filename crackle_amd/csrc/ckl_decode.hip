@@ -2847,9 +2847,24 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 		return !has_sel || std::binary_search(selected.begin(), selected.end(), label);
 	};
 
+	const bool prof = getenv("CKL_PROFILE") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	std::string marks;
+	auto mark = [&](const char* name) {
+		if (!prof) return;
+		CKL_HIP(hipStreamSynchronize(s));
+		const auto now = std::chrono::steady_clock::now();
+		char buf[64];
+		snprintf(buf, sizeof buf, " %s=%.2f", name, std::chrono::duration<double, std::milli>(now - t_last).count());
+		marks += buf;
+		t_last = now;
+	};
+	mark("tables");
+	uint64_t walk_steps = 0;
 	const uint32_t sxy = static_cast<uint32_t>(d.sxy);
 	const uint64_t dirs_stride = (d.sxy + 3) & ~3ull;
 	const uint32_t vis_words = (sxy + 31) / 32;
+	const uint32_t cand_words = ((vis_words + 1) & ~1u) + 2 * kContourWindow;      // a scan window may start at the last word
 	int max_lds = 0;
 	CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, d.device));
 	const bool lds_vis = !getenv("CKL_CONTOUR_HBM_VISITED") && static_cast<uint64_t>(vis_words) * 4 + 256 <= static_cast<uint64_t>(std::max(0, max_lds));
@@ -2867,13 +2882,13 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 	uint32_t tab_cap0 = static_cast<uint32_t>(std::min<uint64_t>(d.sxy / 32 + 1024, d.sxy + 1));
 	if (const char* env = getenv("CKL_CONTOUR_SMALL")) { raw_cap0 = std::max(16, atoi(env)); tab_cap0 = std::max(2, atoi(env) / 8); }      // testing: forces the second pass
 	DevBuf<uint8_t> d_dirs;
-	DevBuf<uint32_t> d_vis, d_counts, d_comp;
+	DevBuf<uint32_t> d_vis, d_counts, d_comp, d_cand;
 	DevBuf<uint4> d_table;
 	uint32_t z0 = 0;
 	while (z0 < ns) {
 		uint32_t raw_cap = raw_cap0, tab_cap = tab_cap0;
 		for (int attempt = 0; ; attempt++) {
-			const uint64_t per_slice = dirs_stride + 4ull * raw_cap + 16ull * tab_cap + 4ull * tab_cap + (lds_vis ? 0 : 4ull * vis_words) + 16;
+			const uint64_t per_slice = dirs_stride + 8ull * cand_words + 4ull * raw_cap + 16ull * tab_cap + 4ull * tab_cap + (lds_vis ? 0 : 4ull * vis_words) + 16;
 			const uint32_t nz = static_cast<uint32_t>(std::min<uint64_t>(ns - z0, std::max<uint64_t>(1, budget / per_slice)));
 			RunGeom gz = g;
 			gz.planeV = g.planeV + static_cast<uint64_t>(z0) * d.plane_words;
@@ -2891,19 +2906,25 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 				d_vis.ensure(static_cast<uint64_t>(vis_words) * nz);
 				CKL_HIP(hipMemsetAsync(d_vis.p, 0, static_cast<uint64_t>(vis_words) * nz * sizeof(uint32_t), s));
 			}
-			hipLaunchKernelGGL(k_contour_dirs, dim3(static_cast<uint32_t>((d.sxy + 255) / 256), nz), dim3(256), 0, s, gz, d.sxy, dirs_stride, d_dirs.p);
+			d_cand.ensure(2ull * cand_words * nz);
+			CKL_HIP(hipMemsetAsync(d_cand.p, 0, 2ull * cand_words * nz * sizeof(uint32_t), s));
+			hipLaunchKernelGGL(k_contour_dirs, dim3(static_cast<uint32_t>((d.sxy + 255) / 256), nz), dim3(256), 0, s, gz, d.sxy, dirs_stride, d_dirs.p,
+				cand_words, d_cand.p, d_cand.p + static_cast<uint64_t>(cand_words) * nz);
+			mark("dirs");
 			ContourArgs ca;
+			ca.cand_a = d_cand.p; ca.cand_b = d_cand.p + static_cast<uint64_t>(cand_words) * nz; ca.cand_words = cand_words;
 			ca.dirs = d_dirs.p; ca.visited = d_vis.p; ca.raw = raw->p; ca.table = d_table.p; ca.counts = d_counts.p;
 			ca.sx = h.sx; ca.sy = h.sy; ca.sxy = sxy; ca.raw_cap = raw_cap; ca.tab_cap = tab_cap; ca.vis_words = vis_words; ca.dirs_stride = dirs_stride;
 			if (lds_vis) hipLaunchKernelGGL(k_trace_contours<true>, dim3(nz), dim3(64), vis_words * 4, s, ca);
 			else hipLaunchKernelGGL(k_trace_contours<false>, dim3(nz), dim3(64), 0, s, ca);
+			mark("trace");
 			hipLaunchKernelGGL(k_contour_components, dim3((tab_cap + 255) / 256, nz), dim3(256), 0, s, gz, rz, d_table.p, d_counts.p, tab_cap, d_comp.p);
 			std::vector<uint32_t> counts(4ull * nz);
 			CKL_HIP(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 			CKL_HIP(hipStreamSynchronize(s));
 			CKL_HIP(hipGetLastError());
 			uint32_t flags = 0;
-			for (uint32_t i = 0; i < nz; i++) flags |= counts[4 * i + 2];
+			for (uint32_t i = 0; i < nz; i++) { flags |= counts[4 * i + 2]; walk_steps += counts[4 * i + 3]; }
 			if (flags & kContourOpenWalk) throw Error(CKL_ERR_RUNTIME, "crackle_amd: point_cloud: a contour walk did not close");
 			if (flags) {
 				if (attempt) throw Error(CKL_ERR_RUNTIME, "crackle_amd: point_cloud: contour buffers overflow");
@@ -2932,6 +2953,7 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 		}
 	}
 
+	mark("collect");
 	// merge_contours_via_vcg_coloring (dual_graph.hpp:213-243): a contour whose first node lies before
 	// the component's current first node goes to the front, any other to the back
 	std::vector<uint64_t> comp_n(d.total_comp, 0);                // contours per component
@@ -2980,6 +3002,7 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 	out.points = static_cast<uint16_t*>(host_out_alloc(std::max<uint64_t>(total_points * 6, 2)));
 	if (!total_points) return;
 
+	mark("order");
 	DevBuf<uint16_t> d_points;
 	d_points.ensure(total_points * 3);
 	std::vector<uint64_t> fill(off.begin(), off.end() - 1);
@@ -3003,6 +3026,7 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 			}
 		}
 	}
+	mark("plan");
 	DevBuf<ContourJob> d_jobs;
 	for (size_t ci = 0; ci < chunks.size(); ci++) {
 		if (jobs[ci].empty()) continue;
@@ -3011,9 +3035,12 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 		hipLaunchKernelGGL(k_contour_emit, dim3(static_cast<uint32_t>((nj + 3) / 4)), dim3(256), 0, s, d_jobs.p, nj, chunks[ci].raw->p, h.sx, d_points.p);
 		CKL_HIP(hipStreamSynchronize(s));      // the job list is reused by the next chunk
 	}
+	mark("emit");
 	CKL_HIP(hipMemcpyAsync(out.points, d_points.p, total_points * 6, hipMemcpyDeviceToHost, s));
 	CKL_HIP(hipStreamSynchronize(s));
 	CKL_HIP(hipGetLastError());
+	mark("d2h");
+	if (prof) fprintf(stderr, "[ckl point_cloud ms]%s | contours=%zu points=%llu walk_steps=%llu\n", marks.c_str(), kept.size(), static_cast<unsigned long long>(total_points), static_cast<unsigned long long>(walk_steps));
 }
 
 }  // namespace

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from crackle_amd import build as ckl_build
+from crackle_amd import build as ckl_build, synth
 import golden_cases
 from util import golden, label_format, flat_1d
 
@@ -26,7 +26,7 @@ def _module():
 
 def test_module_imports_and_exposes_the_reference_names():
   m = _module()
-  for name in ("compress", "decompress", "reencode_markov", "voxel_counts", "centroids", "bounding_boxes", "voxel_connectivity_graph"):
+  for name in ("compress", "decompress", "reencode_markov", "voxel_counts", "centroids", "bounding_boxes", "voxel_connectivity_graph", "array_equal", "mode_pooling_2x2x1", "point_cloud"):
     assert callable(getattr(m, name)), name
   # header problems surface without a device, like the reference's CrackleHeader constructor
   with pytest.raises(RuntimeError):
@@ -75,3 +75,19 @@ def test_ranges_labels_and_statistics_through_the_module():
   assert vcg.shape == (64, 64, 5) and vcg.flags.f_contiguous
   same_x = arr[1:, :, 2:7] == arr[:-1, :, 2:7]
   assert np.array_equal((vcg[1:, :, :] & 2) != 0, same_x)
+
+
+@pytest.mark.gpu
+def test_fastcrackle_point_cloud(checker):
+  """fastcrackle.point_cloud (src/fastcrackle.cpp:315-345): dict label -> flat uint16 triples."""
+  fc = _module()
+  arr = synth.as_numpy_f(synth.voronoi_labels((64, 48, 5), np.uint32, seed=21, cell=(12, 12, 3)))
+  binary = checker.compress(arr)
+  want = checker.point_cloud(binary, 1, 4, None, True)
+  got = fc.point_cloud(binary, 1, 4, None, True, 1)
+  assert sorted(got) == sorted(want)
+  for k in want:
+    assert got[k].dtype == np.uint16 and np.array_equal(got[k], want[k])
+  some = sorted(want)[:2]
+  got = fc.point_cloud(binary, labels=some)
+  assert sorted(got) == some
