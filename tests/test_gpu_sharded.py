@@ -3,6 +3,7 @@ volume; the merged stream must be the reference's whole-volume stream, byte for 
 rank must decode its z-range.  Exercises what the CPU tests cannot: the device-side re-keying,
 the deferred transfer of the crack codes into the page-locked shared mapping and the combined
 label-section crc."""
+import functools
 import os
 import socket
 
@@ -25,78 +26,113 @@ def _free_port():
   return p
 
 
+@functools.lru_cache(maxsize=None)
 def _volume(kind):
+  """Generated on the GPU (the 2048 x 2048 case takes 12 s on a host core) and kept per process."""
+  import torch
+  dev = torch.device("cuda", 0)
   if kind == "voronoi":
-    return synth.as_numpy_f(synth.voronoi_labels((256, 192, 12), np.uint32, seed=41, cell=(16, 16, 4)))
+    return synth.as_numpy_f(synth.voronoi_labels((256, 192, 12), np.uint32, seed=41, cell=(16, 16, 4), device=dev))
   if kind == "wide":
-    v = synth.as_numpy_f(synth.voronoi_labels((128, 96, 8), np.uint32, seed=42, cell=(16, 16, 4), modulus=200)).copy(order="F")
+    v = synth.as_numpy_f(synth.voronoi_labels((128, 96, 8), np.uint32, seed=42, cell=(16, 16, 4), modulus=200, device=dev)).copy(order="F")
     v[3:9, 4:7, 6] = 70000      # the widest label lives in the second slab only
     return v
   if kind == "noise":
     return synth.random_labels((96, 80, 6), np.uint32, seed=43, high=2000)
   if kind == "u64":
     # C3's label type: stored width 8, labels above 2^40 and two above 2^63, one per slab
-    v = synth.as_numpy_f(synth.voronoi_labels((1024, 64, 8), np.uint64, seed=44, cell=(32, 32, 4), offset=1 << 40)).copy(order="F")
+    v = synth.as_numpy_f(synth.voronoi_labels((1024, 64, 8), np.uint64, seed=44, cell=(32, 32, 4), offset=1 << 40, device=dev)).copy(order="F")
     v[5:11, 7:12, 1] = (1 << 63) + 5
     v[200:260, 30:33, 6] = (1 << 64) - 1
     return v
   if kind == "c4":
     # C4's slice shape: 2048 x 2048 (x_width = y_width = 2, component_width = 4)
-    return synth.as_numpy_f(synth.voronoi_labels((2048, 2048, 4), np.uint32, seed=45, cell=(32, 32, 8)))
+    return synth.as_numpy_f(synth.voronoi_labels((2048, 2048, 4), np.uint32, seed=45, cell=(32, 32, 8), device=dev))
   raise ValueError(kind)
 
 
-def _worker(rank, port, kind, order, pins, q):
+CASES = [
+  ("voronoi", 0, False, None), ("voronoi", 3, False, None), ("wide", 0, False, None), ("noise", 0, False, None), ("voronoi", 0, True, None),
+  ("wide", 0, False, "CKL_SHARDED_LEGACY"),      # unique labels exchanged after the slab encode
+  ("voronoi", 0, False, "CKL_TEST_MERGE_FAIL"),  # the in-encode exchange fails on every rank: fallback
+  ("u64", 0, False, None), ("u64", 5, False, "CKL_SHARDED_LEGACY"), ("u64", 5, True, None),      # BASELINE.json configs[3]: uint64 labels
+  ("voronoi", 5, True, None), ("c4", 5, True, None), ("c4", 5, False, None),                       # configs[4]: pins + markov order 5, 2048 x 2048
+]
+ENVS = ("CKL_SHARDED_LEGACY", "CKL_TEST_MERGE_FAIL")
+
+
+def _worker(rank, port, q):
+  """Both ranks run every case in one process group (a spawn per case costs half a minute of
+  imports on a fresh box); each case gets its own codec and its own environment."""
   import torch
   from crackle_amd import distributed as ckd
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   dist.init_process_group("gloo", rank=rank, world_size=WORLD)
   try:
-    vol = _volume(kind)
-    sx, sy, sz = vol.shape
-    szl = sz // WORLD
     dev = torch.device("cuda", 0)
-    signed = {1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[vol.dtype.itemsize]
-    slab = torch.from_numpy(np.ascontiguousarray(vol[:, :, rank * szl:(rank + 1) * szl].transpose(2, 1, 0)).view(signed)).to(dev)
-    codec = ckd.ShardedCodec(ckd.HipBackend(0, zero_copy=True), rank=rank, world=WORLD, device="cpu", compute_device=dev)
-    binary = None
-    for _ in range(2):      # the second call reuses the shared mapping
-      binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order, allow_pins=pins)
-    session = codec.open_decoder(binary, (sx, sy, szl))
-    back = torch.zeros_like(slab)
-    session.run(back)
-    torch.cuda.synchronize()
-    q.put((rank, None if binary is None else bytes(binary), bool(torch.equal(back, slab))))
+    for index, (kind, order, pins, env) in enumerate(CASES):
+      for name in ENVS:
+        os.environ.pop(name, None)
+      if env:
+        os.environ[env] = "1"
+      try:
+        vol = _volume(kind)
+        sx, sy, sz = vol.shape
+        szl = sz // WORLD
+        signed = {1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[vol.dtype.itemsize]
+        slab = torch.from_numpy(np.ascontiguousarray(vol[:, :, rank * szl:(rank + 1) * szl].transpose(2, 1, 0)).view(signed)).to(dev)
+        codec = ckd.ShardedCodec(ckd.HipBackend(0, zero_copy=True), rank=rank, world=WORLD, device="cpu", compute_device=dev)
+        binary = None
+        for _ in range(2):      # the second call reuses the shared mapping
+          binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order, allow_pins=pins)
+        session = codec.open_decoder(binary, (sx, sy, szl))
+        back = torch.zeros_like(slab)
+        session.run(back)
+        torch.cuda.synchronize()
+        q.put((rank, index, None if binary is None else bytes(binary), bool(torch.equal(back, slab)), None))
+        del session, codec, slab, back
+      except Exception as exc:      # reported per case; the other rank would otherwise wait for ever
+        q.put((rank, index, None, False, repr(exc)))
+        raise
   finally:
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,order,pins,env", [
-  ("voronoi", 0, False, None), ("voronoi", 3, False, None), ("wide", 0, False, None), ("noise", 0, False, None), ("voronoi", 0, True, None),
-  ("wide", 0, False, "CKL_SHARDED_LEGACY"),      # unique labels exchanged after the slab encode
-  ("voronoi", 0, False, "CKL_TEST_MERGE_FAIL"),  # the in-encode exchange fails on every rank: fallback
-  ("u64", 0, False, None), ("u64", 5, False, "CKL_SHARDED_LEGACY"), ("u64", 5, True, None),      # BASELINE.json configs[3]: uint64 labels
-  ("voronoi", 5, True, None), ("c4", 5, True, None), ("c4", 5, False, None),                       # configs[4]: pins + markov order 5, 2048 x 2048
-])
-def test_sharded_hip_backend_equals_whole_volume(checker, kind, order, pins, env, monkeypatch):
-  if env:
-    monkeypatch.setenv(env, "1")      # inherited by the spawned ranks
+@pytest.fixture(scope="module")
+def sharded_results():
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
   port = _free_port()
-  procs = [ctx.Process(target=_worker, args=(r, port, kind, order, pins, q)) for r in range(WORLD)]
+  procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
   for p in procs:
     p.start()
   results = {}
-  for _ in range(WORLD):
-    rank, binary, ok = q.get(timeout=300)
-    results[rank] = (binary, ok)
+  failed = None
+  for _ in range(WORLD * len(CASES)):
+    rank, index, binary, ok, err = q.get(timeout=600)
+    results[(rank, index)] = (binary, ok, err)
+    if err:
+      failed = err
+      break
   for p in procs:
-    p.join(timeout=120)
-    assert p.exitcode == 0
+    p.join(timeout=120 if failed is None else 5)
+    if p.is_alive():
+      p.terminate()
+  if failed is None:
+    for p in procs:
+      assert p.exitcode == 0
+  return results
+
+
+@pytest.mark.parametrize("index", range(len(CASES)), ids=[f"{k}-m{o}-{'pins' if p else 'flat'}{'-' + e if e else ''}" for k, o, p, e in CASES])
+def test_sharded_hip_backend_equals_whole_volume(checker, sharded_results, index):
+  kind, order, pins, env = CASES[index]
+  for rank in range(WORLD):
+    assert (rank, index) in sharded_results, "the ranks stopped before this case"
+    assert sharded_results[(rank, index)][2] is None, sharded_results[(rank, index)][2]
   vol = _volume(kind)
   whole = checker.compress(vol, markov_model_order=order, allow_pins=pins)
-  assert results[0][0] == whole, "merged slab streams differ from the whole-volume stream"
-  assert results[1][0] is None
-  assert results[0][1] and results[1][1], "a rank decoded its z-range wrongly"
+  assert sharded_results[(0, index)][0] == whole, "merged slab streams differ from the whole-volume stream"
+  assert sharded_results[(1, index)][0] is None
+  assert sharded_results[(0, index)][1] and sharded_results[(1, index)][1], "a rank decoded its z-range wrongly"
