@@ -65,6 +65,7 @@ struct ContourArgs {
 	const uint32_t* cand_a;    // [nslices][cand_words] start candidates (k_contour_dirs); cand_words covers a scan window past the end
 	const uint32_t* cand_b;
 	uint32_t* visited;         // [nslices][vis_words] (only when the bits do not fit the LDS; zeroed)
+	uint32_t* walked_r;        // [nslices][vis_words] zeroed: the wall at this pixel's right side lies on a loop already walked (null: no memo)
 	uint32_t* raw;             // [nslices][raw_cap] contour nodes as walked
 	uint4* table;              // [nslices][tab_cap]: offset into raw, length, position of the smallest node, that node
 	uint32_t* counts;          // [nslices][4]: contours, nodes, flags (1 raw overflow, 2 table overflow, 4 walk did not close), steps
@@ -78,15 +79,44 @@ constexpr uint32_t kContourRawOverflow = 1u, kContourTableOverflow = 2u, kContou
 constexpr uint32_t kContourWindow = 64u;      // words of the candidate bitmaps one scan step looks at (2048 pixels)
 
 // compute_next_move (dual_graph.hpp:66-131) on rotational direction indices (0 R, 1 D, 2 L, 3 U):
-// first the turn towards the followed wall (clockwise: +1), then straight on, the other turn, back
-__device__ __forceinline__ uint32_t contour_next_move(uint32_t turn, uint32_t last, uint32_t allowed) {
+// first the turn towards the followed wall (clockwise: +1), then straight on, the other turn, back.
+// wall_r: the pixel's right side was tried and found closed, i.e. that wall lies on the loop walked.
+__device__ __forceinline__ uint32_t contour_next_move(uint32_t turn, uint32_t last, uint32_t allowed, bool& wall_r) {
 	const uint32_t a = (last + turn) & 3u, c = (last - turn) & 3u, d = (last + 2u) & 3u;
+	wall_r = false;
 	if ((allowed >> a) & 1u) return a;
+	wall_r = a == 0u;
 	if ((allowed >> last) & 1u) return last;
+	wall_r = wall_r || last == 0u;
 	if ((allowed >> c) & 1u) return c;
+	wall_r = wall_r || c == 0u;
 	if ((allowed >> d) & 1u) return d;
 	return 4u;
 }
+
+// The same as a table per sense of rotation, for the walk's inner loop: entry (last << 4 | allowed)
+// holds the next move (2 bits) resp. whether the right side was tried and found closed (1 bit).
+// A pixel reached by a move always allows the move back, so `allowed` is never 0 there.
+struct ContourMoveTable { unsigned long long next_lo, next_hi, wall_r; };
+constexpr ContourMoveTable contour_move_table(uint32_t turn) {
+	ContourMoveTable t = { 0ull, 0ull, 0ull };
+	for (uint32_t last = 0; last < 4; last++) {
+		for (uint32_t allowed = 0; allowed < 16; allowed++) {
+			const uint32_t order[4] = { (last + turn) & 3u, last, (last - turn) & 3u, (last + 2u) & 3u };
+			uint32_t next = last, wall = 0;
+			for (uint32_t k = 0; k < 4; k++) {
+				if ((allowed >> order[k]) & 1u) { next = order[k]; break; }
+				if (order[k] == 0u) wall = 1;
+			}
+			const uint32_t e = last * 16u + allowed;
+			if (e < 32u) t.next_lo |= static_cast<unsigned long long>(next) << (2u * e);
+			else t.next_hi |= static_cast<unsigned long long>(next) << (2u * (e - 32u));
+			t.wall_r |= static_cast<unsigned long long>(wall) << e;
+		}
+	}
+	return t;
+}
+constexpr ContourMoveTable kContourClockwise = contour_move_table(1u), kContourCounter = contour_move_table(3u);
 
 // the direction masks are written by an earlier launch: read through the constant address space,
 // a wave-uniform index becomes a scalar load (its own counter, no wait behind the node stores)
@@ -103,6 +133,7 @@ __global__ void __launch_bounds__(64) k_trace_contours(ContourArgs a) {
 	const uint32_t* __restrict__ cand_a = a.cand_a + static_cast<uint64_t>(zi) * a.cand_words;
 	const uint32_t* __restrict__ cand_b = a.cand_b + static_cast<uint64_t>(zi) * a.cand_words;
 	uint32_t* vis = LDSVIS ? s_vis : a.visited + static_cast<uint64_t>(zi) * a.vis_words;
+	uint32_t* walked_r = a.walked_r ? a.walked_r + static_cast<uint64_t>(zi) * a.vis_words : nullptr;
 	uint32_t* __restrict__ raw = a.raw + static_cast<uint64_t>(zi) * a.raw_cap;
 	uint4* __restrict__ table = a.table + static_cast<uint64_t>(zi) * a.tab_cap;
 	if (LDSVIS) {
@@ -110,9 +141,9 @@ __global__ void __launch_bounds__(64) k_trace_contours(ContourArgs a) {
 		__syncthreads();
 	}
 	const uint32_t sxy = a.sxy, sx = a.sx, vis_words = a.vis_words;
-	auto delta = [&](uint32_t move) -> uint32_t { return move == 0u ? 1u : move == 1u ? sx : move == 2u ? 0xFFFFFFFFu : 0u - sx; };
+	// step of a move in the row-major pixel index: R +1, D +sx, L -1, U -sx
+	auto delta = [&](uint32_t move) -> uint32_t { const uint32_t d = (move & 1u) ? sx : 1u; return (move & 2u) ? 0u - d : d; };
 	uint32_t n_contours = 0, tail = 0, flags = 0, total_steps = 0;
-	const uint32_t step_cap = 4u * sxy + 8u;      // a closed walk passes every (pixel, heading) at most once
 
 	uint32_t pos = 0;
 	uint32_t win = 0xFFFFFFFFu, a_w = 0, b_w = 0;      // this lane's words of the current candidate window
@@ -139,47 +170,66 @@ __global__ void __launch_bounds__(64) k_trace_contours(ContourArgs a) {
 		uint32_t node = start;
 		const uint32_t m_start = dir_of(node);
 		const bool start_visited = (vis[node >> 5] >> (node & 31u)) & 1u;
+		if (start_visited && walked_r) {
+			// A visited start fires only for its unvisited right neighbour behind a wall; the walk then
+			// follows the loop that wall lies on, clockwise, and is dropped unless it meets a pixel no
+			// walk has passed.  A walk tries a closed side only on the loop it follows, a walk always
+			// closes, and the walk in the other sense is the same loop backwards: once any walk has
+			// tried this wall, every pixel of the loop has been passed and this one changes nothing.
+			uint32_t seen_wall = 0;
+			if (lane == 0) seen_wall = (__hip_atomic_load(walked_r + (start >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (start & 31u)) & 1u;
+			if (__builtin_amdgcn_readfirstlane(seen_wall)) { pos = start + 1u; continue; }
+		}
 		uint32_t already = start_visited ? 1u : 0u;
 		uint32_t n = 0, mn = start, mn_pos = 0;
-		auto push = [&](uint32_t v) {
-			if (tail + n < a.raw_cap) { if (lane == 0) raw[tail + n] = v; }
-			else flags |= kContourRawOverflow;
-			if (v < mn) { mn = v; mn_pos = n; }
-			n++;
-		};
-		auto visit = [&](uint32_t v) -> uint32_t {      // sets the visited bit, returns what it was
-			const uint32_t w = vis[v >> 5], bit = 1u << (v & 31u);
-			if (lane == 0) vis[v >> 5] = w | bit;
-			if (!LDSVIS) __threadfence_block();
-			return (w & bit) ? 1u : 0u;
-		};
+		const uint32_t room = a.raw_cap - tail;      // nodes this walk may still store
+		uint32_t* __restrict__ out = raw + tail;
 		if (m_start == 0u) {
-			visit(node);
-			push(node);
+			// an isolated pixel (dual_graph.hpp:168-171)
+			if (lane == 0) { vis[node >> 5] |= 1u << (node & 31u); if (room) out[0] = node; }
+			if (!room) flags |= kContourRawOverflow;
+			n = 1;
 		}
 		else {
-			push(start);
 			// counterclockwise for |x, clockwise for x| (dual_graph.hpp:177)
 			const bool clockwise = (m_start & kDirR) == 0u || (start_visited && m_start == (kDirU | kDirD));
-			const uint32_t turn = clockwise ? 1u : 3u;
-			const uint32_t ending = contour_next_move(turn, 3u /* UP */, m_start);
-			uint32_t next = ending, steps = 0;
-			uint32_t seen = 0;      // lane 0: visited pixels met on the way
-			do {
-				node += delta(next);
-				if (node >= sxy) { flags |= kContourOpenWalk; break; }
-				const uint32_t m = dir_of(node);      // issued before the visited bit is touched: the two latencies overlap
-				push(node);
-				if (LDSVIS) {
-					// nothing on the walk depends on the old bit: lane 0 swaps it in and counts
-					if (lane == 0) seen += (atomicOr(&vis[node >> 5], 1u << (node & 31u)) >> (node & 31u)) & 1u;
-				}
-				else already += visit(node);
-				next = contour_next_move(turn, next, m);
-				if (++steps > step_cap || next > 3u) { flags |= kContourOpenWalk; break; }
-			} while (!(node == start && next == ending) && !(flags & kContourRawOverflow));
+			const ContourMoveTable tab = clockwise ? kContourClockwise : kContourCounter;
+			bool wall_r = false;
+			const uint32_t ending = contour_next_move(clockwise ? 1u : 3u, 3u /* UP */, m_start, wall_r);
+			// Lane 0 walks alone (the other lanes wait at the end of the branch): its stores and LDS
+			// updates need no per-instruction lane mask, and every value in the loop is still uniform,
+			// so the loop stays on the scalar unit.
+			uint32_t seen = 0, bad = 0;
+			if (lane == 0) {
+				if (room) out[0] = start; else bad = kContourRawOverflow;
+				if (wall_r && walked_r) __hip_atomic_fetch_or(walked_r + (start >> 5), 1u << (start & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				n = 1;
+				uint32_t next = ending;
+				do {
+					node += delta(next);
+					if (node >= sxy || n >= room) { bad = node >= sxy ? kContourOpenWalk : kContourRawOverflow; break; }
+					const uint32_t m = dir_of(node);      // issued before the visited bit is touched: the two latencies overlap
+					out[n] = node;
+					if (node < mn) { mn = node; mn_pos = n; }
+					n++;
+					// nothing on the walk depends on the old bit: swapped in and counted
+					if (LDSVIS) seen += (atomicOr(&vis[node >> 5], 1u << (node & 31u)) >> (node & 31u)) & 1u;
+					else {
+						const uint32_t w = __hip_atomic_load(vis + (node >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						__hip_atomic_store(vis + (node >> 5), w | (1u << (node & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						seen += (w >> (node & 31u)) & 1u;
+					}
+					const uint32_t e = next * 16u + m;
+					if (walked_r && ((tab.wall_r >> e) & 1ull)) __hip_atomic_fetch_or(walked_r + (node >> 5), 1u << (node & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					next = static_cast<uint32_t>(((e & 32u) ? tab.next_hi : tab.next_lo) >> (2u * (e & 31u))) & 3u;
+				} while (!(node == start && next == ending));
+			}
+			n = __builtin_amdgcn_readfirstlane(n);
+			mn = __builtin_amdgcn_readfirstlane(mn);
+			mn_pos = __builtin_amdgcn_readfirstlane(mn_pos);
+			flags |= __builtin_amdgcn_readfirstlane(bad);
 			already += __builtin_amdgcn_readfirstlane(seen);
-			total_steps += steps;
+			total_steps += n - 1u;
 		}
 		pos = start + 1u;
 		if (flags) break;

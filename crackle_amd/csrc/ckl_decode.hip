@@ -2882,13 +2882,13 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 	uint32_t tab_cap0 = static_cast<uint32_t>(std::min<uint64_t>(d.sxy / 32 + 1024, d.sxy + 1));
 	if (const char* env = getenv("CKL_CONTOUR_SMALL")) { raw_cap0 = std::max(16, atoi(env)); tab_cap0 = std::max(2, atoi(env) / 8); }      // testing: forces the second pass
 	DevBuf<uint8_t> d_dirs;
-	DevBuf<uint32_t> d_vis, d_counts, d_comp, d_cand;
+	DevBuf<uint32_t> d_vis, d_counts, d_comp, d_cand, d_walked;
 	DevBuf<uint4> d_table;
 	uint32_t z0 = 0;
 	while (z0 < ns) {
 		uint32_t raw_cap = raw_cap0, tab_cap = tab_cap0;
 		for (int attempt = 0; ; attempt++) {
-			const uint64_t per_slice = dirs_stride + 8ull * cand_words + 4ull * raw_cap + 16ull * tab_cap + 4ull * tab_cap + (lds_vis ? 0 : 4ull * vis_words) + 16;
+			const uint64_t per_slice = dirs_stride + 4ull * vis_words + 8ull * cand_words + 4ull * raw_cap + 16ull * tab_cap + 4ull * tab_cap + (lds_vis ? 0 : 4ull * vis_words) + 16;
 			const uint32_t nz = static_cast<uint32_t>(std::min<uint64_t>(ns - z0, std::max<uint64_t>(1, budget / per_slice)));
 			RunGeom gz = g;
 			gz.planeV = g.planeV + static_cast<uint64_t>(z0) * d.plane_words;
@@ -2911,7 +2911,13 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 			hipLaunchKernelGGL(k_contour_dirs, dim3(static_cast<uint32_t>((d.sxy + 255) / 256), nz), dim3(256), 0, s, gz, d.sxy, dirs_stride, d_dirs.p,
 				cand_words, d_cand.p, d_cand.p + static_cast<uint64_t>(cand_words) * nz);
 			mark("dirs");
+			const bool memo = !getenv("CKL_CONTOUR_NO_MEMO");      // testing: every start is walked, like the reference does
+			if (memo) {
+				d_walked.ensure(static_cast<uint64_t>(vis_words) * nz);
+				CKL_HIP(hipMemsetAsync(d_walked.p, 0, static_cast<uint64_t>(vis_words) * nz * sizeof(uint32_t), s));
+			}
 			ContourArgs ca;
+			ca.walked_r = memo ? d_walked.p : nullptr;
 			ca.cand_a = d_cand.p; ca.cand_b = d_cand.p + static_cast<uint64_t>(cand_words) * nz; ca.cand_words = cand_words;
 			ca.dirs = d_dirs.p; ca.visited = d_vis.p; ca.raw = raw->p; ca.table = d_table.p; ca.counts = d_counts.p;
 			ca.sx = h.sx; ca.sy = h.sy; ca.sxy = sxy; ca.raw_cap = raw_cap; ca.tab_cap = tab_cap; ca.vis_words = vis_words; ca.dirs_stride = dirs_stride;

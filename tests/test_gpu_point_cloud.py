@@ -127,6 +127,15 @@ def test_point_cloud_paths(checker, monkeypatch):
   monkeypatch.setenv("CKL_CONTOUR_SMALL", "64")
   _same(operations._point_cloud_raw(binary, 0, -1, None, False, 0), want, "second pass")
   monkeypatch.delenv("CKL_CONTOUR_SMALL")
+  for name in ("rings", "checker", "spiral", "noise3", "voronoi_mod"):      # every start walked, as the reference does (no walked-loop memo)
+    b = checker.compress(VOLUMES[name]())
+    w = checker.point_cloud(b, 0, -1, None, False)
+    monkeypatch.setenv("CKL_CONTOUR_NO_MEMO", "1")
+    _same(operations._point_cloud_raw(b, 0, -1, None, False, 0), w, ("no memo", name))
+    monkeypatch.delenv("CKL_CONTOUR_NO_MEMO")
+    monkeypatch.setenv("CKL_CONTOUR_HBM_VISITED", "1")
+    _same(operations._point_cloud_raw(b, 0, -1, None, False, 0), w, ("hbm visited", name))
+    monkeypatch.delenv("CKL_CONTOUR_HBM_VISITED")
   big = synth.as_numpy_f(synth.voronoi_labels((2048, 1024, 2), np.uint32, seed=16, cell=(48, 48, 8)))      # 2 M pixels per slice
   b2 = checker.compress(big)
   _same(operations._point_cloud_raw(b2, 0, -1, None, True, 0), checker.point_cloud(b2, 0, -1, None, True), "2048 x 1024")
