@@ -1,6 +1,7 @@
 """Randomised parity sweep on the GPU: random shapes / dtypes / label patterns / options; the
 encoder's bytes must equal the checker's, the decoder must give the volume back, and the
-consumers (statistics, VCG, reencode) must agree with numpy / the checker.
+consumers (statistics, VCG, reencode, point clouds, array_equal, mode pooling) must agree with
+numpy / the checker.
 usage: python tools/random_parity.py [cases] [seed]"""
 import sys
 import time
@@ -10,7 +11,7 @@ import numpy as np
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
 import crackle_amd
-from crackle_amd import synth
+from crackle_amd import operations, synth
 from oracle import oracle
 
 
@@ -18,7 +19,9 @@ def make(rng):
   sx, sy = int(rng.integers(1, 300)), int(rng.integers(1, 300))
   if rng.random() < 0.25:
     sx = int(rng.choice([1, 2, 3, 4, 31, 32, 33, 64, 127, 128, 129, 256, 1024, 1025]))
-  sz = int(rng.integers(1, 7))
+  sz = int(rng.integers(1, 7)) if rng.random() < 0.8 else int(rng.integers(7, 80))      # deep volumes: pin runs, several label registers
+  if sz > 6:
+    sx, sy = min(sx, 96), min(sy, 96)
   dt = [np.uint8, np.uint16, np.uint32, np.uint64][int(rng.integers(0, 4))]
   kind = int(rng.integers(0, 6))
   hi = int(min(np.iinfo(dt).max, [3, 50, 2000, 1 << 20][int(rng.integers(0, 4))]))
@@ -68,6 +71,22 @@ def main():
       ok = ok and np.array_equal(crackle_amd.voxel_connectivity_graph(want, 6), chk.voxel_connectivity_graph(want, 6))
       order = 2 if kw["markov_model_order"] != 2 else 0
       ok = ok and crackle_amd.reencode(want, order) == chk.reencode(want, order)
+    if i % 4 == 1 and arr.size:
+      z0 = int(rng.integers(0, arr.shape[2]))
+      args = (z0, int(rng.integers(z0 + 1, arr.shape[2] + 1)), None, bool(rng.integers(0, 2)))
+      a, b = operations._point_cloud_raw(want, args[0], args[1], args[2], args[3], 0), chk.point_cloud(want, *args)
+      ok = ok and sorted(a) == sorted(b) and all(np.array_equal(a[k], b[k]) for k in b)
+    if i % 7 == 2 and arr.size:
+      ok = ok and crackle_amd.array_equal(want, got)
+      pooled = chk.mode_pooling_2x2x1(want)
+      if len({(crackle_amd.header(b).crack_format, crackle_amd.header(b).stored_data_width >= 0) for b in pooled}) == 1:
+        ok = ok and crackle_amd.mode_pooling_2x2x1(want) == crackle_amd.zstack(pooled)
+      else:      # pooled slices of different crack formats do not stack (crackle/operations.py:474-475 raises too)
+        try:
+          crackle_amd.mode_pooling_2x2x1(want)
+          ok = False
+        except ValueError:
+          pass
     if not ok:
       bad += 1
       print("MISMATCH", tag, flush=True)
