@@ -702,6 +702,65 @@ __global__ void __launch_bounds__(kBlock) k_unique_scatter(const uint64_t* __res
 	for (uint32_t q = 0; q < kUniqPer; q++) if ((flag >> q) & 1u) uniq[o++] = v[q];
 }
 
+// The component labels are first reduced to their distinct values (a volume has far fewer labels
+// than components: C2 has 1.6 M components and 65 k labels), so that only those are sorted: an
+// open-addressing table keyed by label, then the occupied slots compacted like the unique heads
+// above.  The all-ones label doubles as the empty marker and is noted in a flag of its own.
+constexpr uint64_t kLabelHashEmpty = ~0ull;
+__device__ __forceinline__ uint32_t label_hash(uint64_t v) {
+	v ^= v >> 33; v *= 0xff51afd7ed558ccdull; v ^= v >> 33;
+	return static_cast<uint32_t>(v);
+}
+// grid = ceil(n / 256); table: mask + 1 slots, preset to kLabelHashEmpty
+__global__ void __launch_bounds__(kBlock) k_label_hash_insert(const uint64_t* __restrict__ mapping, uint32_t n, unsigned long long* __restrict__ table, uint32_t mask, uint32_t* __restrict__ has_max) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const unsigned long long v = mapping[i];
+	if (v == kLabelHashEmpty) { *has_max = 1u; return; }
+	uint32_t h = label_hash(v) & mask;
+	for (uint32_t probe = 0; probe <= mask; probe++) {
+		const unsigned long long seen = table[h];      // most components find their label already there
+		if (seen == v) return;
+		if (seen == kLabelHashEmpty) {
+			const unsigned long long old = atomicCAS(table + h, kLabelHashEmpty, v);
+			if (old == kLabelHashEmpty || old == v) return;
+		}
+		h = (h + 1u) & mask;
+	}
+}
+__device__ __forceinline__ uint32_t hash_occupied(const unsigned long long* __restrict__ table, uint32_t slots, uint32_t i0, uint64_t (&v)[kUniqPer]) {
+	uint32_t flag = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < kUniqPer; q++) {
+		v[q] = i0 + q < slots ? table[i0 + q] : kLabelHashEmpty;
+		flag |= (v[q] != kLabelHashEmpty ? 1u : 0u) << q;
+	}
+	return flag;
+}
+// grid = ceil(slots / 2048)
+__global__ void __launch_bounds__(kBlock) k_label_hash_count(const unsigned long long* __restrict__ table, uint32_t slots, uint32_t* __restrict__ blk_count) {
+	__shared__ uint32_t s_red[kWaves];
+	uint64_t v[kUniqPer];
+	const uint32_t flag = hash_occupied(table, slots, blockIdx.x * kUniqItems + threadIdx.x * kUniqPer, v);
+	const uint32_t tot = block_sum(static_cast<uint32_t>(__popc(flag)), s_red);
+	if (threadIdx.x == 0) blk_count[blockIdx.x] = tot;
+}
+// grid = ceil(slots / 2048); the all-ones label, if seen, goes behind the others
+__global__ void __launch_bounds__(kBlock) k_label_hash_scatter(
+	const unsigned long long* __restrict__ table, uint32_t slots, const uint32_t* __restrict__ blk_base, const uint32_t* __restrict__ n_found,
+	const uint32_t* __restrict__ has_max, uint64_t* __restrict__ out
+) {
+	__shared__ uint32_t s_scan[kWaves];
+	uint64_t v[kUniqPer];
+	const uint32_t flag = hash_occupied(table, slots, blockIdx.x * kUniqItems + threadIdx.x * kUniqPer, v);
+	uint32_t c[1] = { static_cast<uint32_t>(__popc(flag)) }, tot[1];
+	block_excl_add<1>(c, tot, s_scan);
+	uint32_t o = blk_base[blockIdx.x] + c[0];
+#pragma unroll
+	for (uint32_t q = 0; q < kUniqPer; q++) if ((flag >> q) & 1u) out[o++] = v[q];
+	if (blockIdx.x == 0 && threadIdx.x == 0 && *has_max) out[*n_found] = kLabelHashEmpty;
+}
+
 // The flat label section (labels.hpp:123-152) assembled on device:
 //   u64 num_unique | uniq[num_unique] : stored_width | cc_per_slice[sz] : component_width | key[N] : byte_width(num_unique)
 // grid = ceil(max(U, sz, N) / 256) over three index spaces handled by one kernel
@@ -833,7 +892,7 @@ struct ckl_encoder {
 	DevBuf<uint16_t> d_run_local;
 	DevBuf<uint32_t> d_G, d_crc_acc;
 	uint64_t g_table_pixels = 0;                // slice size the G table was built for
-	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq;
+	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq, d_label_hash, d_label_list;
 	DevBuf<uint8_t> d_keys;
 	DevBuf<uint32_t> d_cc_volume;                // global component id of every voxel (pin encoding only)
 	DevBuf<uint32_t> d_pin_kept, d_pin_u32;      // pin passes (ckl_pins_dev.hpp): kept-run bits, per-component depths
@@ -1510,24 +1569,48 @@ PinCandidates pin_candidates_device(
 uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int component_width, uint32_t ns, const ckl_encode_overrides* ov = nullptr) {
 	hipStream_t s = e.stream2;
 	if (N > 0x7FFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
-	e.d_n_uniq.ensure(1);
-	uint32_t n_pad = 2048;
-	while (n_pad < N) n_pad <<= 1;
-	e.d_sorted.ensure(n_pad);
+	e.d_n_uniq.ensure(2);
 	e.d_uniq.ensure(N + 1);
+	// the values to sort: the distinct labels when the components are many (a hash pass, then the
+	// sort network runs over tens of thousands instead of millions of keys), else all of them
+	const uint64_t* sort_src = e.d_mapping.p;
+	uint64_t n_sort = N;
+	if (N > 8192 && N <= (1ull << 26) && !getenv("CKL_LABEL_SORT_ALL")) {
+		uint32_t slots = 16384;
+		while (slots < 2 * N) slots <<= 1;
+		e.d_label_hash.ensure(slots);
+		CKL_HIP(hipMemsetAsync(e.d_label_hash.p, 0xFF, static_cast<size_t>(slots) * sizeof(uint64_t), s));
+		CKL_HIP(hipMemsetAsync(e.d_n_uniq.p, 0, 2 * sizeof(uint32_t), s));
+		unsigned long long* table = reinterpret_cast<unsigned long long*>(e.d_label_hash.p);
+		hipLaunchKernelGGL(k_label_hash_insert, dim3(static_cast<uint32_t>((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, e.d_mapping.p, static_cast<uint32_t>(N), table, slots - 1u, e.d_n_uniq.p + 1);
+		const uint32_t hb = (slots + kUniqItems - 1) / kUniqItems;
+		e.d_uniq_blk.ensure(hb + 1);
+		hipLaunchKernelGGL(k_label_hash_count, dim3(hb), dim3(kBlock), 0, s, table, slots, e.d_uniq_blk.p);
+		hipLaunchKernelGGL(k_unique_scan, dim3(1), dim3(kBlock), 0, s, e.d_uniq_blk.p, hb, e.d_n_uniq.p);
+		hipLaunchKernelGGL(k_label_hash_scatter, dim3(hb), dim3(kBlock), 0, s, table, slots, e.d_uniq_blk.p, e.d_n_uniq.p, e.d_n_uniq.p + 1, e.d_uniq.p);
+		const std::vector<uint32_t> found = download(e.d_n_uniq.p, 2, s);
+		n_sort = static_cast<uint64_t>(found[0]) + (found[1] ? 1u : 0u);
+		if (n_sort == 0 || n_sort > N) throw Error(CKL_ERR_RUNTIME, "crackle_amd: label table pass failed");
+		e.d_label_list.ensure(n_sort);
+		CKL_HIP(hipMemcpyAsync(e.d_label_list.p, e.d_uniq.p, n_sort * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+		sort_src = e.d_label_list.p;
+	}
+	uint32_t n_pad = 2048;
+	while (n_pad < n_sort) n_pad <<= 1;
+	e.d_sorted.ensure(n_pad);
 	const uint32_t blocks = (n_pad + kBlock - 1) / kBlock;
-	hipLaunchKernelGGL(k_pad_copy_u64, dim3(blocks), dim3(kBlock), 0, s, e.d_mapping.p, N, e.d_sorted.p, static_cast<uint64_t>(n_pad));
+	hipLaunchKernelGGL(k_pad_copy_u64, dim3(blocks), dim3(kBlock), 0, s, sort_src, n_sort, e.d_sorted.p, static_cast<uint64_t>(n_pad));
 	for (uint32_t k = 2; k <= n_pad; k <<= 1) {
 		uint32_t j = k >> 1;
 		for (; j >= 2048; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3(blocks), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 		hipLaunchKernelGGL(k_bitonic_local, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 	}
 	{
-		const uint32_t ub = static_cast<uint32_t>((N + kUniqItems - 1) / kUniqItems);
+		const uint32_t ub = static_cast<uint32_t>((n_sort + kUniqItems - 1) / kUniqItems);
 		e.d_uniq_blk.ensure(ub + 1);
-		hipLaunchKernelGGL(k_unique_count, dim3(ub), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(N), e.d_uniq_blk.p);
+		hipLaunchKernelGGL(k_unique_count, dim3(ub), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(n_sort), e.d_uniq_blk.p);
 		hipLaunchKernelGGL(k_unique_scan, dim3(1), dim3(kBlock), 0, s, e.d_uniq_blk.p, ub, e.d_n_uniq.p);
-		hipLaunchKernelGGL(k_unique_scatter, dim3(ub), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(N), e.d_uniq_blk.p, e.d_uniq.p);
+		hipLaunchKernelGGL(k_unique_scatter, dim3(ub), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(n_sort), e.d_uniq_blk.p, e.d_uniq.p);
 	}
 	uint64_t uniq_bound = N;      // entries of the unique list the section kernel may have to write
 	if (ov && ov->merge_unique) {

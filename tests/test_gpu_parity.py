@@ -502,3 +502,22 @@ def test_mode_pooling_on_device(checker):
   a, bb, c, d = arr[0::2, 0::2], arr[1::2, 0::2], arr[0::2, 1::2], arr[1::2, 1::2]
   want = np.where(a == bb, a, np.where(a == c, a, np.where(bb == c, bb, d)))
   assert np.array_equal(small, want)
+
+
+def test_label_table_hash_pass_and_full_sort(checker, monkeypatch):
+  """The flat label table: distinct labels found by the hash pass before the sort (more than 8192
+  components) or all component labels sorted (CKL_LABEL_SORT_ALL); the all-ones uint64 label is the
+  hash table's empty marker and travels in a flag of its own."""
+  vols = [
+    synth.as_numpy_f(synth.voronoi_labels((512, 384, 4), np.uint32, seed=71, cell=(8, 8, 2))),                       # ~12 k components, ~6 k labels
+    synth.as_numpy_f(synth.voronoi_labels((384, 256, 6), np.uint64, seed=72, cell=(6, 6, 3), offset=1 << 41)).copy(order="F"),
+    synth.random_labels((200, 160, 3), np.uint16, seed=73, high=40000),                                               # nearly every component its own label
+  ]
+  vols[1][5:9, 7:11, 2] = np.uint64((1 << 64) - 1)
+  vols[1][100:130, 90:95, 4] = np.uint64((1 << 64) - 2)
+  for arr in vols:
+    want = checker.compress(arr)
+    assert crackle_amd.compress(arr) == want
+    monkeypatch.setenv("CKL_LABEL_SORT_ALL", "1")
+    assert crackle_amd.compress(arr) == want
+    monkeypatch.delenv("CKL_LABEL_SORT_ALL")
