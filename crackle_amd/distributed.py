@@ -438,9 +438,12 @@ class HipBackend:
 class ShardedCodec:
   """Sharded compress / decode over the default process group (or single process)."""
 
-  def __init__(self, backend, rank: int = 0, world: int = 1, device="cpu", compute_device=None):
+  def __init__(self, backend, rank: int = 0, world: int = 1, device="cpu", compute_device=None, force_sharded: bool = False):
     """device: where the tensors of the collectives live (cuda for RCCL, cpu for gloo);
-    compute_device: where the small tensor work of the label merge runs (default: device)."""
+    compute_device: where the small tensor work of the label merge runs (default: device);
+    force_sharded: a single rank takes the sharded path too (every collective runs over a process
+    group of one: how the RCCL calls are exercised on a one-GPU box)."""
+    self.force_sharded = bool(force_sharded)
     self.backend = backend
     self.rank, self.world = int(rank), int(world)
     self.device = torch.device(device)
@@ -453,7 +456,7 @@ class ShardedCodec:
     """Every rank passes its own z-slab (slab_shape = (sx, sy, sz_local)).  Returns the
     stream of the whole volume on rank 0, None elsewhere."""
     be = self.backend
-    if self.world == 1:
+    if self.world == 1 and not self.force_sharded:
       return be.encode(vol, slab_shape, allow_pins, fortran_order, markov_model_order, None)
     import os, time
     prof = os.environ.get("CKL_PROFILE") is not None
@@ -769,7 +772,7 @@ class ShardedCodec:
   def open_decoder(self, binary: Optional[bytes], slab_shape):
     """Makes the stream resident on every rank (broadcast from rank 0) and returns a
     session that decodes this rank's z-range into a caller-provided volume."""
-    if self.world > 1:
+    if self.world > 1 or self.force_sharded:
       n = torch.tensor([len(binary) if self.rank == 0 else 0], dtype=torch.int64, device=self.device)
       dist.broadcast(n, src=0)
       if self.rank == 0:
