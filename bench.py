@@ -55,6 +55,9 @@ def parse_args(argv=None):
 # ------------------------------------------------------------------------------------
 # multi-rank launcher (no GPU call may precede it: the children are fresh processes)
 # ------------------------------------------------------------------------------------
+_json_out = sys.stdout
+
+
 def _free_port():
   import socket
   with socket.socket() as s:
@@ -86,16 +89,19 @@ def spawn_ranks(args):
   line0, _ = procs[0].communicate()
   rcs = [p.wait() for p in procs]
   text = (line0 or b"").decode("utf-8", "replace")
-  sys.stdout.write(text)
-  sys.stdout.flush()
   if any(rcs):
+    sys.stderr.write(text)
     print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
     return 1
   try:
-    res = json.loads(text.strip().splitlines()[-1])
+    last = text.strip().splitlines()[-1]
+    res = json.loads(last)
   except (ValueError, IndexError):
+    sys.stderr.write(text)
     print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
     return 1
+  sys.stdout.write(last + "\n")      # ONE line: whatever else reached rank 0's stdout is dropped
+  sys.stdout.flush()
   if res.get("n_gpus") != n:
     print(f"bench.py: the line reports n_gpus={res.get('n_gpus')}, --gpus was {n}", file=sys.stderr)
     return 1
@@ -116,7 +122,7 @@ def dry_run(args, world, rank):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   if rank == 0:
     print(json.dumps({"metric": metric_name(args), "value": None, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
-                      "warmup": args.warmup, "dry_run": True, "max_over_ranks": float(t.item()), "scaling": args.scaling}), flush=True)
+                      "warmup": args.warmup, "dry_run": True, "max_over_ranks": float(t.item()), "scaling": args.scaling}), file=_json_out, flush=True)
   if world > 1:
     dist.barrier()
     dist.destroy_process_group()
@@ -248,6 +254,13 @@ def main():
   world_env = os.environ.get("WORLD_SIZE")
   if world_env is None and args.gpus > 1:
     sys.exit(spawn_ranks(args))
+  # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when its first
+  # communicator is made, and other libraries may chat there too: from here on file descriptor 1 is
+  # stderr, and the JSON line goes out through a duplicate of the real stdout.
+  global _json_out
+  sys.stdout.flush()
+  _json_out = os.fdopen(os.dup(1), "w")
+  os.dup2(2, 1)
   world = int(world_env or "1")
   if world != args.gpus:
     print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -268,16 +281,25 @@ def main():
   # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (never for reported
   # numbers): CKL_BENCH_REHEARSAL=1 maps the ranks onto the available devices and uses gloo
   rehearsal = rehearsal_mode == "1"
+  # CKL_BENCH_REHEARSAL=group1: one rank, but through the multi-rank code path (RCCL process group
+  # of one, sharded codec, barriers, max-over-ranks): what a one-GPU box can rehearse of --gpus N
+  group1 = rehearsal_mode == "group1" and world == 1
   n_dev = torch.cuda.device_count()
   if world > 1 and not rehearsal and n_dev < world:
     print(f"bench.py: {world} ranks but {n_dev} GPU(s)", file=sys.stderr)
     sys.exit(2)
   dev_index = (local_rank % max(n_dev, 1)) if (world > 1 and rehearsal) else (local_rank if world > 1 else 0)
-  if world > 1:
+  if world > 1 or group1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if group1:
+      os.environ.setdefault("MASTER_PORT", str(_free_port()))
+      os.environ.setdefault("RANK", "0")
+      os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(dev_index)
     if rehearsal:
       dist.init_process_group(backend="gloo")
+    elif group1:
+      dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{dev_index}"))
     else:
       dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{dev_index}"))
   dev = torch.device(f"cuda:{dev_index}")
@@ -309,11 +331,11 @@ def main():
   # the stream stays in the library's pinned host buffer (no copy into a Python bytes object)
   backend = ckd.HipBackend(dev_index, zero_copy=True)
   coll_dev = torch.device("cpu") if (world > 1 and rehearsal) else dev    # gloo: collectives on host tensors
-  codec = ckd.ShardedCodec(backend, rank=rank, world=world, device=coll_dev, compute_device=dev)
+  codec = ckd.ShardedCodec(backend, rank=rank, world=world, device=coll_dev, compute_device=dev, force_sharded=group1)
 
   def barrier():
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or group1:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -368,7 +390,7 @@ def main():
 
   # max over ranks of the timed wall clock
   t = torch.tensor([total_s, sum(enc_ms), sum(dec_ms), 0.0 if ok_local else 1.0], dtype=torch.float64, device=coll_dev)
-  if world > 1:
+  if world > 1 or group1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   total_s, enc_sum_ms, dec_sum_ms, any_bad = (float(v) for v in t.tolist())
 
@@ -469,9 +491,9 @@ def main():
       if world == 1:
         hip_slab = ckd.HipBackend(dev_index).encode(vol[:ns].contiguous(), (sx, sy, ns), False, True, args.markov, None)
       res["cpu_baseline"] = cpu_baseline(np, slab, args.markov, hip_slab)
-    print(json.dumps(res), flush=True)
+    print(json.dumps(res), file=_json_out, flush=True)
 
-  if world > 1:
+  if world > 1 or group1:
     dist.barrier()
     dist.destroy_process_group()
 
