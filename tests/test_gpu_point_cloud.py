@@ -146,3 +146,23 @@ def test_point_cloud_c2_slice_shape(checker):
   arr = synth.as_numpy_f(synth.voronoi_labels((1024, 1024, 4), np.uint32, seed=17, cell=(32, 32, 8)))
   binary = checker.compress(arr)
   _same(operations._point_cloud_raw(binary, 0, -1, None, False, 0), checker.point_cloud(binary, 0, -1, None, False), "c2")
+
+
+def test_point_cloud_golden_streams_against_the_reference_fixture():
+  """Every small golden stream (C order, pins, markov, PERMISSIBLE noise, single voxels, rows, the
+  empty stream) through the device path, against tests/golden/point_cloud.json — digests of the
+  compiled reference's own output (tests/gen_golden.py --ops)."""
+  import json
+  import os
+  from gen_golden import POINT_CLOUD_ARGS, point_cloud_digest
+  from util import golden
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "point_cloud.json")) as f:
+    want = json.load(f)
+  g = golden()
+  for name in sorted(g):
+    for tag, (z0, z1, labels, skip) in POINT_CLOUD_ARGS.items():
+      try:
+        got = point_cloud_digest(operations._point_cloud_raw(g[name], z0, z1, labels, skip, 0))
+      except RuntimeError as exc:
+        got = "error: " + str(exc)
+      assert got == want[name][tag], (name, tag)
