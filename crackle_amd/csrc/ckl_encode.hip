@@ -1520,46 +1520,69 @@ PinCandidates pin_candidates_device(
 	hipLaunchKernelGGL((k_pin_columns<LABEL, 2>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
 	hipLaunchKernelGGL(k_pin_choice, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s, a, N, choice);
 
+	CKL_HIP(hipStreamSynchronize(s));
+	HT_MARK("p:passes");
 	PinCandidates pc;
 	pc.comp_label = download(comp_label, N, s);
 	pc.comp_first = download(reinterpret_cast<const uint64_t*>(a.first_any), N, s);
 	std::vector<uint64_t> chosen = download(reinterpret_cast<const uint64_t*>(choice), N, s);
 
-	// the distinct chosen runs, in traversal order
-	std::vector<uint64_t> keys;
-	keys.reserve(N);
-	for (uint64_t k : chosen) if (k != kPinNoKey) keys.push_back(k);
-	std::sort(keys.begin(), keys.end());
-	keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-	if (keys.size() >= kPinNone) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many pins");
-	const uint32_t P = static_cast<uint32_t>(keys.size());
+	HT_MARK("p:d2h");
+	// every component's pin as an entry of its own (the same run may appear several times: a pin is
+	// taken at most once, since taking it removes every component that maps to it)
+	if (N >= kPinNone) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many pins");
+	const uint32_t P = static_cast<uint32_t>(N);
 	pc.comp_pin.assign(N, kPinNone);
-	for (uint64_t c = 0; c < N; c++) {
+	pc.pin_x.assign(P, 0); pc.pin_y.assign(P, 0); pc.pin_zs.assign(P, 0);
+	for (uint32_t c = 0; c < P; c++) {
 		if (chosen[c] == kPinNoKey) continue;
-		pc.comp_pin[c] = static_cast<uint32_t>(std::lower_bound(keys.begin(), keys.end(), chosen[c]) - keys.begin());
+		pc.comp_pin[c] = c;
+		const uint64_t col = chosen[c] / v.sz;
+		pc.pin_zs[c] = static_cast<uint32_t>(chosen[c] % v.sz);
+		pc.pin_x[c] = static_cast<uint32_t>(col % v.sx);
+		pc.pin_y[c] = static_cast<uint32_t>(col / v.sx);
 	}
-	pc.pin_x.resize(P); pc.pin_y.resize(P); pc.pin_zs.resize(P);
-	for (uint32_t i = 0; i < P; i++) {
-		const uint64_t col = keys[i] / v.sz;
-		pc.pin_zs[i] = static_cast<uint32_t>(keys[i] % v.sz);
-		pc.pin_x[i] = static_cast<uint32_t>(col % v.sx);
-		pc.pin_y[i] = static_cast<uint32_t>(col / v.sx);
-	}
-	pc.pin_ids_off.assign(P + 1, 0);
-	if (P) {
-		DevBuf<uint64_t> d_keys, d_off;
+	HT_MARK("p:keys");
+	pc.pin_ids_off.assign(static_cast<size_t>(P) + 1, 0);
+	{
+		DevBuf<uint64_t> d_off;
 		DevBuf<uint32_t> d_ze, d_ids;
-		upload(d_keys, keys, s);
 		d_ze.ensure(P);
+		CKL_HIP(hipMemsetAsync(d_ze.p, 0, static_cast<size_t>(P) * sizeof(uint32_t), s));
 		const dim3 pgrid((P + kPinBlock - 1) / kPinBlock);
-		hipLaunchKernelGGL((k_pin_extent<LABEL, false>), pgrid, dim3(kPinBlock), 0, s, labels, v, reinterpret_cast<const unsigned long long*>(d_keys.p), P, d_ze.p);
+		hipLaunchKernelGGL((k_pin_extent<LABEL, false>), pgrid, dim3(kPinBlock), 0, s, labels, v, choice, P, d_ze.p);
 		pc.pin_ze = download(d_ze.p, P, s);
-		for (uint32_t i = 0; i < P; i++) pc.pin_ids_off[i + 1] = pc.pin_ids_off[i] + (pc.pin_ze[i] - pc.pin_zs[i] + 1u);
+		for (uint32_t c = 0; c < P; c++) {
+			if (chosen[c] == kPinNoKey) { pc.pin_ze[c] = pc.pin_zs[c]; pc.pin_ids_off[c + 1] = pc.pin_ids_off[c]; }
+			else pc.pin_ids_off[c + 1] = pc.pin_ids_off[c] + (pc.pin_ze[c] - pc.pin_zs[c] + 1u);
+		}
 		upload(d_off, pc.pin_ids_off, s);
-		d_ids.ensure(pc.pin_ids_off[P]);
-		hipLaunchKernelGGL(k_pin_ids, pgrid, dim3(kPinBlock), 0, s, v, reinterpret_cast<const unsigned long long*>(d_keys.p), d_ze.p, d_off.p, P, d_ids.p);
+		d_ids.ensure(pc.pin_ids_off[P] + 1);
+		hipLaunchKernelGGL(k_pin_ids, pgrid, dim3(kPinBlock), 0, s, v, choice, d_ze.p, d_off.p, P, d_ids.p);
 		pc.pin_ids = download(d_ids.p, pc.pin_ids_off[P], s);
 	}
+	// the labels with the key of their first column run
+	{
+		uint32_t slots = 1024;
+		while (slots < 2 * N) slots <<= 1;
+		DevBuf<uint64_t> d_tab;
+		DevBuf<uint32_t> d_count;
+		d_tab.ensure(4ull * slots + 1);      // keys | values | label list | first list, + the all-ones label's minimum
+		d_count.ensure(1);
+		CKL_HIP(hipMemsetAsync(d_tab.p, 0xFF, (2ull * slots) * sizeof(uint64_t), s));
+		CKL_HIP(hipMemsetAsync(d_tab.p + 4ull * slots, 0xFF, sizeof(uint64_t), s));
+		CKL_HIP(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t), s));
+		unsigned long long* t = reinterpret_cast<unsigned long long*>(d_tab.p);
+		hipLaunchKernelGGL(k_pin_label_first, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s,
+			reinterpret_cast<const unsigned long long*>(comp_label), a.first_any, N, t, t + slots, slots - 1u, t + 4ull * slots);
+		hipLaunchKernelGGL(k_pin_label_list, dim3((slots + kPinBlock - 1) / kPinBlock), dim3(kPinBlock), 0, s, t, t + slots, slots, d_count.p, t + 2ull * slots, t + 3ull * slots);
+		const uint32_t nl = download(d_count.p, 1, s)[0];
+		pc.label_value = download(d_tab.p + 2ull * slots, nl, s);
+		pc.label_first = download(d_tab.p + 3ull * slots, nl, s);
+		const uint64_t max_first = download(d_tab.p + 4ull * slots, 1, s)[0];
+		if (max_first != kPinNoKey) { pc.label_value.push_back(kPinNoKey); pc.label_first.push_back(max_first); }
+	}
+	HT_MARK("p:ids");
 	return pc;
 }
 

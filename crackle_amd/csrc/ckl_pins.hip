@@ -18,6 +18,8 @@
 #include "ckl_pins.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <functional>
 #include <thread>
 #include <unordered_map>
 
@@ -263,70 +265,103 @@ std::vector<uint8_t> pins_cover_host(
 	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
 	const uint64_t N = pc.comp_label.size();
 	const size_t P = pc.pin_x.size();
+	const bool prof = getenv("CKL_PROFILE") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	std::string marks;
+	auto mark = [&](const char* name) {
+		if (!prof) return;
+		const auto now = std::chrono::steady_clock::now();
+		char buf[64];
+		snprintf(buf, sizeof buf, " %s=%.2f", name, std::chrono::duration<double, std::milli>(now - t_last).count());
+		marks += buf;
+		t_last = now;
+	};
 	if (pc.comp_first.size() != N || pc.comp_pin.size() != N || pc.pin_ids_off.size() != P + 1) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
+
+	// worker threads for the per-label phases (labels are independent of each other)
+	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 32);
+	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
+	auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) {
+		const size_t want = std::min(nthreads, std::max<size_t>(1, n / std::max<size_t>(grain, 1)));
+		if (want <= 1) { body(0, n); return; }
+		std::vector<std::thread> pool;
+		std::vector<std::string> errors(want);
+		for (size_t t = 0; t < want; t++) {
+			pool.emplace_back([&, t]() {
+				try { body(n * t / want, n * (t + 1) / want); }
+				catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
+			});
+		}
+		for (auto& th : pool) th.join();
+		for (auto& e : errors) if (!e.empty()) throw Error(CKL_ERR_RUNTIME, e);
+	};
 
 	// ---- pinsets (src/pins.hpp:126-163): a robin-hood node map keyed by label; its slot order
 	// depends on the order the labels were first seen, i.e. on their first column run ----
 	RhTable pinsets;                                  // label -> label index
 	size_t n_labels = 0;
 	{
-		std::vector<std::pair<uint64_t, uint32_t>> order;
-		order.reserve(N);
-		for (uint64_t c = 0; c < N; c++) if (pc.comp_first[c] != kPinNoKey) order.emplace_back(pc.comp_first[c], static_cast<uint32_t>(c));
+		std::vector<std::pair<uint64_t, uint64_t>> order;      // (first key, label)
+		if (!pc.label_value.empty()) {
+			if (pc.label_first.size() != pc.label_value.size()) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
+			order.reserve(pc.label_value.size());
+			for (size_t i = 0; i < pc.label_value.size(); i++) if (pc.label_first[i] != kPinNoKey) order.emplace_back(pc.label_first[i], pc.label_value[i]);
+		}
+		else {
+			order.reserve(N);
+			for (uint64_t c = 0; c < N; c++) if (pc.comp_first[c] != kPinNoKey) order.emplace_back(pc.comp_first[c], pc.comp_label[c]);
+		}
 		std::sort(order.begin(), order.end());
 		for (const auto& o : order) {
 			bool found;
-			pinsets.insert(pc.comp_label[o.second], static_cast<uint32_t>(n_labels), found);
+			pinsets.insert(o.second, static_cast<uint32_t>(n_labels), found);
 			if (!found) n_labels++;
 		}
 	}
+	mark("pinsets");
 
-	// ---- compute_multiverse (src/pins.hpp:165-198): per label the flat set of its component
-	// ids, inserted in linear voxel order = ascending id ----
-	std::vector<RhTable> universe(n_labels);
-	for (uint64_t c = 0; c < N; c++) {
-		size_t s; bool f;
-		if (!pinsets.find(pc.comp_label[c], s)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: component of a label without column runs");
-		universe[pinsets.vals[s]].insert(c, 0, f);
-	}
-
-	// ---- find_suboptimal_pins per label (src/pins.hpp:300-346).  Labels are independent:
-	// solved on a thread pool, stored by label index ----
-	std::vector<std::vector<uint32_t>> chosen(n_labels);      // pin indices, in the order taken
-	auto solve = [&](size_t li) {
-		RhTable& uni = universe[li];
-		std::vector<uint32_t>& out = chosen[li];
-		size_t cursor = 0;
-		while (uni.num) {
-			size_t us;
-			if (!uni.first(us, cursor)) break;
-			const uint64_t picked = uni.keys[us];
-			const uint32_t p = pc.comp_pin[picked];
-			if (p == kPinNone) { uni.erase(picked); continue; }   // cannot happen: every component lies on a kept column run
-			for (uint64_t k = pc.pin_ids_off[p]; k < pc.pin_ids_off[p + 1]; k++) uni.erase(pc.pin_ids[k]);
-			out.push_back(p);
+	// ---- components by label (ascending id within a label = linear voxel order, the insertion
+	// order of compute_multiverse, src/pins.hpp:165-198) ----
+	std::vector<uint32_t> comp_li(N);
+	parallel_for(N, 16384, [&](size_t lo, size_t hi) {
+		for (size_t c = lo; c < hi; c++) {
+			size_t s;
+			if (!pinsets.find(pc.comp_label[c], s)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: component of a label without column runs");
+			comp_li[c] = pinsets.vals[s];
 		}
-	};
+	});
+	std::vector<uint64_t> li_at(n_labels + 1, 0);
+	for (uint64_t c = 0; c < N; c++) li_at[comp_li[c] + 1]++;
+	for (size_t l = 0; l < n_labels; l++) li_at[l + 1] += li_at[l];
+	std::vector<uint32_t> li_comp(N);
 	{
-		const size_t nl = n_labels;
-		size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
-		nthreads = std::min(nthreads, std::max<size_t>(1, nl / 64));
-		if (nthreads <= 1) {
-			for (size_t li = 0; li < nl; li++) solve(li);
-		}
-		else {
-			std::vector<std::thread> pool;
-			std::vector<std::string> errors(nthreads);
-			for (size_t t = 0; t < nthreads; t++) {
-				pool.emplace_back([&, t]() {
-					try { for (size_t li = t; li < nl; li += nthreads) solve(li); }
-					catch (const std::exception& e) { errors[t] = e.what(); }
-				});
-			}
-			for (auto& th : pool) th.join();
-			for (auto& e : errors) if (!e.empty()) throw Error(CKL_ERR_RUNTIME, e);
-		}
+		std::vector<uint64_t> fill(li_at.begin(), li_at.end() - 1);
+		for (uint64_t c = 0; c < N; c++) li_comp[fill[comp_li[c]]++] = static_cast<uint32_t>(c);
 	}
+	mark("universe");
+
+	// ---- per label: the universe (a robin-hood flat set, filled in ascending id) and
+	// find_suboptimal_pins (src/pins.hpp:300-346) ----
+	std::vector<std::vector<uint32_t>> chosen(n_labels);      // pin indices, in the order taken
+	parallel_for(n_labels, 32, [&](size_t lo, size_t hi) {
+		for (size_t li = lo; li < hi; li++) {
+			RhTable uni;
+			bool f;
+			for (uint64_t k = li_at[li]; k < li_at[li + 1]; k++) uni.insert(li_comp[k], 0, f);
+			std::vector<uint32_t>& out = chosen[li];
+			size_t cursor = 0;
+			while (uni.num) {
+				size_t us;
+				if (!uni.first(us, cursor)) break;
+				const uint64_t picked = uni.keys[us];
+				const uint32_t p = pc.comp_pin[picked];
+				if (p == kPinNone) { uni.erase(picked); continue; }   // cannot happen: every component lies on a kept column run
+				for (uint64_t k = pc.pin_ids_off[p]; k < pc.pin_ids_off[p + 1]; k++) uni.erase(pc.pin_ids[k]);
+				out.push_back(p);
+			}
+		}
+	});
+	mark("cover");
 
 	// ---- all_pins: libstdc++ unordered_map filled in pinsets slot order (src/pins.hpp:374-388);
 	// its iteration order breaks ties in find_bgcolor (src/labels.hpp:157-190) ----
@@ -362,6 +397,7 @@ std::vector<uint8_t> pins_cover_host(
 	if (stored_width < 8) bgcolor &= (1ull << (8 * stored_width)) - 1;
 	all_pins.erase(bgcolor);
 
+	mark("bgcolor");
 	// ---- encode_condensed_pins (src/labels.hpp:192-344) ----
 	uint64_t max_pins = 0, max_depth = 0;
 	std::vector<uint64_t> all_labels;
@@ -389,36 +425,51 @@ std::vector<uint8_t> pins_cover_host(
 	for (int64_t z = 0; z < sz; z++) put_le(bin, ncomp[z], component_width);
 	bin.push_back(combined);
 
+	// the labels' records are independent: built side by side, joined in label order
 	struct Sorted { uint64_t idx, depth; uint32_t pin; };
-	for (uint64_t label : all_labels) {
-		const std::vector<uint32_t>& v = chosen[all_pins[label]];
-		std::vector<Sorted> sp;
-		sp.reserve(v.size());
-		for (uint32_t p : v) {
-			sp.push_back({ static_cast<uint64_t>(pc.pin_x[p]) + static_cast<uint64_t>(sx) * (static_cast<uint64_t>(pc.pin_y[p]) + static_cast<uint64_t>(sy) * pc.pin_zs[p]), depth_of(p), p });
+	std::vector<uint32_t> label_li(all_labels.size());
+	for (size_t i = 0; i < all_labels.size(); i++) label_li[i] = all_pins[all_labels[i]];
+	std::vector<std::vector<uint8_t>> parts(all_labels.size());
+	parallel_for(all_labels.size(), 64, [&](size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; i++) {
+			std::vector<uint8_t>& out = parts[i];
+			const std::vector<uint32_t>& v = chosen[label_li[i]];
+			std::vector<Sorted> sp;
+			sp.reserve(v.size());
+			for (uint32_t p : v) {
+				sp.push_back({ static_cast<uint64_t>(pc.pin_x[p]) + static_cast<uint64_t>(sx) * (static_cast<uint64_t>(pc.pin_y[p]) + static_cast<uint64_t>(sy) * pc.pin_zs[p]), depth_of(p), p });
+			}
+			std::sort(sp.begin(), sp.end(), [](const Sorted& a, const Sorted& b) { return a.idx < b.idx; });
+			uint64_t n_pin_repr = 0;
+			for (const Sorted& s : sp) n_pin_repr += (s.depth >= cc_efficient_threshold);
+			put_le(out, n_pin_repr, num_pins_width);
+			uint64_t prev = 0;
+			bool first = true;
+			for (const Sorted& s : sp) {
+				if (s.depth < cc_efficient_threshold) continue;
+				put_le(out, first ? s.idx : s.idx - prev, index_width);
+				prev = s.idx;
+				first = false;
+			}
+			for (const Sorted& s : sp) if (s.depth >= cc_efficient_threshold) put_le(out, s.depth, depth_width);
+			std::vector<uint32_t> ids;
+			for (const Sorted& s : sp) {
+				if (s.depth >= cc_efficient_threshold) continue;
+				for (uint64_t k = pc.pin_ids_off[s.pin]; k < pc.pin_ids_off[s.pin + 1]; k++) ids.push_back(pc.pin_ids[k]);
+			}
+			std::sort(ids.begin(), ids.end());
+			put_le(out, ids.size(), num_pins_width);
+			for (size_t k = 0; k < ids.size(); k++) put_le(out, k ? static_cast<uint32_t>(ids[k] - ids[k - 1]) : ids[k], cc_label_width);
 		}
-		std::sort(sp.begin(), sp.end(), [](const Sorted& a, const Sorted& b) { return a.idx < b.idx; });
-		uint64_t n_pin_repr = 0;
-		for (const Sorted& s : sp) n_pin_repr += (s.depth >= cc_efficient_threshold);
-		put_le(bin, n_pin_repr, num_pins_width);
-		uint64_t prev = 0;
-		bool first = true;
-		for (const Sorted& s : sp) {
-			if (s.depth < cc_efficient_threshold) continue;
-			put_le(bin, first ? s.idx : s.idx - prev, index_width);
-			prev = s.idx;
-			first = false;
-		}
-		for (const Sorted& s : sp) if (s.depth >= cc_efficient_threshold) put_le(bin, s.depth, depth_width);
-		std::vector<uint32_t> ids;
-		for (const Sorted& s : sp) {
-			if (s.depth >= cc_efficient_threshold) continue;
-			for (uint64_t k = pc.pin_ids_off[s.pin]; k < pc.pin_ids_off[s.pin + 1]; k++) ids.push_back(pc.pin_ids[k]);
-		}
-		std::sort(ids.begin(), ids.end());
-		put_le(bin, ids.size(), num_pins_width);
-		for (size_t k = 0; k < ids.size(); k++) put_le(bin, k ? static_cast<uint32_t>(ids[k] - ids[k - 1]) : ids[k], cc_label_width);
+	});
+	{
+		size_t total = bin.size();
+		for (const auto& part : parts) total += part.size();
+		bin.reserve(total);
+		for (const auto& part : parts) bin.insert(bin.end(), part.begin(), part.end());
 	}
+	mark("section");
+	if (prof) fprintf(stderr, "[ckl pins cover ms]%s | components=%llu labels=%zu pins=%zu\n", marks.c_str(), static_cast<unsigned long long>(N), n_labels, P);
 	return bin;
 }
 

@@ -31,7 +31,9 @@ inline uint64_t pin_key(uint64_t x, uint64_t y, uint64_t z_s, uint64_t sx, uint6
 struct PinCandidates {
 	std::vector<uint64_t> comp_label;     // [N] label of component c
 	std::vector<uint64_t> comp_first;     // [N] smallest pin_key of a column run starting inside c (kPinNoKey: none)
-	std::vector<uint32_t> comp_pin;       // [N] pin taken when c is drawn (index below; kPinNone cannot happen)
+	std::vector<uint64_t> label_value, label_first;   // optional: every label once with the smallest comp_first of its components (else derived from the two above)
+	std::vector<uint32_t> comp_pin;       // [N] pin taken when c is drawn (index below; kPinNone cannot happen).  Pins need not be distinct:
+	                                      // a pin is taken at most once, because taking it removes every component that maps to it
 	std::vector<uint32_t> pin_x, pin_y, pin_zs, pin_ze;
 	std::vector<uint64_t> pin_ids_off;    // [P + 1]
 	std::vector<uint32_t> pin_ids;        // component ids along each pin, z ascending

@@ -305,10 +305,42 @@ __global__ void __launch_bounds__(kPinBlock) k_pin_ids(PinVolume v, const unsign
 	const uint32_t i = blockIdx.x * kPinBlock + threadIdx.x;
 	if (i >= n) return;
 	const unsigned long long key = keys[i];
+	if (key == kPinNoKey) return;
 	const uint32_t z_s = static_cast<uint32_t>(key % v.sz);
 	const uint64_t col = key / v.sz;
 	uint32_t* dst = ids + off[i];
 	for (uint32_t z = z_s; z <= z_e[i]; z++) dst[z - z_s] = v.cc[col + v.sxy * z];
+}
+
+
+// The order in which the labels enter `pinsets` (src/pins.hpp:126-163) is that of their first column
+// run: per label the smallest first_any of its components, in an open-addressing table keyed by
+// label (the all-ones label cannot be a key: its minimum goes to max_first), then the occupied
+// slots are appended to a list (any order: the host sorts the few labels by that key).
+__global__ void __launch_bounds__(kPinBlock) k_pin_label_first(
+	const unsigned long long* __restrict__ comp_label, const unsigned long long* __restrict__ first_any, uint64_t n,
+	unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals, uint32_t mask, unsigned long long* __restrict__ max_first
+) {
+	const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kPinBlock + threadIdx.x;
+	if (c >= n) return;
+	const unsigned long long label = comp_label[c], first = first_any[c];
+	if (label == kPinNoKey) { atomicMin(max_first, first); return; }
+	uint32_t h = pin_hash(label) & mask;
+	for (uint32_t probe = 0; probe <= mask; probe++) {
+		unsigned long long seen = keys[h];
+		if (seen == kPinNoKey) seen = atomicCAS(keys + h, kPinNoKey, label);
+		if (seen == kPinNoKey || seen == label) { if (first < vals[h]) atomicMin(vals + h, first); return; }
+		h = (h + 1u) & mask;
+	}
+}
+__global__ void __launch_bounds__(kPinBlock) k_pin_label_list(
+	const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals, uint32_t slots,
+	uint32_t* __restrict__ count, unsigned long long* __restrict__ out_label, unsigned long long* __restrict__ out_first
+) {
+	const uint32_t i = blockIdx.x * kPinBlock + threadIdx.x;
+	if (i >= slots || keys[i] == kPinNoKey) return;
+	const uint32_t at = atomicAdd(count, 1u);
+	out_label[at] = keys[i]; out_first[at] = vals[i];
 }
 
 }  // namespace ckl
