@@ -895,7 +895,7 @@ struct ckl_encoder {
 	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq, d_label_hash, d_label_list;
 	DevBuf<uint8_t> d_keys;
 	DevBuf<uint32_t> d_cc_volume;                // global component id of every voxel (pin encoding only)
-	DevBuf<uint32_t> d_pin_kept, d_pin_u32;      // pin passes (ckl_pins_dev.hpp): kept-run bits, per-component depths
+	DevBuf<uint32_t> d_pin_kept, d_pin_u32;      // pin passes (ckl_pins_dev.hpp): kept-run marks (uint16 per voxel), per-component depths
 	DevBuf<uint8_t> d_pin_tables;                // per-row label tables of k_pin_dedup
 	DevBuf<uint64_t> d_pin_u64;                  // per-component keys
 	DevBuf<uint32_t> d_slice_err2, d_n_uniq, d_uniq_blk;
@@ -1476,10 +1476,11 @@ PinCandidates pin_candidates_device(
 	v.sx = static_cast<uint32_t>(sx_); v.sy = static_cast<uint32_t>(sy_); v.sz = static_cast<uint32_t>(sz_);
 	v.sxy = static_cast<uint64_t>(v.sx) * v.sy;
 	const uint64_t voxels = v.sxy * v.sz;
-	const uint64_t kept_words = (voxels + 31) / 32;
-	e.d_pin_kept.ensure(kept_words);
-	CKL_HIP(hipMemsetAsync(e.d_pin_kept.p, 0, kept_words * sizeof(uint32_t), s));
-	v.cc = cc; v.kept = e.d_pin_kept.p;
+	if (v.sz > 65535u) throw Error(CKL_ERR_ARG, "crackle_amd: pin labels need at most 65535 slices");      // the kept marks hold depth + 1 in 16 bits
+	const uint64_t mark_words = (voxels + 1) / 2;
+	e.d_pin_kept.ensure(mark_words);
+	CKL_HIP(hipMemsetAsync(e.d_pin_kept.p, 0, mark_words * sizeof(uint32_t), s));
+	v.cc = cc; v.mark = reinterpret_cast<uint16_t*>(e.d_pin_kept.p);
 
 	const bool by_thread = getenv("CKL_PINS_ROW_THREADS") != nullptr;      // testing: the general kernel on small volumes
 	if (v.sz <= 1024u && !by_thread) {

@@ -8,8 +8,8 @@
 //                  previous column of the same row: rows are independent, and within a row the
 //                  state is "the last kept run per label of column x-1 and of column x".  One
 //                  thread per row walks x with two generation-stamped open-addressing tables
-//                  (labels of column x-1 / x, no clearing) and marks the kept runs in a bit
-//                  volume at (x, y, z_start).
+//                  (labels of column x-1 / x, no clearing) and marks the kept runs in a
+//                  uint16 volume at (x, y, z_start) with their depth + 1.
 //   k_pin_columns<0>  per component: first column run (any) and first KEPT run containing it,
 //                  in traversal order (y, x, z_start)         — atomicMin on 64-bit keys
 //   k_pin_extent<depth>  depth of that first kept run (one thread per component)
@@ -17,8 +17,8 @@
 //   k_pin_choice   the run find_suboptimal_pins takes per component (src/pins.hpp:325-340)
 //   k_pin_extent / k_pin_ids   z-range and component ids of the distinct chosen runs
 //
-// The two per-column passes read labels + ids + kept bits coalesced along x
-// (~9 B per voxel each); the dedup pass is latency bound (sx * runs-per-column dependent
+// The two per-column passes read labels + ids + kept marks coalesced along x
+// (~10 B per voxel each); the dedup pass is latency bound (sx * runs-per-column dependent
 // steps per row) and reads the volume once through L2.
 #pragma once
 #include "ckl_device.hpp"
@@ -41,7 +41,7 @@ struct PinVolume {
 	uint32_t sx, sy, sz;
 	uint64_t sxy;
 	const uint32_t* cc;      // global component ids
-	uint32_t* kept;          // one bit per voxel: a kept candidate pin starts here
+	uint16_t* mark;          // per voxel: depth + 1 of the kept candidate pin that starts here, else 0 (sz <= 65535)
 };
 
 __device__ __forceinline__ uint32_t pin_hash(uint64_t label) {
@@ -97,8 +97,7 @@ __global__ void __launch_bounds__(kPinRowBlock) k_pin_dedup(const LABEL* __restr
 						const uint32_t lz_s = prev[p].z_s, lz_e = prev[p].z_e;
 						if (lz_s <= z_s && lz_e >= z_e) keep = false;                 // covered by the neighbour: dropped
 						else if (lz_s >= z_s && lz_e <= z_e) {                          // covers the neighbour: takes its place
-							const uint64_t bit = col - 1u + v.sxy * lz_s;
-							atomicAnd(v.kept + (bit >> 5), ~(1u << (bit & 31u)));
+							v.mark[col - 1u + v.sxy * lz_s] = 0;
 						}
 						break;
 					}
@@ -106,8 +105,7 @@ __global__ void __launch_bounds__(kPinRowBlock) k_pin_dedup(const LABEL* __restr
 				}
 			}
 			if (keep) {
-				const uint64_t bit = col + v.sxy * z_s;
-				atomicOr(v.kept + (bit >> 5), 1u << (bit & 31u));
+				v.mark[col + v.sxy * z_s] = static_cast<uint16_t>(z_e - z_s + 1u);
 				cur[slot].label = L; cur[slot].gen = gen; cur[slot].z_s = z_s; cur[slot].z_e = z_e;
 			}
 			label = next;
@@ -121,7 +119,7 @@ __global__ void __launch_bounds__(kPinRowBlock) k_pin_dedup(const LABEL* __restr
 // a ballot of "the label changes above me" gives the column's runs, which the wave then walks
 // uniformly.  The two label tables live in registers, one entry per lane and k: a lookup is a
 // compare + ballot, an append a predicated move.  No LDS, no hashing, no dependent memory
-// round trip per run; the only stores are the kept-bit atomics of lane 0.
+// round trip per run; the only stores are lane 0's kept marks.
 template <typename LABEL>
 __device__ __forceinline__ LABEL wave_read(LABEL v, uint32_t lane) {
 	if constexpr (sizeof(LABEL) == 8) {
@@ -194,10 +192,7 @@ __global__ void __launch_bounds__(64 * kPinWaves) k_pin_dedup_wave(const LABEL* 
 								const uint32_t lzz = __builtin_amdgcn_readlane(prev_zz[j], static_cast<uint32_t>(__ffsll(static_cast<long long>(hm))) - 1u);
 								const uint32_t lz_s = lzz & 0xFFFFu, lz_e = lzz >> 16;
 								if (lz_s <= z_s && lz_e >= z_e) keep = false;                 // covered by the neighbour: dropped
-								else if (lz_s >= z_s && lz_e <= z_e && lane == 0) {             // covers the neighbour: takes its place
-									const uint64_t bit = col - 1u + v.sxy * lz_s;
-									atomicAnd(v.kept + (bit >> 5), ~(1u << (bit & 31u)));
-								}
+								else if (lz_s >= z_s && lz_e <= z_e && lane == 0) v.mark[col - 1u + v.sxy * lz_s] = 0;      // covers the neighbour: takes its place
 							}
 						}
 					}
@@ -207,10 +202,7 @@ __global__ void __launch_bounds__(64 * kPinWaves) k_pin_dedup_wave(const LABEL* 
 						n_cur++;
 					}
 				}
-				if (keep && lane == 0) {
-					const uint64_t bit = col + v.sxy * z_s;
-					atomicOr(v.kept + (bit >> 5), 1u << (bit & 31u));
-				}
+				if (keep && lane == 0) v.mark[col + v.sxy * z_s] = static_cast<uint16_t>(z_e - z_s + 1u);
 				z_s = z_e + 1u;
 			}
 		}
@@ -227,40 +219,78 @@ struct PinComponentArrays {
 	unsigned long long* best;           // [N] 1 + largest key of a kept run deeper than the first (0: none)
 };
 
-// One thread per (x, y) column walks z; PASS 0: firsts, 2: last kept run deeper than the first
-// (the depth of the first comes from k_pin_extent in between).
+// Of the lanes with `want` set, is this one the first (LAST: the last) that names component c?
+// Called by all active lanes of the wavefront.
+template <bool LAST>
+__device__ __forceinline__ bool pin_wave_leader(bool want, uint32_t c) {
+	const unsigned long long m = __ballot(want);
+	const uint32_t lane = threadIdx.x & 63u;
+	const unsigned long long others = LAST ? (lane == 63u ? 0ull : m & (~0ull << (lane + 1u))) : m & ((1ull << lane) - 1ull);
+	// the nearest wanting lane on that side (any lane when there is none: its answer is not used)
+	const uint32_t nb = others ? (LAST ? static_cast<uint32_t>(__ffsll(static_cast<long long>(others))) - 1u : 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(others)))) : lane;
+	const uint32_t c_nb = static_cast<uint32_t>(__shfl(static_cast<int>(c), static_cast<int>(nb)));
+	return want && !(others && c_nb == c);
+}
+
+// One thread per (x, y) column walks z once, eight slices at a time: labels, component ids and kept
+// marks of the eight are loaded together, then the per-component values they will be compared with
+// (independent gathers), then the comparisons; the depth of a kept run comes with its mark, so the
+// run's end need not be known.  PASS 0: first run / first kept run of every component (atomicMin on
+// keys); PASS 2: last kept run deeper than the first (atomicMax; the depth of the first comes from
+// k_pin_extent in between).  A value gathered before another thread's atomic is only ever larger
+// (PASS 0) or smaller (PASS 2) than the current one: the filter in front of the atomics stays safe.
 // grid = ceil(sx / 256) x sy
+constexpr uint32_t kPinChunk = 8;
 template <typename LABEL, int PASS>
 __global__ void __launch_bounds__(kPinBlock) k_pin_columns(const LABEL* __restrict__ labels, PinVolume v, PinComponentArrays a) {
 	const uint32_t x = blockIdx.x * kPinBlock + threadIdx.x;
 	const uint32_t y = blockIdx.y;
 	if (x >= v.sx) return;
 	const uint64_t col = static_cast<uint64_t>(y) * v.sx + x;
-	LABEL label = labels[col];
-	uint32_t z_s = 0;
-	for (uint32_t z = 1; z <= v.sz; z++) {
-		LABEL next = label;
-		bool ends = true;
-		if (z < v.sz) { next = labels[col + v.sxy * z]; ends = next != label; }
-		if (!ends) continue;
-		const uint32_t z_e = z - 1u;
-		const unsigned long long key = (static_cast<unsigned long long>(col)) * v.sz + z_s;
-		const uint64_t bit = col + v.sxy * z_s;
-		const bool kept = (v.kept[bit >> 5] >> (bit & 31u)) & 1u;
-		if (PASS == 0) {
-			const uint32_t c0 = v.cc[bit];
-			if (key < a.first_any[c0]) atomicMin(a.first_any + c0, key);
+	LABEL prev = 0;
+	bool kept = false;
+	uint32_t depth = 0;
+	unsigned long long key = 0;
+	for (uint32_t z0 = 0; z0 < v.sz; z0 += kPinChunk) {
+		LABEL lab[kPinChunk];
+		uint32_t cc[kPinChunk], mk[kPinChunk];
+		unsigned long long g0[kPinChunk];
+		uint32_t g1[kPinChunk];
+#pragma unroll
+		for (uint32_t i = 0; i < kPinChunk; i++) {
+			const uint64_t at = col + v.sxy * min(z0 + i, v.sz - 1u);
+			lab[i] = labels[at]; cc[i] = v.cc[at]; mk[i] = v.mark[at];
 		}
-		if (kept) {
-			const uint32_t depth = z_e - z_s;
-			for (uint32_t zz = z_s; zz <= z_e; zz++) {
-				const uint32_t c = v.cc[col + v.sxy * zz];
-				if (PASS == 0) { if (key < a.first_kept[c]) atomicMin(a.first_kept + c, key); }
-				else { if (depth > a.first_depth[c] && key + 1ull > a.best[c]) atomicMax(a.best + c, key + 1ull); }
+#pragma unroll
+		for (uint32_t i = 0; i < kPinChunk; i++) {
+			if (PASS == 0) { g0[i] = a.first_kept[cc[i]]; g1[i] = 0; }
+			else { g0[i] = a.best[cc[i]]; g1[i] = a.first_depth[cc[i]]; }
+		}
+#pragma unroll
+		for (uint32_t i = 0; i < kPinChunk; i++) {
+			const uint32_t z = z0 + i;
+			if (z >= v.sz) break;
+			const bool start = z == 0 || lab[i] != prev;
+			if (start) {
+				key = static_cast<unsigned long long>(col) * v.sz + z;
+				kept = mk[i] != 0u;
+				depth = mk[i] - 1u;
+			}
+			prev = lab[i];
+			// A component spans many columns of this row: of the lanes that want to update the same
+			// component only the one with the smallest (PASS 0) / largest (PASS 2) key goes to memory —
+			// keys grow with x, so that is the first / last such lane of the wavefront.
+			if (PASS == 0) {
+				const bool want_any = start && key < a.first_any[cc[i]];
+				if (pin_wave_leader<false>(want_any, cc[i])) atomicMin(a.first_any + cc[i], key);
+				const bool want = kept && key < g0[i];
+				if (pin_wave_leader<false>(want, cc[i])) atomicMin(a.first_kept + cc[i], key);
+			}
+			else {
+				const bool want = kept && depth > g1[i] && key + 1ull > g0[i];
+				if (pin_wave_leader<true>(want, cc[i])) atomicMax(a.best + cc[i], key + 1ull);
 			}
 		}
-		label = next;
-		z_s = z;
 	}
 }
 
