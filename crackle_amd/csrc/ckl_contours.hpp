@@ -261,6 +261,34 @@ __global__ void __launch_bounds__(256) k_contour_components(
 	comp[static_cast<uint64_t>(zi) * tab_cap + i] = r.run_cc[r.rbase[zi] + run];
 }
 
+// the kept contours of all slices of a chunk packed one after the other (slice order, discovery
+// order within a slice): one copy to the host instead of one per slice.  grid = (ceil(tab_cap / 256), nslices)
+__global__ void __launch_bounds__(256) k_contour_pack(
+	const uint4* __restrict__ table, const uint32_t* __restrict__ comp, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ base,
+	uint32_t tab_cap, uint4* __restrict__ out_table, uint32_t* __restrict__ out_comp
+) {
+	const uint32_t zi = blockIdx.y;
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= counts[4u * zi]) return;
+	out_table[base[zi] + i] = table[static_cast<uint64_t>(zi) * tab_cap + i];
+	out_comp[base[zi] + i] = comp[static_cast<uint64_t>(zi) * tab_cap + i];
+}
+
+// index of every component's label in the sorted label table (the labels as the label map holds them)
+__global__ void __launch_bounds__(256) k_component_label_index(
+	const uint64_t* __restrict__ label_map, uint64_t n, const uint64_t* __restrict__ table, uint32_t n_table, uint32_t* __restrict__ out
+) {
+	const uint64_t c = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+	if (c >= n) return;
+	const uint64_t v = label_map[c];
+	uint32_t lo = 0, hi = n_table;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (table[mid] < v) lo = mid + 1; else hi = mid;
+	}
+	out[c] = (lo < n_table && table[lo] == v) ? lo : 0xFFFFFFFFu;
+}
+
 struct ContourJob {
 	uint64_t src;       // first node of the contour in the raw array (all slices)
 	uint64_t dst;       // first point of the contour in the output

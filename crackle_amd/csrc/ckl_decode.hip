@@ -2708,27 +2708,34 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	}
 }
 
+// the stream's labels (the unique list of the label section, plus the background colour of a pin
+// stream), as the label map holds them (sign-extended), ascending as unsigned: host and device copy
+void ensure_label_table(ckl_decoder& d) {
+	if (!d.stats_table.empty()) return;
+	const Header& h = d.head;
+	hipStream_t s = d.stream;
+	const int sw = h.stored_data_width;
+	std::vector<uint8_t> raw(static_cast<size_t>(d.num_unique) * sw);
+	const uint64_t at = h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
+	if (!raw.empty()) CKL_HIP(hipMemcpyAsync(raw.data(), d.d_stream.p + at, raw.size(), hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipStreamSynchronize(s));
+	std::vector<uint64_t> t(d.num_unique);
+	for (uint64_t i = 0; i < d.num_unique; i++) t[i] = read_stored(h, raw.data(), i * sw);
+	if (h.label_format != FLAT) t.push_back(d.bgcolor);
+	std::sort(t.begin(), t.end());
+	t.erase(std::unique(t.begin(), t.end()), t.end());
+	d.stats_table.swap(t);
+	upload(d.d_stats_table, d.stats_table, s);
+	CKL_HIP(hipStreamSynchronize(s));
+}
+
 // voxel_counts / centroids / bounding_boxes of the decoded z-range (operations.hpp:321-618):
 // one pipeline run up to the run labels, then k_run_stats instead of the paint.
 void decoder_label_stats(ckl_decoder& d, uint64_t capacity, uint64_t* labels, uint64_t* counts, uint64_t* sums, uint32_t* boxes, uint64_t* n_out) {
 	const Header& h = d.head;
 	hipStream_t s = d.stream;
 	if (d.sxy == 0 || d.nslices == 0) { *n_out = 0; return; }
-	if (d.stats_table.empty()) {
-		const int sw = h.stored_data_width;
-		std::vector<uint8_t> raw(static_cast<size_t>(d.num_unique) * sw);
-		const uint64_t at = h.header_bytes() + h.grid_index_bytes() + d.uniq_offset;
-		if (!raw.empty()) CKL_HIP(hipMemcpyAsync(raw.data(), d.d_stream.p + at, raw.size(), hipMemcpyDeviceToHost, s));
-		CKL_HIP(hipStreamSynchronize(s));
-		std::vector<uint64_t> t(d.num_unique);
-		for (uint64_t i = 0; i < d.num_unique; i++) t[i] = read_stored(h, raw.data(), i * sw);
-		if (h.label_format != FLAT) t.push_back(d.bgcolor);
-		std::sort(t.begin(), t.end());
-		t.erase(std::unique(t.begin(), t.end()), t.end());
-		d.stats_table.swap(t);
-		upload(d.d_stats_table, d.stats_table, s);
-		CKL_HIP(hipStreamSynchronize(s));
-	}
+	ensure_label_table(d);
 	const uint64_t nt = d.stats_table.size();
 	*n_out = nt;
 	if (capacity < nt) throw Error(CKL_ERR_ARG, "crackle_amd: label statistics need room for " + std::to_string(nt) + " labels");
@@ -2832,12 +2839,21 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 	ra.parent = d.d_parent.p; ra.run_start = d.d_run_start.p; ra.run_cc = d.d_run_cc.p;
 	ra.nruns = d.d_nruns.p; ra.ncomp = d.d_ncomp.p; ra.slice_err = d.d_slice_err.p;
 
-	// component -> label, as point_cloud<LABEL> holds it: the unsigned type of the data width
-	std::vector<uint64_t> label_map(d.total_comp);
-	if (d.total_comp) CKL_HIP(hipMemcpyAsync(label_map.data(), d.d_label_map.p, d.total_comp * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-	CKL_HIP(hipStreamSynchronize(s));
+	// component -> label as an index into the stream's sorted label table (binary search on the
+	// device); point_cloud<LABEL> keys its map by the unsigned type of the data width, which keeps
+	// the table's order (sign-extended labels, ascending as unsigned)
+	ensure_label_table(d);
+	const uint32_t n_table = static_cast<uint32_t>(d.stats_table.size());
+	std::vector<uint32_t> comp_key(d.total_comp);
+	if (d.total_comp) {
+		DevBuf<uint32_t> d_comp_key;
+		d_comp_key.ensure(d.total_comp);
+		hipLaunchKernelGGL(k_component_label_index, dim3(static_cast<uint32_t>((d.total_comp + 255) / 256)), dim3(256), 0, s,
+			d.d_label_map.p, d.total_comp, d.d_stats_table.p, n_table, d_comp_key.p);
+		CKL_HIP(hipMemcpyAsync(comp_key.data(), d_comp_key.p, d.total_comp * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		CKL_HIP(hipStreamSynchronize(s));
+	}
 	const uint64_t lmask = h.data_width >= 8 ? ~0ull : ((1ull << (8 * h.data_width)) - 1);
-	for (uint64_t& v : label_map) v &= lmask;
 	std::vector<uint64_t> comp_off(ns + 1, 0);
 	for (uint32_t zi = 0; zi < ns; zi++) comp_off[zi + 1] = comp_off[zi] + d.ncomp_expect_host[zi];
 	std::vector<uint64_t> selected;
@@ -2938,19 +2954,28 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 				tab_cap = sxy + 1;
 				continue;
 			}
-			std::vector<uint4> table(static_cast<uint64_t>(tab_cap) * nz);
-			std::vector<uint32_t> comp(static_cast<uint64_t>(tab_cap) * nz);
-			for (uint32_t i = 0; i < nz; i++) {
-				const uint32_t nc = counts[4 * i];
-				if (!nc) continue;
-				CKL_HIP(hipMemcpyAsync(table.data() + static_cast<uint64_t>(i) * tab_cap, d_table.p + static_cast<uint64_t>(i) * tab_cap, nc * sizeof(uint4), hipMemcpyDeviceToHost, s));
-				CKL_HIP(hipMemcpyAsync(comp.data() + static_cast<uint64_t>(i) * tab_cap, d_comp.p + static_cast<uint64_t>(i) * tab_cap, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-			}
-			CKL_HIP(hipStreamSynchronize(s));
-			for (uint32_t i = 0; i < nz; i++) {
-				for (uint32_t k = 0; k < counts[4 * i]; k++) {
-					const uint4 t = table[static_cast<uint64_t>(i) * tab_cap + k];
-					kept.push_back({ z0 + i, t.x, t.y, t.z, t.w, comp[static_cast<uint64_t>(i) * tab_cap + k] });
+			// the kept contours of the chunk, packed on the device: one copy instead of one per slice
+			std::vector<uint32_t> base(nz + 1, 0);
+			for (uint32_t i = 0; i < nz; i++) base[i + 1] = base[i] + counts[4 * i];
+			const uint32_t n_chunk = base[nz];
+			if (n_chunk) {
+				DevBuf<uint32_t> d_base, d_pcomp;
+				DevBuf<uint4> d_ptable;
+				upload(d_base, base, s);
+				d_ptable.ensure(n_chunk); d_pcomp.ensure(n_chunk);
+				hipLaunchKernelGGL(k_contour_pack, dim3((tab_cap + 255) / 256, nz), dim3(256), 0, s, d_table.p, d_comp.p, d_counts.p, d_base.p, tab_cap, d_ptable.p, d_pcomp.p);
+				std::vector<uint4> table(n_chunk);
+				std::vector<uint32_t> comp(n_chunk);
+				CKL_HIP(hipMemcpyAsync(table.data(), d_ptable.p, n_chunk * sizeof(uint4), hipMemcpyDeviceToHost, s));
+				CKL_HIP(hipMemcpyAsync(comp.data(), d_pcomp.p, n_chunk * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+				CKL_HIP(hipStreamSynchronize(s));
+				const size_t at0 = kept.size();
+				kept.resize(at0 + n_chunk);
+				for (uint32_t i = 0; i < nz; i++) {
+					for (uint32_t k = base[i]; k < base[i + 1]; k++) {
+						const uint4 t = table[k];
+						kept[at0 + k] = { z0 + i, t.x, t.y, t.z, t.w, comp[k] };
+					}
 				}
 			}
 			chunks.push_back({ z0, nz, raw_cap, std::move(raw) });
@@ -2988,17 +3013,28 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 		}
 	}
 
-	// operations.hpp:229-257: components in (z, index) order append to their label's points
+	// operations.hpp:229-257: components in (z, index) order append to their label's points.  The
+	// labels of the output are the table's entries that own a component of the range and pass the
+	// filters, in table order
+	std::vector<uint8_t> present(n_table, 0);
+	for (uint64_t c = 0; c < d.total_comp; c++) {
+		if (comp_key[c] >= n_table) throw Error(CKL_ERR_RUNTIME, "crackle_amd: point_cloud: a component's label is not in the stream's label table");
+		present[comp_key[c]] = 1;
+	}
+	std::vector<int64_t> table_out(n_table, -1);
 	std::vector<uint64_t> keys;
-	for (uint64_t c = 0; c < d.total_comp; c++) if (takes(label_map[c])) keys.push_back(label_map[c]);
-	std::sort(keys.begin(), keys.end());
-	keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+	for (uint32_t i = 0; i < n_table; i++) {
+		const uint64_t label = d.stats_table[i] & lmask;
+		if (!present[i] || !takes(label)) continue;
+		table_out[i] = static_cast<int64_t>(keys.size());
+		keys.push_back(label);
+	}
 	std::vector<uint64_t> off(keys.size() + 1, 0);
 	std::vector<int64_t> key_of(d.total_comp, -1);
 	for (uint64_t c = 0; c < d.total_comp; c++) {
-		if (!takes(label_map[c])) continue;
-		const uint64_t k = static_cast<uint64_t>(std::lower_bound(keys.begin(), keys.end(), label_map[c]) - keys.begin());
-		key_of[c] = static_cast<int64_t>(k);
+		const int64_t k = table_out[comp_key[c]];
+		if (k < 0) continue;
+		key_of[c] = k;
 		for (uint64_t j = comp_at[c]; j < comp_at[c + 1]; j++) off[k + 1] += kept[order[j]].len;
 	}
 	for (size_t k = 0; k < keys.size(); k++) off[k + 1] += off[k];

@@ -131,10 +131,11 @@ def _point_cloud_raw(binary: bytes, z_start: int, z_end: int, label_list, skip_b
     k = int(n.value)
     if k == 0:
       return {}
-    labs = np.frombuffer(C.string_at(lab_p.value, 8 * k), dtype=np.uint64)
-    offs = np.frombuffer(C.string_at(off_p.value, 8 * (k + 1)), dtype=np.uint64)
-    pts = np.frombuffer(C.string_at(pts_p.value, 6 * int(offs[k])), dtype=np.uint16) if int(offs[k]) else np.zeros(0, np.uint16)
-    return {int(labs[i]): pts[3 * int(offs[i]):3 * int(offs[i + 1])].copy() for i in range(k)}
+    labs = np.ctypeslib.as_array(C.cast(lab_p, C.POINTER(C.c_uint64)), shape=(k,)).tolist()
+    offs = (3 * np.ctypeslib.as_array(C.cast(off_p, C.POINTER(C.c_uint64)), shape=(k + 1,))).tolist()
+    # one copy out of the library's buffer; the labels' arrays are views of it
+    pts = np.ctypeslib.as_array(C.cast(pts_p, C.POINTER(C.c_uint16)), shape=(offs[k],)).copy() if offs[k] else np.zeros(0, np.uint16)
+    return {labs[i]: pts[offs[i]:offs[i + 1]] for i in range(k)}
   finally:
     for p in (lab_p, off_p, pts_p):
       if p.value:

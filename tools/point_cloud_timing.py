@@ -6,7 +6,8 @@ import crackle_amd
 from crackle_amd import operations, synth
 
 shape = tuple(int(v) for v in (sys.argv[1:4] or (1024, 1024, 64)))
-arr = synth.as_numpy_f(synth.voronoi_labels(shape, np.uint32, seed=4, cell=(32, 32, 8)))
+import torch
+arr = synth.as_numpy_f(synth.voronoi_labels(shape, np.uint32, seed=4, cell=(32, 32, 8), device=torch.device("cuda", 0)))      # generated on the device: a host core needs minutes for the C2 volume
 binary = crackle_amd.compress(arr)
 os.environ["CKL_PROFILE"] = "1"
 for i in range(3):
