@@ -36,7 +36,9 @@ def main():
       # the consumers of the decode path must come back as well (an answer or an error)
       for fn in (lambda: crackle_amd.voxel_counts(bytes(b)), lambda: crackle_amd.bounding_boxes(bytes(b)),
                  lambda: crackle_amd.voxel_connectivity_graph(bytes(b), 6),
-                 lambda: crackle_amd.reencode(bytes(b), 1 if crackle_amd.header(bytes(b)).markov_model_order != 1 else 0)):
+                 lambda: crackle_amd.reencode(bytes(b), 1 if crackle_amd.header(bytes(b)).markov_model_order != 1 else 0),
+                 lambda: crackle_amd.point_cloud(bytes(b), skip_background=False),
+                 lambda: crackle_amd.array_equal(bytes(b), streams[t % len(streams)])):
         try:
           fn()
           ok2 += 1
@@ -44,7 +46,7 @@ def main():
           err2 += 1
     if t % 50 == 49:
       print(f"trial {t + 1}: decoded {ok}, rejected {err}", flush=True)
-  print(f"done: {trials} corrupted streams, decoded {ok}, rejected {err}, no faults" + (f"; statistics / vcg / reencode calls: {ok2} answered, {err2} rejected" if wide else ""))
+  print(f"done: {trials} corrupted streams, decoded {ok}, rejected {err}, no faults" + (f"; statistics / vcg / reencode / point_cloud / array_equal calls: {ok2} answered, {err2} rejected" if wide else ""))
 
 
 if __name__ == "__main__":
