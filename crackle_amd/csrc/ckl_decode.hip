@@ -404,12 +404,18 @@ struct TileCarry {
 // to the next tile.  The last barrier inside is behind every use of the LDS scratch.
 template <bool COUNT_T>
 __device__ __forceinline__ void tile_symbols(
-	const uint32_t* __restrict__ words, uint32_t wshift, uint32_t n_codes, uint32_t tile, TileCarry& c,
+	const uint32_t* __restrict__ words, uint32_t wshift, uint32_t n_codes, uint32_t span, uint32_t tile, TileCarry& c,
 	WordSyms (&ws)[kCrackWords], uint32_t& o_a, uint32_t& o_dx, uint32_t& o_dy,
 	uint32_t* s_scan, int32_t* s_scanmax, uint8_t* s_last_move, uint8_t* s_last_ctrl
 ) {
 	const uint32_t tid = threadIdx.x;
-	const uint32_t g0 = tile + tid * (kCrackWords * 16u);
+	// `span` positions per thread (a multiple of 16, at most kCrackWords * 16): a slice with fewer codes
+	// than a full tile spreads them over all threads instead of filling the first ones with eight
+	// words each; a thread's words past its span are empty
+	const uint32_t g0 = tile + tid * span;
+	const int64_t lim = min(static_cast<int64_t>(n_codes), static_cast<int64_t>(g0) + span);            // codes of this thread end here
+	const int64_t lim_ev = min(static_cast<int64_t>(n_codes) + 1, static_cast<int64_t>(g0) + span);      // positions
+	const uint32_t last_word = span / 16u - 1u;
 	// -- load, running sums mod 4
 	uint32_t mv[kCrackWords];
 	uint32_t tsum = 0;
@@ -420,13 +426,13 @@ __device__ __forceinline__ void tile_symbols(
 		for (uint32_t j = 0; j <= kCrackWords; j++) {
 			// word j is needed when any of its codes exists; the shifted read also takes the low bytes of word j+1
 			// (issuing all nine loads unconditionally, with clamped indices, was measured slower: 0.322 against 0.313 ms)
-			const bool need = (g0 + 16u * j < n_codes) || (j > 0 && wshift && g0 + 16u * (j - 1u) < n_codes);
+			const bool need = (static_cast<int64_t>(g0) + 16u * j < lim) || (j > 0 && wshift && static_cast<int64_t>(g0) + 16u * (j - 1u) < lim);
 			q[j] = need ? words[w0 + j] : 0u;
 		}
 #pragma unroll
 		for (uint32_t j = 0; j < kCrackWords; j++) {
 			uint32_t cw = wshift ? __funnelshift_r(q[j], q[j + 1], wshift) : q[j];
-			const uint32_t fm = fields_below(static_cast<int64_t>(n_codes) - static_cast<int64_t>(g0 + 16u * j));
+			const uint32_t fm = fields_below(lim - static_cast<int64_t>(g0 + 16u * j));
 			cw &= fm | (fm << 1);
 			cw = prefix_fields(cw);
 			mv[j] = add_fields(cw, tsum * kLo);
@@ -451,10 +457,11 @@ __device__ __forceinline__ void tile_symbols(
 		const uint32_t gw = g0 + 16u * j;
 		const uint32_t prevs = (mv[j] << 2) | (j ? (mv[j - 1] >> 30) : prev_move);
 		const uint32_t x = mv[j] ^ prevs;
-		uint32_t rv = fields_below(static_cast<int64_t>(n_codes) - static_cast<int64_t>(gw));
+		const uint32_t in_span = fields_below(lim - static_cast<int64_t>(gw));
+		uint32_t rv = in_span;
 		if (gw == 0) rv &= ~1u;
 		r[j] = (x >> 1) & ~x & rv;
-		const uint32_t nr = ~r[j] & kLo;
+		const uint32_t nr = ~r[j] & in_span;
 		if (nr) lf = static_cast<int32_t>(gw + ((31u - __clz(nr)) >> 1));
 	}
 	int32_t lf_tot;
@@ -471,10 +478,15 @@ __device__ __forceinline__ void tile_symbols(
 		const uint32_t r2 = rj | (rj << 1);
 		const uint32_t inA = rj & ~(r2 + es);             // fields of the runs counted from an even field
 		ctrl[j] = (inA & kEvenF) | (rj & ~inA & kOddF);
-		const uint32_t nr = ~rj & kLo;
+		const uint32_t nr = ~rj & fields_below(lim - static_cast<int64_t>(gw));
 		if (nr) lf_in = static_cast<int32_t>(gw + ((31u - __clz(nr)) >> 1));
 	}
-	s_last_ctrl[tid] = static_cast<uint8_t>((ctrl[kCrackWords - 1] >> 30) & 1u);
+	{
+		uint32_t lc = ctrl[kCrackWords - 1];
+#pragma unroll
+		for (uint32_t j = 0; j + 1 < kCrackWords; j++) if (j == last_word) lc = ctrl[j];
+		s_last_ctrl[tid] = static_cast<uint8_t>((lc >> 30) & 1u);
+	}
 	__syncthreads();
 	const uint32_t prev_ctrl = tid ? s_last_ctrl[tid - 1] : c.ctrl;
 	const uint32_t tile_last_ctrl = s_last_ctrl[kCrackBlock - 1];
@@ -487,7 +499,7 @@ __device__ __forceinline__ void tile_symbols(
 		WordSyms& w = ws[j];
 		w.prevs = (mv[j] << 2) | (j ? (mv[j - 1] >> 30) : prev_move);
 		const uint32_t pc = ((ctrl[j] << 2) | (j ? ((ctrl[j - 1] >> 30) & 1u) : prev_ctrl)) & kLo;
-		uint32_t ev = fields_below(static_cast<int64_t>(n_codes) + 1 - static_cast<int64_t>(gw));
+		uint32_t ev = fields_below(lim_ev - static_cast<int64_t>(gw));
 		if (gw == 0) ev &= ~1u;
 		const uint32_t emit = ev & ~pc;
 		w.ctl = emit & ctrl[j];
@@ -982,6 +994,8 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	if (a.markov_order) __threadfence_block();
 	stamp(0);
 	const uint32_t n_codes = s_ncodes;
+	// positions per thread: a slice that fits one tile spreads its codes over all threads
+	const uint32_t span = n_codes < kCrackTile ? max(1u, (n_codes + 16u * kCrackBlock) / (16u * kCrackBlock)) * 16u : kCrackWords * 16u;
 	const uint32_t n_nodes = s_nnodes;
 	const uint32_t index_end = 4u + (code_len >= 4u ? rd_le_dev(code, 4) : 0u);
 	// packed difference codes as aligned words + a byte shift (only dereferenced when n_codes > 0)
@@ -1034,7 +1048,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile) {
 			WordSyms ws[kCrackWords];
 			uint32_t o_a, o_dx, o_dy;
-			tile_symbols<false>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+			tile_symbols<false>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
 			if (DIAG && tid == 0 && diag) { const unsigned long long now = __builtin_amdgcn_s_memtime(); diag[static_cast<uint64_t>(blockIdx.x) * 16 + 3] += now - d_t; }      // B up to here: the symbols
 			// ---- record the control symbols with the displacement before them
 #pragma unroll
@@ -1120,7 +1134,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 				TileCarry c;
 				uint32_t ti = 0;
 				for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile, ti++) {
-					tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+					tile_symbols<true>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
 					uint32_t* sb = sym + static_cast<uint64_t>(ti) * kSymWords * kCrackBlock + tid;
 	#pragma unroll
 					for (uint32_t j = 0; j < kCrackWords; j++) {
@@ -1141,7 +1155,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 					if (have_cracks && single_tile) {
 						TileCarry c;
 						if (!have_syms) {
-							tile_symbols<true>(words, wshift, n_codes, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+							tile_symbols<true>(words, wshift, n_codes, span, 0u, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
 							have_syms = true;
 							stamp_add(6);
 						}
@@ -1177,7 +1191,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			for (uint32_t tile = 0; tile <= n_codes; tile += kCrackTile) {
 				WordSyms ws[kCrackWords];
 				uint32_t o_a, o_dx, o_dy;
-				tile_symbols<true>(words, wshift, n_codes, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+				tile_symbols<true>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
 				raster_moves_hbm(ws, o_a, o_dx, o_dy, valid_segs, seg_x, seg_y, sx, sy, row_words, pv, ph, rerr);
 				__syncthreads();
 			}
