@@ -347,12 +347,14 @@ __device__ __forceinline__ void match_controls(
 	sub(10);
 	for (uint32_t i = i0; i < i1; i++) {
 		if (t.kind[i] != SYM_T || i >= n_eff) continue;
-		volatile unsigned long long* lk = t.link;
-		unsigned long long me = lk[i];
+		// relaxed atomics, not volatile: hipcc keeps volatile accesses on flat pointers (a flat
+		// instruction and a wait for all memory traffic per access)
+		unsigned long long* lk = t.link;
+		unsigned long long me = __hip_atomic_load(lk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		for (uint32_t guard = 0; (me >> 32) != kLinkNone && guard <= N; guard++) {
-			const unsigned long long other = lk[static_cast<uint32_t>(me >> 32)];
+			const unsigned long long other = __hip_atomic_load(lk + static_cast<uint32_t>(me >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			me = (other & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(static_cast<uint32_t>(me) + static_cast<uint32_t>(other));
-			lk[i] = me;
+			__hip_atomic_store(lk + i, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
 	__syncthreads();

@@ -1564,6 +1564,7 @@ PinCandidates pin_candidates_device(
 	}
 	// the labels with the key of their first column run
 	{
+		if (N > (1ull << 30)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components for pin labels");
 		uint32_t slots = 1024;
 		while (slots < 2 * N) slots <<= 1;
 		DevBuf<uint64_t> d_tab;
