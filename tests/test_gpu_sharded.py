@@ -136,3 +136,73 @@ def test_sharded_hip_backend_equals_whole_volume(checker, sharded_results, index
   assert sharded_results[(0, index)][0] == whole, "merged slab streams differ from the whole-volume stream"
   assert sharded_results[(1, index)][0] is None
   assert sharded_results[(0, index)][1] and sharded_results[(1, index)][1], "a rank decoded its z-range wrongly"
+
+
+# ---- BASELINE.json configs[3] and configs[4] at FULL size, two ranks on the one GPU -----------------
+FULL = [
+  ("c3_1024x1024x1024_u64", (1024, 1024, 1024), np.uint64, 0, False),
+  ("c4_2048x2048x256_u32_pins_m5", (2048, 2048, 256), np.uint32, 5, True),
+]
+
+
+def _full_worker(rank, port, q):
+  import hashlib
+  import torch
+  from crackle_amd import distributed as ckd
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+  try:
+    dev = torch.device("cuda", 0)
+    for index, (name, (sx, sy, sz), dt, order, pins) in enumerate(FULL):
+      szl = sz // WORLD
+      off = (1 << 40) if np.dtype(dt).itemsize == 8 else 0
+      slab = synth.voronoi_labels((sx, sy, sz), dt, seed=2, device=dev, offset=off, z_range=(rank * szl, (rank + 1) * szl))
+      codec = ckd.ShardedCodec(ckd.HipBackend(0, zero_copy=True), rank=rank, world=WORLD, device="cpu", compute_device=dev)
+      binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order, allow_pins=pins)
+      digest = None if binary is None else (len(binary), hashlib.sha256(binary.view() if hasattr(binary, "view") else bytes(binary)).hexdigest())
+      session = codec.open_decoder(binary, (sx, sy, szl))
+      back = torch.empty_like(slab)
+      session.run(back)
+      torch.cuda.synchronize()
+      q.put((rank, index, digest, bool(torch.equal(back, slab))))
+      session.close()
+      del session, codec, slab, back, binary
+      torch.cuda.empty_cache()
+  finally:
+    dist.destroy_process_group()
+
+
+def test_sharded_full_size_configs_equal_the_single_process_stream():
+  """1024 x 1024 x 1024 uint64 and 2048 x 2048 x 256 uint32 with pins + markov order 5, each as two
+  z-slabs on two ranks: the merged stream must be, byte for byte, the stream one process writes for
+  the whole volume (whose slabs are pinned to the reference's sha256 in tests/test_gpu_strips.py),
+  and every rank must decode its half."""
+  import hashlib
+  import torch
+  from crackle_amd import distributed as ckd
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_full_worker, args=(r, port, q)) for r in range(WORLD)]
+  for p in procs:
+    p.start()
+  results = {}
+  for _ in range(WORLD * len(FULL)):
+    rank, index, digest, ok = q.get(timeout=900)
+    results[(rank, index)] = (digest, ok)
+  for p in procs:
+    p.join(timeout=120)
+    assert p.exitcode == 0
+  dev = torch.device("cuda", 0)
+  be = ckd.HipBackend(0, zero_copy=True)
+  for index, (name, (sx, sy, sz), dt, order, pins) in enumerate(FULL):
+    off = (1 << 40) if np.dtype(dt).itemsize == 8 else 0
+    vol = synth.voronoi_labels((sx, sy, sz), dt, seed=2, device=dev, offset=off)
+    whole = be.encode(vol, (sx, sy, sz), pins, True, order, None)
+    want = (len(whole), hashlib.sha256(whole.view() if hasattr(whole, "view") else bytes(whole)).hexdigest())
+    del vol, whole
+    torch.cuda.empty_cache()
+    assert results[(0, index)][0] == want, name
+    assert results[(1, index)][0] is None
+    assert results[(0, index)][1] and results[(1, index)][1], name
