@@ -56,14 +56,21 @@ def manifest_entry(arr, b):
 
 def main_xl(ref):
   """Full-size BASELINE.json configurations (minutes of CPU time, gigabytes of memory)."""
+  path = os.path.join(HERE, "golden", "manifest_xl.json")
+  only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]      # --only=NAME: (re)generate one entry, keep the others
   manifest = {}
+  if only and os.path.exists(path):
+    with open(path) as f:
+      manifest = json.load(f)
   for name, (thunk, kw) in golden_cases.xl_cases().items():
+    if only and name not in only:
+      continue
     arr = thunk()
     b = ref.compress(arr, parallel=8, **kw)
     manifest[name] = manifest_entry(arr, b)
     print(name, len(b), manifest[name]["sha256"], flush=True)
     del arr, b
-  with open(os.path.join(HERE, "golden", "manifest_xl.json"), "w") as f:
+  with open(path, "w") as f:
     json.dump(manifest, f, indent=1, sort_keys=True)
 
 

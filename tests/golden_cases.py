@@ -183,6 +183,8 @@ def xl_cases():
     "c2_1024x1024x512_u32": (vor((1024, 1024, 512), np.uint32, 2), dict()),
     # C3: one 16-slice slab of the uint64 volume (stored width 8)
     "c3_1024x1024x16_u64": (vor((1024, 1024, 16), np.uint64, 2, offset=1 << 40), dict()),
+    # C3 whole: 1024^3 uint64 (8.6 GB of labels; a quarter of an hour on the build container's cores)
+    "c3_1024x1024x1024_u64": (vor((1024, 1024, 1024), np.uint64, 2, offset=1 << 40), dict()),
     # C4: 2048-wide slices, pins + markov order 5
     "c4_2048x2048x8_u32_pins_m5": (vor((2048, 2048, 8), np.uint32, 2), dict(allow_pins=True, markov_model_order=5)),
     "c4_2048x2048x8_u32_m5": (vor((2048, 2048, 8), np.uint32, 2), dict(markov_model_order=5)),

@@ -196,6 +196,9 @@ def test_sharded_full_size_configs_equal_the_single_process_stream():
     assert p.exitcode == 0
   dev = torch.device("cuda", 0)
   be = ckd.HipBackend(0, zero_copy=True)
+  import json
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest_xl.json")) as f:
+    xl = json.load(f)
   for index, (name, (sx, sy, sz), dt, order, pins) in enumerate(FULL):
     off = (1 << 40) if np.dtype(dt).itemsize == 8 else 0
     vol = synth.voronoi_labels((sx, sy, sz), dt, seed=2, device=dev, offset=off)
@@ -204,5 +207,7 @@ def test_sharded_full_size_configs_equal_the_single_process_stream():
     del vol, whole
     torch.cuda.empty_cache()
     assert results[(0, index)][0] == want, name
+    if name in xl:      # the reference's own sha256 for the whole volume (tests/gen_golden.py --xl)
+      assert want == (xl[name]["length"], xl[name]["sha256"]), name
     assert results[(1, index)][0] is None
     assert results[(0, index)][1] and results[(1, index)][1], name

@@ -136,3 +136,24 @@ def test_c2_full_size_bytes_against_the_reference():
   torch.cuda.synchronize()
   assert torch.equal(out.view(torch.int32), vol.view(torch.int32))
   s.close()
+
+
+def test_c3_full_size_bytes_against_the_reference():
+  """BASELINE.json configs[3] whole (1024 x 1024 x 1024 uint64, labels from 2^40 up), device
+  resident: the encoder's stream has the sha256 of the reference encoder's output (written into
+  manifest_xl.json by `tests/gen_golden.py --xl --only=c3_1024x1024x1024_u64`); decoded back."""
+  import torch
+  from crackle_amd import distributed as ckd
+  want = _manifest_xl().get("c3_1024x1024x1024_u64")
+  assert want is not None, "manifest_xl.json has no entry for the whole C3 volume"
+  dev = torch.device("cuda:0")
+  vol = synth.voronoi_labels((1024, 1024, 1024), np.uint64, seed=2, device=dev, offset=1 << 40)
+  be = ckd.HipBackend(0, zero_copy=True)
+  b = be.encode(vol, (1024, 1024, 1024), False, True, 0, None)
+  assert len(b) == want["length"] and sha(b.view()) == want["sha256"]
+  s = be.open_decoder(b, 0, 1024)
+  out = torch.empty_like(vol)
+  s.run(out)
+  torch.cuda.synchronize()
+  assert torch.equal(out, vol)
+  s.close()
