@@ -188,6 +188,8 @@ def xl_cases():
     # C4: 2048-wide slices, pins + markov order 5
     "c4_2048x2048x8_u32_pins_m5": (vor((2048, 2048, 8), np.uint32, 2), dict(allow_pins=True, markov_model_order=5)),
     "c4_2048x2048x8_u32_m5": (vor((2048, 2048, 8), np.uint32, 2), dict(markov_model_order=5)),
+    # C4 whole: 2048 x 2048 x 256 uint32, pins + markov order 5 (the reference's pin solver over 1.07 G voxels)
+    "c4_2048x2048x256_u32_pins_m5": (vor((2048, 2048, 256), np.uint32, 2), dict(allow_pins=True, markov_model_order=5)),
   }
   for v in cases.values():
     v[1].setdefault("allow_pins", False)
