@@ -179,6 +179,8 @@ def xl_cases():
   def vor(shape, dt, seed, **kw):
     return lambda: synth.as_numpy_f(synth.voronoi_labels(shape, dt, seed=seed, cell=(32, 32, 8), **kw))
   cases = {
+    # C1: 512 x 512 x 128 uint32
+    "c1_512x512x128_u32": (vor((512, 512, 128), np.uint32, 2), dict()),
     # C2: the bench workload itself (bench.py asserts this sha on its own output)
     "c2_1024x1024x512_u32": (vor((1024, 1024, 512), np.uint32, 2), dict()),
     # C3: one 16-slice slab of the uint64 volume (stored width 8)

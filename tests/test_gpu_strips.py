@@ -157,3 +157,16 @@ def test_c3_full_size_bytes_against_the_reference():
   torch.cuda.synchronize()
   assert torch.equal(out, vol)
   s.close()
+
+
+def test_c1_full_size_bytes_against_the_reference():
+  """BASELINE.json configs[1] (512 x 512 x 128 uint32), device resident, against the reference's sha256."""
+  import torch
+  from crackle_amd import distributed as ckd
+  want = _manifest_xl()["c1_512x512x128_u32"]
+  dev = torch.device("cuda:0")
+  vol = synth.voronoi_labels((512, 512, 128), np.uint32, seed=2, device=dev)
+  be = ckd.HipBackend(0)
+  b = be.encode(vol, (512, 512, 128), False, True, 0, None)
+  assert len(b) == want["length"] and sha(b) == want["sha256"]
+  assert np.array_equal(crackle_amd.decompress(b), synth.as_numpy_f(vol))
