@@ -102,6 +102,13 @@ def main_ops(ref):
   with open(os.path.join(HERE, "golden", "point_cloud.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
   print("point_cloud:", len(out), "streams")
+  # the same for BASELINE.json configs[1] at full size (512 x 512 x 128 uint32)
+  thunk, kw = golden_cases.xl_cases()["c1_512x512x128_u32"]
+  stream = ref.compress(thunk(), parallel=8, **kw)
+  big = {tag: point_cloud_digest(ref.point_cloud(stream, z0, z1 if tag != "z1" else 65, labels, skip)) for tag, (z0, z1, labels, skip) in POINT_CLOUD_ARGS.items()}
+  with open(os.path.join(HERE, "golden", "point_cloud_xl.json"), "w") as f:
+    json.dump({"c1_512x512x128_u32": big}, f, indent=1, sort_keys=True)
+  print("point_cloud xl:", big)
 
 
 def main():

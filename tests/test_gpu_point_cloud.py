@@ -166,3 +166,21 @@ def test_point_cloud_golden_streams_against_the_reference_fixture():
       except RuntimeError as exc:
         got = "error: " + str(exc)
       assert got == want[name][tag], (name, tag)
+
+
+def test_point_cloud_c1_full_size_against_the_reference_fixture():
+  """BASELINE.json configs[1] (512 x 512 x 128 uint32) whole: the device's point cloud against the
+  digests of the compiled reference's own output (tests/golden/point_cloud_xl.json, written by
+  tests/gen_golden.py --ops): whole range, background skipped, slices [1, 65)."""
+  import json
+  import os
+  import torch
+  from crackle_amd import distributed as ckd
+  from gen_golden import POINT_CLOUD_ARGS, point_cloud_digest
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "point_cloud_xl.json")) as f:
+    want = json.load(f)["c1_512x512x128_u32"]
+  vol = synth.voronoi_labels((512, 512, 128), np.uint32, seed=2, device=torch.device("cuda:0"))
+  binary = bytes(ckd.HipBackend(0).encode(vol, (512, 512, 128), False, True, 0, None))
+  for tag, (z0, z1, labels, skip) in POINT_CLOUD_ARGS.items():
+    got = point_cloud_digest(operations._point_cloud_raw(binary, z0, 65 if tag == "z1" else z1, labels, skip, 0))
+    assert got == want[tag], tag
