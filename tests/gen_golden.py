@@ -109,6 +109,17 @@ def main_ops(ref):
   with open(os.path.join(HERE, "golden", "point_cloud_xl.json"), "w") as f:
     json.dump({"c1_512x512x128_u32": big}, f, indent=1, sort_keys=True)
   print("point_cloud xl:", big)
+  # the other consumers on the same stream: reencode, mode pooling, voxel connectivity graph
+  ops = {
+    "reencode_m3": hashlib.sha256(ref.reencode(stream, 3)).hexdigest(),
+    "reencode_m0_of_m3": hashlib.sha256(ref.reencode(ref.reencode(stream, 3), 0)).hexdigest(),
+    "mode_pooling_2x2x1": hashlib.sha256(b"".join(ref.mode_pooling_2x2x1(stream))).hexdigest(),
+    "vcg4": hashlib.sha256(np.ascontiguousarray(ref.voxel_connectivity_graph(stream, 4)).tobytes()).hexdigest(),
+    "vcg6": hashlib.sha256(np.ascontiguousarray(ref.voxel_connectivity_graph(stream, 6)).tobytes()).hexdigest(),
+  }
+  with open(os.path.join(HERE, "golden", "ops_xl.json"), "w") as f:
+    json.dump({"c1_512x512x128_u32": ops}, f, indent=1, sort_keys=True)
+  print("ops xl:", ops)
 
 
 def main():

@@ -521,3 +521,26 @@ def test_label_table_hash_pass_and_full_sort(checker, monkeypatch):
     monkeypatch.setenv("CKL_LABEL_SORT_ALL", "1")
     assert crackle_amd.compress(arr) == want
     monkeypatch.delenv("CKL_LABEL_SORT_ALL")
+
+
+def test_consumers_on_the_whole_c1_volume_against_the_reference_fixture():
+  """reencode, mode pooling and the voxel connectivity graph of BASELINE.json configs[1] (512 x 512 x
+  128 uint32) against digests of the compiled reference's own output (tests/golden/ops_xl.json,
+  written by tests/gen_golden.py --ops)."""
+  import hashlib
+  import json
+  import os
+  import torch
+  from crackle_amd import distributed as ckd
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ops_xl.json")) as f:
+    want = json.load(f)["c1_512x512x128_u32"]
+  vol = synth.voronoi_labels((512, 512, 128), np.uint32, seed=2, device=torch.device("cuda:0"))
+  binary = bytes(ckd.HipBackend(0).encode(vol, (512, 512, 128), False, True, 0, None))
+  h = lambda b: hashlib.sha256(b).hexdigest()
+  m3 = crackle_amd.reencode(binary, 3)
+  assert h(m3) == want["reencode_m3"]
+  assert h(crackle_amd.reencode(m3, 0)) == want["reencode_m0_of_m3"] == h(binary)
+  from crackle_amd import operations
+  assert h(b"".join(operations._mode_pooling_slices(binary))) == want["mode_pooling_2x2x1"]
+  for conn in (4, 6):
+    assert h(np.ascontiguousarray(crackle_amd.voxel_connectivity_graph(binary, conn)).tobytes()) == want[f"vcg{conn}"], conn
