@@ -277,8 +277,10 @@ def bounding_boxes(binary: bytes, label: Optional[int] = None, parallel: int = 0
   elif num_labels(binary) == 1:
     bbxes = {int(labels(binary)[0]): np.array([0, 0, 0, head.sx, head.sy, head.sz], dtype=np.uint32)}
   else:
-    lab, _, _, box = _label_stats(binary, device, True)
-    bbxes = {int(l): b.copy() for l, b in zip(lab, box)}
+    lab, cnt, _, box = _label_stats(binary, device, True)
+    # every label of the unique list has an entry (absent ones keep the initial box); a label outside
+    # that list that is absent from the range comes back as a zero box with count 0 and has none
+    bbxes = {int(l): b.copy() for l, c, b in zip(lab, cnt, box) if c or b[0]}
   if no_slice_conversion:
     return bbxes[label] if label is not None else bbxes
   if label is not None:

@@ -1937,6 +1937,7 @@ struct ckl_decoder {
 	DevBuf<unsigned long long> d_stats_acc;
 	DevBuf<uint32_t> d_stats_box;
 	std::vector<uint64_t> stats_table;
+	bool bg_unlisted = false;           // pin stream whose background colour is not in its unique list
 	std::shared_ptr<DevBuf<uint32_t>> G;      // geometric-sum table of the slice size, shared by the sessions of a device (geom_table)
 	DevBuf<uint32_t> d_crc_acc, d_crc_expect, d_slice_err;
 	DevBuf<uint64_t> d_label_map;
@@ -2737,6 +2738,7 @@ void ensure_label_table(ckl_decoder& d) {
 	CKL_HIP(hipStreamSynchronize(s));
 	std::vector<uint64_t> t(d.num_unique);
 	for (uint64_t i = 0; i < d.num_unique; i++) t[i] = read_stored(h, raw.data(), i * sw);
+	d.bg_unlisted = h.label_format != FLAT && std::find(t.begin(), t.end(), d.bgcolor) == t.end();
 	if (h.label_format != FLAT) t.push_back(d.bgcolor);
 	std::sort(t.begin(), t.end());
 	t.erase(std::unique(t.begin(), t.end()), t.end());
@@ -2781,6 +2783,17 @@ void decoder_label_stats(ckl_decoder& d, uint64_t capacity, uint64_t* labels, ui
 		if (labels) labels[i] = d.stats_table[i];
 		if (counts) counts[i] = acc[4 * i];
 		if (sums) { sums[3 * i] = acc[4 * i + 1]; sums[3 * i + 1] = acc[4 * i + 2]; sums[3 * i + 2] = acc[4 * i + 3]; }
+	}
+	// The reference seeds its box map from the unique list only (operations.hpp:561-567); a label outside
+	// that list — the background colour of a pin stream — is default-constructed by bbxes[label] when
+	// its first component is merged (:596), so its minima start at 0; absent, it has no entry at all
+	// (reported here as a zero box with count 0).
+	if (boxes && d.bg_unlisted) {
+		const uint64_t i = static_cast<uint64_t>(std::lower_bound(d.stats_table.begin(), d.stats_table.end(), d.bgcolor) - d.stats_table.begin());
+		if (i < nt && d.stats_table[i] == d.bgcolor) {
+			boxes[6 * i] = boxes[6 * i + 1] = boxes[6 * i + 2] = 0;
+			if (acc[4 * i] == 0) boxes[6 * i + 3] = boxes[6 * i + 4] = boxes[6 * i + 5] = 0;
+		}
 	}
 }
 

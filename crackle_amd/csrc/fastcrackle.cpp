@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <cstdlib>
 #include <optional>
 #include <stdexcept>
@@ -169,7 +170,9 @@ py::dict bounding_boxes(const py::buffer& buffer, int64_t z_start, int64_t z_end
 	const LabelStats st = label_stats(buffer, z_start, z_end);
 	py::dict out;
 	for (size_t i = 0; i < st.labels.size(); i++) {
-		if (!st.counts[i]) continue;
+		// the reference's map has every label of the unique list (absent ones with their initial box,
+		// operations.hpp:561-567); a label outside that list that is absent is reported as a zero box
+		if (!st.counts[i] && !st.boxes[6 * i]) continue;
 		py::array_t<uint32_t> box(6);
 		auto v = box.mutable_unchecked<1>();
 		for (int k = 0; k < 6; k++) v(k) = st.boxes[6 * i + k];

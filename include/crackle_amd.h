@@ -166,7 +166,11 @@ int ckl_mode_pooling_2x2x1(
  * table (flat: the unique list; pins: the unique list and the background color), the voxel
  * count, the sums of the x, y and z coordinates (centroid = sums / count) and the inclusive
  * box [xmin ymin zmin xmax ymax zmax] (z in whole-volume coordinates; a label absent from the
- * range keeps the reference's initial box: mins 0xFFFFFFFF, maxes 0).
+ * range keeps the reference's initial box: mins 0xFFFFFFFF, maxes 0).  The reference seeds its
+ * box map from the unique list only (:561-567): the background color of a pin stream, when it is
+ * not in that list, is default-constructed on first use, so its three minima are 0; when it is
+ * also absent from the range it has no entry in the reference's map and is reported here with
+ * count 0 and an all-zero box (callers drop rows with count == 0 and boxes[0] == 0).
  * Host outputs, any of which may be NULL: labels[capacity] (values as the decoder paints
  * them, sign-extended to 64 bits, ascending as unsigned), counts[capacity],
  * sums[3*capacity], boxes[6*capacity].  *n_labels receives the table size; CKL_ERR_ARG

@@ -1552,6 +1552,126 @@ int ckl_oracle_array_equal(const unsigned char* buf1, uint64_t n1, const unsigne
 	return rc;
 }
 
+/* operations::voxel_counts / centroids / bounding_boxes (src/operations.hpp:321-665), the per-pixel
+ * loops of the reference over (component image, component -> label table) of every slice of the range.
+ * The maps come back as arrays sorted by label (keys = labels as the unsigned type of the data width):
+ * which 0: counts, 1 x uint64 per label; 1: centroids, 3 x double (integer sums, one division each);
+ * 2: boxes, 6 x uint32 — every label of the stream's unique list has an entry, those absent from the
+ * range keep the initial {max, max, max, 0, 0, 0} (:561-567). */
+typedef struct { uint64_t label; uint64_t n, sx_, sy_; uint32_t x0, y0, x1, y1; uint32_t z; int seen; } lstat_t;
+static int lstat_cmp(const void* a, const void* b) {
+	const lstat_t* p = (const lstat_t*)a; const lstat_t* q = (const lstat_t*)b;
+	return p->label < q->label ? -1 : (p->label > q->label ? 1 : 0);
+}
+int ckl_oracle_label_stats(
+	const unsigned char* buf, uint64_t n, int which, int64_t z_start, int64_t z_end, uint64_t parallel,
+	uint64_t** labels_out, void** values_out, uint64_t* n_out
+) {
+	header_t h;
+	*labels_out = NULL; *values_out = NULL; *n_out = 0;
+	if (n < HEADER_BYTES_V0) FAIL("crackle: Input too small to be a valid stream.");
+	if (header_read(&h, buf, n)) return 1;
+	int64_t zs, szr;
+	if (get_szr(&h, z_start, z_end, &zs, &szr)) return 1;
+	const uint64_t sxy = (uint64_t)h.sx * h.sy;
+	if (sxy * (uint64_t)szr == 0) {      /* :333-335: an empty map */
+		*labels_out = (uint64_t*)xmalloc(8); *values_out = xmalloc(8);
+		return 0;
+	}
+	const uint64_t lmask = h.data_width >= 8 ? ~0ull : ((1ull << (8 * h.data_width)) - 1ull);
+	dec_ctx_t d;
+	memset(&d, 0, sizeof d);
+	d.cap_cc = (uint32_t*)xmalloc(sxy * (uint64_t)szr * 4);
+	d.cap_N = (uint64_t*)xcalloc((size_t)szr, sizeof(uint64_t));
+	d.cap_lmap = (uint64_t**)xcalloc((size_t)szr, sizeof(uint64_t*));
+	int rc = dec_run(&d, buf, n, NULL, z_start < 0 ? 0 : z_start, z_end, parallel, 0, 0);
+	lstat_t* rows = NULL;
+	uint64_t nrows = 0;
+	if (!rc) {
+		uint64_t total = 0;
+		for (int64_t zi = 0; zi < szr; zi++) total += d.cap_N[zi];
+		/* boxes: one row per label of the unique list first (labels::unique, src/labels.hpp:393-422) */
+		uint64_t n_uniq = 0, uniq_off = 0;
+		const unsigned char* lb = buf + header_bytes(&h) + grid_index_bytes(&h);
+		if (which == 2) {
+			const uint64_t sw = (uint64_t)h.stored_data_width;
+			if (h.label_format == FLAT) { n_uniq = rd(lb, 0, 8); uniq_off = 8; }
+			else { n_uniq = rd(lb, sw, 8); uniq_off = sw + 8; }
+		}
+		rows = (lstat_t*)xcalloc((size_t)(total + n_uniq + 1), sizeof(lstat_t));
+		for (uint64_t u = 0; u < n_uniq; u++) {
+			lstat_t* r = &rows[nrows++];
+			r->label = rd(lb, uniq_off + u * (uint64_t)h.stored_data_width, h.stored_data_width);
+			r->x0 = r->y0 = 0xFFFFFFFFu; r->seen = 0;
+		}
+		for (int64_t zi = 0; zi < szr; zi++) {
+			const uint64_t N = d.cap_N[zi];
+			lstat_t* sub = (lstat_t*)xcalloc((size_t)N + 1, sizeof(lstat_t));
+			for (uint64_t c = 0; c < N; c++) { sub[c].x0 = sub[c].y0 = 0xFFFFFFFFu; }
+			const uint32_t* cc = d.cap_cc + (uint64_t)zi * sxy;
+			for (uint64_t y = 0; y < h.sy; y++) {
+				for (uint64_t x = 0; x < h.sx; x++) {
+					lstat_t* r = &sub[cc[x + (uint64_t)h.sx * y]];
+					r->n++; r->sx_ += x; r->sy_ += y;
+					if ((uint32_t)x < r->x0) r->x0 = (uint32_t)x;
+					if ((uint32_t)y < r->y0) r->y0 = (uint32_t)y;
+					if ((uint32_t)x > r->x1) r->x1 = (uint32_t)x;
+					if ((uint32_t)y > r->y1) r->y1 = (uint32_t)y;
+				}
+			}
+			for (uint64_t c = 0; c < N; c++) {
+				lstat_t* r = &rows[nrows++];
+				*r = sub[c];
+				r->label = d.cap_lmap[zi][c] & lmask;
+				r->z = (uint32_t)(zs + zi);
+				r->seen = 1;
+			}
+			free(sub);
+		}
+		qsort(rows, (size_t)nrows, sizeof(lstat_t), lstat_cmp);
+		uint64_t nl = 0;
+		for (uint64_t i = 0; i < nrows; i++) if (i == 0 || rows[i].label != rows[i - 1].label) nl++;
+		uint64_t* labels = (uint64_t*)xmalloc((nl + 1) * 8);
+		const size_t vb = which == 0 ? 8 : (which == 1 ? 24 : 24);
+		unsigned char* values = (unsigned char*)xcalloc((size_t)nl + 1, vb);
+		uint64_t k = 0;
+		for (uint64_t i = 0; i < nrows;) {
+			uint64_t j = i, cnt = 0, sumx = 0, sumy = 0, sumz = 0;
+			uint32_t bx[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0 };
+			/* a label outside the unique list (the background colour of a pin stream) is default-constructed
+			 * by bbxes[label_map[i]] (:596): its minima start at 0 */
+			int listed = 0;
+			for (uint64_t q = i; q < nrows && rows[q].label == rows[i].label; q++) listed |= !rows[q].seen;
+			if (which == 2 && !listed) bx[0] = bx[1] = bx[2] = 0;
+			for (; j < nrows && rows[j].label == rows[i].label; j++) {
+				const lstat_t* r = &rows[j];
+				if (!r->seen) continue;
+				cnt += r->n; sumx += r->sx_; sumy += r->sy_; sumz += r->n * (uint64_t)r->z;
+				if (r->x0 < bx[0]) bx[0] = r->x0;
+				if (r->y0 < bx[1]) bx[1] = r->y0;
+				if (r->z < bx[2]) bx[2] = r->z;
+				if (r->x1 > bx[3]) bx[3] = r->x1;
+				if (r->y1 > bx[4]) bx[4] = r->y1;
+				if (r->z > bx[5]) bx[5] = r->z;
+			}
+			labels[k] = rows[i].label;
+			if (which == 0) ((uint64_t*)values)[k] = cnt;
+			else if (which == 1) {
+				double* v = (double*)values + 3 * k;
+				v[0] = (double)sumx / (double)cnt; v[1] = (double)sumy / (double)cnt; v[2] = (double)sumz / (double)cnt;
+			}
+			else memcpy(values + 24 * k, bx, 24);
+			k++;
+			i = j;
+		}
+		*labels_out = labels; *values_out = values; *n_out = nl;
+	}
+	free(rows);
+	for (int64_t zi = 0; zi < szr; zi++) if (d.cap_lmap) free(d.cap_lmap[zi]);
+	free(d.cap_lmap); free(d.cap_N); free(d.cap_cc);
+	return rc;
+}
+
 /* operations::mode_pooling_2x2x1 (src/operations.hpp:1201-1340): *out holds the per-slice streams one
  * after the other (release with ckl_oracle_free), lens_out their lengths (room for sz entries) */
 int ckl_oracle_mode_pooling(

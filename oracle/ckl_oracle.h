@@ -87,6 +87,12 @@ int ckl_oracle_mode_pooling(
 	const unsigned char* buf, uint64_t n, int64_t z_start, int64_t z_end, uint64_t parallel,
 	unsigned char** out, uint64_t* out_len, uint64_t* lens_out, uint64_t* count);
 
+/* operations::voxel_counts / centroids / bounding_boxes (src/operations.hpp:321-665): arrays sorted by
+ * label; which 0: 1 x uint64 (count), 1: 3 x double (centroid), 2: 6 x uint32 (box) per label */
+int ckl_oracle_label_stats(
+	const unsigned char* buf, uint64_t n, int which, int64_t z_start, int64_t z_end, uint64_t parallel,
+	uint64_t** labels_out, void** values_out, uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

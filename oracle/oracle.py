@@ -90,6 +90,11 @@ class _Checker:
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     self._reencode = f
+    f = getattr(L, prefix + "label_stats")
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64, C.c_uint64,
+                  C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    self._label_stats = f
 
   # -- reference-shaped surface (fastcrackle.compress/decompress semantics) --
   def compress(self, labels, allow_pins=False, fortran_order=None, markov_model_order=0,
@@ -231,6 +236,38 @@ class _Checker:
       for p in (lab_p, off_p, pts_p):
         if p.value:
           self._free(p)
+
+  def _stats(self, binary, which, z_start, z_end, parallel):
+    binary = bytes(binary)
+    lab_p, val_p, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+    rc = self._label_stats(binary, len(binary), which, int(z_start), int(z_end), int(parallel), C.byref(lab_p), C.byref(val_p), C.byref(n))
+    if rc != 0:
+      raise RuntimeError(self._err().decode())
+    try:
+      k = int(n.value)
+      labs = np.frombuffer(C.string_at(lab_p.value, 8 * k), dtype=np.uint64).copy()
+      dt, per = ((np.uint64, 1), (np.float64, 3), (np.uint32, 6))[which]
+      vals = np.frombuffer(C.string_at(val_p.value, np.dtype(dt).itemsize * per * k), dtype=dt).reshape(k, per).copy()
+      return labs, vals
+    finally:
+      for p in (lab_p, val_p):
+        if p.value:
+          self._free(p)
+
+  def voxel_counts(self, binary, z_start=0, z_end=-1, parallel=1):
+    """fastcrackle.voxel_counts (src/fastcrackle.cpp:346-365, operations.hpp:321-371): dict label -> count."""
+    labs, vals = self._stats(binary, 0, z_start, z_end, parallel)
+    return {int(l): int(v[0]) for l, v in zip(labs, vals)}
+
+  def centroids(self, binary, z_start=0, z_end=-1, parallel=1):
+    """fastcrackle.centroids (src/fastcrackle.cpp:367-392, operations.hpp:421-491): dict label -> float64[3]."""
+    labs, vals = self._stats(binary, 1, z_start, z_end, parallel)
+    return {int(l): v for l, v in zip(labs, vals)}
+
+  def bounding_boxes(self, binary, z_start=0, z_end=-1, parallel=1):
+    """fastcrackle.bounding_boxes (src/fastcrackle.cpp:394-420, operations.hpp:541-617): dict label -> uint32[6]."""
+    labs, vals = self._stats(binary, 2, z_start, z_end, parallel)
+    return {int(l): v for l, v in zip(labs, vals)}
 
   def crc32c(self, data):
     data = bytes(data)

@@ -20,6 +20,7 @@
 //   crackle::operations::array_equal src/operations.hpp:1039-1184
 //   crackle::operations::mode_pooling_2x2x1 src/operations.hpp:1201-1340
 //   crackle::operations::point_cloud src/operations.hpp:183-262 (dual_graph.hpp:133-275)
+//   crackle::operations::voxel_counts / centroids / bounding_boxes src/operations.hpp:321-665
 
 #include <cstdint>
 #include <cstdlib>
@@ -28,6 +29,7 @@
 #include <stdexcept>
 #include <cmath>
 #include <limits>
+#include <algorithm>
 
 #include "crackle.hpp"
 #include "operations.hpp"
@@ -272,6 +274,51 @@ int ckl_ref_point_cloud(
 			at += v.size();
 		}
 		(*offsets_out)[keys.size()] = at / 3;
+		*n_out = keys.size();
+		return 0;
+	}
+	catch (const std::exception& e) {
+		g_err = e.what();
+		return 1;
+	}
+}
+
+// crackle::operations::voxel_counts / centroids / bounding_boxes  src/operations.hpp:321-665
+// (bound at src/fastcrackle.cpp:346-420).  The maps come back as arrays sorted by label:
+// which: 0 = counts (values: 1 x uint64 per label), 1 = centroids (3 x float64), 2 = boxes (6 x uint32).
+__attribute__((visibility("default")))
+int ckl_ref_label_stats(
+	const unsigned char* buf, uint64_t n, int which, int64_t z_start, int64_t z_end, uint64_t parallel,
+	uint64_t** labels_out, void** values_out, uint64_t* n_out
+) {
+	try {
+		std::vector<uint64_t> keys;
+		if (which == 0) {
+			auto m = crackle::operations::voxel_counts(buf, n, z_start, z_end, parallel);
+			for (const auto& kv : m) keys.push_back(kv.first);
+			std::sort(keys.begin(), keys.end());
+			uint64_t* v = static_cast<uint64_t*>(malloc((keys.size() + 1) * 8));
+			for (size_t i = 0; i < keys.size(); i++) v[i] = m[keys[i]];
+			*values_out = v;
+		}
+		else if (which == 1) {
+			auto m = crackle::operations::centroids(buf, n, z_start, z_end, parallel);
+			for (const auto& kv : m) keys.push_back(kv.first);
+			std::sort(keys.begin(), keys.end());
+			double* v = static_cast<double*>(malloc((keys.size() + 1) * 3 * 8));
+			for (size_t i = 0; i < keys.size(); i++) for (int k = 0; k < 3; k++) v[3 * i + k] = m[keys[i]][k];
+			*values_out = v;
+		}
+		else {
+			auto m = crackle::operations::bounding_boxes(buf, n, z_start, z_end, parallel);
+			for (const auto& kv : m) keys.push_back(kv.first);
+			std::sort(keys.begin(), keys.end());
+			uint32_t* v = static_cast<uint32_t*>(malloc((keys.size() + 1) * 6 * 4));
+			for (size_t i = 0; i < keys.size(); i++) for (int k = 0; k < 6; k++) v[6 * i + k] = m[keys[i]][k];
+			*values_out = v;
+		}
+		*labels_out = static_cast<uint64_t*>(malloc((keys.size() + 1) * 8));
+		for (size_t i = 0; i < keys.size(); i++) (*labels_out)[i] = keys[i];
 		*n_out = keys.size();
 		return 0;
 	}

@@ -8,7 +8,9 @@ into oracle/_ref by `make -C oracle ref`).  Runs only in the build container, wh
 usage: python tests/gen_golden.py [--xl | --ops]
   --xl   writes tests/golden/manifest_xl.json (full-size BASELINE.json configurations)
   --ops  writes tests/golden/point_cloud.json (the reference's point_cloud on the small golden
-         streams: per stream and argument set a sha256 over labels, offsets and points)
+         streams: per stream and argument set a sha256 over labels, offsets and points),
+         tests/golden/label_stats.json (voxel_counts / centroids / bounding_boxes digests of the
+         same streams) and the whole-C1 digests of ops_xl.json / point_cloud_xl.json
 """
 import hashlib
 import json
@@ -84,6 +86,32 @@ def point_cloud_digest(ptc) -> str:
   return h.hexdigest()
 
 
+def stats_digest(m) -> str:
+  """sha256 over a label -> value map of voxel_counts / centroids / bounding_boxes: labels ascending,
+  each followed by its value's little-endian bytes (uint64 count, 3 float64, 6 uint32)."""
+  h = hashlib.sha256()
+  for k in sorted(m):
+    h.update(int(k).to_bytes(8, "little"))
+    v = m[k]
+    h.update(int(v).to_bytes(8, "little") if np.isscalar(v) or isinstance(v, int) else np.ascontiguousarray(v).astype(np.asarray(v).dtype.newbyteorder("<")).tobytes())
+  return h.hexdigest()
+
+
+STATS_RANGES = {"all": (0, -1), "z1": (1, 2)}
+
+
+def label_stats_entry(chk, stream):
+  """digests of the three statistics over each z-range of STATS_RANGES (or the error text)"""
+  entry = {}
+  for tag, (z0, z1) in STATS_RANGES.items():
+    for fn in ("voxel_counts", "centroids", "bounding_boxes"):
+      try:
+        entry[f"{fn}.{tag}"] = stats_digest(getattr(chk, fn)(stream, z0, z1))
+      except RuntimeError as exc:
+        entry[f"{fn}.{tag}"] = "error: " + str(exc)
+  return entry
+
+
 POINT_CLOUD_ARGS = {"all": (0, -1, None, False), "skip0": (0, -1, None, True), "z1": (1, 2, None, False)}
 
 
@@ -102,6 +130,11 @@ def main_ops(ref):
   with open(os.path.join(HERE, "golden", "point_cloud.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
   print("point_cloud:", len(out), "streams")
+  # voxel_counts / centroids / bounding_boxes (operations.hpp:321-665) of the same streams
+  stats = {name: label_stats_entry(ref, streams[name]) for name in sorted(streams)}
+  with open(os.path.join(HERE, "golden", "label_stats.json"), "w") as f:
+    json.dump(stats, f, indent=1, sort_keys=True)
+  print("label_stats:", len(stats), "streams")
   # the same for BASELINE.json configs[1] at full size (512 x 512 x 128 uint32)
   thunk, kw = golden_cases.xl_cases()["c1_512x512x128_u32"]
   stream = ref.compress(thunk(), parallel=8, **kw)
@@ -117,6 +150,7 @@ def main_ops(ref):
     "vcg4": hashlib.sha256(np.ascontiguousarray(ref.voxel_connectivity_graph(stream, 4)).tobytes()).hexdigest(),
     "vcg6": hashlib.sha256(np.ascontiguousarray(ref.voxel_connectivity_graph(stream, 6)).tobytes()).hexdigest(),
   }
+  ops.update(label_stats_entry(ref, stream))
   with open(os.path.join(HERE, "golden", "ops_xl.json"), "w") as f:
     json.dump({"c1_512x512x128_u32": ops}, f, indent=1, sort_keys=True)
   print("ops xl:", ops)

@@ -321,6 +321,39 @@ def test_label_statistics_match_numpy(checker):
   assert crackle_amd.voxel_counts(empty) == {} and crackle_amd.centroids(empty) == {} and crackle_amd.bounding_boxes(empty) == {}
 
 
+def test_label_statistics_against_the_reference_fixture():
+  """voxel_counts / centroids / bounding_boxes of every small golden stream (whole range and one
+  slice) against digests of the compiled reference's own output (tests/golden/label_stats.json,
+  tests/gen_golden.py --ops): counts exact, centroids bit for bit as float64, boxes with the
+  reference's initial values for absent labels and its zero minima for a pin stream's background
+  colour.  The z-ranges go through the fastcrackle module (src/fastcrackle.cpp:346-420 take them)."""
+  import json
+  import os
+  from gen_golden import STATS_RANGES, stats_digest
+  from crackle_amd import fastcrackle as m
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "label_stats.json")) as f:
+    want = json.load(f)
+  g = golden()
+  assert sorted(want) == sorted(g)
+  for name in sorted(g):
+    for tag, (z0, z1) in STATS_RANGES.items():
+      for fn in ("voxel_counts", "centroids", "bounding_boxes"):
+        w = want[name][f"{fn}.{tag}"]
+        try:
+          got = stats_digest(getattr(m, fn)(g[name], z0, z1, 1))
+        except RuntimeError as exc:
+          got = "error: " + str(exc)
+        if w.startswith("error"):
+          assert got.startswith("error"), (name, fn, tag, got)
+        else:
+          assert got == w, (name, fn, tag)
+    # the Python surface (codec.py:949-1067) over the whole stream
+    if not want[name]["voxel_counts.all"].startswith("error") and crackle_amd.num_labels(g[name]) > 1:
+      assert stats_digest(crackle_amd.voxel_counts(g[name])) == want[name]["voxel_counts.all"], name
+      assert stats_digest(crackle_amd.centroids(g[name])) == want[name]["centroids.all"], name
+      assert stats_digest(crackle_amd.bounding_boxes(g[name], no_slice_conversion=True)) == want[name]["bounding_boxes.all"], name
+
+
 def test_label_statistics_run_by_run_merge(checker, monkeypatch):
   """Slices with more components than the LDS accumulators hold merge run by run."""
   monkeypatch.setenv("CKL_STATS_LDS_COMPS", "8")
@@ -544,3 +577,9 @@ def test_consumers_on_the_whole_c1_volume_against_the_reference_fixture():
   assert h(b"".join(operations._mode_pooling_slices(binary))) == want["mode_pooling_2x2x1"]
   for conn in (4, 6):
     assert h(np.ascontiguousarray(crackle_amd.voxel_connectivity_graph(binary, conn)).tobytes()) == want[f"vcg{conn}"], conn
+  # voxel_counts / centroids / bounding_boxes (operations.hpp:321-665) of the same volume
+  from gen_golden import STATS_RANGES, stats_digest
+  from crackle_amd import fastcrackle as m
+  for tag, (z0, z1) in STATS_RANGES.items():
+    for fn in ("voxel_counts", "centroids", "bounding_boxes"):
+      assert stats_digest(getattr(m, fn)(binary, z0, z1, 1)) == want[f"{fn}.{tag}"], (fn, tag)

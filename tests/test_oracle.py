@@ -302,3 +302,55 @@ def test_point_cloud_restatement_against_the_live_reference(port, ref):
         assert sorted(a) == sorted(c), (name, kw, z0, z1)
         for k in a:
           assert np.array_equal(a[k], c[k]), (name, kw, z0, z1, k)
+
+
+def _stats_call(chk, fn, b, z0, z1):
+  try:
+    return getattr(chk, fn)(b, z0, z1)
+  except RuntimeError as exc:
+    return "error: " + str(exc)
+
+
+def test_label_stats_restatement_against_the_reference_fixture(port):
+  """operations::voxel_counts / centroids / bounding_boxes (src/operations.hpp:321-665): the C
+  restatement against tests/golden/label_stats.json, written by tests/gen_golden.py --ops from the
+  compiled reference (every small golden stream, whole range and one slice; the pin streams'
+  background colour with its zero minima included)."""
+  import json
+  from gen_golden import STATS_RANGES, stats_digest
+  from util import golden
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "label_stats.json")) as f:
+    want = json.load(f)
+  g = golden()
+  assert sorted(want) == sorted(g)
+  for name in sorted(g):
+    for tag, (z0, z1) in STATS_RANGES.items():
+      for fn in ("voxel_counts", "centroids", "bounding_boxes"):
+        got = _stats_call(port, fn, g[name], z0, z1)
+        got = got if isinstance(got, str) else stats_digest(got)
+        assert got == want[name][f"{fn}.{tag}"], (name, fn, tag)
+
+
+def test_label_stats_restatement_against_the_live_reference(port, ref):
+  if ref is None:
+    pytest.skip("compiled reference not available")
+  from crackle_amd import synth
+  vols = [
+    (synth.as_numpy_f(synth.voronoi_labels((96, 80, 12), np.uint16, seed=4, cell=(16, 16, 4))), dict()),
+    (synth.as_numpy_f(synth.voronoi_labels((70, 50, 9), np.uint32, seed=12, cell=(20, 20, 4))), dict(allow_pins=True)),
+    (synth.as_numpy_f(synth.voronoi_labels((64, 64, 6), np.uint64, seed=8, cell=(16, 16, 4), offset=1 << 40)), dict(markov_model_order=3)),
+    (synth.random_labels((50, 41, 3), np.uint32, seed=9, high=200), dict()),
+    (synth.as_numpy_f(synth.voronoi_labels((40, 40, 5), np.uint16, seed=3, cell=(8, 8, 2))).astype(np.uint8, order="F"), dict(allow_pins=True)),
+  ]
+  for arr, kw in vols:
+    b = ref.compress(arr, **kw)
+    for z0, z1 in ((0, -1), (1, 3), (2, 2), (4, 100)):
+      for fn in ("voxel_counts", "centroids", "bounding_boxes"):
+        a, c = _stats_call(ref, fn, b, z0, z1), _stats_call(port, fn, b, z0, z1)
+        assert type(a) is type(c), (fn, z0, z1, a if isinstance(a, str) else "", c if isinstance(c, str) else "")
+        if isinstance(a, str):
+          assert a == c
+          continue
+        assert sorted(a) == sorted(c), (fn, z0, z1)
+        for k in a:
+          assert np.array_equal(np.asarray(a[k]), np.asarray(c[k])), (fn, z0, z1, k, a[k], c[k])
