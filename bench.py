@@ -48,7 +48,7 @@ def parse_args(argv=None):
   ap.add_argument("--markov", type=int, default=0)
   ap.add_argument("--pins", type=int, default=0, help="allow_pins (parity / rehearsal runs; the metric is quoted on flat labels)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--cpu-sample-slices", type=int, default=128)
+  ap.add_argument("--cpu-sample-slices", type=int, default=0, help="slices of the CPU baseline's sample (0: the whole slab)")
   return ap.parse_args(argv)
 
 
@@ -152,19 +152,31 @@ def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=5):
   return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
+def lib_sha16():
+  """First 16 hex digits of the sha256 of the library that is loaded: ties a PMC profile to a build."""
+  import hashlib
+  from crackle_amd import _lib
+  try:
+    with open(_lib.LIB_PATH, "rb") as f:
+      return hashlib.sha256(f.read()).hexdigest()[:16]
+  except OSError:
+    return None
+
+
 def pmc_traffic(kernels, workload_key):
   """HBM bytes per launch, summed over `kernels` (name prefixes), from the committed rocprofv3
-  --pmc passes of this workload (profiles/r02_pmc_traffic.json, written by tools/pmc_summary.py:
+  --pmc passes of this workload (profiles/r03_pmc_traffic.json, written by tools/pmc_summary.py:
   separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the guide prescribes for gfx950).
-  None when no counters were collected for this workload or a kernel is missing from them."""
-  for fn in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+  None when no counters were collected for this workload, a kernel is missing from them, or the
+  profile was taken from another build of the library (its recorded lib_sha16 differs)."""
+  for fn in ("r03_pmc_traffic.json",):
     path = os.path.join(ROOT, "profiles", fn)
     try:
       with open(path) as f:
         t = json.load(f)
     except (OSError, ValueError):
       continue
-    if t.get("workload") != workload_key:
+    if t.get("workload") != workload_key or t.get("lib_sha16") != lib_sha16():
       continue
     total, per = 0.0, {}
     for want in kernels:
@@ -191,15 +203,16 @@ def cpu_model():
   return "unknown"
 
 
-def cpu_baseline(np, vol_np_slab, markov, hip_bytes_for_slab=None):
+def cpu_baseline(np, vol_np_slab, markov, hip_bytes_for_slab=None, whole=False):
   """Times the CPU checker (the compiled reference when oracle/_ref travelled here,
-  else the C restatement) on a bounded z-slab of the same workload."""
+  else the C restatement) on the same workload: the whole volume by default (its pool runs one
+  thread per slice at most, src/crackle.hpp:66-69, so a slab would leave cores idle), best of 3."""
   from oracle import oracle
   chk = oracle.best()
   cores = os.cpu_count() or 1
   nz = vol_np_slab.shape[2]
   best_e, best_d, binary = None, None, None
-  for _ in range(2):
+  for _ in range(3):
     t = time.perf_counter()
     binary = chk.compress(vol_np_slab, markov_model_order=markov, parallel=cores)
     te = time.perf_counter() - t
@@ -210,8 +223,8 @@ def cpu_baseline(np, vol_np_slab, markov, hip_bytes_for_slab=None):
     best_d = td if best_d is None else min(best_d, td)
   ok = bool(np.array_equal(out.reshape(vol_np_slab.shape, order="F"), vol_np_slab))
   vox = vol_np_slab.size
-  # one-thread row on a quarter of the sample
-  q = np.asfortranarray(vol_np_slab[:, :, :max(1, nz // 4)])
+  # one-thread row on 16 slices of the sample
+  q = np.asfortranarray(vol_np_slab[:, :, :max(1, min(nz, 16))])
   t = time.perf_counter()
   b1 = chk.compress(q, markov_model_order=markov, parallel=1)
   chk.decompress(b1, parallel=1)
@@ -225,7 +238,7 @@ def cpu_baseline(np, vol_np_slab, markov, hip_bytes_for_slab=None):
     "host_cores": cores,
     "cpu_model": cpu_model(),
     "kind": chk.kind,
-    "sample": f"{vol_np_slab.shape[0]}x{vol_np_slab.shape[1]}x{nz} {vol_np_slab.dtype} z-slab of the same synthetic volume, encode+decode, parallel={cores} asked, {threads} threads effective (one per slice), best of 2",
+    "sample": f"{vol_np_slab.shape[0]}x{vol_np_slab.shape[1]}x{nz} {vol_np_slab.dtype} {'(the whole volume)' if whole else 'z-slab'} of the same synthetic volume, encode+decode, parallel={cores} asked, {threads} threads effective (one per slice at most), best of 3; single_thread row: {q.shape[2]} slices, parallel=1",
     "encode_voxels_per_s": vox / best_e,
     "decode_voxels_per_s": vox / best_d,
     "single_thread_voxels_per_s": q.size / t1,
@@ -343,6 +356,14 @@ def main():
   enc_ms, dec_ms, open_ms, dec_pipe_ms, enc_pipe_ms, enc_kernel_ms = [], [], [], [], [], []
   binary = None
   total_s = 0.0
+  # The encoder leaves its stream in HBM as well (ckl_encoder_keep_device_stream): the decode leg starts
+  # from those resident bytes — every rank from its own slab's stream, which carries the merged label
+  # table: header + z-index + labels + its own crack codes, what SURVEY.md section 8e gives a rank —
+  # and its whole cost, session set-up included, is inside the timed region.  Pin streams are merged on
+  # rank 0 only: with --pins the ranks take the broadcast stream and its set-up stays outside.
+  resident = not (args.pins and (world > 1 or group1))
+  if resident:
+    backend.keep_device_stream((sx, sy, sz), np_dtype.itemsize, True)
   for step in range(args.warmup + args.steps):
     timed = step >= args.warmup
     barrier()
@@ -350,11 +371,16 @@ def main():
     binary = codec.compress(vol, (sx, sy, sz), markov_model_order=args.markov, allow_pins=bool(args.pins))   # merged stream on rank 0
     barrier()
     t1 = time.perf_counter()
-    # decode leg.  Set-up (stream upload over PCIe, header / z-index / label-section parse,
-    # descriptors, scratch) is timed on its own: `value` counts the path from bytes resident in
-    # HBM to labels resident in HBM, decode_total_ms includes the set-up.
-    session = codec.open_decoder(binary, (sx, sy, sz))
-    barrier()
+    # decode leg: compressed bytes resident in HBM -> labels resident in HBM,
+    # ckl_decoder_create_device (header / z-index / label-section head read back, descriptors, scratch)
+    # + ckl_decoder_run
+    if resident:
+      session = backend.open_decoder(backend.device_stream(), 0, sz)
+    else:
+      session = codec.open_decoder(binary, (sx, sy, sz))
+      barrier()
+      t1 = time.perf_counter()
+    torch.cuda.synchronize()
     t2 = time.perf_counter()
     session.run(out)
     barrier()
@@ -363,7 +389,7 @@ def main():
       enc_ms.append((t1 - t0) * 1e3)
       open_ms.append((t2 - t1) * 1e3)
       dec_ms.append((t3 - t2) * 1e3)
-      total_s += (t1 - t0) + (t3 - t2)
+      total_s += (t3 - t0) if resident else (t1 - t0) + (t3 - t2)
       p, _ = session.timing()
       dec_pipe_ms.append(p)
       p, k = backend.encoder_timing()
@@ -377,7 +403,7 @@ def main():
   stage_ms = {}
   if rank == 0 or world > 1:
     os.environ["CKL_DECODE_CHUNKS"] = "1"
-    session = codec.open_decoder(binary, (sx, sy, sz))
+    session = backend.open_decoder(backend.device_stream(), 0, sz) if resident else codec.open_decoder(binary, (sx, sy, sz))
     acc = {}
     for _ in range(3):
       session.run(out)
@@ -389,7 +415,7 @@ def main():
     stage_ms = {n: float(np.mean(v[1:])) for n, v in acc.items()}
 
   # max over ranks of the timed wall clock
-  t = torch.tensor([total_s, sum(enc_ms), sum(dec_ms), 0.0 if ok_local else 1.0], dtype=torch.float64, device=coll_dev)
+  t = torch.tensor([total_s, sum(enc_ms), sum(dec_ms) + (sum(open_ms) if resident else 0.0), 0.0 if ok_local else 1.0], dtype=torch.float64, device=coll_dev)
   if world > 1 or group1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   total_s, enc_sum_ms, dec_sum_ms, any_bad = (float(v) for v in t.tolist())
@@ -436,6 +462,7 @@ def main():
       "decode_ms": float(np.mean(dec_ms)),
       "decoder_create_ms": float(np.mean(open_ms)),
       "decode_total_ms": float(np.mean(open_ms)) + float(np.mean(dec_ms)),
+      "decode_setup_in_value": bool(resident),
       "decode_device_pipeline_ms": pipe_ms,
       "encode_device_pipeline_ms": float(np.mean(enc_pipe_ms)),
       "encode_dfs_kernel_ms": float(np.mean(enc_kernel_ms)),
@@ -485,12 +512,12 @@ def main():
         res["bytes_match_reference"] = bool(sha == ref["sha256"] and ckl_len == ref["length"])
         res["reference_sha256"] = ref["sha256"]
     if not args.no_cpu_baseline:
-      ns = min(args.cpu_sample_slices, sz)
+      ns = min(args.cpu_sample_slices, sz) if args.cpu_sample_slices > 0 else sz
       slab = np.asfortranarray(synth.as_numpy_f(vol[:ns]))
       hip_slab = None
       if world == 1:
         hip_slab = ckd.HipBackend(dev_index).encode(vol[:ns].contiguous(), (sx, sy, ns), False, True, args.markov, None)
-      res["cpu_baseline"] = cpu_baseline(np, slab, args.markov, hip_slab)
+      res["cpu_baseline"] = cpu_baseline(np, slab, args.markov, hip_slab, whole=(ns == sz and world == 1))
     print(json.dumps(res), file=_json_out, flush=True)
 
   if world > 1 or group1:

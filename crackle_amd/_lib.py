@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcrackle_amd.so")
+# CKL_TUNING_LIB=1 (kernel work only): the -DCKL_TUNING build with cycle stamps and ablation switches
+LIB_PATH = os.path.join(HERE, "libcrackle_amd_tuning.so" if os.environ.get("CKL_TUNING_LIB") else "libcrackle_amd.so")
 
 CKL_OK, CKL_ERR_FORMAT, CKL_ERR_RUNTIME, CKL_ERR_ARG, CKL_ERR_NO_DEVICE, CKL_ERR_CRC = range(6)
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -51,6 +52,9 @@ EXPORTS = {
     C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
     C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_int]),
   "ckl_decoder_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+  "ckl_decoder_create_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+  "ckl_encoder_keep_device_stream": (C.c_int, [C.c_void_p, C.c_int]),
+  "ckl_encoder_device_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_decoder_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]),
   "ckl_decoder_label_stats": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
   "ckl_decoder_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

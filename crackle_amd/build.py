@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrackle_amd.so")
 SOURCES = ["ckl_common.hip", "ckl_decode.hip", "ckl_encode.hip", "ckl_pins.hip", "ckl_zstack.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "crackle_amd.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + [os.path.join("..", "..", "include", "crackle_amd.h")]
 ARCH = os.environ.get("CKL_OFFLOAD_ARCH", "gfx950")
 
 
@@ -31,13 +31,22 @@ def _stale(target, deps):
   return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
+TUNING_LIB = os.path.join(HERE, "libcrackle_amd_tuning.so")
+
+
+def build(force=False, verbose=True, tuning=False):
+  """tuning=True builds libcrackle_amd_tuning.so with -DCKL_TUNING (in-kernel cycle stamps and the
+  ablation switches of tools/ablate.sh; selected at run time with CKL_TUNING_LIB=1).  The shipped
+  library has neither."""
   srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
   hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
-  objdir = os.path.join(HERE, "build")
+  objdir = os.path.join(HERE, "build_tuning" if tuning else "build")
   os.makedirs(objdir, exist_ok=True)
   objs = []
   flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+  if tuning:
+    flags.append("-DCKL_TUNING")
+  LIB = TUNING_LIB if tuning else globals()["LIB"]
   for s in srcs:
     o = os.path.join(objdir, os.path.basename(s) + ".o")
     objs.append(o)
@@ -51,7 +60,8 @@ def build(force=False, verbose=True):
     if verbose:
       print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-  build_fastcrackle(force=force, verbose=verbose)
+  if not tuning:
+    build_fastcrackle(force=force, verbose=verbose)
   return LIB
 
 
@@ -83,4 +93,4 @@ def build_fastcrackle(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-  build(force="--force" in sys.argv)
+  build(force="--force" in sys.argv, tuning="--tuning" in sys.argv)

@@ -40,9 +40,10 @@ constexpr size_t kPoolMaxBytes = 96ull << 30;    // of 288 GB of HBM
 constexpr size_t kPoolMaxBlocks = 512;
 }
 
-void* pool_alloc(size_t bytes) {
+void* pool_alloc(size_t bytes, int* device) {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
+	if (device) *device = dev;
 	{
 		std::lock_guard<std::mutex> lock(g_pool_mutex);
 		// best fit among blocks that are not wastefully large for the request
@@ -74,10 +75,10 @@ void* pool_alloc(size_t bytes) {
 	return p;
 }
 
-void pool_free(void* p, size_t bytes) {
+void pool_free(void* p, size_t bytes, int device) {
 	if (!p) return;
-	int dev = 0;
-	(void)hipGetDevice(&dev);
+	int dev = device;
+	if (dev < 0) (void)hipGetDevice(&dev);
 	{
 		std::lock_guard<std::mutex> lock(g_pool_mutex);
 		if (g_pool.size() < kPoolMaxBlocks && g_pool_bytes + bytes <= kPoolMaxBytes) {

@@ -123,30 +123,34 @@ struct Header {
 // scratch through hipFree / hipMalloc costs tens of milliseconds each time.
 void* host_out_alloc(size_t bytes);        // pinned (cached) host buffer for results; release with ckl_free / host_out_free
 void host_out_free(void* p);               // also accepts plain malloc'd pointers
-void* pool_alloc(size_t bytes);            // throws Error on failure
-void pool_free(void* p, size_t bytes);     // returns the block to the pool
+void* pool_alloc(size_t bytes, int* device = nullptr);      // throws Error on failure; *device: the device the block lives on (the current one)
+void pool_free(void* p, size_t bytes, int device = -1);     // returns the block to the pool of its device (-1: the current device)
 void pool_trim();                          // hipFree everything that is pooled
 
 template <typename T>
 struct DevBuf {
 	T* p = nullptr;
 	size_t n = 0;
+	int device = -1;           // the device the block was allocated on: it goes back to that device's pool whatever device is current then
+	bool borrowed = false;     // a view of memory somebody else owns (a part of a packed block, a caller's buffer): never freed here
 	DevBuf() = default;
 	DevBuf(const DevBuf&) = delete;
 	DevBuf& operator=(const DevBuf&) = delete;
 	~DevBuf() { release(); }
 	void release() {
-		if (p) pool_free(p, (n ? n : 1) * sizeof(T));
+		if (p && !borrowed) pool_free(p, (n ? n : 1) * sizeof(T), device);
 		p = nullptr;
 		n = 0;
+		borrowed = false;
 	}
 	// grow-only allocation (contents are not preserved)
 	void ensure(size_t count) {
-		if (count <= n && p) return;
+		if (count <= n && p && !borrowed) return;
 		release();
-		p = static_cast<T*>(pool_alloc((count ? count : 1) * sizeof(T)));
+		p = static_cast<T*>(pool_alloc((count ? count : 1) * sizeof(T), &device));
 		n = count;
 	}
+	void borrow(T* ptr, size_t count) { release(); p = ptr; n = count; borrowed = true; }
 	size_t bytes() const { return n * sizeof(T); }
 };
 

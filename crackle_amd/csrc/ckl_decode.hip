@@ -41,6 +41,7 @@
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <type_traits>
 
 namespace ckl {
 
@@ -404,14 +405,15 @@ struct TileCarry {
 // workgroup: thread t derives the symbols of its 128 positions into ws[] and gets the
 // exclusive counts before its first position (o_a, o_dx, o_dy); the carries advance
 // to the next tile.  The last barrier inside is behind every use of the LDS scratch.
-template <bool COUNT_T>
+template <bool COUNT_T, int BLOCK = kCrackBlock, uint32_t WORDS = kCrackWords>
 __device__ __forceinline__ void tile_symbols(
 	const uint32_t* __restrict__ words, uint32_t wshift, uint32_t n_codes, uint32_t span, uint32_t tile, TileCarry& c,
-	WordSyms (&ws)[kCrackWords], uint32_t& o_a, uint32_t& o_dx, uint32_t& o_dy,
+	WordSyms (&ws)[WORDS], uint32_t& o_a, uint32_t& o_dx, uint32_t& o_dy,
 	uint32_t* s_scan, int32_t* s_scanmax, uint8_t* s_last_move, uint8_t* s_last_ctrl
 ) {
+	constexpr int NW = BLOCK / kWave;
 	const uint32_t tid = threadIdx.x;
-	// `span` positions per thread (a multiple of 16, at most kCrackWords * 16): a slice with fewer codes
+	// `span` positions per thread (a multiple of 16, at most WORDS * 16): a slice with fewer codes
 	// than a full tile spreads them over all threads instead of filling the first ones with eight
 	// words each; a thread's words past its span are empty
 	const uint32_t g0 = tile + tid * span;
@@ -419,20 +421,20 @@ __device__ __forceinline__ void tile_symbols(
 	const int64_t lim_ev = min(static_cast<int64_t>(n_codes) + 1, static_cast<int64_t>(g0) + span);      // positions
 	const uint32_t last_word = span / 16u - 1u;
 	// -- load, running sums mod 4
-	uint32_t mv[kCrackWords];
+	uint32_t mv[WORDS];
 	uint32_t tsum = 0;
 	{
-		uint32_t q[kCrackWords + 1];
+		uint32_t q[WORDS + 1];
 		const uint32_t w0 = g0 / 16u;
 #pragma unroll
-		for (uint32_t j = 0; j <= kCrackWords; j++) {
+		for (uint32_t j = 0; j <= WORDS; j++) {
 			// word j is needed when any of its codes exists; the shifted read also takes the low bytes of word j+1
 			// (issuing all nine loads unconditionally, with clamped indices, was measured slower: 0.322 against 0.313 ms)
 			const bool need = (static_cast<int64_t>(g0) + 16u * j < lim) || (j > 0 && wshift && static_cast<int64_t>(g0) + 16u * (j - 1u) < lim);
 			q[j] = need ? words[w0 + j] : 0u;
 		}
 #pragma unroll
-		for (uint32_t j = 0; j < kCrackWords; j++) {
+		for (uint32_t j = 0; j < WORDS; j++) {
 			uint32_t cw = wshift ? __funnelshift_r(q[j], q[j + 1], wshift) : q[j];
 			const uint32_t fm = fields_below(lim - static_cast<int64_t>(g0 + 16u * j));
 			cw &= fm | (fm << 1);
@@ -442,20 +444,20 @@ __device__ __forceinline__ void tile_symbols(
 		}
 	}
 	uint32_t v1[1] = { tsum }, t1[1];
-	block_excl_add<1, kCrackWaves>(v1, t1, s_scan);
+	block_excl_add<1, NW>(v1, t1, s_scan);
 	const uint32_t base_sum = ((c.sum + v1[0]) & 3u) * kLo;
 #pragma unroll
-	for (uint32_t j = 0; j < kCrackWords; j++) mv[j] = add_fields(mv[j], base_sum);
-	s_last_move[tid] = static_cast<uint8_t>(mv[kCrackWords - 1] >> 30);
+	for (uint32_t j = 0; j < WORDS; j++) mv[j] = add_fields(mv[j], base_sum);
+	s_last_move[tid] = static_cast<uint8_t>(mv[WORDS - 1] >> 30);
 	__syncthreads();
 	const uint32_t prev_move = tid ? s_last_move[tid - 1] : c.move;
-	const uint32_t tile_last_move = s_last_move[kCrackBlock - 1];
+	const uint32_t tile_last_move = s_last_move[BLOCK - 1];
 
 	// -- r: code g is the exact reverse of code g-1
-	uint32_t r[kCrackWords];
+	uint32_t r[WORDS];
 	int32_t lf = INT32_MIN;
 #pragma unroll
-	for (uint32_t j = 0; j < kCrackWords; j++) {
+	for (uint32_t j = 0; j < WORDS; j++) {
 		const uint32_t gw = g0 + 16u * j;
 		const uint32_t prevs = (mv[j] << 2) | (j ? (mv[j - 1] >> 30) : prev_move);
 		const uint32_t x = mv[j] ^ prevs;
@@ -467,12 +469,12 @@ __device__ __forceinline__ void tile_symbols(
 		if (nr) lf = static_cast<int32_t>(gw + ((31u - __clz(nr)) >> 1));
 	}
 	int32_t lf_tot;
-	int32_t lf_in = block_excl_max<kCrackWaves>(lf, lf_tot, s_scanmax);
+	int32_t lf_in = block_excl_max<NW>(lf, lf_tot, s_scanmax);
 	if (lf_in < c.lf) lf_in = c.lf;
 	// -- ctrl: within a run of reverses, the positions at an odd distance from the last non-reverse
-	uint32_t ctrl[kCrackWords];
+	uint32_t ctrl[WORDS];
 #pragma unroll
-	for (uint32_t j = 0; j < kCrackWords; j++) {
+	for (uint32_t j = 0; j < WORDS; j++) {
 		const uint32_t gw = g0 + 16u * j;
 		const uint32_t rj = r[j];
 		uint32_t es = rj & ~(rj << 2) & kEvenF;           // runs starting on an even field
@@ -484,19 +486,19 @@ __device__ __forceinline__ void tile_symbols(
 		if (nr) lf_in = static_cast<int32_t>(gw + ((31u - __clz(nr)) >> 1));
 	}
 	{
-		uint32_t lc = ctrl[kCrackWords - 1];
+		uint32_t lc = ctrl[WORDS - 1];
 #pragma unroll
-		for (uint32_t j = 0; j + 1 < kCrackWords; j++) if (j == last_word) lc = ctrl[j];
+		for (uint32_t j = 0; j + 1 < WORDS; j++) if (j == last_word) lc = ctrl[j];
 		s_last_ctrl[tid] = static_cast<uint8_t>((lc >> 30) & 1u);
 	}
 	__syncthreads();
 	const uint32_t prev_ctrl = tid ? s_last_ctrl[tid - 1] : c.ctrl;
-	const uint32_t tile_last_ctrl = s_last_ctrl[kCrackBlock - 1];
+	const uint32_t tile_last_ctrl = s_last_ctrl[BLOCK - 1];
 
 	// -- events: position g emits the symbol of code g-1 unless g-1 was a control half
 	uint32_t n_a = 0, ddx = 0, ddy = 0;
 #pragma unroll
-	for (uint32_t j = 0; j < kCrackWords; j++) {
+	for (uint32_t j = 0; j < WORDS; j++) {
 		const uint32_t gw = g0 + 16u * j;
 		WordSyms& w = ws[j];
 		w.prevs = (mv[j] << 2) | (j ? (mv[j - 1] >> 30) : prev_move);
@@ -512,7 +514,7 @@ __device__ __forceinline__ void tile_symbols(
 		ddy += __popc(w.down()) - __popc(w.up());
 	}
 	uint32_t v3[3] = { n_a, ddx, ddy }, t3[3];
-	block_excl_add<3, kCrackWaves>(v3, t3, s_scan);
+	block_excl_add<3, NW>(v3, t3, s_scan);
 	o_a = c.a + v3[0]; o_dx = c.dx + v3[1]; o_dy = c.dy + v3[2];
 
 	c.sum = (c.sum + t1[0]) & 3u;
@@ -686,23 +688,23 @@ __device__ __forceinline__ BitMap3 bitmap3_compose(const BitMap3& f, const BitMa
 constexpr uint32_t kMarkovWarm = 64;
 
 // lds: [payload words][rank words][model rows or nothing][2 x kCrackBlock context words]
-__device__ __forceinline__ uint32_t markov_lds_need(uint32_t nbytes, uint32_t cap, int order, uint32_t budget, bool& model_in_lds) {
+__device__ __forceinline__ uint32_t markov_lds_need(uint32_t nbytes, uint32_t cap, int order, uint32_t budget, bool& model_in_lds, uint32_t block = kCrackBlock) {
 	const uint32_t pay = ((nbytes + 3u) / 4u + 2u) * 4u;
 	const uint32_t rnk = (cap / 16u + 2u) * 4u;
-	const uint32_t fix = 2u * kCrackBlock * 4u;
+	const uint32_t fix = 2u * block * 4u;
 	const uint64_t mdl = 4ull << (2 * order);
 	model_in_lds = order <= 8 && pay + rnk + fix + mdl <= budget;
 	return pay + rnk + fix + (model_in_lds ? static_cast<uint32_t>(mdl) : 0u);
 }
 // the same with payload and ranks in the global scratch: only the model and the context words
-__device__ __forceinline__ bool markov_model_fits_alone(int order, uint32_t budget) {
-	return order <= 8 && (4ull << (2 * order)) + 2ull * kCrackBlock * 4ull <= budget;
+__device__ __forceinline__ bool markov_model_fits_alone(int order, uint32_t budget, uint32_t block = kCrackBlock) {
+	return order <= 8 && (4ull << (2 * order)) + 2ull * block * 4ull <= budget;
 }
 
 // GLOBAL: the payload copy and the ranks live in a global scratch area (slices too big for the
 // LDS); those words are written by some threads and read by others of the workgroup, so they are
 // read with L1-bypassing loads.
-template <bool GLOBAL>
+template <bool GLOBAL, int BLOCK = kCrackBlock>
 __device__ __forceinline__ void markov_expand_parallel(
 	const uint8_t* __restrict__ s, uint32_t nbytes, int order, const uint8_t* __restrict__ model_g, uint32_t cap,
 	uint32_t* __restrict__ upacked, uint32_t* lds, uint32_t* gscratch, bool model_in_lds, uint32_t* s_scan, uint32_t* s_total,
@@ -716,17 +718,17 @@ __device__ __forceinline__ void markov_expand_parallel(
 	uint32_t* rows_lds = GLOBAL ? lds : ranks + rank_words;
 	const uint32_t n_rows = 1u << (2 * order);
 	uint32_t* ctx_in = rows_lds + (model_in_lds ? n_rows : 0u);
-	uint32_t* ctx_end = ctx_in + kCrackBlock;
+	uint32_t* ctx_end = ctx_in + BLOCK;
 	const uint32_t* rows = model_in_lds ? rows_lds : reinterpret_cast<const uint32_t*>(model_g);
 
 	// ---- stage the payload (zero padded), clear the ranks, stage the model
-	for (uint32_t w = tid; w < pay_words; w += kCrackBlock) {
+	for (uint32_t w = tid; w < pay_words; w += BLOCK) {
 		uint32_t v = 0;
 		for (uint32_t b = 0; b < 4u; b++) { const uint32_t i = w * 4u + b; if (i < nbytes) v |= static_cast<uint32_t>(s[i]) << (8u * b); }
 		pay[w] = v;
 	}
-	for (uint32_t w = tid; w < rank_words; w += kCrackBlock) ranks[w] = 0;
-	if (model_in_lds) for (uint32_t r = tid; r < n_rows; r += kCrackBlock) rows_lds[r] = reinterpret_cast<const uint32_t*>(model_g)[r];
+	for (uint32_t w = tid; w < rank_words; w += BLOCK) ranks[w] = 0;
+	if (model_in_lds) for (uint32_t r = tid; r < n_rows; r += BLOCK) rows_lds[r] = reinterpret_cast<const uint32_t*>(model_g)[r];
 	if (GLOBAL) __threadfence();      // the zeroes must be in L2 before another wavefront's atomicOr lands there
 	__syncthreads();
 	auto ldw = [&](const uint32_t* p) -> uint32_t { return GLOBAL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
@@ -734,7 +736,7 @@ __device__ __forceinline__ void markov_expand_parallel(
 
 	// ---- 1. code boundaries
 	const uint32_t B = nbytes * 8u;
-	const uint32_t Q = (B - 2u + kCrackBlock - 1u) / kCrackBlock;
+	const uint32_t Q = (B - 2u + BLOCK - 1u) / BLOCK;
 	const uint32_t lo = min(B, 2u + tid * Q), hi = min(B, lo + Q);
 	BitMap3 m;
 	{
@@ -772,7 +774,7 @@ __device__ __forceinline__ void markov_expand_parallel(
 		pre = bitmap3_compose(pre, t);
 	}
 	const BitMap3 before = bitmap3_compose(pre, exc);
-	if (tid == kCrackBlock - 1) *s_total = 1u + bitmap3_compose(before, m).c0;      // + the raw start code
+	if (tid == BLOCK - 1) *s_total = 1u + bitmap3_compose(before, m).c0;      // + the raw start code
 	// ---- 2. ranks by code index (the stream starts at a code start)
 	{
 		uint32_t st = before.e & 3u;
@@ -806,7 +808,7 @@ __device__ __forceinline__ void markov_expand_parallel(
 	// ---- 3. the context recurrence, speculatively per chunk
 	const int shift = 2 * (order - 1);
 	const uint32_t start = ldw(pay) & 3u;
-	uint32_t C = (n + kCrackBlock - 1u) / kCrackBlock;
+	uint32_t C = (n + BLOCK - 1u) / BLOCK;
 	C = max(16u, (C + 15u) & ~15u);
 	const uint32_t nchunks = (n + C - 1u) / C;
 	const uint32_t k0 = tid * C, k1 = min(n, k0 + C);
@@ -1211,6 +1213,8 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 	}
 	if (DIAG && tid == 0 && diag) diag[static_cast<uint64_t>(zi) * 16 + 4] = n_codes;
 }
+
+#include "ckl_crack_records.hpp"
 
 // ------------------------------------------------------------------------------
 // component -> label tables
@@ -1622,16 +1626,23 @@ __device__ __forceinline__ void paint_tile_groups(
 //    0.64 ms, the prologue is not amortised;
 //  * a persistent workgroup that loads two strips ahead of its stores: 0.50 ms (hipcc can only wait
 //    for the prefetched words with vmcnt(0), i.e. for all of the workgroup's stores).
+// The body works in `lds` (paint_strips_words<OUT>() 32-bit words, 16-byte aligned) on strip k of slice
+// zi (k_paint_strips; a body so that the LDS is one block the caller owns).
+template <typename OUT>
+constexpr uint32_t paint_strips_words() {
+	return (((kStripCap + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u + kStripWords + kStripWords / 2u + kWaves + 7u) & ~7u;
+}
 template <typename OUT, bool DIAG>
-__global__ void __launch_bounds__(kBlock) k_paint_strips(
-	RunGeom g, StripArrays sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag
+__device__ __forceinline__ void paint_strips_body(
+	const RunGeom& g, const StripArrays& sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag,
+	uint32_t zi, uint32_t k, uint32_t* lds
 ) {
 	typedef typename Vec4<OUT>::type V4;
-	__shared__ OUT s_lab[kStripCap];          // label of every run
-	__shared__ OUT s_tab[kPaintTable];        // labels of the strip's components (a strip with more reads them from memory)
-	__shared__ uint32_t s_b[kStripWords];
-	__shared__ uint16_t s_wb[kStripWords];
-	__shared__ uint32_t s_scan[kWaves];
+	OUT* s_lab = reinterpret_cast<OUT*>(lds);                // [kStripCap] label of every run
+	OUT* s_tab = s_lab + kStripCap;                          // [kPaintTable] labels of the strip's components (a strip with more reads them from memory)
+	uint32_t* s_b = lds + ((kStripCap + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u;
+	uint16_t* s_wb = reinterpret_cast<uint16_t*>(s_b + kStripWords);
+	uint32_t* s_scan = s_b + kStripWords + kStripWords / 2u;
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 	auto stamp = [&](int slot) {
 		if (DIAG && threadIdx.x == 0) {
@@ -1640,15 +1651,13 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 			d_t = now;
 		}
 	};
-	const uint32_t zi = blockIdx.y + sa.zbase;
-	const uint32_t k = blockIdx.x;
 	const uint32_t si = zi * sa.nstrips + k;
 	const uint32_t y0 = k * sa.strip_rows;
 	const uint32_t y1 = min(y0 + sa.strip_rows, g.sy);
 	const uint32_t rw = g.row_words, sx = g.sx;
 	const uint32_t nw = (y1 - y0) * rw;
 	const uint32_t t = threadIdx.x;
-	const uint64_t slot = (sa.ablate & 0x2000u) ? 0ull : static_cast<uint64_t>(si) * sa.cap;
+	const uint64_t slot = ablated(sa, 0x2000u) ? 0ull : static_cast<uint64_t>(si) * sa.cap;
 	// Two trips to memory in front of the stores, and as few bytes as possible: beside the stores
 	// every byte read costs several bytes' worth of store time (C2: 0.41 ms with every load of the
 	// strip, 0.34 ms with the loads pointed at one cached line; one trip or two made no difference).
@@ -1657,7 +1666,7 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	// load sits in a branch of its own (it would be waited for there): lanes past the end read entry 0.
 	uint32_t b[4];
 	{
-		const uint32_t* pv = (sa.ablate & 0x6000u) ? g.planeV : g.planeV + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+		const uint32_t* pv = ablated(sa, 0x6000u) ? g.planeV : g.planeV + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
 #pragma unroll
 		for (uint32_t j = 0; j < 4; j++) { const uint32_t wl = t * 4u + j; b[j] = pv[wl < nw ? wl : 0u]; }
 	}
@@ -1667,7 +1676,7 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	uint32_t lid[kStripRunsPerThread];
 	const OUT* lab = static_cast<const OUT*>(sa.sc_label) + slot;
 	{
-		const uint16_t* lp = sa.run_lid + ((sa.ablate & 0x8000u) ? 0ull : slot);
+		const uint16_t* lp = sa.run_lid + (ablated(sa, 0x8000u) ? 0ull : slot);
 #pragma unroll
 		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 			const uint32_t j = t + i * kBlock;
@@ -1723,7 +1732,7 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	const uint32_t ngroups = ((y1 - y0) * sx) >> 2;
 	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(y0) * sx;
 	// non-temporal stores: 0.39 against 0.41 ms at C2 (they lose 3 - 10 % in a kernel that only stores)
-	const bool nt = (sa.ablate & 0x800u) == 0, adjacent = (sa.ablate & 0x1000u) != 0;
+	const bool nt = !ablated(sa, 0x800u), adjacent = ablated(sa, 0x1000u);
 	constexpr uint32_t U = 4;
 	for (uint32_t g0 = 0; g0 < ngroups; g0 += kBlock * U) {
 		V4 val[U];
@@ -1741,7 +1750,7 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 			uint32_t run = s_wb[wl] + __popc(bw & mask_le(sh)) - 1u;
 			const uint32_t nib = ((bw >> sh) >> 1) & 7u;
 			at[u] = p;
-			if (sa.ablate & 0x400u) { val[u].x = val[u].y = val[u].z = val[u].w = static_cast<OUT>(run); continue; }
+			if (ablated(sa, 0x400u)) { val[u].x = val[u].y = val[u].z = val[u].w = static_cast<OUT>(run); continue; }
 			val[u].x = s_lab[run];
 			run += nib & 1u;        val[u].y = s_lab[run];
 			run += (nib >> 1) & 1u; val[u].z = s_lab[run];
@@ -1757,6 +1766,14 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 		}
 	}
 	stamp(2);
+}
+
+template <typename OUT, bool DIAG>
+__global__ void __launch_bounds__(kBlock) k_paint_strips(
+	RunGeom g, StripArrays sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag
+) {
+	__shared__ __attribute__((aligned(16))) uint32_t s_lds[paint_strips_words<OUT>()];
+	paint_strips_body<OUT, DIAG>(g, sa, out, sxy, diag, blockIdx.y + sa.zbase, blockIdx.x, s_lds);
 }
 
 // condensed pins on the strip path (labels.hpp:600-614): one thread per (pin, slice) pair
@@ -1916,7 +1933,10 @@ struct ckl_decoder {
 	uint64_t sxy = 0;
 
 	// device residents
-	DevBuf<uint8_t> d_stream;
+	DevBuf<uint8_t> d_stream;            // the whole stream (a view of the caller's buffer for ckl_decoder_create_device)
+	DevBuf<uint8_t> d_desc;              // the per-slice descriptor tables, one block, one upload
+	void* desc_staging = nullptr;        // pinned host image of d_desc (host_out_alloc), kept until the session dies
+	bool stream_resident = false;        // the stream was in HBM already: capacities come from the z-index alone
 	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off, d_rbase;
 	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap, d_rcap;
 	DevBuf<uint8_t> d_model, d_ctl_kind;
@@ -1948,6 +1968,15 @@ struct ckl_decoder {
 	DevBuf<uint64_t> d_sc_label;        // typed on use
 	DevBuf<unsigned long long> d_diag;
 	bool strip_ok = false;              // shape / layout qualify for the strip path
+	// crack records (ckl_crack_records.hpp): the strip path's front end
+	bool use_records = false;           // k_crack_records + rasterising strip kernel instead of k_decode_cracks
+	DevBuf<uint4> d_rec;
+	DevBuf<uint32_t> d_rec_count;
+	DevBuf<uint4> d_words, d_slice_info;      // WordRec per word of 16 code positions / SliceInfo per slice (k_crack_match -> k_crack_bin)
+	DevBuf<uint64_t> d_word_off;
+	uint32_t max_words = 0;             // most words of one slice
+	uint32_t rec_cap = 0, rec_lds_controls = 0;
+	size_t rec_lds = 0;
 	const uint64_t* foreign_label_map = nullptr;   // array_equal: component -> label table of ANOTHER stream (same component counts)
 	int paint_width = 0;                // array_equal: bytes per painted voxel when it is not this stream's data width
 	std::vector<uint32_t> ncomp_expect_host;       // components per slice of the range, as the label section states them
@@ -1981,6 +2010,7 @@ struct ckl_decoder {
 		for (auto& e : chunk_done) if (e) (void)hipEventDestroy(e);
 		for (auto& cs : chunk_stream) if (cs) (void)hipStreamDestroy(cs);
 		if (stream) (void)hipStreamDestroy(stream);
+		if (desc_staging) host_out_free(desc_staging);
 	}
 };
 
@@ -1991,6 +2021,32 @@ void upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t s) {
 	d.ensure(h.size());
 	if (!h.empty()) CKL_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
 }
+
+// The per-slice tables of a session go to the device as ONE block: every table is staged at its offset
+// of a pinned host image and the DevBufs become views of the block (a dozen separate copies from
+// pageable vectors cost more than the rest of ckl_decoder_create together).
+struct DescPacker {
+	struct Item { void* buf; size_t off, bytes, count; void (*bind)(void*, uint8_t*, size_t); };
+	std::vector<Item> items;
+	std::vector<uint8_t> image;
+	template <typename T>
+	void add(DevBuf<T>& dst, const std::vector<T>& src) {
+		const size_t off = (image.size() + 255) & ~static_cast<size_t>(255);
+		image.resize(off + std::max<size_t>(src.size(), 1) * sizeof(T));
+		if (!src.empty()) memcpy(image.data() + off, src.data(), src.size() * sizeof(T));
+		items.push_back({ &dst, off, src.size() * sizeof(T), src.size(),
+			[](void* b, uint8_t* base, size_t n) { static_cast<DevBuf<T>*>(b)->borrow(reinterpret_cast<T*>(base), n); } });
+	}
+	void commit(ckl_decoder& d, hipStream_t s) {
+		if (image.empty()) return;
+		d.d_desc.ensure(image.size());
+		if (d.desc_staging) host_out_free(d.desc_staging);
+		d.desc_staging = host_out_alloc(std::max<size_t>(image.size(), 64u << 10));      // >= 64 KiB: pinned
+		memcpy(d.desc_staging, image.data(), image.size());
+		CKL_HIP(hipMemcpyAsync(d.d_desc.p, d.desc_staging, image.size(), hipMemcpyHostToDevice, s));
+		for (const Item& it : items) it.bind(it.buf, d.d_desc.p + it.off, it.count);
+	}
+};
 
 // G[m] = x^32 + ... + x^(32 m) for m <= pixels of a slice (ckl_runs.hpp): 4 bytes per pixel, built by
 // one kernel launch and a stream sync.  Sessions are created per call by the one-shot API, so the
@@ -2039,7 +2095,10 @@ uint64_t read_stored(const Header& h, const uint8_t* lb, uint64_t offset) {
 	return v;
 }
 
-void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end) {
+// buf: the stream on the host — all of it, or (stream_device given: the stream is resident in HBM already
+// and stays the caller's) an image that holds header, z-index, label section head, markov model and crc
+// tail at their offsets and nothing of the crack codes.
+void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, const uint8_t* stream_device = nullptr) {
 	if (n < Header::kBytesV0) throw Error(CKL_ERR_FORMAT, "crackle: Input too small to be a valid stream. Bytes: " + std::to_string(n));
 	d.head = Header::parse(buf, n);
 	const Header& h = d.head;
@@ -2075,9 +2134,14 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	if (z_index[h.sz] > n || tail > n - z_index[h.sz]) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
 
 	hipStream_t s = d.stream;
-	// the whole stream goes to HBM once
-	d.d_stream.ensure(n + 16);
-	CKL_HIP(hipMemcpyAsync(d.d_stream.p, buf, n, hipMemcpyHostToDevice, s));
+	DescPacker pack;
+	d.stream_resident = stream_device != nullptr;
+	if (stream_device) d.d_stream.borrow(const_cast<uint8_t*>(stream_device), n);
+	else {
+		// the whole stream goes to HBM once
+		d.d_stream.ensure(n + 16);
+		CKL_HIP(hipMemcpyAsync(d.d_stream.p, buf, n, hipMemcpyHostToDevice, s));
+	}
 
 	// per-slice descriptors and scratch layout
 	const int xw = byte_width(static_cast<uint64_t>(h.sx) + 1);
@@ -2093,11 +2157,12 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		if (len > 0xFFFFFFF0ull / 8) throw Error(CKL_ERR_RUNTIME, "crackle_amd: crack code of a slice is too large");
 		code_off[zi] = z_index[z];
 		code_len[zi] = static_cast<uint32_t>(len);
-		const uint64_t index_size = len >= 4 ? rd_le(buf + z_index[z], 4) : 0;
+		// (a resident stream's BOC indices are not looked at here: capacities as if the code were all payload)
+		const uint64_t index_size = (len >= 4 && !stream_device) ? rd_le(buf + z_index[z], 4) : 0;
 		const uint64_t payload = (len >= 4 + index_size) ? len - 4 - index_size : 0;
 		// codes: 4 per byte (plain) or at most 8 per byte (+1 raw) for the markov bitstream
 		const uint64_t cap = (h.markov_model_order ? payload * 8 + 1 : payload * 4) + 2;
-		const uint64_t nodes_cap = std::min<uint64_t>(index_size, len) / xw + 1;
+		const uint64_t nodes_cap = std::min<uint64_t>(stream_device ? len : index_size, len) / xw + 1;
 		// runs: one per row plus one per vertical crack move (IMPERMISSIBLE), else up to one per pixel
 		const uint64_t runs_cap = permissible ? d.sxy : std::min<uint64_t>(d.sxy, static_cast<uint64_t>(h.sy) + cap);
 		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cap); ctot += cap;
@@ -2106,14 +2171,14 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		rbase[zi] = rtot; rcap[zi] = static_cast<uint32_t>(runs_cap); rtot += runs_cap;
 		d.max_rcap = std::max<uint32_t>(d.max_rcap, static_cast<uint32_t>(runs_cap));
 	}
-	upload(d.d_code_off, code_off, s);
-	upload(d.d_code_len, code_len, s);
-	upload(d.d_cbase, cbase, s);
-	upload(d.d_ccap, ccap, s);
-	upload(d.d_nbase, nbase, s);
-	upload(d.d_ncap, ncap, s);
-	upload(d.d_rbase, rbase, s);
-	upload(d.d_rcap, rcap, s);
+	pack.add(d.d_code_off, code_off);
+	pack.add(d.d_code_len, code_len);
+	pack.add(d.d_cbase, cbase);
+	pack.add(d.d_ccap, ccap);
+	pack.add(d.d_nbase, nbase);
+	pack.add(d.d_ncap, ncap);
+	pack.add(d.d_rbase, rbase);
+	pack.add(d.d_rcap, rcap);
 	std::vector<uint64_t> symbase(d.nslices, 0);
 	{
 		// symbols of multi-tile slices: (4 words per packed word + 3 counts) per thread and tile
@@ -2123,7 +2188,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 			const uint64_t tiles = static_cast<uint64_t>(ccap[zi]) / kCrackTile + 1;
 			if (tiles > 1) stot += tiles * (4 * kCrackWords + 3) * kCrackBlock;
 		}
-		upload(d.d_symbase, symbase, s);
+		pack.add(d.d_symbase, symbase);
 		d.d_symbuf.ensure(stot + 4);
 	}
 	std::vector<uint64_t> mkbase;
@@ -2132,7 +2197,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		mkbase.assign(d.nslices, 0);
 		uint64_t mtot = 0;
 		for (uint32_t zi = 0; zi < d.nslices; zi++) { mkbase[zi] = mtot; mtot += (code_len[zi] + 3ull) / 4 + 2 + ccap[zi] / 16 + 2; }
-		upload(d.d_mkbase, mkbase, s);
+		pack.add(d.d_mkbase, mkbase);
 		d.d_mkscratch.ensure(mtot + 4);
 	}
 	{
@@ -2147,7 +2212,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 
 	if (h.markov_model_order) {
 		std::vector<uint8_t> model = markov_model_from_stored(buf + hb + gib + h.num_label_bytes, h.markov_model_bytes(), h.markov_model_order);
-		upload(d.d_model, model, s);
+		pack.add(d.d_model, model);
 	}
 
 	d.row_words = (h.sx + 31) / 32;
@@ -2178,6 +2243,31 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 			d.d_sc_label.ensure(nst * d.strip_cap);
 			if (h.label_format != FLAT) d.d_sc_cc.ensure(nst * d.strip_cap);
 			d.d_overflow.ensure(1);
+			// crack records: vertices packed 16 + 16 bits, one LDS cursor per strip
+			d.use_records = h.sx <= kRecMaxDim && h.sy <= kRecMaxDim && d.nstrips <= kRecMaxStrips && d.rec_lds_controls > 0 && !getenv("CKL_DECODE_RASTER");
+			if (d.use_records) {
+				// a strip's list: one record per 16 codes that touch it, twice that for the records that
+				// straddle two strips and the stretches cut by 't' jumps; a list that still overflows
+				// sends the session to the rasterising kernel
+				const double per_strip = est_codes / 16.0 / (static_cast<double>(d.nslices) * d.nstrips);
+				uint32_t cap = static_cast<uint32_t>(std::min<double>(per_strip * 3.0 + 256.0, 65536.0));
+				if (const char* env = getenv("CKL_REC_CAP")) cap = static_cast<uint32_t>(std::max(1, atoi(env)));      // testing: forces the overflow hand-over
+				d.rec_cap = cap;
+				d.d_rec.ensure(nst * cap);
+				d.d_rec_count.ensure(nst);
+				// words of 16 code positions: k_crack_match deals a slice's codes out in tiles of kRecBlock x <= 8 words
+				std::vector<uint64_t> word_off(d.nslices);
+				uint64_t wtot = 0;
+				d.max_words = 0;
+				for (uint32_t zi = 0; zi < d.nslices; zi++) {
+					const uint32_t nw = (ccap[zi] / kRecTile + 1u) * kRecBlock * kRecWords;
+					word_off[zi] = wtot; wtot += nw;
+					d.max_words = std::max(d.max_words, nw);
+				}
+				pack.add(d.d_word_off, word_off);
+				d.d_words.ensure(wtot);
+				d.d_slice_info.ensure(d.nslices);
+			}
 		}
 	}
 	d.d_ncomp.ensure(d.nslices);
@@ -2226,8 +2316,8 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		ncomp_expect[zi] = static_cast<uint32_t>(c);
 		max_comp = std::max<uint32_t>(max_comp, static_cast<uint32_t>(c));
 	}
-	upload(d.d_comp_off, comp_off, s);
-	upload(d.d_ncomp_expect, ncomp_expect, s);
+	pack.add(d.d_comp_off, comp_off);
+	pack.add(d.d_ncomp_expect, ncomp_expect);
 	d.ncomp_expect_host = ncomp_expect;
 	d.d_label_map.ensure(d.total_comp + 1);
 
@@ -2248,7 +2338,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 			const uint32_t stored = static_cast<uint32_t>(rd_le(crcs + 4ull * (zs + zi), 4));
 			expect[zi] = (~stored) ^ init_term;
 		}
-		upload(d.d_crc_expect, expect, s);
+		pack.add(d.d_crc_expect, expect);
 	}
 	else {
 		d.d_crc_expect.ensure(d.nslices);
@@ -2303,7 +2393,9 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		upload(d.d_ccl_id, ccl_id, s);
 		upload(d.d_ccl_label, ccl_label, s);
 	}
-	CKL_HIP(hipStreamSynchronize(s));   // host vectors above go out of scope
+	pack.commit(d, s);
+	// the caller's host stream and the pin tables above are copied from memory that is not ours to keep
+	if (!stream_device || h.label_format != FLAT) CKL_HIP(hipStreamSynchronize(s));
 }
 
 struct StageTimer {
@@ -2426,7 +2518,7 @@ StripPlan strip_plan(ckl_decoder& d, int has_label, uint64_t label) {
 	sa.slice_err = d.d_slice_err.p; sa.overflow = d.d_overflow.p;
 	sa.nstrips = d.nstrips; sa.strip_rows = d.strip_rows; sa.cap = d.strip_cap; sa.zbase = 0;
 	sa.ablate = 0;
-	if (const char* env = getenv("CKL_ABLATE")) sa.ablate = static_cast<uint32_t>(strtoul(env, nullptr, 0));
+	if (kTuning) if (const char* env = getenv("CKL_ABLATE")) sa.ablate = static_cast<uint32_t>(strtoul(env, nullptr, 0));
 	ResolveArgs& ra = p.ra;
 	ra.idbits = d.idbits; ra.crc_fix = d.crc_fix; ra.check_crc = d.check_crc ? 1u : 0u;
 	ra.crc_expect = d.d_crc_expect.p; ra.ncomp_expect = d.d_ncomp_expect.p; ra.comp_off = d.d_comp_off.p;
@@ -2451,21 +2543,78 @@ void launch_cracks(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t z0, uin
 template <typename OUT>
 void launch_paint_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, const StripPlan& p, uint32_t n, void* out_device, unsigned long long* diag) {
 	const dim3 grid(d.nstrips, n);
-	if (diag) hipLaunchKernelGGL((k_paint_strips<OUT, true>), grid, dim3(kBlock), 0, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), diag + 16);
-	else hipLaunchKernelGGL((k_paint_strips<OUT, false>), grid, dim3(kBlock), 0, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), diag);
+	if constexpr (kTuning) {
+		if (diag) { hipLaunchKernelGGL((k_paint_strips<OUT, true>), grid, dim3(kBlock), 0, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), diag + 16); return; }
+	}
+	hipLaunchKernelGGL((k_paint_strips<OUT, false>), grid, dim3(kBlock), 0, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), static_cast<unsigned long long*>(nullptr));
 }
 
 // strips + resolve of slices [z0, z0 + n); flat labels also paint
+RecordLists record_lists(ckl_decoder& d) {
+	RecordLists rl;
+	rl.rec = d.d_rec.p; rl.count = d.d_rec_count.p; rl.cap = d.rec_cap;
+	rl.nstrips = d.nstrips; rl.strip_rows = d.strip_rows;
+	rl.strip_shift = 0xFFFFFFFFu;
+	for (uint32_t b = 0; b < 32; b++) if ((1u << b) == d.strip_rows) rl.strip_shift = b;
+	return rl;
+}
+
+// crack codes -> the strips' record lists (ckl_crack_records.hpp); also clears the session's error words
+void launch_crack_records(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t z0, uint32_t n, StageTimer* st) {
+	RecArgs ra;
+	ca.zbase = z0;
+	ra.c = ca;
+	ra.lists = record_lists(d);
+	ra.lds_controls = d.rec_lds_controls;
+	ra.lds_bytes = static_cast<uint32_t>(d.rec_lds);
+	ra.words = reinterpret_cast<WordRec*>(d.d_words.p);
+	ra.word_base = d.d_word_off.p;
+	ra.slice_info = reinterpret_cast<SliceInfo*>(d.d_slice_info.p);
+	ra.diag = nullptr;
+	if (kTuning && getenv("CKL_CRACK_DIAG")) {
+		d.d_diag.ensure(64);
+		CKL_HIP(hipMemsetAsync(d.d_diag.p + 32, 0, 32 * sizeof(unsigned long long), s));
+		ra.diag = d.d_diag.p + 32;
+	}
+	hipLaunchKernelGGL(k_crack_match, dim3(n), dim3(kRecBlock), d.rec_lds, s, ra);
+	if (st) st->done("k_crack_match");
+	hipLaunchKernelGGL(k_crack_bin, dim3((d.max_words + kBlock * kBinWords - 1) / (kBlock * kBinWords), n), dim3(kBlock), 0, s, ra);
+	if (st) st->done("k_crack_bin");
+	if (ra.diag) {
+		unsigned long long hd[32];
+		CKL_HIP(hipMemcpyAsync(hd, ra.diag, sizeof(hd), hipMemcpyDeviceToHost, s));
+		CKL_HIP(hipStreamSynchronize(s));
+		const double wg = static_cast<double>((d.max_words + kBlock * kBinWords - 1) / (kBlock * kBinWords)) * n;
+		fprintf(stderr, "[ckl crack diag, mean cycles] k_crack_match per slice: boc=%.0f symbols=%.0f record=%.0f match=%.0f (depth=%.0f tree=%.0f links=%.0f jump=%.0f seg=%.0f) | k_crack_bin per launched workgroup: load=%.0f count=%.0f reserve=%.0f write=%.0f\n",
+			hd[0] / double(n), hd[1] / double(n), hd[2] / double(n), hd[3] / double(n), hd[4] / double(n), hd[5] / double(n), hd[6] / double(n), hd[7] / double(n), hd[8] / double(n),
+			hd[16] / wg, hd[17] / wg, hd[18] / wg, hd[19] / wg);
+	}
+}
+
 template <typename OUT>
-void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p, uint32_t z0, uint32_t n, void* out_device, bool flat, StageTimer* st, unsigned long long* diag) {
+void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p, uint32_t z0, uint32_t n, void* out_device, bool flat, StageTimer* st, unsigned long long* diag, bool records) {
 	p.sa.zbase = z0;
 	const uint32_t npx = static_cast<uint32_t>(d.sxy);
-	if (diag) hipLaunchKernelGGL(k_strip_ccl<true>, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.G->p, npx, diag);
-	else hipLaunchKernelGGL(k_strip_ccl<false>, dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, d.G->p, npx, diag);
+	const RecordLists rl = record_lists(d);
+	bool launched = false;
+	if constexpr (kTuning) {
+		if (diag) {
+			if (records) hipLaunchKernelGGL((k_strip_ccl<true, true>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, diag);
+			else hipLaunchKernelGGL((k_strip_ccl<true, false>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, diag);
+			launched = true;
+		}
+	}
+	if (!launched) {
+		if (records) hipLaunchKernelGGL((k_strip_ccl<false, true>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, static_cast<unsigned long long*>(nullptr));
+		else hipLaunchKernelGGL((k_strip_ccl<false, false>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, static_cast<unsigned long long*>(nullptr));
+	}
 	if (st) st->done("k_strip_ccl");
 	if (flat) {
-		if (diag) hipLaunchKernelGGL((k_slice_resolve<OUT, true, true>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, diag + 8);
-		else hipLaunchKernelGGL((k_slice_resolve<OUT, true, false>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, diag);
+		bool done = false;
+		if constexpr (kTuning) {
+			if (diag) { hipLaunchKernelGGL((k_slice_resolve<OUT, true, true>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, diag + 8); done = true; }
+		}
+		if (!done) hipLaunchKernelGGL((k_slice_resolve<OUT, true, false>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, static_cast<unsigned long long*>(nullptr));
 	}
 	else hipLaunchKernelGGL((k_slice_resolve<OUT, false, false>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, static_cast<unsigned long long*>(nullptr));
 	if (st) st->done("k_slice_resolve");
@@ -2496,24 +2645,25 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 	const uint32_t chunks = decode_chunks(d);
 	if (chunks > 1) CKL_HIP(hipMemsetAsync(d.d_overflow.p, 0, sizeof(uint32_t), s));      // one chunk: the crack kernel clears it
 	unsigned long long* diag = nullptr;
-	if (getenv("CKL_STRIP_DIAG")) {      // cycle stamps of the strip kernels (adds a sync and a print)
-		d.d_diag.ensure(32);
+	if (kTuning && getenv("CKL_STRIP_DIAG")) {      // tuning builds: cycle stamps of the strip kernels (adds a sync and a print)
+		d.d_diag.ensure(64);
 		CKL_HIP(hipMemsetAsync(d.d_diag.p, 0, 32 * sizeof(unsigned long long), s));
 		diag = d.d_diag.p;
 	}
+	const bool records = d.use_records;
 	if (chunks <= 1 || diag) {
 		CrackArgs ca1 = ca;
 		if (chunks <= 1) ca1.overflow = d.d_overflow.p;
-		launch_cracks(d, s, ca1, 0, ns, crack_lds);
-		st.done("k_decode_cracks");
-		launch_strips<OUT>(d, s, g, p, 0, ns, out_device, flat, &st, diag);
+		if (records) launch_crack_records(d, s, ca1, 0, ns, &st);
+		else { launch_cracks(d, s, ca1, 0, ns, crack_lds); st.done("k_decode_cracks"); }
+		launch_strips<OUT>(d, s, g, p, 0, ns, out_device, flat, &st, diag, records);
 		if (diag) {
 			unsigned long long hd[32];
 			CKL_HIP(hipMemcpyAsync(hd, diag, sizeof(hd), hipMemcpyDeviceToHost, s));
 			CKL_HIP(hipStreamSynchronize(s));
 			const double nst = static_cast<double>(d.nstrips) * ns;
-			fprintf(stderr, "[ckl strip diag, mean cycles per workgroup] k_strip_ccl: load+scan=%.0f starts=%.0f unions=%.0f roots+ids=%.0f weights=%.0f | k_slice_resolve: tables=%.0f seams=%.0f rank=%.0f labels+crc=%.0f | k_paint_strips: words+scan=%.0f labels=%.0f paint=%.0f\n",
-				hd[0] / nst, hd[1] / nst, hd[2] / nst, hd[3] / nst, hd[4] / nst, hd[8] / double(ns), hd[9] / double(ns), hd[10] / double(ns), hd[11] / double(ns), hd[16] / nst, hd[17] / nst, hd[18] / nst);
+			fprintf(stderr, "[ckl strip diag, mean cycles per workgroup] k_strip_ccl: raster=%.0f load+scan=%.0f starts=%.0f unions=%.0f roots+ids=%.0f weights=%.0f | k_slice_resolve: tables=%.0f seams=%.0f rank=%.0f labels+crc=%.0f | k_paint_strips: words+scan=%.0f labels=%.0f paint=%.0f\n",
+				hd[5] / nst, hd[0] / nst, hd[1] / nst, hd[2] / nst, hd[3] / nst, hd[4] / nst, hd[8] / double(ns), hd[9] / double(ns), hd[10] / double(ns), hd[11] / double(ns), hd[16] / nst, hd[17] / nst, hd[18] / nst);
 		}
 	}
 	else {
@@ -2530,11 +2680,16 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 			if (!d.chunk_stream[c]) CKL_HIP(hipStreamCreateWithFlags(&d.chunk_stream[c], hipStreamNonBlocking));
 			if (!d.chunk_done[c]) CKL_HIP(hipEventCreateWithFlags(&d.chunk_done[c], hipEventDisableTiming));
 			hipStream_t cs = d.chunk_stream[c];
-			CKL_HIP(hipStreamWaitEvent(cs, d.ev_fork, 0));
-			launch_cracks(d, cs, ca, z0, n, crack_lds);
-			launch_strips<OUT>(d, cs, g, p, z0, n, out_device, flat, nullptr, nullptr);
-			CKL_HIP(hipEventRecord(d.chunk_done[c], cs));
-			CKL_HIP(hipStreamWaitEvent(s, d.chunk_done[c], 0));
+			const bool same_stream = getenv("CKL_DECODE_CHUNKS_SERIAL") != nullptr;      // experiment: the chunks one after the other on the session's stream
+			if (same_stream) cs = s;
+			else CKL_HIP(hipStreamWaitEvent(cs, d.ev_fork, 0));
+			if (records) launch_crack_records(d, cs, ca, z0, n, nullptr);
+			else launch_cracks(d, cs, ca, z0, n, crack_lds);
+			launch_strips<OUT>(d, cs, g, p, z0, n, out_device, flat, nullptr, nullptr, records);
+			if (!same_stream) {
+				CKL_HIP(hipEventRecord(d.chunk_done[c], cs));
+				CKL_HIP(hipStreamWaitEvent(s, d.chunk_done[c], 0));
+			}
 		}
 	}
 	if (!flat) {
@@ -2644,7 +2799,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	ra.nruns = d.d_nruns.p; ra.ncomp = d.d_ncomp.p; ra.slice_err = d.d_slice_err.p;
 
 	const bool paint = !stats && !planes_only && !errs_out;
-	const bool strips = paint && d.strip_ok && !d.use_general && !d.foreign_label_map && !d.paint_width && !getenv("CKL_DECODE_DIAG");
+	const bool strips = paint && d.strip_ok && !d.use_general && !d.foreign_label_map && !d.paint_width && !(kTuning && getenv("CKL_DECODE_DIAG"));
 	if (strips) {
 		// planes -> strips -> labels, z-chunk by z-chunk (ckl_strips.hpp)
 		if (has_label || h.data_width == 1) strip_pipeline<uint8_t>(d, ca, crack_lds, g, ra, out_device, has_label, label, st);
@@ -2653,7 +2808,9 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		else strip_pipeline<uint64_t>(d, ca, crack_lds, g, ra, out_device, has_label, label, st);
 	}
 	else {
-		if (getenv("CKL_DECODE_DIAG")) {
+		bool diag_launched = false;
+		if constexpr (kTuning) if (getenv("CKL_DECODE_DIAG")) {
+			diag_launched = true;
 			DevBuf<unsigned long long> d_diag;
 			d_diag.ensure(static_cast<size_t>(ns) * 16);
 			CKL_HIP(hipMemsetAsync(d_diag.p, 0, static_cast<size_t>(ns) * 128, s));
@@ -2665,7 +2822,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 			for (uint32_t zi = 0; zi < ns; zi++) for (int k = 0; k < 16; k++) m[k] += static_cast<double>(dg[zi * 16 + k]) / ns;
 			fprintf(stderr, "[ckl decode_cracks diag, mean cycles per slice] A(boc)=%.0f B(symbols+record)=%.0f C(match)=%.0f B.symbols=%.0f  codes=%.0f controls=%.0f | match: depth/lastT=%.0f gmin=%.0f links=%.0f jump=%.0f search steps total=%.0f max/thread=%.0f | raster: zero=%.0f symbols=%.0f moves=%.0f store=%.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[6], m[7], m[15]);
 		}
-		else launch_cracks(d, s, ca, 0, ns, crack_lds);
+		if (!diag_launched) launch_cracks(d, s, ca, 0, ns, crack_lds);
 		st.done("k_decode_cracks");
 
 		if (planes_only) {
@@ -2692,6 +2849,16 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	if (strips) CKL_HIP(hipMemcpyAsync(&overflow, d.d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	CKL_HIP(hipStreamSynchronize(s));
 	CKL_HIP(hipGetLastError());
+	if (strips && d.use_records) {
+		// a record list that did not fit (dense slices): this and all later runs of the session take the
+		// rasterising kernel; nothing of the run's output is kept
+		bool list_over = false;
+		for (uint32_t zi = 0; zi < ns; zi++) list_over = list_over || (errs[zi] & ERR_LIST);
+		if (list_over) {
+			d.use_records = false;
+			return decoder_run(d, out_device, out_capacity_bytes, has_label, label, stats, planes_only, errs_out);
+		}
+	}
 	if (strips && overflow) {
 		// a strip or a slice has more runs / strip components than the LDS tables of the strip path
 		// hold (dense, noisy labels): the general pipeline takes over from the planes, for this and
@@ -3118,38 +3285,137 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 
 extern "C" {
 
+// stream, events and kernel attributes of a new session; the caller builds it
+static std::unique_ptr<ckl_decoder> decoder_new(int device) {
+	select_device(device);
+	std::unique_ptr<ckl_decoder> d(new ckl_decoder());
+	d->device = device;
+	CKL_HIP(hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, device));
+	CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+	for (auto& e : d->ev) CKL_HIP(hipEventCreate(&e));
+	CKL_HIP(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
+	int max_lds = 0;
+	CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+	// the kernels' dynamic LDS limits are set once per device and size
+	static std::mutex mu;
+	static std::vector<std::pair<int, size_t>>& done = *new std::vector<std::pair<int, size_t>>();
+	auto once = [&](int key, size_t bytes) {
+		std::lock_guard<std::mutex> lock(mu);
+		const std::pair<int, size_t> k(device * 8 + key, bytes);
+		if (std::find(done.begin(), done.end(), k) != done.end()) return false;
+		done.push_back(k);
+		return true;
+	};
+	{
+		// LDS control tables of k_decode_cracks: as many symbols as the workgroup's LDS allows
+		const size_t budget = static_cast<size_t>(max_lds > 4096 ? max_lds - 4096 : 0);   // static LDS of the kernel: ~2.4 KiB
+		uint32_t nctl = 5120;
+		if (const char* env = getenv("CKL_LDS_CONTROLS")) nctl = static_cast<uint32_t>(std::max(0, atoi(env))) & ~63u;   // testing: forces the global tables (multiples of 64: 16-byte aligned tables)
+		while (nctl > 64 && crack_lds_bytes(nctl) > budget) nctl -= 64;
+		if (crack_lds_bytes(nctl) > budget) nctl = 0;
+		if (nctl > 32000) nctl = 32000;
+		d->lds_controls = nctl;
+		// one workgroup per CU either way: the raster phase takes whatever LDS is left for
+		// its bands (1024x1024 slices: 2 passes instead of 3)
+		d->lds_bytes = getenv("CKL_LDS_CONTROLS") ? crack_lds_bytes(nctl) : std::max(crack_lds_bytes(nctl), budget & ~static_cast<size_t>(15));
+		const int bytes = static_cast<int>(d->lds_bytes);
+		if (once(0, d->lds_bytes)) {
+			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+			if constexpr (kTuning) CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+		}
+	}
+	{
+		// k_crack_match: two workgroups per CU, each with half of the CU's LDS for its control tables
+		const size_t budget = static_cast<size_t>(max_lds / 2 > 4096 ? max_lds / 2 - 4096 : 0);      // static LDS of the kernel: ~1.5 KiB
+		uint32_t nctl = 8192;
+		if (const char* env = getenv("CKL_LDS_CONTROLS")) nctl = static_cast<uint32_t>(std::max(0, atoi(env))) & ~63u;   // testing: forces the global tables
+		while (nctl > 64 && rec_lds_bytes(nctl) > budget) nctl -= 64;
+		if (rec_lds_bytes(nctl) > budget) nctl = 0;
+		d->rec_lds_controls = nctl;
+		d->rec_lds = (rec_lds_bytes(nctl) + 15) & ~static_cast<size_t>(15);
+		// markov streams are expanded in the same LDS: give them all of the half
+		if (!getenv("CKL_LDS_CONTROLS")) d->rec_lds = std::max(d->rec_lds, budget & ~static_cast<size_t>(15));
+		if (nctl && once(1, d->rec_lds)) CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_crack_match), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(d->rec_lds)));
+	}
+	return d;
+}
+
 int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, int device, ckl_decoder** out) {
 	try {
 		if (!buf || !out) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
 		// header problems are format errors even when no device is present
 		if (n < Header::kBytesV0) throw Error(CKL_ERR_FORMAT, "crackle: Input too small to be a valid stream. Bytes: " + std::to_string(n));
 		(void)Header::parse(buf, n);
-		select_device(device);
-		std::unique_ptr<ckl_decoder> d(new ckl_decoder());
-		d->device = device;
-		CKL_HIP(hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, device));
-		CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-		for (auto& e : d->ev) CKL_HIP(hipEventCreate(&e));
-		CKL_HIP(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
-		{
-			// LDS control tables of k_decode_cracks: as many symbols as the workgroup's LDS allows
-			int max_lds = 0;
-			CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
-			const size_t budget = static_cast<size_t>(max_lds > 4096 ? max_lds - 4096 : 0);   // static LDS of the kernel: ~2.4 KiB
-			uint32_t nctl = 5120;
-			if (const char* env = getenv("CKL_LDS_CONTROLS")) nctl = static_cast<uint32_t>(std::max(0, atoi(env))) & ~63u;   // testing: forces the global tables (multiples of 64: 16-byte aligned tables)
-			while (nctl > 64 && crack_lds_bytes(nctl) > budget) nctl -= 64;
-			if (crack_lds_bytes(nctl) > budget) nctl = 0;
-			if (nctl > 32000) nctl = 32000;
-			d->lds_controls = nctl;
-			// one workgroup per CU either way: the raster phase takes whatever LDS is left for
-			// its bands (1024x1024 slices: 2 passes instead of 3)
-			d->lds_bytes = getenv("CKL_LDS_CONTROLS") ? crack_lds_bytes(nctl) : std::max(crack_lds_bytes(nctl), budget & ~static_cast<size_t>(15));
-			const int bytes = static_cast<int>(d->lds_bytes);
-			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-			CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_cracks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-		}
+		std::unique_ptr<ckl_decoder> d = decoder_new(device);
 		decoder_build(*d, buf, n, z_start, z_end);
+		*out = d.release();
+		return CKL_OK;
+	}
+	catch (const Error& e) { set_last_error(e.what()); return e.status; }
+	catch (const std::exception& e) { set_last_error(e.what()); return CKL_ERR_RUNTIME; }
+}
+
+// The stream is resident in HBM already (ckl_encoder_device_stream, or a caller that keeps streams on
+// the device): nothing is uploaded.  What the host has to see — header, z-index, the head of the label
+// section (the whole section of a pin stream), markov model, crc tail — comes back in three small
+// copies, each sized by the one before; the crack codes are never touched by the host.
+int ckl_decoder_create_device(const uint8_t* stream_device, uint64_t n, int64_t z_start, int64_t z_end, int device, ckl_decoder** out) {
+	try {
+		if (!stream_device || !out) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		if (n < Header::kBytesV0) throw Error(CKL_ERR_FORMAT, "crackle: Input too small to be a valid stream. Bytes: " + std::to_string(n));
+		const bool prof = getenv("CKL_PROFILE") != nullptr;
+		auto c0 = std::chrono::steady_clock::now();
+		std::vector<std::pair<const char*, double>> marks;
+		auto mark = [&](const char* name) { if (prof) { auto c1 = std::chrono::steady_clock::now(); marks.emplace_back(name, std::chrono::duration<double, std::milli>(c1 - c0).count()); c0 = c1; } };
+		std::unique_ptr<ckl_decoder> d = decoder_new(device);
+		mark("session");
+		hipStream_t s = d->stream;
+		wait_for_default_stream(s, d->ev_in);      // the caller may just have written the stream on the default stream
+		// sparse host image of the stream: only the ranges fetched below are ever read (decoder_build)
+		struct Image {
+			uint8_t* p = nullptr; uint64_t n = 0;
+			~Image() { if (p) host_out_free(p); }
+		} img;
+		img.n = n;
+		img.p = static_cast<uint8_t*>(host_out_alloc(n));
+		auto fetch = [&](uint64_t off, uint64_t len) {
+			if (off >= n || len == 0) return;
+			len = std::min<uint64_t>(len, n - off);
+			CKL_HIP(hipMemcpyAsync(img.p + off, stream_device + off, len, hipMemcpyDeviceToHost, s));
+		};
+		mark("image");
+		fetch(0, 64);      // header (and the start of the z-index)
+		CKL_HIP(hipStreamSynchronize(s));
+		mark("header");
+		const Header h = Header::parse(img.p, n);
+		if (!h.layout_fits(n)) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_code_offsets: Unable to read past end of buffer.");
+		const uint64_t hb = h.header_bytes(), gib = h.grid_index_bytes();
+		const uint64_t tail = h.format_version == 0 ? 0 : 4ull * (static_cast<uint64_t>(h.sz) + 1);
+		const int sw = h.stored_data_width;
+		const bool flat = h.label_format == FLAT;
+		// z-index, label section head (all of a pin section), model, crc tail
+		fetch(hb, gib + (flat ? 16 : h.num_label_bytes));
+		fetch(hb + gib + h.num_label_bytes, h.markov_model_bytes());
+		fetch(n - tail, tail);
+		CKL_HIP(hipStreamSynchronize(s));
+		if (flat && h.num_label_bytes >= 8 && static_cast<uint64_t>(h.sx) * h.sy) {
+			// component counts: behind the unique labels (labels.hpp:424-451)
+			const uint64_t nu = rd_le(img.p + hb + gib, 8);
+			const uint64_t cw = static_cast<uint64_t>(byte_width(static_cast<uint64_t>(h.sx) * h.sy));
+			if (nu <= (h.num_label_bytes - 8) / static_cast<uint64_t>(sw)) {
+				const uint64_t off = 8 + static_cast<uint64_t>(sw) * nu;
+				fetch(hb + gib + off, std::min<uint64_t>(cw * h.sz, h.num_label_bytes - std::min(off, h.num_label_bytes)));
+				CKL_HIP(hipStreamSynchronize(s));
+			}
+		}
+		mark("tables");
+		decoder_build(*d, img.p, n, z_start, z_end, stream_device);
+		mark("build");
+		if (prof) {
+			fprintf(stderr, "[ckl decoder_create_device host ms]");
+			for (auto& m : marks) fprintf(stderr, " %s=%.3f", m.first, m.second);
+			fprintf(stderr, "\n");
+		}
 		*out = d.release();
 		return CKL_OK;
 	}

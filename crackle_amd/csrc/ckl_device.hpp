@@ -8,29 +8,51 @@
 namespace ckl {
 namespace dev {
 
+// Tuning builds (-DCKL_TUNING, `python -m crackle_amd.build --tuning` -> libcrackle_amd_tuning.so) keep the
+// in-kernel cycle stamps (CKL_*_DIAG) and the ablation switches (CKL_ABLATE: parts of kernels skipped,
+// results wrong); the shipped library compiles both out.
+#ifdef CKL_TUNING
+constexpr bool kTuning = true;
+#else
+constexpr bool kTuning = false;
+#endif
+
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 constexpr int kWaves = kBlock / kWave;
 
 // ---- wavefront / block scans ---------------------------------------------------
+// Scans inside a wavefront run on the DPP data path (row_shr 1, 2, 4, 8 inside the rows of 16 lanes,
+// then row_bcast:15 / row_bcast:31 across them: the sequence LLVM's own atomic optimizer emits for
+// gfx9 wave64): seven VALU instructions.  hipcc lowers __shfl_up to ds_bpermute_b32, a round trip
+// through the LDS crossbar per step.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
+	return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(v), CTRL, ROW_MASK, 0xF, false));
+}
+constexpr int kDppRowShr = 0x110, kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138;
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
-	const int lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-	for (int d = 1; d < kWave; d <<= 1) {
-		uint32_t t = __shfl_up(v, d, kWave);
-		if (lane >= d) v += t;
-	}
+	v += dpp_u32<kDppRowShr + 1, 0xF>(0u, v);
+	v += dpp_u32<kDppRowShr + 2, 0xF>(0u, v);
+	v += dpp_u32<kDppRowShr + 4, 0xF>(0u, v);
+	v += dpp_u32<kDppRowShr + 8, 0xF>(0u, v);
+	v += dpp_u32<kDppBcast15, 0xA>(0u, v);
+	v += dpp_u32<kDppBcast31, 0xC>(0u, v);
 	return v;
 }
 __device__ __forceinline__ int32_t wave_incl_max(int32_t v) {
-	const int lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-	for (int d = 1; d < kWave; d <<= 1) {
-		int32_t t = __shfl_up(v, d, kWave);
-		if (lane >= d) v = t > v ? t : v;
-	}
+	auto mx = [](int32_t a, uint32_t b) { const int32_t c = static_cast<int32_t>(b); return c > a ? c : a; };
+	constexpr uint32_t id = 0x80000000u;      // INT32_MIN
+	v = mx(v, dpp_u32<kDppRowShr + 1, 0xF>(id, static_cast<uint32_t>(v)));
+	v = mx(v, dpp_u32<kDppRowShr + 2, 0xF>(id, static_cast<uint32_t>(v)));
+	v = mx(v, dpp_u32<kDppRowShr + 4, 0xF>(id, static_cast<uint32_t>(v)));
+	v = mx(v, dpp_u32<kDppRowShr + 8, 0xF>(id, static_cast<uint32_t>(v)));
+	v = mx(v, dpp_u32<kDppBcast15, 0xA>(id, static_cast<uint32_t>(v)));
+	v = mx(v, dpp_u32<kDppBcast31, 0xC>(id, static_cast<uint32_t>(v)));
 	return v;
 }
+// value of the lane below (lane 0 gets `first`)
+__device__ __forceinline__ uint32_t wave_shift_up1(uint32_t v, uint32_t first) { return dpp_u32<kDppWaveShr1, 0xF>(first, v); }
 __device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
 #pragma unroll
 	for (int d = kWave / 2; d >= 1; d >>= 1) v ^= __shfl_xor(v, d, kWave);
@@ -78,8 +100,7 @@ __device__ __forceinline__ int32_t block_excl_max(int32_t v, int32_t& total, int
 	const int wave = threadIdx.x >> 6;
 	const int32_t incl = wave_incl_max(v);
 	if (lane == kWave - 1) lds[wave] = incl;
-	int32_t excl = __shfl_up(incl, 1, kWave);
-	if (lane == 0) excl = INT32_MIN;
+	const int32_t excl = static_cast<int32_t>(wave_shift_up1(static_cast<uint32_t>(incl), 0x80000000u));      // lane 0: INT32_MIN
 	__syncthreads();
 	int32_t base = INT32_MIN, tot = INT32_MIN;
 #pragma unroll

@@ -877,6 +877,9 @@ struct ckl_encoder {
 	DevBuf<uint32_t> d_code_report;
 	uint64_t codes_capacity = 0;        // bound of all slices' BOC + payload bytes
 	bool defer_codes = false;           // ckl_encoder_defer_codes: the codes stay in d_codes_out for ckl_encoder_codes_to_host
+	bool keep_device_stream = false;    // ckl_encoder_keep_device_stream: every run also assembles the whole stream in HBM
+	DevBuf<uint8_t> d_stream_out;       // ... here (valid until the next run)
+	uint64_t device_stream_bytes = 0;
 	uint64_t last_codes_total = 0;      // bytes of the last run's crack codes
 	DevBuf<uint32_t> d_stack_node, d_stack_code;
 	DevBuf<uint32_t> d_chain_node, d_chain_off, d_chain_clen, d_chain_order, d_chain_dst, d_chain_vstart;
@@ -1217,7 +1220,7 @@ void crack_pass(
 		ta.cbase = e.d_cbase.p; ta.ccap = e.d_ccap.p; ta.cp = e.d_cp.p; ta.slice_err = e.d_slice_err.p;
 
 		ta.dbg = nullptr;
-		if (getenv("CKL_TRAIL_DIAG")) { d_tdbg.ensure(16); CKL_HIP(hipMemsetAsync(d_tdbg.p, 0, 128, s)); ta.dbg = d_tdbg.p; ta_dbg = d_tdbg.p; }
+		if (kTuning && getenv("CKL_TRAIL_DIAG")) { d_tdbg.ensure(16); CKL_HIP(hipMemsetAsync(d_tdbg.p, 0, 128, s)); ta.dbg = d_tdbg.p; ta_dbg = d_tdbg.p; }
 		ta.graph_blocks = e.graph_blocks; ta.blk_special = e.t_blk_special.p; ta.blk_corner = e.t_blk_corner.p;
 		int max_lds = 0;
 		CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, e.device));
@@ -1238,7 +1241,8 @@ void crack_pass(
 		// The serial k_trail_dfs keeps 1 wavefront per slice busy for ~2 ms while the chip idles.
 		// Slices can be processed in groups on their own streams (CKL_TRAIL_GROUPS): while one
 		// group is in its DFS the others run their parallel stages.
-		uint32_t groups = 1u;      // measured at C2: 2 groups -0.17 ms, 4 and 8 slower (the DFS wavefronts want their SIMDs to themselves); one launch keeps the per-launch accounting simple
+		// measured at C2: 2 groups -0.17 ms, 4 and 8 slower (the DFS wavefronts want their SIMDs to themselves)
+		uint32_t groups = ns >= 128u ? 2u : 1u;
 		if (const char* env = getenv("CKL_TRAIL_GROUPS")) groups = static_cast<uint32_t>(std::max(1, atoi(env)));
 		groups = std::min<uint32_t>(std::min<uint32_t>(groups, ns), kTrailStreams);
 		if (groups > 1) CKL_HIP(hipEventRecord(e.ev_fork, s));
@@ -1274,7 +1278,7 @@ void crack_pass(
 	}
 	CKL_HIP(hipEventRecord(e.evk1, s));
 	HT_MARK("c:enqueue");
-	if (getenv("CKL_TRAIL_DIAG")) {
+	if (kTuning && getenv("CKL_TRAIL_DIAG")) {
 		std::vector<uint32_t> c = download(e.t_counters.p, 5 * static_cast<size_t>(ns), s);
 		double m[5] = { 0 };
 		for (int k = 0; k < 5; k++) for (uint32_t zi = 0; zi < ns; zi++) m[k] += static_cast<double>(c[static_cast<size_t>(k) * ns + zi]) / ns;
@@ -1529,37 +1533,69 @@ PinCandidates pin_candidates_device(
 	std::vector<uint64_t> chosen = download(reinterpret_cast<const uint64_t*>(choice), N, s);
 
 	HT_MARK("p:d2h");
-	// every component's pin as an entry of its own (the same run may appear several times: a pin is
-	// taken at most once, since taking it removes every component that maps to it)
 	if (N >= kPinNone) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many pins");
-	const uint32_t P = static_cast<uint32_t>(N);
+	// The pins: by default every component's pin is an entry of its own (the same run may appear several
+	// times: a pin is taken at most once, since taking it removes every component that maps to it) and no
+	// sorting is needed.  The ids of a run are then stored once per component that chose it — volumes
+	// with long z-runs could reach N x sz ids — so when the entries' ids pass a budget the chosen runs
+	// are reduced to the distinct ones first (a sort of the keys on the host).
+	uint32_t P = static_cast<uint32_t>(N);
+	std::vector<uint64_t> pin_key(chosen);      // key of pin p (identity mapping: the component's choice)
 	pc.comp_pin.assign(N, kPinNone);
+	for (uint32_t c = 0; c < P; c++) if (chosen[c] != kPinNoKey) pc.comp_pin[c] = c;
+	{
+		DevBuf<uint32_t> d_ze0;
+		d_ze0.ensure(P);
+		CKL_HIP(hipMemsetAsync(d_ze0.p, 0, static_cast<size_t>(P) * sizeof(uint32_t), s));
+		hipLaunchKernelGGL((k_pin_extent<LABEL, false>), dim3((P + kPinBlock - 1) / kPinBlock), dim3(kPinBlock), 0, s, labels, v, choice, P, d_ze0.p);
+		pc.pin_ze = download(d_ze0.p, P, s);
+	}
+	uint64_t id_total = 0;
+	for (uint32_t c = 0; c < P; c++) if (chosen[c] != kPinNoKey) id_total += pc.pin_ze[c] - static_cast<uint32_t>(chosen[c] % v.sz) + 1u;
+	uint64_t id_budget = 1ull << 26;      // 256 MiB of ids
+	if (const char* env = getenv("CKL_PIN_IDS_BUDGET")) id_budget = static_cast<uint64_t>(std::max(0, atoi(env)));      // testing: forces the distinct-pin path
+	DevBuf<unsigned long long> d_key2;
+	const unsigned long long* key_dev = choice;
+	if (id_total > id_budget) {
+		std::vector<uint32_t> order;
+		order.reserve(P);
+		for (uint32_t c = 0; c < P; c++) if (chosen[c] != kPinNoKey) order.push_back(c);
+		std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return chosen[a] != chosen[b] ? chosen[a] < chosen[b] : a < b; });
+		std::vector<uint64_t> keys2;
+		std::vector<uint32_t> ze2;
+		for (size_t i = 0; i < order.size(); i++) {
+			const uint32_t c = order[i];
+			if (i == 0 || chosen[c] != chosen[order[i - 1]]) { keys2.push_back(chosen[c]); ze2.push_back(pc.pin_ze[c]); }
+			pc.comp_pin[c] = static_cast<uint32_t>(keys2.size() - 1);
+		}
+		pin_key.swap(keys2);
+		pc.pin_ze.swap(ze2);
+		P = static_cast<uint32_t>(pin_key.size());
+		d_key2.ensure(std::max<size_t>(P, 1));
+		if (P) CKL_HIP(hipMemcpyAsync(d_key2.p, pin_key.data(), static_cast<size_t>(P) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+		key_dev = d_key2.p;
+	}
 	pc.pin_x.assign(P, 0); pc.pin_y.assign(P, 0); pc.pin_zs.assign(P, 0);
-	for (uint32_t c = 0; c < P; c++) {
-		if (chosen[c] == kPinNoKey) continue;
-		pc.comp_pin[c] = c;
-		const uint64_t col = chosen[c] / v.sz;
-		pc.pin_zs[c] = static_cast<uint32_t>(chosen[c] % v.sz);
-		pc.pin_x[c] = static_cast<uint32_t>(col % v.sx);
-		pc.pin_y[c] = static_cast<uint32_t>(col / v.sx);
+	for (uint32_t p = 0; p < P; p++) {
+		if (pin_key[p] == kPinNoKey) continue;
+		const uint64_t col = pin_key[p] / v.sz;
+		pc.pin_zs[p] = static_cast<uint32_t>(pin_key[p] % v.sz);
+		pc.pin_x[p] = static_cast<uint32_t>(col % v.sx);
+		pc.pin_y[p] = static_cast<uint32_t>(col / v.sx);
 	}
 	HT_MARK("p:keys");
 	pc.pin_ids_off.assign(static_cast<size_t>(P) + 1, 0);
 	{
 		DevBuf<uint64_t> d_off;
 		DevBuf<uint32_t> d_ze, d_ids;
-		d_ze.ensure(P);
-		CKL_HIP(hipMemsetAsync(d_ze.p, 0, static_cast<size_t>(P) * sizeof(uint32_t), s));
-		const dim3 pgrid((P + kPinBlock - 1) / kPinBlock);
-		hipLaunchKernelGGL((k_pin_extent<LABEL, false>), pgrid, dim3(kPinBlock), 0, s, labels, v, choice, P, d_ze.p);
-		pc.pin_ze = download(d_ze.p, P, s);
-		for (uint32_t c = 0; c < P; c++) {
-			if (chosen[c] == kPinNoKey) { pc.pin_ze[c] = pc.pin_zs[c]; pc.pin_ids_off[c + 1] = pc.pin_ids_off[c]; }
-			else pc.pin_ids_off[c + 1] = pc.pin_ids_off[c] + (pc.pin_ze[c] - pc.pin_zs[c] + 1u);
+		for (uint32_t p = 0; p < P; p++) {
+			if (pin_key[p] == kPinNoKey) { pc.pin_ze[p] = pc.pin_zs[p]; pc.pin_ids_off[p + 1] = pc.pin_ids_off[p]; }
+			else pc.pin_ids_off[p + 1] = pc.pin_ids_off[p] + (pc.pin_ze[p] - pc.pin_zs[p] + 1u);
 		}
 		upload(d_off, pc.pin_ids_off, s);
+		upload(d_ze, pc.pin_ze, s);
 		d_ids.ensure(pc.pin_ids_off[P] + 1);
-		hipLaunchKernelGGL(k_pin_ids, pgrid, dim3(kPinBlock), 0, s, v, choice, d_ze.p, d_off.p, P, d_ids.p);
+		if (P) hipLaunchKernelGGL(k_pin_ids, dim3((P + kPinBlock - 1) / kPinBlock), dim3(kPinBlock), 0, s, v, key_dev, d_ze.p, d_off.p, P, d_ids.p);
 		pc.pin_ids = download(d_ids.p, pc.pin_ids_off[P], s);
 	}
 	// the labels with the key of their first column run
@@ -1849,6 +1885,23 @@ void encode_typed(
 		if (!stored_model.empty()) memcpy(o + off_model, stored_model.data(), stored_model.size());
 		for (int64_t z = 0; z < sz; z++) put4(off_tail + 4 + 4ull * z, fr.crcs[z]);
 		put4(off_tail, labels_crc);
+		e.device_stream_bytes = 0;
+		if (e.keep_device_stream) {
+			// the same bytes once more in HBM, for a decoder that takes its stream from the device
+			// (ckl_decoder_create_device): the two bulky sections are device-to-device copies, the small
+			// ones go up from the host buffer
+			e.d_stream_out.ensure(total + 16);
+			uint8_t* ds = e.d_stream_out.p;
+			CKL_HIP(hipMemcpyAsync(ds, o, off_labels, hipMemcpyHostToDevice, s));
+			if (label_bytes) {
+				if (head.label_format == FLAT) CKL_HIP(hipMemcpyAsync(ds + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToDevice, s));
+				else CKL_HIP(hipMemcpyAsync(ds + off_labels, o + off_labels, label_bytes, hipMemcpyHostToDevice, s));
+			}
+			if (!stored_model.empty()) CKL_HIP(hipMemcpyAsync(ds + off_model, o + off_model, stored_model.size(), hipMemcpyHostToDevice, s));
+			if (cr.total) CKL_HIP(hipMemcpyAsync(ds + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToDevice, s));
+			CKL_HIP(hipMemcpyAsync(ds + off_tail, o + off_tail, 4ull * (sz + 1), hipMemcpyHostToDevice, s));
+			e.device_stream_bytes = total;
+		}
 		ht.mark("assembly");
 		CKL_HIP(hipEventRecord(e.ev1, s));
 		CKL_HIP(hipStreamSynchronize(s));
@@ -2043,6 +2096,20 @@ int ckl_reencode_markov(const uint8_t* buf, uint64_t n, int markov_model_order, 
 int ckl_encoder_defer_codes(ckl_encoder* e, int defer) {
 	if (!e) { set_last_error("crackle_amd: null encoder"); return CKL_ERR_ARG; }
 	e->defer_codes = defer != 0;
+	return CKL_OK;
+}
+
+int ckl_encoder_keep_device_stream(ckl_encoder* e, int keep) {
+	if (!e) { set_last_error("crackle_amd: null encoder"); return CKL_ERR_ARG; }
+	e->keep_device_stream = keep != 0;
+	return CKL_OK;
+}
+
+int ckl_encoder_device_stream(const ckl_encoder* e, const uint8_t** stream_device, uint64_t* n_bytes) {
+	if (!e || !stream_device || !n_bytes) { set_last_error("crackle_amd: null argument"); return CKL_ERR_ARG; }
+	if (!e->device_stream_bytes) { set_last_error("crackle_amd: no device-resident stream (ckl_encoder_keep_device_stream before the run)"); return CKL_ERR_ARG; }
+	*stream_device = e->d_stream_out.p;
+	*n_bytes = e->device_stream_bytes;
 	return CKL_OK;
 }
 

@@ -22,6 +22,7 @@ enum : uint32_t {
 	ERR_CAPACITY = 4u,     // scratch capacity exceeded
 	ERR_NCOMP = 8u,        // component count differs from the label section
 	ERR_CRC = 16u,         // crc32c of the component image differs from the stored one
+	ERR_LIST = 32u,        // a strip's record list overflowed (k_crack_records): not an error of the stream, the rasterising path takes over
 };
 
 // ------------------------------------------------------------------------------

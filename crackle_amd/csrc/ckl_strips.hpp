@@ -58,25 +58,84 @@ struct StripArrays {
 	uint32_t ablate;           // tuning aid (CKL_ABLATE): skips parts of the strip kernels, results are wrong
 };
 
+// tuning builds only: is part `mask` of a strip kernel switched off (CKL_ABLATE)
+__device__ __forceinline__ bool ablated(const StripArrays& sa, uint32_t mask) { return kTuning && (sa.ablate & mask) != 0u; }
+
 // strip component of run j of a strip with nsc components: stored in one byte while nsc <= 256
 __device__ __forceinline__ uint32_t strip_lid(const uint16_t* slot_lids, uint32_t nsc, uint32_t j) {
 	return nsc <= 256u ? reinterpret_cast<const uint8_t*>(slot_lids)[j] : slot_lids[j];
+}
+
+// ---- crack records (k_crack_records, ckl_crack_records.hpp) -----------------------------------------
+// the lists the records go to: one slot of `cap` records per strip
+struct RecordLists {
+	uint4* rec;                  // [strips of all slices][cap]
+	uint32_t* count;             // [strips of all slices]
+	uint32_t cap;                // records per list
+	uint32_t nstrips, strip_rows;
+	uint32_t strip_shift;        // log2(strip_rows) when it is a power of two, else 0xFFFFFFFF
+	__device__ __forceinline__ uint32_t strip_of(uint32_t y) const { return strip_shift != 0xFFFFFFFFu ? y >> strip_shift : y / strip_rows; }
+};
+
+// Walks one record — x: the vertex before its first move, packed y << 16 | x; y: the 16 moves of its
+// word, 2 bits each (0 up, 1 right, 2 down, 3 left); z: bit 2k set when position k emits its move, bit
+// 2k + 1 when position k is a 't' (at most one per record): the walk jumps by w there — and sets the
+// cracks its moves cross in rows [y0, y0 + rows) of the strip's plane pieces in LDS
+// (crackcodes.hpp:706-862: a vertical move crosses plane V, a horizontal one plane H, at the smaller of
+// its two vertices; moves along the outer border cross nothing).  `bad` is raised when a move leaves the
+// vertex grid.
+__device__ __forceinline__ void raster_record(
+	const uint4 rec, uint32_t y0, uint32_t rows, uint32_t sx, uint32_t sy, uint32_t rw, uint32_t* sV, uint32_t* sH, uint32_t& bad
+) {
+	uint32_t p = rec.x;
+	const uint32_t jump = rec.z & 0xAAAAAAAAu;
+#pragma unroll
+	for (uint32_t k = 0; k < 16; k++) {
+		if ((jump >> (2u * k + 1u)) & 1u) p += rec.w;
+		if (((rec.z >> (2u * k)) & 1u) == 0u) continue;
+		const uint32_t kind = (rec.y >> (2u * k)) & 3u;
+		const uint32_t horiz = kind & 1u;
+		const uint32_t unit = horiz ? 1u : 0x10000u;
+		const uint32_t neg = ((kind ^ (kind >> 1)) & 1u) ^ 1u;      // up (0) and left (3)
+		const uint32_t q = neg ? p - unit : p + unit;
+		const uint32_t c = p < q ? p : q;
+		const uint32_t col = c & 0xFFFFu, row = c >> 16;
+		const uint32_t qx = q & 0xFFFFu, qy = q >> 16;
+		if (qx > sx || qy > sy) bad |= 1u;
+		else {
+			const bool ok = horiz ? (row - 1u < sy - 1u && col < sx) : (col - 1u < sx - 1u && row < sy);
+			const uint32_t rel = row - y0;
+			if (ok && rel < rows) atomicOr((horiz ? sH : sV) + rel * rw + (col >> 5), 1u << (col & 31u));
+		}
+		p = q;
+	}
 }
 
 // grid = (nstrips, slices of the launch), block = kBlock.  The kernel waits on LDS round trips
 // (union-find), so what counts is the number of resident wavefronts: <= 72 registers and 22 KiB of
 // LDS keep seven workgroups on a CU.  (A persistent variant that fetched the next strip's words
 // while working on the current one needed 113 registers and was slower: 0.36 against 0.29 ms.)
-template <bool DIAG>
-static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, StripArrays sa, const uint32_t* __restrict__ G, uint32_t n_pixels, unsigned long long* __restrict__ diag) {
-	__shared__ uint32_t s_parent[kStripCap];          // union-find, then the crc weights per strip component
-	__shared__ uint32_t s_mem[kStripEdgeCap];         // s_b | s_pool, and over both of them the edge list of the unions
-	__shared__ uint16_t s_wb[kStripWords];            // runs before each word
+// RECORDS: the strip's plane pieces are rasterised here, in LDS, from the strip's list of crack records
+// (k_crack_records) and written to the planes in HBM on the way (the paint kernel and the seams of
+// k_slice_resolve read them there); otherwise they are read from the planes k_decode_cracks left.
+// The body works in `lds` (kStripCclWords 32-bit words, 16-byte aligned) on strip k of slice zi, so that
+// the caller owns the block (a launch mixing stages of different slice groups was tried: DESIGN.md section 10).
+constexpr uint32_t kStripCclWords = (kStripCap + kStripEdgeCap + kStripWords / 2 + 2 * kStripBitmapWords + kWaves + 2 + 7) & ~7u;
+template <bool DIAG, bool RECORDS>
+__device__ __forceinline__ void strip_ccl_body(
+	const RunGeom& g, const StripArrays& sa, const RecordLists& rl, const uint32_t* __restrict__ G, uint32_t n_pixels, unsigned long long* __restrict__ diag,
+	uint32_t zi, uint32_t k, uint32_t* lds
+) {
+	uint32_t* s_parent = lds;                         // union-find, then the crc weights per strip component (RECORDS: first the piece of plane H)
+	uint32_t* s_mem = s_parent + kStripCap;           // s_b | s_pool, and over both of them the edge list of the unions
+	uint16_t* s_wb = reinterpret_cast<uint16_t*>(s_mem + kStripEdgeCap);          // runs before each word
 	uint32_t* s_b = s_mem;                                                        // break words of the strip
 	uint16_t* s_pool = reinterpret_cast<uint16_t*>(s_mem + kStripWords);          // first pixel of each run (relative to the strip), later its strip component
-	__shared__ uint32_t s_bm[kStripBitmapWords], s_bmbase[kStripBitmapWords];
-	__shared__ uint32_t s_scan[kWaves];
-	__shared__ uint32_t s_misc[2];
+	uint32_t* s_bm = s_mem + kStripEdgeCap + kStripWords / 2;
+	uint32_t* s_bmbase = s_bm + kStripBitmapWords;
+	uint32_t* s_scan = s_bmbase + kStripBitmapWords;
+	uint32_t* s_misc = s_scan + kWaves;
+	static_assert((kStripCap * 4) % 16 == 0 && (kStripEdgeCap * 4) % 16 == 0, "tables stay 16-byte aligned");
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 	auto stamp = [&](int slot) {
 		if (DIAG && threadIdx.x == 0) {
@@ -87,8 +146,6 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 	};
 	const uint32_t rw = g.row_words;
 	const uint32_t t = threadIdx.x;
-	const uint32_t zi = blockIdx.y + sa.zbase;
-	const uint32_t k = blockIdx.x;
 	const uint32_t si = zi * sa.nstrips + k;
 	const uint32_t y0 = k * sa.strip_rows;
 	const uint32_t y1 = min(y0 + sa.strip_rows, g.sy);
@@ -97,7 +154,44 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 	// ---- plane words: every load is issued at once, none sits in a branch (a load inside a branch
 	// is waited for there); words past the strip read word 0
 	uint32_t b[4], up[4], upl[4], cnt = 0;
-	{
+	if (RECORDS) {
+		// the strip's records -> its pieces of the two planes, in LDS (s_mem: plane V, later the break
+		// words; s_parent: plane H, dead once the words are in registers)
+		static_assert(kStripCap >= kStripWords, "plane H piece is built in the union-find table");
+		uint32_t* sV = s_mem;
+		uint32_t* sH = s_parent;
+		const uint32_t n_rec = min(rl.count[si], rl.cap);
+		const uint4* list = rl.rec + static_cast<uint64_t>(si) * rl.cap;
+		uint4 first = list[t < rl.cap ? t : 0u];      // requested with the count, not behind it
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) { sV[t * 4u + j] = 0u; sH[t * 4u + j] = 0u; }
+		__syncthreads();
+		uint32_t bad = 0;
+		if (t < n_rec) raster_record(first, y0, y1 - y0, g.sx, g.sy, rw, sV, sH, bad);
+		for (uint32_t r = t + kBlock; r < n_rec; r += kBlock) raster_record(list[r], y0, y1 - y0, g.sx, g.sy, rw, sV, sH, bad);
+		if (bad) atomicOr(sa.slice_err + zi, ERR_RANGE);
+		__syncthreads();
+		stamp(5);
+		const uint4 v4 = *reinterpret_cast<const uint4*>(sV + t * 4u);
+		const uint4 h4 = *reinterpret_cast<const uint4*>(sH + t * 4u);
+		b[0] = v4.x; b[1] = v4.y; b[2] = v4.z; b[3] = v4.w;
+		up[0] = h4.x; up[1] = h4.y; up[2] = h4.z; up[3] = h4.w;
+		upl[0] = sH[t ? t * 4u - 1u : 0u];
+		// planes to HBM: 16 bytes per thread, the strip's rows are contiguous
+		if (t * 4u < nw) {
+			uint32_t* pv = const_cast<uint32_t*>(g.planeV) + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+			uint32_t* ph = const_cast<uint32_t*>(g.planeH) + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+			if (t * 4u + 4u <= nw) {
+				*reinterpret_cast<uint4*>(pv + t * 4u) = v4;
+				*reinterpret_cast<uint4*>(ph + t * 4u) = h4;
+			}
+			else {
+				for (uint32_t j = 0; t * 4u + j < nw; j++) { pv[t * 4u + j] = b[j]; ph[t * 4u + j] = up[j]; }
+			}
+		}
+		__syncthreads();      // every read of the pieces is done: s_mem / s_parent take their tables
+	}
+	else {
 		const uint32_t* pv = g.planeV + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
 		const uint32_t* ph = g.planeH + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
 #pragma unroll
@@ -160,7 +254,7 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 #pragma unroll
 		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 			const uint32_t j = t + i * kBlock;
-			gv[i] = G[(sa.ablate & 4u) ? j : n_pixels - (p0 + s_pool[j < nloc ? j : 0u])];
+			gv[i] = G[ablated(sa, 4u) ? j : n_pixels - (p0 + s_pool[j < nloc ? j : 0u])];
 		}
 	}
 	// per-row and seam tables
@@ -188,7 +282,7 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 			const uint32_t wl = t * 4u + j;
 			const uint32_t above = up[j] ? wl - rw : 0u;
 			b_up[j] = s_b[above]; base_up[j] = s_wb[above]; base_here[j] = s_wb[wl < nw ? wl : 0u];
-			c[j] = (sa.ablate & 1u) ? 0u : up[j] & (~((up[j] << 1) | (upl[j] >> 31)) | b[j] | b_up[j]);
+			c[j] = ablated(sa, 1u) ? 0u : up[j] & (~((up[j] << 1) | (upl[j] >> 31)) | b[j] | b_up[j]);
 			n_e += __popc(c[j]);
 		}
 		uint32_t ve[1] = { n_e }, te[1];
@@ -261,7 +355,7 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 #pragma unroll
 	for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 		const uint32_t j = t + i * kBlock;
-		if (j >= nloc || (sa.ablate & 2u)) break;
+		if (j >= nloc || ablated(sa, 2u)) break;
 		atomicXor(s_parent + s_pool[j], gv[i]);
 		if (j) atomicXor(s_parent + s_pool[j - 1], gv[i]);
 	}
@@ -271,6 +365,12 @@ static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, Strip
 	for (uint32_t j = t; j < nsc; j += kBlock) w_out[j] = s_parent[j];
 	if (t == 0) { sa.strip_nruns[si] = nloc; sa.strip_nsc[si] = nsc; }
 	stamp(4);
+}
+
+template <bool DIAG, bool RECORDS>
+static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl(RunGeom g, StripArrays sa, RecordLists rl, const uint32_t* __restrict__ G, uint32_t n_pixels, unsigned long long* __restrict__ diag) {
+	__shared__ __attribute__((aligned(16))) uint32_t s_lds[kStripCclWords];
+	strip_ccl_body<DIAG, RECORDS>(g, sa, rl, G, n_pixels, diag, blockIdx.y + sa.zbase, blockIdx.x, s_lds);
 }
 
 // what k_slice_resolve needs besides the strips
@@ -293,12 +393,16 @@ struct ResolveArgs {
 // grid = slices of the launch, block = kResolveBlock
 // LABELS: flat labels (label_map is ready): the label of every strip component is written here.
 // Otherwise its component id goes to sc_cc (pins: the label table needs the ids first).
+// Registers: nothing per strip component survives a barrier — roots keep their index in the low 16 bits
+// of their table entry and get their rank in the high 16 (kResolveCap <= 65535) — so that two
+// workgroups of 1024 share a CU (<= 64 registers) and all slices of a 512-slice volume run at once.
 template <typename OUT, bool LABELS, bool DIAG>
-static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom g, StripArrays sa, ResolveArgs ra, uint32_t* __restrict__ ncomp_out, unsigned long long* __restrict__ diag) {
+static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGeom g, StripArrays sa, ResolveArgs ra, uint32_t* __restrict__ ncomp_out, unsigned long long* __restrict__ diag) {
 	__shared__ uint32_t s_tab[kResolveCap];
 	__shared__ uint32_t s_scbase[kMaxStrips + 1];
 	__shared__ uint32_t s_scan[kResolveBlock / kWave];
 	__shared__ uint32_t s_flag;
+	static_assert(kResolveCap <= 0xFFFFu, "index and rank share a table entry");
 	constexpr int NW = kResolveBlock / kWave;
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 	auto stamp = [&](int slot) {
@@ -355,8 +459,6 @@ static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom 
 		if (t == 0) atomicOr(sa.overflow, 1u);
 		return;
 	}
-	const uint32_t per = (total + kResolveBlock - 1) / kResolveBlock;      // <= kResolvePer
-	const uint32_t i0 = min(total, t * per), i1 = min(total, i0 + per);
 	for (uint32_t i = t; i < total; i += kResolveBlock) s_tab[i] = i;
 	__syncthreads();
 	stamp(0);
@@ -382,77 +484,75 @@ static __global__ void __launch_bounds__(kResolveBlock) k_slice_resolve(RunGeom 
 	}
 	__syncthreads();
 	stamp(1);
-	// ---- roots ranked in index order = raster order of the components' first pixels
-	uint32_t root[kResolvePer], nroot = 0;
-#pragma unroll
-	for (uint32_t q = 0; q < kResolvePer; q++) {
-		const uint32_t i = i0 + q;
-		root[q] = i < i1 ? sm_find(s_tab, i) : 0u;
-		nroot += (i < i1 && root[q] == i) ? 1u : 0u;
-	}
-	// the crc weights are requested before the scan's barriers
-	uint32_t wgt[kResolvePer];
-	uint64_t gi[kResolvePer];
-	{
-		uint32_t s = 0;
-		if (i0 < i1) {      // strip of my first entry
-			uint32_t lo = 0, hi = ns;
-			while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_scbase[mid] <= i0) lo = mid; else hi = mid; }
-			s = lo;
-		}
-#pragma unroll
-		for (uint32_t q = 0; q < kResolvePer; q++) {
-			const uint32_t i = i0 + q;
-			wgt[q] = 0; gi[q] = 0;
-			if (i >= i1) continue;
-			while (s + 1 < ns && s_scbase[s + 1] <= i) s++;
-			gi[q] = static_cast<uint64_t>(si0 + s) * sa.cap + (i - s_scbase[s]);
-			wgt[q] = sa.sc_w[gi[q]];
-		}
+	// ---- every entry -> its root (a racing find only ever meets ancestors); the roots ranked in index order =
+	// raster order of the components' first pixels
+	const uint32_t per = (total + kResolveBlock - 1) / kResolveBlock;      // <= kResolvePer
+	const uint32_t i0 = min(total, t * per), i1 = min(total, i0 + per);
+	for (uint32_t i = i0; i < i1; i++) sm_store(s_tab, i, sm_find(s_tab, i));
+	__syncthreads();
+	uint32_t nroot = 0;
+	for (uint32_t i = i0; i < i1; i++) nroot += s_tab[i] == i ? 1u : 0u;
+	// the crc weights of the first entries are requested before the scan's barriers
+	constexpr uint32_t kPer = 4;
+	uint32_t strip0 = 0;
+	if (i0 < i1) {      // strip of my first entry
+		uint32_t lo = 0, hi = ns;
+		while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_scbase[mid] <= i0) lo = mid; else hi = mid; }
+		strip0 = lo;
 	}
 	uint32_t v2[1] = { nroot }, tot2[1];
-	block_excl_add<1, NW>(v2, tot2, s_scan);      // its barriers also end every find
+	block_excl_add<1, NW>(v2, tot2, s_scan);
 	{
 		uint32_t rk = v2[0];
-#pragma unroll
-		for (uint32_t q = 0; q < kResolvePer; q++) {
-			const uint32_t i = i0 + q;
-			if (i < i1 && root[q] == i) s_tab[i] = rk++;
-		}
+		for (uint32_t i = i0; i < i1; i++) if (s_tab[i] == i) s_tab[i] = i | (rk++ << 16);
 	}
 	__syncthreads();
 	stamp(2);
 	const uint32_t ncomp = tot2[0];
 	const uint32_t nexp = ra.ncomp_expect[zi];
 	const uint64_t coff = ra.comp_off[zi];
-	// ---- ids, labels, crc32c of the component image
+	// ---- ids, labels, crc32c of the component image: four entries per round, their loads side by side
 	uint32_t part = 0;
+	uint32_t sidx = strip0;
+	for (uint32_t r0 = i0; r0 < i1; r0 += kPer) {
+		uint32_t cc[kPer], wgt[kPer];
+		uint64_t gi[kPer], key[kPer];
 #pragma unroll
-	for (uint32_t q = 0; q < kResolvePer; q++) {
-		const uint32_t i = i0 + q;
-		if (i >= i1) continue;
-		const uint32_t cc = s_tab[root[q]];
-		if (LABELS) {
-			uint64_t val = 0;
-			if (cc < nexp) {
-				const uint8_t* kp = ra.keys + (coff + cc) * ra.key_width;
-				uint64_t key = 0;
-				for (uint32_t bt = 0; bt < ra.key_width; bt++) key |= static_cast<uint64_t>(kp[bt]) << (8u * bt);
-				if (key < ra.num_unique) {
-					const uint8_t* up = ra.uniq + key * ra.stored_width;
+		for (uint32_t q = 0; q < kPer; q++) {
+			const uint32_t i = r0 + q;
+			const bool on = i < i1;
+			const uint32_t ii = on ? i : i0;
+			if (on) while (sidx + 1 < ns && s_scbase[sidx + 1] <= ii) sidx++;
+			const uint32_t sq = on ? sidx : strip0;
+			gi[q] = static_cast<uint64_t>(si0 + sq) * sa.cap + (ii - s_scbase[sq]);
+			cc[q] = s_tab[s_tab[ii] & 0xFFFFu] >> 16;
+			wgt[q] = sa.sc_w[gi[q]];
+			key[q] = 0;
+			if (LABELS) {
+				const uint8_t* kp = ra.keys + (coff + (cc[q] < nexp ? cc[q] : 0u)) * ra.key_width;
+				for (uint32_t bt = 0; bt < ra.key_width; bt++) key[q] |= static_cast<uint64_t>(kp[bt]) << (8u * bt);
+			}
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < kPer; q++) {
+			if (r0 + q >= i1) continue;
+			if (LABELS) {
+				uint64_t val = 0;
+				if (cc[q] < nexp && key[q] < ra.num_unique) {
+					const uint8_t* up = ra.uniq + key[q] * ra.stored_width;
 					for (uint32_t bt = 0; bt < ra.stored_width; bt++) val |= static_cast<uint64_t>(up[bt]) << (8u * bt);
 					if (ra.is_signed && ra.stored_width < 8u && (val >> (8u * ra.stored_width - 1u))) val |= ~0ull << (8u * ra.stored_width);
 				}
+				if (ra.has_label) val = (val == ra.label);
+				static_cast<OUT*>(sa.sc_label)[gi[q]] = static_cast<OUT>(val);
 			}
-			if (ra.has_label) val = (val == ra.label);
-			static_cast<OUT*>(sa.sc_label)[gi[q]] = static_cast<OUT>(val);
-		}
-		else sa.sc_cc[gi[q]] = cc;
-		// sum over set bits j < idbits of the id:  wgt * x^(idbits-1-j)
-		uint32_t wg = wgt[q];
-		for (int j = static_cast<int>(ra.idbits) - 1; j >= 0; j--) {
-			part ^= ((cc >> j) & 1u) ? wg : 0u;
-			wg = (wg >> 1) ^ ((wg & 1u) ? kCrcPoly : 0u);
+			else sa.sc_cc[gi[q]] = cc[q];
+			// sum over set bits j < idbits of the id:  wgt * x^(idbits-1-j)
+			uint32_t wg = wgt[q];
+			for (int j = static_cast<int>(ra.idbits) - 1; j >= 0; j--) {
+				part ^= ((cc[q] >> j) & 1u) ? wg : 0u;
+				wg = (wg >> 1) ^ ((wg & 1u) ? kCrcPoly : 0u);
+			}
 		}
 	}
 	part = wave_xor(part);

@@ -111,11 +111,19 @@ py::bytes compress(
 	return b;
 }
 
+// every C-ABI call below runs whole-volume GPU work and stream syncs: none of them touches a Python
+// object, so the GIL is released around each (buffers and output arrays are obtained before)
+template <typename F>
+int nogil(F&& call) {
+	py::gil_scoped_release release;
+	return call();
+}
+
 py::bytes reencode_markov(const py::buffer buffer, int markov_model_order, size_t /*parallel*/) {
 	Stream s(buffer);
 	uint8_t* out = nullptr;
 	uint64_t n = 0;
-	check(ckl_reencode_markov(s.p, s.n, markov_model_order, device(), &out, &n));
+	check(nogil([&] { return ckl_reencode_markov(s.p, s.n, markov_model_order, device(), &out, &n); }));
 	py::bytes b(reinterpret_cast<const char*>(out), n);
 	ckl_free(out);
 	return b;
@@ -132,14 +140,22 @@ LabelStats label_stats(const py::buffer& buffer, int64_t z_start, int64_t z_end)
 	Stream s(buffer);
 	LabelStats st;
 	st.mask = s.head.data_width >= 8 ? ~0ull : ((1ull << (8 * s.head.data_width)) - 1ull);
+	{
+		// operations::get_szr (src/operations.hpp:54-72) comes first in all three: an empty range raises,
+		// with header.sz - 1 taken in 32-bit unsigned arithmetic as there
+		int64_t zs = std::max<int64_t>(std::min<int64_t>(z_start, static_cast<int64_t>(static_cast<uint32_t>(s.head.sz - 1u))), 0);
+		int64_t ze = z_end < 0 ? static_cast<int64_t>(s.head.sz) : z_end;
+		ze = std::max<int64_t>(std::min<int64_t>(ze, static_cast<int64_t>(s.head.sz)), 0);
+		if (zs >= ze) throw std::runtime_error("crackle: Invalid range: " + std::to_string(zs) + " - " + std::to_string(ze));
+	}
 	if (static_cast<uint64_t>(s.head.sx) * s.head.sy * s.head.sz == 0) return st;
 	ckl_decoder* d = nullptr;
-	check(ckl_decoder_create(s.p, s.n, z_start, z_end, device(), &d));
+	check(nogil([&] { return ckl_decoder_create(s.p, s.n, z_start, z_end, device(), &d); }));
 	uint64_t n = 0;
-	int rc = ckl_decoder_label_stats(d, 0, nullptr, nullptr, nullptr, nullptr, &n);      // size query: reports the table size
+	int rc = nogil([&] { return ckl_decoder_label_stats(d, 0, nullptr, nullptr, nullptr, nullptr, &n); });      // size query: reports the table size
 	if (rc == CKL_OK || n) {
 		st.labels.resize(n); st.counts.resize(n); st.sums.resize(3 * n); st.boxes.resize(6 * n);
-		rc = n ? ckl_decoder_label_stats(d, n, st.labels.data(), st.counts.data(), st.sums.data(), st.boxes.data(), &n) : CKL_OK;
+		rc = n ? nogil([&] { return ckl_decoder_label_stats(d, n, st.labels.data(), st.counts.data(), st.sums.data(), st.boxes.data(), &n); }) : CKL_OK;
 	}
 	ckl_decoder_destroy(d);
 	check(rc);
@@ -189,7 +205,8 @@ py::array voxel_connectivity_graph(const py::buffer buffer, int64_t z_start, int
 	// x fastest, like the reference's to_numpy (src/fastcrackle.cpp:19-38)
 	py::array_t<uint8_t> arr({ sx, sy, nz }, { static_cast<uint64_t>(1), sx, sx * sy });
 	if (sx * sy * nz == 0) return arr;
-	check(ckl_voxel_connectivity_graph_range(s.p, s.n, zs, ze, connectivity, device(), arr.mutable_data(), sx * sy * nz));
+	uint8_t* dst = arr.mutable_data();
+	check(nogil([&] { return ckl_voxel_connectivity_graph_range(s.p, s.n, zs, ze, connectivity, device(), dst, sx * sy * nz); }));
 	return arr;
 }
 
@@ -197,7 +214,7 @@ bool array_equal(const py::buffer buffer1, const py::buffer buffer2, size_t /*pa
 	Stream a(buffer1), b(buffer2);
 	if (a.p == b.p) return true;      // src/fastcrackle.cpp:609-611
 	int eq = 0;
-	check(ckl_array_equal(a.p, a.n, b.p, b.n, device(), &eq));
+	check(nogil([&] { return ckl_array_equal(a.p, a.n, b.p, b.n, device(), &eq); }));
 	return eq != 0;
 }
 
@@ -206,7 +223,7 @@ py::list mode_pooling_2x2x1(const py::buffer buffer, int64_t z_start, int64_t z_
 	uint8_t* out = nullptr;
 	uint64_t n = 0, count = 0;
 	uint64_t* lens = nullptr;
-	check(ckl_mode_pooling_2x2x1(s.p, s.n, z_start, z_end, device(), &out, &n, &lens, &count));
+	check(nogil([&] { return ckl_mode_pooling_2x2x1(s.p, s.n, z_start, z_end, device(), &out, &n, &lens, &count); }));
 	py::list result;
 	uint64_t at = 0;
 	for (uint64_t i = 0; i < count; i++) {
@@ -223,8 +240,8 @@ py::dict point_cloud(const py::buffer buffer, int64_t z_start, int64_t z_end, co
 	Stream s(buffer);
 	uint64_t* lab = nullptr; uint64_t* off = nullptr; uint16_t* pts = nullptr;
 	uint64_t n = 0;
-	check(ckl_point_cloud(s.p, s.n, z_start, z_end, labels ? labels->data() : nullptr, labels ? labels->size() : 0, labels ? 1 : 0,
-		skip_background ? 1 : 0, device(), &lab, &off, &pts, &n));
+	check(nogil([&] { return ckl_point_cloud(s.p, s.n, z_start, z_end, labels ? labels->data() : nullptr, labels ? labels->size() : 0, labels ? 1 : 0,
+		skip_background ? 1 : 0, device(), &lab, &off, &pts, &n); }));
 	py::dict result;
 	for (uint64_t i = 0; i < n; i++) {
 		const uint64_t count = 3 * (off[i + 1] - off[i]);

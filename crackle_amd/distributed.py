@@ -230,13 +230,27 @@ class _SharedOutput:
     self.close()
 
 
+class DeviceStream:
+  """A .ckl stream resident in HBM: pointer and length (the encoder session's own copy of its last
+  stream, ckl_encoder_device_stream, or any device buffer a caller keeps alive through `owner`)."""
+
+  def __init__(self, ptr: int, n: int, owner=None):
+    self.ptr, self.n, self.owner = int(ptr), int(n), owner
+
+  def __len__(self):
+    return self.n
+
+
 class HipDecodeSession:
   def __init__(self, binary, z_start: int, z_end: int, device_index: int):
     self._L = _lib.lib()
     self._h = C.c_void_p()
     self._binary = binary   # keep alive
-    ptr, n = _lib.as_pointer(binary)
-    rc = self._L.ckl_decoder_create(ptr, n, z_start, z_end, device_index, C.byref(self._h))
+    if isinstance(binary, DeviceStream):
+      rc = self._L.ckl_decoder_create_device(binary.ptr, binary.n, z_start, z_end, device_index, C.byref(self._h))
+    else:
+      ptr, n = _lib.as_pointer(binary)
+      rc = self._L.ckl_decoder_create(ptr, n, z_start, z_end, device_index, C.byref(self._h))
     if rc != _lib.CKL_OK:
       raise RuntimeError(_lib.last_error())
 
@@ -405,6 +419,18 @@ class HipBackend:
       return np.frombuffer(C.string_at(out_p.value, out_n.value), dtype=np.uint8)
     finally:
       self._L.ckl_free(out_p)
+
+  def keep_device_stream(self, shape, itemsize: int, keep: bool = True):
+    """Following encodes of this shape also leave their whole stream in HBM (device_stream())."""
+    self._L.ckl_encoder_keep_device_stream(self._encoder(shape, itemsize), int(bool(keep)))
+
+  def device_stream(self) -> DeviceStream:
+    """The last encode's stream in HBM (valid until the session's next encode)."""
+    p, n = C.c_void_p(), C.c_uint64()
+    rc = self._L.ckl_encoder_device_stream(self._enc, C.byref(p), C.byref(n))
+    if rc != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+    return DeviceStream(p.value, n.value, owner=self)
 
   def defer_codes(self, shape, itemsize: int, defer: bool):
     """Following encodes of this shape leave the crack codes in HBM for codes_to_host."""
@@ -749,6 +775,12 @@ class ShardedCodec:
     device memory with point-to-point transfers: device to device when the process group carries
     device tensors (RCCL over xGMI), through host staging otherwise (gloo).  None off rank 0."""
     direct = self.device.type == mine.device.type
+    # the unsigned 16 / 32 / 64-bit dtypes have no entry in the collective backends' type tables: the
+    # labels travel as the signed type of the same width (bit patterns; the caller gets `mine`'s dtype back)
+    as_signed = {torch.uint16: torch.int16, torch.uint32: torch.int32, torch.uint64: torch.int64}
+    orig_dtype = mine.dtype
+    if orig_dtype in as_signed:
+      mine = mine.view(as_signed[orig_dtype])
     if self.rank != 0:
       if counts[self.rank]:
         dist.send(mine.contiguous() if direct else mine.to(self.device), dst=0)
@@ -766,7 +798,7 @@ class ShardedCodec:
         dist.recv(stage, src=r)
         whole[off:off + counts[r]] = stage.to(mine.device)
       off += counts[r]
-    return whole
+    return whole.view(orig_dtype) if orig_dtype in as_signed else whole
 
   # -- decode -------------------------------------------------------------------
   def open_decoder(self, binary: Optional[bytes], slab_shape):

@@ -113,6 +113,15 @@ typedef struct ckl_decoder ckl_decoder;
 int ckl_decoder_create(
 	const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end,
 	int device, ckl_decoder** out);
+/* The same for a stream that is resident in HBM already (the encoder's ckl_encoder_device_stream, or a
+ * caller that keeps its streams on the device): `stream_device` is used in place — it stays the
+ * caller's and must outlive the session — and nothing is uploaded.  The host reads back what
+ * crackle::decompress parses before its slice loop (header, z-index, src/crackle.hpp:262-313; label
+ * section head, src/labels.hpp:424-451; markov model; crc tail) in three small copies, never the
+ * crack codes.  Ordered after the device's default stream. */
+int ckl_decoder_create_device(
+	const uint8_t* stream_device, uint64_t n, int64_t z_start, int64_t z_end,
+	int device, ckl_decoder** out);
 /* Runs the device pipeline into a DEVICE output buffer and waits for it. */
 int ckl_decoder_run(ckl_decoder* d, void* out_device, uint64_t out_capacity_bytes, int has_label, uint64_t label);
 /* Runs only the crack decoder of the session: the two crack bit planes of every slice of the
@@ -225,6 +234,12 @@ int ckl_encoder_run(
  * and ckl_encoder_codes_to_host copies them, contiguous in slice order, to where they belong:
  * one transfer over the GPU's own link instead of a transfer and a host copy. */
 int ckl_encoder_defer_codes(ckl_encoder* e, int defer);
+/* With keep != 0 every following run also leaves the whole stream, byte for byte what it returns on
+ * the host, in HBM: the encode -> decode round trip of a device-resident volume then never re-uploads
+ * its own bytes.  ckl_encoder_device_stream hands out pointer and length of the last run's stream; the
+ * buffer is the session's and valid until its next run or its destruction. */
+int ckl_encoder_keep_device_stream(ckl_encoder* e, int keep);
+int ckl_encoder_device_stream(const ckl_encoder* e, const uint8_t** stream_device, uint64_t* n_bytes);
 int ckl_encoder_codes_to_host(ckl_encoder* e, uint8_t* dst_host, uint64_t capacity, uint64_t* n_bytes);
 /* Page-locks / releases a host range for device transfers (e.g. a shared mapping). */
 int ckl_host_register(void* p, uint64_t bytes);

@@ -1,4 +1,4 @@
-"""World-size-2 gloo tests of the sharded codec orchestration
+"""World-size-2 / 4 / 8 gloo tests of the sharded codec orchestration
 (crackle_amd/distributed.py): the reductions, the model agreement, the gather and the
 zstack merge must reproduce, byte for byte, what a single encoder produces for the
 whole volume.  The per-slab compute is injected: here the CPU oracle (the product
@@ -29,6 +29,11 @@ def _free_port():
 def _volume(kind):
   if kind == "voronoi":
     return synth.as_numpy_f(synth.voronoi_labels((96, 80, 12), np.uint16, seed=4, cell=(16, 16, 4)))
+  if kind == "voronoi16":
+    # 16 slices: slabs of 4 / 2 slices at world 4 / 8; labels of the upper half only appear there
+    v = synth.as_numpy_f(synth.voronoi_labels((80, 64, 16), np.uint32, seed=14, cell=(16, 16, 4))).copy(order="F")
+    v[:, :, 8:] += 100000
+    return v
   if kind == "wide_labels":
     # max label lives in the second slab only: stored width must come from the all-gather
     v = synth.as_numpy_f(synth.voronoi_labels((64, 48, 8), np.uint32, seed=6, cell=(16, 16, 4), modulus=200)).copy(order="F")
@@ -49,19 +54,20 @@ def _volume(kind):
   raise ValueError(kind)
 
 
-def _worker(rank, port, kind, order, q, pins=False):
+def _worker(rank, port, kind, order, q, pins=False, world=WORLD):
   import sys
   sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
   from oracle_backend import OracleBackend
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
-  dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+  os.environ.setdefault("OMP_NUM_THREADS", "1")
+  dist.init_process_group("gloo", rank=rank, world_size=world)
   try:
     vol = _volume(kind)
     sx, sy, sz = vol.shape
-    szl = sz // WORLD
+    szl = sz // world
     slab = np.asfortranarray(vol[:, :, rank * szl:(rank + 1) * szl])
-    codec = ckd.ShardedCodec(OracleBackend(), rank=rank, world=WORLD, device="cpu")
+    codec = ckd.ShardedCodec(OracleBackend(), rank=rank, world=world, device="cpu")
     binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order, allow_pins=pins)
     session = codec.open_decoder(binary, (sx, sy, szl))
     back = np.zeros_like(slab)
@@ -126,3 +132,32 @@ def test_stats_to_model_matches_reference_tie_rule(port):
   assert m[1].tolist() == [2, 1, 3, 0]
   assert m[2].tolist() == [2, 1, 0, 3]
   assert m[3].tolist() == [3, 2, 1, 0]
+
+
+def _run_world(port_fixture, kind, order, pins, world):
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  p = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, p, kind, order, q, pins, world)) for r in range(world)]
+  for pr in procs:
+    pr.start()
+  results = {}
+  for _ in range(world):
+    rank, binary, ok = q.get(timeout=300)
+    results[rank] = (binary, ok)
+  for pr in procs:
+    pr.join(timeout=120)
+    assert pr.exitcode == 0
+  vol = _volume(kind)
+  whole = port_fixture.compress(vol, allow_pins=pins, markov_model_order=order)
+  assert results[0][0] == whole, f"world {world}: merged slab streams differ from the whole-volume stream"
+  assert all(results[r][0] is None for r in range(1, world))
+  assert all(results[r][1] for r in range(world)), "a rank decoded its z-range wrongly"
+
+
+@pytest.mark.parametrize("world,kind,order,pins", [(4, "voronoi16", 0, False), (4, "voronoi16", 2, True), (8, "voronoi16", 3, False)])
+def test_sharded_compress_at_world_4_and_8(port, kind, order, pins, world):
+  """The same orchestration with 4 and 8 ranks (the node size north_star names): every collective,
+  the label merge, the per-rank crc parts and the placement of the sections with more than two
+  slabs; pins through the whole-volume stage on rank 0."""
+  _run_world(port, kind, order, pins, world)

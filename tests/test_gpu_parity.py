@@ -155,6 +155,61 @@ def test_device_resident_sessions_full_size_properties():
   L.ckl_decoder_destroy(dec)
 
 
+def test_decoder_from_device_resident_stream(checker):
+  """ckl_encoder_keep_device_stream / ckl_encoder_device_stream / ckl_decoder_create_device: the encoder's
+  HBM copy of its stream is byte for byte the host stream, and a decoder session created from it (no
+  upload; header, z-index, label head and crcs read back) decodes the volume — flat, markov, pins,
+  uint64 labels, z-ranges, and a stream a caller put into HBM itself."""
+  import torch
+  from crackle_amd import distributed as ckd
+  hip = C.CDLL("libamdhip64.so")
+  dev = torch.device("cuda:0")
+  be = ckd.HipBackend(0)
+  cases = [
+    ((160, 128, 6), np.uint32, dict(), 0),
+    ((160, 128, 6), np.uint32, dict(markov_model_order=4), 0),
+    ((96, 80, 7), np.uint16, dict(allow_pins=True), 0),
+    ((64, 64, 5), np.uint64, dict(), 1 << 40),
+    ((1024, 1024, 3), np.uint32, dict(), 0),
+  ]
+  for shape, dt, kw, offset in cases:
+    vol = synth.voronoi_labels(shape, dt, seed=71, device=dev, cell=(16, 16, 4), offset=offset)
+    sx, sy, sz = shape
+    be.keep_device_stream(shape, vol.element_size(), True)
+    host = bytes(be.encode(vol, shape, bool(kw.get("allow_pins")), True, int(kw.get("markov_model_order", 0)), None))
+    assert host == checker.compress(synth.as_numpy_f(vol), **kw), (shape, kw)
+    ds = be.device_stream()
+    assert len(ds) == len(host)
+    back = np.zeros(len(host), dtype=np.uint8)
+    assert hip.hipMemcpy(C.c_void_p(back.ctypes.data), C.c_void_p(ds.ptr), C.c_size_t(len(host)), 2) == 0
+    assert back.tobytes() == host, (shape, kw)
+    out = torch.empty_like(vol)
+    s = be.open_decoder(ds, 0, sz)
+    s.run(out)
+    s.close()
+    assert torch.equal(out, vol), (shape, kw)
+    if sz > 3:
+      part = torch.empty_like(vol[1:sz - 1])
+      s = be.open_decoder(ds, 1, sz - 1)
+      s.run(part)
+      s.close()
+      assert torch.equal(part, vol[1:sz - 1]), (shape, kw)
+    # a stream the caller uploaded itself
+    mine = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+    s = be.open_decoder(ckd.DeviceStream(mine.data_ptr(), mine.numel(), owner=mine), 0, sz)
+    out.zero_()
+    s.run(out)
+    s.close()
+    assert torch.equal(out, vol), (shape, kw)
+    be.keep_device_stream(shape, vol.element_size(), False)
+  # a corrupted resident stream is refused like a host one
+  bad = bytearray(host)
+  bad[30] ^= 0x40      # z-index
+  mine = torch.frombuffer(bad, dtype=torch.uint8).to(dev)
+  with pytest.raises(RuntimeError):
+    be.open_decoder(ckd.DeviceStream(mine.data_ptr(), mine.numel(), owner=mine), 0, sz)
+
+
 def test_large_slices_and_dense_graphs(checker):
   """Slices of the C4 shape (2048 x 2048: node tables of the trail near the LDS limit),
   a PERMISSIBLE volume big enough to leave the LDS tables (dense crack graph, loops,
@@ -283,6 +338,24 @@ def _numpy_label_stats(arr):
   return counts, cents, boxes
 
 
+def _reference_box_quirk(binary, boxes):
+  """The reference seeds its box map from the unique list only (operations.hpp:561-567): a pin
+  stream's background colour outside that list starts from a default-constructed box, so its three
+  minima are 0 (tests/golden/label_stats.json pins the same behaviour to the reference itself)."""
+  if label_format(binary) == 0:
+    return boxes
+  sz = int.from_bytes(binary[15:19], "little")
+  sw = 1 << ((int.from_bytes(binary[5:7], "little") >> 2) & 3)
+  lb = binary[29 + 4 * (sz + 1):]
+  bg = int.from_bytes(lb[:sw], "little")
+  n = int.from_bytes(lb[sw:sw + 8], "little")
+  uniq = {int.from_bytes(lb[sw + 8 + i * sw: sw + 8 + (i + 1) * sw], "little") for i in range(n)}
+  if bg not in uniq and bg in boxes:
+    boxes = dict(boxes)
+    boxes[bg] = (0, 0, 0) + tuple(boxes[bg][3:])
+  return boxes
+
+
 def test_label_statistics_match_numpy(checker):
   """voxel_counts / centroids / bounding_boxes (codec.py:949-1067) from the device runs."""
   cases = [
@@ -295,6 +368,7 @@ def test_label_statistics_match_numpy(checker):
   for arr, kw in cases:
     binary = checker.compress(arr, **kw)
     counts, cents, boxes = _numpy_label_stats(arr)
+    boxes = _reference_box_quirk(binary, boxes)
     assert crackle_amd.voxel_counts(binary) == counts
     got_c = crackle_amd.centroids(binary)
     assert sorted(got_c) == sorted(cents)
@@ -343,10 +417,7 @@ def test_label_statistics_against_the_reference_fixture():
           got = stats_digest(getattr(m, fn)(g[name], z0, z1, 1))
         except RuntimeError as exc:
           got = "error: " + str(exc)
-        if w.startswith("error"):
-          assert got.startswith("error"), (name, fn, tag, got)
-        else:
-          assert got == w, (name, fn, tag)
+        assert got == w, (name, fn, tag)      # the error texts of the empty stream included
     # the Python surface (codec.py:949-1067) over the whole stream
     if not want[name]["voxel_counts.all"].startswith("error") and crackle_amd.num_labels(g[name]) > 1:
       assert stats_digest(crackle_amd.voxel_counts(g[name])) == want[name]["voxel_counts.all"], name
@@ -363,7 +434,7 @@ def test_label_statistics_run_by_run_merge(checker, monkeypatch):
     binary = checker.compress(arr, **kw)
     assert crackle_amd.voxel_counts(binary) == counts
     got_b = crackle_amd.bounding_boxes(binary, no_slice_conversion=True)
-    assert {k: tuple(int(v) for v in b) for k, b in got_b.items()} == boxes
+    assert {k: tuple(int(v) for v in b) for k, b in got_b.items()} == _reference_box_quirk(binary, boxes)
     got_c = crackle_amd.centroids(binary)
     assert all(np.array_equal(got_c[k], cents[k]) for k in cents)
 

@@ -98,6 +98,15 @@ def test_thread_per_row_dedup_equals_oracle(name, checker, monkeypatch):
   assert crackle_amd.compress(arr, allow_pins=1) == checker.compress(arr, allow_pins=True)
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_distinct_pin_path_equals_oracle(name, checker, monkeypatch):
+  """The chosen runs reduced to the distinct ones before their ids are gathered (what volumes whose
+  per-component id lists would pass the budget take: CKL_PIN_IDS_BUDGET=0 forces it)."""
+  monkeypatch.setenv("CKL_PIN_IDS_BUDGET", "0")
+  arr = CASES[name]()
+  assert crackle_amd.compress(arr, allow_pins=1) == checker.compress(arr, allow_pins=True), name
+
+
 def test_whole_volume_pin_stage_on_device(checker):
   """ckl_encoder_components_device + ckl_encoder_pin_labels (the sharded encoder's whole-volume
   stage on rank 0): ids of two slabs painted into one device volume, the section computed from

@@ -50,6 +50,19 @@ def test_strip_path_matches_general_path_and_oracle(shape, dt, cell, checker, mo
       assert np.array_equal(part, arr[:, :, 1:shape[2] - 1]), f"strip path z-range {shape} {kw}"
     monkeypatch.setenv("CKL_DECODE_GENERAL", "1")
     assert np.array_equal(crackle_amd.decompress(b), arr), f"general path {shape} {kw}"
+    monkeypatch.delenv("CKL_DECODE_GENERAL", raising=False)
+    # the strip path behind the rasterising kernel (k_decode_cracks) instead of the crack records
+    monkeypatch.setenv("CKL_DECODE_RASTER", "1")
+    assert np.array_equal(crackle_amd.decompress(b), arr), f"raster front end {shape} {kw}"
+    monkeypatch.delenv("CKL_DECODE_RASTER", raising=False)
+    # record lists too small: the session hands over to the rasterising kernel
+    monkeypatch.setenv("CKL_REC_CAP", "3")
+    assert np.array_equal(crackle_amd.decompress(b), arr), f"record list overflow {shape} {kw}"
+    monkeypatch.delenv("CKL_REC_CAP", raising=False)
+    # control tables of k_crack_match in HBM
+    monkeypatch.setenv("CKL_LDS_CONTROLS", "64")
+    assert np.array_equal(crackle_amd.decompress(b), arr), f"global control tables {shape} {kw}"
+    monkeypatch.delenv("CKL_LDS_CONTROLS", raising=False)
   monkeypatch.delenv("CKL_DECODE_GENERAL", raising=False)
 
 

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Folds two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass, see
 /opt/skills/guides/MI355X_MICROARCH.md, HBM / PMC slots) of `bench.py` into
-profiles/pmc_traffic.json: memory-side bytes per launch of every ckl kernel.
+profiles/r03_pmc_traffic.json: memory-side bytes per launch of every ckl kernel.
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
-  python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write "1024x1024x512 uint32 markov 0" profiles/pmc_traffic.json
+  python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write "1024x1024x512 uint32 markov 0" profiles/r03_pmc_traffic.json
 
 Units and corrections (the guide's HBM section): both counters are reported in KiB
 (TCC_EA0_RDREQ / WRREQ scaled by the request size); on gfx950 FETCH_SIZE tallies the
@@ -69,8 +69,13 @@ def main():
     k["write_KiB_raw"] += wm
   for k in kernels.values():
     k["hbm_bytes_per_launch"] = (2.0 * k["fetch_KiB_raw"] + k["write_KiB_raw"]) * 1024.0
+  import hashlib
+  lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "crackle_amd", "libcrackle_amd.so")
+  with open(lib, "rb") as fh:
+    sha16 = hashlib.sha256(fh.read()).hexdigest()[:16]
   res = {
     "workload": workload,
+    "lib_sha16": sha16,      # bench.py takes roofline.traffic from this file only while it runs the same build
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1",
     "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950 counts 128-byte read requests at 64 bytes",
     "kernels": kernels,
