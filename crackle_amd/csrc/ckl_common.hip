@@ -108,7 +108,7 @@ namespace {
 struct HostBlock { void* p; size_t bytes; };
 std::mutex g_host_mutex;
 std::vector<HostBlock> g_host_live, g_host_free;
-constexpr size_t kHostCacheBlocks = 4;
+constexpr size_t kHostCacheBlocks = 12;
 constexpr size_t kHostCacheMaxBytes = 1ull << 30;
 }
 
@@ -140,6 +140,12 @@ void* host_out_alloc(size_t bytes) {
 	p = malloc(bytes);
 	if (!p) throw Error(CKL_ERR_RUNTIME, "crackle_amd: out of host memory");
 	return p;
+}
+
+bool host_out_is_pinned(const void* p) {
+	std::lock_guard<std::mutex> lock(g_host_mutex);
+	for (const HostBlock& b : g_host_live) if (b.p == p) return true;
+	return false;
 }
 
 void host_out_free(void* p) {

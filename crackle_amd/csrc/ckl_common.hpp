@@ -123,6 +123,7 @@ struct Header {
 // scratch through hipFree / hipMalloc costs tens of milliseconds each time.
 void* host_out_alloc(size_t bytes);        // pinned (cached) host buffer for results; release with ckl_free / host_out_free
 void host_out_free(void* p);               // also accepts plain malloc'd pointers
+bool host_out_is_pinned(const void* p);    // a block of host_out_alloc that is page-locked and mapped into the device's address space
 void* pool_alloc(size_t bytes, int* device = nullptr);      // throws Error on failure; *device: the device the block lives on (the current one)
 void pool_free(void* p, size_t bytes, int device = -1);     // returns the block to the pool of its device (-1: the current device)
 void pool_trim();                          // hipFree everything that is pooled

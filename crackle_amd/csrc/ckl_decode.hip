@@ -1903,6 +1903,25 @@ __global__ void __launch_bounds__(kBlock) k_mode_pool_2x2(const LABEL* __restric
 	out[i] = v;
 }
 
+// the per-slice error words and the strip path's overflow word, stored straight into the host's pinned memory
+__global__ void __launch_bounds__(kBlock) k_flags_to_host(const uint32_t* __restrict__ slice_err, uint32_t n, const uint32_t* __restrict__ overflow, uint32_t* __restrict__ dst_host) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i < n) dst_host[i] = slice_err[i];
+	if (i == 0) dst_host[n] = overflow ? *overflow : 0u;
+}
+
+// a few KiB from HBM into the host's pinned (device-mapped) memory: what ckl_decoder_create_device reads
+// back.  A kernel's stores arrive sooner than a copy-engine transfer is even scheduled.
+__global__ void __launch_bounds__(kBlock) k_fetch_to_host(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst_host, uint64_t off0, uint64_t len0, uint64_t off1, uint64_t len1) {
+	const uint64_t i = (static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x) * 16u;
+	const uint64_t off = blockIdx.y ? off1 : off0, len = blockIdx.y ? len1 : len0;
+	if (i >= len) return;
+	if (i + 16u <= len && ((reinterpret_cast<uintptr_t>(src + off + i) | reinterpret_cast<uintptr_t>(dst_host + off + i)) & 15u) == 0) {
+		*reinterpret_cast<uint4*>(dst_host + off + i) = *reinterpret_cast<const uint4*>(src + off + i);
+	}
+	else for (uint64_t b = i; b < len && b < i + 16u; b++) dst_host[off + b] = src[off + b];
+}
+
 }  // namespace ckl
 
 // ------------------------------------------------------------------------------
@@ -1917,6 +1936,7 @@ constexpr int kMaxStages = 20;
 struct ckl_decoder {
 	int device = 0;
 	int n_cus = 256;
+	int max_lds = 0;
 	hipStream_t stream = nullptr;
 	// stage boundaries: ev[i] .. ev[i+1] brackets stage i of the last run
 	hipEvent_t ev[kMaxStages + 2] = {};      // [kMaxStages + 1]: end of the pipeline
@@ -1936,6 +1956,8 @@ struct ckl_decoder {
 	DevBuf<uint8_t> d_stream;            // the whole stream (a view of the caller's buffer for ckl_decoder_create_device)
 	DevBuf<uint8_t> d_desc;              // the per-slice descriptor tables, one block, one upload
 	void* desc_staging = nullptr;        // pinned host image of d_desc (host_out_alloc), kept until the session dies
+	uint32_t* host_flags = nullptr;      // pinned: the runs' per-slice error words + overflow word land here
+	bool host_flags_pinned = false;
 	bool stream_resident = false;        // the stream was in HBM already: capacities come from the z-index alone
 	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off, d_rbase;
 	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap, d_rcap;
@@ -2011,6 +2033,7 @@ struct ckl_decoder {
 		for (auto& cs : chunk_stream) if (cs) (void)hipStreamDestroy(cs);
 		if (stream) (void)hipStreamDestroy(stream);
 		if (desc_staging) host_out_free(desc_staging);
+		if (host_flags) host_out_free(host_flags);
 	}
 };
 
@@ -2845,9 +2868,23 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	auto h1 = std::chrono::steady_clock::now();
 	std::vector<uint32_t> errs(ns);
 	uint32_t overflow = 0;
-	CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-	if (strips) CKL_HIP(hipMemcpyAsync(&overflow, d.d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-	CKL_HIP(hipStreamSynchronize(s));
+	// the verdicts come back through the host's pinned memory (a kernel's stores: a copy-engine transfer of
+	// two KiB costs tens of microseconds before it starts)
+	if (!d.host_flags) {
+		d.host_flags = static_cast<uint32_t*>(host_out_alloc(std::max<size_t>(64u << 10, (static_cast<size_t>(ns) + 4) * sizeof(uint32_t))));
+		d.host_flags_pinned = host_out_is_pinned(d.host_flags);
+	}
+	if (d.host_flags_pinned) {
+		hipLaunchKernelGGL(k_flags_to_host, dim3((ns + kBlock) / kBlock), dim3(kBlock), 0, s, d.d_slice_err.p, ns, strips ? d.d_overflow.p : nullptr, d.host_flags);
+		CKL_HIP(hipStreamSynchronize(s));
+		memcpy(errs.data(), d.host_flags, ns * sizeof(uint32_t));
+		overflow = d.host_flags[ns];
+	}
+	else {
+		CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		if (strips) CKL_HIP(hipMemcpyAsync(&overflow, d.d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		CKL_HIP(hipStreamSynchronize(s));
+	}
 	CKL_HIP(hipGetLastError());
 	if (strips && d.use_records) {
 		// a record list that did not fit (dense slices): this and all later runs of the session take the
@@ -3285,17 +3322,45 @@ void decoder_point_cloud(ckl_decoder& d, const uint64_t* sel, uint64_t n_sel, bo
 
 extern "C" {
 
+// A session's stream and its two dozen events cost more to create than the rest of its set-up: sessions
+// that end hand them to a small per-device cache (ckl_decoder_destroy), new ones take them from it.
+struct SessionResources {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[kMaxStages + 2] = {};
+	hipEvent_t ev_in = nullptr;
+	int n_cus = 0, max_lds = 0;
+};
+static std::mutex g_session_mutex;
+static std::vector<SessionResources>& session_cache() { static std::vector<SessionResources>& c = *new std::vector<SessionResources>(); return c; }      // never destroyed: no HIP calls at exit
+
 // stream, events and kernel attributes of a new session; the caller builds it
 static std::unique_ptr<ckl_decoder> decoder_new(int device) {
 	select_device(device);
 	std::unique_ptr<ckl_decoder> d(new ckl_decoder());
 	d->device = device;
-	CKL_HIP(hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, device));
-	CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-	for (auto& e : d->ev) CKL_HIP(hipEventCreate(&e));
-	CKL_HIP(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
 	int max_lds = 0;
-	CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+	bool cached = false;
+	{
+		std::lock_guard<std::mutex> lock(g_session_mutex);
+		auto& c = session_cache();
+		for (size_t i = 0; i < c.size(); i++) {
+			if (c[i].device != device) continue;
+			d->stream = c[i].stream; d->ev_in = c[i].ev_in; d->n_cus = c[i].n_cus; max_lds = c[i].max_lds;
+			for (int k = 0; k < kMaxStages + 2; k++) d->ev[k] = c[i].ev[k];
+			c[i] = c.back(); c.pop_back();
+			cached = true;
+			break;
+		}
+	}
+	if (!cached) {
+		CKL_HIP(hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, device));
+		CKL_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+		for (auto& e : d->ev) CKL_HIP(hipEventCreate(&e));
+		CKL_HIP(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
+		CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+	}
+	d->max_lds = max_lds;
 	// the kernels' dynamic LDS limits are set once per device and size
 	static std::mutex mu;
 	static std::vector<std::pair<int, size_t>>& done = *new std::vector<std::pair<int, size_t>>();
@@ -3378,13 +3443,23 @@ int ckl_decoder_create_device(const uint8_t* stream_device, uint64_t n, int64_t 
 		} img;
 		img.n = n;
 		img.p = static_cast<uint8_t*>(host_out_alloc(n));
+		const bool mapped = host_out_is_pinned(img.p);      // host_out_alloc pins (and maps) blocks of 64 KiB and more
 		auto fetch = [&](uint64_t off, uint64_t len) {
 			if (off >= n || len == 0) return;
 			len = std::min<uint64_t>(len, n - off);
-			CKL_HIP(hipMemcpyAsync(img.p + off, stream_device + off, len, hipMemcpyDeviceToHost, s));
+			if (mapped && len <= (1u << 20)) hipLaunchKernelGGL(k_fetch_to_host, dim3(static_cast<uint32_t>((len + 16u * kBlock - 1) / (16u * kBlock)), 1), dim3(kBlock), 0, s, stream_device, img.p, off, len, 0ull, 0ull);
+			else CKL_HIP(hipMemcpyAsync(img.p + off, stream_device + off, len, hipMemcpyDeviceToHost, s));
 		};
 		mark("image");
-		fetch(0, 64);      // header (and the start of the z-index)
+		// first round, sized for the common case: the front of the stream (header, z-index and label section
+		// head of up to ~16 K slices) and its end (the crc tail); what a stream needs beyond that follows
+		const uint64_t kFront = 64u << 10;
+		const uint64_t front = std::min<uint64_t>(n, kFront), back0 = n > 2 * kFront ? n - kFront : front;
+		if (mapped) {      // both ranges in one launch
+			const uint64_t longest = std::max(front, n - back0);
+			hipLaunchKernelGGL(k_fetch_to_host, dim3(static_cast<uint32_t>((longest + 16u * kBlock - 1) / (16u * kBlock)), 2), dim3(kBlock), 0, s, stream_device, img.p, 0ull, front, back0, n - back0);
+		}
+		else { fetch(0, front); fetch(back0, n - back0); }
 		CKL_HIP(hipStreamSynchronize(s));
 		mark("header");
 		const Header h = Header::parse(img.p, n);
@@ -3393,11 +3468,18 @@ int ckl_decoder_create_device(const uint8_t* stream_device, uint64_t n, int64_t 
 		const uint64_t tail = h.format_version == 0 ? 0 : 4ull * (static_cast<uint64_t>(h.sz) + 1);
 		const int sw = h.stored_data_width;
 		const bool flat = h.label_format == FLAT;
-		// z-index, label section head (all of a pin section), model, crc tail
-		fetch(hb, gib + (flat ? 16 : h.num_label_bytes));
-		fetch(hb + gib + h.num_label_bytes, h.markov_model_bytes());
-		fetch(n - tail, tail);
-		CKL_HIP(hipStreamSynchronize(s));
+		// z-index, label section head (all of a pin section), model, crc tail: whatever the first round missed
+		auto need = [&](uint64_t off, uint64_t len) {
+			if (len == 0 || off >= n) return false;
+			len = std::min<uint64_t>(len, n - off);
+			if (off + len <= front || off >= back0) return false;
+			fetch(off, len);
+			return true;
+		};
+		bool more = need(hb, gib + (flat ? 16 : h.num_label_bytes));
+		more = need(hb + gib + h.num_label_bytes, h.markov_model_bytes()) || more;
+		more = need(n - tail, tail) || more;
+		if (more) CKL_HIP(hipStreamSynchronize(s));
 		if (flat && h.num_label_bytes >= 8 && static_cast<uint64_t>(h.sx) * h.sy) {
 			// component counts: behind the unique labels (labels.hpp:424-451)
 			const uint64_t nu = rd_le(img.p + hb + gib, 8);
@@ -3566,7 +3648,22 @@ int ckl_decoder_stage_timing(const ckl_decoder* d, int index, const char** name,
 	return CKL_OK;
 }
 
-void ckl_decoder_destroy(ckl_decoder* d) { delete d; }
+void ckl_decoder_destroy(ckl_decoder* d) {
+	if (!d) return;
+	// stream and events go to the cache (at most four sets are kept), idle: every run waits for its own work
+	if (d->stream) {
+		std::lock_guard<std::mutex> lock(g_session_mutex);
+		auto& c = session_cache();
+		if (c.size() < 4) {
+			SessionResources r;
+			r.device = d->device; r.stream = d->stream; r.ev_in = d->ev_in; r.n_cus = d->n_cus; r.max_lds = d->max_lds;
+			for (int k = 0; k < kMaxStages + 2; k++) { r.ev[k] = d->ev[k]; d->ev[k] = nullptr; }
+			d->stream = nullptr; d->ev_in = nullptr;
+			c.push_back(r);
+		}
+	}
+	delete d;
+}
 
 int ckl_array_equal(const uint8_t* buf1, uint64_t n1, const uint8_t* buf2, uint64_t n2, int device, int* equal) {
 	ckl_decoder *d1 = nullptr, *d2 = nullptr;

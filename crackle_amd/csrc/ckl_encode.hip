@@ -1241,8 +1241,7 @@ void crack_pass(
 		// The serial k_trail_dfs keeps 1 wavefront per slice busy for ~2 ms while the chip idles.
 		// Slices can be processed in groups on their own streams (CKL_TRAIL_GROUPS): while one
 		// group is in its DFS the others run their parallel stages.
-		// measured at C2: 2 groups -0.17 ms, 4 and 8 slower (the DFS wavefronts want their SIMDs to themselves)
-		uint32_t groups = ns >= 128u ? 2u : 1u;
+		uint32_t groups = 1u;      // measured at C2: 2 groups between -0.17 and +0.1 ms from run to run, 4 and 8 slower (the DFS wavefronts want their SIMDs to themselves)
 		if (const char* env = getenv("CKL_TRAIL_GROUPS")) groups = static_cast<uint32_t>(std::max(1, atoi(env)));
 		groups = std::min<uint32_t>(std::min<uint32_t>(groups, ns), kTrailStreams);
 		if (groups > 1) CKL_HIP(hipEventRecord(e.ev_fork, s));
