@@ -7,19 +7,18 @@
 // in a workgroup's LDS (one 1024-thread workgroup per CU, 149 KiB) and spends most of its time
 // there.  Here a slice's workgroup only resolves WHERE every stretch of moves starts:
 //
-//   k_crack_match     one workgroup of 1024 per slice, two per CU (76 KiB of LDS, <= 64 registers): BOC index,
+//   k_crack_match     one workgroup of 512 per slice, two per CU (76 KiB of LDS): BOC index,
 //                     symbols 16 codes per word (tile_symbols), control symbols recorded with
 //                     the displacement before them, branch matching (match_controls_packed) ->
 //                     the offset of every segment between 't' jumps.  On the way every word
-//                     of 16 code positions is written out as it stands in the registers: its
-//                     moves, which positions emit one, which are 't's, the displacement and the
-//                     number of 't's before it (WordRec, 16 bytes, stream order).
-//   k_crack_bin       one THREAD per word, no scan, no order: the word's segment offsets turn
-//                     its displacement into the absolute start vertex (y << 16 | x) and the
-//                     word into one 16-byte RECORD per pair of stretches between 't's (the
-//                     record carries the jump between the two).  A record goes to the list of
-//                     every strip of rows its moves can touch (one, seldom two): counted per
-//                     workgroup in LDS, one reservation per strip, then written.
+//                     of 16 code positions is parked as it stands in the registers — its moves,
+//                     which positions emit one, which are 't's, the displacement and the number
+//                     of 't's before it (WordRec, 16 bytes) — and read back once the offsets
+//                     are known: the word's segment offsets turn its displacement into the
+//                     absolute start vertex (y << 16 | x) and the word into one 16-byte RECORD
+//                     per pair of stretches between 't's (the record carries the jump between
+//                     the two).  A record goes to the list of every strip of rows its moves can
+//                     touch (one, seldom two), through one cursor per strip in LDS.
 //   raster_record     (ckl_strips.hpp) the strip kernel walks the records of its list into the
 //                     strip's two plane pieces in LDS — 8 KiB instead of 256 KiB — and goes on
 //                     to label them without the planes making a round trip through HBM.
@@ -200,17 +199,13 @@ __device__ __forceinline__ void match_controls_packed(
 	sub(8);
 }
 
-// what k_crack_match leaves for k_crack_bin
+// a word of 16 code positions as k_crack_match parks it between its two passes
 struct WordRec {               // per word of 16 code positions (16 bytes)
 	uint32_t prevs;            // the move position k would emit, 2 bits each
 	uint32_t flags;            // bit 2k: position k emits its move; bit 2k + 1: position k is a 't'
 	uint32_t o_p;              // packed displacement of the stream before the word
 	uint32_t o_t;              // 't's before the word
 };
-struct SliceInfo {             // per slice (16 bytes)
-	uint32_t n_words, valid_segs, pad0, pad1;      // n_words = 0: nothing to bin
-};
-
 struct RecArgs {
 	CrackArgs c;                 // stream, descriptors, markov scratch, global control tables (g_dx: positions, g_seg_x: segment offsets)
 	RecordLists lists;
@@ -218,8 +213,7 @@ struct RecArgs {
 	uint32_t lds_bytes;
 	WordRec* words;              // [word_base[zi] + word]
 	const uint64_t* word_base;   // [nslices]
-	SliceInfo* slice_info;       // [nslices]
-	unsigned long long* diag;    // tuning builds: cycle stamps, summed over the slices (k_crack_match: [0..15], k_crack_bin: [16..23])
+	unsigned long long* diag;    // tuning builds: cycle stamps, summed over the slices
 };
 
 // the seldom-taken parts of k_crack_match (as functions of their own, not inlined, they made the kernel
@@ -274,6 +268,75 @@ __device__ __forceinline__ void rec_match_global(
 	if (rerr) atomicOr(rerr_out, rerr);
 }
 
+// The records of one parked word: the stretches between its 't's, two per record ([A] t [B] | t [A] t [B]
+// | ...; the record carries the jump between its two), each record into the list of every strip its
+// moves can touch.  seg: the segments' offsets (LDS or global), cursor: the slice's list lengths in LDS.
+__device__ __forceinline__ void word_to_records(
+	const uint4& word, const uint32_t* seg, uint32_t valid_segs, const RecordLists& L, uint4* lists, uint32_t* cursor,
+	uint32_t sx, uint32_t sy, uint32_t& rerr
+) {
+	const uint32_t prevs = word.x, ms = word.y & kLo, isT = (word.y >> 1) & kLo, o_p = word.z, o_t0 = word.w;
+	if ((ms | isT) == 0u) return;
+	const uint32_t nstrips = L.nstrips;
+	const uint32_t mR = ms & ~(prevs >> 1) & prevs, mL = ms & (prevs >> 1) & prevs, mD = ms & (prevs >> 1) & ~prevs, mU = ms & ~(prevs >> 1) & ~prevs;
+	// packed displacement of the word's moves at the positions of `mask`
+	auto disp = [&](uint32_t mask) -> uint32_t { return __popc(mR & mask) - __popc(mL & mask) + ((__popc(mD & mask) - __popc(mU & mask)) << 16); };
+	// the record goes to the strips k0 .. k1 and, when it jumps, to those of k2 .. k3 not among them
+	auto put_to = [&](const uint4& rec, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+		for (uint32_t k = k0; k <= k1; k++) {
+			const uint32_t at = atomicAdd(&cursor[k], 1u);
+			if (at < L.cap) lists[static_cast<uint64_t>(k) * L.cap + at] = rec;
+		}
+		for (uint32_t k = k2; k <= k3; k++) {
+			if (k >= k0 && k <= k1) continue;
+			const uint32_t at = atomicAdd(&cursor[k], 1u);
+			if (at < L.cap) lists[static_cast<uint64_t>(k) * L.cap + at] = rec;
+		}
+	};
+	// strips of the rows a stretch of moves from vertex `start` can touch: the vertex rows
+	// [y - ups, y + downs] (vertical moves cross the plane row of their smaller vertex, horizontal ones
+	// that of their own); false when the vertex is outside the grid
+	auto strips_of = [&](uint32_t start, uint32_t part, uint32_t& k0, uint32_t& k1) -> bool {
+		const uint32_t y = start >> 16, x = start & 0xFFFFu;
+		if (x > sx || y > sy) { rerr |= ERR_RANGE; return false; }
+		const uint32_t nu = __popc(mU & part), nd = __popc(mD & part);
+		const uint32_t ya = y > nu ? y - nu : 0u, yb = min(y + nd, sy);
+		k0 = L.strip_of(ya); k1 = min(L.strip_of(yb), nstrips - 1u);
+		return true;
+	};
+	uint32_t ot = o_t0, done = 0;      // done: spread mask of the positions handed out (and of the 't's passed)
+	for (uint32_t tm = isT; ; ) {
+		const uint32_t bA = tm ? __ffs(tm) - 1u : 32u;
+		const uint32_t uptoA = bA >= 32u ? kLo : ((1u << bA) - 1u) & kLo;
+		const uint32_t partA = ms & uptoA & ~done;
+		const bool actA = ot < valid_segs;
+		const uint32_t offA = actA ? seg[ot] : 0u;
+		const uint32_t startA = offA + o_p + disp(done);
+		uint32_t k0 = 1, k1 = 0, k2 = 1, k3 = 0;
+		if (!tm) {
+			if (partA && actA && strips_of(startA, partA, k0, k1)) put_to(make_uint4(startA, prevs, partA, 0u), k0, k1, 1u, 0u);
+			break;
+		}
+		const uint32_t tm2 = tm & (tm - 1u);
+		const uint32_t bB = tm2 ? __ffs(tm2) - 1u : 32u;
+		const uint32_t uptoB = bB >= 32u ? kLo : ((1u << bB) - 1u) & kLo;
+		const uint32_t behindA = uptoA | (1u << bA);
+		const uint32_t partB = ms & uptoB & ~behindA;
+		const bool actB = ot + 1u < valid_segs;
+		const uint32_t offB = actB ? seg[ot + 1u] : 0u;
+		const uint32_t startB = offB + o_p + disp(behindA);
+		const bool hasA = partA && actA && strips_of(startA, partA, k0, k1);
+		const bool hasB = partB && actB && strips_of(startB, partB, k2, k3);
+		if (hasA && hasB) put_to(make_uint4(startA, prevs, partA | partB | (1u << (bA + 1u)), offB - offA), k0, k1, k2, k3);
+		else if (hasA) put_to(make_uint4(startA, prevs, partA, 0u), k0, k1, 1u, 0u);
+		else if (hasB) put_to(make_uint4(startB, prevs, partB, 0u), k2, k3, 1u, 0u);
+		if (!tm2) break;
+		done = uptoB | (1u << bB);
+		ot += 2u;
+		tm = tm2 & (tm2 - 1u);
+	}
+}
+
 // grid = slices of the launch, block = kRecBlock, dynamic LDS = lds_bytes
 __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long s_dyn[];
@@ -284,6 +347,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 	__shared__ uint32_t s_nnodes, s_ncodes, s_valid_segs, s_err, s_first_dead;
 	__shared__ uint32_t s_loff[14], s_lcnt[14];
 	__shared__ uint32_t s_mk_parallel, s_mk_total, s_index_end;
+	__shared__ uint32_t s_cursor[kRecMaxStrips];      // lengths of the slice's record lists
 
 	unsigned long long d_t = (kTuning && ra.diag) ? __builtin_amdgcn_s_memtime() : 0ull;
 	auto stamp = [&](int slot) { if (kTuning && ra.diag && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(ra.diag + slot, now - d_t); d_t = now; } };
@@ -299,8 +363,8 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 	const uint32_t sxe = a.sx + 1, sye = a.sy + 1;
 	const uint32_t sx = a.sx, sy = a.sy;
 	uint32_t* upacked = a.upacked ? a.upacked + cb / 16u + 2ull * zi : nullptr;
-	// the lists' lengths start at zero (k_crack_emit reserves in them)
-	for (uint32_t k = tid; k < ra.lists.nstrips; k += kRecBlock) ra.lists.count[static_cast<uint64_t>(zi) * ra.lists.nstrips + k] = 0u;
+	const uint32_t nstrips = ra.lists.nstrips;
+	for (uint32_t k = tid; k < nstrips; k += kRecBlock) s_cursor[k] = 0u;
 
 	// ---- beginning-of-chain index (crackcodes.hpp:283-316), one thread ----
 	if (tid == 0) {
@@ -405,7 +469,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 		lt.lastT = p2; p2 += lcap;
 		lt.gmin = reinterpret_cast<int16_t*>(p2); p2 += lcap / 7 + 48;
 		lt.kind = reinterpret_cast<uint8_t*>(p2);
-		lt.seg = a.g_seg_x + kb;
+		lt.seg = reinterpret_cast<uint32_t*>(lt.depth);      // over depth | lastT, dead by the time the offsets are written
 	}
 	uint32_t rerr = 0;
 	const bool have_cracks = n_nodes > 0 && n_codes > 0;
@@ -457,6 +521,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 		}
 		// ---- branch matching
 		const uint32_t n_ctl = c.a;
+		const uint32_t* seg = lt.seg;
 		if (n_ctl + 2u <= lcap) {
 			match_controls_packed<uint16_t, int16_t, kRecBlock>(lt, n_ctl, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, rerr, ra.diag);
 		}
@@ -471,156 +536,84 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			__syncthreads();
 			__threadfence_block();
 			rec_match_global(&gt, n, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, &s_err);
+			__threadfence_block();
+			seg = gt.seg;
+		}
+		stamp(3);
+		// ---- the parked words once more (through L2): records into the strips' lists.  Four words out of five
+		// hold no 't': they become their one record on the spot; the others are queued (in the link table,
+		// which is free now) and dealt out again, so that the loop over stretches runs with all lanes busy
+		// instead of once per word for the sake of a few lanes.
+		{
+			const uint32_t valid_segs = s_valid_segs;
+			const RecordLists& L = ra.lists;
+			uint4* lists = L.rec + static_cast<uint64_t>(zi) * nstrips * L.cap;
+			const uint4* wsrc = reinterpret_cast<const uint4*>(wout);
+			uint32_t* queue = reinterpret_cast<uint32_t*>(lt.link);      // word indices
+			const uint32_t queue_cap = lcap * 2u;
+			uint32_t* s_qn = &s_mk_total;      // (the markov expansion is long done)
+			if (tid == 0) *s_qn = 0u;
+			__syncthreads();
+			typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+			auto load_word = [&](uint32_t w) -> uint4 {
+				const u32x4_t raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wsrc + w));      // written by other threads of the workgroup: not through L1
+				return make_uint4(raw.x, raw.y, raw.z, raw.w);
+			};
+			constexpr uint32_t kBatch = 4;      // words of a thread in flight
+			for (uint32_t w0 = 0; w0 < n_words; w0 += kBatch * kRecBlock) {
+				uint4 wr[kBatch];
+#pragma unroll
+				for (uint32_t q = 0; q < kBatch; q++) {
+					const uint32_t w = w0 + q * kRecBlock + tid;
+					wr[q] = load_word(w < n_words ? w : 0u);
+					if (w >= n_words) wr[q].y = 0u;
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < kBatch; q++) {
+					const uint32_t flags = wr[q].y;
+					if (flags == 0u) continue;
+					if (flags & 0xAAAAAAAAu) {      // a 't' in the word: later, with its like
+						const uint32_t at = atomicAdd(s_qn, 1u);
+						if (at < queue_cap) queue[at] = w0 + q * kRecBlock + tid;
+						else word_to_records(wr[q], seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
+						continue;
+					}
+					// one stretch, one record
+					const uint32_t o_t = wr[q].w;
+					if (o_t >= valid_segs) continue;
+					const uint32_t prevs = wr[q].x, ms = flags;
+					const uint32_t start = seg[o_t] + wr[q].z;
+					const uint32_t y = start >> 16, x = start & 0xFFFFu;
+					if (x > sx || y > sy) { rerr |= ERR_RANGE; continue; }
+					const uint32_t nu = __popc(ms & ~(prevs >> 1) & ~prevs), nd = __popc(ms & (prevs >> 1) & ~prevs);
+					const uint32_t k0 = L.strip_of(y > nu ? y - nu : 0u), k1 = min(L.strip_of(min(y + nd, sy)), nstrips - 1u);
+					const uint4 rec = make_uint4(start, prevs, ms, 0u);
+					for (uint32_t k = k0; k <= k1; k++) {
+						const uint32_t at = atomicAdd(&s_cursor[k], 1u);
+						if (at < L.cap) lists[static_cast<uint64_t>(k) * L.cap + at] = rec;
+					}
+				}
+			}
+			__syncthreads();
+			const uint32_t qn = min(*s_qn, queue_cap);
+			for (uint32_t i = tid; i < qn; i += kRecBlock) word_to_records(load_word(queue[i]), seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
 		}
 	}
-	stamp(3);
+	__syncthreads();
+	{
+		const RecordLists& L = ra.lists;
+		for (uint32_t k = tid; k < nstrips; k += kRecBlock) {
+			const uint32_t n = s_cursor[k];
+			L.count[static_cast<uint64_t>(zi) * nstrips + k] = min(n, L.cap);
+			if (n > L.cap) rerr |= ERR_LIST;
+		}
+	}
+	stamp(9);
 	if (rerr) atomicOr(&s_err, rerr);
 	__syncthreads();
 	if (tid == 0) {
-		SliceInfo si;
-		si.n_words = n_words; si.valid_segs = s_valid_segs; si.pad0 = 0; si.pad1 = 0;
-		*reinterpret_cast<uint4*>(ra.slice_info + zi) = *reinterpret_cast<const uint4*>(&si);
 		a.slice_err[zi] = s_err;      // later kernels of the decode OR their bits in
 		if (a.overflow && blockIdx.x == 0 && a.zbase == 0) *a.overflow = 0u;      // the strip kernels' overflow word (this is the first kernel of the decode)
 	}
 }
 
-// One thread per word, kBlock consecutive entries of the slice's word array per workgroup (half a row of
-// [tile][j][thread]: threads in stream order, so the segments they walk through are consecutive too):
-// records counted per strip in LDS, one reservation per strip and workgroup in the strip's list, then
-// written.  (Four words per thread — 7 workgroups per slice instead of 25 — took the same time:
-// the kernel is three dependent trips to memory per workgroup, and four times the registers.)
-// grid = (ceil(most words of a slice / (kBlock * kBinWords)), slices of the launch), block = kBlock
-constexpr uint32_t kBinWords = 1;
-__global__ void __launch_bounds__(kBlock) k_crack_bin(RecArgs ra) {
-	__shared__ uint32_t s_cnt[kRecMaxStrips], s_base[kRecMaxStrips];
-	__shared__ uint32_t s_seg[kEmitSegWindow];      // the segment offsets the workgroup's words look up
-	__shared__ uint32_t s_win[2];
-	unsigned long long d_t = (kTuning && ra.diag) ? __builtin_amdgcn_s_memtime() : 0ull;
-	auto stamp = [&](int slot) { if (kTuning && ra.diag && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(ra.diag + slot, now - d_t); d_t = now; } };
-	const CrackArgs& a = ra.c;
-	const uint32_t zi = blockIdx.y + a.zbase;
-	const uint32_t tid = threadIdx.x;
-	const SliceInfo si = ra.slice_info[zi];
-	const uint32_t wg0 = blockIdx.x * kBlock * kBinWords;      // first word of the workgroup
-	if (wg0 >= si.n_words) return;      // uniform
-	const RecordLists& L = ra.lists;
-	const uint32_t nstrips = L.nstrips;
-	for (uint32_t k = tid; k < nstrips; k += kBlock) s_cnt[k] = 0u;
-	const uint32_t sx = a.sx, sy = a.sy;
-	const uint32_t* seg = a.g_seg_x + (a.cbase[zi] / 2u + 4ull * zi);
-	const uint32_t valid_segs = si.valid_segs;
-	// word i of the thread: wg0 + i * kBlock + tid (coalesced)
-	uint4 wr[kBinWords];
-	{
-		const uint4* wsrc = reinterpret_cast<const uint4*>(ra.words + ra.word_base[zi]);
-#pragma unroll
-		for (uint32_t i = 0; i < kBinWords; i++) {
-			const uint32_t w = wg0 + i * kBlock + tid;
-			wr[i] = wsrc[w < si.n_words ? w : wg0];
-			if (w >= si.n_words) wr[i].y = 0u;      // nothing emitted, no 't'
-		}
-	}
-	// The words of a workgroup are consecutive: so are the segments they walk through.  Their offsets are
-	// staged in LDS once (a look-up would otherwise be a dependent trip to memory in each of the two sweeps).
-	{
-		const uint32_t w_last = min(wg0 + kBlock * kBinWords, si.n_words) - 1u;
-		if (tid == 0) s_win[0] = wr[0].w;
-#pragma unroll
-		for (uint32_t i = 0; i < kBinWords; i++) if (wg0 + i * kBlock + tid == w_last) s_win[1] = wr[i].w + __popc((wr[i].y >> 1) & kLo);
-	}
-	__syncthreads();
-	const uint32_t w0 = s_win[0];
-	const uint32_t w1 = min(s_win[1], valid_segs ? valid_segs - 1u : 0u);      // last segment looked up
-	const bool seg_staged = w1 >= w0 && w1 - w0 < kEmitSegWindow;
-	if (seg_staged) for (uint32_t i = tid; i <= w1 - w0; i += kBlock) s_seg[i] = seg[w0 + i];
-	auto seg_at = [&](uint32_t o) -> uint32_t { return seg_staged ? s_seg[o - w0] : seg[o]; };
-	uint32_t rerr = 0;
-	uint4* lists = L.rec + static_cast<uint64_t>(zi) * nstrips * L.cap;
-	// every record of a word: WRITE = false counts it into its strips, WRITE = true stores it
-	auto sweep = [&](auto write_tag, const uint4& word) {
-		constexpr bool WRITE = decltype(write_tag)::value;
-		const uint32_t prevs = word.x, ms = word.y & kLo, isT = (word.y >> 1) & kLo, o_p = word.z, o_t0 = word.w;
-		if ((ms | isT) == 0u) return;
-		const uint32_t mR = ms & ~(prevs >> 1) & prevs, mL = ms & (prevs >> 1) & prevs, mD = ms & (prevs >> 1) & ~prevs, mU = ms & ~(prevs >> 1) & ~prevs;
-		// packed displacement of the word's moves at the positions of `mask`
-		auto disp = [&](uint32_t mask) -> uint32_t { return __popc(mR & mask) - __popc(mL & mask) + ((__popc(mD & mask) - __popc(mU & mask)) << 16); };
-		// the record goes to the strips k0 .. k1 and, when it jumps, to those of k2 .. k3 not among them
-		auto put_to = [&](const uint4& rec, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
-			for (uint32_t k = k0; k <= k1; k++) {
-				const uint32_t at = atomicAdd(&s_cnt[k], 1u);
-				if (WRITE) { const uint32_t dst = s_base[k] + at; if (dst < L.cap) lists[static_cast<uint64_t>(k) * L.cap + dst] = rec; }
-			}
-			for (uint32_t k = k2; k <= k3; k++) {
-				if (k >= k0 && k <= k1) continue;
-				const uint32_t at = atomicAdd(&s_cnt[k], 1u);
-				if (WRITE) { const uint32_t dst = s_base[k] + at; if (dst < L.cap) lists[static_cast<uint64_t>(k) * L.cap + dst] = rec; }
-			}
-		};
-		// strips of the rows a stretch of moves from vertex `start` can touch: the vertex rows
-		// [y - ups, y + downs] (vertical moves cross the plane row of their smaller vertex, horizontal ones
-		// that of their own); false when the vertex is outside the grid
-		auto strips_of = [&](uint32_t start, uint32_t part, uint32_t& k0, uint32_t& k1) -> bool {
-			const uint32_t y = start >> 16, x = start & 0xFFFFu;
-			if (x > sx || y > sy) { rerr |= ERR_RANGE; return false; }
-			const uint32_t nu = __popc(mU & part), nd = __popc(mD & part);
-			const uint32_t ya = y > nu ? y - nu : 0u, yb = min(y + nd, sy);
-			k0 = L.strip_of(ya); k1 = min(L.strip_of(yb), nstrips - 1u);
-			return true;
-		};
-		// stretches between the 't's of the word, two per record: [A] t [B] | t [A] t [B] | ...
-		uint32_t ot = o_t0, done = 0;      // done: spread mask of the positions handed out (and of the 't's passed)
-		for (uint32_t tm = isT; ; ) {
-			const uint32_t bA = tm ? __ffs(tm) - 1u : 32u;
-			const uint32_t uptoA = bA >= 32u ? kLo : ((1u << bA) - 1u) & kLo;
-			const uint32_t partA = ms & uptoA & ~done;
-			const bool actA = ot < valid_segs;
-			const uint32_t offA = actA ? seg_at(ot) : 0u;
-			const uint32_t startA = offA + o_p + disp(done);
-			uint32_t k0 = 1, k1 = 0, k2 = 1, k3 = 0;
-			if (!tm) {
-				if (partA && actA && strips_of(startA, partA, k0, k1)) put_to(make_uint4(startA, prevs, partA, 0u), k0, k1, 1u, 0u);
-				break;
-			}
-			const uint32_t tm2 = tm & (tm - 1u);
-			const uint32_t bB = tm2 ? __ffs(tm2) - 1u : 32u;
-			const uint32_t uptoB = bB >= 32u ? kLo : ((1u << bB) - 1u) & kLo;
-			const uint32_t behindA = uptoA | (1u << bA);
-			const uint32_t partB = ms & uptoB & ~behindA;
-			const bool actB = ot + 1u < valid_segs;
-			const uint32_t offB = actB ? seg_at(ot + 1u) : 0u;
-			const uint32_t startB = offB + o_p + disp(behindA);
-			const bool hasA = partA && actA && strips_of(startA, partA, k0, k1);
-			const bool hasB = partB && actB && strips_of(startB, partB, k2, k3);
-			if (hasA && hasB) put_to(make_uint4(startA, prevs, partA | partB | (1u << (bA + 1u)), offB - offA), k0, k1, k2, k3);
-			else if (hasA) put_to(make_uint4(startA, prevs, partA, 0u), k0, k1, 1u, 0u);
-			else if (hasB) put_to(make_uint4(startB, prevs, partB, 0u), k2, k3, 1u, 0u);
-			if (!tm2) break;
-			done = uptoB | (1u << bB);
-			ot += 2u;
-			tm = tm2 & (tm2 - 1u);
-		}
-	};
-	__syncthreads();
-	stamp(16);
-#pragma unroll
-	for (uint32_t i = 0; i < kBinWords; i++) sweep(std::false_type(), wr[i]);
-	__syncthreads();
-	stamp(17);
-	for (uint32_t k = tid; k < nstrips; k += kBlock) {
-		const uint32_t n = s_cnt[k];
-		uint32_t base = 0;
-		if (n) {
-			base = atomicAdd(L.count + static_cast<uint64_t>(zi) * nstrips + k, n);
-			if (base + n > L.cap) rerr |= ERR_LIST;
-		}
-		s_base[k] = base;
-		s_cnt[k] = 0u;
-	}
-	__syncthreads();
-	stamp(18);
-#pragma unroll
-	for (uint32_t i = 0; i < kBinWords; i++) sweep(std::true_type(), wr[i]);
-	stamp(19);
-	if (rerr) atomicOr(a.slice_err + zi, rerr);
-}

@@ -1994,7 +1994,7 @@ struct ckl_decoder {
 	bool use_records = false;           // k_crack_records + rasterising strip kernel instead of k_decode_cracks
 	DevBuf<uint4> d_rec;
 	DevBuf<uint32_t> d_rec_count;
-	DevBuf<uint4> d_words, d_slice_info;      // WordRec per word of 16 code positions / SliceInfo per slice (k_crack_match -> k_crack_bin)
+	DevBuf<uint4> d_words;             // WordRec per word of 16 code positions, parked between the two passes of k_crack_match
 	DevBuf<uint64_t> d_word_off;
 	uint32_t max_words = 0;             // most words of one slice
 	uint32_t rec_cap = 0, rec_lds_controls = 0;
@@ -2289,7 +2289,6 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 				}
 				pack.add(d.d_word_off, word_off);
 				d.d_words.ensure(wtot);
-				d.d_slice_info.ensure(d.nslices);
 			}
 		}
 	}
@@ -2592,7 +2591,6 @@ void launch_crack_records(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t 
 	ra.lds_bytes = static_cast<uint32_t>(d.rec_lds);
 	ra.words = reinterpret_cast<WordRec*>(d.d_words.p);
 	ra.word_base = d.d_word_off.p;
-	ra.slice_info = reinterpret_cast<SliceInfo*>(d.d_slice_info.p);
 	ra.diag = nullptr;
 	if (kTuning && getenv("CKL_CRACK_DIAG")) {
 		d.d_diag.ensure(64);
@@ -2601,16 +2599,12 @@ void launch_crack_records(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t 
 	}
 	hipLaunchKernelGGL(k_crack_match, dim3(n), dim3(kRecBlock), d.rec_lds, s, ra);
 	if (st) st->done("k_crack_match");
-	hipLaunchKernelGGL(k_crack_bin, dim3((d.max_words + kBlock * kBinWords - 1) / (kBlock * kBinWords), n), dim3(kBlock), 0, s, ra);
-	if (st) st->done("k_crack_bin");
 	if (ra.diag) {
 		unsigned long long hd[32];
 		CKL_HIP(hipMemcpyAsync(hd, ra.diag, sizeof(hd), hipMemcpyDeviceToHost, s));
 		CKL_HIP(hipStreamSynchronize(s));
-		const double wg = static_cast<double>((d.max_words + kBlock * kBinWords - 1) / (kBlock * kBinWords)) * n;
-		fprintf(stderr, "[ckl crack diag, mean cycles] k_crack_match per slice: boc=%.0f symbols=%.0f record=%.0f match=%.0f (depth=%.0f tree=%.0f links=%.0f jump=%.0f seg=%.0f) | k_crack_bin per launched workgroup: load=%.0f count=%.0f reserve=%.0f write=%.0f\n",
-			hd[0] / double(n), hd[1] / double(n), hd[2] / double(n), hd[3] / double(n), hd[4] / double(n), hd[5] / double(n), hd[6] / double(n), hd[7] / double(n), hd[8] / double(n),
-			hd[16] / wg, hd[17] / wg, hd[18] / wg, hd[19] / wg);
+		fprintf(stderr, "[ckl crack diag, mean cycles per slice] k_crack_match: boc=%.0f symbols=%.0f record=%.0f match=%.0f (depth=%.0f tree=%.0f links=%.0f jump=%.0f seg=%.0f) records=%.0f\n",
+			hd[0] / double(n), hd[1] / double(n), hd[2] / double(n), hd[3] / double(n), hd[4] / double(n), hd[5] / double(n), hd[6] / double(n), hd[7] / double(n), hd[8] / double(n), hd[9] / double(n));
 	}
 }
 
