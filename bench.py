@@ -153,12 +153,10 @@ def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=5):
 
 
 def lib_sha16():
-  """First 16 hex digits of the sha256 of the library that is loaded: ties a PMC profile to a build."""
-  import hashlib
-  from crackle_amd import _lib
+  """Digest of the library's sources (crackle_amd.build.source_digest): ties a PMC profile to a build."""
   try:
-    with open(_lib.LIB_PATH, "rb") as f:
-      return hashlib.sha256(f.read()).hexdigest()[:16]
+    from crackle_amd import build as ckl_build
+    return ckl_build.source_digest()
   except OSError:
     return None
 

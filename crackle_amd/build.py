@@ -17,6 +17,19 @@ HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + 
 ARCH = os.environ.get("CKL_OFFLOAD_ARCH", "gfx950")
 
 
+def source_digest():
+  """sha256 (first 16 hex digits) over the library's sources: names a build whatever machine compiled it
+  (profiles/r03_pmc_traffic.json records it, bench.py takes roofline.traffic from that file only while
+  the sources are the ones that were profiled)."""
+  import hashlib
+  h = hashlib.sha256()
+  for name in sorted(SOURCES) + sorted(os.path.basename(x) for x in HEADERS):
+    path = os.path.join(CSRC, name) if not name.endswith("crackle_amd.h") else os.path.join(HERE, "..", "include", "crackle_amd.h")
+    with open(path, "rb") as f:
+      h.update(name.encode() + b"\0" + f.read())
+  return h.hexdigest()[:16]
+
+
 def _hipcc():
   for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
     if c and (os.path.sep not in c or os.path.exists(c)):

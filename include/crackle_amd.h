@@ -75,7 +75,11 @@ int ckl_header_info_from_bytes(const uint8_t* buf, uint64_t n, ckl_header_info* 
  *   labels        x-fastest volume of sx*sy*sz elements, dtype_bytes in {1,2,4,8}
  *   labels_mem    CKL_MEM_HOST or CKL_MEM_DEVICE (pointer valid on `device`)
  *   is_signed     must be 0 (crackle/codec.py:720-721 rejects signed input)
- *   allow_pins .. manual_bgcolor   same meaning as the reference's arguments
+ *   allow_pins .. manual_bgcolor   same meaning as the reference's arguments, with two refusals
+ *                 (CKL_ERR_ARG): optimize_pins (allow_pins = 2, find_optimal_pins: out of scope) and
+ *                 markov_model_order 14 and 15 — the header's four bits allow them
+ *                 (src/header.hpp:126,223), but their 4^N x 4 histogram (4 and 16 GiB of counters) is
+ *                 more than this encoder keeps on the device; the decoder takes every order
  *   device        HIP device ordinal
  *   out/out_len   library-owned host buffer holding the .ckl bytes; release with ckl_free (only)
  */

@@ -69,13 +69,12 @@ def main():
     k["write_KiB_raw"] += wm
   for k in kernels.values():
     k["hbm_bytes_per_launch"] = (2.0 * k["fetch_KiB_raw"] + k["write_KiB_raw"]) * 1024.0
-  import hashlib
-  lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "crackle_amd", "libcrackle_amd.so")
-  with open(lib, "rb") as fh:
-    sha16 = hashlib.sha256(fh.read()).hexdigest()[:16]
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  from crackle_amd import build as ckl_build
+  sha16 = ckl_build.source_digest()
   res = {
     "workload": workload,
-    "lib_sha16": sha16,      # bench.py takes roofline.traffic from this file only while it runs the same build
+    "lib_sha16": sha16,      # digest of the library's sources: bench.py takes roofline.traffic from this file only while they are unchanged
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1",
     "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950 counts 128-byte read requests at 64 bytes",
     "kernels": kernels,
