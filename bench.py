@@ -492,9 +492,9 @@ def main():
     # wavefront per slice, bound by dependent instruction latency, not by bytes)
     enc_k = float(np.mean(enc_kernel_ms))
     if enc_k > 0:
-      etraffic, _ = pmc_traffic(["k_trail_dfs"], workload_key)
+      etraffic, _ = pmc_traffic(["k_trail_walk"], workload_key)
       res["roofline_encode"] = {
-        "bound": "hbm", "kernel": "k_trail_dfs (encode)",
+        "bound": "hbm", "kernel": "k_trail_walk (encode)",
         "achieved": alg_bytes / (enc_k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": alg_bytes / (enc_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "traffic": etraffic,

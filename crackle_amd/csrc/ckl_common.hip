@@ -40,6 +40,14 @@ constexpr size_t kPoolMaxBytes = 96ull << 30;    // of 288 GB of HBM
 constexpr size_t kPoolMaxBlocks = 512;
 }
 
+// Testing (CKL_POOL_POISON=1): every block handed out is filled with 0xA5 first, so that a kernel which
+// reads memory nobody wrote fails the same way every time instead of only after some other volume.
+static void* pool_poison(void* p, size_t bytes) {
+	static const bool on = getenv("CKL_POOL_POISON") != nullptr;
+	if (on && p) { (void)hipMemset(p, 0xA5, bytes); (void)hipDeviceSynchronize(); }
+	return p;
+}
+
 void* pool_alloc(size_t bytes, int* device) {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
@@ -58,7 +66,7 @@ void* pool_alloc(size_t bytes, int* device) {
 			g_pool_bytes -= g_pool[best].bytes;
 			g_pool[best] = g_pool.back();
 			g_pool.pop_back();
-			return p;
+			return pool_poison(p, bytes);
 		}
 	}
 	void* p = nullptr;
@@ -72,7 +80,7 @@ void* pool_alloc(size_t bytes, int* device) {
 		(void)hipGetLastError();
 		throw Error(CKL_ERR_RUNTIME, std::string("crackle_amd: hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
 	}
-	return p;
+	return pool_poison(p, bytes);
 }
 
 void pool_free(void* p, size_t bytes, int device) {

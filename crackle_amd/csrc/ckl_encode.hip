@@ -860,7 +860,7 @@ struct ckl_encoder {
 	hipStream_t stream = nullptr;      // crack codes
 	hipStream_t stream2 = nullptr;     // labels (components, crcs, label table), concurrent with the crack trail
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr, ev_in = nullptr;
-	hipEvent_t evd0 = nullptr, evd1 = nullptr;      // around k_trail_dfs (first slice group)
+	hipEvent_t evd0 = nullptr, evd1 = nullptr;      // around k_trail_walk (first slice group)
 	float trail_ms = 0.f;
 	hipStream_t trail_stream[kTrailStreams] = {};     // slice groups of the crack trail
 	hipEvent_t ev_fork = nullptr, ev_join[kTrailStreams] = {};
@@ -921,12 +921,12 @@ struct ckl_encoder {
 	bool graph_permissible = false;
 	DevBuf<uint64_t> t_nbase, t_cobase, t_ibase;
 	DevBuf<uint32_t> t_ncap, t_cocap, t_icap, t_max_steps;
-	DevBuf<uint32_t> t_counters;                 // n_nodes | n_snap | n_corners | n_starts | n_items, [nslices] each
+	DevBuf<uint32_t> t_counters;                 // n_nodes | n_snap | n_corners | n_starts | n_items | n_events, [nslices] each
 	DevBuf<uint32_t> t_node_vertex, t_vert2node, t_corner_vertex;
 	DevBuf<uint8_t> t_node_adj;
 	DevBuf<uint32_t> t_dart_end, t_dart_len, t_dart_minv, t_dart_minpos, t_parent, t_start_bits, t_starts;
 	DevBuf<unsigned long long> t_compmin;
-	DevBuf<uint32_t> t_items, t_item_off, t_chain_item0;
+	DevBuf<uint32_t> t_items, t_item_off, t_chain_item0, t_events, t_chain_ev0, t_ev_lnd, t_ev_item;
 
 	~ckl_encoder() {
 		if (ev0) (void)hipEventDestroy(ev0);
@@ -1179,6 +1179,7 @@ void crack_pass(
 	fa.payload_len = e.d_payload_len.p; fa.boc_len = e.d_boc_len.p;
 
 	unsigned long long* ta_dbg = nullptr;
+	size_t trail_lds_used = 0;
 	DevBuf<unsigned long long> d_tdbg;
 	CKL_HIP(hipEventRecord(e.evk0, s));
 	{
@@ -1187,8 +1188,8 @@ void crack_pass(
 		upload(e.t_cobase, cobase, s); upload(e.t_cocap, cocap, s);
 		upload(e.t_ibase, ibase, s); upload(e.t_icap, icap, s);
 		upload(e.t_max_steps, max_steps, s);
-		e.t_counters.ensure(5 * static_cast<size_t>(ns));
-		CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 5 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
+		e.t_counters.ensure(6 * static_cast<size_t>(ns));
+		CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 6 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
 		e.t_node_vertex.ensure(ntot); e.t_node_adj.ensure(ntot + 16); e.t_vert2node.ensure(nverts * ns);
 		e.t_corner_vertex.ensure(cotot);
 		e.t_dart_end.ensure(4 * ntot); e.t_dart_len.ensure(4 * ntot); e.t_dart_minv.ensure(4 * ntot); e.t_dart_minpos.ensure(4 * ntot);
@@ -1197,6 +1198,7 @@ void crack_pass(
 		e.t_start_bits.ensure(static_cast<size_t>(start_words) * ns);
 		CKL_HIP(hipMemsetAsync(e.t_start_bits.p, 0, static_cast<size_t>(start_words) * ns * sizeof(uint32_t), s));
 		e.t_items.ensure(itot); e.t_item_off.ensure(itot); e.t_chain_item0.ensure(ktot);
+		e.t_events.ensure(itot); e.t_chain_ev0.ensure(ktot); e.t_ev_lnd.ensure(itot); e.t_ev_item.ensure(itot);
 
 		TrailArgs ta;
 		ta.adjm = e.d_adjm.p; ta.adjm_stride = e.adjm_stride; ta.mtx2 = e.mtx2; ta.tiles_x = e.tiles_x; ta.tiles_y = e.tiles_y;
@@ -1219,7 +1221,10 @@ void crack_pass(
 		ta.n_chains = e.d_n_chains.p; ta.n_raw = e.d_n_raw.p; ta.n_valid = e.d_n_valid.p;
 		ta.cbase = e.d_cbase.p; ta.ccap = e.d_ccap.p; ta.cp = e.d_cp.p; ta.slice_err = e.d_slice_err.p;
 
+		ta.events = e.t_events.p; ta.n_events = e.t_counters.p + 5 * ns; ta.chain_ev0 = e.t_chain_ev0.p; ta.ev_lnd = e.t_ev_lnd.p; ta.ev_item = e.t_ev_item.p;
 		ta.dbg = nullptr;
+		{ const char* env = getenv("CKL_TRAIL_WALK"); ta.walk_plain = (env && !strcmp(env, "plain")) ? 1u : 0u; }
+		{ const char* env = getenv("CKL_TRAIL_WALK_STACK"); ta.walk_stack_cap = env ? static_cast<uint32_t>(std::max(1, atoi(env))) : 0xFFFFFFFFu; }
 		if (kTuning && getenv("CKL_TRAIL_DIAG")) { d_tdbg.ensure(16); CKL_HIP(hipMemsetAsync(d_tdbg.p, 0, 128, s)); ta.dbg = d_tdbg.p; ta_dbg = d_tdbg.p; }
 		ta.graph_blocks = e.graph_blocks; ta.blk_special = e.t_blk_special.p; ta.blk_corner = e.t_blk_corner.p;
 		int max_lds = 0;
@@ -1231,14 +1236,17 @@ void crack_pass(
 		if (const char* env = getenv("CKL_TRAIL_LDS")) clds = static_cast<size_t>(std::max(0, atoi(env)));
 		clds = (std::min(budget, std::max<size_t>(clds, 1024)) / 16) * 16;
 		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_components), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(clds)));
-		// node tables of k_trail_dfs in LDS: 9 bytes per node + 16 KiB of branch stack when that fits
-		size_t lds = (static_cast<size_t>(max_special) + 256) * 9 + 16384 + 1024;
+		// node tables of k_trail_walk in LDS + 16 KiB of branch stack when that fits
+		size_t lds = (static_cast<size_t>(max_special) + 256) * 16 + 16384 + 1024;      // k_trail_walk's records of 16 bytes per node + 16 KiB of branch stack
 		if (const char* env = getenv("CKL_TRAIL_LDS")) lds = static_cast<size_t>(std::max(0, atoi(env)));   // testing: small values force the global tables
+		// two walks per CU when there are more slices than CUs: 80 KiB each, as long as 12 KiB of branch stack remain
+		if (lds > 81920 && (static_cast<size_t>(max_special) + 256) * 16 + 12288 <= 81920 && !getenv("CKL_TRAIL_LDS")) lds = 81920;
 		lds = std::min(budget, std::max<size_t>(lds, 4096));
 		lds = (lds / 16) * 16;
-		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_dfs), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_walk), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+		trail_lds_used = lds;
 
-		// The serial k_trail_dfs keeps 1 wavefront per slice busy for ~2 ms while the chip idles.
+		// The serial k_trail_walk keeps 1 wavefront per slice busy for ~1 ms while the chip idles.
 		// Slices can be processed in groups on their own streams (CKL_TRAIL_GROUPS): while one
 		// group is in its DFS the others run their parallel stages.
 		uint32_t groups = 1u;      // measured at C2: 2 groups between -0.17 and +0.1 ms from run to run, 4 and 8 slower (the DFS wavefronts want their SIMDs to themselves)
@@ -1264,8 +1272,9 @@ void crack_pass(
 				hipLaunchKernelGGL(k_trail_components, dim3(gn), dim3(kCompBlock), clds, gs, ta, static_cast<uint32_t>(clds));
 			}
 			if (g == 0) CKL_HIP(hipEventRecord(e.evd0, gs));
-			hipLaunchKernelGGL(k_trail_dfs, dim3(gn), dim3(kWave), lds, gs, ta, static_cast<uint32_t>(lds));
+			hipLaunchKernelGGL(k_trail_walk, dim3(gn), dim3(kWave), lds, gs, ta, static_cast<uint32_t>(lds));
 			if (g == 0) CKL_HIP(hipEventRecord(e.evd1, gs));
+			hipLaunchKernelGGL(k_trail_items, dim3(gn), dim3(kBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_trail_offsets, dim3(gn), dim3(kBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kExpandChunk * kWaves - 1) / (kExpandChunk * kWaves), gn), dim3(kBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_finish, dim3(gn), dim3(kFinishBlock), 0, gs, fa);
@@ -1285,7 +1294,8 @@ void crack_pass(
 		for (uint32_t zi = 0; zi < ns; zi++) { sp += static_cast<double>(e.count_special[zi]) / ns; co += static_cast<double>(e.count_corner[zi]) / ns; }
 		if (ta_dbg) {
 			std::vector<unsigned long long> g = download(ta_dbg, 16, s);
-			if (g[11]) fprintf(stderr, "[ckl trail diag, k_trail_dfs] slices=%llu iterations/slice=%.0f cycles/iteration=%.0f clock=%.2f GHz (cycles / 100 MHz ticks)\n",
+			if (g[11]) fprintf(stderr, "[ckl trail diag, k_trail_walk] mean cycles per slice: table fill=%.0f fill + walk=%.0f\n", static_cast<double>(g[6]) / g[11], static_cast<double>(g[7]) / g[11]);
+			if (g[11]) fprintf(stderr, "[ckl trail diag, k_trail_walk] slices=%llu iterations/slice=%.0f cycles/iteration=%.0f clock=%.2f GHz (cycles / 100 MHz ticks)\n",
 				g[11], static_cast<double>(g[8]) / g[11], g[8] ? static_cast<double>(g[9]) / g[8] : 0.0, g[10] ? static_cast<double>(g[9]) / (g[10] * 10.0) : 0.0);
 			fprintf(stderr, "[ckl trail diag, k_trail_components, mean cycles per slice] union=%.0f component minima=%.0f starts/splits=%.0f bitmap scan=%.0f\n",
 				static_cast<double>(g[12]) / ns, static_cast<double>(g[13]) / ns, static_cast<double>(g[14]) / ns, static_cast<double>(g[15]) / ns);
@@ -1293,6 +1303,7 @@ void crack_pass(
 				g[4], g[4] ? static_cast<double>(g[0]) / g[4] : 0.0, g[1], g[4] ? static_cast<double>(g[2]) / g[4] : 0.0, g[3],
 				g[0] ? static_cast<double>(g[2]) / g[0] : 0.0, g[0] ? static_cast<double>(g[5]) / g[0] : 0.0);
 		}
+		fprintf(stderr, "[ckl trail diag] max degree-1/3/4 vertices of a slice=%u, k_trail_walk LDS=%zu bytes\n", max_special, trail_lds_used);
 		fprintf(stderr, "[ckl trail diag, mean per slice] degree-1/3/4 vertices=%.0f corners=%.0f nodes=%.0f starts=%.0f items=%.0f\n", sp, co, m[0], m[3], m[4]);
 	}
 
@@ -1908,7 +1919,7 @@ void encode_typed(
 		CKL_HIP(hipGetLastError());
 		CKL_HIP(hipEventElapsedTime(&e.pipeline_ms, e.ev0, e.ev1));
 		CKL_HIP(hipEventElapsedTime(&e.trail_ms, e.evk0, e.evk1));
-		CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evd0, e.evd1));      // the encoder's longest kernel: k_trail_dfs
+		CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evd0, e.evd1));      // the encoder's longest kernel: k_trail_walk
 	}
 	catch (...) { host_out_free(o); throw; }
 	*out = o;
@@ -2034,7 +2045,15 @@ int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int 
 		e->device = device;
 		e->max_sx = sx; e->max_sy = sy; e->max_sz = sz; e->dtype_bytes = dtype_bytes;
 		CKL_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-		CKL_HIP(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+		{
+			// the label stream ahead of the trail stream: its many small kernels should be through before
+			// the serial walk (k_trail_walk, one wavefront per slice) starts, whose step time suffers beside them
+			int lo = 0, hi = 0;
+			CKL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+			const char* env = getenv("CKL_LABEL_STREAM_PRIORITY");
+			const int prio = env ? atoi(env) : hi;
+			CKL_HIP(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio));
+		}
 		CKL_HIP(hipEventCreate(&e->ev0));
 		CKL_HIP(hipEventCreate(&e->ev1));
 		CKL_HIP(hipEventCreate(&e->evk0));

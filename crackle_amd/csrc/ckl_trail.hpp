@@ -19,10 +19,11 @@
 //                      in LDS) and their smallest vertex = where next_cluster starts the
 //                      chain (crackcodes.hpp:41-49, 399); a start in the middle of a
 //                      segment splits it; start vertices in ascending order (bitmap scan)
-//   k_trail_dfs        the exact serial trail, but over nodes only (tables in LDS): one
-//                      item per traversed segment / 'b' / 't', with
-//                      remove_initial_branch (185-242) and remove_spurious_branches
-//                      (250-281) folded in
+//   k_trail_walk       the exact serial trail, but over nodes only (tables in LDS) and reduced to
+//                      WHERE it goes: one event per step (segment, 'b' + segment, dead end)
+//   k_trail_items      events -> items (segment / 'b' / 't'), for all steps of a slice at once: forms
+//                      of 'b' and 't', remove_initial_branch (185-242), remove_spurious_branches
+//                      (250-281)
 //   k_trail_offsets    item -> code offset (prefix sum of segment lengths)
 //   k_trail_expand     one thread per item re-walks its segment and writes the code points
 //
@@ -111,7 +112,7 @@ struct TrailArgs {
 	const uint64_t* sbase;       // [nslices] base into the branch stack spill
 	const uint32_t* scap;
 	uint32_t* stack_node;
-	uint32_t* stack_item;
+	uint32_t* stack_item;        // event of the entry's kEvBseg
 	// chains (k_finish input)
 	const uint64_t* kbase;
 	const uint32_t* kcap;
@@ -126,6 +127,13 @@ struct TrailArgs {
 	const uint32_t* ccap;
 	uint8_t* cp;
 	uint32_t* slice_err;
+	uint32_t* events;            // [at ibase] k_trail_walk -> k_trail_items
+	uint32_t* n_events;          // [nslices]
+	uint32_t* chain_ev0;         // [at kbase] first event of the chain
+	uint32_t* ev_lnd;            // [at ibase] scratch of k_trail_items
+	uint32_t* ev_item;
+	uint32_t walk_plain;         // testing (CKL_TRAIL_WALK=plain): trail_walk_slice for every slice
+	uint32_t walk_stack_cap;     // testing (CKL_TRAIL_WALK_STACK=n): branch stack of the hand-scheduled walk capped at n entries
 	unsigned long long* dbg;     // diagnostics (nullable): [0] wave iterations, [1] max per wave, [2] cycles, [3] max cycles, [4] waves, [5] lane-steps
 };
 
@@ -638,19 +646,17 @@ static __global__ void __launch_bounds__(kCompBlock) k_trail_components(TrailArg
 	else trail_components_slice<false>(a, zi, a.parent + a.nbase[zi], nn, s_scan, &s_nstart);
 }
 
-// ---- the serial trail over nodes ------------------------------------------------
-// One wavefront per slice, wave-uniform scalar state (values read from memory go through
-// readfirstlane); stores are issued by lane 0.  Node tables: LDS (16-bit dart ends) when
-// the slice has few enough nodes, else the global arrays.  A step costs one LDS round
-// trip: the remaining-edge nibble and the four dart ends of a node are fetched together,
-// the edge consumed on arrival is carried in a register (pend) instead of being cleared
-// at the far node first.
+// ---- node tables of the walk ------------------------------------------------------
+// The walk runs in lane 0 of one wavefront per slice with wave-uniform scalar state (values read
+// from memory go through readfirstlane).  Node tables: LDS (16-bit dart ends) when the slice has
+// few enough nodes, else the global arrays.  The remaining-edge nibble and the four dart ends of a
+// node are fetched together; the edge consumed on arrival is carried in a register (pend) instead
+// of being cleared at the far node first.
 enum : uint32_t { TCODE_UP = 0, TCODE_RIGHT = 1, TCODE_DOWN = 2, TCODE_LEFT = 3, TCODE_NONE = 0xFE };
 
 struct TrailTabLds {
 	uint8_t* adj;
 	unsigned long long* end4;      // four 16-bit dart ends (node << 2 | arrival) per node
-	uint32_t dummy;                // byte offset from adj of 64 scratch dwords: where the lanes other than 0 write
 	__device__ __forceinline__ void load(uint32_t j, uint32_t& av, uint32_t& e_lo, uint32_t& e_hi) const {
 		const uint32_t a0 = adj[j];
 		const unsigned long long e = end4[j];
@@ -662,210 +668,303 @@ struct TrailTabLds {
 		const uint32_t w = (k & 2u) ? e_hi : e_lo;
 		return (w >> ((k & 1u) * 16u)) & 0xFFFFu;
 	}
-	// no exec-mask juggling and no 64-way same-address write: lane 0 stores to the table,
-	// every other lane to its own scratch dword
-	__device__ __forceinline__ void set_adj(uint32_t j, uint32_t v, bool l0) const {
-		adj[l0 ? j : dummy + (threadIdx.x << 2)] = static_cast<uint8_t>(v);
-	}
-	__device__ __forceinline__ uint32_t get_end(uint32_t d) const {
-		return __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(end4)[d]));
-	}
+	__device__ __forceinline__ void set_adj(uint32_t j, uint32_t v) const { adj[j] = static_cast<uint8_t>(v); }
 };
 struct TrailTabGlobal {
 	uint8_t* adj;
 	const uint32_t* end;
 	__device__ __forceinline__ void load(uint32_t j, uint32_t& av, uint32_t& e_lo, uint32_t& e_hi) const {
-		// word loads that bypass the vector L1: lane 0's stores must be read back as written
+		// word loads that bypass the vector L1: the lane's own stores must be read back as written
 		const uint32_t* w = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(adj + j) & ~static_cast<uintptr_t>(3));
 		const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(adj + j) & 3u) * 8u;
 		av = (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> sh) & 0xFFu;
 		e_lo = j; e_hi = 0;
 	}
 	__device__ __forceinline__ uint32_t pick(uint32_t e_lo, uint32_t e_hi, uint32_t k) const { return __builtin_amdgcn_readfirstlane(end[e_lo * 4u + k]); }
-	__device__ __forceinline__ void set_adj(uint32_t j, uint32_t v, bool l0) const {
-		if (l0) {
-			// read-modify-write of the containing word (single writer per slice, slices are 16-byte aligned)
-			uint32_t* w = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(adj + j) & ~static_cast<uintptr_t>(3));
-			const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(adj + j) & 3u) * 8u;
-			const uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(w, (old & ~(0xFFu << sh)) | ((v & 0xFFu) << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
+	__device__ __forceinline__ void set_adj(uint32_t j, uint32_t v) const {
+		// read-modify-write of the containing word (single writer per slice, slices are 16-byte aligned)
+		uint32_t* w = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(adj + j) & ~static_cast<uintptr_t>(3));
+		const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(adj + j) & 3u) * 8u;
+		const uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(w, (old & ~(0xFFu << sh)) | ((v & 0xFFu) << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
-	__device__ __forceinline__ uint32_t get_end(uint32_t d) const { return __builtin_amdgcn_readfirstlane(end[d]); }
 };
 
+// ---- the walk alone -----------------------------------------------------------------
+// What is serial in the trail is only WHERE it goes: which edge is taken at a node, where a dead
+// end jumps back to.  That depends on the remaining-edge nibbles and the branch stack, never on what
+// was emitted.  The forms of 'b' / 't', remove_initial_branch and remove_spurious_branches are
+// functions of the sequence of steps, and k_trail_items computes them for all steps at once.  So the
+// walk emits one EVENT per step and nothing else:
+//   kEvSeg  | dart        along the only remaining edge of the node
+//   kEvBseg | dart        more than one edge left: the node goes on the branch stack first ('b')
+//   kEvDead | event       dead end: back to the most recent branch node; `event` = its kEvBseg
+//   kEvEnd                dead end with an empty stack: the chain is complete
+constexpr uint32_t kEvSeg = 0u << 30, kEvBseg = 1u << 30, kEvDead = 2u << 30, kEvEnd = 3u << 30, kEvMask = 3u << 30;
+
+// Runs in lane 0.  Branch stack: entry q in LDS slot q + 1 (slot 0 takes the stores of steps that
+// push nothing), entries beyond the LDS part in stack_node / stack_item.
 template <typename TAB>
-__device__ __forceinline__ void trail_dfs_slice(
-	const TrailArgs& a, uint32_t zi, const TAB& tab, uint32_t* s_stack, uint32_t lds_stack_cap
+__device__ __forceinline__ void trail_walk_slice(
+	const TrailArgs& a, uint32_t zi, const TAB& tab, uint2* s_stack2, uint32_t lds_slots
 ) {
-	const bool l0 = (threadIdx.x == 0);
 	const uint64_t nb = a.nbase[zi];
 	const uint32_t* starts = a.starts + nb;
 	const uint32_t n_starts = a.n_starts[zi];
-	uint32_t* items = a.items + a.ibase[zi];
-	const uint32_t icap = a.icap[zi];
+	uint32_t* ev = a.events + a.ibase[zi];
+	const uint32_t ecap = a.icap[zi];
 	uint32_t* st_node = a.stack_node + a.sbase[zi];
-	uint32_t* st_item = a.stack_item + a.sbase[zi];
+	uint32_t* st_ev = a.stack_item + a.sbase[zi];
 	const uint32_t scap = a.scap[zi];
 	uint32_t* ch_node = a.chain_node + a.kbase[zi];
-	uint32_t* ch_item0 = a.chain_item0 + a.kbase[zi];
+	uint32_t* ch_ev0 = a.chain_ev0 + a.kbase[zi];
 	const uint32_t kcap = a.kcap[zi];
 	const uint32_t* vert2node = a.vert2node + static_cast<uint64_t>(zi) * a.nverts;
-	uint2* s_stack2 = reinterpret_cast<uint2*>(s_stack);
+	const uint32_t cap1 = lds_slots - 1u;
 
-	// Every lane carries the same state, so stores need no lane predicate: all lanes write
-	// the same value to the same address (one LDS / memory transaction).
-	uint32_t ni = 0, nch = 0, err = 0, dbg_iters = 0;
-	const unsigned long long dbg_t0 = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-	const unsigned long long dbg_r0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
-	// last: direction of the previous symbol's last code point as an EDGE BIT number
-	// (0 right, 1 left, 2 down, 3 up), 4 = nothing emitted yet.
-	// 'b' is (UP,DOWN) unless the previous code is DOWN (or there is none), then (LEFT,RIGHT);
-	// 't' is (DOWN,UP) unless the previous code is UP (or there is none), then (RIGHT,LEFT)   (crackcodes.hpp:155-174)
-	constexpr uint32_t kNone = 4u, kLeft = 1u, kDown = 2u, kUp = 3u;
-	constexpr uint32_t kB = kItemCtl | TCODE_UP | (TCODE_DOWN << 2), kBalt = kItemCtl | TCODE_LEFT | (TCODE_RIGHT << 2);
-	constexpr uint32_t kT = kItemCtl | TCODE_DOWN | (TCODE_UP << 2), kTalt = kItemCtl | TCODE_RIGHT | (TCODE_LEFT << 2);
-	struct __attribute__((packed, aligned(4))) Item2 { uint32_t a, b; };
-	for (uint32_t si = 0; si < n_starts; si++) {
+	uint32_t ne = 0, nch = 0, err = 0;
+	const unsigned long long dbg_t0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
+	const unsigned long long dbg_r0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	for (uint32_t si = 0; si < n_starts && !err; si++) {
 		const uint32_t sv = __builtin_amdgcn_readfirstlane(starts[si]);
 		uint32_t j = __builtin_amdgcn_readfirstlane(vert2node[sv]);
-		const uint32_t chain_begin = ni;
-		uint32_t sp = 0, last = kNone, prev_t_b = 0, adjusted = sv;
-		uint32_t prevt = 0;        // previous symbol is a live 't' that popped the 'b' item prev_t_b
-		uint32_t rib = 0;          // chain began with 'b', no other 'b' and no 't' yet
-		uint32_t pend = 0;         // edge of node j consumed by the move that led here
-		for (;;) {
-			if (ni + 4u > icap) { err |= TRAIL_ERR_CAPACITY; break; }
-			dbg_iters++;
-			uint32_t av_raw, e_lo, e_hi;
-			tab.load(j, av_raw, e_lo, e_hi);
-			const uint32_t av = av_raw & ~pend;
-			if (av == 0) {
-				if (pend) tab.set_adj(j, 0u, l0);
-				pend = 0;
-				// ---- 't': dead end, back to the most recent branch vertex
-				if (sp == 0) break;
-				sp--;
-				uint32_t pj, pitem;
-				if (sp < lds_stack_cap) {
-					const uint2 pr = s_stack2[sp];
-					pj = __builtin_amdgcn_readfirstlane(pr.x);
-					pitem = __builtin_amdgcn_readfirstlane(pr.y);
-				}
-				else {
-					pj = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_node + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-					pitem = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_item + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-				}
-				if (rib) {
-					// remove_initial_branch (crackcodes.hpp:185-242): the leading 'b' and this 't'
-					// vanish, the first stretch is walked backwards from where it ended
-					adjusted = __builtin_amdgcn_readfirstlane(a.node_vertex[nb + j]);
-					uint32_t lc = last;
-					if (l0) {
-						items[chain_begin] = kItemDead;
-						if (ni > chain_begin + 1u) {
-							uint32_t lo = chain_begin + 1u, hi = ni - 1u;
-							while (lo < hi) {
-								const uint32_t x = items[lo], y = items[hi];
-								items[lo] = kItemSeg | tab.get_end(y & ~kItemMask);
-								items[hi] = kItemSeg | tab.get_end(x & ~kItemMask);
-								lo++; hi--;
-							}
-							if (lo == hi) items[lo] = kItemSeg | tab.get_end(items[lo] & ~kItemMask);
-							const uint32_t e = tab.get_end(items[ni - 1u] & ~kItemMask);
-							lc = (e & 3u) ^ 1u;
-						}
-					}
-					last = __builtin_amdgcn_readfirstlane(lc);
-					rib = 0;
-				}
-				else if (prevt) {
-					// remove_spurious_branches (crackcodes.hpp:250-281): the 'b' popped by the
-					// previous 't' and this 't' vanish
-					items[prev_t_b] = kItemDead;
-					prev_t_b = pitem;
-				}
-				else {
-					const bool alt = (last == kNone) || (last == kUp);
-					items[ni] = alt ? kTalt : kT;
-					ni++;
-					last = alt ? kLeft : kUp;
-					prevt = 1;
-					prev_t_b = pitem;
-				}
-				j = pj;
-				continue;
-			}
-			pend = 0;
-			// ---- along the lowest-numbered remaining edge: right, left, down, up
-			const uint32_t k = __ffs(av) - 1;
-			tab.set_adj(j, av & ~(1u << k), l0);
-			const uint32_t e = tab.pick(e_lo, e_hi, k);
-			const uint32_t seg = kItemSeg | (j * 4u + k);
-			if (av & (av - 1u)) {
-				// ---- 'b' first: more than one edge left, remember the vertex
-				if (sp < lds_stack_cap) s_stack2[l0 ? sp : lds_stack_cap + threadIdx.x] = make_uint2(j, ni);
-				else if (sp < scap) { if (l0) { st_node[sp] = j; st_item[sp] = ni; } }
-				else err |= TRAIL_ERR_CAPACITY;
-				sp++;
-				const bool alt = (last == kNone) || (last == kDown);
-				Item2 two;
-				two.a = alt ? kBalt : kB; two.b = seg;
-				*reinterpret_cast<Item2*>(items + ni) = two;        // both items in one store
-				ni += 2;
-				rib = (last == kNone) ? 1u : 0u;
-			}
-			else { items[ni] = seg; ni++; }
-			prevt = 0;
-			const uint32_t k2 = e & 3u;
-			last = k2 ^ 1u;
-			pend = 1u << k2;
-			j = e >> 2;
-		}
-		// the closing 't' (crackcodes.hpp:436-439)
-		if (prevt) items[prev_t_b] = kItemDead;
-		else {
-			const bool alt = (last == kNone) || (last == kUp);
-			if (ni < icap) items[ni] = alt ? kTalt : kT;
-			else err |= TRAIL_ERR_CAPACITY;
-			ni++;
-		}
-		if (nch < kcap) { ch_node[nch] = adjusted; ch_item0[nch] = chain_begin; }
+		if (nch < kcap) { ch_node[nch] = sv; ch_ev0[nch] = ne; }
 		else err |= TRAIL_ERR_CAPACITY;
 		nch++;
-		if (err) break;
+		uint32_t sp = 0, pend = 0;        // pend: edge of node j consumed by the move that led here
+		for (;;) {
+			if (ne + 2u > ecap) { err |= TRAIL_ERR_CAPACITY; break; }
+			uint32_t av_raw, e_lo, e_hi;
+			tab.load(j, av_raw, e_lo, e_hi);
+			const uint2 top = s_stack2[sp < cap1 ? sp : cap1];
+			const uint32_t av = av_raw & ~pend;
+			if (av == 0) {
+				tab.set_adj(j, 0u);
+				if (sp == 0) { ev[ne] = kEvEnd; ne++; break; }
+				uint32_t pj = __builtin_amdgcn_readfirstlane(top.x), pev = __builtin_amdgcn_readfirstlane(top.y);
+				if (sp > cap1) {
+					pj = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_node + sp - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+					pev = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st_ev + sp - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+				}
+				ev[ne] = kEvDead | pev;
+				ne++; sp--; pend = 0; j = pj;
+				continue;
+			}
+			// along the lowest-numbered remaining edge: right, left, down, up
+			const uint32_t k = __ffs(av) - 1;
+			const uint32_t rest = av & ~(1u << k);
+			tab.set_adj(j, rest);
+			const uint32_t e = tab.pick(e_lo, e_hi, k);
+			const bool multi = rest != 0;
+			if (multi && sp >= cap1) {
+				if (sp < scap) { st_node[sp] = j; st_ev[sp] = ne; }
+				else err |= TRAIL_ERR_CAPACITY;
+			}
+			s_stack2[(multi && sp < cap1) ? sp + 1u : 0u] = make_uint2(j, ne);
+			ev[ne] = (multi ? kEvBseg : kEvSeg) | (j * 4u + k);
+			ne++;
+			sp += multi ? 1u : 0u;
+			pend = 1u << (e & 3u);
+			j = e >> 2;
+		}
 	}
-	if (l0 && a.dbg) {
-		atomicAdd(a.dbg + 8, static_cast<unsigned long long>(dbg_iters));
+	if (kTuning && a.dbg) {
+		atomicAdd(a.dbg + 8, static_cast<unsigned long long>(ne));
 		atomicAdd(a.dbg + 9, __builtin_amdgcn_s_memtime() - dbg_t0);
 		atomicAdd(a.dbg + 10, __builtin_amdgcn_s_memrealtime() - dbg_r0);
 		atomicAdd(a.dbg + 11, 1ull);
 	}
-	if (l0) {
-		a.n_items[zi] = ni < icap ? ni : icap;
-		a.n_chains[zi] = nch < kcap ? nch : kcap;
-		if (err) atomicOr(a.slice_err + zi, err);
+	a.n_events[zi] = ne < ecap ? ne : ecap;
+	a.n_chains[zi] = nch < kcap ? nch : kcap;
+	if (err) atomicOr(a.slice_err + zi, err);
+}
+
+// The walk of one chain in hand-scheduled code.  A single wavefront issues one instruction every
+// ~4.5 cycles whatever its kind, pays ~22 for a taken branch, ~50 for an LDS round trip and ~25 more for
+// the hop VGPR -> SGPR (tools/micro/wave_latency.hip), and hipcc's version of trail_walk_slice spends
+// 70 instructions and 3-4 taken branches on a step (~550 cycles).  Here a step is 25-35 instructions:
+//   node records of 16 bytes at LDS address 16 * node: { remaining edges, ends 0|1, ends 2|3, - },
+//   an end = 16 * node at the far end | edge it arrives by, so that the next record's address is one
+//   AND away; the branch stack's top entry is fetched with the record; event words go out through a
+//   VGPR byte offset that doubles as the event's index on the branch stack.
+// Needs 16 * nodes < 65536 and the dynamic LDS at address 0.  Returns 0 (chain complete), 1 (events
+// full) or 2 (branch stack beyond its LDS part: the caller walks the slice again with the tables in
+// memory).  Lane 0 only.
+__device__ __forceinline__ uint32_t trail_walk_chain_fast(
+	uint32_t j_addr, uint32_t& ev_off, uint32_t& ev_left, uint32_t stack_base, uint32_t max_depth, uint32_t* ev
+) {
+	uint32_t status, off = ev_off, left = ev_left;
+	const uint32_t top0 = stack_base - 8u;        // "top entry" of the empty stack: never used
+	const uint32_t ev_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ev)));
+	const uint32_t ev_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ev) >> 32));
+	j_addr = __builtin_amdgcn_readfirstlane(j_addr);
+	max_depth = __builtin_amdgcn_readfirstlane(max_depth);
+	asm volatile(
+		"s_setprio 3\n"                             // the label stream's kernels share the CU: this wavefront issues first
+		"s_mov_b32 s40, %[j]\n"
+		"s_mov_b32 s41, 0\n"                        // pend
+		"s_mov_b32 s42, 0\n"                        // stack depth
+		"v_readfirstlane_b32 s43, %[left]\n"
+		"s_mov_b32 s52, %[evlo]\n"
+		"s_mov_b32 s53, %[evhi]\n"
+		"s_mov_b32 s54, %[maxd]\n"
+		"v_mov_b32 v29, %[off]\n"
+		"v_mov_b32 v25, %[top]\n"
+		"1:\n"                                      // ---- a step
+		"v_mov_b32 v20, s40\n"
+		"ds_read_b128 v[32:35], v20\n"
+		"ds_read_b64 v[26:27], v25\n"
+		"s_sub_u32 s43, s43, 1\n"
+		"s_cbranch_scc1 8f\n"                       // no room for another event
+		"s_waitcnt lgkmcnt(0)\n"
+		"v_readfirstlane_b32 s46, v32\n"
+		"v_readfirstlane_b32 s44, v33\n"
+		"v_readfirstlane_b32 s45, v34\n"
+		"s_andn2_b32 s46, s46, s41\n"               // remaining edges without the one we came by
+		"s_cbranch_scc0 4f\n"
+		"s_ff1_i32_b32 s47, s46\n"                  // lowest-numbered edge: right, left, down, up
+		"s_bitset0_b32 s46, s47\n"
+		"v_mov_b32 v21, s46\n"
+		"ds_write_b32 v20, v21\n"
+		"s_lshl_b32 s48, s47, 4\n"
+		"s_lshr_b64 s[44:45], s[44:45], s48\n"      // the edge's end in the low 16 bits
+		"s_lshr_b32 s49, s40, 2\n"
+		"s_or_b32 s49, s49, s47\n"                  // dart = 4 * node + edge
+		"s_cmp_eq_u32 s46, 0\n"
+		"s_cbranch_scc1 3f\n"
+		"s_cmp_ge_u32 s42, s54\n"                   // ---- more edges left: the node goes on the branch stack
+		"s_cbranch_scc1 9f\n"
+		"s_bitset1_b32 s49, 30\n"                   // kEvBseg
+		"v_add_u32 v25, 8, v25\n"
+		"v_mov_b32 v28, s40\n"
+		"s_add_u32 s42, s42, 1\n"
+		"ds_write_b64 v25, v[28:29]\n"              // (node, this event)
+		"3:\n"
+		"v_mov_b32 v30, s49\n"
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"s_and_b32 s48, s44, 3\n"
+		"s_lshl_b32 s41, 1, s48\n"                  // the edge consumed at the far end
+		"s_and_b32 s40, s44, 0xfff0\n"
+		"s_branch 1b\n"
+		"4:\n"                                      // ---- dead end
+		"v_mov_b32 v21, 0\n"
+		"ds_write_b32 v20, v21\n"
+		"s_cmp_eq_u32 s42, 0\n"
+		"s_cbranch_scc1 7f\n"
+		"v_readfirstlane_b32 s40, v26\n"            // back to the most recent branch node
+		"v_readfirstlane_b32 s49, v27\n"
+		"s_lshr_b32 s49, s49, 2\n"
+		"s_bitset1_b32 s49, 31\n"                   // kEvDead | its kEvBseg
+		"v_mov_b32 v30, s49\n"
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"v_add_u32 v25, -8, v25\n"
+		"s_sub_u32 s42, s42, 1\n"
+		"s_mov_b32 s41, 0\n"
+		"s_branch 1b\n"
+		"7:\n"                                      // ---- the chain is complete
+		"v_mov_b32 v30, 0xc0000000\n"               // kEvEnd
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"s_mov_b32 s48, 0\n"
+		"s_branch 6f\n"
+		"8:\n"
+		"s_mov_b32 s43, 0\n"
+		"s_mov_b32 s48, 1\n"
+		"s_branch 6f\n"
+		"9:\n"
+		"s_mov_b32 s48, 2\n"
+		"6:\n"
+		"s_setprio 0\n"
+		"s_waitcnt lgkmcnt(0)\n"
+		"v_mov_b32 %[off], v29\n"
+		"v_mov_b32 %[left], s43\n"
+		"v_mov_b32 %[st], s48\n"
+		: [off] "+v"(off), [left] "+v"(left), [st] "=v"(status)
+		: [j] "s"(j_addr), [top] "v"(top0), [evlo] "s"(ev_lo), [evhi] "s"(ev_hi), [maxd] "s"(max_depth)
+		: "memory", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s52", "s53", "s54",
+		  "v20", "v21", "v25", "v32", "v33", "v34", "v35", "v26", "v27", "v28", "v29", "v30");
+	ev_off = __builtin_amdgcn_readfirstlane(off);
+	ev_left = __builtin_amdgcn_readfirstlane(left);
+	return __builtin_amdgcn_readfirstlane(status);
+}
+
+// The slice through trail_walk_chain_fast; false: the branch stack did not fit, nothing was kept.
+__device__ __forceinline__ bool trail_walk_slice_fast(const TrailArgs& a, uint32_t zi, uint32_t stack_base, uint32_t lds_bytes) {
+	const uint64_t nb = a.nbase[zi];
+	const uint32_t* starts = a.starts + nb;
+	const uint32_t n_starts = a.n_starts[zi];
+	uint32_t* ev = a.events + a.ibase[zi];
+	const uint32_t ecap = a.icap[zi];
+	uint32_t* ch_node = a.chain_node + a.kbase[zi];
+	uint32_t* ch_ev0 = a.chain_ev0 + a.kbase[zi];
+	const uint32_t kcap = a.kcap[zi];
+	const uint32_t* vert2node = a.vert2node + static_cast<uint64_t>(zi) * a.nverts;
+	const uint32_t max_depth = min((lds_bytes - stack_base) / 8u, a.walk_stack_cap);
+	uint32_t off = 0, left = ecap, nch = 0, err = 0;
+	const unsigned long long dbg_t0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
+	const unsigned long long dbg_r0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	for (uint32_t si = 0; si < n_starts && !err; si++) {
+		const uint32_t sv = __builtin_amdgcn_readfirstlane(starts[si]);
+		const uint32_t j = __builtin_amdgcn_readfirstlane(vert2node[sv]);
+		if (nch < kcap) { ch_node[nch] = sv; ch_ev0[nch] = off >> 2; }
+		else err |= TRAIL_ERR_CAPACITY;
+		nch++;
+		const uint32_t st = trail_walk_chain_fast(j << 4, off, left, stack_base, max_depth, ev);
+		if (st == 2u) return false;
+		if (st) err |= TRAIL_ERR_CAPACITY;
 	}
+	if (kTuning && a.dbg) {
+		atomicAdd(a.dbg + 8, static_cast<unsigned long long>(off >> 2));
+		atomicAdd(a.dbg + 9, __builtin_amdgcn_s_memtime() - dbg_t0);
+		atomicAdd(a.dbg + 10, __builtin_amdgcn_s_memrealtime() - dbg_r0);
+		atomicAdd(a.dbg + 11, 1ull);
+	}
+	a.n_events[zi] = off >> 2;
+	a.n_chains[zi] = nch < kcap ? nch : kcap;
+	if (err) atomicOr(a.slice_err + zi, err);
+	return true;
 }
 
 // grid = nslices, block = one wavefront; dynamic LDS = lds_bytes
-static __global__ void __launch_bounds__(kWave) k_trail_dfs(TrailArgs a, uint32_t lds_bytes) {
+static __global__ void __launch_bounds__(kWave) k_trail_walk(TrailArgs a, uint32_t lds_bytes) {
 	extern __shared__ uint32_t s_trail[];
 	const uint32_t zi = blockIdx.x + a.z0;
 	const uint32_t nn = min(a.n_nodes[zi], a.ncap[zi]);
 	const uint64_t nb = a.nbase[zi];
 	if (a.slice_err[zi]) {
-		if (threadIdx.x == 0) { a.n_items[zi] = 0; a.n_chains[zi] = 0; }
+		if (threadIdx.x == 0) { a.n_events[zi] = 0; a.n_chains[zi] = 0; }
 		return;
 	}
-	// LDS: [dart ends u16 x 4 nn][adj u8 x nn][64 scratch dwords][branch stack: (node, item) pairs + 64 scratch pairs]
-	const uint32_t tab_bytes = ((nn * 9u + 15u) / 16u) * 16u + 256u;
-	const bool in_lds = nn < 16384u && tab_bytes + 2048u + 512u <= lds_bytes;
+	const unsigned long long dbg_k0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
+	// hand-scheduled walk: [node records of 16 bytes][branch stack: (node, event) pairs]
+	const uint32_t rec_bytes = nn * 16u + 16u;
+	if (!a.walk_plain && nn < 4095u && rec_bytes + 4096u <= lds_bytes && __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s_trail))) == 0u) {
+		for (uint32_t j = threadIdx.x; j < nn; j += kWave) {
+			uint32_t e[4];
+#pragma unroll
+			for (uint32_t k = 0; k < 4; k++) {
+				const uint32_t d = a.dart_end[(nb + j) * 4u + k];
+				e[k] = d == kDartNone ? 0xFFFFu : (((d >> 2) << 4) | (d & 3u));
+			}
+			reinterpret_cast<uint4*>(s_trail)[j] = make_uint4(a.node_adj[nb + j], e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u);
+		}
+		__syncthreads();
+		if (kTuning && a.dbg && threadIdx.x == 0) atomicAdd(a.dbg + 6, __builtin_amdgcn_s_memtime() - dbg_k0);
+		bool done = false;
+		if (threadIdx.x == 0) done = trail_walk_slice_fast(a, zi, rec_bytes, lds_bytes);
+		if (kTuning && a.dbg && threadIdx.x == 0) atomicAdd(a.dbg + 7, __builtin_amdgcn_s_memtime() - dbg_k0);
+		if (__builtin_amdgcn_readfirstlane(done ? 1u : 0u)) return;
+		__syncthreads();
+	}
+	// LDS: [dart ends u16 x 4 nn][adj u8 x nn][branch stack: (node, event) pairs]
+	const uint32_t tab_bytes = ((nn * 9u + 15u) / 16u) * 16u;
+	const bool in_lds = nn < 16384u && tab_bytes + 2048u <= lds_bytes;
 	if (in_lds) {
 		TrailTabLds t;
 		t.end4 = reinterpret_cast<unsigned long long*>(s_trail);
 		t.adj = reinterpret_cast<uint8_t*>(s_trail) + nn * 8u;
-		t.dummy = (tab_bytes - 256u) - nn * 8u;
 		uint16_t* e16 = reinterpret_cast<uint16_t*>(s_trail);
 		for (uint32_t d = threadIdx.x; d < nn * 4u; d += kWave) {
 			const uint32_t e = a.dart_end[nb * 4u + d];
@@ -873,15 +972,234 @@ static __global__ void __launch_bounds__(kWave) k_trail_dfs(TrailArgs a, uint32_
 		}
 		for (uint32_t j = threadIdx.x; j < nn; j += kWave) t.adj[j] = a.node_adj[nb + j];
 		__syncthreads();
-		uint32_t* stack = s_trail + tab_bytes / 4u;
-		trail_dfs_slice<TrailTabLds>(a, zi, t, stack, (lds_bytes - tab_bytes) / 8u - 64u);
+		if (threadIdx.x == 0) trail_walk_slice<TrailTabLds>(a, zi, t, reinterpret_cast<uint2*>(s_trail + tab_bytes / 4u), (lds_bytes - tab_bytes) / 8u);
 	}
-	else {
+	else if (threadIdx.x == 0) {
 		TrailTabGlobal t;
 		t.adj = a.node_adj + nb;
 		t.end = a.dart_end + nb * 4u;
-		trail_dfs_slice<TrailTabGlobal>(a, zi, t, s_trail, lds_bytes / 8u - 64u);
+		trail_walk_slice<TrailTabGlobal>(a, zi, t, reinterpret_cast<uint2*>(s_trail), lds_bytes / 8u);
 	}
+}
+
+// ---- events -> items ------------------------------------------------------------------
+// What the reference's walk decides step by step as it emits, for all steps of a slice at once (one
+// workgroup per slice).
+// Per event i of a chain (a chain's events end with its kEvEnd):
+//   rib(i)      kEvDead that remove_initial_branch swallows (crackcodes.hpp:185-242): the chain began
+//               with a kEvBseg and nothing but plain segments lies between the two.  The leading 'b'
+//               and this 't' vanish, the first stretch is emitted backwards (its darts reversed), the
+//               chain starts where that stretch ended
+//   dead(i)     kEvDead / kEvEnd that is not rib(i): a 't'
+//   items       kEvSeg 1, kEvBseg 2 ('b' + segment), dead(i) 1 -- unless dead(i - 1): then the 't' and
+//               the 'b' that event i - 1 had popped vanish instead (remove_spurious_branches,
+//               crackcodes.hpp:250-281; the chain's end counts as a 't', crackcodes.hpp:436-439)
+//   last(i)     direction of the code in front of event i's items, which picks the form of 'b' and 't'
+//               (crackcodes.hpp:155-174): arrival direction of a segment; after a run of dead events
+//               only its first one emitted, so the direction in front of the run decides
+// Scratch: lnp[i] = latest event <= i that is not a plain segment, lnd[i] = latest event <= i that is
+// not dead, xi[i] = first item of event i | flags.
+constexpr uint32_t kXiRib = 1u << 31, kXiDead = 1u << 30, kXiPrevDead = 1u << 29, kXiMask = (1u << 29) - 1u;
+constexpr uint32_t kRibList = 32, kRibSerial = 32;
+
+struct TrailEvents {
+	const uint32_t* ev;
+	const int32_t* lnp;
+	uint32_t n;
+	__device__ __forceinline__ bool first(uint32_t i) const { return i == 0 || (ev[i - 1] & kEvMask) == kEvEnd; }
+	// chain-first kEvBseg that event i (a kEvDead) closes as an initial branch, or -1
+	__device__ __forceinline__ int32_t rib_of(uint32_t i) const {
+		if ((ev[i] & kEvMask) != kEvDead || i == 0) return -1;
+		const int32_t q = lnp[i - 1];
+		if (q < 0 || (ev[q] & kEvMask) != kEvBseg || !first(static_cast<uint32_t>(q))) return -1;
+		return q;
+	}
+	__device__ __forceinline__ bool dead(uint32_t i) const {
+		const uint32_t k = ev[i] & kEvMask;
+		return k == kEvEnd || (k == kEvDead && rib_of(i) < 0);
+	}
+};
+
+// grid = nslices
+static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
+	__shared__ uint32_t s_scan[kWaves];
+	__shared__ int32_t s_scan_max[kWaves];
+	__shared__ uint32_t s_nrib;
+	__shared__ uint32_t s_rib[kRibList];
+	const uint32_t zi = blockIdx.x + a.z0;
+	if (a.slice_err[zi]) {
+		if (threadIdx.x == 0) a.n_items[zi] = 0;
+		return;
+	}
+	const uint32_t n = a.n_events[zi];
+	const uint64_t ib = a.ibase[zi], nb = a.nbase[zi];
+	const uint32_t* ev = a.events + ib;
+	int32_t* lnp = reinterpret_cast<int32_t*>(a.item_off + ib);      // free until k_trail_offsets
+	int32_t* lnd = reinterpret_cast<int32_t*>(a.ev_lnd + ib);
+	uint32_t* xi = a.ev_item + ib;
+	uint32_t* items = a.items + ib;
+	const uint32_t icap = a.icap[zi];
+	const uint32_t* dend = a.dart_end + nb * 4u;
+	constexpr uint32_t kPer = 4;
+	constexpr uint32_t kNone = 4u, kLeft = 1u, kUp = 3u;
+	constexpr uint32_t kB = kItemCtl | TCODE_UP | (TCODE_DOWN << 2), kBalt = kItemCtl | TCODE_LEFT | (TCODE_RIGHT << 2);
+	constexpr uint32_t kT = kItemCtl | TCODE_DOWN | (TCODE_UP << 2), kTalt = kItemCtl | TCODE_RIGHT | (TCODE_LEFT << 2);
+	if (threadIdx.x == 0) s_nrib = 0;
+
+	// pass 1: lnp
+	{
+		int32_t carry = -1;
+		for (uint32_t i0 = 0; i0 < n; i0 += kBlock * kPer) {
+			int32_t v[kPer], run = -1;
+#pragma unroll
+			for (uint32_t q = 0; q < kPer; q++) {
+				const uint32_t i = i0 + threadIdx.x * kPer + q;
+				if (i < n && (ev[i] & kEvMask) != kEvSeg) run = static_cast<int32_t>(i);
+				v[q] = run;
+			}
+			int32_t total;
+			const int32_t excl = block_excl_max(run, total, s_scan_max);
+			const int32_t pre = carry > excl ? carry : excl;
+#pragma unroll
+			for (uint32_t q = 0; q < kPer; q++) {
+				const uint32_t i = i0 + threadIdx.x * kPer + q;
+				if (i < n) lnp[i] = v[q] > pre ? v[q] : pre;
+			}
+			carry = carry > total ? carry : total;
+		}
+	}
+	__syncthreads();
+	__threadfence_block();
+	TrailEvents te = { ev, lnp, n };
+
+	// pass 2: flags, first item of every event, lnd
+	uint32_t total_items = 0;
+	{
+		int32_t carry_max = -1;
+		for (uint32_t i0 = 0; i0 < n; i0 += kBlock * kPer) {
+			uint32_t cnt[kPer], fl[kPer], sum = 0;
+			int32_t v[kPer], run = -1;
+#pragma unroll
+			for (uint32_t q = 0; q < kPer; q++) {
+				const uint32_t i = i0 + threadIdx.x * kPer + q;
+				cnt[q] = 0; fl[q] = 0;
+				if (i < n) {
+					const uint32_t k = ev[i] & kEvMask;
+					if (k == kEvSeg) cnt[q] = 1;
+					else if (k == kEvBseg) cnt[q] = 2;
+					else {
+						const bool rib = k == kEvDead && te.rib_of(i) >= 0;
+						const bool prev_dead = !te.first(i) && te.dead(i - 1);
+						if (rib) fl[q] = kXiRib;
+						else { fl[q] = kXiDead | (prev_dead ? kXiPrevDead : 0u); cnt[q] = prev_dead ? 0u : 1u; }
+					}
+					if (!(fl[q] & kXiDead)) run = static_cast<int32_t>(i);
+				}
+				v[q] = run;
+				sum += cnt[q];
+			}
+			uint32_t sv[1] = { sum }, tot[1];
+			block_excl_add<1>(sv, tot, s_scan);
+			int32_t total_max;
+			const int32_t excl = block_excl_max(run, total_max, s_scan_max);
+			const int32_t pre = carry_max > excl ? carry_max : excl;
+			uint32_t x = total_items + sv[0];
+#pragma unroll
+			for (uint32_t q = 0; q < kPer; q++) {
+				const uint32_t i = i0 + threadIdx.x * kPer + q;
+				if (i < n) {
+					xi[i] = x | fl[q];
+					lnd[i] = v[q] > pre ? v[q] : pre;
+				}
+				x += cnt[q];
+			}
+			total_items += tot[0];
+			carry_max = carry_max > total_max ? carry_max : total_max;
+		}
+	}
+	__syncthreads();
+	__threadfence_block();
+	if (total_items > icap || total_items > kXiMask) {
+		if (threadIdx.x == 0) { atomicOr(a.slice_err + zi, TRAIL_ERR_CAPACITY); a.n_items[zi] = 0; }
+		return;
+	}
+
+	// direction of the code in front of event i when event i - 1 is not dead (4: none)
+	auto last_simple = [&](uint32_t i) -> uint32_t {
+		if (te.first(i)) return kNone;
+		const uint32_t p = ev[i - 1];
+		if ((p & kEvMask) == kEvDead) {      // rib: the reversed stretch ends with the first segment walked backwards
+			const int32_t q = lnp[i - 2];
+			return (ev[q] & 3u) ^ 1u;
+		}
+		return (dend[p & ~kEvMask] & 3u) ^ 1u;
+	};
+	auto last_before = [&](uint32_t i) -> uint32_t {
+		if (te.first(i) || !(xi[i - 1] & kXiDead)) return last_simple(i);
+		// a run of dead events in front: its first one emitted the 't'
+		const uint32_t r = static_cast<uint32_t>(lnd[i - 1] + 1);
+		const uint32_t lb = last_simple(r);
+		return ((0x18u >> lb) & 1u) ? kLeft : kUp;
+	};
+
+	// pass 3: the items
+	for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+		const uint32_t e = ev[i], k = e & kEvMask, xf = xi[i], x = xf & kXiMask;
+		if (k == kEvSeg) items[x] = kItemSeg | (e & ~kEvMask);
+		else if (k == kEvBseg) {
+			const uint32_t lb = last_before(i);
+			items[x] = ((0x14u >> lb) & 1u) ? kBalt : kB;        // no code in front, or DOWN
+			items[x + 1] = kItemSeg | (e & ~kEvMask);
+		}
+		else if ((xf & (kXiDead | kXiPrevDead)) == kXiDead) {
+			const uint32_t lb = last_simple(i);
+			items[x] = ((0x18u >> lb) & 1u) ? kTalt : kT;        // no code in front, or UP
+		}
+	}
+	__syncthreads();
+	__threadfence_block();
+
+	// pass 4: what vanishes, and the initial branches
+	for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+		const uint32_t xf = xi[i];
+		if ((xf & (kXiDead | kXiPrevDead)) == (kXiDead | kXiPrevDead)) {
+			const uint32_t b = ev[i - 1] & ~kEvMask;        // event i - 1 is a kEvDead: the 'b' it popped
+			items[xi[b] & kXiMask] = kItemDead;
+		}
+		if (xf & kXiRib) {
+			const uint32_t q = static_cast<uint32_t>(lnp[i - 1]);
+			const uint32_t x0 = xi[q] & kXiMask;
+			items[x0] = kItemDead;
+			// chain of q: the start moves to where the stretch ended
+			const uint32_t* ev0 = a.chain_ev0 + a.kbase[zi];
+			uint32_t lo = 0, hi = a.n_chains[zi];
+			while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (ev0[mid] <= q) lo = mid; else hi = mid; }
+			a.chain_node[a.kbase[zi] + lo] = a.node_vertex[nb + (dend[ev[i - 1] & ~kEvMask] >> 2)];
+			const uint32_t len = i - q;
+			uint32_t slot = kRibList;
+			if (len > kRibSerial) slot = atomicAdd(&s_nrib, 1u);
+			if (slot < kRibList) s_rib[slot] = i;
+			else for (uint32_t m = q; m < i; m++) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[ev[m] & ~kEvMask];
+		}
+	}
+	__syncthreads();
+	{
+		const uint32_t nr = s_nrib < kRibList ? s_nrib : kRibList;
+		for (uint32_t r = 0; r < nr; r++) {
+			const uint32_t i = s_rib[r];
+			const uint32_t q = static_cast<uint32_t>(lnp[i - 1]);
+			const uint32_t x0 = xi[q] & kXiMask;
+			for (uint32_t m = q + threadIdx.x; m < i; m += kBlock) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[ev[m] & ~kEvMask];
+		}
+	}
+	// chains
+	{
+		const uint32_t nch = a.n_chains[zi];
+		const uint32_t* ev0 = a.chain_ev0 + a.kbase[zi];
+		uint32_t* item0 = a.chain_item0 + a.kbase[zi];
+		for (uint32_t c = threadIdx.x; c < nch; c += kBlock) item0[c] = ev0[c] < n ? (xi[ev0[c]] & kXiMask) : total_items;
+	}
+	if (threadIdx.x == 0) a.n_items[zi] = total_items;
 }
 
 // grid = nslices: code offset of every item, chain offsets and lengths

@@ -11,7 +11,7 @@ starts = [i for i, n in enumerate(names) if "k_label_planes" in n]
 first = starts[-1]
 last = next(i for i in range(first, len(rows)) if "k_decode_cracks" in names[i])
 t0 = int(rows[first]["Start_Timestamp"])
-trail_q = next(r["Queue_Id"] for r in rows[first:last] if "k_trail_dfs" in r["Kernel_Name"])
+trail_q = next(r["Queue_Id"] for r in rows[first:last] if "k_trail_walk" in r["Kernel_Name"])
 prev_end = None
 for r in rows[first:last]:
   s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
