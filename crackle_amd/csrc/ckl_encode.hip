@@ -873,6 +873,7 @@ struct ckl_encoder {
 	DevBuf<uint32_t> d_slice_err;
 	DevBuf<uint64_t> d_cbase, d_sbase, d_kbase, d_pbase, d_bbase, d_out_off, d_comp_off;
 	DevBuf<uint32_t> d_ccap, d_scap, d_kcap;
+	DevBuf<uint8_t> d_crack_tables;               // packed block behind the per-slice base / capacity tables of crack_pass
 	DevBuf<uint8_t> d_cp, d_fcode, d_dcode, d_payload, d_boc, d_codes_out, d_model;
 	DevBuf<uint32_t> d_code_report;
 	uint64_t codes_capacity = 0;        // bound of all slices' BOC + payload bytes
@@ -951,6 +952,29 @@ void upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t s) {
 	d.ensure(h.size());
 	if (!h.empty()) CKL_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
 }
+// Many small tables in ONE copy: the tables become views of a packed block (a copy of a few bytes costs
+// ~8 us of stream time, and crack_pass needs fifteen of them between two kernels of the trail).
+struct UploadPacker {
+	struct Item { void* buf; size_t off, count; void (*bind)(void*, uint8_t*, size_t); };
+	std::vector<Item> items;
+	std::vector<uint8_t> image;
+	template <typename T>
+	void add(DevBuf<T>& dst, const std::vector<T>& src) {
+		const size_t off = (image.size() + 255) & ~static_cast<size_t>(255);
+		image.resize(off + std::max<size_t>(src.size(), 1) * sizeof(T));
+		if (!src.empty()) memcpy(image.data() + off, src.data(), src.size() * sizeof(T));
+		items.push_back({ &dst, off, src.size(), [](void* b, uint8_t* base, size_t n) { static_cast<DevBuf<T>*>(b)->borrow(reinterpret_cast<T*>(base), n); } });
+	}
+	// `block` must not be in use by kernels of another stream; the copy is ordered on `s`
+	void commit(DevBuf<uint8_t>& block, hipStream_t s) {
+		if (image.empty()) return;
+		for (const Item& it : items) it.bind(it.buf, nullptr, 0);        // views of the old block go first: ensure() may free it
+		block.ensure(image.size());
+		CKL_HIP(hipMemcpyAsync(block.p, image.data(), image.size(), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
+		for (const Item& it : items) it.bind(it.buf, block.p + it.off, it.count);
+	}
+};
+
 template <typename T>
 std::vector<T> download(const T* p, size_t n, hipStream_t s) {
 	std::vector<T> h(n);
@@ -1139,9 +1163,10 @@ void crack_pass(
 		max_special = std::max<uint32_t>(max_special, e.count_special[zi]);
 	}
 	if (result) result->any_chain = any;
-	upload(e.d_cbase, cbase, s); upload(e.d_ccap, ccap, s);
-	upload(e.d_sbase, sbase, s); upload(e.d_scap, scap, s);
-	upload(e.d_kbase, kbase, s); upload(e.d_kcap, kcap, s);
+	UploadPacker tables;
+	tables.add(e.d_cbase, cbase); tables.add(e.d_ccap, ccap);
+	tables.add(e.d_sbase, sbase); tables.add(e.d_scap, scap);
+	tables.add(e.d_kbase, kbase); tables.add(e.d_kcap, kcap);
 	e.d_cp.ensure(ctot); e.d_fcode.ensure(ctot);
 	if (markov_order) e.d_dcode.ensure(ctot);
 	e.d_stack_node.ensure(stot); e.d_stack_code.ensure(stot);
@@ -1162,7 +1187,12 @@ void crack_pass(
 		const uint64_t bbytes = 4 + yw + static_cast<uint64_t>(kcap[zi]) * (yw + 2 * xw);
 		bbase[zi] = btot; btot += bbytes;
 	}
-	upload(e.d_pbase, pbase, s); upload(e.d_bbase, bbase, s);
+	tables.add(e.d_pbase, pbase); tables.add(e.d_bbase, bbase);
+	tables.add(e.t_nbase, nbase); tables.add(e.t_ncap, ncap);
+	tables.add(e.t_cobase, cobase); tables.add(e.t_cocap, cocap);
+	tables.add(e.t_ibase, ibase); tables.add(e.t_icap, icap);
+	tables.add(e.t_max_steps, max_steps);
+	tables.commit(e.d_crack_tables, s);
 	e.d_payload.ensure(ptot + 8); e.d_boc.ensure(btot + 8);
 	e.codes_capacity = ptot + btot;
 	if (markov_order) CKL_HIP(hipMemsetAsync(e.d_payload.p, 0, ptot + 8, s));
@@ -1184,10 +1214,6 @@ void crack_pass(
 	CKL_HIP(hipEventRecord(e.evk0, s));
 	{
 		// ---- the trail over the node graph (ckl_trail.hpp)
-		upload(e.t_nbase, nbase, s); upload(e.t_ncap, ncap, s);
-		upload(e.t_cobase, cobase, s); upload(e.t_cocap, cocap, s);
-		upload(e.t_ibase, ibase, s); upload(e.t_icap, icap, s);
-		upload(e.t_max_steps, max_steps, s);
 		e.t_counters.ensure(6 * static_cast<size_t>(ns));
 		CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 6 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
 		e.t_node_vertex.ensure(ntot); e.t_node_adj.ensure(ntot + 16); e.t_vert2node.ensure(nverts * ns);

@@ -9,7 +9,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 starts = [i for i, n in enumerate(names) if "k_label_planes" in n]
 first = starts[-1]
-last = next(i for i in range(first, len(rows)) if "k_decode_cracks" in names[i])
+last = next(i for i in range(first, len(rows)) if ("k_crack_match" in names[i] or "k_decode_cracks" in names[i]))
 t0 = int(rows[first]["Start_Timestamp"])
 trail_q = next(r["Queue_Id"] for r in rows[first:last] if "k_trail_walk" in r["Kernel_Name"])
 prev_end = None
