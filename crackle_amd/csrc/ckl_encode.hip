@@ -926,6 +926,8 @@ struct ckl_encoder {
 	DevBuf<uint32_t> t_node_vertex, t_vert2node, t_corner_vertex;
 	DevBuf<uint8_t> t_node_adj;
 	DevBuf<uint32_t> t_dart_end, t_dart_len, t_dart_minv, t_dart_minpos, t_parent, t_start_bits, t_starts;
+	DevBuf<uint4> t_dart_codes;
+	DevBuf<uint8_t> t_dart_inline;
 	DevBuf<unsigned long long> t_compmin;
 	DevBuf<uint32_t> t_items, t_item_off, t_chain_item0, t_events, t_chain_ev0, t_ev_lnd, t_ev_item;
 
@@ -1219,6 +1221,7 @@ void crack_pass(
 		e.t_node_vertex.ensure(ntot); e.t_node_adj.ensure(ntot + 16); e.t_vert2node.ensure(nverts * ns);
 		e.t_corner_vertex.ensure(cotot);
 		e.t_dart_end.ensure(4 * ntot); e.t_dart_len.ensure(4 * ntot); e.t_dart_minv.ensure(4 * ntot); e.t_dart_minpos.ensure(4 * ntot);
+		e.t_dart_codes.ensure(4 * ntot); e.t_dart_inline.ensure(4 * ntot);
 		e.t_parent.ensure(ntot); e.t_compmin.ensure(ntot); e.t_starts.ensure(ntot);
 		const uint32_t start_words = static_cast<uint32_t>((nverts + 31) / 32);
 		e.t_start_bits.ensure(static_cast<size_t>(start_words) * ns);
@@ -1238,6 +1241,7 @@ void crack_pass(
 		ta.node_vertex = e.t_node_vertex.p; ta.node_adj = e.t_node_adj.p; ta.vert2node = e.t_vert2node.p;
 		ta.cobase = e.t_cobase.p; ta.cocap = e.t_cocap.p; ta.corner_vertex = e.t_corner_vertex.p;
 		ta.dart_end = e.t_dart_end.p; ta.dart_len = e.t_dart_len.p; ta.dart_minv = e.t_dart_minv.p; ta.dart_minpos = e.t_dart_minpos.p;
+		ta.dart_codes = e.t_dart_codes.p; ta.dart_inline = e.t_dart_inline.p;
 		ta.parent = e.t_parent.p; ta.compmin = e.t_compmin.p;
 		ta.start_bits = e.t_start_bits.p; ta.start_words = start_words; ta.starts = e.t_starts.p;
 		ta.ibase = e.t_ibase.p; ta.icap = e.t_icap.p; ta.items = e.t_items.p; ta.item_off = e.t_item_off.p;
@@ -1300,7 +1304,7 @@ void crack_pass(
 			if (g == 0) CKL_HIP(hipEventRecord(e.evd0, gs));
 			hipLaunchKernelGGL(k_trail_walk, dim3(gn), dim3(kWave), lds, gs, ta, static_cast<uint32_t>(lds));
 			if (g == 0) CKL_HIP(hipEventRecord(e.evd1, gs));
-			hipLaunchKernelGGL(k_trail_items, dim3(gn), dim3(kBlock), 0, gs, ta);
+			hipLaunchKernelGGL(k_trail_items, dim3(gn), dim3(kItemsBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_trail_offsets, dim3(gn), dim3(kBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_trail_expand, dim3((max_icap + kExpandChunk * kWaves - 1) / (kExpandChunk * kWaves), gn), dim3(kBlock), 0, gs, ta);
 			hipLaunchKernelGGL(k_finish, dim3(gn), dim3(kFinishBlock), 0, gs, fa);

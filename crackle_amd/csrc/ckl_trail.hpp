@@ -96,6 +96,8 @@ struct TrailArgs {
 	uint32_t* dart_len;
 	uint32_t* dart_minv;         // smallest vertex on the closed segment
 	uint32_t* dart_minpos;       // its distance from the node << 2 | arrival edge there
+	uint4* dart_codes;           // the segment's first kInlineCodes code points, 2 bits each (code i at bit 2 i)
+	uint8_t* dart_inline;        // 1: dart_codes holds the whole segment (k_trail_expand copies instead of walking)
 	// components
 	uint32_t* parent;
 	unsigned long long* compmin; // smallest vertex << 32 | dart that saw it
@@ -315,6 +317,7 @@ constexpr uint32_t kWalkChunk = 192;       // darts per wavefront (k_trail_segme
 constexpr uint32_t kExpandChunk = 384;     // items per wavefront (k_trail_expand)
 constexpr int kWalkRefill = 16;     // idle lanes that trigger a refill (its loads cost as much as a step)
 constexpr int kWalkAhead = 3;       // steps a lane may run ahead inside its micro-tile per memory round trip
+constexpr uint32_t kInlineCodes = 64;      // code points of a segment that k_trail_segments keeps beside the dart (16 bytes)
 
 // Results are staged in LDS and written out once per wavefront: on this architecture loads
 // and stores retire in order on one counter, so a store inside the loop would make every
@@ -322,6 +325,7 @@ constexpr int kWalkAhead = 3;       // steps a lane may run ahead inside its mic
 // grid = (ceil(4 * max nodes / (kWalkChunk * 4)), nslices)
 static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 	__shared__ uint4 s_res[kWaves][kWalkChunk];       // end, len, minv, minpos
+	__shared__ uint4 s_codes[kWaves][kWalkChunk];     // the walk's code points
 	const uint32_t zi = blockIdx.y + a.z0;
 	const uint32_t lane = threadIdx.x & (kWave - 1);
 	const uint32_t wv = threadIdx.x >> 6;
@@ -337,12 +341,21 @@ static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 	const uint32_t cap = a.max_steps[zi];
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	uint4* res = s_res[wv];
+	uint4* res_codes = s_codes[wv];
 	for (uint32_t i = lane; i < kWalkChunk; i += kWave) res[i] = make_uint4(kDartNone, 0u, 0u, 0u);
 	MicroTile c;
 	c.lo = c.hi = make_uint4(0, 0, 0, 0); c.mx = c.my = 0xFFFFFFFFu;
 	bool active = false;
 	// (x, y): the vertex to look at next, reached by a move in direction k after `steps` edges
 	uint32_t d = 0, x = 0, y = 0, k = 0, steps = 0, minv = 0, minpos = 0, err = 0;
+	// the last kInlineCodes code points, newest in the top bits: a move shifts the 128 bits down by two
+	uint4 cq = make_uint4(0, 0, 0, 0);
+	auto push_code = [&](uint32_t kk) {
+		cq.x = __builtin_amdgcn_alignbit(cq.y, cq.x, 2);
+		cq.y = __builtin_amdgcn_alignbit(cq.z, cq.y, 2);
+		cq.z = __builtin_amdgcn_alignbit(cq.w, cq.z, 2);
+		cq.w = (cq.w >> 2) | (trail_code(kk) << 30);
+	};
 	unsigned long long dbg_iter = 0, dbg_lane = 0;
 	const unsigned long long dbg_t0 = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 	for (;;) {
@@ -368,10 +381,11 @@ static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 				bool fin = false;
 				if (__popc(nib) != 2) fin = true;
 				else if (steps >= cap) { err = TRAIL_ERR_CAPACITY; fin = true; }
-				else { k = __ffs(nib & ~(1u << arr)) - 1; trail_step(x, y, k); steps++; }
+				else { k = __ffs(nib & ~(1u << arr)) - 1; push_code(k); trail_step(x, y, k); steps++; }
 				if (fin) {
 					// x: end vertex << 2 | arrival edge (the vertex becomes a node index in the flush below)
 					res[d - range_begin] = make_uint4((w << 2) | arr, steps, minv, minpos);
+					res_codes[d - range_begin] = cq;
 					active = false;
 				}
 			}
@@ -380,6 +394,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 			d = cand; k = cand & 3u;
 			y = r_v0 / a.sxe; x = r_v0 - y * a.sxe;
 			minv = r_v0; minpos = 0;
+			push_code(k);
 			trail_step(x, y, k);
 			steps = 1;
 			active = true;
@@ -401,6 +416,20 @@ static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 		a.dart_len[db + i] = r.y;
 		a.dart_minv[db + i] = r.z;
 		a.dart_minpos[db + i] = r.w;
+		// the first code point to bit 0: the newest sits at bit 126
+		const uint4 q = res_codes[i];
+		const bool whole = r.x != kDartNone && r.y >= 1u && r.y <= kInlineCodes;
+		uint4 o = make_uint4(0, 0, 0, 0);
+		if (whole) {
+			const uint32_t sh = 128u - 2u * r.y, w = sh >> 5, b = sh & 31u;
+			const uint32_t v[5] = { q.x, q.y, q.z, q.w, 0u };
+			auto word = [&](uint32_t t) -> uint32_t { return t == 0 ? v[0] : t == 1 ? v[1] : t == 2 ? v[2] : t == 3 ? v[3] : 0u; };
+			auto pick = [&](uint32_t t) -> uint32_t { return __builtin_amdgcn_alignbit(word(t + w + 1u), word(t + w), b); };
+			o = make_uint4(pick(0), pick(1), pick(2), pick(3));
+			(void)v;
+		}
+		a.dart_codes[db + i] = o;
+		a.dart_inline[db + i] = whole ? 1u : 0u;
 	}
 	if (err) atomicOr(a.slice_err + zi, err);
 }
@@ -443,7 +472,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_loops(TrailArgs a) {
 	a.node_adj[nb + j] = 5u;
 	a.vert2node[static_cast<uint64_t>(zi) * a.nverts + v0] = j;
 	const uint64_t db = (nb + j) * 4u;
-	for (uint32_t q = 0; q < 4; q++) { a.dart_end[db + q] = kDartNone; a.dart_len[db + q] = 0; a.dart_minv[db + q] = v0; a.dart_minpos[db + q] = 0; }
+	for (uint32_t q = 0; q < 4; q++) { a.dart_end[db + q] = kDartNone; a.dart_len[db + q] = 0; a.dart_minv[db + q] = v0; a.dart_minpos[db + q] = 0; a.dart_inline[db + q] = 0; }
 	a.dart_end[db + 0] = (j << 2) | 2u; a.dart_len[db + 0] = steps;     // leaves to the right, comes back up the down edge
 	a.dart_end[db + 2] = (j << 2) | 0u; a.dart_len[db + 2] = steps;
 }
@@ -578,7 +607,7 @@ __device__ __forceinline__ void trail_components_slice(const TrailArgs& a, uint3
 		a.vert2node[static_cast<uint64_t>(zi) * a.nverts + minv] = s;
 		const uint32_t d2 = a.dart_end[db + d];              // far end: node << 2 | arrival = the dart that runs back
 		const uint32_t other = arr ^ 2u;
-		for (uint32_t q = 0; q < 4; q++) { a.dart_end[db + s * 4u + q] = kDartNone; a.dart_len[db + s * 4u + q] = 0; }
+		for (uint32_t q = 0; q < 4; q++) { a.dart_end[db + s * 4u + q] = kDartNone; a.dart_len[db + s * 4u + q] = 0; a.dart_inline[db + s * 4u + q] = 0; }      // (the two halves keep their codes: a prefix)
 		a.dart_end[db + d] = (s << 2) | arr;        a.dart_len[db + d] = pos;
 		a.dart_end[db + d2] = (s << 2) | other;     a.dart_len[db + d2] = len - pos;
 		a.dart_end[db + s * 4u + arr] = d;          a.dart_len[db + s * 4u + arr] = pos;
@@ -1020,10 +1049,13 @@ struct TrailEvents {
 	}
 };
 
+constexpr int kItemsBlock = 1024;      // the passes are chains of dependent loads: resident wavefronts are what hides them
+
 // grid = nslices
-static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
-	__shared__ uint32_t s_scan[kWaves];
-	__shared__ int32_t s_scan_max[kWaves];
+static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a) {
+	constexpr int kNW = kItemsBlock / kWave;
+	__shared__ uint32_t s_scan[kNW];
+	__shared__ int32_t s_scan_max[kNW];
 	__shared__ uint32_t s_nrib;
 	__shared__ uint32_t s_rib[kRibList];
 	const uint32_t zi = blockIdx.x + a.z0;
@@ -1049,7 +1081,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
 	// pass 1: lnp
 	{
 		int32_t carry = -1;
-		for (uint32_t i0 = 0; i0 < n; i0 += kBlock * kPer) {
+		for (uint32_t i0 = 0; i0 < n; i0 += kItemsBlock * kPer) {
 			int32_t v[kPer], run = -1;
 #pragma unroll
 			for (uint32_t q = 0; q < kPer; q++) {
@@ -1058,7 +1090,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
 				v[q] = run;
 			}
 			int32_t total;
-			const int32_t excl = block_excl_max(run, total, s_scan_max);
+			const int32_t excl = block_excl_max<kNW>(run, total, s_scan_max);
 			const int32_t pre = carry > excl ? carry : excl;
 #pragma unroll
 			for (uint32_t q = 0; q < kPer; q++) {
@@ -1076,7 +1108,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
 	uint32_t total_items = 0;
 	{
 		int32_t carry_max = -1;
-		for (uint32_t i0 = 0; i0 < n; i0 += kBlock * kPer) {
+		for (uint32_t i0 = 0; i0 < n; i0 += kItemsBlock * kPer) {
 			uint32_t cnt[kPer], fl[kPer], sum = 0;
 			int32_t v[kPer], run = -1;
 #pragma unroll
@@ -1099,9 +1131,9 @@ static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
 				sum += cnt[q];
 			}
 			uint32_t sv[1] = { sum }, tot[1];
-			block_excl_add<1>(sv, tot, s_scan);
+			block_excl_add<1, kNW>(sv, tot, s_scan);
 			int32_t total_max;
-			const int32_t excl = block_excl_max(run, total_max, s_scan_max);
+			const int32_t excl = block_excl_max<kNW>(run, total_max, s_scan_max);
 			const int32_t pre = carry_max > excl ? carry_max : excl;
 			uint32_t x = total_items + sv[0];
 #pragma unroll
@@ -1143,7 +1175,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
 	};
 
 	// pass 3: the items
-	for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+	for (uint32_t i = threadIdx.x; i < n; i += kItemsBlock) {
 		const uint32_t e = ev[i], k = e & kEvMask, xf = xi[i], x = xf & kXiMask;
 		if (k == kEvSeg) items[x] = kItemSeg | (e & ~kEvMask);
 		else if (k == kEvBseg) {
@@ -1160,7 +1192,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
 	__threadfence_block();
 
 	// pass 4: what vanishes, and the initial branches
-	for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+	for (uint32_t i = threadIdx.x; i < n; i += kItemsBlock) {
 		const uint32_t xf = xi[i];
 		if ((xf & (kXiDead | kXiPrevDead)) == (kXiDead | kXiPrevDead)) {
 			const uint32_t b = ev[i - 1] & ~kEvMask;        // event i - 1 is a kEvDead: the 'b' it popped
@@ -1189,7 +1221,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
 			const uint32_t i = s_rib[r];
 			const uint32_t q = static_cast<uint32_t>(lnp[i - 1]);
 			const uint32_t x0 = xi[q] & kXiMask;
-			for (uint32_t m = q + threadIdx.x; m < i; m += kBlock) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[ev[m] & ~kEvMask];
+			for (uint32_t m = q + threadIdx.x; m < i; m += kItemsBlock) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[ev[m] & ~kEvMask];
 		}
 	}
 	// chains
@@ -1197,7 +1229,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_items(TrailArgs a) {
 		const uint32_t nch = a.n_chains[zi];
 		const uint32_t* ev0 = a.chain_ev0 + a.kbase[zi];
 		uint32_t* item0 = a.chain_item0 + a.kbase[zi];
-		for (uint32_t c = threadIdx.x; c < nch; c += kBlock) item0[c] = ev0[c] < n ? (xi[ev0[c]] & kXiMask) : total_items;
+		for (uint32_t c = threadIdx.x; c < nch; c += kItemsBlock) item0[c] = ev0[c] < n ? (xi[ev0[c]] & kXiMask) : total_items;
 	}
 	if (threadIdx.x == 0) a.n_items[zi] = total_items;
 }
@@ -1256,37 +1288,82 @@ static __global__ void __launch_bounds__(kBlock) k_trail_offsets(TrailArgs a) {
 	}
 }
 
-// grid = (ceil(max items / (kExpandChunk * 4)), nslices): every item writes its code points;
-// segment items are re-walked, lanes refill from the wavefront's range like k_trail_segments
+// grid = (ceil(max items / (kExpandChunk * 4)), nslices): every item writes its code points.  A segment
+// whose code points k_trail_segments kept beside its dart (nearly all: kInlineCodes of them) is a copy;
+// the others are re-walked, lanes refilling from the wavefront's list like k_trail_segments
 static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
+	__shared__ uint32_t s_long[kWaves][kExpandChunk];      // items to walk
 	const uint32_t zi = blockIdx.y + a.z0;
 	if (a.slice_err[zi]) return;
 	const uint32_t lane = threadIdx.x & (kWave - 1);
-	const uint32_t wave = blockIdx.x * kWaves + (threadIdx.x >> 6);
+	const uint32_t wv = threadIdx.x >> 6;
+	const uint32_t wave = blockIdx.x * kWaves + wv;
 	const uint32_t n_items = a.n_items[zi];
-	uint32_t next = wave * kExpandChunk;
-	const uint32_t range_end = min(next + kExpandChunk, n_items);
-	if (next >= range_end) return;
+	const uint32_t range_begin = wave * kExpandChunk;
+	const uint32_t range_end = min(range_begin + kExpandChunk, n_items);
+	if (range_begin >= range_end) return;
 	const uint64_t nb = a.nbase[zi];
 	const uint32_t* items = a.items + a.ibase[zi];
 	const uint32_t* item_off = a.item_off + a.ibase[zi];
 	uint8_t* cp0 = a.cp + a.cbase[zi];
 	const uint4* adjm = a.adjm + zi * a.adjm_stride;
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+	uint32_t* longs = s_long[wv];
+	struct __attribute__((packed)) U64 { unsigned long long v; };
+
+	// ---- the copies
+	uint32_t n_long = 0;
+	for (uint32_t i0 = range_begin; i0 < range_end; i0 += kWave) {
+		const uint32_t i = i0 + lane;
+		bool walk = false;
+		if (i < range_end) {
+			const uint32_t it = items[i], kind = it & kItemMask;
+			uint8_t* o = cp0 + item_off[i];
+			if (kind == kItemCtl) { o[0] = static_cast<uint8_t>(it & 3u); o[1] = static_cast<uint8_t>((it >> 2) & 3u); }
+			else if (kind == kItemSeg) {
+				const uint32_t d = it & ~kItemMask;
+				const uint32_t len = a.dart_len[nb * 4u + d];
+				if (len && a.dart_inline[nb * 4u + d] && len <= kInlineCodes) {
+					const uint4 q = a.dart_codes[nb * 4u + d];
+					const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+					// eight code points (16 bits) -> eight bytes per store
+#pragma unroll
+					for (uint32_t g = 0; g < kInlineCodes / 8u; g++) {
+						if (g * 8u < len) {
+							const uint32_t h = (w[g >> 1] >> ((g & 1u) * 16u)) & 0xFFFFu;
+							uint32_t lo = h & 0xFFu, hi = h >> 8;
+							lo = (lo | (lo << 12)) & 0x000F000Fu; lo = (lo | (lo << 6)) & 0x03030303u;
+							hi = (hi | (hi << 12)) & 0x000F000Fu; hi = (hi | (hi << 6)) & 0x03030303u;
+							const unsigned long long v = (static_cast<unsigned long long>(hi) << 32) | lo;
+							if (g * 8u + 8u <= len) reinterpret_cast<U64*>(o + g * 8u)->v = v;
+							else for (uint32_t t = 0; t < len - g * 8u; t++) o[g * 8u + t] = static_cast<uint8_t>(v >> (8u * t));
+						}
+					}
+				}
+				else walk = len != 0;
+			}
+		}
+		const unsigned long long m = __ballot(walk);
+		if (walk) longs[n_long + static_cast<uint32_t>(__popcll(m & lt_mask))] = i;
+		n_long += static_cast<uint32_t>(__popcll(m));
+	}
+	if (n_long == 0) return;
+
+	// ---- the walks
 	MicroTile c;
 	c.lo = c.hi = make_uint4(0, 0, 0, 0); c.mx = c.my = 0xFFFFFFFFu;
 	bool active = false, need_nib = false;
 	// at vertex (x, y); k: direction of the next move, or (need_nib) of the move that led here
-	uint32_t x = 0, y = 0, k = 0, left = 0, nacc = 0;
+	uint32_t x = 0, y = 0, k = 0, left = 0, nacc = 0, next = 0;
 	unsigned long long acc = 0;
 	uint8_t* cp = cp0;
 	for (;;) {
 		const unsigned long long need = __ballot(!active);
-		const bool refill = next < range_end && (__popcll(need) >= kWalkRefill || need == ~0ull);
+		const bool refill = next < n_long && (__popcll(need) >= kWalkRefill || need == ~0ull);
 		const uint32_t cand = next + static_cast<uint32_t>(__popcll(need & lt_mask));
-		const bool take = refill && !active && cand < range_end;
+		const bool take = refill && !active && cand < n_long;
 		uint32_t r_it = kItemDead, r_off = 0;
-		if (take) { r_it = items[cand]; r_off = item_off[cand]; }
+		if (take) { const uint32_t i = longs[cand]; r_it = items[i]; r_off = item_off[i]; }
 		if (active && need_nib && !c.holds(x, y)) mt_load(c, adjm, x, y, a.mtx2);
 		for (int it = 0; it < kWalkAhead; it++) {
 			const bool go = active && (!need_nib || c.holds(x, y));
@@ -1299,7 +1376,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
 				trail_step(x, y, k);
 				--left;
 				if (nacc == 8u || left == 0) {
-					if (nacc == 8u) { struct __attribute__((packed)) U64 { unsigned long long v; }; reinterpret_cast<U64*>(cp)->v = acc; }
+					if (nacc == 8u) reinterpret_cast<U64*>(cp)->v = acc;
 					else for (uint32_t q = 0; q < nacc; q++) cp[q] = static_cast<uint8_t>(acc >> (8u * q));
 					cp += nacc; acc = 0; nacc = 0;
 				}
@@ -1308,26 +1385,17 @@ static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
 			}
 		}
 		if (take) {
-			const uint32_t kind = r_it & kItemMask;
-			if (kind == kItemCtl) {
-				uint8_t* o = cp0 + r_off;
-				o[0] = static_cast<uint8_t>(r_it & 3u); o[1] = static_cast<uint8_t>((r_it >> 2) & 3u);
-			}
-			else if (kind == kItemSeg) {
-				const uint32_t d = r_it & ~kItemMask;
-				left = a.dart_len[nb * 4u + d];
-				if (left) {
-					const uint32_t v0 = a.node_vertex[nb + (d >> 2)];
-					y = v0 / a.sxe; x = v0 - y * a.sxe;
-					k = d & 3u;
-					cp = cp0 + r_off;
-					need_nib = false;
-					active = true;
-				}
-			}
+			const uint32_t d = r_it & ~kItemMask;
+			left = a.dart_len[nb * 4u + d];
+			const uint32_t v0 = a.node_vertex[nb + (d >> 2)];
+			y = v0 / a.sxe; x = v0 - y * a.sxe;
+			k = d & 3u;
+			cp = cp0 + r_off;
+			need_nib = false;
+			active = true;
 		}
 		if (refill) next += static_cast<uint32_t>(__popcll(need));
-		if (!__ballot(active) && next >= range_end) break;
+		if (!__ballot(active) && next >= n_long) break;
 	}
 }
 
