@@ -54,6 +54,8 @@ EXPORTS = {
   "ckl_decoder_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
   "ckl_decoder_create_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
   "ckl_encoder_keep_device_stream": (C.c_int, [C.c_void_p, C.c_int]),
+  "ckl_encoder_async_host_copy": (C.c_int, [C.c_void_p, C.c_int]),
+  "ckl_encoder_host_wait": (C.c_int, [C.c_void_p]),
   "ckl_encoder_device_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
   "ckl_decoder_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]),
   "ckl_decoder_label_stats": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),

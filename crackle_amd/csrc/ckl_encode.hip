@@ -879,6 +879,10 @@ struct ckl_encoder {
 	uint64_t codes_capacity = 0;        // bound of all slices' BOC + payload bytes
 	bool defer_codes = false;           // ckl_encoder_defer_codes: the codes stay in d_codes_out for ckl_encoder_codes_to_host
 	bool keep_device_stream = false;    // ckl_encoder_keep_device_stream: every run also assembles the whole stream in HBM
+	bool async_host_copy = false;       // ckl_encoder_async_host_copy: a run returns when the stream is complete in HBM; its crack codes reach the host buffer on stream_copy
+	bool host_copy_pending = false;     // ... until ckl_encoder_host_wait
+	hipStream_t stream_copy = nullptr;
+	hipEvent_t ev_codes = nullptr;
 	DevBuf<uint8_t> d_stream_out;       // ... here (valid until the next run)
 	uint64_t device_stream_bytes = 0;
 	uint64_t last_codes_total = 0;      // bytes of the last run's crack codes
@@ -944,6 +948,8 @@ struct ckl_encoder {
 		for (auto& st : trail_stream) if (st) (void)hipStreamDestroy(st);
 		if (stream) (void)hipStreamDestroy(stream);
 		if (stream2) (void)hipStreamDestroy(stream2);
+		if (stream_copy) { (void)hipStreamSynchronize(stream_copy); (void)hipStreamDestroy(stream_copy); }
+		if (ev_codes) (void)hipEventDestroy(ev_codes);
 	}
 };
 
@@ -1911,7 +1917,19 @@ void encode_typed(
 	}
 	try {
 		e.last_codes_total = cr.total;
-		if (cr.total && !e.defer_codes) CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
+		if (cr.total && !e.defer_codes) {
+			if (e.async_host_copy && e.keep_device_stream) {
+				// the caller goes on with the stream in HBM (a decoder, the next volume's planes) while the codes
+				// cross PCIe: ckl_encoder_host_wait before the host bytes are read
+				if (!e.stream_copy) CKL_HIP(hipStreamCreateWithFlags(&e.stream_copy, hipStreamNonBlocking));
+				if (!e.ev_codes) CKL_HIP(hipEventCreateWithFlags(&e.ev_codes, hipEventDisableTiming));
+				CKL_HIP(hipEventRecord(e.ev_codes, s));
+				CKL_HIP(hipStreamWaitEvent(e.stream_copy, e.ev_codes, 0));
+				CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, e.stream_copy));
+				e.host_copy_pending = true;
+			}
+			else CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
+		}
 		if (head.label_format == PINS_VARIABLE_WIDTH) {
 			if (label_bytes) memcpy(o + off_labels, pins_binary.data(), label_bytes);
 			labels_crc = crc32c(o + off_labels, label_bytes);
@@ -2111,6 +2129,10 @@ int ckl_encoder_run(
 		check_dims(sx, sy, sz, e->dtype_bytes, 0);
 		if (markov_model_order > 15) throw Error(CKL_ERR_ARG, "crackle_amd: markov_model_order must be in [0, 15]");
 		select_device(e->device);
+		if (e->host_copy_pending) {      // the previous run's codes are still on their way out of d_codes_out
+			CKL_HIP(hipStreamSynchronize(e->stream_copy));
+			e->host_copy_pending = false;
+		}
 		wait_for_default_stream(e->stream, e->ev_in);
 		wait_for_default_stream(e->stream2, e->ev_in);
 		const auto t_run0 = std::chrono::steady_clock::now();
@@ -2145,6 +2167,26 @@ int ckl_encoder_defer_codes(ckl_encoder* e, int defer) {
 	if (!e) { set_last_error("crackle_amd: null encoder"); return CKL_ERR_ARG; }
 	e->defer_codes = defer != 0;
 	return CKL_OK;
+}
+
+int ckl_encoder_async_host_copy(ckl_encoder* e, int on) {
+	if (!e) { set_last_error("crackle_amd: null encoder"); return CKL_ERR_ARG; }
+	e->async_host_copy = on != 0;
+	return CKL_OK;
+}
+
+int ckl_encoder_host_wait(ckl_encoder* e) {
+	try {
+		if (!e) throw Error(CKL_ERR_ARG, "crackle_amd: null encoder");
+		if (e->host_copy_pending) {
+			select_device(e->device);
+			CKL_HIP(hipStreamSynchronize(e->stream_copy));
+			e->host_copy_pending = false;
+		}
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
 }
 
 int ckl_encoder_keep_device_stream(ckl_encoder* e, int keep) {

@@ -424,6 +424,17 @@ class HipBackend:
     """Following encodes of this shape also leave their whole stream in HBM (device_stream())."""
     self._L.ckl_encoder_keep_device_stream(self._encoder(shape, itemsize), int(bool(keep)))
 
+  def async_host_copy(self, shape, itemsize: int, on: bool = True):
+    """Following encodes of this shape return when their stream is complete in HBM; the crack codes reach
+    the returned host buffer in the background (needs keep_device_stream): host_wait() before its bytes are
+    read or released."""
+    self._L.ckl_encoder_async_host_copy(self._encoder(shape, itemsize), int(bool(on)))
+
+  def host_wait(self):
+    """Blocks until the last encode's host buffer is complete (ckl_encoder_host_wait)."""
+    if self._enc and self._L.ckl_encoder_host_wait(self._enc) != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+
   def device_stream(self) -> DeviceStream:
     """The last encode's stream in HBM (valid until the session's next encode)."""
     p, n = C.c_void_p(), C.c_uint64()

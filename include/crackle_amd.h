@@ -243,6 +243,14 @@ int ckl_encoder_defer_codes(ckl_encoder* e, int defer);
  * its own bytes.  ckl_encoder_device_stream hands out pointer and length of the last run's stream; the
  * buffer is the session's and valid until its next run or its destruction. */
 int ckl_encoder_keep_device_stream(ckl_encoder* e, int keep);
+/* With on != 0 (and ckl_encoder_keep_device_stream), ckl_encoder_run returns as soon as the stream is complete
+ * in HBM: header, z-index, labels and crcs are in the returned host buffer, its crack codes (the bulk) are
+ * still crossing PCIe on a stream of their own.  ckl_encoder_host_wait blocks until they have arrived; the
+ * host bytes must not be read, and the buffer not be freed, before.  In between the caller may decode from
+ * ckl_encoder_device_stream or do anything else on the device; the encoder's next run waits by itself.
+ * (The reference returns host bytes from a synchronous call, src/crackle.hpp:220-257: that is the default.) */
+int ckl_encoder_async_host_copy(ckl_encoder* e, int on);
+int ckl_encoder_host_wait(ckl_encoder* e);
 int ckl_encoder_device_stream(const ckl_encoder* e, const uint8_t** stream_device, uint64_t* n_bytes);
 int ckl_encoder_codes_to_host(ckl_encoder* e, uint8_t* dst_host, uint64_t capacity, uint64_t* n_bytes);
 /* Page-locks / releases a host range for device transfers (e.g. a shared mapping). */

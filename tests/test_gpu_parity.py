@@ -155,6 +155,35 @@ def test_device_resident_sessions_full_size_properties():
   L.ckl_decoder_destroy(dec)
 
 
+def test_encoder_async_host_copy(checker):
+  """ckl_encoder_async_host_copy / ckl_encoder_host_wait: the call returns with the stream complete in HBM
+  (a decoder runs from it at once), the host buffer is complete after the wait, and the next run waits for
+  a copy still in flight by itself."""
+  import torch
+  from crackle_amd import distributed as ckd
+  dev = torch.device("cuda:0")
+  be = ckd.HipBackend(0, zero_copy=True)
+  shape = (512, 384, 24)
+  vols = [synth.voronoi_labels(shape, np.uint32, seed=s, device=dev, cell=(16, 16, 4)) for s in (81, 82)]
+  want = [checker.compress(synth.as_numpy_f(v)) for v in vols]
+  be.keep_device_stream(shape, 4, True)
+  be.async_host_copy(shape, 4, True)
+  out = torch.empty_like(vols[0])
+  for it in range(3):
+    v, w = vols[it % 2], want[it % 2]
+    stream = be.encode(v, shape, False, True, 0, None)
+    s = be.open_decoder(be.device_stream(), 0, shape[2])      # before the host bytes are there
+    s.run(out)
+    s.close()
+    assert torch.equal(out, v)
+    if it != 1:      # the second round leaves the wait to the next run
+      be.host_wait()
+      assert bytes(stream) == w
+  be.host_wait()
+  be.async_host_copy(shape, 4, False)
+  assert bytes(be.encode(vols[0], shape, False, True, 0, None)) == want[0]
+
+
 def test_decoder_from_device_resident_stream(checker):
   """ckl_encoder_keep_device_stream / ckl_encoder_device_stream / ckl_decoder_create_device: the encoder's
   HBM copy of its stream is byte for byte the host stream, and a decoder session created from it (no
