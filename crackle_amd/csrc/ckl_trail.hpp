@@ -206,8 +206,11 @@ static __global__ void __launch_bounds__(kBlock) k_trail_graph(
 ) {
 	__shared__ uint32_t s_red[2 * kWaves];
 	const uint32_t zi = blockIdx.y;
-	const uint32_t tile = blockIdx.x * kGraphTiles + (threadIdx.x >> 5);
-	const uint32_t r = threadIdx.x & 31u;
+	// thread -> (tile of the workgroup, row of the tile): neighbouring lanes take the SAME row of
+	// neighbouring tiles, so that a wavefront's plane loads are 8 stretches of 32 bytes instead of
+	// 64 different lines (the tiles of a workgroup lie side by side)
+	const uint32_t tile = blockIdx.x * kGraphTiles + (threadIdx.x & (kGraphTiles - 1u));
+	const uint32_t r = threadIdx.x / kGraphTiles;
 	const uint32_t mtx = (sx + 1u + 7u) >> 3, mty = (sy + 1u + 7u) >> 3;
 	uint32_t ns = 0, nc = 0;
 	if (tile < tiles_x * tiles_y) {
@@ -263,12 +266,12 @@ static __global__ void __launch_bounds__(kBlock) k_trail_count_scan(
 }
 
 // grid = (graph_blocks, nslices), same thread -> tile row mapping as k_trail_graph:
-// nodes are numbered in (tile, row, x) order, no atomics
+// nodes are numbered in (workgroup, row, tile, x) order, no atomics
 static __global__ void __launch_bounds__(kBlock) k_trail_nodes(TrailArgs a) {
 	__shared__ uint32_t s_scan[2 * kWaves];
 	const uint32_t zi = blockIdx.y + a.z0;
-	const uint32_t tile = blockIdx.x * kGraphTiles + (threadIdx.x >> 5);
-	const uint32_t r = threadIdx.x & 31u;
+	const uint32_t tile = blockIdx.x * kGraphTiles + (threadIdx.x & (kGraphTiles - 1u));
+	const uint32_t r = threadIdx.x / kGraphTiles;
 	TileRowBits b = { 0, 0, 0, 0 };
 	uint32_t x0 = 0, y = 0;
 	if (tile < a.tiles_x * a.tiles_y) {
