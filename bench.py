@@ -363,11 +363,12 @@ def main():
   resident = not (args.pins and (world > 1 or group1))
   if resident:
     backend.keep_device_stream((sx, sy, sz), np_dtype.itemsize, True)
-  # One process, plain path: the encoder returns when the stream is complete in HBM and its crack codes
-  # (the bulk of the host copy, 16 MB at C2) cross PCIe while the decode leg runs from the resident
-  # stream (ckl_encoder_async_host_copy); the step ends only when the host bytes have arrived too
-  # (host_wait below, inside the timed region).  --sync-host-copy restores the synchronous call.
-  overlap_copy = resident and world == 1 and not group1 and not args.sync_host_copy
+  # The encoder returns when the (slab's) stream is complete in HBM and its crack codes (the bulk of the
+  # host copy, 16 MB at C2) cross PCIe — into the host buffer, or into their place in the ranks' shared
+  # buffer — while the decode leg runs from the resident stream (ckl_encoder_async_host_copy); the step
+  # ends only when the host bytes have arrived and, with several ranks, the merged stream is sealed
+  # (`pending()` below, inside the timed region).  --sync-host-copy restores the synchronous call.
+  overlap_copy = resident and not args.sync_host_copy
   if overlap_copy:
     backend.async_host_copy((sx, sy, sz), np_dtype.itemsize, True)
   copy_wait_ms = []
@@ -375,8 +376,10 @@ def main():
     timed = step >= args.warmup
     barrier()
     t0 = time.perf_counter()
-    binary = codec.compress(vol, (sx, sy, sz), markov_model_order=args.markov, allow_pins=bool(args.pins))   # merged stream on rank 0
-    if not overlap_copy:
+    if overlap_copy:
+      pending = codec.compress(vol, (sx, sy, sz), markov_model_order=args.markov, allow_pins=bool(args.pins), defer=True)
+    else:
+      binary = codec.compress(vol, (sx, sy, sz), markov_model_order=args.markov, allow_pins=bool(args.pins))   # merged stream on rank 0
       barrier()
     t1 = time.perf_counter()
     # decode leg: compressed bytes resident in HBM -> labels resident in HBM,
@@ -394,7 +397,7 @@ def main():
     session.run(out)
     if overlap_copy:
       tw = time.perf_counter()
-      backend.host_wait()
+      binary = pending()      # waits for the codes' copy; several ranks: barrier + the merged stream's crcs on rank 0
       if timed:
         copy_wait_ms.append((time.perf_counter() - tw) * 1e3)
     barrier()

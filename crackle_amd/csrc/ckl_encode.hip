@@ -1723,12 +1723,15 @@ uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int componen
 	if (ov && ov->merge_unique) {
 		// sharded encode: the keys are written against the unique labels of all slabs.  The caller
 		// exchanges the lists now, under the crack trail that is still running on the other stream.
+		HT_MARK("l:enqueue");
 		const uint32_t n_local = download(e.d_n_uniq.p, 1, s)[0];
 		std::vector<uint64_t> local = download(e.d_uniq.p, n_local, s);
+		HT_MARK("l:local");
 		const uint64_t* merged = nullptr;
 		uint64_t n_merged = 0;
 		if (ov->merge_unique(ov->merge_ctx, local.data(), n_local, &merged, &n_merged) != 0 || (!merged && n_merged))
 			throw Error(CKL_ERR_RUNTIME, "crackle_amd: the merge_unique callback failed");
+		HT_MARK("l:merge");
 		if (n_merged < n_local || n_merged > 0xFFFFFFFFull) throw Error(CKL_ERR_ARG, "crackle_amd: merge_unique returned a list that cannot contain the slab's labels");
 		e.d_uniq.ensure(n_merged + 1);
 		if (n_merged) CKL_HIP(hipMemcpyAsync(e.d_uniq.p, merged, n_merged * sizeof(uint64_t), hipMemcpyHostToDevice, s));
@@ -2210,6 +2213,13 @@ int ckl_encoder_codes_to_host(ckl_encoder* e, uint8_t* dst_host, uint64_t capaci
 		if (e->last_codes_total == 0) return CKL_OK;
 		if (!dst_host || capacity < e->last_codes_total) throw Error(CKL_ERR_ARG, "crackle_amd: code buffer too small: need " + std::to_string(e->last_codes_total) + " bytes");
 		select_device(e->device);
+		if (e->async_host_copy) {
+			// (the run that left the codes has drained e->stream: nothing to order after)
+			if (!e->stream_copy) CKL_HIP(hipStreamCreateWithFlags(&e->stream_copy, hipStreamNonBlocking));
+			CKL_HIP(hipMemcpyAsync(dst_host, e->d_codes_out.p, e->last_codes_total, hipMemcpyDeviceToHost, e->stream_copy));
+			e->host_copy_pending = true;
+			return CKL_OK;
+		}
 		CKL_HIP(hipMemcpyAsync(dst_host, e->d_codes_out.p, e->last_codes_total, hipMemcpyDeviceToHost, e->stream));
 		CKL_HIP(hipStreamSynchronize(e->stream));
 		return CKL_OK;

@@ -489,12 +489,21 @@ class ShardedCodec:
     self._shared_vol = None # node-local labels + component ids of the whole volume (pin encoding)
 
   # -- encode -------------------------------------------------------------------
-  def compress(self, vol, slab_shape, markov_model_order: int = 0, allow_pins: bool = False, fortran_order: bool = True) -> Optional[bytes]:
+  def compress(self, vol, slab_shape, markov_model_order: int = 0, allow_pins: bool = False, fortran_order: bool = True, defer: bool = False):
     """Every rank passes its own z-slab (slab_shape = (sx, sy, sz_local)).  Returns the
-    stream of the whole volume on rank 0, None elsewhere."""
+    stream of the whole volume on rank 0, None elsewhere.
+    defer=True returns a callable instead, as soon as this rank's slab stream is complete in HBM: with a
+    backend whose crack codes travel to the host in the background (HipBackend.async_host_copy) the
+    caller can decode from the resident stream meanwhile; calling it waits for the copy, joins the
+    ranks and returns what compress() returns."""
     be = self.backend
     if self.world == 1 and not self.force_sharded:
-      return be.encode(vol, slab_shape, allow_pins, fortran_order, markov_model_order, None)
+      whole = be.encode(vol, slab_shape, allow_pins, fortran_order, markov_model_order, None)
+      def _done():
+        if hasattr(be, "host_wait"):
+          be.host_wait()
+        return whole
+      return _done if defer else _done()
     import os, time
     prof = os.environ.get("CKL_PROFILE") is not None
     marks = []
@@ -553,16 +562,35 @@ class ShardedCodec:
       def _merge_unique(local: np.ndarray) -> np.ndarray:
         if _os.environ.get("CKL_TEST_MERGE_FAIL"):      # testing: exercises the fallback below
           raise RuntimeError("forced failure of the in-encode merge")
-        mine_n = torch.tensor([local.size], dtype=torch.int64, device=self.device)
-        sizes = [torch.empty_like(mine_n) for _ in range(self.world)]
-        dist.all_gather(sizes, mine_n)
-        sizes = [int(v) for v in torch.cat(sizes).cpu().tolist()]      # one transfer, not one per rank
-        pad = torch.zeros(max(max(sizes), 1), dtype=torch.int64, device=self.device)
-        pad[:local.size] = torch.from_numpy(local.view(np.int64)).to(self.device)
-        everyone = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(everyone, pad)
-        m = torch.unique(torch.cat([everyone[r][:sizes[r]].to(cdev0) for r in range(self.world)]))      # ascending as int64
-        m = torch.cat([m[m >= 0], m[m < 0]])                                                            # ascending as uint64
+        # two collectives (sizes, then the padded lists), each into ONE tensor, and one sort: this runs on
+        # the label stream's host thread under the crack trail and should stay shorter than the trail
+        # (1.0 ms as a group of one over RCCL at C2: a dozen small torch operations; putting them on a
+        # high-priority stream changed nothing)
+        dev_c = self.device
+        flat_gather = dist.get_backend() == "nccl"       # gloo has no all_gather_into_tensor
+        mine_n = torch.tensor([local.size], dtype=torch.int64, device=dev_c)
+        if flat_gather:
+          sizes_t = torch.empty(self.world, dtype=torch.int64, device=dev_c)
+          dist.all_gather_into_tensor(sizes_t, mine_n)
+        else:
+          parts = [torch.empty_like(mine_n) for _ in range(self.world)]
+          dist.all_gather(parts, mine_n)
+          sizes_t = torch.cat(parts)
+        sizes_h = sizes_t.cpu()                          # one transfer, not one per rank
+        maxn = max(int(sizes_h.max()), 1)
+        pad = torch.zeros(maxn, dtype=torch.int64, device=dev_c)
+        pad[:local.size] = torch.from_numpy(local.view(np.int64)).to(dev_c)
+        if flat_gather:
+          allv = torch.empty(self.world * maxn, dtype=torch.int64, device=dev_c)
+          dist.all_gather_into_tensor(allv, pad)
+        else:
+          parts = [torch.empty_like(pad) for _ in range(self.world)]
+          dist.all_gather(parts, pad)
+          allv = torch.cat(parts)
+        allv = allv.view(self.world, maxn).to(cdev0)
+        keep = torch.arange(maxn, device=cdev0)[None, :] < sizes_h.to(cdev0)[:, None]
+        sign = -(1 << 63)                                # flipping the sign bit maps the unsigned order onto the signed one
+        m = torch.unique(allv[keep] ^ sign) ^ sign
         return m.cpu().numpy().view(np.uint64)
       overrides["merge_unique"] = _merge_unique
     direct = hasattr(be, "codes_to_host")      # the crack codes go from HBM straight to their place in the shared buffer
@@ -762,9 +790,17 @@ class ShardedCodec:
       head[28] = _crc8(bytes(head[5:28]))
       out[0:29] = np.frombuffer(bytes(head), dtype=np.uint8)
     mark("place")
-    dist.barrier()
-    if self.rank != 0:
-      return None
+    def _finish():
+      if direct and hasattr(be, "host_wait"):
+        be.host_wait()                      # the crack codes are in their place in the shared buffer
+      dist.barrier()
+      if self.rank != 0:
+        return None
+      return self._seal(out, base, L, o_zidx, sz_tot, use_pins, o_labels, label_bytes, o_part, o_comp, o_tail, total, mark, marks, prof)
+    return _finish if defer else _finish()
+
+  def _seal(self, out, base, L, o_zidx, sz_tot, use_pins, o_labels, label_bytes, o_part, o_comp, o_tail, total, mark, marks, prof):
+    """Rank 0, after the barrier: z-index crc and the label section's crc32c from the ranks' parts."""
     out[o_zidx + 4 * sz_tot: o_zidx + 4 * sz_tot + 4] = np.frombuffer(int(L.ckl_crc32c(base + o_zidx, 4 * sz_tot)).to_bytes(4, "little"), dtype=np.uint8)
     if use_pins:
       labels_crc = int(L.ckl_crc32c(base + o_labels, label_bytes))

@@ -248,6 +248,7 @@ int ckl_encoder_keep_device_stream(ckl_encoder* e, int keep);
  * still crossing PCIe on a stream of their own.  ckl_encoder_host_wait blocks until they have arrived; the
  * host bytes must not be read, and the buffer not be freed, before.  In between the caller may decode from
  * ckl_encoder_device_stream or do anything else on the device; the encoder's next run waits by itself.
+ * With ckl_encoder_defer_codes the same holds for ckl_encoder_codes_to_host: it starts the copy and returns.
  * (The reference returns host bytes from a synchronous call, src/crackle.hpp:220-257: that is the default.) */
 int ckl_encoder_async_host_copy(ckl_encoder* e, int on);
 int ckl_encoder_host_wait(ckl_encoder* e);
