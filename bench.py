@@ -87,9 +87,32 @@ def spawn_ranks(args):
     e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
     out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e, stdout=out))
-  line0, _ = procs[0].communicate()
+  # rank 0's stdout is drained by a thread; the ranks are polled, and when one of them fails the others
+  # (which would wait for it in the rendezvous or a collective for ever) are ended: exactly the
+  # processes started above
+  import threading
+  chunks = []
+  reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+  reader.start()
+  failed = False
+  while any(p.poll() is None for p in procs):
+    if any(p.poll() not in (None, 0) for p in procs):
+      failed = True
+      break
+    time.sleep(0.05)
+  if failed:
+    time.sleep(1.0)      # let the others fail by themselves first (their own messages are the better diagnosis)
+    for p in procs:
+      if p.poll() is None:
+        p.terminate()
+    for p in procs:
+      try:
+        p.wait(timeout=10)
+      except subprocess.TimeoutExpired:
+        p.kill()
   rcs = [p.wait() for p in procs]
-  text = (line0 or b"").decode("utf-8", "replace")
+  reader.join(timeout=10)
+  text = (chunks[0] if chunks and chunks[0] else b"").decode("utf-8", "replace")
   if any(rcs):
     sys.stderr.write(text)
     print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
@@ -112,6 +135,8 @@ def spawn_ranks(args):
 def dry_run(args, world, rank):
   """CKL_BENCH_REHEARSAL=dry: rendezvous, barriers and the max-over-ranks reduction of the
   real run over gloo, no compute — covers the launcher on a box without GPUs."""
+  if os.environ.get("CKL_BENCH_TEST_FAIL_RANK") == str(rank):      # testing: a rank that dies before the rendezvous
+    sys.exit(3)
   import torch
   import torch.distributed as dist
   if world > 1:

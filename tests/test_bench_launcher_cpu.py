@@ -43,3 +43,13 @@ def test_too_few_gpus_is_refused():
   # no rehearsal: the launcher counts devices (none here, or fewer than 64 anywhere) and refuses
   p = _run(["--gpus", "64"], {})
   assert p.returncode != 0 and "GPU" in p.stderr
+
+
+def test_a_failed_rank_ends_the_others():
+  """One rank dies before the rendezvous: the launcher ends the rank that would wait for it for ever and
+  reports the failure, instead of hanging on rank 0's output."""
+  import time
+  t0 = time.time()
+  p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"CKL_BENCH_REHEARSAL": "dry", "CKL_BENCH_TEST_FAIL_RANK": "1"})
+  assert p.returncode != 0 and "exit codes" in p.stderr, p.stderr
+  assert time.time() - t0 < 120
