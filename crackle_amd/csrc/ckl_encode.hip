@@ -926,7 +926,7 @@ struct ckl_encoder {
 	bool graph_permissible = false;
 	DevBuf<uint64_t> t_nbase, t_cobase, t_ibase;
 	DevBuf<uint32_t> t_ncap, t_cocap, t_icap, t_max_steps;
-	DevBuf<uint32_t> t_counters;                 // n_nodes | n_snap | n_corners | n_starts | n_items | n_events, [nslices] each
+	DevBuf<uint32_t> t_counters;                 // n_nodes | n_snap | n_corners | n_starts | n_items | n_events | seg_len_sum, [nslices] each
 	DevBuf<uint32_t> t_node_vertex, t_vert2node, t_corner_vertex;
 	DevBuf<uint8_t> t_node_adj;
 	DevBuf<uint32_t> t_dart_end, t_dart_len, t_dart_minv, t_dart_minpos, t_parent, t_start_bits, t_starts;
@@ -1222,8 +1222,8 @@ void crack_pass(
 	CKL_HIP(hipEventRecord(e.evk0, s));
 	{
 		// ---- the trail over the node graph (ckl_trail.hpp)
-		e.t_counters.ensure(6 * static_cast<size_t>(ns));
-		CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 6 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
+		e.t_counters.ensure(7 * static_cast<size_t>(ns));
+		CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 7 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
 		e.t_node_vertex.ensure(ntot); e.t_node_adj.ensure(ntot + 16); e.t_vert2node.ensure(nverts * ns);
 		e.t_corner_vertex.ensure(cotot);
 		e.t_dart_end.ensure(4 * ntot); e.t_dart_len.ensure(4 * ntot); e.t_dart_minv.ensure(4 * ntot); e.t_dart_minpos.ensure(4 * ntot);
@@ -1257,7 +1257,7 @@ void crack_pass(
 		ta.n_chains = e.d_n_chains.p; ta.n_raw = e.d_n_raw.p; ta.n_valid = e.d_n_valid.p;
 		ta.cbase = e.d_cbase.p; ta.ccap = e.d_ccap.p; ta.cp = e.d_cp.p; ta.slice_err = e.d_slice_err.p;
 
-		ta.events = e.t_events.p; ta.n_events = e.t_counters.p + 5 * ns; ta.chain_ev0 = e.t_chain_ev0.p; ta.ev_lnd = e.t_ev_lnd.p; ta.ev_item = e.t_ev_item.p;
+		ta.events = e.t_events.p; ta.n_events = e.t_counters.p + 5 * ns; ta.seg_len_sum = e.t_counters.p + 6 * ns; ta.chain_ev0 = e.t_chain_ev0.p; ta.ev_lnd = e.t_ev_lnd.p; ta.ev_item = e.t_ev_item.p;
 		ta.dbg = nullptr;
 		{ const char* env = getenv("CKL_TRAIL_WALK"); ta.walk_plain = (env && !strcmp(env, "plain")) ? 1u : 0u; }
 		{ const char* env = getenv("CKL_TRAIL_WALK_STACK"); ta.walk_stack_cap = env ? static_cast<uint32_t>(std::max(1, atoi(env))) : 0xFFFFFFFFu; }

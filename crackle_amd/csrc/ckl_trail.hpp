@@ -131,6 +131,7 @@ struct TrailArgs {
 	uint32_t* slice_err;
 	uint32_t* events;            // [at ibase] k_trail_walk -> k_trail_items
 	uint32_t* n_events;          // [nslices]
+	uint32_t* seg_len_sum;       // [nslices] sum of the darts' segment lengths (k_trail_segments): 2 x the crack edges unless some lie on node-free loops
 	uint32_t* chain_ev0;         // [at kbase] first event of the chain
 	uint32_t* ev_lnd;            // [at ibase] scratch of k_trail_items
 	uint32_t* ev_item;
@@ -413,6 +414,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 	}
 	// (LDS accesses of one wavefront are ordered: no barrier needed for its own rows)
 	const uint64_t db = nb * 4u + range_begin;
+	uint32_t len_sum = 0;
 	for (uint32_t i = lane; i < range_end - range_begin; i += kWave) {
 		const uint4 r = res[i];
 		a.dart_end[db + i] = r.x == kDartNone ? kDartNone : ((v2n[r.x >> 2] << 2) | (r.x & 3u));
@@ -433,7 +435,10 @@ static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 		}
 		a.dart_codes[db + i] = o;
 		a.dart_inline[db + i] = whole ? 1u : 0u;
+		len_sum += r.x == kDartNone ? 0u : r.y;
 	}
+	len_sum = wave_sum(len_sum);
+	if (lane == 0 && len_sum) atomicAdd(a.seg_len_sum + zi, len_sum);
 	if (err) atomicOr(a.slice_err + zi, err);
 }
 
@@ -441,6 +446,9 @@ static __global__ void __launch_bounds__(kBlock) k_trail_segments(TrailArgs a) {
 // closed loop when following the loop from it never meets a node or a smaller vertex
 static __global__ void __launch_bounds__(kBlock) k_trail_loops(TrailArgs a) {
 	const uint32_t zi = blockIdx.y + a.z0;
+	// every crack edge lies on a segment between nodes (each counted from both of its darts): the slice
+	// has no node-free loop, there is nothing to look for
+	if (a.seg_len_sum[zi] == 2u * (a.max_steps[zi] - 1u)) return;
 	const uint32_t ci = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t nc = min(a.n_corners[zi], a.cocap[zi]);
 	const uint4* adjm = a.adjm + zi * a.adjm_stride;
@@ -1032,7 +1040,6 @@ static __global__ void __launch_bounds__(kWave) k_trail_walk(TrailArgs a, uint32
 // Scratch: lnp[i] = latest event <= i that is not a plain segment, lnd[i] = latest event <= i that is
 // not dead, xi[i] = first item of event i | flags.
 constexpr uint32_t kXiRib = 1u << 31, kXiDead = 1u << 30, kXiPrevDead = 1u << 29, kXiMask = (1u << 29) - 1u;
-constexpr uint32_t kRibList = 32, kRibSerial = 32;
 
 struct TrailEvents {
 	const uint32_t* ev;
@@ -1059,8 +1066,6 @@ static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a)
 	constexpr int kNW = kItemsBlock / kWave;
 	__shared__ uint32_t s_scan[kNW];
 	__shared__ int32_t s_scan_max[kNW];
-	__shared__ uint32_t s_nrib;
-	__shared__ uint32_t s_rib[kRibList];
 	const uint32_t zi = blockIdx.x + a.z0;
 	if (a.slice_err[zi]) {
 		if (threadIdx.x == 0) a.n_items[zi] = 0;
@@ -1079,7 +1084,6 @@ static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a)
 	constexpr uint32_t kNone = 4u, kLeft = 1u, kUp = 3u;
 	constexpr uint32_t kB = kItemCtl | TCODE_UP | (TCODE_DOWN << 2), kBalt = kItemCtl | TCODE_LEFT | (TCODE_RIGHT << 2);
 	constexpr uint32_t kT = kItemCtl | TCODE_DOWN | (TCODE_UP << 2), kTalt = kItemCtl | TCODE_RIGHT | (TCODE_LEFT << 2);
-	if (threadIdx.x == 0) s_nrib = 0;
 
 	// pass 1: lnp
 	{
@@ -1210,23 +1214,12 @@ static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a)
 			uint32_t lo = 0, hi = a.n_chains[zi];
 			while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (ev0[mid] <= q) lo = mid; else hi = mid; }
 			a.chain_node[a.kbase[zi] + lo] = a.node_vertex[nb + (dend[ev[i - 1] & ~kEvMask] >> 2)];
-			const uint32_t len = i - q;
-			uint32_t slot = kRibList;
-			if (len > kRibSerial) slot = atomicAdd(&s_nrib, 1u);
-			if (slot < kRibList) s_rib[slot] = i;
-			else for (uint32_t m = q; m < i; m++) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[ev[m] & ~kEvMask];
+			// (the stretch is one segment, or two when the first one came back to the start node: a node
+			// reached for the first time either has more than one edge left, which ends the stretch, or none)
+			for (uint32_t m = q; m < i; m++) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[ev[m] & ~kEvMask];
 		}
 	}
 	__syncthreads();
-	{
-		const uint32_t nr = s_nrib < kRibList ? s_nrib : kRibList;
-		for (uint32_t r = 0; r < nr; r++) {
-			const uint32_t i = s_rib[r];
-			const uint32_t q = static_cast<uint32_t>(lnp[i - 1]);
-			const uint32_t x0 = xi[q] & kXiMask;
-			for (uint32_t m = q + threadIdx.x; m < i; m += kItemsBlock) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[ev[m] & ~kEvMask];
-		}
-	}
 	// chains
 	{
 		const uint32_t nch = a.n_chains[zi];
