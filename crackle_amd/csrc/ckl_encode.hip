@@ -1123,6 +1123,9 @@ struct CrackResult {
 	bool any_chain = false;
 };
 
+// Dynamic LDS of k_trail_walk for slices of up to `max_special` nodes (+ what k_trail_loops / _components add)
+inline size_t trail_walk_lds(uint32_t max_special) { return (static_cast<size_t>(max_special) + 256) * 16 + 1024; }
+
 // Runs graph + walk + finish.  When `hist_only` is set, stops after the markov
 // histogram (returned in hist).  `model` (symbol -> rank) is required for markov packing.
 void crack_pass(
@@ -1273,10 +1276,8 @@ void crack_pass(
 		clds = (std::min(budget, std::max<size_t>(clds, 1024)) / 16) * 16;
 		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_components), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(clds)));
 		// node tables of k_trail_walk in LDS + 16 KiB of branch stack when that fits
-		size_t lds = (static_cast<size_t>(max_special) + 256) * 16 + 16384 + 1024;      // k_trail_walk's records of 16 bytes per node + 16 KiB of branch stack
+		size_t lds = trail_walk_lds(max_special);      // k_trail_walk: 12 bytes of record + 4 of branch stack per node
 		if (const char* env = getenv("CKL_TRAIL_LDS")) lds = static_cast<size_t>(std::max(0, atoi(env)));   // testing: small values force the global tables
-		// two walks per CU when there are more slices than CUs: 80 KiB each, as long as 12 KiB of branch stack remain
-		if (lds > 81920 && (static_cast<size_t>(max_special) + 256) * 16 + 12288 <= 81920 && !getenv("CKL_TRAIL_LDS")) lds = 81920;
 		lds = std::min(budget, std::max<size_t>(lds, 4096));
 		lds = (lds / 16) * 16;
 		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_walk), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -1812,9 +1813,27 @@ void encode_typed(
 
 	// labels (labels.hpp:30-155): components + crcs start on the label stream now and are
 	// collected while the crack trail runs
-	flat_enqueue(e, sx, sy, sz);
+	// When does the label stream's component labelling run?  Beside the trail's chip-filling kernels the two
+	// take turns (graph 0.2 -> 0.65 ms at C2); the serial walk leaves the chip idle for a millisecond, and
+	// two walks per CU leave room for other workgroups when they keep to a third of the LDS each.  Then the
+	// label stream starts with the walk (it waits for the event in front of it).  Otherwise it starts now,
+	// in front of the graph kernel: slices too large for that (decided from their size, before the node
+	// counts are known), and the sharded encode, whose label stream carries the exchange of the unique
+	// labels between the ranks and has to be through before the trail is.
+	bool labels_at_walk = false;
+	const bool labels_first = (ov && ov->merge_unique) || getenv("CKL_NO_OVERLAP") || static_cast<uint64_t>(sx) * sy > (1536ull * 1536ull)
+		|| (getenv("CKL_LABELS_AT_WALK") && atoi(getenv("CKL_LABELS_AT_WALK")) == 0);
+	if (labels_first) flat_enqueue(e, sx, sy, sz);
 	graph_pass(e, sx, sy, sz, head.crack_format == PERMISSIBLE);
 	ht.mark("graph");
+	if (!labels_first) {
+		uint32_t max_special = 0;
+		for (uint32_t v : e.count_special) max_special = std::max(max_special, v);
+		int max_lds = 0;
+		CKL_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, e.device));
+		labels_at_walk = max_special < 5000 && 2 * trail_walk_lds(max_special) + 40960 <= static_cast<size_t>(max_lds);
+		if (!labels_at_walk) flat_enqueue(e, sx, sy, sz);
+	}
 
 	const bool permissible = head.crack_format == PERMISSIBLE;
 	// if no slice has a crack edge the reference resets the markov order to 0 (crackle.hpp:107-118)
@@ -1862,6 +1881,10 @@ void encode_typed(
 	const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
 	hipStream_t s2 = e.stream2;
 	auto label_side = [&]() {
+		if (labels_at_walk) {
+			CKL_HIP(hipStreamWaitEvent(s2, e.evd0, 0));      // (starting one kernel earlier, beside k_trail_components, cost 0.2 ms)
+			flat_enqueue(e, sx, sy, sz);
+		}
 		flat_collect<LABEL>(e, labels, sx, sy, sz, fr);
 		HT_MARK("flat");
 		const uint64_t N = fr.total;

@@ -741,6 +741,8 @@ struct TrailTabGlobal {
 //   kEvDead | event       dead end: back to the most recent branch node; `event` = its kEvBseg
 //   kEvEnd                dead end with an empty stack: the chain is complete
 constexpr uint32_t kEvSeg = 0u << 30, kEvBseg = 1u << 30, kEvDead = 2u << 30, kEvEnd = 3u << 30, kEvMask = 3u << 30;
+// n_events' top bit: the segment events of the slice carry 12 * node | edge instead of the dart 4 * node + edge
+constexpr uint32_t kEvFormatAddr12 = 1u << 31;
 
 // Runs in lane 0.  Branch stack: entry q in LDS slot q + 1 (slot 0 takes the stores of steps that
 // push nothing), entries beyond the LDS part in stack_node / stack_item.
@@ -823,24 +825,27 @@ __device__ __forceinline__ void trail_walk_slice(
 // ~4.5 cycles whatever its kind, pays ~22 for a taken branch, ~50 for an LDS round trip and ~25 more for
 // the hop VGPR -> SGPR (tools/micro/wave_latency.hip), and hipcc's version of trail_walk_slice spends
 // 70 instructions and 3-4 taken branches on a step (~550 cycles).  Here a step is 25-35 instructions:
-//   node records of 16 bytes at LDS address 16 * node: { remaining edges, ends 0|1, ends 2|3, - },
-//   an end = 16 * node at the far end | edge it arrives by, so that the next record's address is one
-//   AND away; the branch stack's top entry is fetched with the record; event words go out through a
-//   VGPR byte offset that doubles as the event's index on the branch stack.
-// Needs 16 * nodes < 65536 and the dynamic LDS at address 0.  Returns 0 (chain complete), 1 (events
-// full) or 2 (branch stack beyond its LDS part: the caller walks the slice again with the tables in
-// memory).  Lane 0 only.
+//   node records of 12 bytes at LDS address 12 * node: { remaining edges, ends 0|1, ends 2|3 },
+//   an end = 12 * node at the far end | edge it arrives by, so that the next record's address is one
+//   AND away; the branch stack's top entry (4 bytes: event << 16 | node address) is fetched with the
+//   record; event words go out through a VGPR byte offset that doubles as the event's index on the
+//   branch stack.  A segment event carries 12 * node | edge (kEvFormatAddr12: k_trail_items divides).
+// 16 bytes of LDS per node in all, so that two walks leave a third of a CU's LDS to the kernels of the
+// label stream, which are scheduled beside them.
+// Needs 12 * nodes < 65536, fewer than 65536 events and the dynamic LDS at address 0.  Returns 0 (chain
+// complete), 1 (events full) or 2 (branch stack beyond its LDS part: the caller walks the slice again
+// with the compiled walk).  Lane 0 only.
 __device__ __forceinline__ uint32_t trail_walk_chain_fast(
 	uint32_t j_addr, uint32_t& ev_off, uint32_t& ev_left, uint32_t stack_base, uint32_t max_depth, uint32_t* ev
 ) {
 	uint32_t status, off = ev_off, left = ev_left;
-	const uint32_t top0 = stack_base - 8u;        // "top entry" of the empty stack: never used
+	const uint32_t top0 = stack_base - 4u;        // "top entry" of the empty stack: never used
 	const uint32_t ev_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ev)));
 	const uint32_t ev_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ev) >> 32));
 	j_addr = __builtin_amdgcn_readfirstlane(j_addr);
 	max_depth = __builtin_amdgcn_readfirstlane(max_depth);
 	asm volatile(
-		"s_setprio 3\n"                             // the label stream's kernels share the CU: this wavefront issues first
+		"s_setprio 3\n"
 		"s_mov_b32 s40, %[j]\n"
 		"s_mov_b32 s41, 0\n"                        // pend
 		"s_mov_b32 s42, 0\n"                        // stack depth
@@ -852,8 +857,9 @@ __device__ __forceinline__ uint32_t trail_walk_chain_fast(
 		"v_mov_b32 v25, %[top]\n"
 		"1:\n"                                      // ---- a step
 		"v_mov_b32 v20, s40\n"
-		"ds_read_b128 v[32:35], v20\n"
-		"ds_read_b64 v[26:27], v25\n"
+		"ds_read2_b32 v[32:33], v20 offset1:1\n"    // remaining edges, ends 0|1
+		"ds_read_b32 v34, v20 offset:8\n"           // ends 2|3
+		"ds_read_b32 v26, v25\n"                    // top of the branch stack
 		"s_sub_u32 s43, s43, 1\n"
 		"s_cbranch_scc1 8f\n"                       // no room for another event
 		"s_waitcnt lgkmcnt(0)\n"
@@ -868,38 +874,37 @@ __device__ __forceinline__ uint32_t trail_walk_chain_fast(
 		"ds_write_b32 v20, v21\n"
 		"s_lshl_b32 s48, s47, 4\n"
 		"s_lshr_b64 s[44:45], s[44:45], s48\n"      // the edge's end in the low 16 bits
-		"s_lshr_b32 s49, s40, 2\n"
-		"s_or_b32 s49, s49, s47\n"                  // dart = 4 * node + edge
+		"s_or_b32 s49, s40, s47\n"                  // 12 * node | edge
 		"s_cmp_eq_u32 s46, 0\n"
 		"s_cbranch_scc1 3f\n"
 		"s_cmp_ge_u32 s42, s54\n"                   // ---- more edges left: the node goes on the branch stack
 		"s_cbranch_scc1 9f\n"
 		"s_bitset1_b32 s49, 30\n"                   // kEvBseg
-		"v_add_u32 v25, 8, v25\n"
-		"v_mov_b32 v28, s40\n"
+		"v_add_u32 v25, 4, v25\n"
+		"v_lshl_or_b32 v28, v29, 14, s40\n"         // this event's index << 16 | node address
 		"s_add_u32 s42, s42, 1\n"
-		"ds_write_b64 v25, v[28:29]\n"              // (node, this event)
+		"ds_write_b32 v25, v28\n"
 		"3:\n"
 		"v_mov_b32 v30, s49\n"
 		"global_store_dword v29, v30, s[52:53]\n"
 		"v_add_u32 v29, 4, v29\n"
 		"s_and_b32 s48, s44, 3\n"
 		"s_lshl_b32 s41, 1, s48\n"                  // the edge consumed at the far end
-		"s_and_b32 s40, s44, 0xfff0\n"
+		"s_and_b32 s40, s44, 0xfffc\n"
 		"s_branch 1b\n"
 		"4:\n"                                      // ---- dead end
 		"v_mov_b32 v21, 0\n"
 		"ds_write_b32 v20, v21\n"
 		"s_cmp_eq_u32 s42, 0\n"
 		"s_cbranch_scc1 7f\n"
-		"v_readfirstlane_b32 s40, v26\n"            // back to the most recent branch node
-		"v_readfirstlane_b32 s49, v27\n"
-		"s_lshr_b32 s49, s49, 2\n"
+		"v_readfirstlane_b32 s49, v26\n"            // back to the most recent branch node
+		"s_and_b32 s40, s49, 0xffff\n"
+		"s_lshr_b32 s49, s49, 16\n"
 		"s_bitset1_b32 s49, 31\n"                   // kEvDead | its kEvBseg
 		"v_mov_b32 v30, s49\n"
 		"global_store_dword v29, v30, s[52:53]\n"
 		"v_add_u32 v29, 4, v29\n"
-		"v_add_u32 v25, -8, v25\n"
+		"v_add_u32 v25, -4, v25\n"
 		"s_sub_u32 s42, s42, 1\n"
 		"s_mov_b32 s41, 0\n"
 		"s_branch 1b\n"
@@ -924,7 +929,7 @@ __device__ __forceinline__ uint32_t trail_walk_chain_fast(
 		: [off] "+v"(off), [left] "+v"(left), [st] "=v"(status)
 		: [j] "s"(j_addr), [top] "v"(top0), [evlo] "s"(ev_lo), [evhi] "s"(ev_hi), [maxd] "s"(max_depth)
 		: "memory", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s52", "s53", "s54",
-		  "v20", "v21", "v25", "v32", "v33", "v34", "v35", "v26", "v27", "v28", "v29", "v30");
+		  "v20", "v21", "v25", "v26", "v28", "v29", "v30", "v32", "v33", "v34");
 	ev_off = __builtin_amdgcn_readfirstlane(off);
 	ev_left = __builtin_amdgcn_readfirstlane(left);
 	return __builtin_amdgcn_readfirstlane(status);
@@ -941,8 +946,8 @@ __device__ __forceinline__ bool trail_walk_slice_fast(const TrailArgs& a, uint32
 	uint32_t* ch_ev0 = a.chain_ev0 + a.kbase[zi];
 	const uint32_t kcap = a.kcap[zi];
 	const uint32_t* vert2node = a.vert2node + static_cast<uint64_t>(zi) * a.nverts;
-	const uint32_t max_depth = min((lds_bytes - stack_base) / 8u, a.walk_stack_cap);
-	uint32_t off = 0, left = ecap, nch = 0, err = 0;
+	const uint32_t max_depth = min((lds_bytes - stack_base) / 4u, a.walk_stack_cap);
+	uint32_t off = 0, left = min(ecap, 65535u), nch = 0, err = 0;
 	const unsigned long long dbg_t0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
 	const unsigned long long dbg_r0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	for (uint32_t si = 0; si < n_starts && !err; si++) {
@@ -951,8 +956,8 @@ __device__ __forceinline__ bool trail_walk_slice_fast(const TrailArgs& a, uint32
 		if (nch < kcap) { ch_node[nch] = sv; ch_ev0[nch] = off >> 2; }
 		else err |= TRAIL_ERR_CAPACITY;
 		nch++;
-		const uint32_t st = trail_walk_chain_fast(j << 4, off, left, stack_base, max_depth, ev);
-		if (st == 2u) return false;
+		const uint32_t st = trail_walk_chain_fast(j * 12u, off, left, stack_base, max_depth, ev);
+		if (st == 2u || (st == 1u && ecap > 65535u)) return false;      // (more events than a stack entry can name: the compiled walk)
 		if (st) err |= TRAIL_ERR_CAPACITY;
 	}
 	if (kTuning && a.dbg) {
@@ -961,7 +966,7 @@ __device__ __forceinline__ bool trail_walk_slice_fast(const TrailArgs& a, uint32
 		atomicAdd(a.dbg + 10, __builtin_amdgcn_s_memrealtime() - dbg_r0);
 		atomicAdd(a.dbg + 11, 1ull);
 	}
-	a.n_events[zi] = off >> 2;
+	a.n_events[zi] = (off >> 2) | kEvFormatAddr12;
 	a.n_chains[zi] = nch < kcap ? nch : kcap;
 	if (err) atomicOr(a.slice_err + zi, err);
 	return true;
@@ -978,17 +983,19 @@ static __global__ void __launch_bounds__(kWave) k_trail_walk(TrailArgs a, uint32
 		return;
 	}
 	const unsigned long long dbg_k0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
-	// hand-scheduled walk: [node records of 16 bytes][branch stack: (node, event) pairs]
-	const uint32_t rec_bytes = nn * 16u + 16u;
-	if (!a.walk_plain && nn < 4095u && rec_bytes + 4096u <= lds_bytes && __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s_trail))) == 0u) {
+	// hand-scheduled walk: [node records of 12 bytes][branch stack: 4 bytes per entry]
+	const uint32_t rec_bytes = nn * 12u + 16u;
+	if (!a.walk_plain && nn < 5461u && rec_bytes + 2048u <= lds_bytes && __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s_trail))) == 0u) {
 		for (uint32_t j = threadIdx.x; j < nn; j += kWave) {
 			uint32_t e[4];
 #pragma unroll
 			for (uint32_t k = 0; k < 4; k++) {
 				const uint32_t d = a.dart_end[(nb + j) * 4u + k];
-				e[k] = d == kDartNone ? 0xFFFFu : (((d >> 2) << 4) | (d & 3u));
+				e[k] = d == kDartNone ? 0xFFFFu : (((d >> 2) * 12u) | (d & 3u));
 			}
-			reinterpret_cast<uint4*>(s_trail)[j] = make_uint4(a.node_adj[nb + j], e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u);
+			s_trail[j * 3u] = a.node_adj[nb + j];
+			s_trail[j * 3u + 1u] = e[0] | (e[1] << 16);
+			s_trail[j * 3u + 2u] = e[2] | (e[3] << 16);
 		}
 		__syncthreads();
 		if (kTuning && a.dbg && threadIdx.x == 0) atomicAdd(a.dbg + 6, __builtin_amdgcn_s_memtime() - dbg_k0);
@@ -1071,7 +1078,13 @@ static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a)
 		if (threadIdx.x == 0) a.n_items[zi] = 0;
 		return;
 	}
-	const uint32_t n = a.n_events[zi];
+	const uint32_t n = a.n_events[zi] & ~kEvFormatAddr12;
+	const bool addr12 = (a.n_events[zi] & kEvFormatAddr12) != 0;
+	// the dart (4 * node + edge) of a segment event
+	auto dart = [&](uint32_t e) -> uint32_t {
+		const uint32_t p = e & ~kEvMask;
+		return addr12 ? (((((p >> 2) * 0xAAABu) >> 17) << 2) | (p & 3u)) : p;      // p = 12 * node | edge
+	};
 	const uint64_t ib = a.ibase[zi], nb = a.nbase[zi];
 	const uint32_t* ev = a.events + ib;
 	int32_t* lnp = reinterpret_cast<int32_t*>(a.item_off + ib);      // free until k_trail_offsets
@@ -1171,7 +1184,7 @@ static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a)
 			const int32_t q = lnp[i - 2];
 			return (ev[q] & 3u) ^ 1u;
 		}
-		return (dend[p & ~kEvMask] & 3u) ^ 1u;
+		return (dend[dart(p)] & 3u) ^ 1u;
 	};
 	auto last_before = [&](uint32_t i) -> uint32_t {
 		if (te.first(i) || !(xi[i - 1] & kXiDead)) return last_simple(i);
@@ -1184,11 +1197,11 @@ static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a)
 	// pass 3: the items
 	for (uint32_t i = threadIdx.x; i < n; i += kItemsBlock) {
 		const uint32_t e = ev[i], k = e & kEvMask, xf = xi[i], x = xf & kXiMask;
-		if (k == kEvSeg) items[x] = kItemSeg | (e & ~kEvMask);
+		if (k == kEvSeg) items[x] = kItemSeg | dart(e);
 		else if (k == kEvBseg) {
 			const uint32_t lb = last_before(i);
 			items[x] = ((0x14u >> lb) & 1u) ? kBalt : kB;        // no code in front, or DOWN
-			items[x + 1] = kItemSeg | (e & ~kEvMask);
+			items[x + 1] = kItemSeg | dart(e);
 		}
 		else if ((xf & (kXiDead | kXiPrevDead)) == kXiDead) {
 			const uint32_t lb = last_simple(i);
@@ -1213,10 +1226,10 @@ static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a)
 			const uint32_t* ev0 = a.chain_ev0 + a.kbase[zi];
 			uint32_t lo = 0, hi = a.n_chains[zi];
 			while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (ev0[mid] <= q) lo = mid; else hi = mid; }
-			a.chain_node[a.kbase[zi] + lo] = a.node_vertex[nb + (dend[ev[i - 1] & ~kEvMask] >> 2)];
+			a.chain_node[a.kbase[zi] + lo] = a.node_vertex[nb + (dend[dart(ev[i - 1])] >> 2)];
 			// (the stretch is one segment, or two when the first one came back to the start node: a node
 			// reached for the first time either has more than one edge left, which ends the stretch, or none)
-			for (uint32_t m = q; m < i; m++) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[ev[m] & ~kEvMask];
+			for (uint32_t m = q; m < i; m++) items[x0 + 1u + (i - 1u - m)] = kItemSeg | dend[dart(ev[m])];
 		}
 	}
 	__syncthreads();

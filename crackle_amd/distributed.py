@@ -567,6 +567,10 @@ class ShardedCodec:
         # (1.0 ms as a group of one over RCCL at C2: a dozen small torch operations; putting them on a
         # high-priority stream changed nothing)
         dev_c = self.device
+        _t = [time.perf_counter()] if prof else None
+        def _m(name):
+          if prof:
+            now = time.perf_counter(); marks.append(("merge:" + name, (now - _t[0]) * 1e3)); _t[0] = now
         flat_gather = dist.get_backend() == "nccl"       # gloo has no all_gather_into_tensor
         mine_n = torch.tensor([local.size], dtype=torch.int64, device=dev_c)
         if flat_gather:
@@ -577,6 +581,7 @@ class ShardedCodec:
           dist.all_gather(parts, mine_n)
           sizes_t = torch.cat(parts)
         sizes_h = sizes_t.cpu()                          # one transfer, not one per rank
+        _m("sizes")
         maxn = max(int(sizes_h.max()), 1)
         pad = torch.zeros(maxn, dtype=torch.int64, device=dev_c)
         pad[:local.size] = torch.from_numpy(local.view(np.int64)).to(dev_c)
@@ -587,11 +592,14 @@ class ShardedCodec:
           parts = [torch.empty_like(pad) for _ in range(self.world)]
           dist.all_gather(parts, pad)
           allv = torch.cat(parts)
+        _m("lists")
         allv = allv.view(self.world, maxn).to(cdev0)
         keep = torch.arange(maxn, device=cdev0)[None, :] < sizes_h.to(cdev0)[:, None]
         sign = -(1 << 63)                                # flipping the sign bit maps the unsigned order onto the signed one
         m = torch.unique(allv[keep] ^ sign) ^ sign
-        return m.cpu().numpy().view(np.uint64)
+        out = m.cpu().numpy().view(np.uint64)
+        _m("unique")
+        return out
       overrides["merge_unique"] = _merge_unique
     direct = hasattr(be, "codes_to_host")      # the crack codes go from HBM straight to their place in the shared buffer
     if direct:
