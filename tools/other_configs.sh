@@ -7,7 +7,7 @@ run() {
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" 2>/dev/null | python -c "
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(f'$name: {d[\"value\"]/1e9:.1f} GVx/s encode {d[\"encode_ms\"]:.2f} ms decode {d[\"decode_ms\"]:.2f} ms ok={d[\"roundtrip_ok\"]} dfs={d[\"encode_dfs_kernel_ms\"]:.2f} cracks={d[\"roofline\"][\"decode_stage_ms\"][\"k_decode_cracks\"]:.2f}')" >> $out
+print(f'$name: {d[\"value\"]/1e9:.1f} GVx/s encode {d[\"encode_ms\"]:.2f} ms decode {d[\"decode_ms\"]:.2f} ms ok={d[\"roundtrip_ok\"]} walk={d[\"encode_dfs_kernel_ms\"]:.2f} stages={d[\"roofline\"][\"decode_stage_ms\"]}')" >> $out
 }
 run "C2 markov 5" --markov 5
 run "C1 512x512x128 u32" --shape 512x512x128
