@@ -633,6 +633,27 @@ __global__ void __launch_bounds__(kBlock) k_bitonic_step(uint64_t* __restrict__ 
 	}
 }
 // all steps with j < 2048 of one k-stage inside LDS (2048 elements per workgroup)
+// every stage k = 2 .. 2048 of the network inside blocks of 2048 keys: one launch instead of eleven
+__global__ void __launch_bounds__(kBlock) k_bitonic_first(uint64_t* __restrict__ a, uint32_t n) {
+	__shared__ uint64_t s[2048];
+	const uint32_t base = blockIdx.x * 2048u;
+	for (uint32_t t = threadIdx.x; t < 2048u; t += kBlock) s[t] = base + t < n ? a[base + t] : ~0ull;
+	__syncthreads();
+	for (uint32_t k = 2; k <= 2048u; k <<= 1) {
+		for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+			for (uint32_t t = threadIdx.x; t < 2048u; t += kBlock) {
+				const uint32_t l = t ^ j;
+				if (l > t) {
+					const uint64_t x = s[t], y = s[l];
+					const bool up = ((base + t) & k) == 0;
+					if ((x > y) == up) { s[t] = y; s[l] = x; }
+				}
+			}
+			__syncthreads();
+		}
+	}
+	for (uint32_t t = threadIdx.x; t < 2048u; t += kBlock) if (base + t < n) a[base + t] = s[t];
+}
 __global__ void __launch_bounds__(kBlock) k_bitonic_local(uint64_t* __restrict__ a, uint32_t j_start, uint32_t k, uint32_t n) {
 	__shared__ uint64_t s[2048];
 	const uint32_t base = blockIdx.x * 2048u;
@@ -1708,7 +1729,8 @@ uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int componen
 	e.d_sorted.ensure(n_pad);
 	const uint32_t blocks = (n_pad + kBlock - 1) / kBlock;
 	hipLaunchKernelGGL(k_pad_copy_u64, dim3(blocks), dim3(kBlock), 0, s, sort_src, n_sort, e.d_sorted.p, static_cast<uint64_t>(n_pad));
-	for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+	hipLaunchKernelGGL(k_bitonic_first, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, n_pad);
+	for (uint32_t k = 4096; k <= n_pad; k <<= 1) {
 		uint32_t j = k >> 1;
 		for (; j >= 2048; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3(blocks), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 		hipLaunchKernelGGL(k_bitonic_local, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
