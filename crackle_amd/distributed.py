@@ -351,8 +351,15 @@ class HipBackend:
         state = {"merged": None, "error": None}
         def _cb(ctx, local_ptr, n_local, merged_out, n_out):
           try:
+            import time as _time
+            _t0 = _time.perf_counter()
             local = np.ctypeslib.as_array(local_ptr, shape=(int(n_local),)).copy() if n_local else np.zeros(0, np.uint64)
+            _t1 = _time.perf_counter()
             state["merged"] = np.ascontiguousarray(merge(local), dtype=np.uint64)
+            import os as _os2
+            if _os2.environ.get("CKL_PROFILE"):
+              import sys as _sys
+              print(f"[ckl merge callback ms] view+copy={(_t1 - _t0) * 1e3:.2f} merge={(_time.perf_counter() - _t1) * 1e3:.2f}", file=_sys.stderr)
             merged_out[0] = state["merged"].ctypes.data
             n_out[0] = state["merged"].size
             return 0
