@@ -1724,8 +1724,12 @@ uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int componen
 		CKL_HIP(hipMemcpyAsync(e.d_label_list.p, e.d_uniq.p, n_sort * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
 		sort_src = e.d_label_list.p;
 	}
+	// sharded encode: the ranks' lists are merged (and sorted) by the caller anyway, so the slab's distinct
+	// labels go out as the hash pass left them and the local sort is skipped
+	const bool merge_unsorted = ov && ov->merge_unique && sort_src == e.d_label_list.p;
 	uint32_t n_pad = 2048;
 	while (n_pad < n_sort) n_pad <<= 1;
+	if (!merge_unsorted) {
 	e.d_sorted.ensure(n_pad);
 	const uint32_t blocks = (n_pad + kBlock - 1) / kBlock;
 	hipLaunchKernelGGL(k_pad_copy_u64, dim3(blocks), dim3(kBlock), 0, s, sort_src, n_sort, e.d_sorted.p, static_cast<uint64_t>(n_pad));
@@ -1742,13 +1746,14 @@ uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int componen
 		hipLaunchKernelGGL(k_unique_scan, dim3(1), dim3(kBlock), 0, s, e.d_uniq_blk.p, ub, e.d_n_uniq.p);
 		hipLaunchKernelGGL(k_unique_scatter, dim3(ub), dim3(kBlock), 0, s, e.d_sorted.p, static_cast<uint32_t>(n_sort), e.d_uniq_blk.p, e.d_uniq.p);
 	}
+	}
 	uint64_t uniq_bound = N;      // entries of the unique list the section kernel may have to write
 	if (ov && ov->merge_unique) {
 		// sharded encode: the keys are written against the unique labels of all slabs.  The caller
 		// exchanges the lists now, under the crack trail that is still running on the other stream.
 		HT_MARK("l:enqueue");
-		const uint32_t n_local = download(e.d_n_uniq.p, 1, s)[0];
-		std::vector<uint64_t> local = download(e.d_uniq.p, n_local, s);
+		const uint32_t n_local = merge_unsorted ? static_cast<uint32_t>(n_sort) : download(e.d_n_uniq.p, 1, s)[0];
+		std::vector<uint64_t> local = download(merge_unsorted ? e.d_label_list.p : e.d_uniq.p, n_local, s);      // distinct; sorted unless merge_unsorted
 		HT_MARK("l:local");
 		const uint64_t* merged = nullptr;
 		uint64_t n_merged = 0;
@@ -1840,10 +1845,10 @@ void encode_typed(
 	// two walks per CU leave room for other workgroups when they keep to a third of the LDS each.  Then the
 	// label stream starts with the walk (it waits for the event in front of it).  Otherwise it starts now,
 	// in front of the graph kernel: slices too large for that (decided from their size, before the node
-	// counts are known), and the sharded encode, whose label stream carries the exchange of the unique
-	// labels between the ranks and has to be through before the trail is.
+	// counts are known).  (The sharded encode's label stream also carries the ranks' exchange of unique
+	// labels: 0.5 ms on the host.  It fits since the slab's labels are exchanged unsorted.)
 	bool labels_at_walk = false;
-	const bool labels_first = (ov && ov->merge_unique) || getenv("CKL_NO_OVERLAP") || static_cast<uint64_t>(sx) * sy > (1536ull * 1536ull)
+	const bool labels_first = getenv("CKL_NO_OVERLAP") || static_cast<uint64_t>(sx) * sy > (1536ull * 1536ull)
 		|| (getenv("CKL_LABELS_AT_WALK") && atoi(getenv("CKL_LABELS_AT_WALK")) == 0);
 	if (labels_first) flat_enqueue(e, sx, sy, sz);
 	graph_pass(e, sx, sy, sz, head.crack_format == PERMISSIBLE);

@@ -214,11 +214,12 @@ typedef struct ckl_encode_overrides {
 	int32_t has_model;               /* 1: use `model` (4^order rows x 4 symbol->rank bytes) instead of this volume's statistics */
 	const uint8_t* model;
 	/* Optional: called once per run, while the crack trail is still executing, with the slab's
-	 * sorted unique labels (host memory).  It returns the sorted unique labels of ALL slabs
+	 * distinct labels (host memory; in no particular order when they come straight from the hash
+	 * pass: the caller sorts the union anyway).  It returns the sorted unique labels of ALL slabs
 	 * (a superset; host memory that stays valid until the run returns); the flat label section
 	 * is then written against that list, so that the slabs' sections concatenate without
 	 * re-keying.  Return non-zero to abort the run.  NULL: the slab's own list is used. */
-	int (*merge_unique)(void* ctx, const uint64_t* local_sorted, uint64_t n_local,
+	int (*merge_unique)(void* ctx, const uint64_t* local_distinct, uint64_t n_local,
 	                    const uint64_t** merged_sorted, uint64_t* n_merged);
 	void* merge_ctx;
 } ckl_encode_overrides;
