@@ -319,8 +319,8 @@ static __global__ void __launch_bounds__(kBlock) k_trail_nodes(TrailArgs a) {
 // (small: the walks are latency bound, so the chip wants many wavefronts in flight).
 constexpr uint32_t kWalkChunk = 192;       // darts per wavefront (k_trail_segments)
 constexpr uint32_t kExpandChunk = 384;     // items per wavefront (k_trail_expand)
-constexpr int kWalkRefill = 16;     // idle lanes that trigger a refill (its loads cost as much as a step)
-constexpr int kWalkAhead = 3;       // steps a lane may run ahead inside its micro-tile per memory round trip
+constexpr int kWalkRefill = 8;      // idle lanes that trigger a refill (its loads cost as much as a step); round 3 with the code points kept: 8 and 2 below beat 16 and 3 (0.47 against 0.51 ms)
+constexpr int kWalkAhead = 2;       // steps a lane may run ahead inside its micro-tile per memory round trip
 constexpr uint32_t kInlineCodes = 64;      // code points of a segment that k_trail_segments keeps beside the dart (16 bytes)
 
 // Results are staged in LDS and written out once per wavefront: on this architecture loads
