@@ -75,6 +75,7 @@ struct RunArrays {
 	uint32_t* parent;          // union-find over runs (root = smallest run index)
 	uint32_t* run_start;       // first pixel of the run (slice-linear)
 	uint32_t* run_cc;          // component id of the run
+	uint32_t* comp_pix = nullptr;      // optional, [at rbase, one entry per component]: first pixel of the component (its root run's start)
 	uint32_t* nruns;           // [nslices]
 	uint32_t* ncomp;           // [nslices]
 	uint32_t* slice_err;
@@ -444,7 +445,10 @@ static __global__ void __launch_bounds__(kBlock) k_run_assign(RunArrays r, Resol
 			if (la.has_label) v = (v == la.label);
 			static_cast<OUT*>(la.run_label)[rb + i] = static_cast<OUT>(v);
 		}
-		else r.run_cc[rb + i] = cc[k];
+		else {
+			r.run_cc[rb + i] = cc[k];
+			if (r.comp_pix && root[k] == i) r.comp_pix[rb + cc[k]] = a[k];      // a component has fewer entries than the slice has runs
+		}
 		uint32_t wgt = G[n_pixels - a[k]] ^ G[n_pixels - b[k]];
 		// sum over set bits j < idbits of c:  wgt * x^(idbits-1-j)
 		for (int j = static_cast<int>(idbits) - 1; j >= 0; j--) {
