@@ -883,7 +883,6 @@ struct ckl_encoder {
 	hipStream_t stream2 = nullptr;     // labels (components, crcs, label table), concurrent with the crack trail
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr, ev_in = nullptr;
 	hipEvent_t evd0 = nullptr, evd1 = nullptr;      // around k_trail_walk (first slice group)
-	hipEvent_t ev_piece[4] = { nullptr, nullptr, nullptr, nullptr };      // pieces of the label section's copy to the host
 	float trail_ms = 0.f;
 	hipStream_t trail_stream[kTrailStreams] = {};     // slice groups of the crack trail
 	hipEvent_t ev_fork = nullptr, ev_join[kTrailStreams] = {};
@@ -965,7 +964,6 @@ struct ckl_encoder {
 		if (evk1) (void)hipEventDestroy(evk1);
 		if (evd0) (void)hipEventDestroy(evd0);
 		if (evd1) (void)hipEventDestroy(evd1);
-		for (auto& ev : ev_piece) if (ev) (void)hipEventDestroy(ev);
 		if (ev_in) (void)hipEventDestroy(ev_in);
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
 		for (auto& ev : ev_join) if (ev) (void)hipEventDestroy(ev);
@@ -1944,24 +1942,13 @@ void encode_typed(
 			// that outgrows the estimate is moved to a larger buffer at assembly.
 			early_cap = off_labels + label_bytes + model_bytes_est + est_code_bytes + 4ull * (sz + 1) + 64;
 			early.p = host_out_alloc(early_cap);
+			HT_MARK("l:buffer");
 			uint8_t* eo = static_cast<uint8_t*>(early.p);
-			// copied in four pieces, each checksummed while the next one is on the link
-			constexpr int kPieces = 4;
-			const uint64_t piece = ((label_bytes + kPieces - 1) / kPieces + 63) & ~63ull;
-			int n_pieces = 0;
-			for (uint64_t at = 0; at < label_bytes; at += piece, n_pieces++) {
-				const uint64_t len = std::min<uint64_t>(piece, label_bytes - at);
-				CKL_HIP(hipMemcpyAsync(eo + off_labels + at, e.d_labels_bin.p + at, len, hipMemcpyDeviceToHost, s2));
-				if (!e.ev_piece[n_pieces]) CKL_HIP(hipEventCreateWithFlags(&e.ev_piece[n_pieces], hipEventDisableTiming));
-				CKL_HIP(hipEventRecord(e.ev_piece[n_pieces], s2));
-			}
-			labels_crc = crc32c(eo + off_labels, 0);
-			for (int i = 0; i < n_pieces; i++) {
-				const uint64_t at = piece * i, len = std::min<uint64_t>(piece, label_bytes - at);
-				CKL_HIP(hipEventSynchronize(e.ev_piece[i]));
-				labels_crc = ckl_crc32c_combine(labels_crc, crc32c(eo + off_labels + at, len), len);
-			}
+			// (one copy: four pieces with an event each, checksummed while the next was on the link, saved 0.04 ms
+			// and now and then stalled the enqueueing thread for milliseconds)
+			if (label_bytes) CKL_HIP(hipMemcpyAsync(eo + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToHost, s2));
 			CKL_HIP(hipStreamSynchronize(s2));
+			labels_crc = crc32c(eo + off_labels, label_bytes);
 			HT_MARK("labels_d2h");
 		}
 	};
