@@ -393,7 +393,9 @@ def main():
   # buffer — while the decode leg runs from the resident stream (ckl_encoder_async_host_copy); the step
   # ends only when the host bytes have arrived and, with several ranks, the merged stream is sealed
   # (`pending()` below, inside the timed region).  --sync-host-copy restores the synchronous call.
-  overlap_copy = resident and not args.sync_host_copy
+  # (not with a markov model: the decoder's set-up then reads the model back as well, and its small round
+  # trips queue behind the codes on the link: 1.3 instead of 0.08 ms at C2)
+  overlap_copy = resident and not args.sync_host_copy and args.markov == 0
   if overlap_copy:
     backend.async_host_copy((sx, sy, sz), np_dtype.itemsize, True)
   copy_wait_ms = []
