@@ -213,6 +213,8 @@ struct RecArgs {
 	uint32_t lds_bytes;
 	WordRec* words;              // [word_base[zi] + word]
 	const uint64_t* word_base;   // [nslices]
+	uint32_t* fused_ctl;         // k_strip_fused's words (fused_ctl_words of ticket counters and timeout, arrive[fused_n], ready[fused_n]): zeroed here, or null
+	uint32_t fused_n, fused_ctl_words;
 	unsigned long long* diag;    // tuning builds: cycle stamps, summed over the slices
 };
 
@@ -614,6 +616,11 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 	if (tid == 0) {
 		a.slice_err[zi] = s_err;      // later kernels of the decode OR their bits in
 		if (a.overflow && blockIdx.x == 0 && a.zbase == 0) *a.overflow = 0u;      // the strip kernels' overflow word (this is the first kernel of the decode)
+		if (ra.fused_ctl) {      // the next launch's ticket / arrival / ready words (a kernel boundary lies between)
+			ra.fused_ctl[ra.fused_ctl_words + zi] = 0u;
+			ra.fused_ctl[ra.fused_ctl_words + ra.fused_n + zi] = 0u;
+		}
 	}
+	if (ra.fused_ctl && blockIdx.x == 0) for (uint32_t w = tid; w < ra.fused_ctl_words; w += kRecBlock) ra.fused_ctl[w] = 0u;      // ticket counters, timeout
 }
 

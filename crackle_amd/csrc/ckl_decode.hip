@@ -1628,6 +1628,43 @@ __device__ __forceinline__ void paint_tile_groups(
 //    for the prefetched words with vmcnt(0), i.e. for all of the workgroup's stores).
 // The body works in `lds` (paint_strips_words<OUT>() 32-bit words, 16-byte aligned) on strip k of slice
 // zi (k_paint_strips; a body so that the LDS is one block the caller owns).
+// `units` groups of PX pixels of a strip from its tables in LDS; each wave-store is one contiguous stretch
+// (16 bytes per lane for 4- and 8-byte labels).  SX32: rows are whole plane words (pixel p = bit p & 31 of word p >> 5).
+template <typename OUT, uint32_t PX, bool SX32, typename F>
+__device__ __forceinline__ void paint_units_from_lds(const uint32_t* s_b, const uint16_t* s_wb, F label_of, OUT* __restrict__ oz, uint32_t units, uint32_t sx, uint32_t rw) {
+	constexpr uint32_t U = 4;
+	struct alignas(PX * sizeof(OUT)) VX { OUT v[PX]; };
+	const uint32_t t = threadIdx.x;
+	const uint32_t inv_sx = SX32 ? 0u : 0xFFFFFFFFu / sx + 1u;      // p / sx = umulhi(p, inv) for p * sx < 2^32 (a strip has at most 2^15 pixels)
+	for (uint32_t g0 = 0; g0 < units; g0 += kBlock * U) {
+		VX val[U];
+		uint32_t at[U];
+#pragma unroll
+		for (uint32_t u = 0; u < U; u++) {
+			const uint32_t gi = g0 + u * kBlock + t;
+			at[u] = 0xFFFFFFFFu;
+			if (gi >= units) continue;
+			const uint32_t p = gi * PX;
+			uint32_t wl, sh;
+			if constexpr (SX32) { wl = p >> 5; sh = p & 31u; }
+			else {
+				const uint32_t row = __umulhi(p, inv_sx);
+				const uint32_t x = p - row * sx;
+				wl = row * rw + (x >> 5); sh = x & 31u;
+			}
+			const uint32_t bw = s_b[wl];
+			uint32_t run = s_wb[wl] + __popc(bw & mask_le(sh)) - 1u;
+			const uint32_t nib = (bw >> sh) >> 1;
+			at[u] = p;
+			val[u].v[0] = label_of(run);
+#pragma unroll
+			for (uint32_t q = 1; q < PX; q++) { run += (nib >> (q - 1u)) & 1u; val[u].v[q] = label_of(run); }
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < U; u++) if (at[u] != 0xFFFFFFFFu && !(exp_on(2u) && val[u].v[0] != static_cast<OUT>(0x5A))) store_stream(oz + at[u], val[u]);
+	}
+}
+
 template <typename OUT>
 constexpr uint32_t paint_strips_words() {
 	return (((kStripCap + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u + kStripWords + kStripWords / 2u + kWaves + 7u) & ~7u;
@@ -1637,7 +1674,6 @@ __device__ __forceinline__ void paint_strips_body(
 	const RunGeom& g, const StripArrays& sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag,
 	uint32_t zi, uint32_t k, uint32_t* lds
 ) {
-	typedef typename Vec4<OUT>::type V4;
 	OUT* s_lab = reinterpret_cast<OUT*>(lds);                // [kStripCap] label of every run
 	OUT* s_tab = s_lab + kStripCap;                          // [kPaintTable] labels of the strip's components (a strip with more reads them from memory)
 	uint32_t* s_b = lds + ((kStripCap + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u;
@@ -1728,45 +1764,14 @@ __device__ __forceinline__ void paint_strips_body(
 	}
 	__syncthreads();
 	stamp(1);
-	// groups of 4 pixels
-	const uint32_t ngroups = ((y1 - y0) * sx) >> 2;
+	// groups of 4 pixels (2 for 8-byte labels: 16 bytes per lane, so that every wave-store is one contiguous KiB —
+	// 32 bytes per lane left C3's paint at 2.0 TB/s); non-temporal stores: 0.39 against 0.41 ms at C2
 	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(y0) * sx;
-	// non-temporal stores: 0.39 against 0.41 ms at C2 (they lose 3 - 10 % in a kernel that only stores)
-	const bool nt = !ablated(sa, 0x800u), adjacent = ablated(sa, 0x1000u);
-	constexpr uint32_t U = 4;
-	// ceil(2^32 / sx): floor(p * inv / 2^32) = p / sx for p * sx < 2^32, and a strip has at most 2^15 pixels of at most 2^15 per row
-	const uint32_t inv_sx = 0xFFFFFFFFu / sx + 1u;
-	for (uint32_t g0 = 0; g0 < ngroups; g0 += kBlock * U) {
-		V4 val[U];
-		uint32_t at[U];
-#pragma unroll
-		for (uint32_t u = 0; u < U; u++) {
-			const uint32_t gi = adjacent ? g0 + t * U + u : g0 + u * kBlock + t;
-			at[u] = 0xFFFFFFFFu;
-			if (gi >= ngroups) continue;
-			const uint32_t p = gi << 2;
-			const uint32_t row = __umulhi(p, inv_sx);      // p / sx without the division sequence (32 of them per thread)
-			const uint32_t x = p - row * sx;
-			const uint32_t wl = row * rw + (x >> 5);
-			const uint32_t bw = s_b[wl], sh = x & 31u;
-			uint32_t run = s_wb[wl] + __popc(bw & mask_le(sh)) - 1u;
-			const uint32_t nib = ((bw >> sh) >> 1) & 7u;
-			at[u] = p;
-			if (ablated(sa, 0x400u)) { val[u].x = val[u].y = val[u].z = val[u].w = static_cast<OUT>(run); continue; }
-			val[u].x = s_lab[run];
-			run += nib & 1u;        val[u].y = s_lab[run];
-			run += (nib >> 1) & 1u; val[u].z = s_lab[run];
-			run += (nib >> 2) & 1u; val[u].w = s_lab[run];
-		}
-		if (nt) {
-#pragma unroll
-			for (uint32_t u = 0; u < U; u++) if (at[u] != 0xFFFFFFFFu) store_stream(oz + at[u], val[u]);
-		}
-		else {
-#pragma unroll
-			for (uint32_t u = 0; u < U; u++) if (at[u] != 0xFFFFFFFFu) *reinterpret_cast<V4*>(oz + at[u]) = val[u];
-		}
-	}
+	const uint32_t npix = (y1 - y0) * sx;
+	auto label_of = [&](uint32_t run) -> OUT { return s_lab[run]; };
+	constexpr uint32_t PX = sizeof(OUT) == 8 ? 2u : 4u;
+	if (sx == rw * 32u) paint_units_from_lds<OUT, PX, true>(s_b, s_wb, label_of, oz, npix / PX, sx, rw);
+	else paint_units_from_lds<OUT, PX, false>(s_b, s_wb, label_of, oz, npix / PX, sx, rw);
 	stamp(2);
 }
 
@@ -1776,6 +1781,208 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 ) {
 	__shared__ __attribute__((aligned(16))) uint32_t s_lds[paint_strips_words<OUT>()];
 	paint_strips_body<OUT, DIAG>(g, sa, out, sxy, diag, blockIdx.y + sa.zbase, blockIdx.x, s_lds);
+}
+
+// ---- k_strip_fused: strips -> labels in ONE launch ------------------------------------------------------
+// Replaces, for flat labels on the record path, the three launches k_strip_ccl / k_slice_resolve /
+// k_paint_strips (color_connectivity_graph + relabel, src/cc3d.hpp:114-254; crc32c of the component image,
+// src/crackle.hpp:599-611; decode_flat, src/labels.hpp:453-506; the paint loop, src/crackle.hpp:617-656) with
+// one launch in which the VALU-bound labelling of later slices runs beside the store-bound paint of earlier ones.
+// Every workgroup takes ONE work item from a ticket counter; the items of a counter are, in order: the strips of
+// the first `lag` slices to LABEL, then alternately one strip of slice i + lag to label and one strip of slice i
+// to PAINT, then the strips of the last `lag` slices to paint.
+//   label  strip_ccl_body<FUSED>: records -> plane pieces -> runs -> strip components, all in LDS; the strip's
+//          paint tables (break words, run prefixes, strip component of every run: one block of 11 KiB) and what
+//          the resolver reads leave with write-through stores; the workgroup counts itself in on its slice (one
+//          agent-scope atomic add), and the one whose add came last resolves the slice (slice_resolve_body: seams,
+//          ranks = the reference's ids, crc32c, the label of every strip component) and raises the slice's flag;
+//   paint  polls that flag (one lane, relaxed, s_sleep; raised long before when `lag` covers label + resolve),
+//          fetches the strip's tables and labels in ONE trip to memory (no scan, nothing derived again) and paints.
+// Forward progress: a paint item only ever waits for label items with SMALLER tickets of the same counter, which
+// running workgroups hold (tickets are taken by workgroups that already run) and which wait for nothing.  Waits are
+// bounded all the same (`timeout` -> the host falls back to the three launches).
+// Tickets come from `nheads` counters (one word serves ~90 tickets per microsecond, the launch takes 70): a
+// workgroup starts at counter blockIdx % nheads — workgroups b and b + 8 share an XCD, so a slice's strips and
+// their tables mostly stay in one L2 — and moves on to the next counter when its own is used up.
+// Hand-offs follow the write-through form (every handed-off byte stored sc1 in 4- or 16-byte pieces and drained
+// by its wave, a barrier, then one lane's agent-scope atomic; every load of those bytes sc1): no dependence on
+// dispatch order or XCD placement, no L2 write-back / invalidate while the paint's stores are in flight.
+constexpr uint32_t kFusedStateWords = kStripEdgeCap + kStripWords / 2u;      // s_mem (s_b | s_pool) and s_wb of strip_ccl_body, as they lie in LDS
+constexpr uint32_t kFusedScbaseWords = 264;                                      // nstrips + 1 <= 257
+constexpr uint32_t kFusedResolveCap = kStripCap + kFusedStateWords - kFusedScbaseWords;      // strip components of a slice the resolver's table holds
+constexpr uint32_t kFusedMaxStrips = 256;
+constexpr uint32_t kFusedMaxHeads = 8;
+constexpr uint32_t kFusedHeadStride = 64;          // words between two ticket counters: a 256-byte stretch each (one line serves ~90 atomics per microsecond whatever the word)
+constexpr uint32_t kFusedCtlWords = (kFusedMaxHeads + 1u) * kFusedHeadStride;      // heads, timeout; then arrive[nslices], ready[nslices]
+constexpr uint32_t kFusedSpinLimit = 1u << 21;
+static_assert(kFusedStateWords % 4 == 0 && kStripCap % 4 == 0 && kStripWords % 8 == 0, "16-byte pieces");
+static_assert(kFusedResolveCap <= 0xFFFFu, "index and rank share a table entry");
+
+struct FusedCtl {
+	uint32_t* heads;       // [nheads] items handed out so far (zeroed by k_crack_match, like arrive / ready / timeout)
+	uint32_t* arrive;      // [nslices] strips of the slice that are labelled
+	uint32_t* ready;       // [nslices] 0: not yet, 1: sc_label holds the labels of the slice's strip components, 2: the slice does not fit the strip tables
+	uint32_t* timeout;     // a wait gave up
+	uint32_t* state;       // [strips][kFusedStateWords] paint tables of every strip
+	uint32_t nslices, nheads, lag;      // lag: slices (of one counter) between label and paint
+};
+
+template <typename OUT>
+__global__ void __launch_bounds__(kBlock, 7) k_strip_fused(
+	RunGeom g, StripArrays sa, RecordLists rl, ResolveArgs ra, FusedCtl fc, const uint32_t* __restrict__ G, uint32_t n_pixels,
+	uint32_t* __restrict__ ncomp_out, OUT* __restrict__ out, uint32_t sxy
+) {
+	typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+	__shared__ __attribute__((aligned(16))) uint32_t s_lds[kStripCclWords];
+	__shared__ uint32_t s_ctl[6];
+	const uint32_t t = threadIdx.x;
+	const uint32_t N = sa.nstrips;
+	// ---- one work item
+	if (t == 0) {
+		uint32_t found = 0xFFFFFFFFu, head = 0;
+		for (uint32_t a = 0; a < fc.nheads; a++) {
+			const uint32_t h = (blockIdx.x + a) % fc.nheads;
+			const uint32_t n_h = h < fc.nslices ? (fc.nslices - h + fc.nheads - 1u) / fc.nheads : 0u;
+			const uint32_t items = 2u * n_h * N;
+			if (items == 0u) continue;
+			const uint32_t tk = __hip_atomic_fetch_add(fc.heads + h * kFusedHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (tk < items) { found = tk; head = h; break; }
+		}
+		s_ctl[0] = found; s_ctl[1] = head;
+	}
+	__syncthreads();
+	if (s_ctl[0] == 0xFFFFFFFFu) return;      // (the grid is exactly the items: cannot happen)
+	uint32_t zi, k;
+	bool paint;
+	{
+		const uint32_t tk = s_ctl[0], h = s_ctl[1];
+		const uint32_t n_h = (fc.nslices - h + fc.nheads - 1u) / fc.nheads;
+		const uint32_t lag = min(fc.lag, n_h);
+		const uint32_t head_items = lag * N, mixed = 2u * (n_h - lag) * N;
+		uint32_t strip;      // strip index within the counter's slices
+		if (tk < head_items) { paint = false; strip = tk; }
+		else if (tk < head_items + mixed) { const uint32_t m = tk - head_items; paint = (m & 1u) != 0u; strip = paint ? (m >> 1) : head_items + (m >> 1); }
+		else { paint = true; strip = (n_h - lag) * N + (tk - head_items - mixed); }
+		const uint32_t zl = strip / N;
+		k = strip - zl * N;
+		zi = h + zl * fc.nheads;
+	}
+	const uint32_t si = zi * N + k;
+	uint32_t* state = fc.state + static_cast<uint64_t>(si) * kFusedStateWords;
+	const __amdgpu_buffer_rsrc_t state_rsrc = __builtin_amdgcn_make_buffer_rsrc(state, 0, kFusedStateWords * 4u, 0x00020000);
+	const uint32_t y0 = k * sa.strip_rows;
+	const uint32_t y1 = min(y0 + sa.strip_rows, g.sy);
+	const uint32_t nw = (y1 - y0) * g.row_words;
+	u32x4_t* keep = reinterpret_cast<u32x4_t*>(s_lds + kStripCap);      // s_b [kStripWords] | s_pool [kStripCap / 2] | s_wb [kStripWords / 2]
+	constexpr uint32_t kPoolAt = kStripWords / 4u, kWbAt = kStripEdgeCap / 4u;      // in 16-byte pieces
+
+	if (!paint) {
+		// ================= label =================
+		uint32_t nsc = 0;
+		const uint32_t nloc = exp_on(32u) ? 1u : strip_ccl_body<false, true, true>(g, sa, rl, G, n_pixels, nullptr, zi, k, s_lds, &nsc);
+		if (nloc != kStripOverflow) {      // uniform: the strip's paint tables (write-through, 16 bytes per lane)
+			const uint32_t nb = (nw + 3u) / 4u, np = (nloc + 7u) / 8u, nwb = (nw + 7u) / 8u;
+			for (uint32_t i = t; i < kFusedStateWords / 4u; i += kBlock) {
+				const bool on = i < kPoolAt ? i < nb : (i < kWbAt ? i - kPoolAt < np : i - kWbAt < nwb);
+				if (on && !exp_on(4u)) {
+					if (exp_on(1u)) __builtin_amdgcn_raw_buffer_store_b128(keep[i], state_rsrc, i * 16u, 0, 0);
+					else __builtin_amdgcn_raw_buffer_store_b128(keep[i], state_rsrc, i * 16u, 0, 16);
+				}
+			}
+		}
+		// count in: every wave has drained its write-through stores, then one lane adds
+		if (!exp_on(8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (t == 0) s_ctl[2] = __hip_atomic_fetch_add(fc.arrive + zi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+		if (s_ctl[2] + 1u != N) return;      // uniform
+		// the slice's last strip resolves it, its LDS is free
+		ResolveArgs rb = ra;
+		rb.cap = min(ra.cap, kFusedResolveCap);
+		uint32_t* s_scan = s_lds + kStripCap + kFusedStateWords;
+		const bool ok = slice_resolve_body<OUT, true, false, kBlock, true>(g, sa, rb, ncomp_out, nullptr, zi, s_lds + kFusedScbaseWords, s_lds, s_scan, &s_ctl[3]);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its labels are out
+		__syncthreads();
+		if (t == 0) __hip_atomic_store(fc.ready + zi, ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return;
+	}
+	// ================= paint =================
+	if (t == 0) {
+		uint32_t v, spins = 0;
+		while ((v = __hip_atomic_load(fc.ready + zi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+			__builtin_amdgcn_s_sleep(16);
+			if (++spins > kFusedSpinLimit) { atomicOr(fc.timeout, 1u); v = 3u; break; }
+		}
+		s_ctl[4] = v;
+	}
+	__syncthreads();
+	if (s_ctl[4] != 1u || exp_on(16u)) return;      // uniform: the host repaints through the general pipeline
+	// one trip: counts, the strip's tables, the first labels
+	typedef typename std::conditional<sizeof(OUT) < 4, uint32_t, OUT>::type LAB;      // narrow labels travel as 32-bit words
+	const LAB* lab = static_cast<const LAB*>(sa.sc_label) + static_cast<uint64_t>(si) * sa.cap;
+	const uint32_t nloc = hand_ld<true>(sa.strip_nruns + si);
+	const uint32_t nsc = min(hand_ld<true>(sa.strip_nsc + si), sa.cap);
+	LAB first_lab = hand_ld<true>(lab + (t < sa.cap ? t : 0u));
+	{
+		const uint32_t nb = (nw + 3u) / 4u, np = (sa.cap + 7u) / 8u, nwb = (nw + 7u) / 8u;      // (the runs are not known yet: the whole pool)
+		constexpr uint32_t kPer = (kFusedStateWords / 4u + kBlock - 1u) / kBlock;
+		u32x4_t piece[kPer];
+#pragma unroll
+		for (uint32_t q = 0; q < kPer; q++) {
+			const uint32_t i = t + q * kBlock;
+			const bool on = i < kPoolAt ? i < nb : (i < kWbAt ? i - kPoolAt < np : (i < kFusedStateWords / 4u && i - kWbAt < nwb));
+			piece[q] = __builtin_amdgcn_raw_buffer_load_b128(state_rsrc, ((on && !exp_on(4u)) ? i : 0u) * 16u, 0, 16);
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < kPer; q++) { const uint32_t i = t + q * kBlock; if (i < kFusedStateWords / 4u) keep[i] = piece[q]; }
+	}
+	if (nloc > sa.cap) return;      // uniform (kStripOverflow; cannot be: the slice would not be ready)
+	const uint32_t* s_b = s_lds + kStripCap;
+	const uint16_t* s_pool = reinterpret_cast<const uint16_t*>(s_lds + kStripCap + kStripWords);
+	const uint16_t* s_wb = reinterpret_cast<const uint16_t*>(s_lds + kStripCap + kStripEdgeCap);
+	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(y0) * g.sx;
+	const uint32_t npix = (y1 - y0) * g.sx;
+	const bool sx32 = g.sx == g.row_words * 32u;
+	// the strip components' labels staged over the union-find table's place: kStripCap words
+	OUT* s_tab = reinterpret_cast<OUT*>(s_lds);
+	constexpr uint32_t kTab = kStripCap * 4u / static_cast<uint32_t>(sizeof(OUT)) >= kStripCap ? kStripCap : kStripCap * 4u / static_cast<uint32_t>(sizeof(OUT));
+	const bool staged = nsc <= kTab;      // uniform
+	if (staged) {
+		if (t < nsc) s_tab[t] = static_cast<OUT>(first_lab);
+		for (uint32_t j = t + kBlock; j < nsc; j += kBlock) s_tab[j] = static_cast<OUT>(hand_ld<true>(lab + j));      // a second trip: strips with more than 256 components
+	}
+	__syncthreads();
+	if (!staged) {      // more strip components than the table holds: every pixel looks its label up in memory
+		auto label_of = [&](uint32_t run) -> OUT { return static_cast<OUT>(hand_ld<true>(lab + s_pool[run])); };
+		if constexpr (sizeof(OUT) == 8) paint_units_from_lds<OUT, 2, false>(s_b, s_wb, label_of, oz, npix >> 1, g.sx, g.row_words);
+		else paint_units_from_lds<OUT, 4, false>(s_b, s_wb, label_of, oz, npix >> 2, g.sx, g.row_words);
+		return;
+	}
+	if constexpr (sizeof(OUT) == 8) {
+		// 8-byte labels: a pixel looks up run -> strip component -> label; a lane paints 2 pixels = 16 bytes per
+		// store, so that a wave-store is one contiguous KiB
+		auto label_of = [&](uint32_t run) -> OUT { return s_tab[s_pool[run]]; };
+		if (sx32) paint_units_from_lds<OUT, 2, true>(s_b, s_wb, label_of, oz, npix >> 1, g.sx, g.row_words);
+		else paint_units_from_lds<OUT, 2, false>(s_b, s_wb, label_of, oz, npix >> 1, g.sx, g.row_words);
+	}
+	else {
+		// the label of every run, once, in the table's place: a pixel then costs one look-up
+		OUT lv[kStripRunsPerThread];
+#pragma unroll
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
+			const uint32_t j = t + i * kBlock;
+			const uint32_t lid = s_pool[j < nloc ? j : 0u];
+			lv[i] = s_tab[lid < nsc ? lid : 0u];
+		}
+		__syncthreads();
+		OUT* s_lab = reinterpret_cast<OUT*>(s_lds);
+#pragma unroll
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) { const uint32_t j = t + i * kBlock; if (j < nloc) s_lab[j] = lv[i]; }
+		__syncthreads();
+		auto label_of = [&](uint32_t run) -> OUT { return s_lab[run]; };
+		if (sx32) paint_units_from_lds<OUT, 4, true>(s_b, s_wb, label_of, oz, npix >> 2, g.sx, g.row_words);
+		else paint_units_from_lds<OUT, 4, false>(s_b, s_wb, label_of, oz, npix >> 2, g.sx, g.row_words);
+	}
 }
 
 // condensed pins on the strip path (labels.hpp:600-614): one thread per (pin, slice) pair
@@ -1906,10 +2113,10 @@ __global__ void __launch_bounds__(kBlock) k_mode_pool_2x2(const LABEL* __restric
 }
 
 // the per-slice error words and the strip path's overflow word, stored straight into the host's pinned memory
-__global__ void __launch_bounds__(kBlock) k_flags_to_host(const uint32_t* __restrict__ slice_err, uint32_t n, const uint32_t* __restrict__ overflow, uint32_t* __restrict__ dst_host) {
+__global__ void __launch_bounds__(kBlock) k_flags_to_host(const uint32_t* __restrict__ slice_err, uint32_t n, const uint32_t* __restrict__ overflow, const uint32_t* __restrict__ timeout, uint32_t* __restrict__ dst_host) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i < n) dst_host[i] = slice_err[i];
-	if (i == 0) dst_host[n] = overflow ? *overflow : 0u;
+	if (i == 0) { dst_host[n] = overflow ? *overflow : 0u; dst_host[n + 1] = timeout ? *timeout : 0u; }
 }
 
 // a few KiB from HBM into the host's pinned (device-mapped) memory: what ckl_decoder_create_device reads
@@ -1994,6 +2201,11 @@ struct ckl_decoder {
 	bool strip_ok = false;              // shape / layout qualify for the strip path
 	// crack records (ckl_crack_records.hpp): the strip path's front end
 	bool use_records = false;           // k_crack_records + rasterising strip kernel instead of k_decode_cracks
+	bool ran_fused = false;             // the last run went through k_strip_fused
+	bool use_fused = false;             // k_strip_fused (flat labels on the record path): strips, resolve and paint in one launch
+	DevBuf<uint32_t> d_fused_ctl;       // heads[8], timeout, pad to kFusedCtlWords, arrive[nslices], ready[nslices]
+	DevBuf<uint32_t> d_fused_state;     // [strips][kFusedStateWords]: the paint tables of every strip
+	DevBuf<uint32_t> d_seam32;          // [2][strips][row_words]
 	DevBuf<uint4> d_rec;
 	DevBuf<uint32_t> d_rec_count;
 	DevBuf<uint4> d_words;             // WordRec per word of 16 code positions, parked between the two passes of k_crack_match
@@ -2291,6 +2503,15 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 				}
 				pack.add(d.d_word_off, word_off);
 				d.d_words.ensure(wtot);
+				// one launch for strips + resolve + paint (k_strip_fused): flat labels, a slice's strips resident together
+				// (opt-in: measured slower than the three launches at C2)
+				d.use_fused = h.label_format == FLAT && d.nstrips <= kFusedMaxStrips && getenv("CKL_DECODE_FUSED") != nullptr;
+				if (d.use_fused) {
+					d.d_fused_ctl.ensure(kFusedCtlWords + 2 * static_cast<size_t>(d.nslices));
+					d.d_fused_state.ensure(nst * kFusedStateWords);
+					d.d_seam32.ensure(2 * nst * d.row_words);
+					d.d_sc_cc.ensure(nst * d.strip_cap);      // lid32 (the pins' table is free on the flat path)
+				}
 			}
 		}
 	}
@@ -2539,6 +2760,8 @@ StripPlan strip_plan(ckl_decoder& d, int has_label, uint64_t label) {
 	sa.run_lid = d.d_run_lid.p; sa.sc_w = d.d_sc_w.p; sa.sc_cc = d.d_sc_cc.p; sa.sc_label = d.d_sc_label.p;
 	sa.strip_nruns = d.d_strip_nruns.p; sa.strip_nsc = d.d_strip_nsc.p; sa.row_run = d.d_row_run.p;
 	sa.seam_first = d.d_seam_first.p; sa.seam_last = d.d_seam_last.p;
+	sa.seam32_first = d.d_seam32.p; sa.seam32_last = d.d_seam32.p ? d.d_seam32.p + static_cast<size_t>(d.nstrips) * d.nslices * d.row_words : nullptr;
+	sa.lid32 = d.d_sc_cc.p;
 	sa.slice_err = d.d_slice_err.p; sa.overflow = d.d_overflow.p;
 	sa.nstrips = d.nstrips; sa.strip_rows = d.strip_rows; sa.cap = d.strip_cap; sa.zbase = 0;
 	sa.ablate = 0;
@@ -2593,6 +2816,9 @@ void launch_crack_records(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t 
 	ra.lds_bytes = static_cast<uint32_t>(d.rec_lds);
 	ra.words = reinterpret_cast<WordRec*>(d.d_words.p);
 	ra.word_base = d.d_word_off.p;
+	ra.fused_ctl = (d.use_fused && z0 == 0 && n == d.nslices) ? d.d_fused_ctl.p : nullptr;      // k_strip_fused's counters start from zero
+	ra.fused_n = d.nslices;
+	ra.fused_ctl_words = kFusedCtlWords;
 	ra.diag = nullptr;
 	if (kTuning && getenv("CKL_CRACK_DIAG")) {
 		d.d_diag.ensure(64);
@@ -2675,7 +2901,29 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 		if (chunks <= 1) ca1.overflow = d.d_overflow.p;
 		if (records) launch_crack_records(d, s, ca1, 0, ns, &st);
 		else { launch_cracks(d, s, ca1, 0, ns, crack_lds); st.done("k_decode_cracks"); }
-		launch_strips<OUT>(d, s, g, p, 0, ns, out_device, flat, &st, diag, records);
+		if (records && flat && d.use_fused && chunks <= 1 && !diag) {
+			// strips, resolve and paint in one launch (k_strip_fused); its counters were zeroed by k_crack_match
+			FusedCtl fc;
+			uint32_t* ctl = d.d_fused_ctl.p;
+			fc.heads = ctl; fc.timeout = ctl + kFusedMaxHeads * kFusedHeadStride; fc.arrive = ctl + kFusedCtlWords; fc.ready = ctl + kFusedCtlWords + ns;
+			fc.state = d.d_fused_state.p; fc.nslices = ns;
+			fc.nheads = std::min<uint32_t>(kFusedMaxHeads, ns);
+			fc.lag = 12;      // slices of one counter between a strip's labelling and its paint: covers label + resolve at C2 (tools: CKL_FUSED_LAG)
+			if (const char* env = getenv("CKL_FUSED_LAG")) fc.lag = static_cast<uint32_t>(std::max(1, atoi(env)));
+			if (const char* env = getenv("CKL_FUSED_HEADS")) fc.nheads = std::max<uint32_t>(1u, std::min<uint32_t>(fc.nheads, static_cast<uint32_t>(atoi(env))));
+			p.sa.zbase = 0;
+#ifdef CKL_TUNING
+			{
+				const uint32_t ex = getenv("CKL_EXP") ? static_cast<uint32_t>(strtoul(getenv("CKL_EXP"), nullptr, 0)) : 0u;
+				CKL_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(ckl::dev::g_exp_flags), &ex, sizeof(ex), 0, hipMemcpyHostToDevice, s));
+			}
+#endif
+			hipLaunchKernelGGL(k_strip_fused<OUT>, dim3(2u * d.nstrips * ns), dim3(kBlock), 0, s, g, p.sa, record_lists(d), p.ra, fc, d.G->p,
+				static_cast<uint32_t>(d.sxy), d.d_ncomp.p, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy));
+			st.done("k_strip_fused");
+			d.ran_fused = true;
+		}
+		else launch_strips<OUT>(d, s, g, p, 0, ns, out_device, flat, &st, diag, records);
 		if (diag) {
 			unsigned long long hd[32];
 			CKL_HIP(hipMemcpyAsync(hd, diag, sizeof(hd), hipMemcpyDeviceToHost, s));
@@ -2863,7 +3111,9 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 
 	auto h1 = std::chrono::steady_clock::now();
 	std::vector<uint32_t> errs(ns);
-	uint32_t overflow = 0;
+	uint32_t overflow = 0, timeout = 0;
+	const bool fused_ran = d.ran_fused;
+	d.ran_fused = false;
 	// the verdicts come back through the host's pinned memory (a kernel's stores: a copy-engine transfer of
 	// two KiB costs tens of microseconds before it starts)
 	if (!d.host_flags) {
@@ -2871,17 +3121,24 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		d.host_flags_pinned = host_out_is_pinned(d.host_flags);
 	}
 	if (d.host_flags_pinned) {
-		hipLaunchKernelGGL(k_flags_to_host, dim3((ns + kBlock) / kBlock), dim3(kBlock), 0, s, d.d_slice_err.p, ns, strips ? d.d_overflow.p : nullptr, d.host_flags);
+		hipLaunchKernelGGL(k_flags_to_host, dim3((ns + kBlock) / kBlock), dim3(kBlock), 0, s, d.d_slice_err.p, ns, strips ? d.d_overflow.p : nullptr, fused_ran ? d.d_fused_ctl.p + kFusedMaxHeads * kFusedHeadStride : nullptr, d.host_flags);
 		CKL_HIP(hipStreamSynchronize(s));
 		memcpy(errs.data(), d.host_flags, ns * sizeof(uint32_t));
 		overflow = d.host_flags[ns];
+		timeout = d.host_flags[ns + 1];
 	}
 	else {
 		CKL_HIP(hipMemcpyAsync(errs.data(), d.d_slice_err.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 		if (strips) CKL_HIP(hipMemcpyAsync(&overflow, d.d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		if (fused_ran) CKL_HIP(hipMemcpyAsync(&timeout, d.d_fused_ctl.p + kFusedMaxHeads * kFusedHeadStride, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 		CKL_HIP(hipStreamSynchronize(s));
 	}
 	CKL_HIP(hipGetLastError());
+	if (fused_ran && timeout) {
+		// a wait inside k_strip_fused gave up (it never should): this and all later runs of the session take the three launches
+		d.use_fused = false;
+		return decoder_run(d, out_device, out_capacity_bytes, has_label, label, stats, planes_only, errs_out);
+	}
 	if (strips && d.use_records) {
 		// a record list that did not fit (dense slices): this and all later runs of the session take the
 		// rasterising kernel; nothing of the run's output is kept

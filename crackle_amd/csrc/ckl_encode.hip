@@ -2030,7 +2030,12 @@ void encode_typed(
 		CKL_HIP(hipEventElapsedTime(&e.trail_ms, e.evk0, e.evk1));
 		CKL_HIP(hipEventElapsedTime(&e.dominant_ms, e.evd0, e.evd1));      // the encoder's longest kernel: k_trail_walk
 	}
-	catch (...) { host_out_free(o); throw; }
+	catch (...) {
+		// the codes' background copy may already be queued into `o`: it must be over before the block goes back to the cache
+		if (e.host_copy_pending) { (void)hipStreamSynchronize(e.stream_copy); e.host_copy_pending = false; }
+		host_out_free(o);
+		throw;
+	}
 	*out = o;
 	*out_len = total;
 }

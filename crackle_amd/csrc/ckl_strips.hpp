@@ -23,6 +23,7 @@
 #pragma once
 
 #include "ckl_runs.hpp"
+#include <type_traits>
 
 namespace ckl {
 namespace dev {
@@ -50,6 +51,11 @@ struct StripArrays {
 	uint16_t* row_run;         // [nslices][sy] runs of the strip before each row (pins look pixels up)
 	uint16_t* seam_first;      // [strips][row_words] runs of the strip before each word of its first row
 	uint16_t* seam_last;       // ... of its last row
+	// k_strip_fused hands these three over inside the launch, as 32-bit words (the in-launch hand-off is kept to
+	// 4-byte accesses): the seam prefixes, and the strip component of every run of a strip's first and last row
+	uint32_t* seam32_first;    // [strips][row_words]
+	uint32_t* seam32_last;
+	uint32_t* lid32;           // [strips][cap]
 	uint32_t* slice_err;
 	uint32_t* overflow;        // one word
 	uint32_t nstrips, strip_rows;
@@ -64,6 +70,34 @@ __device__ __forceinline__ bool ablated(const StripArrays& sa, uint32_t mask) { 
 // strip component of run j of a strip with nsc components: stored in one byte while nsc <= 256
 __device__ __forceinline__ uint32_t strip_lid(const uint16_t* slot_lids, uint32_t nsc, uint32_t j) {
 	return nsc <= 256u ? reinterpret_cast<const uint8_t*>(slot_lids)[j] : slot_lids[j];
+}
+
+// Loads / stores of bytes that another workgroup of the SAME launch wrote / will read (k_strip_fused): agent-scope
+// relaxed atomics = `global_load/store ... sc1` — the store writes through the XCD's L2, the load bypasses this CU's
+// L1 (MI355X: per-XCD L2s are not coherent, L1 is never refreshed by other CUs' stores).  H = false: plain accesses
+// (the data crossed a kernel boundary).
+template <bool H, typename T>
+__device__ __forceinline__ T hand_ld(const T* p) {
+	if constexpr (H) return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else return *p;
+}
+#ifdef CKL_TUNING
+__device__ uint32_t g_exp_flags;      // CKL_EXP (tuning builds): timing experiments on k_strip_fused, results may be wrong
+#endif
+__device__ __forceinline__ bool exp_on(uint32_t bit) {
+#ifdef CKL_TUNING
+	return (g_exp_flags & bit) != 0u;
+#else
+	return false;
+#endif
+}
+template <bool H, typename T>
+__device__ __forceinline__ void hand_st(T* p, T v) {
+	if constexpr (H) {
+		if (exp_on(1u)) *p = v;
+		else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	else *p = v;
 }
 
 // ---- crack records (k_crack_records, ckl_crack_records.hpp) -----------------------------------------
@@ -121,10 +155,14 @@ __device__ __forceinline__ void raster_record(
 // The body works in `lds` (kStripCclWords 32-bit words, 16-byte aligned) on strip k of slice zi, so that
 // the caller owns the block (a launch mixing stages of different slice groups was tried: DESIGN.md section 10).
 constexpr uint32_t kStripCclWords = (kStripCap + kStripEdgeCap + kStripWords / 2 + 2 * kStripBitmapWords + kWaves + 2 + 7) & ~7u;
-template <bool DIAG, bool RECORDS>
-__device__ __forceinline__ void strip_ccl_body(
+// FUSED (k_strip_fused: the same workgroup paints the strip once its slice is resolved): the break words, the run
+// prefixes and the runs' strip components stay in LDS (s_b, s_wb, s_pool) and only what the slice's resolver reads
+// leaves the workgroup, with write-through stores (hand_st): counts, weights, the seam rows of the planes and the
+// strip components of the runs of the first and the last row.  Returns the strip's runs (kStripOverflow: too many).
+template <bool DIAG, bool RECORDS, bool FUSED = false>
+__device__ __forceinline__ uint32_t strip_ccl_body(
 	const RunGeom& g, const StripArrays& sa, const RecordLists& rl, const uint32_t* __restrict__ G, uint32_t n_pixels, unsigned long long* __restrict__ diag,
-	uint32_t zi, uint32_t k, uint32_t* lds
+	uint32_t zi, uint32_t k, uint32_t* lds, uint32_t* nsc_ret = nullptr
 ) {
 	uint32_t* s_parent = lds;                         // union-find, then the crc weights per strip component (RECORDS: first the piece of plane H)
 	uint32_t* s_mem = s_parent + kStripCap;           // s_b | s_pool, and over both of them the edge list of the unions
@@ -177,8 +215,19 @@ __device__ __forceinline__ void strip_ccl_body(
 		b[0] = v4.x; b[1] = v4.y; b[2] = v4.z; b[3] = v4.w;
 		up[0] = h4.x; up[1] = h4.y; up[2] = h4.z; up[3] = h4.w;
 		upl[0] = sH[t ? t * 4u - 1u : 0u];
+		if constexpr (FUSED) {
+			// only the rows the resolver unites across: V and H of the first row, V of the last
+			uint32_t* pv = const_cast<uint32_t*>(g.planeV) + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+			uint32_t* ph = const_cast<uint32_t*>(g.planeH) + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+#pragma unroll
+			for (uint32_t j = 0; j < 4; j++) {
+				const uint32_t wl = t * 4u + j;
+				if (wl < rw) { hand_st<true>(pv + wl, b[j]); hand_st<true>(ph + wl, up[j]); }
+				else if (wl < nw && wl + rw >= nw) hand_st<true>(pv + wl, b[j]);
+			}
+		}
 		// planes to HBM: 16 bytes per thread, the strip's rows are contiguous
-		if (t * 4u < nw) {
+		else if (t * 4u < nw) {
 			uint32_t* pv = const_cast<uint32_t*>(g.planeV) + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
 			uint32_t* ph = const_cast<uint32_t*>(g.planeH) + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
 			if (t * 4u + 4u <= nw) {
@@ -225,8 +274,8 @@ __device__ __forceinline__ void strip_ccl_body(
 	block_excl_add<1>(v, tot, s_scan);
 	const uint32_t nloc = tot[0];
 	if (nloc > sa.cap) {      // uniform: the general pipeline takes over (host)
-		if (t == 0) { sa.strip_nruns[si] = kStripOverflow; sa.strip_nsc[si] = 0; atomicOr(sa.overflow, 1u); }
-		return;
+		if (t == 0) { hand_st<FUSED>(sa.strip_nruns + si, kStripOverflow); hand_st<FUSED>(sa.strip_nsc + si, 0u); atomicOr(sa.overflow, 1u); }
+		return kStripOverflow;
 	}
 	stamp(0);
 	{
@@ -266,11 +315,20 @@ __device__ __forceinline__ void strip_ccl_body(
 			if (j && w[j] == 0) yy++;
 			if (wl >= nw) break;
 			const uint16_t wbv = s_wb[wl];
-			if (w[j] == 0) sa.row_run[static_cast<uint64_t>(zi) * g.sy + y0 + yy] = wbv;
-			if (wl < rw) sa.seam_first[static_cast<uint64_t>(si) * rw + wl] = wbv;
-			if (wl + rw >= nw) sa.seam_last[static_cast<uint64_t>(si) * rw + (wl + rw - nw)] = wbv;
+			if (!FUSED && w[j] == 0) sa.row_run[static_cast<uint64_t>(zi) * g.sy + y0 + yy] = wbv;      // (pins look pixels up: never on the fused path)
+			if constexpr (FUSED) {
+				if (wl < rw) hand_st<true>(sa.seam32_first + static_cast<uint64_t>(si) * rw + wl, static_cast<uint32_t>(wbv));
+				if (wl + rw >= nw) hand_st<true>(sa.seam32_last + static_cast<uint64_t>(si) * rw + (wl + rw - nw), static_cast<uint32_t>(wbv));
+			}
+			else {
+				if (wl < rw) sa.seam_first[static_cast<uint64_t>(si) * rw + wl] = wbv;
+				if (wl + rw >= nw) sa.seam_last[static_cast<uint64_t>(si) * rw + (wl + rw - nw)] = wbv;
+			}
 		}
 	}
+	// FUSED: runs [0, n_top) are the first row's, [bot0, nloc) the last row's (read before the edge list takes the tables)
+	const uint32_t n_top = FUSED ? (nw > rw ? s_wb[rw] : nloc) : 0u;
+	const uint32_t bot0 = FUSED ? s_wb[nw - rw] : 0u;
 	// ---- unions between vertically adjacent runs of the strip (first contact of each pair).
 	// The contacts are spread unevenly over the words (0 .. 6 each): they are first written out as a
 	// list of (run, run above) pairs, over the break words and the run pool, which nobody needs any
@@ -311,6 +369,10 @@ __device__ __forceinline__ void strip_ccl_body(
 		}
 	}
 	__syncthreads();      // the pool now takes the strip components
+	if constexpr (FUSED) {      // and the break words come back for the paint
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) { const uint32_t wl = t * 4u + j; if (wl < nw) s_b[wl] = b[j]; }
+	}
 	stamp(2);
 	// ---- roots -> strip-local component ids in run order
 	uint32_t root[kStripRunsPerThread];
@@ -345,6 +407,10 @@ __device__ __forceinline__ void strip_ccl_body(
 		const uint32_t r = root[i];
 		const uint32_t lid = s_bmbase[r >> 5] + __popc(s_bm[r >> 5] & ((1u << (r & 31u)) - 1u));
 		s_pool[j] = static_cast<uint16_t>(lid);
+		if constexpr (FUSED) {      // only the seam rows' runs are looked up by the resolver
+			if (j < n_top || j >= bot0) hand_st<true>(sa.lid32 + slot + j, lid);
+			continue;
+		}
 		if (narrow) reinterpret_cast<uint8_t*>(lid_out)[j] = static_cast<uint8_t>(lid);
 		else lid_out[j] = static_cast<uint16_t>(lid);
 	}
@@ -362,9 +428,11 @@ __device__ __forceinline__ void strip_ccl_body(
 	if (t == 0 && nloc) atomicXor(s_parent + s_pool[nloc - 1], G[n_pixels - y1 * g.sx]);
 	__syncthreads();
 	uint32_t* w_out = sa.sc_w + slot;
-	for (uint32_t j = t; j < nsc; j += kBlock) w_out[j] = s_parent[j];
-	if (t == 0) { sa.strip_nruns[si] = nloc; sa.strip_nsc[si] = nsc; }
+	for (uint32_t j = t; j < nsc; j += kBlock) hand_st<FUSED>(w_out + j, s_parent[j]);
+	if (t == 0) { hand_st<FUSED>(sa.strip_nruns + si, nloc); hand_st<FUSED>(sa.strip_nsc + si, nsc); }
 	stamp(4);
+	if (nsc_ret) *nsc_ret = nsc;
+	return nloc;
 }
 
 template <bool DIAG, bool RECORDS>
@@ -396,12 +464,17 @@ struct ResolveArgs {
 // Registers: nothing per strip component survives a barrier — roots keep their index in the low 16 bits
 // of their table entry and get their rank in the high 16 (kResolveCap <= 65535) — so that two
 // workgroups of 1024 share a CU (<= 64 registers) and all slices of a 512-slice volume run at once.
-template <typename OUT, bool LABELS, bool DIAG>
-static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGeom g, StripArrays sa, ResolveArgs ra, uint32_t* __restrict__ ncomp_out, unsigned long long* __restrict__ diag) {
-	__shared__ uint32_t s_tab[kResolveCap];
-	__shared__ uint32_t s_scbase[kMaxStrips + 1];
-	__shared__ uint32_t s_scan[kResolveBlock / kWave];
-	__shared__ uint32_t s_flag;
+// The body works for a workgroup of BLOCK threads on slice zi with its tables in the caller's LDS (s_tab: ra.cap
+// entries, s_scbase: nstrips + 1, s_scan: BLOCK / 64, s_flag: 1) — k_slice_resolve (1024 threads, a launch of its
+// own) and the last strip workgroup of a slice in k_strip_fused (256 threads, HANDOFF: what the strips of the slice
+// left is read with hand_ld and the labels are written with hand_st).  Returns false when the slice does not fit.
+template <typename OUT, bool LABELS, bool DIAG, int BLOCK, bool HANDOFF>
+__device__ __forceinline__ bool slice_resolve_body(
+	const RunGeom& g, const StripArrays& sa, const ResolveArgs& ra, uint32_t* __restrict__ ncomp_out, unsigned long long* __restrict__ diag,
+	uint32_t zi, uint32_t* s_tab, uint32_t* s_scbase, uint32_t* s_scan, uint32_t* s_flag_p
+) {
+	constexpr int kResolveBlock = BLOCK;      // (shadows the launch constant: the body is written in its terms)
+	uint32_t& s_flag = *s_flag_p;
 	static_assert(kResolveCap <= 0xFFFFu, "index and rank share a table entry");
 	constexpr int NW = kResolveBlock / kWave;
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -412,7 +485,6 @@ static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGe
 			d_t = now;
 		}
 	};
-	const uint32_t zi = blockIdx.x + sa.zbase;
 	const uint32_t t = threadIdx.x;
 	const uint32_t ns = sa.nstrips;
 	const uint32_t rw = g.row_words;
@@ -430,10 +502,16 @@ static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGe
 			const uint32_t seam = it / rw, w = it - seam * rw;
 			const uint32_t k = seam + 1u, y = k * sa.strip_rows;
 			const uint64_t at = zi * g.plane_words + static_cast<uint64_t>(y) * rw + w;
-			const uint32_t h = g.planeH[at], hp = g.planeH[w ? at - 1u : at];
-			const uint32_t vh = g.planeV[at], vu = g.planeV[at - rw];
-			q_wh[u] = sa.seam_first[static_cast<uint64_t>(si0 + k) * rw + w];
-			q_wu[u] = sa.seam_last[static_cast<uint64_t>(si0 + k - 1u) * rw + w];
+			const uint32_t h = hand_ld<HANDOFF>(g.planeH + at), hp = hand_ld<HANDOFF>(g.planeH + (w ? at - 1u : at));
+			const uint32_t vh = hand_ld<HANDOFF>(g.planeV + at), vu = hand_ld<HANDOFF>(g.planeV + (at - rw));
+			if constexpr (HANDOFF) {
+				q_wh[u] = hand_ld<true>(sa.seam32_first + static_cast<uint64_t>(si0 + k) * rw + w);
+				q_wu[u] = hand_ld<true>(sa.seam32_last + static_cast<uint64_t>(si0 + k - 1u) * rw + w);
+			}
+			else {
+				q_wh[u] = sa.seam_first[static_cast<uint64_t>(si0 + k) * rw + w];
+				q_wu[u] = sa.seam_last[static_cast<uint64_t>(si0 + k - 1u) * rw + w];
+			}
 			q_up[u] = it_raw < items ? g.ups_of(h, w) : 0u;
 			q_prev[u] = w ? (g.ups_of(hp, w - 1u) >> 31) : 0u;
 			q_bh[u] = g.breaks_of(vh, w); q_bu[u] = g.breaks_of(vu, w);
@@ -444,10 +522,10 @@ static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGe
 	uint32_t my_nsc = 0;
 	if (t == 0) s_flag = 0;
 	__syncthreads();
-	if (t < ns) {
-		const uint32_t nr = sa.strip_nruns[si0 + t];
+	if (t < ns) {      // ns <= BLOCK (the host checks it for either caller): a strip per thread
+		const uint32_t nr = hand_ld<HANDOFF>(sa.strip_nruns + si0 + t);
 		if (nr == kStripOverflow) s_flag = 1;
-		my_nsc = sa.strip_nsc[si0 + t];
+		my_nsc = hand_ld<HANDOFF>(sa.strip_nsc + si0 + t);
 	}
 	uint32_t v[1] = { my_nsc }, tot[1];
 	block_excl_add<1, NW>(v, tot, s_scan);
@@ -457,7 +535,7 @@ static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGe
 	__syncthreads();
 	if (s_flag || total > ra.cap) {      // uniform
 		if (t == 0) atomicOr(sa.overflow, 1u);
-		return;
+		return false;
 	}
 	for (uint32_t i = t; i < total; i += kResolveBlock) s_tab[i] = i;
 	__syncthreads();
@@ -477,7 +555,12 @@ static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGe
 				const uint32_t m = mask_le(__ffs(c) - 1u);
 				const uint32_t jh = q_wh[u] + __popc(q_bh[u] & m) - 1u, ju = q_wu[u] + __popc(q_bu[u] & m) - 1u;
 				if (jh >= sa.cap || ju >= sa.cap) continue;
-				const uint32_t lh = strip_lid(lid_h, nsc_h, jh), lu = strip_lid(lid_u, nsc_u, ju);
+				uint32_t lh, lu;
+				if constexpr (HANDOFF) {
+					lh = hand_ld<true>(sa.lid32 + static_cast<uint64_t>(si0 + k) * sa.cap + jh);
+					lu = hand_ld<true>(sa.lid32 + static_cast<uint64_t>(si0 + k - 1u) * sa.cap + ju);
+				}
+				else { lh = strip_lid(lid_h, nsc_h, jh); lu = strip_lid(lid_u, nsc_u, ju); }
 				if (lh < nsc_h && lu < nsc_u) sm_unite(s_tab, s_scbase[k] + lh, s_scbase[k - 1u] + lu);
 			}
 		}
@@ -526,7 +609,7 @@ static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGe
 			const uint32_t sq = on ? sidx : strip0;
 			gi[q] = static_cast<uint64_t>(si0 + sq) * sa.cap + (ii - s_scbase[sq]);
 			cc[q] = s_tab[s_tab[ii] & 0xFFFFu] >> 16;
-			wgt[q] = sa.sc_w[gi[q]];
+			wgt[q] = hand_ld<HANDOFF>(sa.sc_w + gi[q]);
 			key[q] = 0;
 			if (LABELS) {
 				const uint8_t* kp = ra.keys + (coff + (cc[q] < nexp ? cc[q] : 0u)) * ra.key_width;
@@ -544,7 +627,11 @@ static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGe
 					if (ra.is_signed && ra.stored_width < 8u && (val >> (8u * ra.stored_width - 1u))) val |= ~0ull << (8u * ra.stored_width);
 				}
 				if (ra.has_label) val = (val == ra.label);
-				static_cast<OUT*>(sa.sc_label)[gi[q]] = static_cast<OUT>(val);
+				if constexpr (HANDOFF) {      // (narrow labels travel as 32-bit words inside the launch)
+					typedef typename std::conditional<sizeof(OUT) < 4, uint32_t, OUT>::type LAB;
+					hand_st<true>(static_cast<LAB*>(sa.sc_label) + gi[q], static_cast<LAB>(static_cast<OUT>(val)));
+				}
+				else static_cast<OUT*>(sa.sc_label)[gi[q]] = static_cast<OUT>(val);
 			}
 			else sa.sc_cc[gi[q]] = cc[q];
 			// sum over set bits j < idbits of the id:  wgt * x^(idbits-1-j)
@@ -568,6 +655,16 @@ static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGe
 		ncomp_out[zi] = ncomp;
 	}
 	stamp(3);
+	return true;
+}
+
+template <typename OUT, bool LABELS, bool DIAG>
+static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGeom g, StripArrays sa, ResolveArgs ra, uint32_t* __restrict__ ncomp_out, unsigned long long* __restrict__ diag) {
+	__shared__ uint32_t s_tab[kResolveCap];
+	__shared__ uint32_t s_scbase[kMaxStrips + 1];
+	__shared__ uint32_t s_scan[kResolveBlock / kWave];
+	__shared__ uint32_t s_flag;
+	slice_resolve_body<OUT, LABELS, DIAG, kResolveBlock, false>(g, sa, ra, ncomp_out, diag, blockIdx.x + sa.zbase, s_tab, s_scbase, s_scan, &s_flag);
 }
 
 // pins: labels of the strip components once label_map has been filled from their component ids

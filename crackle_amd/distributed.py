@@ -234,8 +234,20 @@ class DeviceStream:
   """A .ckl stream resident in HBM: pointer and length (the encoder session's own copy of its last
   stream, ckl_encoder_device_stream, or any device buffer a caller keeps alive through `owner`)."""
 
-  def __init__(self, ptr: int, n: int, owner=None):
+  def __init__(self, ptr: int, n: int, owner=None, generation=None):
     self.ptr, self.n, self.owner = int(ptr), int(n), owner
+    # an encoder session's stream lives until that session's next encode (or its end): the backend counts
+    # its encodes and a stream of an earlier count refuses to be decoded from
+    self.generation = generation
+
+  def valid(self) -> bool:
+    if self.generation is None or self.owner is None:
+      return True
+    return getattr(self.owner, "_stream_generation", None) == self.generation
+
+  def check(self):
+    if not self.valid():
+      raise RuntimeError("crackle_amd: the device-resident stream was overwritten by a later encode of its session")
 
   def __len__(self):
     return self.n
@@ -247,6 +259,7 @@ class HipDecodeSession:
     self._h = C.c_void_p()
     self._binary = binary   # keep alive
     if isinstance(binary, DeviceStream):
+      binary.check()
       rc = self._L.ckl_decoder_create_device(binary.ptr, binary.n, z_start, z_end, device_index, C.byref(self._h))
     else:
       ptr, n = _lib.as_pointer(binary)
@@ -255,6 +268,8 @@ class HipDecodeSession:
       raise RuntimeError(_lib.last_error())
 
   def run(self, out: torch.Tensor, label: Optional[int] = None):
+    if isinstance(self._binary, DeviceStream):
+      self._binary.check()      # a session kept across an encode would read freed or rewritten bytes
     rc = self._L.ckl_decoder_run(self._h, out.data_ptr(), out.numel() * out.element_size(), int(label is not None), int(label or 0))
     if rc != _lib.CKL_OK:
       raise RuntimeError(_lib.last_error())
@@ -298,10 +313,12 @@ class HipBackend:
     self._L = _lib.lib()
     self._enc = None
     self._enc_key = None
+    self._stream_generation = 0       # DeviceStream objects of earlier encodes are dead (DeviceStream.check)
 
   def _encoder(self, shape, itemsize):
     key = (tuple(shape), itemsize)
     if self._enc_key != key:
+      self._stream_generation += 1
       if self._enc:
         self._L.ckl_encoder_destroy(self._enc)
       h = C.c_void_p()
@@ -371,6 +388,7 @@ class HipBackend:
         keep = (keep, cb, state)
       ov_ptr = C.byref(ov)
     out, n = C.c_void_p(), C.c_uint64()
+    self._stream_generation += 1      # the session's stream buffer in HBM is rewritten (and may move)
     rc = self._L.ckl_encoder_run(
       e, vol.data_ptr(), shape[0], shape[1], shape[2],
       int(bool(allow_pins)), int(fortran_order), int(markov_model_order), 0, 1, 0,
@@ -383,6 +401,9 @@ class HipBackend:
     if self.zero_copy:
       return _lib.HostStream(out.value, n.value)
     try:
+      # with async_host_copy the crack codes may still be on their way into `out`
+      # (include/crackle_amd.h: neither read nor free before ckl_encoder_host_wait)
+      self.host_wait()
       return C.string_at(out.value, n.value)
     finally:
       self._L.ckl_free(out)
@@ -448,7 +469,7 @@ class HipBackend:
     rc = self._L.ckl_encoder_device_stream(self._enc, C.byref(p), C.byref(n))
     if rc != _lib.CKL_OK:
       raise RuntimeError(_lib.last_error())
-    return DeviceStream(p.value, n.value, owner=self)
+    return DeviceStream(p.value, n.value, owner=self, generation=self._stream_generation)
 
   def defer_codes(self, shape, itemsize: int, defer: bool):
     """Following encodes of this shape leave the crack codes in HBM for codes_to_host."""
