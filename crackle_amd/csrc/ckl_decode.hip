@@ -42,6 +42,7 @@
 #include <memory>
 #include <mutex>
 #include <type_traits>
+#include <tuple>
 
 namespace ckl {
 
@@ -732,7 +733,6 @@ __device__ __forceinline__ void markov_expand_parallel(
 	if (GLOBAL) __threadfence();      // the zeroes must be in L2 before another wavefront's atomicOr lands there
 	__syncthreads();
 	auto ldw = [&](const uint32_t* p) -> uint32_t { return GLOBAL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
-	auto bit = [&](uint32_t p) -> uint32_t { return (ldw(pay + (p >> 5)) >> (p & 31u)) & 1u; };      // bits past the end read 0
 
 	// ---- 1. code boundaries
 	const uint32_t B = nbytes * 8u;
@@ -782,8 +782,23 @@ __device__ __forceinline__ void markov_expand_parallel(
 		uint32_t cur = 0;                      // index of the code in progress (valid when it started in my range)
 		bool mine = false;
 		uint32_t p = lo;
+		// One payload word per 32 bits and one rank word per 16 codes: with the tables in the global scratch (2048 x 2048
+		// slices) a load per bit and an atomic per code made this phase 1.8 ms of C4's decode.  The codes that start
+		// in my range are consecutive; only the first and the last rank word they touch can be shared with a neighbour.
+		uint32_t wcur = ldw(pay + (p >> 5));
+		uint32_t acc = 0, acc_w = 0xFFFFFFFFu;
+		bool acc_shared = true;
+		auto flush = [&](bool last) {
+			if (acc_w == 0xFFFFFFFFu) return;      // nothing assembled yet
+			if (acc) {
+				if (acc_shared || last) atomicOr(ranks + acc_w, acc);
+				else if (GLOBAL) __hip_atomic_store(ranks + acc_w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				else ranks[acc_w] = acc;
+			}
+			acc_shared = false;      // (the words after my first one are mine alone, but for the last)
+		};
 		while (p < hi || (mine && st != 0u)) {
-			const uint32_t b = bit(p);
+			const uint32_t b = (wcur >> (p & 31u)) & 1u;      // bits past the end read 0
 			if (st == 0u) {
 				if (p >= hi) break;
 				cur = k++; mine = true;
@@ -793,11 +808,16 @@ __device__ __forceinline__ void markov_expand_parallel(
 			else if (b) st++;
 			else { rank = st; st = 0u; }
 			if (rank != 4u && mine) {
-				if (cur < cap) atomicOr(ranks + (cur >> 4), rank << (2u * (cur & 15u)));
+				if (cur < cap) {
+					if ((cur >> 4) != acc_w) { flush(false); acc_w = cur >> 4; acc = 0; }
+					acc |= rank << (2u * (cur & 15u));
+				}
 				mine = false;
 			}
 			p++;
+			if ((p & 31u) == 0u) wcur = ldw(pay + (p >> 5));
 		}
+		flush(true);
 	}
 	if (GLOBAL) __threadfence();
 	__syncthreads();
@@ -2201,6 +2221,7 @@ struct ckl_decoder {
 	bool strip_ok = false;              // shape / layout qualify for the strip path
 	// crack records (ckl_crack_records.hpp): the strip path's front end
 	bool use_records = false;           // k_crack_records + rasterising strip kernel instead of k_decode_cracks
+	uint32_t resolve_cap = 12288;       // strip components of a slice k_slice_resolve's table holds (dynamic LDS)
 	bool ran_fused = false;             // the last run went through k_strip_fused
 	bool use_fused = false;             // k_strip_fused (flat labels on the record path): strips, resolve and paint in one launch
 	DevBuf<uint32_t> d_fused_ctl;       // heads[8], timeout, pad to kFusedCtlWords, arrive[nslices], ready[nslices]
@@ -2335,6 +2356,17 @@ uint64_t read_stored(const Header& h, const uint8_t* lb, uint64_t offset) {
 // buf: the stream on the host — all of it, or (stream_device given: the stream is resident in HBM already
 // and stays the caller's) an image that holds header, z-index, label section head, markov model and crc
 // tail at their offsets and nothing of the crack codes.
+// a kernel's dynamic LDS beyond the default 64 KiB has to be allowed once per device and function
+void allow_dynamic_lds(const void* fn, int device, size_t bytes) {
+	if (bytes <= 48u * 1024u) return;
+	static std::mutex mu;
+	static std::vector<std::tuple<const void*, int, size_t>>& done = *new std::vector<std::tuple<const void*, int, size_t>>();
+	std::lock_guard<std::mutex> lock(mu);
+	for (auto& e : done) if (std::get<0>(e) == fn && std::get<1>(e) == device && std::get<2>(e) >= bytes) return;
+	CKL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+	done.emplace_back(fn, device, bytes);
+}
+
 void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_start, int64_t z_end, const uint8_t* stream_device = nullptr) {
 	if (n < Header::kBytesV0) throw Error(CKL_ERR_FORMAT, "crackle: Input too small to be a valid stream. Bytes: " + std::to_string(n));
 	d.head = Header::parse(buf, n);
@@ -2471,6 +2503,20 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		d.strip_ok = h.fortran_order && (h.sx % 4 == 0) && d.row_words <= kStripWords && d.nstrips <= kMaxStrips &&
 			d.sxy < 0xFFFF0000ull && !getenv("CKL_DECODE_GENERAL");
 		if (d.strip_ok) {
+			// per-slice kernels (k_slice_resolve, k_crack_match): two workgroups share a CU's LDS while a decode has more
+			// slices than the chip has CUs; with fewer (C4: 32 slices of 2048 x 2048 per GPU) one takes nearly all of it
+			const bool few = d.nslices <= static_cast<uint32_t>(std::max(1, d.n_cus));
+			const size_t lds_share = few ? static_cast<size_t>(d.max_lds) - 8192u : static_cast<size_t>(d.max_lds) / 2u - 6144u;
+			d.resolve_cap = static_cast<uint32_t>(std::min<size_t>(kResolveCap, (lds_share - (kMaxStrips + 64u) * 4u) / 4u));
+			if (few && !getenv("CKL_LDS_CONTROLS")) {
+				uint32_t nctl = 16384;
+				while (nctl > 64 && rec_lds_bytes(nctl) > lds_share) nctl -= 64;
+				if (rec_lds_bytes(nctl) <= lds_share && nctl > d.rec_lds_controls) {
+					d.rec_lds_controls = nctl;
+					d.rec_lds = lds_share & ~static_cast<size_t>(15);
+					allow_dynamic_lds(reinterpret_cast<const void*>(&k_crack_match), d.device, d.rec_lds);
+				}
+			}
 			const size_t nst = static_cast<size_t>(d.nstrips) * d.nslices;
 			d.strip_cap = static_cast<uint32_t>(std::min<uint64_t>(kStripCap, static_cast<uint64_t>(d.strip_rows) * h.sx));
 			d.d_row_run.ensure(static_cast<size_t>(h.sy) * d.nslices);
@@ -2777,8 +2823,8 @@ StripPlan strip_plan(ckl_decoder& d, int has_label, uint64_t label) {
 		ra.key_width = static_cast<uint32_t>(d.key_width); ra.stored_width = static_cast<uint32_t>(h.stored_data_width);
 		ra.is_signed = h.is_signed ? 1u : 0u; ra.num_unique = d.num_unique;
 	}
-	ra.cap = kResolveCap;
-	if (const char* env = getenv("CKL_RESOLVE_CAP")) ra.cap = std::min<uint32_t>(kResolveCap, static_cast<uint32_t>(std::max(1, atoi(env))));   // testing: forces the overflow path
+	ra.cap = d.resolve_cap;
+	if (const char* env = getenv("CKL_RESOLVE_CAP")) ra.cap = std::min<uint32_t>(d.resolve_cap, static_cast<uint32_t>(std::max(1, atoi(env))));   // testing: forces the overflow path
 	return p;
 }
 
@@ -2854,14 +2900,24 @@ void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p,
 		else hipLaunchKernelGGL((k_strip_ccl<false, false>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, static_cast<unsigned long long*>(nullptr));
 	}
 	if (st) st->done("k_strip_ccl");
+	const size_t tab_bytes = static_cast<size_t>(p.ra.cap) * sizeof(uint32_t);      // k_slice_resolve's table
 	if (flat) {
 		bool done = false;
 		if constexpr (kTuning) {
-			if (diag) { hipLaunchKernelGGL((k_slice_resolve<OUT, true, true>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, diag + 8); done = true; }
+			if (diag) {
+				allow_dynamic_lds(reinterpret_cast<const void*>(&k_slice_resolve<OUT, true, true>), d.device, tab_bytes);
+				hipLaunchKernelGGL((k_slice_resolve<OUT, true, true>), dim3(n), dim3(kResolveBlock), tab_bytes, s, g, p.sa, p.ra, d.d_ncomp.p, diag + 8); done = true;
+			}
 		}
-		if (!done) hipLaunchKernelGGL((k_slice_resolve<OUT, true, false>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, static_cast<unsigned long long*>(nullptr));
+		if (!done) {
+			allow_dynamic_lds(reinterpret_cast<const void*>(&k_slice_resolve<OUT, true, false>), d.device, tab_bytes);
+			hipLaunchKernelGGL((k_slice_resolve<OUT, true, false>), dim3(n), dim3(kResolveBlock), tab_bytes, s, g, p.sa, p.ra, d.d_ncomp.p, static_cast<unsigned long long*>(nullptr));
+		}
 	}
-	else hipLaunchKernelGGL((k_slice_resolve<OUT, false, false>), dim3(n), dim3(kResolveBlock), 0, s, g, p.sa, p.ra, d.d_ncomp.p, static_cast<unsigned long long*>(nullptr));
+	else {
+		allow_dynamic_lds(reinterpret_cast<const void*>(&k_slice_resolve<OUT, false, false>), d.device, tab_bytes);
+		hipLaunchKernelGGL((k_slice_resolve<OUT, false, false>), dim3(n), dim3(kResolveBlock), tab_bytes, s, g, p.sa, p.ra, d.d_ncomp.p, static_cast<unsigned long long*>(nullptr));
+	}
 	if (st) st->done("k_slice_resolve");
 	if (!flat) return;
 	launch_paint_strips<OUT>(d, s, g, p, n, out_device, diag);
@@ -3134,8 +3190,9 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		CKL_HIP(hipStreamSynchronize(s));
 	}
 	CKL_HIP(hipGetLastError());
-	if (fused_ran && timeout) {
-		// a wait inside k_strip_fused gave up (it never should): this and all later runs of the session take the three launches
+	if (fused_ran && (timeout || overflow)) {
+		// a wait inside k_strip_fused gave up (it never should), or a strip / slice did not fit its tables (the fused
+		// launch leaves no planes in HBM for the general pipeline): this and all later runs of the session take the three launches
 		d.use_fused = false;
 		return decoder_run(d, out_device, out_capacity_bytes, has_label, label, stats, planes_only, errs_out);
 	}

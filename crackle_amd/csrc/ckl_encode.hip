@@ -948,6 +948,7 @@ struct ckl_encoder {
 	bool graph_permissible = false;
 	DevBuf<uint64_t> t_nbase, t_cobase, t_ibase;
 	DevBuf<uint32_t> t_ncap, t_cocap, t_icap, t_max_steps;
+	size_t last_trail_slices = 0;                // slices of the last crack pass (the layout of t_counters)
 	DevBuf<uint32_t> t_counters;                 // n_nodes | n_snap | n_corners | n_starts | n_items | n_events | seg_len_sum, [nslices] each
 	DevBuf<uint32_t> t_node_vertex, t_vert2node, t_corner_vertex;
 	DevBuf<uint8_t> t_node_adj;
@@ -1282,6 +1283,7 @@ void crack_pass(
 		ta.n_chains = e.d_n_chains.p; ta.n_raw = e.d_n_raw.p; ta.n_valid = e.d_n_valid.p;
 		ta.cbase = e.d_cbase.p; ta.ccap = e.d_ccap.p; ta.cp = e.d_cp.p; ta.slice_err = e.d_slice_err.p;
 
+		e.last_trail_slices = ns;
 		ta.events = e.t_events.p; ta.n_events = e.t_counters.p + 5 * ns; ta.seg_len_sum = e.t_counters.p + 6 * ns; ta.chain_ev0 = e.t_chain_ev0.p; ta.ev_lnd = e.t_ev_lnd.p; ta.ev_item = e.t_ev_item.p;
 		ta.dbg = nullptr;
 		{ const char* env = getenv("CKL_TRAIL_WALK"); ta.walk_plain = (env && !strcmp(env, "plain")) ? 1u : 0u; }
@@ -2478,6 +2480,25 @@ int ckl_encoder_last_timing(const ckl_encoder* e, float* pipeline_ms, float* dom
 	if (pipeline_ms) *pipeline_ms = e->pipeline_ms;
 	if (dominant_kernel_ms) *dominant_kernel_ms = e->dominant_ms;
 	return CKL_OK;
+}
+
+int ckl_encoder_walk_paths(ckl_encoder* e, uint32_t* fast_slices, uint32_t* compiled_slices) {
+	try {
+		if (!e) throw Error(CKL_ERR_ARG, "crackle_amd: null encoder");
+		uint32_t fast = 0, plain = 0;
+		const size_t ns = e->last_trail_slices;
+		if (ns && e->t_counters.p) {
+			select_device(e->device);
+			std::vector<uint32_t> nev(ns);
+			CKL_HIP(hipMemcpy(nev.data(), e->t_counters.p + 5 * ns, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));      // n_events, flagged with the event format
+			for (uint32_t v : nev) { if (v & kEvFormatAddr12) fast++; else if (v) plain++; }
+		}
+		if (fast_slices) *fast_slices = fast;
+		if (compiled_slices) *compiled_slices = plain;
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
 }
 
 void ckl_encoder_destroy(ckl_encoder* e) { delete e; }

@@ -35,8 +35,7 @@ constexpr uint32_t kStripBitmapWords = kStripCap / 32;
 constexpr uint32_t kStripEdgeCap = kStripWords + kStripCap / 2;      // 32-bit words of the break words + the 16-bit run pool
 constexpr uint32_t kStripOverflow = 0xFFFFFFFFu;
 constexpr int kResolveBlock = 1024;
-constexpr uint32_t kResolveCap = 12288;     // strip components per slice held in LDS
-constexpr uint32_t kResolvePer = kResolveCap / kResolveBlock;
+constexpr uint32_t kResolveCap = 0xFFFFu;   // strip components per slice: index and rank share a table entry; the table is dynamic LDS, sized by the host (ResolveArgs::cap)
 constexpr uint32_t kMaxStrips = 1024;
 
 struct StripArrays {
@@ -660,7 +659,7 @@ __device__ __forceinline__ bool slice_resolve_body(
 
 template <typename OUT, bool LABELS, bool DIAG>
 static __global__ void __launch_bounds__(kResolveBlock, 8) k_slice_resolve(RunGeom g, StripArrays sa, ResolveArgs ra, uint32_t* __restrict__ ncomp_out, unsigned long long* __restrict__ diag) {
-	__shared__ uint32_t s_tab[kResolveCap];
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];      // ra.cap entries
 	__shared__ uint32_t s_scbase[kMaxStrips + 1];
 	__shared__ uint32_t s_scan[kResolveBlock / kWave];
 	__shared__ uint32_t s_flag;

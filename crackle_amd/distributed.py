@@ -489,6 +489,13 @@ class HipBackend:
       self._L.ckl_encoder_last_timing(self._enc, C.byref(p), C.byref(k))
     return p.value, k.value
 
+  def walk_paths(self) -> Tuple[int, int]:
+    """(slices walked by the hand-scheduled loop, slices walked by the compiled one) of the last encode."""
+    f, c = C.c_uint32(), C.c_uint32()
+    if self._enc and self._L.ckl_encoder_walk_paths(self._enc, C.byref(f), C.byref(c)) != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+    return f.value, c.value
+
   def open_decoder(self, binary: bytes, z_start: int, z_end: int):
     return HipDecodeSession(binary, z_start, z_end, self.device_index)
 

@@ -303,6 +303,11 @@ int ckl_encoder_pin_labels(
 	uint8_t** out, uint64_t* out_len);
 
 int ckl_encoder_last_timing(const ckl_encoder* e, float* pipeline_ms, float* dominant_kernel_ms);
+/* Which walk the last run's crack trail took (create_crack_codes, src/crackcodes.hpp:374-453): slices walked by
+ * the hand-scheduled k_trail_walk loop / by the compiled one (slices with too many nodes or events for its
+ * 16-bit fields, or a branch stack beyond its LDS part).  Tests assert the path with it; no reference
+ * counterpart. */
+int ckl_encoder_walk_paths(ckl_encoder* e, uint32_t* fast_slices, uint32_t* compiled_slices);
 void ckl_encoder_destroy(ckl_encoder* e);
 
 /* ---- host-side stream surgery used by the sharded encoder ------------------ */
