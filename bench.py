@@ -47,6 +47,9 @@ def parse_args(argv=None):
   ap.add_argument("--scaling", type=str, default="weak", choices=("weak", "strong"))
   ap.add_argument("--markov", type=int, default=0)
   ap.add_argument("--pins", type=int, default=0, help="allow_pins (parity / rehearsal runs; the metric is quoted on flat labels)")
+  ap.add_argument("--data", type=str, default="voronoi", choices=("voronoi", "noise2000", "binary"),
+                  help="voronoi: the connectomics-style volume the metric is quoted on; noise2000 / binary: the reference's adversarial "
+                       "inputs (uniform-random labels in [0, 2000) / in {0, 1}: benchmarks/README.md:108-114, 193-227), reported for honesty")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--sync-host-copy", action="store_true", help="the encoder call returns only when its host bytes are complete (default at N = 1: the codes' PCIe copy overlaps the decode leg and is waited for inside the step)")
   ap.add_argument("--cpu-sample-slices", type=int, default=0, help="slices of the CPU baseline's sample (0: the whole slab)")
@@ -66,15 +69,39 @@ def _free_port():
     return s.getsockname()[1]
 
 
+def visible_gpus():
+  """GPUs this process may use, counted without touching a GPU runtime: the KFD topology nodes that have
+  SIMDs (CPU nodes have none), capped by the device lists of HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+  CUDA_VISIBLE_DEVICES.  None when the topology cannot be read (the ranks then check for themselves)."""
+  import glob
+  n = 0
+  paths = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+  if not paths:
+    return None
+  for path in paths:
+    try:
+      with open(path) as f:
+        for line in f:
+          k, _, v = line.partition(" ")
+          if k == "simd_count" and int(v.strip() or 0) > 0:
+            n += 1
+    except (OSError, ValueError):
+      return None
+  for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    v = os.environ.get(var)
+    if v is not None:
+      n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+  return n
+
+
 def spawn_ranks(args):
   """`python bench.py --gpus N` without a launcher: start N rank processes of this script
   and relay rank 0's JSON line.  Returns the exit code."""
   n = args.gpus
   rehearsal = os.environ.get("CKL_BENCH_REHEARSAL", "")
   if not rehearsal:
-    import torch   # device_count() does not initialise the GPU on this image
-    have = torch.cuda.device_count()
-    if have < n:
+    have = visible_gpus()      # from sysfs: the launcher makes no HIP / torch call at all
+    if have is not None and have < n:
       print(f"bench.py: --gpus {n} asked for but only {have} GPU(s) are visible", file=sys.stderr)
       return 2
   env = dict(os.environ)
@@ -157,7 +184,8 @@ def dry_run(args, world, rank):
 # ------------------------------------------------------------------------------------
 def metric_name(args):
   sx, sy, sz = (int(v) for v in args.shape.lower().split("x"))
-  return f"voxels/s encode+decode, {sx}x{sy}x{sz} {args.dtype}; bit-exact .ckl bytes"
+  extra = "" if args.data == "voronoi" else f" ({args.data} labels)"
+  return f"voxels/s encode+decode, {sx}x{sy}x{sz} {args.dtype}{extra}; bit-exact .ckl bytes"
 
 
 def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=5):
@@ -193,7 +221,7 @@ def pmc_traffic(kernels, workload_key):
   separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the guide prescribes for gfx950).
   None when no counters were collected for this workload, a kernel is missing from them, or the
   profile was taken from another build of the library (its recorded lib_sha16 differs)."""
-  for fn in ("r03_pmc_traffic.json",):
+  for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
     path = os.path.join(ROOT, "profiles", fn)
     try:
       with open(path) as f:
@@ -360,9 +388,13 @@ def main():
   # synthetic connectomics-style labels, generated on device;
   # rank r holds slices [r*sz, (r+1)*sz) of one global volume
   offset = (1 << 40) if np_dtype.itemsize == 8 else 0
-  vol = synth.voronoi_labels((sx, sy, sz_total), np_dtype, seed=2, device=dev, offset=offset,
-                             z_range=(rank * sz, (rank + 1) * sz)) if world > 1 else \
-        synth.voronoi_labels((sx, sy, sz), np_dtype, seed=2, device=dev, offset=offset)
+  if args.data == "voronoi":
+    vol = synth.voronoi_labels((sx, sy, sz_total), np_dtype, seed=2, device=dev, offset=offset,
+                               z_range=(rank * sz, (rank + 1) * sz)) if world > 1 else \
+          synth.voronoi_labels((sx, sy, sz), np_dtype, seed=2, device=dev, offset=offset)
+  else:
+    vol = synth.random_labels_device((sx, sy, sz_total), np_dtype, seed=2, high=2000 if args.data == "noise2000" else 2,
+                                     device=dev, z_range=(rank * sz, (rank + 1) * sz))
   torch.cuda.synchronize()
 
   # the stream stays in the library's pinned host buffer (no copy into a Python bytes object)
@@ -441,6 +473,15 @@ def main():
     session.close()
 
   ok_local = bool(torch.equal(out.view(torch.uint8), vol.view(torch.uint8)))
+  # The timed decode leg reads each rank's resident slab stream; the stream the job RETURNS is the merged one
+  # in the host buffer (async code copy, _finish, _seal): it is decoded here once, outside the timed region,
+  # through the broadcast path (every rank its own z-range), and has to give the same labels.
+  if resident:
+    out.zero_()
+    session = codec.open_decoder(binary, (sx, sy, sz))
+    session.run(out)
+    session.close()
+    ok_local = ok_local and bool(torch.equal(out.view(torch.uint8), vol.view(torch.uint8)))
 
   # one more decode with the z-chunks serialised on one stream, for the per-kernel table:
   # HIP events between the kernels on the decoder's own stream (ckl_decoder_stage_timing)
@@ -493,7 +534,7 @@ def main():
       "dtype": {1: "u8", 2: "u16", 4: "u32", 8: "u64"}[item],
       "data": "synthetic",
       "config": {
-        "workload": f"{sx}x{sy}x{sz_total} {np_dtype.name} jittered-Voronoi labels (cell 32x32x8), encode+decode, {'pin' if args.pins else 'flat'} labels, markov {args.markov}",
+        "workload": f"{sx}x{sy}x{sz_total} {np_dtype.name} " + {"voronoi": "jittered-Voronoi labels (cell 32x32x8)", "noise2000": "uniform-random labels in [0, 2000)", "binary": "uniform-random labels in {0, 1}"}[args.data] + f", encode+decode, {'pin' if args.pins else 'flat'} labels, markov {args.markov}",
         "per_gpu_slab": f"{sx}x{sy}x{sz}",
         "parallelism": f"z-slab x{world}",
       },
@@ -539,22 +580,24 @@ def main():
         },
       },
     }
-    # the same figure for the encoder's longest kernel (the serial trail over nodes: one
-    # wavefront per slice, bound by dependent instruction latency, not by bytes)
+    # the same figure for the encode direction as one unit: the slab's label bytes read + its stream bytes
+    # written over the encoder's device pipeline (first kernel to last, HIP events on its own streams).  Its
+    # longest kernel, the serial trail over nodes (one wavefront per slice, bound by dependent instruction
+    # latency, 44 MB of traffic), is a detail field: bytes over ITS time alone are not a roofline fraction.
     enc_k = float(np.mean(enc_kernel_ms))
-    if enc_k > 0:
-      etraffic, _ = pmc_traffic(["k_trail_walk"], workload_key)
+    enc_p = float(np.mean(enc_pipe_ms))
+    if enc_p > 0:
       res["roofline_encode"] = {
-        "bound": "hbm", "kernel": "k_trail_walk (encode)",
-        "achieved": alg_bytes / (enc_k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": alg_bytes / (enc_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": etraffic,
-        "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": enc_k,
-        "encode_pipeline_frac": alg_bytes / (float(np.mean(enc_pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": "encode pipeline (planes, trail, label stream: two streams)",
+        "achieved": alg_bytes / (enc_p * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg_bytes / (enc_p * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": enc_p,
+        "longest_kernel": {"kernel": "k_trail_walk", "kernel_ms": enc_k, "share_of_pipeline": (enc_k / enc_p) if enc_p > 0 else None},
       }
     # bytes against the reference encoder's own output at full size (sha256 of the whole stream)
     if world == 1 and not args.pins:
-      name = f"c2_{sx}x{sy}x{sz}_u32" if (np_dtype.itemsize == 4 and args.markov == 0) else None
+      name = f"c2_{sx}x{sy}x{sz}_u32" if (np_dtype.itemsize == 4 and args.markov == 0 and args.data == "voronoi") else None
       ref = reference_manifest(name) if name else None
       if ref is not None:
         sha = hashlib.sha256(bytes(binary.view()) if hasattr(binary, "view") else bytes(binary)).hexdigest()

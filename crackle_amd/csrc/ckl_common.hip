@@ -308,12 +308,16 @@ void Header::write(std::vector<uint8_t>& out) const {
 	fmt |= static_cast<uint16_t>((is_signed ? 1 : 0) << 8);
 	fmt |= static_cast<uint16_t>((markov_model_order & 15) << 9);
 	fmt |= static_cast<uint16_t>((is_sorted ? 0 : 1) << 13);
-	out.push_back(1);
+	// version 0 (src/header.hpp:213-245): 4-byte num_label_bytes, no crc8 — kept when a version 0 stream is
+	// rewritten (reencode), as long as the label section's size fits the field
+	const bool v0 = format_version == 0 && num_label_bytes <= 0xFFFFFFFFull;
+	out.push_back(v0 ? 0 : 1);
 	put_le(out, fmt, 2);
 	put_le(out, sx, 4);
 	put_le(out, sy, 4);
 	put_le(out, sz, 4);
 	out.push_back(log2_grid_size);
+	if (v0) { put_le(out, num_label_bytes, 4); return; }
 	put_le(out, num_label_bytes, 8);
 	out.push_back(crc8(out.data() + base + 5, kBytes - 1 - 5));
 }

@@ -2058,15 +2058,20 @@ void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int devic
 		*out = o; *out_len = len;
 	};
 	if (head.markov_model_order == markov_order) { copy_out(buf, n); return; }      // crackle.hpp:887-889
-	if (head.format_version == 0) throw Error(CKL_ERR_ARG, "crackle_amd: reencode of version 0 streams is not supported");
+	// Version 0 streams (24-byte header, no crcs) stay version 0, as src/crackle.hpp:947-984 means them to: the
+	// reference's own output for them is broken — its header vector has 29 bytes of which 24 are written
+	// (src/header.hpp:277-281), so five stray zero bytes follow the header (tests/golden/v0.npz keeps a sample) —
+	// what is written here is the stream that code intends, which the reference reads back.
+	const bool v0 = head.format_version == 0;
 	const uint64_t sz = head.sz;
+	const uint64_t tail_bytes = v0 ? 0 : 4 * (sz + 1);
 	const uint64_t off_index = head.header_bytes();
 	const uint64_t off_labels = off_index + head.grid_index_bytes();
 	if (!head.layout_fits(n)) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_code_offsets: Unable to read past end of buffer.");      // no sum of untrusted fields that could wrap
 	const uint64_t old_codes = off_labels + head.num_label_bytes + head.markov_model_bytes();
 	uint64_t old_tail = old_codes;
 	for (uint64_t z = 0; z < sz; z++) old_tail += rd_le(buf + off_index + 4 * z, 4);
-	if (old_tail > n || 4 * (sz + 1) > n - old_tail) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
+	if (old_tail > n || tail_bytes > n - old_tail) throw Error(CKL_ERR_RUNTIME, "crackle: get_crack_codes: Unable to read past end of buffer.");
 
 	const bool prof = getenv("CKL_PROFILE") != nullptr;
 	auto t_prev = std::chrono::steady_clock::now();
@@ -2119,7 +2124,7 @@ void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int devic
 	const uint64_t off_model = off_labels + head.num_label_bytes;
 	const uint64_t off_codes = off_model + stored_model.size();
 	const uint64_t off_tail = off_codes + cr.total;
-	const uint64_t total = off_tail + 4 * (sz + 1);
+	const uint64_t total = off_tail + tail_bytes;
 	uint8_t* o = static_cast<uint8_t*>(host_out_alloc(total));
 	try {
 		if (cr.total) CKL_HIP(hipMemcpyAsync(o + off_codes, enc.e->d_codes_out.p, cr.total, hipMemcpyDeviceToHost, enc.e->stream));
@@ -2128,10 +2133,10 @@ void reencode_markov(const uint8_t* buf, uint64_t n, int markov_order, int devic
 		memcpy(o, hb.data(), hb.size());
 		auto put4 = [&](uint64_t at, uint32_t v) { for (int b = 0; b < 4; b++) o[at + b] = static_cast<uint8_t>((v >> (8 * b)) & 0xFF); };
 		for (uint64_t z = 0; z < sz; z++) put4(off_index + 4 * z, cr.code_len[z]);
-		put4(off_index + 4 * sz, crc32c(o + off_index, 4 * sz));
+		if (!v0) put4(off_index + 4 * sz, crc32c(o + off_index, 4 * sz));
 		memcpy(o + off_labels, buf + off_labels, head.num_label_bytes);
 		if (!stored_model.empty()) memcpy(o + off_model, stored_model.data(), stored_model.size());
-		memcpy(o + off_tail, buf + old_tail, 4 * (sz + 1));
+		if (tail_bytes) memcpy(o + off_tail, buf + old_tail, tail_bytes);
 		if (cr.total) CKL_HIP(hipStreamSynchronize(enc.e->stream));
 		lap("assembly");
 	}

@@ -133,6 +133,21 @@ def as_numpy_f(t: torch.Tensor) -> np.ndarray:
   return tt.numpy().view(np_dt).transpose(2, 1, 0)
 
 
+def random_labels_device(shape, dtype=np.uint32, seed=0, high=2000, device="cpu", z_range=None) -> torch.Tensor:
+  """Uniform-random labels in [0, high) as a tensor of shape (sz, sy, sx) on `device`: the same values as
+  random_labels (voxel i = x + sx * (y + sy * z) hashed), generated where they are needed (bench.py --data
+  noise2000 / binary: the reference's adversarial inputs, benchmarks/README.md:108-114, 193-227)."""
+  sx, sy, sz = (int(s) for s in shape)
+  z0, z1 = (0, sz) if z_range is None else (int(z_range[0]), int(z_range[1]))
+  store_dt, final_dt = _torch_dtype(dtype)
+  out = torch.empty((z1 - z0, sy, sx), dtype=store_dt, device=device)
+  for z in range(z0, z1):      # slice by slice: the int64 hash of a whole volume would take 8 bytes per voxel
+    i = torch.arange(z * sx * sy, (z + 1) * sx * sy, dtype=torch.int64, device=device)
+    v = _hash32(i * 3 + (int(seed) & 0xFFFF) * 7919) % int(high)
+    out[z - z0] = v.reshape(sy, sx).to(store_dt)
+  return out.view(final_dt)
+
+
 def random_labels(shape, dtype=np.uint32, seed=0, high=2000) -> np.ndarray:
   """Uniform-random labels in [0, high) (adversarial PERMISSIBLE case), F-ordered numpy."""
   sx, sy, sz = (int(s) for s in shape)

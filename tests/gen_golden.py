@@ -5,12 +5,15 @@ into oracle/_ref by `make -C oracle ref`).  Runs only in the build container, wh
   tests/golden/golden.npz      exact .ckl bytes for every small case
   tests/golden/manifest.json   sha256/length/section hashes for larger generated cases
 
-usage: python tests/gen_golden.py [--xl | --ops]
+usage: python tests/gen_golden.py [--xl | --ops | --v0]
   --xl   writes tests/golden/manifest_xl.json (full-size BASELINE.json configurations)
   --ops  writes tests/golden/point_cloud.json (the reference's point_cloud on the small golden
          streams: per stream and argument set a sha256 over labels, offsets and points),
          tests/golden/label_stats.json (voxel_counts / centroids / bounding_boxes digests of the
          same streams) and the whole-C1 digests of ops_xl.json / point_cloud_xl.json
+  --v0   writes tests/golden/v0.npz: golden streams rewritten as format version 0 (24-byte header with a
+         4-byte num_label_bytes and no crc8, z-index without its crc32c, no crc tail: src/header.hpp:113-129,
+         168-183, src/crackle.hpp:276, 566, 599) together with the sha256 of what the REFERENCE decodes them to
 """
 import hashlib
 import json
@@ -156,11 +159,49 @@ def main_ops(ref):
   print("ops xl:", ops)
 
 
+def to_v0(binary: bytes) -> bytes:
+  """The same stream as the reference's version 0 layout (pure byte surgery, no re-encoding)."""
+  sec = sections(binary)
+  h = sec["header"]
+  assert h[4] == 1
+  nlb = int.from_bytes(h[20:28], "little")
+  assert nlb < (1 << 32)
+  head0 = h[:4] + b"\x00" + h[5:20] + nlb.to_bytes(4, "little")
+  sz = int.from_bytes(h[15:19], "little")
+  return head0 + sec["z_index"][:4 * sz] + sec["labels"] + sec["model"] + sec["cracks"]
+
+
+V0_CASES = ["c0_voronoi_u8", "c0_voronoi_u8_m5", "c0_voronoi_u8_pins_m5", "c0_voronoi_u8_c", "rand_17x13x5_uint64_F_m3_p1", "noise_2000", "kat_4x4", "single_voxel"]
+
+
+def main_v0(ref):
+  with np.load(os.path.join(HERE, "golden", "golden.npz")) as z:
+    names = [n for n in V0_CASES if n in z.files] or sorted(z.files)[:6]
+    streams = {k: z[k].tobytes() for k in names}
+  out = {}
+  for name, b1 in streams.items():
+    b0 = to_v0(b1)
+    a1 = ref.decompress(b1)
+    a0 = ref.decompress(b0)      # the reference itself reads the version 0 stream
+    assert np.array_equal(a0, a1), name
+    out[name] = np.frombuffer(b0, dtype=np.uint8)
+    out[name + ".decoded_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(a0).tobytes()).hexdigest().encode(), dtype=np.uint8)
+    try:      # what the reference's reencode makes of it (src/crackle.hpp:947-984)
+      r = ref.reencode(b0, 0)
+      out[name + ".ref_reencode_m0"] = np.frombuffer(bytes(r), dtype=np.uint8)
+    except RuntimeError as exc:
+      out[name + ".ref_reencode_error"] = np.frombuffer(str(exc).encode(), dtype=np.uint8)
+    print(name, len(b1), "->", len(b0))
+  np.savez_compressed(os.path.join(HERE, "golden", "v0.npz"), **out)
+
+
 def main():
   ref = oracle.ref()
   assert ref is not None, "build oracle/_ref first (make -C oracle ref)"
   if "--xl" in sys.argv:
     return main_xl(ref)
+  if "--v0" in sys.argv:
+    return main_v0(ref)
   if "--ops" in sys.argv:
     return main_ops(ref)
   blobs = {}
