@@ -885,7 +885,7 @@ struct ckl_encoder {
 	hipEvent_t evd0 = nullptr, evd1 = nullptr;      // around k_trail_walk (first slice group)
 	float trail_ms = 0.f;
 	hipStream_t trail_stream[kTrailStreams] = {};     // slice groups of the crack trail
-	hipEvent_t ev_fork = nullptr, ev_join[kTrailStreams] = {};
+	hipEvent_t ev_fork = nullptr, ev_join[kTrailStreams] = {}, ev_pre[kTrailStreams] = {};      // ev_pre[g]: group g's kernels in front of its walk are done
 	float pipeline_ms = 0.f, dominant_ms = 0.f;
 	int64_t max_sx = 0, max_sy = 0, max_sz = 0;
 	int dtype_bytes = 0;
@@ -968,6 +968,7 @@ struct ckl_encoder {
 		if (ev_in) (void)hipEventDestroy(ev_in);
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
 		for (auto& ev : ev_join) if (ev) (void)hipEventDestroy(ev);
+		for (auto& ev : ev_pre) if (ev) (void)hipEventDestroy(ev);
 		for (auto& st : trail_stream) if (st) (void)hipStreamDestroy(st);
 		if (stream) (void)hipStreamDestroy(stream);
 		if (stream2) (void)hipStreamDestroy(stream2);
@@ -1313,6 +1314,7 @@ void crack_pass(
 		uint32_t groups = 1u;      // measured at C2: 2 groups between -0.17 and +0.1 ms from run to run, 4 and 8 slower (the DFS wavefronts want their SIMDs to themselves)
 		if (const char* env = getenv("CKL_TRAIL_GROUPS")) groups = static_cast<uint32_t>(std::max(1, atoi(env)));
 		groups = std::min<uint32_t>(std::min<uint32_t>(groups, ns), kTrailStreams);
+		const bool stagger = getenv("CKL_TRAIL_STAGGER") != nullptr;
 		if (groups > 1) CKL_HIP(hipEventRecord(e.ev_fork, s));
 		for (uint32_t g = 0; g < groups; g++) {
 			const uint32_t z0 = static_cast<uint32_t>(static_cast<uint64_t>(ns) * g / groups);
@@ -1323,7 +1325,9 @@ void crack_pass(
 			// queues (4 by default), streams created later share one and serialise
 			if (g > 0 && !e.trail_stream[g - 1]) CKL_HIP(hipStreamCreateWithFlags(&e.trail_stream[g - 1], hipStreamNonBlocking));      // only when slice groups are asked for
 			hipStream_t gs = g == 0 ? s : e.trail_stream[g - 1];
-			if (g > 0) CKL_HIP(hipStreamWaitEvent(gs, e.ev_fork, 0));
+			// staggered: a group's chip-filling kernels start when the previous group's are through, i.e. beside
+			// that group's serial walk (one wavefront per slice), instead of all groups at once
+			if (g > 0) CKL_HIP(hipStreamWaitEvent(gs, stagger ? e.ev_pre[g - 1] : e.ev_fork, 0));
 			ta.z0 = z0;
 			fa.z0 = z0;
 			if (any) {
@@ -1333,6 +1337,7 @@ void crack_pass(
 				hipLaunchKernelGGL(k_trail_components, dim3(gn), dim3(kCompBlock), clds, gs, ta, static_cast<uint32_t>(clds));
 			}
 			if (g == 0) CKL_HIP(hipEventRecord(e.evd0, gs));
+			if (groups > 1) CKL_HIP(hipEventRecord(e.ev_pre[g], gs));
 			hipLaunchKernelGGL(k_trail_walk, dim3(gn), dim3(kWave), lds, gs, ta, static_cast<uint32_t>(lds));
 			if (g == 0) CKL_HIP(hipEventRecord(e.evd1, gs));
 			hipLaunchKernelGGL(k_trail_items, dim3(gn), dim3(kItemsBlock), 0, gs, ta);
@@ -1542,25 +1547,38 @@ void flat_collect(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, i
 	out.total = total;
 }
 
-// extract_columns / compute_multiverse / the component -> pin choice of find_suboptimal_pins
-// (src/pins.hpp:95-198, 300-346) as device passes over the resident label volume and
-// the component id volume (ckl_pins_dev.hpp); only per-component facts and the chosen pins are copied out.
-template <typename LABEL>
-PinCandidates pin_candidates_device(
-	ckl_encoder& e, const LABEL* labels, const uint32_t* cc /* device: component id of every voxel */,
-	const uint64_t* comp_label /* device: label of every component */, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N
-) {
+// the labels with the key of their first column run (the order they enter `pinsets`, src/pins.hpp:126-163), from the
+// components' labels and first runs on the device
+void pin_label_table(ckl_encoder& e, const uint64_t* comp_label, const uint64_t* first_any_dev, uint64_t N, PinCandidates& pc) {
 	hipStream_t s = e.stream2;
-	PinVolume v;
-	v.sx = static_cast<uint32_t>(sx_); v.sy = static_cast<uint32_t>(sy_); v.sz = static_cast<uint32_t>(sz_);
-	v.sxy = static_cast<uint64_t>(v.sx) * v.sy;
-	const uint64_t voxels = v.sxy * v.sz;
-	if (v.sz > 65535u) throw Error(CKL_ERR_ARG, "crackle_amd: pin labels need at most 65535 slices");      // the kept marks hold depth + 1 in 16 bits
-	const uint64_t mark_words = (voxels + 1) / 2;
-	e.d_pin_kept.ensure(mark_words);
-	CKL_HIP(hipMemsetAsync(e.d_pin_kept.p, 0, mark_words * sizeof(uint32_t), s));
-	v.cc = cc; v.mark = reinterpret_cast<uint16_t*>(e.d_pin_kept.p);
+	struct { const unsigned long long* first_any; } a = { reinterpret_cast<const unsigned long long*>(first_any_dev) };
+	{
+		if (N > (1ull << 30)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components for pin labels");
+		uint32_t slots = 1024;
+		while (slots < 2 * N) slots <<= 1;
+		DevBuf<uint64_t> d_tab;
+		DevBuf<uint32_t> d_count;
+		d_tab.ensure(4ull * slots + 1);      // keys | values | label list | first list, + the all-ones label's minimum
+		d_count.ensure(1);
+		CKL_HIP(hipMemsetAsync(d_tab.p, 0xFF, (2ull * slots) * sizeof(uint64_t), s));
+		CKL_HIP(hipMemsetAsync(d_tab.p + 4ull * slots, 0xFF, sizeof(uint64_t), s));
+		CKL_HIP(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t), s));
+		unsigned long long* t = reinterpret_cast<unsigned long long*>(d_tab.p);
+		hipLaunchKernelGGL(k_pin_label_first, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s,
+			reinterpret_cast<const unsigned long long*>(comp_label), a.first_any, N, t, t + slots, slots - 1u, t + 4ull * slots);
+		hipLaunchKernelGGL(k_pin_label_list, dim3((slots + kPinBlock - 1) / kPinBlock), dim3(kPinBlock), 0, s, t, t + slots, slots, d_count.p, t + 2ull * slots, t + 3ull * slots);
+		const uint32_t nl = download(d_count.p, 1, s)[0];
+		pc.label_value = download(d_tab.p + 2ull * slots, nl, s);
+		pc.label_first = download(d_tab.p + 3ull * slots, nl, s);
+		const uint64_t max_first = download(d_tab.p + 4ull * slots, 1, s)[0];
+		if (max_first != kPinNoKey) { pc.label_value.push_back(kPinNoKey); pc.label_first.push_back(max_first); }
+	}
+}
 
+// extract_columns + add_pin (src/pins.hpp:95-163) over the rows of `v`: the kept runs marked in v.mark
+template <typename LABEL>
+void pin_dedup_pass(ckl_encoder& e, const LABEL* labels, const PinVolume& v) {
+	hipStream_t s = e.stream2;
 	const bool by_thread = getenv("CKL_PINS_ROW_THREADS") != nullptr;      // testing: the general kernel on small volumes
 	if (v.sz <= 1024u && !by_thread) {
 		// a wavefront per row, label tables in registers
@@ -1581,6 +1599,29 @@ PinCandidates pin_candidates_device(
 		hipLaunchKernelGGL(k_pin_dedup<LABEL>, dim3((v.sy + kPinRowBlock - 1) / kPinRowBlock), dim3(kPinRowBlock), 0, s,
 			labels, v, reinterpret_cast<PinSlot*>(e.d_pin_tables.p), cap);
 	}
+
+}
+
+// extract_columns / compute_multiverse / the component -> pin choice of find_suboptimal_pins
+// (src/pins.hpp:95-198, 300-346) as device passes over the resident label volume and
+// the component id volume (ckl_pins_dev.hpp); only per-component facts and the chosen pins are copied out.
+template <typename LABEL>
+PinCandidates pin_candidates_device(
+	ckl_encoder& e, const LABEL* labels, const uint32_t* cc /* device: component id of every voxel */,
+	const uint64_t* comp_label /* device: label of every component */, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N
+) {
+	hipStream_t s = e.stream2;
+	PinVolume v;
+	v.sx = static_cast<uint32_t>(sx_); v.sy = static_cast<uint32_t>(sy_); v.sz = static_cast<uint32_t>(sz_);
+	v.sxy = static_cast<uint64_t>(v.sx) * v.sy;
+	const uint64_t voxels = v.sxy * v.sz;
+	if (v.sz > 65535u) throw Error(CKL_ERR_ARG, "crackle_amd: pin labels need at most 65535 slices");      // the kept marks hold depth + 1 in 16 bits
+	const uint64_t mark_words = (voxels + 1) / 2;
+	e.d_pin_kept.ensure(mark_words);
+	CKL_HIP(hipMemsetAsync(e.d_pin_kept.p, 0, mark_words * sizeof(uint32_t), s));
+	v.cc = cc; v.mark = reinterpret_cast<uint16_t*>(e.d_pin_kept.p);
+
+	pin_dedup_pass<LABEL>(e, labels, v);
 
 	e.d_pin_u64.ensure(4 * N + 1);
 	e.d_pin_u32.ensure(N + 1);
@@ -1673,30 +1714,112 @@ PinCandidates pin_candidates_device(
 		if (P) hipLaunchKernelGGL(k_pin_ids, dim3((P + kPinBlock - 1) / kPinBlock), dim3(kPinBlock), 0, s, v, key_dev, d_ze.p, d_off.p, P, d_ids.p);
 		pc.pin_ids = download(d_ids.p, pc.pin_ids_off[P], s);
 	}
-	// the labels with the key of their first column run
-	{
-		if (N > (1ull << 30)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components for pin labels");
-		uint32_t slots = 1024;
-		while (slots < 2 * N) slots <<= 1;
-		DevBuf<uint64_t> d_tab;
-		DevBuf<uint32_t> d_count;
-		d_tab.ensure(4ull * slots + 1);      // keys | values | label list | first list, + the all-ones label's minimum
-		d_count.ensure(1);
-		CKL_HIP(hipMemsetAsync(d_tab.p, 0xFF, (2ull * slots) * sizeof(uint64_t), s));
-		CKL_HIP(hipMemsetAsync(d_tab.p + 4ull * slots, 0xFF, sizeof(uint64_t), s));
-		CKL_HIP(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t), s));
-		unsigned long long* t = reinterpret_cast<unsigned long long*>(d_tab.p);
-		hipLaunchKernelGGL(k_pin_label_first, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s,
-			reinterpret_cast<const unsigned long long*>(comp_label), a.first_any, N, t, t + slots, slots - 1u, t + 4ull * slots);
-		hipLaunchKernelGGL(k_pin_label_list, dim3((slots + kPinBlock - 1) / kPinBlock), dim3(kPinBlock), 0, s, t, t + slots, slots, d_count.p, t + 2ull * slots, t + 3ull * slots);
-		const uint32_t nl = download(d_count.p, 1, s)[0];
-		pc.label_value = download(d_tab.p + 2ull * slots, nl, s);
-		pc.label_first = download(d_tab.p + 3ull * slots, nl, s);
-		const uint64_t max_first = download(d_tab.p + 4ull * slots, 1, s)[0];
-		if (max_first != kPinNoKey) { pc.label_value.push_back(kPinNoKey); pc.label_first.push_back(max_first); }
-	}
+	pin_label_table(e, comp_label, reinterpret_cast<const uint64_t*>(a.first_any), N, pc);
 	HT_MARK("p:ids");
 	return pc;
+}
+
+
+// ---- the pin stage sharded by ROWS (config C4 on several GPUs) -----------------------------------------------------
+// Candidate pins are z-runs per (x, y) column over the WHOLE volume, so a z-slab cannot find them; a slab of rows
+// [y0, y0 + rows) of every slice can: extract_columns / add_pin compare a run only with the label's last pin in the
+// previous column of the same row (src/pins.hpp:134-160), so rows are independent, and what is kept per COMPONENT
+// (a component lies in one slice but spans rows) is an extremum over its voxels:
+//   first_any   smallest key of a run starting in the component                          -> minimum over the ranks
+//   first_kept  smallest key of a kept run containing it, with that run's depth          -> minimum of key << 16 | depth
+//   best        1 + largest key of a kept run deeper than the first kept one (0: none)   -> maximum, once every rank knows
+//                                                                                           the first run's depth
+//   z_e + 1     last slice of the chosen run, known to the rank that holds its row        -> maximum (0 elsewhere)
+//   ids         component ids along the chosen run, likewise                              -> maximum (0 elsewhere)
+// The caller (crackle_amd/distributed.py) holds the arrays in its device memory, reduces them over its process group
+// between the calls (RCCL all_reduce of N-entry arrays: 13 MB each for C4's 1.6 M components) and hands the reduced
+// arrays back; rank 0 finally runs the ordered cover (ckl_pins_rows_section).  Keys name columns of the whole volume.
+template <typename LABEL>
+PinVolume pin_rows_volume(ckl_encoder& e, const uint32_t* cc, int64_t sx, int64_t rows, int64_t sz, int64_t y0, bool fresh_marks) {
+	PinVolume v;
+	v.sx = static_cast<uint32_t>(sx); v.sy = static_cast<uint32_t>(rows); v.sz = static_cast<uint32_t>(sz);
+	v.sxy = static_cast<uint64_t>(v.sx) * v.sy;
+	v.key_col0 = static_cast<uint64_t>(y0) * v.sx;
+	if (v.sz > 65535u) throw Error(CKL_ERR_ARG, "crackle_amd: pin labels need at most 65535 slices");
+	const uint64_t mark_words = (v.sxy * v.sz + 1) / 2;
+	if (fresh_marks) {
+		e.d_pin_kept.ensure(mark_words);
+		CKL_HIP(hipMemsetAsync(e.d_pin_kept.p, 0, mark_words * sizeof(uint32_t), e.stream2));
+	}
+	else if (!e.d_pin_kept.p || e.d_pin_kept.n < mark_words) throw Error(CKL_ERR_ARG, "crackle_amd: ckl_pins_rows_first has to run first");
+	v.cc = cc; v.mark = reinterpret_cast<uint16_t*>(e.d_pin_kept.p);
+	return v;
+}
+
+template <typename LABEL>
+void pins_rows_first(ckl_encoder& e, const LABEL* labels, const uint32_t* cc, int64_t sx, int64_t rows, int64_t sz, int64_t y0, uint64_t N,
+	uint64_t* first_any, uint64_t* first_kept_packed, uint64_t* comp_label) {
+	hipStream_t s = e.stream2;
+	const PinVolume v = pin_rows_volume<LABEL>(e, cc, sx, rows, sz, y0, true);
+	const uint32_t nb = static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock);
+	// the label of every component that shows in these rows (0 elsewhere: the ranks' arrays merge by maximum)
+	e.d_slice_err2.ensure(1);
+	CKL_HIP(hipMemsetAsync(comp_label, 0, N * sizeof(uint64_t), s));
+	CKL_HIP(hipMemsetAsync(e.d_slice_err2.p, 0, sizeof(uint32_t), s));
+	const uint64_t voxels = v.sxy * v.sz;
+	const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((voxels + kPinBlock - 1) / kPinBlock, 0x7FFFFFFFull));
+	hipLaunchKernelGGL(k_pin_component_labels<LABEL>, dim3(blocks), dim3(kPinBlock), 0, s, labels, cc, voxels, v.sx, N, reinterpret_cast<unsigned long long*>(comp_label), e.d_slice_err2.p);
+	pin_dedup_pass<LABEL>(e, labels, v);
+	e.d_pin_u64.ensure(N + 1);
+	e.d_pin_u32.ensure(N + 1);
+	PinComponentArrays a;
+	a.first_any = reinterpret_cast<unsigned long long*>(first_any);
+	a.first_kept = reinterpret_cast<unsigned long long*>(e.d_pin_u64.p);
+	a.best = nullptr;
+	a.first_depth = e.d_pin_u32.p;
+	CKL_HIP(hipMemsetAsync(a.first_any, 0xFF, N * sizeof(uint64_t), s));
+	CKL_HIP(hipMemsetAsync(a.first_kept, 0xFF, N * sizeof(uint64_t), s));
+	CKL_HIP(hipMemsetAsync(a.first_depth, 0, N * sizeof(uint32_t), s));
+	const dim3 cgrid((v.sx + kPinBlock - 1) / kPinBlock, v.sy);
+	hipLaunchKernelGGL((k_pin_columns<LABEL, 0>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
+	hipLaunchKernelGGL((k_pin_extent<LABEL, true>), dim3(nb), dim3(kPinBlock), 0, s, labels, v, a.first_kept, static_cast<uint32_t>(N), a.first_depth);
+	hipLaunchKernelGGL(k_pin_pack_first, dim3(nb), dim3(kPinBlock), 0, s, a.first_kept, a.first_depth, N, reinterpret_cast<unsigned long long*>(first_kept_packed));
+	if (download(e.d_slice_err2.p, 1, s)[0]) throw Error(CKL_ERR_ARG, "crackle_amd: component id out of range");
+}
+
+template <typename LABEL>
+void pins_rows_best(ckl_encoder& e, const LABEL* labels, const uint32_t* cc, int64_t sx, int64_t rows, int64_t sz, int64_t y0, uint64_t N,
+	const uint64_t* first_kept_packed, uint64_t* best) {
+	hipStream_t s = e.stream2;
+	const PinVolume v = pin_rows_volume<LABEL>(e, cc, sx, rows, sz, y0, false);
+	const uint32_t nb = static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock);
+	e.d_pin_u64.ensure(N + 1);
+	e.d_pin_u32.ensure(N + 1);
+	PinComponentArrays a;
+	a.first_any = nullptr;
+	a.first_kept = reinterpret_cast<unsigned long long*>(e.d_pin_u64.p);
+	a.best = reinterpret_cast<unsigned long long*>(best);
+	a.first_depth = e.d_pin_u32.p;
+	hipLaunchKernelGGL(k_pin_unpack_first, dim3(nb), dim3(kPinBlock), 0, s, reinterpret_cast<const unsigned long long*>(first_kept_packed), N, a.first_kept, a.first_depth);
+	CKL_HIP(hipMemsetAsync(a.best, 0, N * sizeof(uint64_t), s));
+	const dim3 cgrid((v.sx + kPinBlock - 1) / kPinBlock, v.sy);
+	hipLaunchKernelGGL((k_pin_columns<LABEL, 2>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
+	CKL_HIP(hipStreamSynchronize(s));
+}
+
+template <typename LABEL>
+void pins_rows_extent(ckl_encoder& e, const LABEL* labels, const uint32_t* cc, int64_t sx, int64_t rows, int64_t sz, int64_t y0, uint64_t N,
+	const uint64_t* first_kept_packed, const uint64_t* best, uint64_t* choice, uint32_t* ze_plus1) {
+	hipStream_t s = e.stream2;
+	const PinVolume v = pin_rows_volume<LABEL>(e, cc, sx, rows, sz, y0, false);
+	const uint32_t nb = static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock);
+	e.d_pin_u64.ensure(N + 1);
+	e.d_pin_u32.ensure(N + 1);
+	PinComponentArrays a;
+	a.first_any = nullptr;
+	a.first_kept = reinterpret_cast<unsigned long long*>(e.d_pin_u64.p);
+	a.best = reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(best));
+	a.first_depth = e.d_pin_u32.p;
+	hipLaunchKernelGGL(k_pin_unpack_first, dim3(nb), dim3(kPinBlock), 0, s, reinterpret_cast<const unsigned long long*>(first_kept_packed), N, a.first_kept, a.first_depth);
+	hipLaunchKernelGGL(k_pin_choice, dim3(nb), dim3(kPinBlock), 0, s, a, N, reinterpret_cast<unsigned long long*>(choice));
+	CKL_HIP(hipMemsetAsync(ze_plus1, 0, N * sizeof(uint32_t), s));
+	hipLaunchKernelGGL((k_pin_extent<LABEL, false, true>), dim3(nb), dim3(kPinBlock), 0, s, labels, v, reinterpret_cast<const unsigned long long*>(choice), static_cast<uint32_t>(N), ze_plus1);
+	CKL_HIP(hipStreamSynchronize(s));
 }
 
 // The flat label section (labels.hpp:92-152) on device: sort + unique of the component
@@ -2184,6 +2307,7 @@ int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int 
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
 		for (auto& ev : e->ev_join) CKL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		for (auto& ev : e->ev_pre) CKL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		*out = e.release();
 		return CKL_OK;
 	}
@@ -2469,6 +2593,136 @@ int ckl_encoder_pin_labels(
 		else if (e->dtype_bytes == 4) CKL_PINS(uint32_t);
 		else CKL_PINS(uint64_t);
 #undef CKL_PINS
+		const std::vector<uint8_t> bin = pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor != 0, manual_bgcolor);
+		uint8_t* p = static_cast<uint8_t*>(host_out_alloc(bin.size() ? bin.size() : 1));
+		memcpy(p, bin.data(), bin.size());
+		*out = p;
+		*out_len = bin.size();
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+
+#define CKL_ROWS_DISPATCH(CALL) do { \
+		if (e->dtype_bytes == 1) { typedef uint8_t T; CALL; } \
+		else if (e->dtype_bytes == 2) { typedef uint16_t T; CALL; } \
+		else if (e->dtype_bytes == 4) { typedef uint32_t T; CALL; } \
+		else { typedef uint64_t T; CALL; } \
+	} while (0)
+
+static void pins_rows_check(const ckl_encoder* e, const void* labels, const uint32_t* cc, int64_t sx, int64_t rows, int64_t sz, int64_t y0, uint64_t N) {
+	if (!e || !labels || !cc) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+	if (sx <= 0 || rows <= 0 || sz <= 0 || y0 < 0) throw Error(CKL_ERR_ARG, "crackle_amd: empty row slab");
+	if (sx > 0x7FFFFFF0ll || rows > 0x7FFFFFF0ll || y0 > 0x7FFFFFF0ll || sz > 65535) throw Error(CKL_ERR_ARG, "crackle_amd: row slab dimensions out of range");
+	if (N == 0 || N >= kPinNone) throw Error(CKL_ERR_ARG, "crackle_amd: component count out of range");
+	if (static_cast<unsigned __int128>(y0 + rows) * static_cast<uint64_t>(sx) * static_cast<uint64_t>(sz) >= (static_cast<unsigned __int128>(1) << 47)) throw Error(CKL_ERR_ARG, "crackle_amd: volume too large for the row-sharded pin stage");
+}
+
+int ckl_pins_rows_first(ckl_encoder* e, const void* labels_rows, const uint32_t* cc_rows, int64_t sx, int64_t rows, int64_t sz, int64_t y0, uint64_t n_components,
+	uint64_t* first_any, uint64_t* first_kept, uint64_t* comp_label) {
+	try {
+		pins_rows_check(e, labels_rows, cc_rows, sx, rows, sz, y0, n_components);
+		if (!first_any || !first_kept || !comp_label) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		select_device(e->device);
+		wait_for_default_stream(e->stream2, e->ev_in);
+		CKL_ROWS_DISPATCH(pins_rows_first<T>(*e, static_cast<const T*>(labels_rows), cc_rows, sx, rows, sz, y0, n_components, first_any, first_kept, comp_label));
+		CKL_HIP(hipStreamSynchronize(e->stream2));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_pins_rows_best(ckl_encoder* e, const void* labels_rows, const uint32_t* cc_rows, int64_t sx, int64_t rows, int64_t sz, int64_t y0, uint64_t n_components,
+	const uint64_t* first_kept, uint64_t* best) {
+	try {
+		pins_rows_check(e, labels_rows, cc_rows, sx, rows, sz, y0, n_components);
+		if (!first_kept || !best) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		select_device(e->device);
+		wait_for_default_stream(e->stream2, e->ev_in);
+		CKL_ROWS_DISPATCH(pins_rows_best<T>(*e, static_cast<const T*>(labels_rows), cc_rows, sx, rows, sz, y0, n_components, first_kept, best));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_pins_rows_extent(ckl_encoder* e, const void* labels_rows, const uint32_t* cc_rows, int64_t sx, int64_t rows, int64_t sz, int64_t y0, uint64_t n_components,
+	const uint64_t* first_kept, const uint64_t* best, uint64_t* choice, uint32_t* ze_plus1) {
+	try {
+		pins_rows_check(e, labels_rows, cc_rows, sx, rows, sz, y0, n_components);
+		if (!first_kept || !best || !choice || !ze_plus1) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		select_device(e->device);
+		wait_for_default_stream(e->stream2, e->ev_in);
+		CKL_ROWS_DISPATCH(pins_rows_extent<T>(*e, static_cast<const T*>(labels_rows), cc_rows, sx, rows, sz, y0, n_components, first_kept, best, choice, ze_plus1));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_pins_rows_ids(ckl_encoder* e, const uint32_t* cc_rows, int64_t sx, int64_t rows, int64_t sz, int64_t y0, uint64_t n_components,
+	const uint64_t* choice, const uint32_t* ze_plus1, const uint64_t* offsets, uint32_t* ids) {
+	try {
+		if (!e || !cc_rows || !choice || !ze_plus1 || !offsets || !ids) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		if (sx <= 0 || rows <= 0 || sz <= 0 || y0 < 0 || n_components == 0 || n_components >= kPinNone) throw Error(CKL_ERR_ARG, "crackle_amd: row slab out of range");
+		select_device(e->device);
+		wait_for_default_stream(e->stream2, e->ev_in);
+		hipStream_t s = e->stream2;
+		PinVolume v;
+		v.sx = static_cast<uint32_t>(sx); v.sy = static_cast<uint32_t>(rows); v.sz = static_cast<uint32_t>(sz);
+		v.sxy = static_cast<uint64_t>(v.sx) * v.sy; v.key_col0 = static_cast<uint64_t>(y0) * v.sx; v.cc = cc_rows; v.mark = nullptr;
+		// k_pin_ids wants the last slice itself: the entries that are 0 ("not mine") are skipped by the row check, so ze_plus1 - 1 of the others
+		DevBuf<uint32_t> d_ze;
+		d_ze.ensure(n_components);
+		const uint32_t nb = static_cast<uint32_t>((n_components + kPinBlock - 1) / kPinBlock);
+		hipLaunchKernelGGL(k_pin_minus1, dim3(nb), dim3(kPinBlock), 0, s, ze_plus1, n_components, d_ze.p);
+		hipLaunchKernelGGL(k_pin_ids, dim3(nb), dim3(kPinBlock), 0, s, v, reinterpret_cast<const unsigned long long*>(choice), d_ze.p, offsets, static_cast<uint32_t>(n_components), ids);
+		CKL_HIP(hipStreamSynchronize(s));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
+int ckl_pins_rows_section(ckl_encoder* e, int64_t sx, int64_t sy, int64_t sz, uint64_t n_components, const uint32_t* ncomp_host,
+	const uint64_t* comp_label, const uint64_t* first_any, const uint64_t* choice, const uint32_t* ze_plus1, const uint64_t* offsets, const uint32_t* ids,
+	int stored_width, int auto_bgcolor, int64_t manual_bgcolor, uint8_t** out, uint64_t* out_len) {
+	try {
+		if (!e || !ncomp_host || !comp_label || !first_any || !choice || !ze_plus1 || !offsets || !ids || !out || !out_len) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		if (sx <= 0 || sy <= 0 || sz <= 0) throw Error(CKL_ERR_ARG, "crackle_amd: empty volume");
+		if (stored_width != 1 && stored_width != 2 && stored_width != 4 && stored_width != 8) throw Error(CKL_ERR_ARG, "crackle_amd: stored width must be 1, 2, 4 or 8 bytes");
+		const uint64_t N = n_components;
+		if (N == 0 || N >= kPinNone) throw Error(CKL_ERR_ARG, "crackle_amd: component count out of range");
+		select_device(e->device);
+		wait_for_default_stream(e->stream2, e->ev_in);
+		hipStream_t s = e->stream2;
+		std::vector<uint32_t> nc(ncomp_host, ncomp_host + sz);
+		PinCandidates pc;
+		pc.comp_label = download(comp_label, N, s);
+		pc.comp_first = download(first_any, N, s);
+		const std::vector<uint64_t> chosen = download(choice, N, s);
+		pc.pin_ze = download(ze_plus1, N, s);
+		pc.pin_ids_off = download(offsets, N + 1, s);
+		pc.pin_ids = download(ids, pc.pin_ids_off[N], s);
+		pc.comp_pin.assign(N, kPinNone);
+		pc.pin_x.assign(N, 0); pc.pin_y.assign(N, 0); pc.pin_zs.assign(N, 0);
+		const uint64_t usx = static_cast<uint64_t>(sx), usz = static_cast<uint64_t>(sz);
+		for (uint64_t c = 0; c < N; c++) {
+			if (chosen[c] == kPinNoKey) { pc.pin_ze[c] = 0; continue; }
+			if (pc.pin_ze[c] == 0) throw Error(CKL_ERR_RUNTIME, "crackle_amd: a chosen pin lies in no rank's rows");
+			pc.comp_pin[c] = static_cast<uint32_t>(c);
+			const uint64_t col = chosen[c] / usz;
+			pc.pin_zs[c] = static_cast<uint32_t>(chosen[c] % usz);
+			pc.pin_ze[c] -= 1u;
+			pc.pin_x[c] = static_cast<uint32_t>(col % usx);
+			pc.pin_y[c] = static_cast<uint32_t>(col / usx);
+		}
+		pin_label_table(*e, comp_label, first_any, N, pc);
+		Header h;
+		h.sx = static_cast<uint32_t>(sx); h.sy = static_cast<uint32_t>(sy); h.sz = static_cast<uint32_t>(sz);
 		const std::vector<uint8_t> bin = pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor != 0, manual_bgcolor);
 		uint8_t* p = static_cast<uint8_t*>(host_out_alloc(bin.size() ? bin.size() : 1));
 		memcpy(p, bin.data(), bin.size());

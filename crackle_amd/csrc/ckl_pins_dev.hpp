@@ -38,10 +38,11 @@ struct PinSlot {
 };
 
 struct PinVolume {
-	uint32_t sx, sy, sz;
-	uint64_t sxy;
+	uint32_t sx, sy, sz;     // sy: the rows held here (all of them, or one rank's rows [y0, y0 + sy) of the row-sharded stage)
+	uint64_t sxy;            // sx * sy: voxels between two slices of the volume as it is held
 	const uint32_t* cc;      // global component ids
 	uint16_t* mark;          // per voxel: depth + 1 of the kept candidate pin that starts here, else 0 (sz <= 65535)
+	uint64_t key_col0 = 0;   // y0 * sx: keys name columns of the WHOLE volume ((y * sx + x) * sz + z_start), whatever rows are held
 };
 
 __device__ __forceinline__ uint32_t pin_hash(uint64_t label) {
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(kPinBlock) k_pin_columns(const LABEL* __restri
 			if (z >= v.sz) break;
 			const bool start = z == 0 || lab[i] != prev;
 			if (start) {
-				key = static_cast<unsigned long long>(col) * v.sz + z;
+				key = static_cast<unsigned long long>(col + v.key_col0) * v.sz + z;
 				kept = mk[i] != 0u;
 				depth = mk[i] - 1u;
 			}
@@ -317,18 +318,21 @@ __global__ void __launch_bounds__(kPinBlock) k_pin_component_labels(
 
 // z-range of a run given by its key, one thread per key: the last slice (the distinct chosen
 // runs) or the depth (the first kept run of every component; a component without one keeps 0)
-template <typename LABEL, bool DEPTH>
+// PLUS1 (row-sharded stage): last slice + 1, so that 0 says "not my rows" and the ranks' arrays merge by maximum
+template <typename LABEL, bool DEPTH, bool PLUS1 = false>
 __global__ void __launch_bounds__(kPinBlock) k_pin_extent(const LABEL* __restrict__ labels, PinVolume v, const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ out) {
 	const uint32_t i = blockIdx.x * kPinBlock + threadIdx.x;
 	if (i >= n) return;
 	const unsigned long long key = keys[i];
 	if (key == kPinNoKey) return;
 	const uint32_t z_s = static_cast<uint32_t>(key % v.sz);
-	const uint64_t col = key / v.sz;
+	const uint64_t gcol = key / v.sz;
+	if (gcol < v.key_col0 || gcol - v.key_col0 >= v.sxy) return;      // a run of another rank's rows
+	const uint64_t col = gcol - v.key_col0;
 	const LABEL label = labels[col + v.sxy * z_s];
 	uint32_t z = z_s + 1u;
 	while (z < v.sz && labels[col + v.sxy * z] == label) z++;
-	out[i] = DEPTH ? z - 1u - z_s : z - 1u;
+	out[i] = DEPTH ? z - 1u - z_s : (PLUS1 ? z : z - 1u);
 }
 
 __global__ void __launch_bounds__(kPinBlock) k_pin_ids(PinVolume v, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ z_e, const uint64_t* __restrict__ off, uint32_t n, uint32_t* __restrict__ ids) {
@@ -337,9 +341,39 @@ __global__ void __launch_bounds__(kPinBlock) k_pin_ids(PinVolume v, const unsign
 	const unsigned long long key = keys[i];
 	if (key == kPinNoKey) return;
 	const uint32_t z_s = static_cast<uint32_t>(key % v.sz);
-	const uint64_t col = key / v.sz;
+	const uint64_t gcol = key / v.sz;
+	if (gcol < v.key_col0 || gcol - v.key_col0 >= v.sxy) return;      // a run of another rank's rows (its ids stay 0 here)
+	const uint64_t col = gcol - v.key_col0;
 	uint32_t* dst = ids + off[i];
 	for (uint32_t z = z_s; z <= z_e[i]; z++) dst[z - z_s] = v.cc[col + v.sxy * z];
+}
+
+// row-sharded stage: (first kept run, its depth) of every component in one word, so that the ranks' answers merge
+// by minimum — key << 16 | depth (keys < 2^47: volumes of < 2^47 voxels; depth < 2^16) — and back
+__global__ void __launch_bounds__(kPinBlock) k_pin_pack_first(const unsigned long long* __restrict__ first_kept, const uint32_t* __restrict__ depth, uint64_t n, unsigned long long* __restrict__ packed) {
+	const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kPinBlock + threadIdx.x;
+	if (c >= n) return;
+	const unsigned long long k = first_kept[c];
+	packed[c] = k == kPinNoKey ? kPinNoKey : ((k << 16) | (depth[c] & 0xFFFFu));
+}
+__global__ void __launch_bounds__(kPinBlock) k_pin_unpack_first(const unsigned long long* __restrict__ packed, uint64_t n, unsigned long long* __restrict__ first_kept, uint32_t* __restrict__ depth) {
+	const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kPinBlock + threadIdx.x;
+	if (c >= n) return;
+	const unsigned long long p = packed[c];
+	first_kept[c] = p == kPinNoKey ? kPinNoKey : (p >> 16);
+	depth[c] = p == kPinNoKey ? 0u : static_cast<uint32_t>(p & 0xFFFFu);
+}
+__global__ void __launch_bounds__(kPinBlock) k_pin_minus1(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out) {
+	const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kPinBlock + threadIdx.x;
+	if (c < n) out[c] = in[c] ? in[c] - 1u : 0u;
+}
+// offsets of the components' id lists from their chosen runs (exclusive prefix by the host is avoided: one pass with a scan per block would do,
+// but the lists are only needed on the rank that writes the section: it scans there)
+__global__ void __launch_bounds__(kPinBlock) k_pin_id_counts(const unsigned long long* __restrict__ choice, const uint32_t* __restrict__ ze_plus1, uint32_t sz, uint64_t n, uint32_t* __restrict__ count) {
+	const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kPinBlock + threadIdx.x;
+	if (c >= n) return;
+	const unsigned long long k = choice[c];
+	count[c] = (k == kPinNoKey || ze_plus1[c] == 0u) ? 0u : ze_plus1[c] - static_cast<uint32_t>(k % sz);
 }
 
 

@@ -448,6 +448,35 @@ class HipBackend:
     finally:
       self._L.ckl_free(out_p)
 
+  # -- the pin stage sharded by rows (ckl_pins_rows_*): every array is a device tensor of the caller ----------
+  def _rows_call(self, fn, *args):
+    if fn(self._enc, *args) != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+
+  def pins_rows_first(self, lab_rows, cc_rows, sx, rows, sz, y0, n, first_any, first_kept, comp_label):
+    self._rows_call(self._L.ckl_pins_rows_first, lab_rows.data_ptr(), cc_rows.data_ptr(), sx, rows, sz, y0, n,
+                    first_any.data_ptr(), first_kept.data_ptr(), comp_label.data_ptr())
+
+  def pins_rows_best(self, lab_rows, cc_rows, sx, rows, sz, y0, n, first_kept, best):
+    self._rows_call(self._L.ckl_pins_rows_best, lab_rows.data_ptr(), cc_rows.data_ptr(), sx, rows, sz, y0, n, first_kept.data_ptr(), best.data_ptr())
+
+  def pins_rows_extent(self, lab_rows, cc_rows, sx, rows, sz, y0, n, first_kept, best, choice, ze_plus1):
+    self._rows_call(self._L.ckl_pins_rows_extent, lab_rows.data_ptr(), cc_rows.data_ptr(), sx, rows, sz, y0, n,
+                    first_kept.data_ptr(), best.data_ptr(), choice.data_ptr(), ze_plus1.data_ptr())
+
+  def pins_rows_ids(self, cc_rows, sx, rows, sz, y0, n, choice, ze_plus1, offsets, ids):
+    self._rows_call(self._L.ckl_pins_rows_ids, cc_rows.data_ptr(), sx, rows, sz, y0, n, choice.data_ptr(), ze_plus1.data_ptr(), offsets.data_ptr(), ids.data_ptr())
+
+  def pins_rows_section(self, sx, sy, sz, n, ncomp_all: np.ndarray, comp_label, first_any, choice, ze_plus1, offsets, ids, stored_width: int) -> np.ndarray:
+    nc = np.ascontiguousarray(ncomp_all, dtype=np.uint32)
+    out_p, out_n = C.c_void_p(), C.c_uint64()
+    self._rows_call(self._L.ckl_pins_rows_section, sx, sy, sz, n, nc.ctypes.data, comp_label.data_ptr(), first_any.data_ptr(), choice.data_ptr(),
+                    ze_plus1.data_ptr(), offsets.data_ptr(), ids.data_ptr(), int(stored_width), 1, 0, C.byref(out_p), C.byref(out_n))
+    try:
+      return np.frombuffer(C.string_at(out_p.value, out_n.value), dtype=np.uint8)
+    finally:
+      self._L.ckl_free(out_p)
+
   def keep_device_stream(self, shape, itemsize: int, keep: bool = True):
     """Following encodes of this shape also leave their whole stream in HBM (device_stream())."""
     self._L.ckl_encoder_keep_device_stream(self._encoder(shape, itemsize), int(bool(keep)))
@@ -704,7 +733,17 @@ class ShardedCodec:
     sz_tot = int(table[:, 3].sum())
     z_before = int(table[:self.rank, 3].sum())
     pins_section = None
-    if use_pins and hasattr(be, "pin_labels_device"):
+    import os as _os3
+    rows_done = False
+    if use_pins and hasattr(be, "pins_rows_first") and not _os3.environ.get("CKL_PINS_ON_ROOT") and not getattr(self, "_pins_rows_fallback", False):
+      # every rank works on its own rows of the whole volume; rank 0 only writes the section
+      got = self._pins_by_rows(be, vol, slab_shape, table, sec, cw, sw, mark)
+      if got is not None:
+        rows_done = True
+        pins_section = got if self.rank == 0 else None
+    if rows_done:
+      pass
+    elif use_pins and hasattr(be, "pin_labels_device"):
       # Pin labels (pins.hpp:348-403, labels.hpp:157-344): candidate pins are z-runs per (x,y)
       # column over the WHOLE volume and the greedy cover is order sensitive.  The slabs' labels
       # and component ids (numbered continuously over all slices) are collected in rank 0's HBM
@@ -860,17 +899,142 @@ class ShardedCodec:
       print("[ckl sharded compress ms] " + " ".join(f"{n}={v:.2f}" for n, v in marks), file=sys.stderr)
     return SharedStream(self._shared.mm, total)
 
+  # -- pins, sharded by rows ------------------------------------------------------
+  def _rows_of(self, sy: int):
+    """[(y0, rows)] of every rank: the rows dealt out as evenly as they go (the first ranks take the remainder)."""
+    base, rem = divmod(int(sy), self.world)
+    out, y = [], 0
+    for r in range(self.world):
+      n = base + (1 if r < rem else 0)
+      out.append((y, n))
+      y += n
+    return out
+
+  def _to_row_slabs(self, t3: torch.Tensor, sz_list, rows):
+    """This rank's z-slab (sz_local, sy, sx) -> its rows of EVERY slice (sz_total, rows_mine, sx): one
+    all_to_all_single (over xGMI with RCCL; staged through the host under gloo).  Unsigned dtypes travel as the
+    signed type of the same width (bit patterns)."""
+    orig = t3.dtype
+    item = t3.element_size()
+    sz_l, sy, sx = (int(v) for v in t3.shape)
+    y0_me, rows_me = rows[self.rank]
+    # as bytes: neither RCCL nor gloo knows every integer width (no 16-bit integers, no unsigned 32 / 64 under gloo)
+    send = torch.cat([t3[:, y0:y0 + n, :].reshape(-1) for (y0, n) in rows]).view(torch.uint8) if sz_l else torch.empty(0, dtype=torch.uint8, device=t3.device)
+    in_split = [sz_l * n * sx * item for (_, n) in rows]
+    out_split = [int(z) * rows_me * sx * item for z in sz_list]
+    direct = self.device.type == t3.device.type
+    src = send if direct else send.to(self.device)
+    recv = torch.empty(sum(out_split), dtype=torch.uint8, device=src.device)
+    if self.world > 1:
+      dist.all_to_all_single(recv, src, out_split, in_split)
+    else:
+      recv.copy_(src)
+    if not direct:
+      recv = recv.to(t3.device)
+    return recv.view(orig).view(int(sum(sz_list)), rows_me, sx)
+
+  def _reduce(self, t: torch.Tensor, op: str, unsigned: bool):
+    """all_reduce of a device tensor of integer bit patterns in place; unsigned 64-bit order through the sign flip."""
+    if self.world == 1:
+      return
+    sign = -(1 << 63)
+    if unsigned:
+      t ^= sign
+    direct = self.device.type == t.device.type
+    w = t if direct else t.to(self.device)
+    dist.all_reduce(w, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op])
+    if not direct:
+      t.copy_(w.to(t.device))
+    if unsigned:
+      t ^= sign
+
+  def _pins_by_rows(self, be, vol, slab_shape, table, sec, cw, sw, mark):
+    """The pin label section with every rank working on its own ROWS of the whole volume (ckl_pins_rows_*,
+    include/crackle_amd.h): labels and component ids are transposed from z-slabs to row slabs, the per-component
+    extrema are reduced over the ranks between the device passes, rank 0 writes the section (ordered cover).
+    Returns the section on rank 0, b"" elsewhere; None when the stage has to fall back to the collection on
+    rank 0 (id lists beyond the budget)."""
+    import os
+    sx, sy, sz = slab_shape
+    sxy = sx * sy
+    dev = vol.device
+    sz_list = [int(table[r, 3]) for r in range(self.world)]
+    sz_tot = int(sum(sz_list))
+    N = int(table[:, 1].sum())
+    ncomp_mine = _unpack(sec.comp, cw, sec.sz)
+    id_base = int(table[:self.rank, 1].sum())
+    cc_mine = torch.empty(max(sxy * sec.sz, 1), dtype=torch.int32, device=dev)
+    nc_mine = be.components_device(vol, slab_shape, id_base, cc_mine)
+    if not np.array_equal(nc_mine.astype(np.int64), ncomp_mine):
+      raise RuntimeError("component counts of the slab stream and of the component pass differ")
+    rows = self._rows_of(sy)
+    y0, nrows = rows[self.rank]
+    lab_rows = self._to_row_slabs(vol.reshape(sec.sz, sy, sx), sz_list, rows)
+    cc_rows = self._to_row_slabs(cc_mine[:sxy * sec.sz].view(sec.sz, sy, sx), sz_list, rows)
+    mark("pins:transpose")
+    i64 = dict(dtype=torch.int64, device=dev)
+    first_any = torch.full((N,), -1, **i64)
+    first_kept = torch.full((N,), -1, **i64)
+    comp_label = torch.zeros(N, **i64)
+    if nrows:
+      be.pins_rows_first(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_any, first_kept, comp_label)
+    self._reduce(first_any, "min", True)
+    self._reduce(first_kept, "min", True)
+    self._reduce(comp_label, "max", True)
+    best = torch.zeros(N, **i64)
+    if nrows:
+      be.pins_rows_best(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_kept, best)
+    self._reduce(best, "max", False)
+    choice = torch.full((N,), -1, **i64)
+    ze = torch.zeros(N, dtype=torch.int32, device=dev)
+    if nrows:
+      be.pins_rows_extent(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_kept, best, choice, ze)
+    self._reduce(ze, "max", False)
+    if not nrows:      # (a rank without rows: the choice is a function of the reduced arrays alone)
+      choice = torch.where(best != 0, best - 1, torch.where(first_kept == -1, first_kept, first_kept >> 16))
+    counts = torch.where((choice != -1) & (ze > 0), ze.to(torch.int64) - (choice % sz_tot), torch.zeros_like(choice))
+    offsets = torch.zeros(N + 1, **i64)
+    torch.cumsum(counts, 0, out=offsets[1:])
+    total = int(offsets[-1].item())
+    budget = int(os.environ.get("CKL_PIN_IDS_BUDGET", str(1 << 26)))
+    if total > budget:      # volumes with long z-runs: the whole-volume stage makes the chosen pins distinct first
+      self._pins_rows_fallback = True
+      return None
+    ids = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
+    if nrows and total:
+      be.pins_rows_ids(cc_rows, sx, nrows, sz_tot, y0, N, choice, ze, offsets, ids)
+    self._reduce(ids, "sum", False)      # one rank holds each run: the others add zeros
+    mark("pins:passes")
+    # component counts of every slice
+    max_sz = max(max(sz_list), 1)
+    nc_pad = torch.zeros(max_sz, dtype=torch.int64, device=self.device)
+    nc_pad[:sec.sz] = torch.from_numpy(nc_mine.astype(np.int64)).to(self.device)
+    nc_every = [torch.empty_like(nc_pad) for _ in range(self.world)]
+    dist.all_gather(nc_every, nc_pad)
+    if self.rank != 0:
+      return np.zeros(0, np.uint8)
+    nc_all = np.concatenate([nc_every[r][:sz_list[r]].cpu().numpy() for r in range(self.world)]).astype(np.uint32)
+    section = be.pins_rows_section(sx, sy, sz_tot, N, nc_all, comp_label, first_any, choice, ze, offsets, ids, sw)
+    mark("pins:section")
+    return section
+
   def _collect_on_root(self, mine: torch.Tensor, counts):
     """Concatenates every rank's 1-D device tensor (counts[r] elements, rank order) in rank 0's
     device memory with point-to-point transfers: device to device when the process group carries
     device tensors (RCCL over xGMI), through host staging otherwise (gloo).  None off rank 0."""
+    import os
+    if os.environ.get("CKL_TEST_NO_COLLECT"):      # testing: the pin stage must not fall back to the collection on rank 0
+      raise RuntimeError("the whole volume was asked for on rank 0 (CKL_TEST_NO_COLLECT)")
     direct = self.device.type == mine.device.type
     # the unsigned 16 / 32 / 64-bit dtypes have no entry in the collective backends' type tables: the
     # labels travel as the signed type of the same width (bit patterns; the caller gets `mine`'s dtype back)
-    as_signed = {torch.uint16: torch.int16, torch.uint32: torch.int32, torch.uint64: torch.int64}
+    # (16-bit integers, which neither RCCL nor gloo carries, go as bytes)
+    as_signed = {torch.uint16: torch.uint8, torch.int16: torch.uint8, torch.uint32: torch.int32, torch.uint64: torch.int64}
     orig_dtype = mine.dtype
+    scale = 2 if orig_dtype in (torch.uint16, torch.int16) else 1
     if orig_dtype in as_signed:
       mine = mine.view(as_signed[orig_dtype])
+      counts = [c * scale for c in counts]
     if self.rank != 0:
       if counts[self.rank]:
         dist.send(mine.contiguous() if direct else mine.to(self.device), dst=0)

@@ -302,6 +302,35 @@ int ckl_encoder_pin_labels(
 	int stored_width, int auto_bgcolor, int64_t manual_bgcolor,
 	uint8_t** out, uint64_t* out_len);
 
+/* ---- the pin stage sharded by rows (BASELINE.json configs[4] on several GPUs) ----------------------------------
+ * pins::compute (src/pins.hpp:348-403) needs every (x, y) column over ALL slices (extract_columns, :95-163), so a
+ * z-slab cannot run it; a slab of ROWS can, because add_pin compares a run only with the label's last pin in the
+ * previous column of the same row (:134-160).  The sharded encoder transposes its z-slabs of labels and component ids
+ * into row slabs (all-to-all over xGMI) and every rank calls these on rows [y0, y0 + rows) of every slice (x fastest,
+ * then its rows, then z).  All arrays are DEVICE memory of n_components entries owned by the caller, who reduces them
+ * over its ranks between the calls: unsigned minimum for first_any / first_kept, unsigned maximum for comp_label,
+ * best, ze_plus1 and ids.  Keys name columns of the whole volume: (y * sx + x) * sz + z_start.
+ *   first   -> first_any (smallest key of a run starting in the component), first_kept (smallest key of a kept run
+ *              containing it, << 16 | its depth; all ones: none), comp_label (label of the components seen, else 0)
+ *   best    first_kept reduced -> best (1 + largest key of a kept run deeper than the first; 0: none)
+ *   extent  first_kept, best reduced -> choice (the run find_suboptimal_pins draws per component, :325-340; the same
+ *           on every rank) and ze_plus1 (its last slice + 1 where this rank holds its row, else 0)
+ *   ids     choice, ze_plus1 reduced, offsets (exclusive prefix of the runs' lengths, n_components + 1 entries) ->
+ *           ids (component ids along the runs of this rank's rows; the caller zeroes the array first)
+ *   section (one rank) the reduced arrays -> the pin label section (encode_condensed_pins, src/labels.hpp:192-344),
+ *           released with ckl_free.  ncomp_host: component count of every slice. */
+int ckl_pins_rows_first(ckl_encoder* e, const void* labels_rows, const uint32_t* cc_rows, int64_t sx, int64_t rows, int64_t sz, int64_t y0,
+	uint64_t n_components, uint64_t* first_any, uint64_t* first_kept, uint64_t* comp_label);
+int ckl_pins_rows_best(ckl_encoder* e, const void* labels_rows, const uint32_t* cc_rows, int64_t sx, int64_t rows, int64_t sz, int64_t y0,
+	uint64_t n_components, const uint64_t* first_kept, uint64_t* best);
+int ckl_pins_rows_extent(ckl_encoder* e, const void* labels_rows, const uint32_t* cc_rows, int64_t sx, int64_t rows, int64_t sz, int64_t y0,
+	uint64_t n_components, const uint64_t* first_kept, const uint64_t* best, uint64_t* choice, uint32_t* ze_plus1);
+int ckl_pins_rows_ids(ckl_encoder* e, const uint32_t* cc_rows, int64_t sx, int64_t rows, int64_t sz, int64_t y0,
+	uint64_t n_components, const uint64_t* choice, const uint32_t* ze_plus1, const uint64_t* offsets, uint32_t* ids);
+int ckl_pins_rows_section(ckl_encoder* e, int64_t sx, int64_t sy, int64_t sz, uint64_t n_components, const uint32_t* ncomp_host,
+	const uint64_t* comp_label, const uint64_t* first_any, const uint64_t* choice, const uint32_t* ze_plus1, const uint64_t* offsets, const uint32_t* ids,
+	int stored_width, int auto_bgcolor, int64_t manual_bgcolor, uint8_t** out, uint64_t* out_len);
+
 int ckl_encoder_last_timing(const ckl_encoder* e, float* pipeline_ms, float* dominant_kernel_ms);
 /* Which walk the last run's crack trail took (create_crack_codes, src/crackcodes.hpp:374-453): slices walked by
  * the hand-scheduled k_trail_walk loop / by the compiled one (slices with too many nodes or events for its

@@ -57,8 +57,12 @@ CASES = [
   ("voronoi", 0, False, "CKL_TEST_MERGE_FAIL"),  # the in-encode exchange fails on every rank: fallback
   ("u64", 0, False, None), ("u64", 5, False, "CKL_SHARDED_LEGACY"), ("u64", 5, True, None),      # BASELINE.json configs[3]: uint64 labels
   ("voronoi", 5, True, None), ("c4", 5, True, None), ("c4", 5, False, None),                       # configs[4]: pins + markov order 5, 2048 x 2048
+  # the pin stage sharded by rows (ckl_pins_rows_*): the whole volume must not be collected on rank 0 ...
+  ("voronoi", 0, True, "CKL_TEST_NO_COLLECT"), ("u64", 5, True, "CKL_TEST_NO_COLLECT"), ("c4", 5, True, "CKL_TEST_NO_COLLECT"),
+  # ... unless asked for, or when the chosen pins' id lists pass their budget (here: one entry)
+  ("voronoi", 5, True, "CKL_PINS_ON_ROOT"), ("voronoi", 0, True, "CKL_PIN_IDS_BUDGET"),
 ]
-ENVS = ("CKL_SHARDED_LEGACY", "CKL_TEST_MERGE_FAIL")
+ENVS = ("CKL_SHARDED_LEGACY", "CKL_TEST_MERGE_FAIL", "CKL_TEST_NO_COLLECT", "CKL_PINS_ON_ROOT", "CKL_PIN_IDS_BUDGET")
 
 
 def _worker(rank, port, q):
@@ -110,7 +114,7 @@ def sharded_results():
   results = {}
   failed = None
   for _ in range(WORLD * len(CASES)):
-    rank, index, binary, ok, err = q.get(timeout=600)
+    rank, index, binary, ok, err = q.get(timeout=300)
     results[(rank, index)] = (binary, ok, err)
     if err:
       failed = err
@@ -159,7 +163,10 @@ def _full_worker(rank, port, q):
       off = (1 << 40) if np.dtype(dt).itemsize == 8 else 0
       slab = synth.voronoi_labels((sx, sy, sz), dt, seed=2, device=dev, offset=off, z_range=(rank * szl, (rank + 1) * szl))
       codec = ckd.ShardedCodec(ckd.HipBackend(0, zero_copy=True), rank=rank, world=WORLD, device="cpu", compute_device=dev)
+      if pins:
+        os.environ["CKL_TEST_NO_COLLECT"] = "1"      # the pin stage works on rows: no rank may ask for the whole volume
       binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order, allow_pins=pins)
+      os.environ.pop("CKL_TEST_NO_COLLECT", None)
       digest = None if binary is None else (len(binary), hashlib.sha256(binary.view() if hasattr(binary, "view") else bytes(binary)).hexdigest())
       session = codec.open_decoder(binary, (sx, sy, szl))
       back = torch.empty_like(slab)
@@ -211,3 +218,66 @@ def test_sharded_full_size_configs_equal_the_single_process_stream():
       assert want == (xl[name]["length"], xl[name]["sha256"]), name
     assert results[(1, index)][0] is None
     assert results[(0, index)][1] and results[(1, index)][1], name
+
+
+# ---- the row-sharded pin stage over four ranks (rows and slices that do not divide evenly) ------------------------
+def _pins4_worker(rank, world, port, q):
+  import torch
+  from crackle_amd import distributed as ckd
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  os.environ["CKL_TEST_NO_COLLECT"] = "1"
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    dev = torch.device("cuda", 0)
+    out = []
+    for shape, dt, order, cell in (((190, 150, 12), np.uint32, 0, (16, 16, 4)), ((64, 3, 8), np.uint16, 2, (8, 2, 2)), ((130, 97, 20), np.uint64, 5, (16, 16, 4))):
+      sx, sy, sz = shape
+      szl = sz // world
+      off = (1 << 40) if np.dtype(dt).itemsize == 8 else 0
+      slab = synth.voronoi_labels(shape, dt, seed=77, device=dev, offset=off, cell=cell, z_range=(rank * szl, (rank + 1) * szl))
+      codec = ckd.ShardedCodec(ckd.HipBackend(0, zero_copy=True), rank=rank, world=world, device="cpu", compute_device=dev)
+      binary = codec.compress(slab, (sx, sy, szl), markov_model_order=order, allow_pins=True)
+      session = codec.open_decoder(binary, (sx, sy, szl))
+      back = torch.zeros_like(slab)
+      session.run(back)
+      torch.cuda.synchronize()
+      out.append((None if binary is None else bytes(binary), bool(torch.equal(back, slab))))
+      session.close()
+    q.put((rank, out))
+  except Exception as exc:      # the other ranks would wait in a collective for ever: the parent ends them
+    q.put((rank, repr(exc)))
+    raise
+  finally:
+    dist.destroy_process_group()
+
+
+def test_pin_stage_by_rows_over_four_ranks(checker):
+  """Four HIP ranks on the one GPU (gloo): 150 and 97 rows over four ranks (38 / 37 and 25 / 24), three rows
+  over four ranks (one rank holds none), uint64 labels; merged bytes against the reference's whole-volume stream."""
+  world = 4
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_pins4_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  got = {}
+  for _ in range(world):
+    rank, res = q.get(timeout=240)
+    if isinstance(res, str):
+      for p in procs:
+        p.terminate()
+      pytest.fail(f"rank {rank}: {res}")
+    got[rank] = res
+  for p in procs:
+    p.join(timeout=120)
+    assert p.exitcode == 0
+  cases = (((190, 150, 12), np.uint32, 0, (16, 16, 4)), ((64, 3, 8), np.uint16, 2, (8, 2, 2)), ((130, 97, 20), np.uint64, 5, (16, 16, 4)))
+  for i, (shape, dt, order, cell) in enumerate(cases):
+    off = (1 << 40) if np.dtype(dt).itemsize == 8 else 0
+    whole = synth.as_numpy_f(synth.voronoi_labels(shape, dt, seed=77, offset=off, cell=cell))
+    want = checker.compress(whole, markov_model_order=order, allow_pins=True)
+    assert got[0][i][0] == want, (shape, dt, order)
+    for r in range(world):
+      assert got[r][i][1], (r, shape)
