@@ -934,6 +934,11 @@ struct ckl_encoder {
 	// label planes left by ckl_encoder_stats for the ckl_encoder_run that follows on the same
 	// volume (the sharded encoder: stats -> all-gather -> run with the agreed formats)
 	const void* planes_for = nullptr;
+	// ckl_encoder_markov_stats leaves the whole trail behind (difference codes, chains, BOC index): the run that
+	// follows for the same volume and crack format only packs them under the agreed model (single use, like the planes)
+	const void* trail_for = nullptr;
+	bool trail_perm = false;
+	int trail_order = 0;
 	VolumeStats planes_stats;          // max / pairs of the volume the cached planes were built from
 	int64_t planes_dims[3] = { 0, 0, 0 };
 	std::vector<uint64_t> h_rbase;
@@ -1156,13 +1161,13 @@ void crack_pass(
 	ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, bool permissible,
 	int markov_order, bool hist_only, const std::vector<uint8_t>* model_in,
 	std::vector<uint32_t>* hist_out, std::vector<uint8_t>* model_out, CrackResult* result,
-	const std::function<void()>& overlap = std::function<void()>()
+	const std::function<void()>& overlap = std::function<void()>(), bool reuse_trail = false
 ) {
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
 	e.d_slice_err.ensure(ns);
-	CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
+	if (!reuse_trail) CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
 	// exact crack edge count per slice: interior pixel pairs that differ (or are equal)
 	const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
 
@@ -1247,7 +1252,7 @@ void crack_pass(
 	size_t trail_lds_used = 0;
 	DevBuf<unsigned long long> d_tdbg;
 	CKL_HIP(hipEventRecord(e.evk0, s));
-	{
+	if (!reuse_trail) {
 		// ---- the trail over the node graph (ckl_trail.hpp)
 		e.t_counters.ensure(7 * static_cast<size_t>(ns));
 		CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 7 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
@@ -1981,7 +1986,10 @@ void encode_typed(
 	const bool labels_first = getenv("CKL_NO_OVERLAP") || static_cast<uint64_t>(sx) * sy > (1536ull * 1536ull)
 		|| (getenv("CKL_LABELS_AT_WALK") && atoi(getenv("CKL_LABELS_AT_WALK")) == 0);
 	if (labels_first) flat_enqueue(e, sx, sy, sz);
-	graph_pass(e, sx, sy, sz, head.crack_format == PERMISSIBLE);
+	const bool trail_cached = planes_cached && ov && ov->has_model && head.markov_model_order > 0 && e.trail_for == static_cast<const void*>(labels)
+		&& e.trail_perm == (head.crack_format == PERMISSIBLE) && e.trail_order == head.markov_model_order && !getenv("CKL_NO_TRAIL_REUSE");
+	e.trail_for = nullptr;
+	if (!trail_cached) graph_pass(e, sx, sy, sz, head.crack_format == PERMISSIBLE);
 	ht.mark("graph");
 	if (!labels_first) {
 		uint32_t max_special = 0;
@@ -2081,10 +2089,10 @@ void encode_typed(
 	CrackResult cr;
 	std::vector<uint8_t> model, stored_model;
 	if (getenv("CKL_NO_OVERLAP")) {   // diagnostic: kernel timings without the two streams competing
-		crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr);
+		crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr, std::function<void()>(), trail_cached);
 		label_side();
 	}
-	else crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr, label_side);
+	else crack_pass(e, sx, sy, sz, permissible, head.markov_model_order, false, model_in, nullptr, &model, &cr, label_side, trail_cached);
 	ht.mark("cracks");
 	if (head.markov_model_order > 0) stored_model = markov_model_to_stored(model);
 
@@ -2483,8 +2491,10 @@ int ckl_encoder_markov_stats(
 			else if (e->dtype_bytes == 2) planes_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz, nullptr);
 			else if (e->dtype_bytes == 4) planes_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz, nullptr);
 			else planes_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz, nullptr);
+			e->trail_for = nullptr;
 			graph_pass(*e, sx, sy, sz, perm);
 			crack_pass(*e, sx, sy, sz, perm, order, true, nullptr, &h, nullptr, nullptr);
+			if (cached) { e->trail_for = labels_device; e->trail_perm = perm; e->trail_order = order; }      // (only beside cached planes: the run checks both)
 		}
 		memcpy(hist, h.data(), h.size() * sizeof(uint32_t));
 		return CKL_OK;
@@ -2750,7 +2760,7 @@ int ckl_encoder_walk_paths(ckl_encoder* e, uint32_t* fast_slices, uint32_t* comp
 			select_device(e->device);
 			std::vector<uint32_t> nev(ns);
 			CKL_HIP(hipMemcpy(nev.data(), e->t_counters.p + 5 * ns, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));      // n_events, flagged with the event format
-			for (uint32_t v : nev) { if (v & kEvFormatAddr12) fast++; else if (v) plain++; }
+			for (uint32_t v : nev) { if (v & (kEvFormatAddr12 | kEvWalkWide)) fast++; else if (v) plain++; }
 		}
 		if (fast_slices) *fast_slices = fast;
 		if (compiled_slices) *compiled_slices = plain;

@@ -743,6 +743,7 @@ struct TrailTabGlobal {
 constexpr uint32_t kEvSeg = 0u << 30, kEvBseg = 1u << 30, kEvDead = 2u << 30, kEvEnd = 3u << 30, kEvMask = 3u << 30;
 // n_events' top bit: the segment events of the slice carry 12 * node | edge instead of the dart 4 * node + edge
 constexpr uint32_t kEvFormatAddr12 = 1u << 31;
+constexpr uint32_t kEvWalkWide = 1u << 30;       // on a slice's event count: walked by trail_walk_chain_wide (events in the plain format; for ckl_encoder_walk_paths)
 
 // Runs in lane 0.  Branch stack: entry q in LDS slot q + 1 (slot 0 takes the stores of steps that
 // push nothing), entries beyond the LDS part in stack_node / stack_item.
@@ -972,6 +973,150 @@ __device__ __forceinline__ bool trail_walk_slice_fast(const TrailArgs& a, uint32
 	return true;
 }
 
+
+// The same walk for slices of up to 16 383 nodes (2048 x 2048 slices of C4: 13 k) on the COMPILED walk's LDS tables:
+// [four 16-bit dart ends (node << 2 | arrival edge): 8 bytes per node][remaining edges: 1 byte per node][branch
+// stack: 4 bytes per entry = event index << 14 | node].  12-byte records would not fit the LDS (16 k x 12 = 192 KiB);
+// here a node costs 9 bytes.  The step is the one of trail_walk_chain_fast plus a shift for the record address, a
+// second address register for the edge byte and a shift for the event word (node * 4 + edge, the plain format):
+// about 300 cycles against the compiled walk's 550.  s40 holds node * 8.  Needs fewer than 2^18 events.
+__device__ __forceinline__ uint32_t trail_walk_chain_wide(
+	uint32_t j_node, uint32_t& ev_off, uint32_t& ev_left, uint32_t adj_base, uint32_t stack_base, uint32_t max_depth, uint32_t* ev
+) {
+	uint32_t status, off = ev_off, left = ev_left;
+	const uint32_t top0 = stack_base - 4u;        // "top entry" of the empty stack: never used
+	const uint32_t ev_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ev)));
+	const uint32_t ev_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ev) >> 32));
+	const uint32_t j8 = __builtin_amdgcn_readfirstlane(j_node * 8u);
+	max_depth = __builtin_amdgcn_readfirstlane(max_depth);
+	adj_base = __builtin_amdgcn_readfirstlane(adj_base);
+	asm volatile(
+		"s_setprio 3\n"
+		"s_mov_b32 s40, %[j]\n"                     // node * 8
+		"s_mov_b32 s41, 0\n"                        // pend
+		"s_mov_b32 s42, 0\n"                        // stack depth
+		"v_readfirstlane_b32 s43, %[left]\n"
+		"s_mov_b32 s52, %[evlo]\n"
+		"s_mov_b32 s53, %[evhi]\n"
+		"s_mov_b32 s54, %[maxd]\n"
+		"s_mov_b32 s55, %[adjb]\n"
+		"v_mov_b32 v29, %[off]\n"
+		"v_mov_b32 v25, %[top]\n"
+		"1:\n"                                      // ---- a step
+		"s_lshr_b32 s51, s40, 3\n"                  // node
+		"v_mov_b32 v20, s40\n"
+		"s_add_u32 s50, s51, s55\n"
+		"ds_read_b64 v[32:33], v20\n"               // ends 0|1, 2|3
+		"v_mov_b32 v22, s50\n"
+		"ds_read_u8 v34, v22\n"                     // remaining edges
+		"ds_read_b32 v26, v25\n"                    // top of the branch stack
+		"s_sub_u32 s43, s43, 1\n"
+		"s_cbranch_scc1 8f\n"                       // no room for another event
+		"s_waitcnt lgkmcnt(0)\n"
+		"v_readfirstlane_b32 s46, v34\n"
+		"v_readfirstlane_b32 s44, v32\n"
+		"v_readfirstlane_b32 s45, v33\n"
+		"s_andn2_b32 s46, s46, s41\n"               // remaining edges without the one we came by
+		"s_cbranch_scc0 4f\n"
+		"s_ff1_i32_b32 s47, s46\n"                  // lowest-numbered edge: right, left, down, up
+		"s_bitset0_b32 s46, s47\n"
+		"v_mov_b32 v21, s46\n"
+		"ds_write_b8 v22, v21\n"
+		"s_lshl_b32 s48, s47, 4\n"
+		"s_lshr_b64 s[44:45], s[44:45], s48\n"      // the edge's end in the low 16 bits
+		"s_lshr_b32 s49, s40, 1\n"
+		"s_or_b32 s49, s49, s47\n"                  // node * 4 + edge
+		"s_cmp_eq_u32 s46, 0\n"
+		"s_cbranch_scc1 3f\n"
+		"s_cmp_ge_u32 s42, s54\n"                   // ---- more edges left: the node goes on the branch stack
+		"s_cbranch_scc1 9f\n"
+		"s_bitset1_b32 s49, 30\n"                   // kEvBseg
+		"v_add_u32 v25, 4, v25\n"
+		"v_lshl_or_b32 v28, v29, 12, s51\n"         // this event's index << 14 | node
+		"s_add_u32 s42, s42, 1\n"
+		"ds_write_b32 v25, v28\n"
+		"3:\n"
+		"v_mov_b32 v30, s49\n"
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"s_and_b32 s48, s44, 3\n"
+		"s_lshl_b32 s41, 1, s48\n"                  // the edge consumed at the far end
+		"s_and_b32 s40, s44, 0xfffc\n"
+		"s_lshl_b32 s40, s40, 1\n"                  // its node * 8
+		"s_branch 1b\n"
+		"4:\n"                                      // ---- dead end
+		"v_mov_b32 v21, 0\n"
+		"ds_write_b8 v22, v21\n"
+		"s_cmp_eq_u32 s42, 0\n"
+		"s_cbranch_scc1 7f\n"
+		"v_readfirstlane_b32 s49, v26\n"            // back to the most recent branch node
+		"s_and_b32 s40, s49, 0x3fff\n"
+		"s_lshl_b32 s40, s40, 3\n"
+		"s_lshr_b32 s49, s49, 14\n"
+		"s_bitset1_b32 s49, 31\n"                   // kEvDead | its kEvBseg
+		"v_mov_b32 v30, s49\n"
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"v_add_u32 v25, -4, v25\n"
+		"s_sub_u32 s42, s42, 1\n"
+		"s_mov_b32 s41, 0\n"
+		"s_branch 1b\n"
+		"7:\n"                                      // ---- the chain is complete
+		"v_mov_b32 v30, 0xc0000000\n"               // kEvEnd
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"s_mov_b32 s48, 0\n"
+		"s_branch 6f\n"
+		"8:\n"
+		"s_mov_b32 s43, 0\n"
+		"s_mov_b32 s48, 1\n"
+		"s_branch 6f\n"
+		"9:\n"
+		"s_mov_b32 s48, 2\n"
+		"6:\n"
+		"s_setprio 0\n"
+		"s_waitcnt lgkmcnt(0)\n"
+		"v_mov_b32 %[off], v29\n"
+		"v_mov_b32 %[left], s43\n"
+		"v_mov_b32 %[st], s48\n"
+		: [off] "+v"(off), [left] "+v"(left), [st] "=v"(status)
+		: [j] "s"(j8), [top] "v"(top0), [evlo] "s"(ev_lo), [evhi] "s"(ev_hi), [maxd] "s"(max_depth), [adjb] "s"(adj_base)
+		: "memory", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+		  "v20", "v21", "v22", "v25", "v26", "v28", "v29", "v30", "v32", "v33", "v34");
+	ev_off = __builtin_amdgcn_readfirstlane(off);
+	ev_left = __builtin_amdgcn_readfirstlane(left);
+	return __builtin_amdgcn_readfirstlane(status);
+}
+
+// The slice through trail_walk_chain_wide; false: the branch stack did not fit or the events outgrew 18 bits, nothing was kept.
+__device__ __forceinline__ bool trail_walk_slice_wide(const TrailArgs& a, uint32_t zi, uint32_t adj_base, uint32_t stack_base, uint32_t lds_bytes) {
+	const uint64_t nb = a.nbase[zi];
+	const uint32_t* starts = a.starts + nb;
+	const uint32_t n_starts = a.n_starts[zi];
+	uint32_t* ev = a.events + a.ibase[zi];
+	const uint32_t ecap = a.icap[zi];
+	uint32_t* ch_node = a.chain_node + a.kbase[zi];
+	uint32_t* ch_ev0 = a.chain_ev0 + a.kbase[zi];
+	const uint32_t kcap = a.kcap[zi];
+	const uint32_t* vert2node = a.vert2node + static_cast<uint64_t>(zi) * a.nverts;
+	const uint32_t max_depth = min((lds_bytes - stack_base) / 4u, a.walk_stack_cap);
+	uint32_t off = 0, left = min(ecap, 262143u), nch = 0, err = 0;
+	for (uint32_t si = 0; si < n_starts && !err; si++) {
+		const uint32_t sv = __builtin_amdgcn_readfirstlane(starts[si]);
+		const uint32_t j = __builtin_amdgcn_readfirstlane(vert2node[sv]);
+		if (nch < kcap) { ch_node[nch] = sv; ch_ev0[nch] = off >> 2; }
+		else err |= TRAIL_ERR_CAPACITY;
+		nch++;
+		const uint32_t st = trail_walk_chain_wide(j, off, left, adj_base, stack_base, max_depth, ev);
+		if (st == 2u || (st == 1u && ecap > 262143u)) return false;
+		if (st) err |= TRAIL_ERR_CAPACITY;
+	}
+	a.n_events[zi] = (off >> 2) | kEvWalkWide;
+	a.n_chains[zi] = nch < kcap ? nch : kcap;
+	if (err) atomicOr(a.slice_err + zi, err);
+	return true;
+}
+
 // grid = nslices, block = one wavefront; dynamic LDS = lds_bytes
 static __global__ void __launch_bounds__(kWave) k_trail_walk(TrailArgs a, uint32_t lds_bytes) {
 	extern __shared__ uint32_t s_trail[];
@@ -1013,12 +1158,24 @@ static __global__ void __launch_bounds__(kWave) k_trail_walk(TrailArgs a, uint32
 		t.end4 = reinterpret_cast<unsigned long long*>(s_trail);
 		t.adj = reinterpret_cast<uint8_t*>(s_trail) + nn * 8u;
 		uint16_t* e16 = reinterpret_cast<uint16_t*>(s_trail);
-		for (uint32_t d = threadIdx.x; d < nn * 4u; d += kWave) {
-			const uint32_t e = a.dart_end[nb * 4u + d];
-			e16[d] = static_cast<uint16_t>(e == kDartNone ? 0xFFFFu : e);
+		auto fill = [&]() {
+			for (uint32_t d = threadIdx.x; d < nn * 4u; d += kWave) {
+				const uint32_t e = a.dart_end[nb * 4u + d];
+				e16[d] = static_cast<uint16_t>(e == kDartNone ? 0xFFFFu : e);
+			}
+			for (uint32_t j = threadIdx.x; j < nn; j += kWave) t.adj[j] = a.node_adj[nb + j];
+			__syncthreads();
+		};
+		fill();
+		// the hand-scheduled loop on these tables (slices too large for the 12-byte records); it starts over with the
+		// compiled walk below when its branch stack (4 bytes per entry behind the tables) or its event index runs out
+		if (!a.walk_plain && tab_bytes + 2048u <= lds_bytes && __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s_trail))) == 0u) {
+			bool done = false;
+			if (threadIdx.x == 0) done = trail_walk_slice_wide(a, zi, nn * 8u, tab_bytes, lds_bytes);
+			if (__builtin_amdgcn_readfirstlane(done ? 1u : 0u)) return;
+			__syncthreads();
+			fill();      // the walk consumed the edge bytes
 		}
-		for (uint32_t j = threadIdx.x; j < nn; j += kWave) t.adj[j] = a.node_adj[nb + j];
-		__syncthreads();
 		if (threadIdx.x == 0) trail_walk_slice<TrailTabLds>(a, zi, t, reinterpret_cast<uint2*>(s_trail + tab_bytes / 4u), (lds_bytes - tab_bytes) / 8u);
 	}
 	else if (threadIdx.x == 0) {
@@ -1078,7 +1235,7 @@ static __global__ void __launch_bounds__(kItemsBlock) k_trail_items(TrailArgs a)
 		if (threadIdx.x == 0) a.n_items[zi] = 0;
 		return;
 	}
-	const uint32_t n = a.n_events[zi] & ~kEvFormatAddr12;
+	const uint32_t n = a.n_events[zi] & ~(kEvFormatAddr12 | kEvWalkWide);
 	const bool addr12 = (a.n_events[zi] & kEvFormatAddr12) != 0;
 	// the dart (4 * node + edge) of a segment event
 	auto dart = [&](uint32_t e) -> uint32_t {
