@@ -144,6 +144,50 @@ __device__ __forceinline__ void raster_record(
 	}
 }
 
+// The same for HALF a record — positions 8 h .. 8 h + 7 — without a branch per move: two lanes share a record, so
+// that a strip's ~250 records keep all 256 lanes busy for 8 steps instead of some of them for 16 (a strip with
+// more than 128 records paid a second round of 16 for a handful of them).  The half's start is the record's start
+// plus the displacement of the moves in front (four popcounts); a move that crosses no crack of this strip ORs a
+// zero into word 0 instead of being skipped (no exec-mask juggling in the unrolled body: 813 SALU instructions per
+// wavefront went with it).  `lds_h` / `lds_v`: the strip's plane pieces; rlo_h: first row whose upper crack lies in
+// the strip and inside the image (max(y0, 1)).
+__device__ __forceinline__ void raster_half_record(
+	const uint4 rec, uint32_t h, uint32_t y0, uint32_t y1, uint32_t rlo_h, uint32_t sx, uint32_t sy, uint32_t rw, uint32_t* lds_v, uint32_t* lds_h, uint32_t& bad
+) {
+	constexpr uint32_t kLo = 0x55555555u;
+	uint32_t p = rec.x;
+	uint32_t kinds = rec.y, flags = rec.z;
+	if (h) {
+		// displacement of positions 0 .. 7 (the emitting ones), and the jump when the record's 't' lies among them
+		const uint32_t ms = flags & kLo & 0xFFFFu, pv = kinds;
+		const uint32_t mR = ms & ~(pv >> 1) & pv, mL = ms & (pv >> 1) & pv, mD = ms & (pv >> 1) & ~pv, mU = ms & ~(pv >> 1) & ~pv;
+		p += __popc(mR) - __popc(mL) + ((__popc(mD) - __popc(mU)) << 16);
+		if (flags & 0xAAAAu) p += rec.w;
+		kinds >>= 16; flags >>= 16;
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < 8; k++) {
+		const uint32_t j = (flags >> (2u * k + 1u)) & 1u;
+		p += rec.w & (0u - j);
+		const uint32_t e = (flags >> (2u * k)) & 1u;
+		const uint32_t kind = (kinds >> (2u * k)) & 3u;
+		const uint32_t horiz = kind & 1u;
+		const uint32_t neg = ((kind ^ (kind >> 1)) & 1u) ^ 1u;      // up (0) and left (3)
+		const uint32_t unit = horiz ? 1u : 0x10000u;
+		const uint32_t d = ((unit ^ (0u - neg)) + neg) & (0u - e);
+		const uint32_t q = p + d;
+		const uint32_t c = p < q ? p : q;
+		const uint32_t col = c & 0xFFFFu, row = c >> 16;
+		bad |= ((q & 0xFFFFu) > sx || (q >> 16) > sy) ? 1u : 0u;
+		const uint32_t rlo = horiz ? rlo_h : y0, clo = horiz ? 0u : 1u;
+		const bool ok = e != 0u && (row - rlo) <= (y1 - 1u - rlo) && row >= rlo && (col - clo) <= (sx - 1u - clo) && col >= clo;
+		uint32_t* base = horiz ? lds_h : lds_v;
+		const uint32_t at = ok ? (row - y0) * rw + (col >> 5) : 0u;
+		atomicOr(base + at, ok ? (1u << (col & 31u)) : 0u);
+		p = q;
+	}
+}
+
 // grid = (nstrips, slices of the launch), block = kBlock.  The kernel waits on LDS round trips
 // (union-find), so what counts is the number of resident wavefronts: <= 72 registers and 22 KiB of
 // LDS keep seven workgroups on a CU.  (A persistent variant that fetched the next strip's words
@@ -199,13 +243,17 @@ __device__ __forceinline__ uint32_t strip_ccl_body(
 		uint32_t* sH = s_parent;
 		const uint32_t n_rec = min(rl.count[si], rl.cap);
 		const uint4* list = rl.rec + static_cast<uint64_t>(si) * rl.cap;
-		uint4 first = list[t < rl.cap ? t : 0u];      // requested with the count, not behind it
+		uint4 first = list[(t >> 1) < rl.cap ? (t >> 1) : 0u];      // requested with the count, not behind it
 #pragma unroll
 		for (uint32_t j = 0; j < 4; j++) { sV[t * 4u + j] = 0u; sH[t * 4u + j] = 0u; }
 		__syncthreads();
 		uint32_t bad = 0;
-		if (t < n_rec) raster_record(first, y0, y1 - y0, g.sx, g.sy, rw, sV, sH, bad);
-		for (uint32_t r = t + kBlock; r < n_rec; r += kBlock) raster_record(list[r], y0, y1 - y0, g.sx, g.sy, rw, sV, sH, bad);
+		{
+			// two lanes per record, eight positions each
+			const uint32_t half = t & 1u, rlo_h = y0 ? y0 : 1u;
+			if ((t >> 1) < n_rec) raster_half_record(first, half, y0, y1, rlo_h, g.sx, g.sy, rw, sV, sH, bad);
+			for (uint32_t r = (t >> 1) + kBlock / 2u; r < n_rec; r += kBlock / 2u) raster_half_record(list[r], half, y0, y1, rlo_h, g.sx, g.sy, rw, sV, sH, bad);
+		}
 		if (bad) atomicOr(sa.slice_err + zi, ERR_RANGE);
 		__syncthreads();
 		stamp(5);

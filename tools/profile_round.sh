@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex ckl --output-fo
 echo "write done"
 cd $root
 python3 tools/pmc_summary.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write "1024x1024x512 uint32 markov 0" gpurun_out/${tag}_pmc_traffic.json > gpurun_out/${tag}_pmc.txt
-cp gpurun_out/${tag}_pmc_traffic.json profiles/r03_pmc_traffic.json   # bench.py below reads roofline.traffic from it (same build: lib_sha16)
+cp gpurun_out/${tag}_pmc_traffic.json profiles/r04_pmc_traffic.json   # bench.py below reads roofline.traffic from it (same build: lib_sha16)
 # the raw traces are tens of MiB: keep the summaries only
 mkdir -p gpurun_out/${tag}
 find gpurun_out/${tag}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}/kernel_stats.csv \;
