@@ -223,10 +223,10 @@ struct RecArgs {
 template <bool GLOBAL>
 __device__ __forceinline__ void rec_markov_expand(
 	const uint8_t* s, uint32_t nbytes, int order, const uint8_t* model_g, uint32_t cap, uint32_t* upacked, uint32_t* lds, uint32_t* gscratch,
-	bool model_in_lds, uint32_t* s_scan, uint32_t* s_total, uint32_t* out2 /* codes, error bits */
+	bool model_in_lds, uint32_t* s_scan, uint32_t* s_total, uint32_t* out2 /* codes, error bits */, uint32_t lds_words
 ) {
 	uint32_t nc = 0, er = 0;
-	markov_expand_parallel<GLOBAL, kRecBlock>(s, nbytes, order, model_g, cap, upacked, lds, gscratch, model_in_lds, s_scan, s_total, nc, er);
+	markov_expand_parallel<GLOBAL, kRecBlock>(s, nbytes, order, model_g, cap, upacked, lds, gscratch, model_in_lds, s_scan, s_total, nc, er, lds_words);
 	if (threadIdx.x == 0) { out2[0] = nc; out2[1] = er; }
 }
 // one thread: the markov bitstream -> difference codes, 16 per word (markov.hpp:268-313); returns the codes, *err the error bits
@@ -430,8 +430,8 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 		const uint32_t mode = s_mk_parallel;
 		uint32_t* gsc = a.mkscratch ? a.mkscratch + a.mkbase[zi] : nullptr;
 		__shared__ uint32_t s_mk_out[2];
-		if (mode <= 2u) rec_markov_expand<false>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 2u, s_scan, &s_mk_total, s_mk_out);
-		else rec_markov_expand<true>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 4u, s_scan, &s_mk_total, s_mk_out);
+		if (mode <= 2u) rec_markov_expand<false>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 2u, s_scan, &s_mk_total, s_mk_out, ra.lds_bytes / 4u);
+		else rec_markov_expand<true>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 4u, s_scan, &s_mk_total, s_mk_out, ra.lds_bytes / 4u);
 		if (tid == 0) { s_ncodes = s_mk_out[0]; if (s_mk_out[1]) s_err |= s_mk_out[1]; }
 		__syncthreads();
 	}

@@ -709,7 +709,7 @@ template <bool GLOBAL, int BLOCK = kCrackBlock>
 __device__ __forceinline__ void markov_expand_parallel(
 	const uint8_t* __restrict__ s, uint32_t nbytes, int order, const uint8_t* __restrict__ model_g, uint32_t cap,
 	uint32_t* __restrict__ upacked, uint32_t* lds, uint32_t* gscratch, bool model_in_lds, uint32_t* s_scan, uint32_t* s_total,
-	uint32_t& ncodes_out, uint32_t& err_out
+	uint32_t& ncodes_out, uint32_t& err_out, uint32_t lds_words = 0
 ) {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t pay_words = (nbytes + 3u) / 4u + 2u;
@@ -809,8 +809,11 @@ __device__ __forceinline__ void markov_expand_parallel(
 			else { rank = st; st = 0u; }
 			if (rank != 4u && mine) {
 				if (cur < cap) {
-					if ((cur >> 4) != acc_w) { flush(false); acc_w = cur >> 4; acc = 0; }
-					acc |= rank << (2u * (cur & 15u));
+					if constexpr (GLOBAL) {
+						if ((cur >> 4) != acc_w) { flush(false); acc_w = cur >> 4; acc = 0; }
+						acc |= rank << (2u * (cur & 15u));
+					}
+					else atomicOr(ranks + (cur >> 4), rank << (2u * (cur & 15u)));      // in LDS an atomic per code is the cheaper form (C2, markov 5: 0.39 against 0.45 ms)
 				}
 				mine = false;
 			}
@@ -825,6 +828,22 @@ __device__ __forceinline__ void markov_expand_parallel(
 	if (n > cap) { n = cap; err_out |= ERR_CAPACITY; }
 	ncodes_out = n;
 
+	// GLOBAL: the ranks as they stand (2 bits per code that exists, not per code the slice's bytes could hold) often fit
+	// the LDS behind the model: the chunk decoders below then read them there instead of through a chain of ~60
+	// dependent L1-bypassing loads per pass (2048 x 2048 slices: 27 k words)
+	const uint32_t* ranks_src = ranks;
+	bool ranks_in_lds = false;
+	if (GLOBAL) {
+		uint32_t* stage = ctx_end + BLOCK;
+		const uint32_t used = static_cast<uint32_t>(stage - lds), need = (n >> 4) + 2u;
+		if (lds_words > used && need <= lds_words - used) {      // uniform
+			for (uint32_t w = tid; w < need; w += BLOCK) stage[w] = ldw(ranks + w);
+			__syncthreads();
+			ranks_src = stage;
+			ranks_in_lds = true;
+		}
+	}
+	auto ldr = [&](uint32_t w) -> uint32_t { return (GLOBAL && !ranks_in_lds) ? __hip_atomic_load(ranks_src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ranks_src[w]; };
 	// ---- 3. the context recurrence, speculatively per chunk
 	const int shift = 2 * (order - 1);
 	const uint32_t start = ldw(pay) & 3u;
@@ -838,7 +857,7 @@ __device__ __forceinline__ void markov_expand_parallel(
 		const uint32_t kfirst = max(k0, 1u);
 		uint32_t rw = 0;
 		for (uint32_t k = kfirst; k < k1; k++) {
-			if ((k & 15u) == 0u || k == kfirst) rw = ldw(ranks + (k >> 4));
+			if ((k & 15u) == 0u || k == kfirst) rw = ldr(k >> 4);
 			const uint32_t r = (rw >> (2u * (k & 15u))) & 3u;
 			const uint32_t v = (rows[ctx] >> (8u * r)) & 3u;
 			ctx = (ctx >> 2) + (v << shift);
@@ -856,7 +875,7 @@ __device__ __forceinline__ void markov_expand_parallel(
 			uint32_t ctx = kb == 1u ? (start << shift) : 0u;
 			uint32_t rw = 0;
 			for (uint32_t k = kb; k < k0; k++) {
-				if ((k & 15u) == 0u || k == kb) rw = ldw(ranks + (k >> 4));
+				if ((k & 15u) == 0u || k == kb) rw = ldr(k >> 4);
 				const uint32_t r = (rw >> (2u * (k & 15u))) & 3u;
 				const uint32_t v = (rows[ctx] >> (8u * r)) & 3u;
 				ctx = (ctx >> 2) + (v << shift);
@@ -1011,7 +1030,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 		const uint32_t mode = s_mk_parallel;
 		uint32_t* gsc = a.mkscratch ? a.mkscratch + a.mkbase[zi] : nullptr;
 		if (mode <= 2u) markov_expand_parallel<false>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 2u, s_scan, &s_mk_total, nc, er);
-		else markov_expand_parallel<true>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 4u, s_scan, &s_mk_total, nc, er);
+		else markov_expand_parallel<true>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 4u, s_scan, &s_mk_total, nc, er, a.lds_words);
 		if (tid == 0) { s_ncodes = nc; if (er) s_err |= er; }
 		__syncthreads();
 	}
