@@ -3342,6 +3342,7 @@ void decoder_vcg(ckl_decoder& d, uint8_t* out_device, uint64_t capacity, int con
 	DevBuf<uint8_t> labels;
 	if (six) {
 		// the z bits compare decoded labels: the whole pipeline runs into a scratch volume first
+		d.use_fused = false;      // (k_vcg reads the crack planes afterwards: the one-launch strip kernel leaves only their seam rows in HBM)
 		labels.ensure(need * h.data_width);
 		decoder_run(d, labels.p, need * h.data_width, 0, 0);
 	}
