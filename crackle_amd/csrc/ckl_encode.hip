@@ -16,6 +16,7 @@
 #include "ckl_pins_dev.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <functional>
 #include <memory>
@@ -333,19 +334,32 @@ __device__ __forceinline__ void put_le_dev(uint8_t* p, uint32_t v, int w) {
 constexpr int kFinishBlock = 1024;
 constexpr int kFinishWaves = kFinishBlock / kWave;
 
+// chains of a slice whose tables k_finish stages in LDS (a slice of the bench volume has ~100; noise has thousands)
+constexpr uint32_t kFinishChains = 2048;
+
 __global__ void __launch_bounds__(kFinishBlock) k_finish(FinishArgs a) {
 	__shared__ uint32_t s_scan[kFinishWaves];
+	// phase 1 is one thread's serial walk over the chains — an insertion sort and the BOC index, every step a
+	// dependent access — and in global memory each of those was a trip of a microsecond: a third of the kernel.  The
+	// chain tables are staged here (5 x 8 KiB; two workgroups share a CU) and phase 2 reads them back from here.
+	__shared__ uint32_t s_node[kFinishChains], s_clen[kFinishChains], s_off[kFinishChains], s_ord[kFinishChains], s_dst[kFinishChains], s_vst[kFinishChains];
 	const uint32_t zi = blockIdx.x + a.z0;
 	const int tid = threadIdx.x;
 	const uint32_t nch = a.n_chains[zi], nraw = a.n_raw[zi], nvalid = a.n_valid[zi];
 	const uint8_t* cp = a.cp + a.cbase[zi];
 	uint8_t* fcode = a.fcode + a.cbase[zi];
+	const bool staged = nch <= kFinishChains;      // uniform
 	const uint32_t* ch_node = a.chain_node + a.kbase[zi];
 	const uint32_t* ch_off = a.chain_off + a.kbase[zi];
 	const uint32_t* ch_clen = a.chain_clen + a.kbase[zi];
 	uint32_t* order = a.chain_order + a.kbase[zi];
 	uint32_t* dst = a.chain_dst + a.kbase[zi];
 	uint32_t* vstart = a.chain_vstart + a.kbase[zi];
+	if (staged) {
+		for (uint32_t c = tid; c < nch; c += kFinishBlock) { s_node[c] = ch_node[c]; s_clen[c] = ch_clen[c]; s_off[c] = ch_off[c]; }
+		__syncthreads();
+		ch_node = s_node; ch_off = s_off; ch_clen = s_clen; order = s_ord; dst = s_dst; vstart = s_vst;
+	}
 	const uint32_t sxe = a.sx + 1;
 
 	// ---- phase 1 (serial over chains): order by start vertex, output offsets, BOC index ----
@@ -405,12 +419,19 @@ __global__ void __launch_bounds__(kFinishBlock) k_finish(FinishArgs a) {
 		const uint32_t i0 = tile + tid * kPer;
 		uint32_t cnt = 0;
 		uint8_t c[kPer];
+		static_assert(kPer == 16, "one 16-byte load per thread");
+		if (i0 + kPer <= nraw) {      // (the slice's codes start 16-byte aligned: crack_pass rounds the capacities)
+			const uint4 v = *reinterpret_cast<const uint4*>(cp + i0);
+			const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-		for (uint32_t k = 0; k < kPer; k++) {
-			const uint32_t i = i0 + k;
-			c[k] = i < nraw ? cp[i] : CODE_TOMB;
-			cnt += (c[k] != CODE_TOMB);
+			for (uint32_t k = 0; k < kPer; k++) c[k] = static_cast<uint8_t>(w4[k >> 2] >> (8u * (k & 3u)));
 		}
+		else {
+#pragma unroll
+			for (uint32_t k = 0; k < kPer; k++) { const uint32_t i = i0 + k; c[k] = i < nraw ? cp[i] : CODE_TOMB; }
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < kPer; k++) cnt += (c[k] != CODE_TOMB);
 		uint32_t v[1] = { cnt }, tot[1];
 		block_excl_add<1, kFinishWaves>(v, tot, s_scan);
 		uint32_t g = carry + v[0];
@@ -455,7 +476,12 @@ __global__ void __launch_bounds__(kFinishBlock) k_finish(FinishArgs a) {
 		for (uint32_t w = tid; w < nwords; w += kFinishBlock) {
 			const uint32_t g0 = w * 16u;
 			uint8_t c[16];
-			if (g0 + 16u <= nvalid) memcpy(c, fcode + g0, 16);
+			if (g0 + 16u <= nvalid) {
+				const uint4 v = *reinterpret_cast<const uint4*>(fcode + g0);
+				const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+				for (uint32_t j = 0; j < 16; j++) c[j] = static_cast<uint8_t>(w4[j >> 2] >> (8u * (j & 3u)));
+			}
 			else {
 #pragma unroll
 				for (uint32_t j = 0; j < 16; j++) c[j] = g0 + j < nvalid ? fcode[g0 + j] : 0;
@@ -865,6 +891,32 @@ __global__ void __launch_bounds__(kBlock) k_gather_codes(
 	for (uint32_t i = threadIdx.x; i < np; i += kBlock) o[nb + i] = p[i];
 }
 
+// n bytes from src to dst, any alignment on either side: the device-resident copy of the assembled stream
+// (ckl_encoder_keep_device_stream) takes its two bulky sections from buffers of this session.  A device-to-device
+// hipMemcpyAsync moved the 13 MB of C2's crack codes at 115 GB/s (113 us on the encode's tail); this is a plain
+// streaming kernel.  Destination words are written aligned; a source word is two aligned loads and a funnel shift.
+// grid-stride, block = kBlock.
+__global__ void __launch_bounds__(kBlock) k_copy_bytes(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n) {
+	const uint64_t head = min(n, static_cast<uint64_t>((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));      // bytes in front of dst's first aligned word
+	const uint64_t words = (n - head) / 4u;
+	const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+	const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+	if (tid < head) dst[tid] = src[tid];
+	const uint64_t tail0 = head + words * 4u;
+	if (tid < n - tail0) dst[tail0 + tid] = src[tail0 + tid];
+	const uint8_t* s0 = src + head;
+	const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s0) & 3u) * 8u;
+	const uint32_t* sw = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(s0) & ~static_cast<uintptr_t>(3));
+	uint32_t* dw = reinterpret_cast<uint32_t*>(dst + head);
+	if (sh == 0u) {
+		for (uint64_t i = tid; i < words; i += stride) dw[i] = sw[i];
+	}
+	else {
+		// (the last word's second load reads the aligned word that holds the source's last bytes: inside the buffer)
+		for (uint64_t i = tid; i < words; i += stride) dw[i] = __funnelshift_r(sw[i], sw[i + 1], sh);
+	}
+}
+
 }  // namespace ckl
 
 // ------------------------------------------------------------------------------
@@ -872,6 +924,12 @@ __global__ void __launch_bounds__(kBlock) k_gather_codes(
 // ------------------------------------------------------------------------------
 using namespace ckl;
 
+// k_copy_bytes on stream s
+static void copy_bytes_device(const uint8_t* src, uint8_t* dst, uint64_t n, hipStream_t s) {
+	if (!n) return;
+	const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n / 4u + kBlock - 1) / kBlock + 1u, 8192u));
+	hipLaunchKernelGGL(k_copy_bytes, dim3(blocks), dim3(kBlock), 0, s, src, dst, n);
+}
 
 constexpr uint32_t kTrailStreams = 8;
 
@@ -921,6 +979,7 @@ struct ckl_encoder {
 	DevBuf<uint32_t> d_rcap, d_word_base, d_parent, d_run_start, d_run_cc, d_comp_pix, d_nruns, d_ncomp, d_idbits, d_blk_roots;
 	DevBuf<uint16_t> d_run_local;
 	DevBuf<uint32_t> d_G, d_crc_acc;
+	DevBuf<uint32_t> d_flat_report;     // [4][nslices]: ncomp | crc_acc | idbits | slice_err2 (views above)
 	uint64_t g_table_pixels = 0;                // slice size the G table was built for
 	DevBuf<uint64_t> d_mapping, d_sorted, d_uniq, d_label_hash, d_label_list;
 	DevBuf<uint8_t> d_keys;
@@ -1183,7 +1242,7 @@ void crack_pass(
 		const uint64_t differ = static_cast<uint64_t>(e.count_v[zi]) + e.count_h[zi];
 		const uint64_t E = permissible ? interior - differ : differ;
 		any = any || E > 0;
-		const uint64_t cc = 7 * E + 16;
+		const uint64_t cc = ((7 * E + 16 + 15) / 16) * 16;      // a multiple of 16: every slice's code arrays start 16-byte aligned (k_finish loads 16 codes at once)
 		if (cc > 0xFFFFFFF0ull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: slice has too many crack edges");
 		cbase[zi] = ctot; ccap[zi] = static_cast<uint32_t>(cc); ctot += cc;
 		max_steps[zi] = static_cast<uint32_t>(E + 1);
@@ -1378,6 +1437,19 @@ void crack_pass(
 		fprintf(stderr, "[ckl trail diag, mean per slice] degree-1/3/4 vertices=%.0f corners=%.0f nodes=%.0f starts=%.0f items=%.0f\n", sp, co, m[0], m[3], m[4]);
 	}
 
+	// without a markov model nothing stands between k_finish and the final offsets + gather: they are enqueued before the
+	// label side takes the host thread (it is host-synchronous and ends after the trail: the trail's queue used to idle
+	// 0.2 ms until the host came back to launch them)
+	const bool early_tail = !markov_order && result != nullptr;
+	auto enqueue_tail = [&]() {
+		e.d_out_off.ensure(ns);
+		e.d_code_report.ensure(static_cast<size_t>(ns) + 3);
+		e.d_codes_out.ensure(e.codes_capacity + 8);
+		hipLaunchKernelGGL(k_code_offsets, dim3(1), dim3(kBlock), 0, s, e.d_boc_len.p, e.d_payload_len.p, e.d_slice_err.p, ns, e.d_out_off.p, e.d_code_report.p);
+		hipLaunchKernelGGL(k_gather_codes, dim3(ns), dim3(kBlock), 0, s, e.d_boc.p, e.d_bbase.p, e.d_boc_len.p,
+			e.d_payload.p, e.d_pbase.p, e.d_payload_len.p, e.d_out_off.p, e.d_codes_out.p);
+	};
+	if (early_tail) enqueue_tail();
 	// the label side (other stream, host-synchronous) runs while the trail kernels execute
 	if (overlap) overlap();
 	HT_MARK("c:overlap");
@@ -1413,12 +1485,7 @@ void crack_pass(
 
 	// final offsets on the device, the gather behind them, one small report back (lengths for the
 	// z-index, total, error bits): a single wait before the codes are copied out
-	e.d_out_off.ensure(ns);
-	e.d_code_report.ensure(static_cast<size_t>(ns) + 3);
-	e.d_codes_out.ensure(e.codes_capacity + 8);
-	hipLaunchKernelGGL(k_code_offsets, dim3(1), dim3(kBlock), 0, s, e.d_boc_len.p, e.d_payload_len.p, e.d_slice_err.p, ns, e.d_out_off.p, e.d_code_report.p);
-	hipLaunchKernelGGL(k_gather_codes, dim3(ns), dim3(kBlock), 0, s, e.d_boc.p, e.d_bbase.p, e.d_boc_len.p,
-		e.d_payload.p, e.d_pbase.p, e.d_payload_len.p, e.d_out_off.p, e.d_codes_out.p);
+	if (!early_tail) enqueue_tail();
 	HT_MARK("c:finish_enq");
 	std::vector<uint32_t> report = download(e.d_code_report.p, static_cast<size_t>(ns) + 3, s);
 	HT_MARK("c:finish_wait");
@@ -1489,8 +1556,12 @@ void flat_enqueue(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz) {
 	upload(e.d_rbase, rbase, s); upload(e.d_rcap, rcap, s);
 	e.d_word_base.ensure(e.plane_words * ns);
 	e.d_parent.ensure(rtot); e.d_run_start.ensure(rtot); e.d_run_cc.ensure(rtot); e.d_comp_pix.ensure(rtot);
-	e.d_nruns.ensure(ns); e.d_ncomp.ensure(ns); e.d_idbits.ensure(ns); e.d_crc_acc.ensure(ns);
-	e.d_slice_err2.ensure(ns);
+	// component counts, crc accumulators, id widths and error words of the slices lie side by side: flat_collect brings
+	// them back in ONE transfer (four separate round trips cost the label path 0.2 ms, and it is what the encode ends with)
+	e.d_nruns.ensure(ns);
+	e.d_flat_report.ensure(4 * static_cast<size_t>(ns));
+	e.d_ncomp.borrow(e.d_flat_report.p, ns); e.d_crc_acc.borrow(e.d_flat_report.p + ns, ns);
+	e.d_idbits.borrow(e.d_flat_report.p + 2 * static_cast<size_t>(ns), ns); e.d_slice_err2.borrow(e.d_flat_report.p + 3 * static_cast<size_t>(ns), ns);
 	CKL_HIP(hipMemsetAsync(e.d_slice_err2.p, 0, ns * sizeof(uint32_t), s));
 
 	RunGeom g;
@@ -1520,11 +1591,22 @@ void flat_collect(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, i
 	hipStream_t s = e.stream2;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
-	out.ncomp = download(e.d_ncomp.p, ns, s);
-	HT_MARK("f:wait");
-	std::vector<uint32_t> acc = download(e.d_crc_acc.p, ns, s);
-	std::vector<uint32_t> idbits = download(e.d_idbits.p, ns, s);
-	std::vector<uint32_t> errs = download(e.d_slice_err2.p, ns, s);
+	std::vector<uint32_t> acc, idbits, errs;
+	if (e.d_ncomp.p == e.d_flat_report.p && e.d_flat_report.p) {      // laid out by flat_enqueue: one transfer
+		const std::vector<uint32_t> rep = download(e.d_flat_report.p, 4 * static_cast<size_t>(ns), s);
+		out.ncomp.assign(rep.begin(), rep.begin() + ns);
+		acc.assign(rep.begin() + ns, rep.begin() + 2 * static_cast<size_t>(ns));
+		idbits.assign(rep.begin() + 2 * static_cast<size_t>(ns), rep.begin() + 3 * static_cast<size_t>(ns));
+		errs.assign(rep.begin() + 3 * static_cast<size_t>(ns), rep.end());
+		HT_MARK("f:wait");
+	}
+	else {
+		out.ncomp = download(e.d_ncomp.p, ns, s);
+		HT_MARK("f:wait");
+		acc = download(e.d_crc_acc.p, ns, s);
+		idbits = download(e.d_idbits.p, ns, s);
+		errs = download(e.d_slice_err2.p, ns, s);
+	}
 	for (uint32_t zi = 0; zi < ns; zi++) if (errs[zi]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: run table overflow on z=" + std::to_string(zi));
 	const uint32_t init_term = gf_mul(0xFFFFFFFFu, gf_xpow(32ull * sxy));
 	out.crcs.resize(ns);
@@ -2111,19 +2193,6 @@ void encode_typed(
 	}
 	try {
 		e.last_codes_total = cr.total;
-		if (cr.total && !e.defer_codes) {
-			if (e.async_host_copy && e.keep_device_stream) {
-				// the caller goes on with the stream in HBM (a decoder, the next volume's planes) while the codes
-				// cross PCIe: ckl_encoder_host_wait before the host bytes are read
-				if (!e.stream_copy) CKL_HIP(hipStreamCreateWithFlags(&e.stream_copy, hipStreamNonBlocking));
-				if (!e.ev_codes) CKL_HIP(hipEventCreateWithFlags(&e.ev_codes, hipEventDisableTiming));
-				CKL_HIP(hipEventRecord(e.ev_codes, s));
-				CKL_HIP(hipStreamWaitEvent(e.stream_copy, e.ev_codes, 0));
-				CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, e.stream_copy));
-				e.host_copy_pending = true;
-			}
-			else CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
-		}
 		if (head.label_format == PINS_VARIABLE_WIDTH) {
 			if (label_bytes) memcpy(o + off_labels, pins_binary.data(), label_bytes);
 			labels_crc = crc32c(o + off_labels, label_bytes);
@@ -2146,13 +2215,28 @@ void encode_typed(
 			uint8_t* ds = e.d_stream_out.p;
 			CKL_HIP(hipMemcpyAsync(ds, o, off_labels, hipMemcpyHostToDevice, s));
 			if (label_bytes) {
-				if (head.label_format == FLAT) CKL_HIP(hipMemcpyAsync(ds + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToDevice, s));
+				if (head.label_format == FLAT) copy_bytes_device(e.d_labels_bin.p, ds + off_labels, label_bytes, s);
 				else CKL_HIP(hipMemcpyAsync(ds + off_labels, o + off_labels, label_bytes, hipMemcpyHostToDevice, s));
 			}
 			if (!stored_model.empty()) CKL_HIP(hipMemcpyAsync(ds + off_model, o + off_model, stored_model.size(), hipMemcpyHostToDevice, s));
-			if (cr.total) CKL_HIP(hipMemcpyAsync(ds + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToDevice, s));
+			if (cr.total) copy_bytes_device(e.d_codes_out.p, ds + off_codes, cr.total, s);
 			CKL_HIP(hipMemcpyAsync(ds + off_tail, o + off_tail, 4ull * (sz + 1), hipMemcpyHostToDevice, s));
 			e.device_stream_bytes = total;
+		}
+		// the crack codes' copy to the host goes LAST: started first, its 13 MB kept the link busy and the 2 KB header
+		// upload above waited 0.19 ms behind it (rocprofv3 timeline, round 4)
+		if (cr.total && !e.defer_codes) {
+			if (e.async_host_copy && e.keep_device_stream) {
+				// the caller goes on with the stream in HBM (a decoder, the next volume's planes) while the codes
+				// cross PCIe: ckl_encoder_host_wait before the host bytes are read
+				if (!e.stream_copy) CKL_HIP(hipStreamCreateWithFlags(&e.stream_copy, hipStreamNonBlocking));
+				if (!e.ev_codes) CKL_HIP(hipEventCreateWithFlags(&e.ev_codes, hipEventDisableTiming));
+				CKL_HIP(hipEventRecord(e.ev_codes, s));
+				CKL_HIP(hipStreamWaitEvent(e.stream_copy, e.ev_codes, 0));
+				CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, e.stream_copy));
+				e.host_copy_pending = true;
+			}
+			else CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
 		}
 		ht.mark("assembly");
 		CKL_HIP(hipEventRecord(e.ev1, s));
