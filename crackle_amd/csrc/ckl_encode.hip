@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kBlock) k_label_planes_fast(
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t task = blockIdx.x * kWaves + wave;
 	uint32_t nv = 0, nh = 0, pairs = 0;
-	unsigned long long mx = 0;
+	LABEL mxl = 0;      // (in the label's own width: a 64-bit compare + select per pixel was a tenth of the kernel's VALU work)
 	if (task < strips * bands) {
 		const uint32_t band = task / strips, strip = task - band * strips;
 		const uint32_t x = strip * (64u * P) + lane * P;
@@ -194,16 +194,19 @@ __global__ void __launch_bounds__(kBlock) k_label_planes_fast(
 				if (lane == 0) { left = edges[r]; have_left = have_edges[r]; }
 				uint32_t bv = 0, bh = 0;
 				if (active) {
+					// bit i: pixel i differs from its left / upper neighbour; the border cases (no left neighbour at
+					// the volume's first voxel, x == 0, y == 0) are masked once per row instead of tested per pixel
 #pragma unroll
 					for (uint32_t i = 0; i < P; i++) {
 						const LABEL l = i ? cur.v[i - 1] : left;
-						const bool differs = cur.v[i] != l;
-						const bool counted = i ? true : have_left;
-						pairs += (counted && !differs) ? 1u : 0u;
-						bv |= ((differs && (x + i) > 0) ? 1u : 0u) << i;
-						bh |= ((y > 0 && cur.v[i] != prev.v[i]) ? 1u : 0u) << i;
-						mx = static_cast<unsigned long long>(cur.v[i]) > mx ? static_cast<unsigned long long>(cur.v[i]) : mx;
+						bv |= (cur.v[i] != l ? 1u : 0u) << i;
+						bh |= (cur.v[i] != prev.v[i] ? 1u : 0u) << i;
+						mxl = cur.v[i] > mxl ? cur.v[i] : mxl;
 					}
+					// lib::pixel_pairs counts equal LINEAR neighbours (lib.hpp:249-256): every pixel but the volume's first has one
+					pairs += P - __popc(bv) - ((have_left || (bv & 1u)) ? 0u : 1u);
+					if (x == 0) bv &= ~1u;      // no crack along the image's left border
+					if (y == 0) bh = 0u;
 				}
 				nv += __popc(bv); nh += __popc(bh);
 				bv <<= (lane % G) * P; bh <<= (lane % G) * P;
@@ -221,6 +224,7 @@ __global__ void __launch_bounds__(kBlock) k_label_planes_fast(
 		}
 	}
 	nv = wave_sum(nv); nh = wave_sum(nh); pairs = wave_sum(pairs);
+	unsigned long long mx = static_cast<unsigned long long>(mxl);
 	for (int d = kWave / 2; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d, kWave); mx = o > mx ? o : mx; }
 	if (lane == 0) { s_red[wave] = nv; s_red[kWaves + wave] = nh; s_red[2 * kWaves + wave] = pairs; s_max[wave] = mx; }
 	__syncthreads();
