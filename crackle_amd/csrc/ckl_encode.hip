@@ -947,6 +947,7 @@ struct ckl_encoder {
 	hipEvent_t evd0 = nullptr, evd1 = nullptr;      // around k_trail_walk (first slice group)
 	float trail_ms = 0.f;
 	hipStream_t trail_stream[kTrailStreams] = {};     // slice groups of the crack trail
+	hipEvent_t ev_prezero = nullptr;   // trail_prezero()'s fills on stream2 are done
 	hipEvent_t ev_fork = nullptr, ev_join[kTrailStreams] = {}, ev_pre[kTrailStreams] = {};      // ev_pre[g]: group g's kernels in front of its walk are done
 	float pipeline_ms = 0.f, dominant_ms = 0.f;
 	int64_t max_sx = 0, max_sy = 0, max_sz = 0;
@@ -1014,6 +1015,7 @@ struct ckl_encoder {
 	uint32_t tiles_x = 0, tiles_y = 0, mtx2 = 0;
 	uint64_t adjm_stride = 0;
 	bool graph_permissible = false;
+	bool trail_zeroed = false;         // trail_prezero() ran on the stream since the last trail: crack_pass skips its fills
 	DevBuf<uint64_t> t_nbase, t_cobase, t_ibase;
 	DevBuf<uint32_t> t_ncap, t_cocap, t_icap, t_max_steps;
 	size_t last_trail_slices = 0;                // slices of the last crack pass (the layout of t_counters)
@@ -1035,6 +1037,7 @@ struct ckl_encoder {
 		if (evd1) (void)hipEventDestroy(evd1);
 		if (ev_in) (void)hipEventDestroy(ev_in);
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
+		if (ev_prezero) (void)hipEventDestroy(ev_prezero);
 		for (auto& ev : ev_join) if (ev) (void)hipEventDestroy(ev);
 		for (auto& ev : ev_pre) if (ev) (void)hipEventDestroy(ev);
 		for (auto& st : trail_stream) if (st) (void)hipStreamDestroy(st);
@@ -1134,10 +1137,29 @@ VolumeStats volume_stats(ckl_encoder& e, const LABEL* labels, uint64_t voxels);
 // One pass over the labels -> the two "differs from neighbour" bit planes and their
 // per-slice population counts (exact crack edge and run counts follow from these) and,
 // on the fast path, the whole-volume reductions of lib.hpp:224-256 from the same read.
+// The trail's zero fills (slice errors, counters, chain start bits) depend on the dimensions only.  On the
+// label stream, which is idle until the walk, they run beside the planes kernel instead of between the node
+// counts and k_trail_nodes (3 fills, 25 us + their launch gaps at C2).  crack_pass waits for ev_prezero.
+void trail_prezero(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz) {
+	hipStream_t s = e.stream2;
+	const uint32_t ns = static_cast<uint32_t>(sz);
+	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
+	const uint32_t start_words = static_cast<uint32_t>((nverts + 31) / 32);
+	e.d_slice_err.ensure(ns);
+	e.t_counters.ensure(7 * static_cast<size_t>(ns));
+	e.t_start_bits.ensure(static_cast<size_t>(start_words) * ns);
+	CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
+	CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 7 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
+	CKL_HIP(hipMemsetAsync(e.t_start_bits.p, 0, static_cast<size_t>(start_words) * ns * sizeof(uint32_t), s));
+	CKL_HIP(hipEventRecord(e.ev_prezero, s));
+	e.trail_zeroed = true;
+}
+
 template <typename LABEL>
 void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, VolumeStats* st) {
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
+	e.trail_zeroed = false;
 	e.row_words = static_cast<uint32_t>((sx + 31) / 32);
 	e.plane_words = static_cast<uint64_t>(e.row_words) * sy;
 	e.d_planes.ensure(2 * e.plane_words * ns);
@@ -1150,6 +1172,7 @@ void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, in
 		e.d_plane_partial.ensure(4ull * nblk * ns);
 		e.d_plane_partial_max.ensure(static_cast<size_t>(nblk) * ns);
 		e.d_plane_out.ensure(4ull * ns);
+		if (!getenv("CKL_NO_PREZERO")) trail_prezero(e, sx, sy, sz);
 		hipLaunchKernelGGL(k_label_planes_fast<LABEL>, dim3(nblk, ns), dim3(kBlock), 0, s,
 			labels, static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), strips, bands,
 			e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
@@ -1230,7 +1253,10 @@ void crack_pass(
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	const uint64_t nverts = static_cast<uint64_t>(sx + 1) * (sy + 1);
 	e.d_slice_err.ensure(ns);
-	if (!reuse_trail) CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
+	const bool prezeroed = e.trail_zeroed && !reuse_trail;
+	e.trail_zeroed = false;
+	if (prezeroed) CKL_HIP(hipStreamWaitEvent(s, e.ev_prezero, 0));
+	if (!reuse_trail && !prezeroed) CKL_HIP(hipMemsetAsync(e.d_slice_err.p, 0, ns * sizeof(uint32_t), s));
 	// exact crack edge count per slice: interior pixel pairs that differ (or are equal)
 	const uint64_t interior = static_cast<uint64_t>(sx > 0 ? sx - 1 : 0) * sy + static_cast<uint64_t>(sx) * (sy > 0 ? sy - 1 : 0);
 
@@ -1266,6 +1292,7 @@ void crack_pass(
 		max_special = std::max<uint32_t>(max_special, e.count_special[zi]);
 	}
 	if (result) result->any_chain = any;
+	HT_MARK("c:caps");
 	UploadPacker tables;
 	tables.add(e.d_cbase, cbase); tables.add(e.d_ccap, ccap);
 	tables.add(e.d_sbase, sbase); tables.add(e.d_scap, scap);
@@ -1296,6 +1323,7 @@ void crack_pass(
 	tables.add(e.t_ibase, ibase); tables.add(e.t_icap, icap);
 	tables.add(e.t_max_steps, max_steps);
 	tables.commit(e.d_crack_tables, s);
+	HT_MARK("c:tables");
 	e.d_payload.ensure(ptot + 8); e.d_boc.ensure(btot + 8);
 	e.codes_capacity = ptot + btot;
 	if (markov_order) CKL_HIP(hipMemsetAsync(e.d_payload.p, 0, ptot + 8, s));
@@ -1318,7 +1346,7 @@ void crack_pass(
 	if (!reuse_trail) {
 		// ---- the trail over the node graph (ckl_trail.hpp)
 		e.t_counters.ensure(7 * static_cast<size_t>(ns));
-		CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 7 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
+		if (!prezeroed) CKL_HIP(hipMemsetAsync(e.t_counters.p, 0, 7 * static_cast<size_t>(ns) * sizeof(uint32_t), s));
 		e.t_node_vertex.ensure(ntot); e.t_node_adj.ensure(ntot + 16); e.t_vert2node.ensure(nverts * ns);
 		e.t_corner_vertex.ensure(cotot);
 		e.t_dart_end.ensure(4 * ntot); e.t_dart_len.ensure(4 * ntot); e.t_dart_minv.ensure(4 * ntot); e.t_dart_minpos.ensure(4 * ntot);
@@ -1326,7 +1354,7 @@ void crack_pass(
 		e.t_parent.ensure(ntot); e.t_compmin.ensure(ntot); e.t_starts.ensure(ntot);
 		const uint32_t start_words = static_cast<uint32_t>((nverts + 31) / 32);
 		e.t_start_bits.ensure(static_cast<size_t>(start_words) * ns);
-		CKL_HIP(hipMemsetAsync(e.t_start_bits.p, 0, static_cast<size_t>(start_words) * ns * sizeof(uint32_t), s));
+		if (!prezeroed) CKL_HIP(hipMemsetAsync(e.t_start_bits.p, 0, static_cast<size_t>(start_words) * ns * sizeof(uint32_t), s));
 		e.t_items.ensure(itot); e.t_item_off.ensure(itot); e.t_chain_item0.ensure(ktot);
 		e.t_events.ensure(itot); e.t_chain_ev0.ensure(ktot); e.t_ev_lnd.ensure(itot); e.t_ev_item.ensure(itot);
 
@@ -1375,6 +1403,7 @@ void crack_pass(
 		lds = (lds / 16) * 16;
 		CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trail_walk), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
 		trail_lds_used = lds;
+		HT_MARK("c:setup");
 
 		// The serial k_trail_walk keeps 1 wavefront per slice busy for ~1 ms while the chip idles.
 		// Slices can be processed in groups on their own streams (CKL_TRAIL_GROUPS): while one
@@ -2015,6 +2044,7 @@ void encode_typed(
 	HostTimer ht;
 	g_ht = &ht;
 	VolumeStats st;
+	e.trail_zeroed = false;
 	const bool planes_cached = ov && voxels > 0 && e.planes_for == static_cast<const void*>(labels)
 		&& e.planes_dims[0] == sx && e.planes_dims[1] == sy && e.planes_dims[2] == sz;
 	e.planes_for = nullptr;       // single use: the caller may change the volume afterwards
@@ -2402,6 +2432,7 @@ int ckl_encoder_create(int64_t sx, int64_t sy, int64_t sz, int dtype_bytes, int 
 		CKL_HIP(hipEventCreate(&e->evd1));
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
 		CKL_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+		CKL_HIP(hipEventCreateWithFlags(&e->ev_prezero, hipEventDisableTiming));
 		for (auto& ev : e->ev_join) CKL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		for (auto& ev : e->ev_pre) CKL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		*out = e.release();

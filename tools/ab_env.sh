@@ -9,7 +9,8 @@ for r in $(seq 1 $reps); do
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 st = d["roofline"]["decode_stage_ms"]
-print(f"{sys.argv[1]:40s} GVx/s={d['value']/1e9:6.2f} enc={d['encode_ms']:.3f} dec={d['decode_ms']:.3f} dfs={d['encode_dfs_kernel_ms']:.3f} ok={d['roundtrip_ok']} strips={st['k_run_union_strips']:.3f} cracks={st['k_decode_cracks']:.3f}", flush=True)
+stages = " ".join(f"{k}={v:.3f}" for k, v in st.items())
+print(f"{sys.argv[1]:40s} GVx/s={d['value']/1e9:6.2f} enc={d['encode_ms']:.3f} dec={d['decode_ms']:.3f} dfs={d['encode_dfs_kernel_ms']:.3f} ok={d['roundtrip_ok']} {stages}", flush=True)
 PY
     i=$((i+1))
   done
