@@ -137,8 +137,10 @@ template <typename LABEL>
 __global__ void __launch_bounds__(kBlock) k_label_planes_fast(
 	const LABEL* __restrict__ labels, uint32_t sx, uint32_t sy, uint32_t strips, uint32_t bands,
 	uint32_t* __restrict__ planeV, uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
-	uint32_t* __restrict__ partial /* [nslices][gridDim.x][4]: nv, nh, pairs, - */, unsigned long long* __restrict__ partial_max
+	uint32_t* __restrict__ partial /* [nslices][gridDim.x][4]: nv, nh, pairs, - */, unsigned long long* __restrict__ partial_max,
+	unsigned long long* __restrict__ total_pairs /* zeroed here, summed by k_planes_reduce behind this kernel */
 ) {
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *total_pairs = 0;
 	constexpr uint32_t P = 16 / sizeof(LABEL);        // pixels per lane
 	constexpr uint32_t G = 32 / P;                    // lanes per plane word
 	struct alignas(16) Vec { LABEL v[P]; };
@@ -274,7 +276,8 @@ __global__ void __launch_bounds__(kBlock) k_planes_from_cracks(
 // grid = nslices: folds the per-workgroup partials of one slice
 __global__ void __launch_bounds__(kBlock) k_planes_reduce(
 	const uint32_t* __restrict__ partial, const unsigned long long* __restrict__ partial_max, uint32_t nblk,
-	unsigned long long* __restrict__ out /* [nslices][4]: count_v, count_h, pairs, max */
+	unsigned long long* __restrict__ out /* [nslices][4]: count_v, count_h, pairs, max */,
+	unsigned long long* __restrict__ total_pairs /* the volume's equal pixel pairs: k_trail_graph decides the crack format from it */
 ) {
 	__shared__ uint32_t s_red[kWaves];
 	__shared__ unsigned long long s_max[kWaves];
@@ -294,6 +297,7 @@ __global__ void __launch_bounds__(kBlock) k_planes_reduce(
 	if (threadIdx.x == 0) {
 		for (int w = 0; w < kWaves; w++) tm = s_max[w] > tm ? s_max[w] : tm;
 		out[4ull * zi + 0] = tv; out[4ull * zi + 1] = th; out[4ull * zi + 2] = tp; out[4ull * zi + 3] = tm;
+		atomicAdd(total_pairs, static_cast<unsigned long long>(tp));
 	}
 }
 
@@ -1015,6 +1019,7 @@ struct ckl_encoder {
 	uint32_t tiles_x = 0, tiles_y = 0, mtx2 = 0;
 	uint64_t adjm_stride = 0;
 	bool graph_permissible = false;
+	bool planes_deferred = false;      // planes_pass left its counts on the device: graph_pass (or planes_collect) fetches them
 	bool trail_zeroed = false;         // trail_prezero() ran on the stream since the last trail: crack_pass skips its fills
 	DevBuf<uint64_t> t_nbase, t_cobase, t_ibase;
 	DevBuf<uint32_t> t_ncap, t_cocap, t_icap, t_max_steps;
@@ -1137,6 +1142,23 @@ VolumeStats volume_stats(ckl_encoder& e, const LABEL* labels, uint64_t voxels);
 // One pass over the labels -> the two "differs from neighbour" bit planes and their
 // per-slice population counts (exact crack edge and run counts follow from these) and,
 // on the fast path, the whole-volume reductions of lib.hpp:224-256 from the same read.
+// the fast planes kernel's per-slice counts -> e.count_v / count_h and the volume's statistics
+void planes_collect(ckl_encoder& e, uint32_t ns, VolumeStats* st, const std::vector<unsigned long long>* fetched = nullptr) {
+	std::vector<unsigned long long> mine;
+	if (!fetched) { mine = download(e.d_plane_out.p, 4ull * ns, e.stream); fetched = &mine; }
+	const std::vector<unsigned long long>& o = *fetched;
+	e.count_v.resize(ns); e.count_h.resize(ns);
+	VolumeStats v;
+	for (uint32_t zi = 0; zi < ns; zi++) {
+		e.count_v[zi] = static_cast<uint32_t>(o[4ull * zi]);
+		e.count_h[zi] = static_cast<uint32_t>(o[4ull * zi + 1]);
+		v.pairs += o[4ull * zi + 2];
+		v.max_label = std::max<uint64_t>(v.max_label, o[4ull * zi + 3]);
+	}
+	e.planes_deferred = false;
+	if (st) *st = v;
+}
+
 // The trail's zero fills (slice errors, counters, chain start bits) depend on the dimensions only.  On the
 // label stream, which is idle until the walk, they run beside the planes kernel instead of between the node
 // counts and k_trail_nodes (3 fills, 25 us + their launch gaps at C2).  crack_pass waits for ev_prezero.
@@ -1156,10 +1178,11 @@ void trail_prezero(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz) {
 }
 
 template <typename LABEL>
-void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, VolumeStats* st) {
+void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, int64_t sz, VolumeStats* st, bool defer = false) {
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	e.trail_zeroed = false;
+	e.planes_deferred = false;
 	e.row_words = static_cast<uint32_t>((sx + 31) / 32);
 	e.plane_words = static_cast<uint64_t>(e.row_words) * sy;
 	e.d_planes.ensure(2 * e.plane_words * ns);
@@ -1171,23 +1194,17 @@ void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, in
 		const uint32_t nblk = (strips * bands + kWaves - 1) / kWaves;
 		e.d_plane_partial.ensure(4ull * nblk * ns);
 		e.d_plane_partial_max.ensure(static_cast<size_t>(nblk) * ns);
-		e.d_plane_out.ensure(4ull * ns);
+		e.d_plane_out.ensure(4ull * ns + 1);
 		if (!getenv("CKL_NO_PREZERO")) trail_prezero(e, sx, sy, sz);
 		hipLaunchKernelGGL(k_label_planes_fast<LABEL>, dim3(nblk, ns), dim3(kBlock), 0, s,
 			labels, static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), strips, bands,
 			e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
-			e.d_plane_partial.p, e.d_plane_partial_max.p);
-		hipLaunchKernelGGL(k_planes_reduce, dim3(ns), dim3(kBlock), 0, s, e.d_plane_partial.p, e.d_plane_partial_max.p, nblk, e.d_plane_out.p);
-		std::vector<unsigned long long> o = download(e.d_plane_out.p, 4ull * ns, s);
-		e.count_v.resize(ns); e.count_h.resize(ns);
-		VolumeStats v;
-		for (uint32_t zi = 0; zi < ns; zi++) {
-			e.count_v[zi] = static_cast<uint32_t>(o[4ull * zi]);
-			e.count_h[zi] = static_cast<uint32_t>(o[4ull * zi + 1]);
-			v.pairs += o[4ull * zi + 2];
-			v.max_label = std::max<uint64_t>(v.max_label, o[4ull * zi + 3]);
-		}
-		if (st) *st = v;
+			e.d_plane_partial.p, e.d_plane_partial_max.p, e.d_plane_out.p + 4ull * ns);
+		hipLaunchKernelGGL(k_planes_reduce, dim3(ns), dim3(kBlock), 0, s, e.d_plane_partial.p, e.d_plane_partial_max.p, nblk, e.d_plane_out.p, e.d_plane_out.p + 4ull * ns);
+		// deferred: graph_pass fetches the counts together with its own (k_trail_graph decides the crack
+		// format from the device's pair count: one host round trip less in front of it)
+		e.planes_deferred = defer && !getenv("CKL_NO_DEFER");
+		if (!e.planes_deferred) planes_collect(e, ns, st);
 		return;
 	}
 	if (st) *st = volume_stats<LABEL>(e, labels, static_cast<uint64_t>(sx) * sy * sz);
@@ -1206,7 +1223,9 @@ void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, in
 
 // crack graph (vertex nibbles in tiles, crackcodes.hpp:66-125) + the node / corner counts
 // of the trail graph (ckl_trail.hpp)
-void graph_pass(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, bool permissible) {
+// perm_mode: 0 impermissible, 1 permissible, 2 decided on the device from the planes kernel's pair count
+// (crackle.hpp:50-55; needs planes_deferred); `st` receives the deferred statistics
+void graph_pass(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, int perm_mode, VolumeStats* st = nullptr) {
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	e.tiles_x = static_cast<uint32_t>((sx + 1 + kTrailTileDim - 1) / kTrailTileDim);
@@ -1220,16 +1239,28 @@ void graph_pass(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, bool permiss
 	e.t_blk_special.ensure(static_cast<size_t>(e.graph_blocks) * ns);
 	e.t_blk_corner.ensure(static_cast<size_t>(e.graph_blocks) * ns);
 	e.d_count_vh.ensure(4 * static_cast<size_t>(ns));
-	e.graph_permissible = permissible;
+	if (perm_mode == 2 && !e.planes_deferred) throw Error(CKL_ERR_RUNTIME, "crackle_amd: internal: crack format left to the device without deferred counts");
+	const unsigned long long half_voxels = static_cast<unsigned long long>(static_cast<int64_t>(static_cast<uint64_t>(sx) * sy * sz) / 2);
 	hipLaunchKernelGGL(k_trail_graph, dim3(e.graph_blocks, ns), dim3(kBlock), 0, s,
 		e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
-		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), permissible ? 1u : 0u, reinterpret_cast<uint32_t*>(e.d_adjm.p), e.adjm_stride * 4,
+		static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), static_cast<uint32_t>(perm_mode),
+		perm_mode == 2 ? e.d_plane_out.p + 4ull * ns : nullptr, half_voxels,
+		reinterpret_cast<uint32_t*>(e.d_adjm.p), e.adjm_stride * 4,
 		e.mtx2, e.tiles_x, e.tiles_y, e.t_blk_special.p, e.t_blk_corner.p);
 	hipLaunchKernelGGL(k_trail_count_scan, dim3(ns), dim3(kBlock), 0, s, e.t_blk_special.p, e.t_blk_corner.p, e.graph_blocks,
 		e.d_count_vh.p + 2 * static_cast<size_t>(ns), e.d_count_vh.p + 3 * static_cast<size_t>(ns));
+	std::vector<unsigned long long> po;
+	if (e.planes_deferred) {
+		po.resize(4ull * ns);
+		CKL_HIP(hipMemcpyAsync(po.data(), e.d_plane_out.p, po.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	}
 	std::vector<uint32_t> c = download(e.d_count_vh.p + 2 * static_cast<size_t>(ns), 2 * static_cast<size_t>(ns), s);
 	e.count_special.assign(c.begin(), c.begin() + ns);
 	e.count_corner.assign(c.begin() + ns, c.end());
+	VolumeStats v;
+	if (!po.empty()) planes_collect(e, ns, &v, &po);
+	if (st && !po.empty()) *st = v;
+	e.graph_permissible = perm_mode == 2 ? static_cast<int64_t>(v.pairs) < static_cast<int64_t>(static_cast<uint64_t>(sx) * sy * sz) / 2 : perm_mode == 1;
 }
 
 struct CrackResult {
@@ -2048,9 +2079,23 @@ void encode_typed(
 	const bool planes_cached = ov && voxels > 0 && e.planes_for == static_cast<const void*>(labels)
 		&& e.planes_dims[0] == sx && e.planes_dims[1] == sy && e.planes_dims[2] == sz;
 	e.planes_for = nullptr;       // single use: the caller may change the volume afterwards
-	if (voxels > 0 && !planes_cached) planes_pass<LABEL>(e, labels, sx, sy, sz, &st);
+	const bool labels_first = getenv("CKL_NO_OVERLAP") || static_cast<uint64_t>(sx) * sy > (1536ull * 1536ull)
+		|| (getenv("CKL_LABELS_AT_WALK") && atoi(getenv("CKL_LABELS_AT_WALK")) == 0);
+	// (a label stream that starts in front of the graph kernel sizes its run arrays from the planes' counts: no deferral then)
+	if (voxels > 0 && !planes_cached) planes_pass<LABEL>(e, labels, sx, sy, sz, &st, !labels_first);
 	else if (planes_cached) st = e.planes_stats;      // overrides that force nothing still decide from the volume
 	ht.mark("planes");
+	bool graph_done = false;
+	if (e.planes_deferred) {
+		// the planes kernel's counts are still on the device: the graph kernel goes behind it without a round
+		// trip (it reads the crack format's deciding pair count there), both kernels' counts come in one
+		int perm_mode = 2;
+		if (ov && ov->force_crack_format >= 0) perm_mode = ov->force_crack_format == PERMISSIBLE ? 1 : 0;
+		e.trail_for = nullptr;
+		graph_pass(e, sx, sy, sz, perm_mode, &st);
+		graph_done = true;
+		ht.mark("graph");
+	}
 	int stored_width = byte_width(st.max_label);                     // crackle.hpp:233-235
 	if (ov && ov->force_stored_width) stored_width = ov->force_stored_width;
 
@@ -2099,13 +2144,12 @@ void encode_typed(
 	// counts are known).  (The sharded encode's label stream also carries the ranks' exchange of unique
 	// labels: 0.5 ms on the host.  It fits since the slab's labels are exchanged unsorted.)
 	bool labels_at_walk = false;
-	const bool labels_first = getenv("CKL_NO_OVERLAP") || static_cast<uint64_t>(sx) * sy > (1536ull * 1536ull)
-		|| (getenv("CKL_LABELS_AT_WALK") && atoi(getenv("CKL_LABELS_AT_WALK")) == 0);
-	if (labels_first) flat_enqueue(e, sx, sy, sz);
-	const bool trail_cached = planes_cached && ov && ov->has_model && head.markov_model_order > 0 && e.trail_for == static_cast<const void*>(labels)
+	if (labels_first && !graph_done) flat_enqueue(e, sx, sy, sz);
+	const bool trail_cached = !graph_done && planes_cached && ov && ov->has_model && head.markov_model_order > 0 && e.trail_for == static_cast<const void*>(labels)
 		&& e.trail_perm == (head.crack_format == PERMISSIBLE) && e.trail_order == head.markov_model_order && !getenv("CKL_NO_TRAIL_REUSE");
 	e.trail_for = nullptr;
-	if (!trail_cached) graph_pass(e, sx, sy, sz, head.crack_format == PERMISSIBLE);
+	if (graph_done && e.graph_permissible != (head.crack_format == PERMISSIBLE)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: internal: device and host disagree on the crack format");
+	if (!trail_cached && !graph_done) graph_pass(e, sx, sy, sz, head.crack_format == PERMISSIBLE ? 1 : 0);
 	ht.mark("graph");
 	if (!labels_first) {
 		uint32_t max_special = 0;

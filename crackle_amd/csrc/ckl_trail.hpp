@@ -202,11 +202,14 @@ constexpr uint32_t kGraphTiles = kBlock / kTrailTileDim;     // 32 x 32 vertex t
 // grid = (graph_blocks, nslices)
 static __global__ void __launch_bounds__(kBlock) k_trail_graph(
 	const uint32_t* __restrict__ planeV, const uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
-	uint32_t sx, uint32_t sy, uint32_t permissible, uint32_t* __restrict__ adjm_words, uint64_t adjm_stride_words,
+	uint32_t sx, uint32_t sy, uint32_t perm_mode, const unsigned long long* __restrict__ total_pairs, unsigned long long half_voxels,
+	uint32_t* __restrict__ adjm_words, uint64_t adjm_stride_words,
 	uint32_t mtx2, uint32_t tiles_x, uint32_t tiles_y, uint32_t* __restrict__ blk_special, uint32_t* __restrict__ blk_corner
 ) {
 	__shared__ uint32_t s_red[2 * kWaves];
 	const uint32_t zi = blockIdx.y;
+	// perm_mode 2: the crack format follows from the volume's equal pixel pairs (crackle.hpp:50-55), counted by the kernels in front
+	const bool permissible = perm_mode == 2u ? static_cast<long long>(*total_pairs) < static_cast<long long>(half_voxels) : perm_mode != 0u;
 	// thread -> (tile of the workgroup, row of the tile): neighbouring lanes take the SAME row of
 	// neighbouring tiles, so that a wavefront's plane loads are 8 stretches of 32 bytes instead of
 	// 64 different lines (the tiles of a workgroup lie side by side)
