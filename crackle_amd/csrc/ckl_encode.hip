@@ -1757,12 +1757,12 @@ void pin_dedup_pass(ckl_encoder& e, const LABEL* labels, const PinVolume& v) {
 // (src/pins.hpp:95-198, 300-346) as device passes over the resident label volume and
 // the component id volume (ckl_pins_dev.hpp); only per-component facts and the chosen pins are copied out.
 template <typename LABEL>
-PinCandidates pin_candidates_device(
+void pin_passes_device(
 	ckl_encoder& e, const LABEL* labels, const uint32_t* cc /* device: component id of every voxel */,
-	const uint64_t* comp_label /* device: label of every component */, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N
+	int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N, PinVolume& v, unsigned long long*& choice, const uint64_t*& first_any
 ) {
 	hipStream_t s = e.stream2;
-	PinVolume v;
+	v = PinVolume();
 	v.sx = static_cast<uint32_t>(sx_); v.sy = static_cast<uint32_t>(sy_); v.sz = static_cast<uint32_t>(sz_);
 	v.sxy = static_cast<uint64_t>(v.sx) * v.sy;
 	const uint64_t voxels = v.sxy * v.sz;
@@ -1780,7 +1780,8 @@ PinCandidates pin_candidates_device(
 	a.first_any = reinterpret_cast<unsigned long long*>(e.d_pin_u64.p);
 	a.first_kept = a.first_any + N;
 	a.best = a.first_kept + N;
-	unsigned long long* choice = a.best + N;
+	choice = a.best + N;
+	first_any = reinterpret_cast<const uint64_t*>(a.first_any);
 	a.first_depth = e.d_pin_u32.p;
 	CKL_HIP(hipMemsetAsync(a.first_any, 0xFF, 2 * N * sizeof(uint64_t), s));
 	CKL_HIP(hipMemsetAsync(a.best, 0, N * sizeof(uint64_t), s));
@@ -1791,6 +1792,20 @@ PinCandidates pin_candidates_device(
 		labels, v, a.first_kept, static_cast<uint32_t>(N), a.first_depth);
 	hipLaunchKernelGGL((k_pin_columns<LABEL, 2>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
 	hipLaunchKernelGGL(k_pin_choice, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s, a, N, choice);
+}
+
+// `passes`: the PinVolume / choice / first_any of a pin_passes_device call that has run already (else it runs here)
+template <typename LABEL>
+PinCandidates pin_candidates_device(
+	ckl_encoder& e, const LABEL* labels, const uint32_t* cc /* device: component id of every voxel */,
+	const uint64_t* comp_label /* device: label of every component */, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N,
+	const PinVolume* passes = nullptr, unsigned long long* choice = nullptr, const uint64_t* first_any_dev = nullptr
+) {
+	hipStream_t s = e.stream2;
+	PinVolume v;
+	if (passes) v = *passes;
+	else pin_passes_device<LABEL>(e, labels, cc, sx_, sy_, sz_, N, v, choice, first_any_dev);
+	struct { const unsigned long long* first_any; } a = { reinterpret_cast<const unsigned long long*>(first_any_dev) };
 
 	CKL_HIP(hipStreamSynchronize(s));
 	HT_MARK("p:passes");
@@ -1971,6 +1986,102 @@ void pins_rows_extent(ckl_encoder& e, const LABEL* labels, const uint32_t* cc, i
 	CKL_HIP(hipMemsetAsync(ze_plus1, 0, N * sizeof(uint32_t), s));
 	hipLaunchKernelGGL((k_pin_extent<LABEL, false, true>), dim3(nb), dim3(kPinBlock), 0, s, labels, v, reinterpret_cast<const unsigned long long*>(choice), static_cast<uint32_t>(N), ze_plus1);
 	CKL_HIP(hipStreamSynchronize(s));
+}
+
+// The pin label section from the per-component arrays in device memory (every chosen pin an entry of its own:
+// pin c is component c's choice): the arrays come to the host in ONE pinned block (host_out_alloc: cached between
+// calls), the per-pin bookkeeping runs on the worker threads, pins_cover_host reads the block in place.
+// choice[c]: key of the chosen run or kPinNoKey; ze_plus1[c]: its last slice + 1; offsets: N + 1 prefix sums of the
+// runs' lengths; ids: the component ids along the runs.
+std::vector<uint8_t> pins_section_from_device(
+	ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, uint64_t N, const std::vector<uint32_t>& nc,
+	const uint64_t* d_comp_label, const uint64_t* d_first_any, const uint64_t* d_choice, const uint32_t* d_ze_plus1, const uint64_t* d_offsets, const uint32_t* d_ids,
+	int stored_width, bool auto_bgcolor, int64_t manual_bgcolor
+) {
+	hipStream_t s = e.stream2;
+	PinCandidates pc;
+	pin_label_table(e, d_comp_label, d_first_any, N, pc);      // the labels with their first runs: a few downloads of its own
+	const uint64_t total = download(d_offsets + N, 1, s)[0];
+	auto up64 = [](uint64_t b) { return (b + 63) & ~static_cast<uint64_t>(63); };
+	const uint64_t o_label = 0, o_choice = o_label + up64(N * 8), o_off = o_choice + up64(N * 8), o_ze = o_off + up64((N + 1) * 8), o_ids = o_ze + up64(N * 4);
+	const uint64_t bytes = o_ids + up64(std::max<uint64_t>(total, 1) * 4);
+	struct Block { uint8_t* p = nullptr; ~Block() { if (p) host_out_free(p); } } blk;
+	blk.p = static_cast<uint8_t*>(host_out_alloc(bytes));
+	CKL_HIP(hipMemcpyAsync(blk.p + o_label, d_comp_label, N * 8, hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipMemcpyAsync(blk.p + o_choice, d_choice, N * 8, hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipMemcpyAsync(blk.p + o_off, d_offsets, (N + 1) * 8, hipMemcpyDeviceToHost, s));
+	CKL_HIP(hipMemcpyAsync(blk.p + o_ze, d_ze_plus1, N * 4, hipMemcpyDeviceToHost, s));
+	if (total) CKL_HIP(hipMemcpyAsync(blk.p + o_ids, d_ids, total * 4, hipMemcpyDeviceToHost, s));
+	pc.comp_pin.resize(N); pc.pin_x.resize(N); pc.pin_y.resize(N); pc.pin_zs.resize(N); pc.pin_ze.resize(N);      // (first touched by the threads below)
+	CKL_HIP(hipStreamSynchronize(s));
+	HT_MARK("p:d2h");
+	const uint64_t* chosen = reinterpret_cast<const uint64_t*>(blk.p + o_choice);
+	const uint32_t* ze_plus1 = reinterpret_cast<const uint32_t*>(blk.p + o_ze);
+	const uint64_t usx = static_cast<uint64_t>(sx), usz = static_cast<uint64_t>(sz);
+	host_parallel_for(N, 65536, [&](size_t lo, size_t hi) {
+		for (size_t c = lo; c < hi; c++) {
+			if (chosen[c] == kPinNoKey) { pc.comp_pin[c] = kPinNone; pc.pin_x[c] = pc.pin_y[c] = pc.pin_zs[c] = pc.pin_ze[c] = 0; continue; }
+			if (ze_plus1[c] == 0) throw Error(CKL_ERR_RUNTIME, "crackle_amd: a chosen pin lies in no rank's rows");
+			pc.comp_pin[c] = static_cast<uint32_t>(c);
+			const uint64_t col = chosen[c] / usz;
+			pc.pin_zs[c] = static_cast<uint32_t>(chosen[c] % usz);
+			pc.pin_ze[c] = ze_plus1[c] - 1u;
+			pc.pin_x[c] = static_cast<uint32_t>(col % usx);
+			pc.pin_y[c] = static_cast<uint32_t>(col / usx);
+		}
+	});
+	pc.view_components = N;
+	pc.view_comp_label = reinterpret_cast<const uint64_t*>(blk.p + o_label);
+	pc.view_pin_ids_off = reinterpret_cast<const uint64_t*>(blk.p + o_off);
+	pc.view_pin_ids = reinterpret_cast<const uint32_t*>(blk.p + o_ids);
+	HT_MARK("p:keys");
+	Header h;
+	h.sx = static_cast<uint32_t>(sx); h.sy = static_cast<uint32_t>(sy); h.sz = static_cast<uint32_t>(sz);
+	return pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
+}
+
+// The whole pin stage of a volume that one device holds: the passes of pin_candidates_device, then the chosen
+// runs' ends, lengths, offsets (a device scan) and ids without a visit to the host, then pins_section_from_device.
+// Volumes whose id lists pass the budget (long z-runs chosen by many components) take pin_candidates_device's
+// route, which reduces the chosen runs to the distinct ones first.
+template <typename LABEL>
+std::vector<uint8_t> pins_section_plain(
+	ckl_encoder& e, const LABEL* labels, const uint32_t* cc, const uint64_t* comp_label, int64_t sx, int64_t sy, int64_t sz, uint64_t N,
+	const std::vector<uint32_t>& nc, int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor
+) {
+	hipStream_t s = e.stream2;
+	if (N >= kPinNone) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many pins");
+	unsigned long long* choice = nullptr;
+	const uint64_t* first_any = nullptr;
+	PinVolume v;
+	pin_passes_device<LABEL>(e, labels, cc, sx, sy, sz, N, v, choice, first_any);
+	const uint32_t nb = static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock);
+	const uint32_t pieces = static_cast<uint32_t>((N + kPinScanPiece - 1) / kPinScanPiece);
+	DevBuf<uint32_t> d_zep, d_count, d_ze, d_ids;
+	DevBuf<unsigned long long> d_piece, d_off;
+	d_zep.ensure(N); d_count.ensure(N); d_piece.ensure(static_cast<size_t>(pieces) + 1); d_off.ensure(N + 1);
+	CKL_HIP(hipMemsetAsync(d_zep.p, 0, N * sizeof(uint32_t), s));
+	hipLaunchKernelGGL((k_pin_extent<LABEL, false, true>), dim3(nb), dim3(kPinBlock), 0, s, labels, v, choice, static_cast<uint32_t>(N), d_zep.p);
+	hipLaunchKernelGGL(k_pin_id_counts, dim3(nb), dim3(kPinBlock), 0, s, choice, d_zep.p, v.sz, N, d_count.p);
+	hipLaunchKernelGGL(k_pin_scan_pieces, dim3(pieces), dim3(kPinBlock), 0, s, d_count.p, N, d_piece.p);
+	hipLaunchKernelGGL(k_pin_scan_tops, dim3(1), dim3(kPinBlock), 0, s, d_piece.p, pieces);
+	hipLaunchKernelGGL(k_pin_scan_offsets, dim3(pieces), dim3(kPinBlock), 0, s, d_count.p, N, d_piece.p, pieces, d_off.p);
+	const uint64_t total = download(d_off.p + N, 1, s)[0];
+	HT_MARK("p:passes");
+	uint64_t id_budget = 1ull << 26;      // 256 MiB of ids
+	if (const char* env = getenv("CKL_PIN_IDS_BUDGET")) id_budget = static_cast<uint64_t>(std::max(0, atoi(env)));      // testing: forces the distinct-pin path
+	if (total > id_budget || getenv("CKL_PINS_HOST_BOOKKEEPING")) {
+		const PinCandidates pc = pin_candidates_device<LABEL>(e, labels, cc, comp_label, sx, sy, sz, N, &v, choice, first_any);
+		HT_MARK("pins_device");
+		return pins_cover_host(pc, sx, sy, sz, nc, N, index_width, stored_width, auto_bgcolor, manual_bgcolor);
+	}
+	d_ze.ensure(N); d_ids.ensure(total + 1);
+	hipLaunchKernelGGL(k_pin_minus1, dim3(nb), dim3(kPinBlock), 0, s, d_zep.p, N, d_ze.p);
+	hipLaunchKernelGGL(k_pin_ids, dim3(nb), dim3(kPinBlock), 0, s, v, choice, d_ze.p, reinterpret_cast<const uint64_t*>(d_off.p), static_cast<uint32_t>(N), d_ids.p);
+	std::vector<uint8_t> bin = pins_section_from_device(e, sx, sy, sz, N, nc, comp_label, first_any, reinterpret_cast<const uint64_t*>(choice), d_zep.p,
+		reinterpret_cast<const uint64_t*>(d_off.p), d_ids.p, stored_width, auto_bgcolor, manual_bgcolor);
+	HT_MARK("pins_host");
+	return bin;
 }
 
 // The flat label section (labels.hpp:92-152) on device: sort + unique of the component
@@ -2221,11 +2332,8 @@ void encode_typed(
 			hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((static_cast<uint64_t>(sx) * sy + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
 				e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
 				e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, 0u, e.d_cc_volume.p);
-			const PinCandidates pc = pin_candidates_device<LABEL>(e, labels, e.d_cc_volume.p, e.d_mapping.p, sx, sy, sz, N);
-			HT_MARK("pins_device");
-			pins_binary = pins_cover_host(pc, sx, sy, sz, fr.ncomp, N, head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
+			pins_binary = pins_section_plain<LABEL>(e, labels, e.d_cc_volume.p, e.d_mapping.p, sx, sy, sz, N, fr.ncomp, head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
 			label_bytes = pins_binary.size();
-			HT_MARK("pins_host");
 		}
 		else {
 			label_bytes = flat_section(e, N, stored_width, component_width, static_cast<uint32_t>(sz), ov);
@@ -2753,20 +2861,19 @@ int ckl_encoder_pin_labels(
 		e->d_slice_err2.ensure(1);
 		CKL_HIP(hipMemsetAsync(e->d_mapping.p, 0, N * sizeof(uint64_t), s));
 		CKL_HIP(hipMemsetAsync(e->d_slice_err2.p, 0, sizeof(uint32_t), s));
-		PinCandidates pc;
+		std::vector<uint8_t> bin;
 		const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((voxels + kPinBlock - 1) / kPinBlock, 0x7FFFFFFFull));
 #define CKL_PINS(T) do { \
 			hipLaunchKernelGGL(k_pin_component_labels<T>, dim3(blocks), dim3(kPinBlock), 0, s, reinterpret_cast<const T*>(labels_device), cc_device, voxels, static_cast<uint32_t>(sx), N, \
 				reinterpret_cast<unsigned long long*>(e->d_mapping.p), e->d_slice_err2.p); \
 			if (download(e->d_slice_err2.p, 1, s)[0]) throw Error(CKL_ERR_ARG, "crackle_amd: component id out of range"); \
-			pc = pin_candidates_device<T>(*e, reinterpret_cast<const T*>(labels_device), cc_device, e->d_mapping.p, sx, sy, sz, N); \
+			bin = pins_section_plain<T>(*e, reinterpret_cast<const T*>(labels_device), cc_device, e->d_mapping.p, sx, sy, sz, N, nc, h.pin_index_width(), stored_width, auto_bgcolor != 0, manual_bgcolor); \
 		} while (0)
 		if (e->dtype_bytes == 1) CKL_PINS(uint8_t);
 		else if (e->dtype_bytes == 2) CKL_PINS(uint16_t);
 		else if (e->dtype_bytes == 4) CKL_PINS(uint32_t);
 		else CKL_PINS(uint64_t);
 #undef CKL_PINS
-		const std::vector<uint8_t> bin = pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor != 0, manual_bgcolor);
 		uint8_t* p = static_cast<uint8_t*>(host_out_alloc(bin.size() ? bin.size() : 1));
 		memcpy(p, bin.data(), bin.size());
 		*out = p;
@@ -2871,32 +2978,11 @@ int ckl_pins_rows_section(ckl_encoder* e, int64_t sx, int64_t sy, int64_t sz, ui
 		if (N == 0 || N >= kPinNone) throw Error(CKL_ERR_ARG, "crackle_amd: component count out of range");
 		select_device(e->device);
 		wait_for_default_stream(e->stream2, e->ev_in);
-		hipStream_t s = e->stream2;
 		std::vector<uint32_t> nc(ncomp_host, ncomp_host + sz);
-		PinCandidates pc;
-		pc.comp_label = download(comp_label, N, s);
-		pc.comp_first = download(first_any, N, s);
-		const std::vector<uint64_t> chosen = download(choice, N, s);
-		pc.pin_ze = download(ze_plus1, N, s);
-		pc.pin_ids_off = download(offsets, N + 1, s);
-		pc.pin_ids = download(ids, pc.pin_ids_off[N], s);
-		pc.comp_pin.assign(N, kPinNone);
-		pc.pin_x.assign(N, 0); pc.pin_y.assign(N, 0); pc.pin_zs.assign(N, 0);
-		const uint64_t usx = static_cast<uint64_t>(sx), usz = static_cast<uint64_t>(sz);
-		for (uint64_t c = 0; c < N; c++) {
-			if (chosen[c] == kPinNoKey) { pc.pin_ze[c] = 0; continue; }
-			if (pc.pin_ze[c] == 0) throw Error(CKL_ERR_RUNTIME, "crackle_amd: a chosen pin lies in no rank's rows");
-			pc.comp_pin[c] = static_cast<uint32_t>(c);
-			const uint64_t col = chosen[c] / usz;
-			pc.pin_zs[c] = static_cast<uint32_t>(chosen[c] % usz);
-			pc.pin_ze[c] -= 1u;
-			pc.pin_x[c] = static_cast<uint32_t>(col % usx);
-			pc.pin_y[c] = static_cast<uint32_t>(col / usx);
-		}
-		pin_label_table(*e, comp_label, first_any, N, pc);
-		Header h;
-		h.sx = static_cast<uint32_t>(sx); h.sy = static_cast<uint32_t>(sy); h.sz = static_cast<uint32_t>(sz);
-		const std::vector<uint8_t> bin = pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor != 0, manual_bgcolor);
+		HostTimer ht;
+		g_ht = &ht;
+		const std::vector<uint8_t> bin = pins_section_from_device(*e, sx, sy, sz, N, nc, comp_label, first_any, choice, ze_plus1, offsets, ids, stored_width, auto_bgcolor != 0, manual_bgcolor);
+		ht.mark("p:cover");
 		uint8_t* p = static_cast<uint8_t*>(host_out_alloc(bin.size() ? bin.size() : 1));
 		memcpy(p, bin.data(), bin.size());
 		*out = p;

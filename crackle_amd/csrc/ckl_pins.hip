@@ -42,6 +42,8 @@ public:
 	static size_t with_buffer(size_t n) { const size_t m = calc_max(n); return n + std::min<size_t>(m, 0xFF); }
 
 	bool allocated() const { return mask != 0; }
+	// back to the state of a new table (the vectors keep their memory)
+	void reset() { mask = 0; num = 0; max_allowed = 0; nbuf = 0; info_inc = 32; info_shift = 0; mult = 0xc4ceb9fe1a85ec53ull; }
 
 	void key_to_idx(uint64_t key, size_t& idx, uint32_t& inf) const {
 		uint64_t h = key;
@@ -257,14 +259,35 @@ template PinCandidates pin_candidates_host<uint16_t>(const uint16_t*, const uint
 template PinCandidates pin_candidates_host<uint32_t>(const uint32_t*, const uint32_t*, int64_t, int64_t, int64_t, uint64_t);
 template PinCandidates pin_candidates_host<uint64_t>(const uint64_t*, const uint32_t*, int64_t, int64_t, int64_t, uint64_t);
 
+void host_parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& body, size_t max_threads) {
+	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), max_threads);
+	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
+	const size_t want = std::min(nthreads, std::max<size_t>(1, n / std::max<size_t>(grain, 1)));
+	if (want <= 1) { body(0, n); return; }
+	std::vector<std::thread> pool;
+	std::vector<std::string> errors(want);
+	for (size_t t = 0; t < want; t++) {
+		pool.emplace_back([&, t]() {
+			try { body(n * t / want, n * (t + 1) / want); }
+			catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
+		});
+	}
+	for (auto& th : pool) th.join();
+	for (auto& e : errors) if (!e.empty()) throw Error(CKL_ERR_RUNTIME, e);
+}
+
 std::vector<uint8_t> pins_cover_host(
 	const PinCandidates& pc, int64_t sx, int64_t sy, int64_t sz,
 	const std::vector<uint32_t>& ncomp, uint64_t n_total,
 	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor
 ) {
 	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
-	const uint64_t N = pc.comp_label.size();
+	const bool viewed = pc.view_components != 0;
+	const uint64_t N = viewed ? pc.view_components : pc.comp_label.size();
 	const size_t P = pc.pin_x.size();
+	const uint64_t* const comp_label = viewed ? pc.view_comp_label : pc.comp_label.data();
+	const uint64_t* const ids_off = viewed ? pc.view_pin_ids_off : pc.pin_ids_off.data();
+	const uint32_t* const ids = viewed ? pc.view_pin_ids : pc.pin_ids.data();
 	const bool prof = getenv("CKL_PROFILE") != nullptr;
 	auto t_last = std::chrono::steady_clock::now();
 	std::string marks;
@@ -276,24 +299,28 @@ std::vector<uint8_t> pins_cover_host(
 		marks += buf;
 		t_last = now;
 	};
-	if (pc.comp_first.size() != N || pc.comp_pin.size() != N || pc.pin_ids_off.size() != P + 1) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
+	if (pc.comp_pin.size() != N || (!viewed && pc.pin_ids_off.size() != P + 1) || (viewed && (!comp_label || !ids_off || !ids))) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
+	if (pc.label_value.empty() && pc.comp_first.size() != N) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
 
 	// worker threads for the per-label phases (labels are independent of each other)
 	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 32);
 	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
-	auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) {
-		const size_t want = std::min(nthreads, std::max<size_t>(1, n / std::max<size_t>(grain, 1)));
-		if (want <= 1) { body(0, n); return; }
-		std::vector<std::thread> pool;
-		std::vector<std::string> errors(want);
-		for (size_t t = 0; t < want; t++) {
-			pool.emplace_back([&, t]() {
-				try { body(n * t / want, n * (t + 1) / want); }
-				catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
+	auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) { host_parallel_for(n, grain, body, 32); };
+
+	// sort in pieces on the worker threads, then merge the pieces pairwise
+	auto parallel_sort = [&](auto first, auto last, auto less) {
+		const size_t n = static_cast<size_t>(last - first);
+		size_t pieces = 1;
+		while (pieces < nthreads && pieces < 16 && n / (2 * pieces) >= 4096) pieces *= 2;
+		if (pieces == 1) { std::sort(first, last, less); return; }
+		auto bound = [&](size_t i) { return first + static_cast<std::ptrdiff_t>(n * i / pieces); };
+		parallel_for(pieces, 1, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) std::sort(bound(i), bound(i + 1), less); });
+		for (size_t w = 1; w < pieces; w *= 2) {
+			const size_t pairs = pieces / (2 * w);
+			parallel_for(pairs, 1, [&](size_t lo, size_t hi) {
+				for (size_t i = lo; i < hi; i++) std::inplace_merge(bound(2 * w * i), bound(2 * w * i + w), bound(2 * w * (i + 1)), less);
 			});
 		}
-		for (auto& th : pool) th.join();
-		for (auto& e : errors) if (!e.empty()) throw Error(CKL_ERR_RUNTIME, e);
 	};
 
 	// ---- pinsets (src/pins.hpp:126-163): a robin-hood node map keyed by label; its slot order
@@ -309,9 +336,9 @@ std::vector<uint8_t> pins_cover_host(
 		}
 		else {
 			order.reserve(N);
-			for (uint64_t c = 0; c < N; c++) if (pc.comp_first[c] != kPinNoKey) order.emplace_back(pc.comp_first[c], pc.comp_label[c]);
+			for (uint64_t c = 0; c < N; c++) if (pc.comp_first[c] != kPinNoKey) order.emplace_back(pc.comp_first[c], comp_label[c]);
 		}
-		std::sort(order.begin(), order.end());
+		parallel_sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a < b; });
 		for (const auto& o : order) {
 			bool found;
 			pinsets.insert(o.second, static_cast<uint32_t>(n_labels), found);
@@ -326,7 +353,7 @@ std::vector<uint8_t> pins_cover_host(
 	parallel_for(N, 16384, [&](size_t lo, size_t hi) {
 		for (size_t c = lo; c < hi; c++) {
 			size_t s;
-			if (!pinsets.find(pc.comp_label[c], s)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: component of a label without column runs");
+			if (!pinsets.find(comp_label[c], s)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: component of a label without column runs");
 			comp_li[c] = pinsets.vals[s];
 		}
 	});
@@ -341,14 +368,22 @@ std::vector<uint8_t> pins_cover_host(
 	mark("universe");
 
 	// ---- per label: the universe (a robin-hood flat set, filled in ascending id) and
-	// find_suboptimal_pins (src/pins.hpp:300-346) ----
-	std::vector<std::vector<uint32_t>> chosen(n_labels);      // pin indices, in the order taken
+	// find_suboptimal_pins (src/pins.hpp:300-346).  A label takes at most one pin per component: its
+	// pins, in the order taken, go to chosen[li_at[li] ...] (no vector per label: 143 k labels at C4) ----
+	auto depth_of = [&](uint32_t p) { return static_cast<uint64_t>(pc.pin_ze[p] - pc.pin_zs[p]); };
+	std::vector<uint32_t> chosen(N);
+	std::vector<uint32_t> n_chosen(n_labels, 0);
+	std::vector<uint64_t> depth_sum(n_labels, 0), depth_max(n_labels, 0);
 	parallel_for(n_labels, 32, [&](size_t lo, size_t hi) {
+		RhTable uni;
 		for (size_t li = lo; li < hi; li++) {
-			RhTable uni;
+			uni.reset();
 			bool f;
 			for (uint64_t k = li_at[li]; k < li_at[li + 1]; k++) uni.insert(li_comp[k], 0, f);
-			std::vector<uint32_t>& out = chosen[li];
+			uint32_t* out = chosen.data() + li_at[li];
+			const uint64_t room = li_at[li + 1] - li_at[li];
+			uint32_t taken = 0;
+			uint64_t dsum = 0, dmax = 0;
 			size_t cursor = 0;
 			while (uni.num) {
 				size_t us;
@@ -356,59 +391,66 @@ std::vector<uint8_t> pins_cover_host(
 				const uint64_t picked = uni.keys[us];
 				const uint32_t p = pc.comp_pin[picked];
 				if (p == kPinNone) { uni.erase(picked); continue; }   // cannot happen: every component lies on a kept column run
-				for (uint64_t k = pc.pin_ids_off[p]; k < pc.pin_ids_off[p + 1]; k++) uni.erase(pc.pin_ids[k]);
-				out.push_back(p);
+				const size_t before = uni.num;
+				for (uint64_t k = ids_off[p]; k < ids_off[p + 1]; k++) uni.erase(ids[k]);
+				if (uni.num == before) throw Error(CKL_ERR_RUNTIME, "crackle_amd: a pin without its own component");      // (would loop for ever)
+				if (taken >= room) throw Error(CKL_ERR_RUNTIME, "crackle_amd: more pins than components");
+				out[taken++] = p;
+				const uint64_t d = depth_of(p);
+				dsum += d; dmax = std::max(dmax, d);
 			}
+			n_chosen[li] = taken; depth_sum[li] = dsum; depth_max[li] = dmax;
 		}
 	});
 	mark("cover");
 
 	// ---- all_pins: libstdc++ unordered_map filled in pinsets slot order (src/pins.hpp:374-388);
-	// its iteration order breaks ties in find_bgcolor (src/labels.hpp:157-190) ----
-	std::unordered_map<uint64_t, uint32_t> all_pins;   // label -> label index
-	all_pins.reserve(128);
+	// its iteration order breaks ties in find_bgcolor (src/labels.hpp:157-190).  find_bgcolor keeps the
+	// first label in that order with the greatest (number of pins, summed depth): when one label alone
+	// holds the maximum the order does not matter and the map (143 k node allocations at C4) is not built ----
+	std::vector<std::pair<uint64_t, uint32_t>> slot_labels;      // (label, label index) in slot order
+	slot_labels.reserve(n_labels);
 	for (size_t slot = 0; slot < pinsets.nbuf && pinsets.allocated(); slot++) {
-		if (!pinsets.info[slot]) continue;
-		all_pins[pinsets.keys[slot]] = pinsets.vals[slot];
+		if (pinsets.info[slot]) slot_labels.emplace_back(pinsets.keys[slot], pinsets.vals[slot]);
 	}
-	auto depth_of = [&](uint32_t p) { return static_cast<uint64_t>(pc.pin_ze[p] - pc.pin_zs[p]); };
-	auto total_depth = [&](const std::vector<uint32_t>& v) {
-		uint64_t d = 0;
-		for (uint32_t p : v) d += depth_of(p);
-		return d;
-	};
 	uint64_t bgcolor = (manual_bgcolor != 0) ? 1 : 0;   // Q1: compress_helper takes `const bool manual_bgcolor`
 	if (auto_bgcolor) {
 		bgcolor = 0;
 		uint64_t max_pins = 0, max_pins_depth = static_cast<uint64_t>(sz);
-		for (const auto& kv : all_pins) {
-			const std::vector<uint32_t>& v = chosen[kv.second];
-			if (v.size() > max_pins) {
-				bgcolor = kv.first;
-				max_pins = v.size();
-				max_pins_depth = total_depth(v);
-			}
-			else if (v.size() == max_pins) {
-				const uint64_t d = total_depth(v);
-				if (d > max_pins_depth) { bgcolor = kv.first; max_pins_depth = d; }
+		size_t holders = 0;
+		for (const auto& kv : slot_labels) {
+			const uint64_t np = n_chosen[kv.second], d = depth_sum[kv.second];
+			if (np > max_pins || (np == max_pins && d > max_pins_depth)) { bgcolor = kv.first; max_pins = np; max_pins_depth = d; holders = 1; }
+			else if (np == max_pins && d == max_pins_depth) holders++;
+		}
+		if (holders > 1 || getenv("CKL_PINS_BGCOLOR_MAP")) {
+			std::unordered_map<uint64_t, uint32_t> all_pins;   // label -> label index
+			all_pins.reserve(128);
+			for (const auto& kv : slot_labels) all_pins[kv.first] = kv.second;
+			bgcolor = 0; max_pins = 0; max_pins_depth = static_cast<uint64_t>(sz);
+			for (const auto& kv : all_pins) {
+				const uint64_t np = n_chosen[kv.second], d = depth_sum[kv.second];
+				if (np > max_pins) { bgcolor = kv.first; max_pins = np; max_pins_depth = d; }
+				else if (np == max_pins && d > max_pins_depth) { bgcolor = kv.first; max_pins_depth = d; }
 			}
 		}
 	}
 	if (stored_width < 8) bgcolor &= (1ull << (8 * stored_width)) - 1;
-	all_pins.erase(bgcolor);
 
 	mark("bgcolor");
 	// ---- encode_condensed_pins (src/labels.hpp:192-344) ----
 	uint64_t max_pins = 0, max_depth = 0;
-	std::vector<uint64_t> all_labels;
-	all_labels.reserve(all_pins.size());
-	for (const auto& kv : all_pins) {
-		const std::vector<uint32_t>& v = chosen[kv.second];
-		max_pins = std::max<uint64_t>(max_pins, v.size());
-		for (uint32_t p : v) max_depth = std::max<uint64_t>(max_depth, depth_of(p));
-		all_labels.push_back(kv.first);
+	std::vector<std::pair<uint64_t, uint32_t>>& all_labels = slot_labels;      // every label but the background colour, ascending
+	{
+		size_t keep = 0;
+		for (size_t i = 0; i < all_labels.size(); i++) if (all_labels[i].first != bgcolor) all_labels[keep++] = all_labels[i];
+		all_labels.resize(keep);
 	}
-	std::sort(all_labels.begin(), all_labels.end());
+	for (const auto& kv : all_labels) {
+		max_pins = std::max<uint64_t>(max_pins, n_chosen[kv.second]);
+		max_depth = std::max<uint64_t>(max_depth, depth_max[kv.second]);
+	}
+	parallel_sort(all_labels.begin(), all_labels.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; });
 
 	const int num_pins_width = byte_width(max_pins);
 	const int depth_width = byte_width(max_depth);
@@ -421,53 +463,68 @@ std::vector<uint8_t> pins_cover_host(
 	std::vector<uint8_t> bin;
 	put_le(bin, bgcolor, stored_width);
 	put_le(bin, all_labels.size(), 8);
-	for (uint64_t l : all_labels) put_le(bin, l, stored_width);
+	bin.reserve(bin.size() + all_labels.size() * static_cast<size_t>(stored_width) + static_cast<size_t>(sz) * component_width + 1);
+	for (const auto& kv : all_labels) put_le(bin, kv.first, stored_width);
 	for (int64_t z = 0; z < sz; z++) put_le(bin, ncomp[z], component_width);
 	bin.push_back(combined);
 
-	// the labels' records are independent: built side by side, joined in label order
-	struct Sorted { uint64_t idx, depth; uint32_t pin; };
-	std::vector<uint32_t> label_li(all_labels.size());
-	for (size_t i = 0; i < all_labels.size(); i++) label_li[i] = all_pins[all_labels[i]];
-	std::vector<std::vector<uint8_t>> parts(all_labels.size());
-	parallel_for(all_labels.size(), 64, [&](size_t lo, size_t hi) {
+	// the labels' records are independent: sized first, then written side by side at their places
+	const size_t n_rec = all_labels.size();
+	std::vector<uint64_t> rec_at(n_rec + 1, 0);
+	parallel_for(n_rec, 256, [&](size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; i++) {
-			std::vector<uint8_t>& out = parts[i];
-			const std::vector<uint32_t>& v = chosen[label_li[i]];
-			std::vector<Sorted> sp;
-			sp.reserve(v.size());
-			for (uint32_t p : v) {
+			const uint32_t li = all_labels[i].second;
+			const uint32_t* v = chosen.data() + li_at[li];
+			uint64_t n_repr = 0, n_ids = 0;
+			for (uint32_t k = 0; k < n_chosen[li]; k++) {
+				const uint32_t p = v[k];
+				if (depth_of(p) >= cc_efficient_threshold) n_repr++;
+				else n_ids += ids_off[p + 1] - ids_off[p];
+			}
+			rec_at[i + 1] = 2ull * num_pins_width + n_repr * static_cast<uint64_t>(index_width + depth_width) + n_ids * static_cast<uint64_t>(cc_label_width);
+		}
+	});
+	for (size_t i = 0; i < n_rec; i++) rec_at[i + 1] += rec_at[i];
+	const size_t head_bytes = bin.size();
+	bin.resize(head_bytes + rec_at[n_rec]);
+	struct Sorted { uint64_t idx, depth; uint32_t pin; };
+	auto put_at = [](uint8_t*& o, uint64_t v, int w) { for (int b = 0; b < w; b++) *o++ = static_cast<uint8_t>(v >> (8 * b)); };
+	parallel_for(n_rec, 64, [&](size_t lo, size_t hi) {
+		std::vector<Sorted> sp;
+		std::vector<uint32_t> idv;
+		for (size_t i = lo; i < hi; i++) {
+			uint8_t* o = bin.data() + head_bytes + rec_at[i];
+			const uint32_t li = all_labels[i].second;
+			const uint32_t* v = chosen.data() + li_at[li];
+			sp.clear();
+			for (uint32_t k = 0; k < n_chosen[li]; k++) {
+				const uint32_t p = v[k];
 				sp.push_back({ static_cast<uint64_t>(pc.pin_x[p]) + static_cast<uint64_t>(sx) * (static_cast<uint64_t>(pc.pin_y[p]) + static_cast<uint64_t>(sy) * pc.pin_zs[p]), depth_of(p), p });
 			}
 			std::sort(sp.begin(), sp.end(), [](const Sorted& a, const Sorted& b) { return a.idx < b.idx; });
 			uint64_t n_pin_repr = 0;
 			for (const Sorted& s : sp) n_pin_repr += (s.depth >= cc_efficient_threshold);
-			put_le(out, n_pin_repr, num_pins_width);
+			put_at(o, n_pin_repr, num_pins_width);
 			uint64_t prev = 0;
 			bool first = true;
 			for (const Sorted& s : sp) {
 				if (s.depth < cc_efficient_threshold) continue;
-				put_le(out, first ? s.idx : s.idx - prev, index_width);
+				put_at(o, first ? s.idx : s.idx - prev, index_width);
 				prev = s.idx;
 				first = false;
 			}
-			for (const Sorted& s : sp) if (s.depth >= cc_efficient_threshold) put_le(out, s.depth, depth_width);
-			std::vector<uint32_t> ids;
+			for (const Sorted& s : sp) if (s.depth >= cc_efficient_threshold) put_at(o, s.depth, depth_width);
+			idv.clear();
 			for (const Sorted& s : sp) {
 				if (s.depth >= cc_efficient_threshold) continue;
-				for (uint64_t k = pc.pin_ids_off[s.pin]; k < pc.pin_ids_off[s.pin + 1]; k++) ids.push_back(pc.pin_ids[k]);
+				for (uint64_t k = ids_off[s.pin]; k < ids_off[s.pin + 1]; k++) idv.push_back(ids[k]);
 			}
-			std::sort(ids.begin(), ids.end());
-			put_le(out, ids.size(), num_pins_width);
-			for (size_t k = 0; k < ids.size(); k++) put_le(out, k ? static_cast<uint32_t>(ids[k] - ids[k - 1]) : ids[k], cc_label_width);
+			std::sort(idv.begin(), idv.end());
+			put_at(o, idv.size(), num_pins_width);
+			for (size_t k = 0; k < idv.size(); k++) put_at(o, k ? static_cast<uint32_t>(idv[k] - idv[k - 1]) : idv[k], cc_label_width);
+			if (o != bin.data() + head_bytes + rec_at[i + 1]) throw Error(CKL_ERR_RUNTIME, "crackle_amd: internal: pin record size");
 		}
 	});
-	{
-		size_t total = bin.size();
-		for (const auto& part : parts) total += part.size();
-		bin.reserve(total);
-		for (const auto& part : parts) bin.insert(bin.end(), part.begin(), part.end());
-	}
 	mark("section");
 	if (prof) fprintf(stderr, "[ckl pins cover ms]%s | components=%llu labels=%zu pins=%zu\n", marks.c_str(), static_cast<unsigned long long>(N), n_labels, P);
 	return bin;

@@ -18,6 +18,7 @@
 #pragma once
 #include "ckl_common.hpp"
 
+#include <functional>
 #include <vector>
 
 namespace ckl {
@@ -37,7 +38,16 @@ struct PinCandidates {
 	std::vector<uint32_t> pin_x, pin_y, pin_zs, pin_ze;
 	std::vector<uint64_t> pin_ids_off;    // [P + 1]
 	std::vector<uint32_t> pin_ids;        // component ids along each pin, z ascending
+	// The three large arrays may live in memory held by the caller instead (the pinned block the device arrays
+	// were copied into): when view_components is set, these are read and the vectors of the same name are not.
+	uint64_t view_components = 0;
+	const uint64_t* view_comp_label = nullptr;
+	const uint64_t* view_pin_ids_off = nullptr;
+	const uint32_t* view_pin_ids = nullptr;
 };
+
+// worker threads for host loops over components / labels: body(lo, hi) on disjoint ranges, errors rethrown
+void host_parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& body, size_t max_threads = 32);
 
 // The order-sensitive part (cover, background colour, section bytes) on the host.
 std::vector<uint8_t> pins_cover_host(

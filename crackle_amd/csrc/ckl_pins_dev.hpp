@@ -377,6 +377,64 @@ __global__ void __launch_bounds__(kPinBlock) k_pin_id_counts(const unsigned long
 }
 
 
+// ---- exclusive prefix sums of the id counts (uint32 counts -> uint64 offsets, n + 1 entries) in three launches:
+// totals of 2048-count pieces, their scan by one workgroup, the offsets
+constexpr uint32_t kPinScanItems = 8;
+constexpr uint32_t kPinScanPiece = kPinBlock * kPinScanItems;
+__device__ __forceinline__ unsigned long long pin_block_scan(unsigned long long mine, unsigned long long* s_wave, unsigned long long& total) {
+	// inclusive scan over the workgroup's threads; `total` = the workgroup's sum
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	unsigned long long v = mine;
+	for (uint32_t d = 1; d < 64u; d <<= 1) {
+		const unsigned long long o = __shfl_up(v, d);
+		if (lane >= d) v += o;
+	}
+	if (lane == 63u) s_wave[wave] = v;
+	__syncthreads();
+	unsigned long long base = 0, all = 0;
+	for (uint32_t w = 0; w < kPinBlock / 64u; w++) { if (w < wave) base += s_wave[w]; all += s_wave[w]; }
+	__syncthreads();
+	total = all;
+	return v + base;
+}
+__global__ void __launch_bounds__(kPinBlock) k_pin_scan_pieces(const uint32_t* __restrict__ count, uint64_t n, unsigned long long* __restrict__ piece_sum) {
+	__shared__ unsigned long long s_wave[kPinBlock / 64u];
+	const uint64_t at = static_cast<uint64_t>(blockIdx.x) * kPinScanPiece + static_cast<uint64_t>(threadIdx.x) * kPinScanItems;
+	unsigned long long mine = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < kPinScanItems; i++) if (at + i < n) mine += count[at + i];
+	unsigned long long total;
+	(void)pin_block_scan(mine, s_wave, total);
+	if (threadIdx.x == 0) piece_sum[blockIdx.x] = total;
+}
+// one workgroup: piece_sum[i] -> sum of the pieces in front of i; piece_sum[pieces] = everything
+__global__ void __launch_bounds__(kPinBlock) k_pin_scan_tops(unsigned long long* __restrict__ piece_sum, uint32_t pieces) {
+	__shared__ unsigned long long s_wave[kPinBlock / 64u];
+	unsigned long long carry = 0;
+	for (uint32_t i0 = 0; i0 < pieces; i0 += kPinBlock) {
+		const uint32_t i = i0 + threadIdx.x;
+		const unsigned long long mine = i < pieces ? piece_sum[i] : 0ull;
+		unsigned long long total;
+		const unsigned long long incl = pin_block_scan(mine, s_wave, total);
+		if (i < pieces) piece_sum[i] = carry + incl - mine;
+		carry += total;
+	}
+	if (threadIdx.x == 0) piece_sum[pieces] = carry;
+}
+__global__ void __launch_bounds__(kPinBlock) k_pin_scan_offsets(const uint32_t* __restrict__ count, uint64_t n, const unsigned long long* __restrict__ piece_sum, uint32_t pieces, unsigned long long* __restrict__ off /* [n + 1] */) {
+	__shared__ unsigned long long s_wave[kPinBlock / 64u];
+	const uint64_t at = static_cast<uint64_t>(blockIdx.x) * kPinScanPiece + static_cast<uint64_t>(threadIdx.x) * kPinScanItems;
+	uint32_t c[kPinScanItems];
+	unsigned long long mine = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < kPinScanItems; i++) { c[i] = at + i < n ? count[at + i] : 0u; mine += c[i]; }
+	unsigned long long total;
+	unsigned long long run = piece_sum[blockIdx.x] + pin_block_scan(mine, s_wave, total) - mine;
+#pragma unroll
+	for (uint32_t i = 0; i < kPinScanItems; i++) { if (at + i < n) off[at + i] = run; run += c[i]; }
+	if (blockIdx.x == 0 && threadIdx.x == 0) off[n] = piece_sum[pieces];
+}
+
 // The order in which the labels enter `pinsets` (src/pins.hpp:126-163) is that of their first column
 // run: per label the smallest first_any of its components, in an open-addressing table keyed by
 // label (the all-ones label cannot be a key: its minimum goes to max_first), then the occupied

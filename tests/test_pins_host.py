@@ -71,6 +71,30 @@ def test_pin_section_ties_and_many_labels(checker):
   assert _pin_section(L, checker, arr) == want
 
 
+def test_pin_section_tens_of_thousands_of_labels(checker):
+  """45 k labels: the host stage sorts in pieces on its worker threads and writes the labels' records
+  side by side at precomputed places; with and without the unordered_map of the background colour."""
+  import os
+  L = _lib.lib()
+  rng = np.random.default_rng(5)
+  small = rng.integers(1, 2**31, size=(150, 150, 2), dtype=np.int64)
+  arr = np.asfortranarray(np.kron(small, np.ones((2, 2, 3), dtype=np.int64)).astype(np.uint32))
+  arr[:, :, 0] = 7      # one label with many pins: a background colour without a tie
+  want = _want_section(checker, arr)
+  assert want is not None
+  assert _pin_section(L, checker, arr) == want
+  os.environ["CKL_PINS_BGCOLOR_MAP"] = "1"
+  try:
+    assert _pin_section(L, checker, arr) == want
+  finally:
+    del os.environ["CKL_PINS_BGCOLOR_MAP"]
+  os.environ["CKL_PINS_THREADS"] = "1"
+  try:
+    assert _pin_section(L, checker, arr) == want
+  finally:
+    del os.environ["CKL_PINS_THREADS"]
+
+
 def test_pin_host_argument_checks():
   L = _lib.lib()
   out, n = C.c_void_p(), C.c_uint64()

@@ -4,7 +4,7 @@ tag=$1
 root=$PWD
 cd /tmp && export TMPDIR=/tmp
 rm -rf $root/gpurun_out/${tag}_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o s -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $root/gpurun_out/${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o s -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline $CKL_BENCH_ARGS > $root/gpurun_out/${tag}_stats.log 2>&1
 cd $root
 python3 - "$tag" <<'PY'
 import csv, glob, sys
