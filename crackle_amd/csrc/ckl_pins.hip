@@ -19,6 +19,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <unistd.h>
 #include <functional>
 #include <thread>
 #include <unordered_map>
@@ -259,20 +262,77 @@ template PinCandidates pin_candidates_host<uint16_t>(const uint16_t*, const uint
 template PinCandidates pin_candidates_host<uint32_t>(const uint32_t*, const uint32_t*, int64_t, int64_t, int64_t, uint64_t);
 template PinCandidates pin_candidates_host<uint64_t>(const uint64_t*, const uint32_t*, int64_t, int64_t, int64_t, uint64_t);
 
+namespace {
+
+// Worker threads that stay: starting 32 threads costs 0.5-0.8 ms, and the pin stage runs some twenty parallel
+// regions per volume.  One region at a time; a caller that finds the pool taken (another encoder's region), or
+// that runs in a process forked after the pool was made, starts threads of its own as before.
+class HostPool {
+public:
+	static HostPool& get() { static HostPool* pool = new HostPool();  return *pool; }      // never destroyed: the workers wait for ever
+	size_t size() const { return n_workers; }
+	// job(t) for t in [0, want) on the workers; false: not run (pool taken or not ours)
+	bool run(size_t want, const std::function<void(size_t)>& job) {
+		if (want > n_workers || getpid() != pid) return false;
+		std::unique_lock<std::mutex> one(region, std::try_to_lock);
+		if (!one.owns_lock()) return false;
+		{
+			std::lock_guard<std::mutex> lock(m);
+			current = &job; n_want = want; remaining = want; generation++;
+		}
+		cv_work.notify_all();
+		std::unique_lock<std::mutex> lock(m);
+		cv_done.wait(lock, [&] { return remaining == 0; });
+		current = nullptr;
+		return true;
+	}
+private:
+	HostPool() : pid(getpid()) {
+		n_workers = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 32);
+		for (size_t t = 0; t < n_workers; t++) std::thread([this, t] { work(t); }).detach();
+	}
+	void work(size_t t) {
+		uint64_t seen = 0;
+		for (;;) {
+			const std::function<void(size_t)>* job = nullptr;
+			{
+				std::unique_lock<std::mutex> lock(m);
+				cv_work.wait(lock, [&] { return generation != seen; });
+				seen = generation;
+				if (t < n_want) job = current;
+			}
+			if (!job) continue;
+			(*job)(t);
+			std::lock_guard<std::mutex> lock(m);
+			if (--remaining == 0) cv_done.notify_all();
+		}
+	}
+	std::mutex m, region;
+	std::condition_variable cv_work, cv_done;
+	const std::function<void(size_t)>* current = nullptr;
+	size_t n_workers = 0, n_want = 0, remaining = 0;
+	uint64_t generation = 0;
+	pid_t pid;
+};
+
+}  // namespace
+
 void host_parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& body, size_t max_threads) {
 	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), max_threads);
 	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
 	const size_t want = std::min(nthreads, std::max<size_t>(1, n / std::max<size_t>(grain, 1)));
 	if (want <= 1) { body(0, n); return; }
-	std::vector<std::thread> pool;
 	std::vector<std::string> errors(want);
-	for (size_t t = 0; t < want; t++) {
-		pool.emplace_back([&, t]() {
-			try { body(n * t / want, n * (t + 1) / want); }
-			catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
-		});
+	const std::function<void(size_t)> job = [&](size_t t) {
+		try { body(n * t / want, n * (t + 1) / want); }
+		catch (const std::exception& e) { errors[t] = e.what(); if (errors[t].empty()) errors[t] = "error"; }
+		catch (...) { errors[t] = "error"; }
+	};
+	if (getenv("CKL_PINS_NO_POOL") || !HostPool::get().run(want, job)) {
+		std::vector<std::thread> pool;
+		for (size_t t = 0; t < want; t++) pool.emplace_back([&, t]() { job(t); });
+		for (auto& th : pool) th.join();
 	}
-	for (auto& th : pool) th.join();
 	for (auto& e : errors) if (!e.empty()) throw Error(CKL_ERR_RUNTIME, e);
 }
 

@@ -116,11 +116,15 @@ __global__ void __launch_bounds__(kPinRowBlock) k_pin_dedup(const LABEL* __restr
 }
 
 // ---- k_pin_dedup, one wavefront per row (sz <= 64 * K) ----
-// Lane l holds the labels of slices 64 k + l of the current column (loaded one column ahead);
-// a ballot of "the label changes above me" gives the column's runs, which the wave then walks
-// uniformly.  The two label tables live in registers, one entry per lane and k: a lookup is a
-// compare + ballot, an append a predicated move.  No LDS, no hashing, no dependent memory
-// round trip per run; the only stores are lane 0's kept marks.
+// Lane l holds the labels of slices 64 k + l of the current column (loaded one column ahead).  A run lives in the
+// lane of its LAST slice: a ballot of "the label changes above me" marks the runs, the highest such lane below
+// gives a run its first slice.  add_pin (src/pins.hpp:134-160) compares a run with its label's last pin in the
+// previous column: the previous column's kept runs are broadcast one by one (readlane) and every lane compares
+// its own label — all runs of the column are decided together, ~30 broadcasts per column instead of a dependent
+// chain of table lookups per run (the first version walked the runs one at a time: 42.6 ms for 2048 x 2048 x 256,
+// the wavefronts of 2048 rows being all the parallelism there is).  A label with several runs in one column —
+// rare — is put right afterwards in run order: once one of its runs is kept the later ones are plain appends.
+// No LDS, no hashing; the stores are the kept marks, one lane per run.
 template <typename LABEL>
 __device__ __forceinline__ LABEL wave_read(LABEL v, uint32_t lane) {
 	if constexpr (sizeof(LABEL) == 8) {
@@ -132,84 +136,138 @@ __device__ __forceinline__ LABEL wave_read(LABEL v, uint32_t lane) {
 }
 
 constexpr uint32_t kPinWaves = 4;      // rows per workgroup
+constexpr uint32_t kPinDupBits = 12;   // slots of a wavefront's duplicate-label table (4096 x 2 bytes)
 
 // grid = ceil(sy / 4) x 256
-template <typename LABEL, int K>
+// G: columns fetched by one load (4 when the rows allow it: labels aligned to 4 of them and sx a multiple of 4).
+// A lane's loads of one column lie in 64 K different slices, megabytes apart: with G = 4 a quarter of the requests.
+template <typename LABEL, int K, int G>
 __global__ void __launch_bounds__(64 * kPinWaves) k_pin_dedup_wave(const LABEL* __restrict__ labels, PinVolume v) {
+	struct alignas(G * sizeof(LABEL)) Group { LABEL c[G]; };
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t y = blockIdx.x * kPinWaves + (threadIdx.x >> 6);
 	if (y >= v.sy) return;
 	const uint64_t row = static_cast<uint64_t>(y) * v.sx;
-	LABEL lab[K], nlab[K];
-	LABEL cur_lab[K], prev_lab[K];
-	uint32_t cur_zz[K], prev_zz[K];      // z_s | z_e << 16
-	uint32_t n_prev = 0;
+	const unsigned long long below_me = (1ull << lane) - 1ull;
+	__shared__ uint16_t s_dup[kPinWaves << kPinDupBits];
+	uint16_t* dup_table = s_dup + ((threadIdx.x >> 6) << kPinDupBits);
+	LABEL lab[K], prev_lab[K];
+	Group grp[K], ngrp[K];
+	uint32_t prev_zz[K];                       // z_s | z_e << 16 of the run that ends in this lane
+	unsigned long long prev_kept[K];           // lanes of the previous column's kept runs (uniform)
 #pragma unroll
 	for (int k = 0; k < K; k++) {
-		nlab[k] = labels[row + v.sxy * min(static_cast<uint32_t>(k) * 64u + lane, v.sz - 1u)];
-		cur_lab[k] = prev_lab[k] = 0; cur_zz[k] = prev_zz[k] = 0;
+		ngrp[k] = *reinterpret_cast<const Group*>(labels + row + v.sxy * min(static_cast<uint32_t>(k) * 64u + lane, v.sz - 1u));
+		prev_lab[k] = 0; prev_zz[k] = 0; prev_kept[k] = 0;
 	}
-	for (uint32_t x = 0; x < v.sx; x++) {
+	for (uint32_t x0 = 0; x0 < v.sx; x0 += G) {
+#pragma unroll
+		for (int k = 0; k < K; k++) grp[k] = ngrp[k];
+		{
+			const uint64_t ncol = row + min(x0 + G, v.sx - G);      // (the last group again: not used)
+#pragma unroll
+			for (int k = 0; k < K; k++) ngrp[k] = *reinterpret_cast<const Group*>(labels + ncol + v.sxy * min(static_cast<uint32_t>(k) * 64u + lane, v.sz - 1u));
+		}
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+		const uint32_t x = x0 + g;
+		if (x >= v.sx) break;
 		const uint64_t col = row + x;
 #pragma unroll
-		for (int k = 0; k < K; k++) lab[k] = nlab[k];
-		{
-			const uint64_t ncol = row + min(x + 1u, v.sx - 1u);
-#pragma unroll
-			for (int k = 0; k < K; k++) nlab[k] = labels[ncol + v.sxy * min(static_cast<uint32_t>(k) * 64u + lane, v.sz - 1u)];
-		}
-		uint32_t n_cur = 0, z_s = 0;
+		for (int k = 0; k < K; k++) lab[k] = grp[k].c[g];
+		// the column's runs
+		unsigned long long ends_m[K];
+		uint32_t zz[K];
+		bool ends[K];
+		int carry_end = -1;
 #pragma unroll
 		for (int k = 0; k < K; k++) {
 			const uint32_t z = static_cast<uint32_t>(k) * 64u + lane;
 			// label of the slice above: the next lane, or lane 0 of the next register
 			LABEL up = __shfl_down(lab[k], 1);
 			if (k + 1 < K) { const LABEL first_up = wave_read(lab[k + 1 < K ? k + 1 : k], 0); if (lane == 63u) up = first_up; }
-			const bool ends = z < v.sz && (z == v.sz - 1u || up != lab[k]);
-			unsigned long long m = __ballot(ends);
-			while (m) {
-				const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
-				m &= m - 1ull;
-				const uint32_t z_e = static_cast<uint32_t>(k) * 64u + b;
-				const LABEL L = wave_read(lab[k], b);
-				const uint32_t zz = z_s | (z_e << 16);
-				// an earlier run of this column is L's last pin: plain append, it becomes the last
-				bool in_cur = false;
+			ends[k] = z < v.sz && (z == v.sz - 1u || up != lab[k]);
+			const unsigned long long m = __ballot(ends[k]);
+			ends_m[k] = m;
+			const unsigned long long below = m & below_me;
+			const int prev_end = below ? k * 64 + 63 - __clzll(static_cast<long long>(below)) : carry_end;
+			zz[k] = static_cast<uint32_t>(prev_end + 1) | (z << 16);
+			if (m) carry_end = k * 64 + 63 - __clzll(static_cast<long long>(m));
+		}
+		// the label's last pin of the previous column, if it has one there (kPinNoRun: none; a run's word is z_s | z_e << 16
+		// with z_e < 1024)
+		constexpr uint32_t kPinNoRun = 0xFFFFFFFFu;
+		uint32_t found[K];
 #pragma unroll
-				for (int j = 0; j < K; j++) {
-					if (static_cast<uint32_t>(j) * 64u < n_cur) {
-						const bool hit = static_cast<uint32_t>(j) * 64u + lane < n_cur && cur_lab[j] == L;
-						if (__ballot(hit)) { in_cur = true; if (hit) cur_zz[j] = zz; }
-					}
-				}
-				bool keep = true;
-				if (!in_cur) {
+		for (int k = 0; k < K; k++) found[k] = kPinNoRun;
 #pragma unroll
-					for (int j = 0; j < K; j++) {
-						if (static_cast<uint32_t>(j) * 64u < n_prev) {
-							const bool hit = static_cast<uint32_t>(j) * 64u + lane < n_prev && prev_lab[j] == L;
-							const unsigned long long hm = __ballot(hit);
-							if (hm) {
-								const uint32_t lzz = __builtin_amdgcn_readlane(prev_zz[j], static_cast<uint32_t>(__ffsll(static_cast<long long>(hm))) - 1u);
-								const uint32_t lz_s = lzz & 0xFFFFu, lz_e = lzz >> 16;
-								if (lz_s <= z_s && lz_e >= z_e) keep = false;                 // covered by the neighbour: dropped
-								else if (lz_s >= z_s && lz_e <= z_e && lane == 0) v.mark[col - 1u + v.sxy * lz_s] = 0;      // covers the neighbour: takes its place
-							}
-						}
-					}
-					if (keep) {
+		for (int kp = 0; kp < K; kp++) {
+			unsigned long long pm = prev_kept[kp];
+			while (pm) {
+				const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(pm))) - 1u;
+				pm &= pm - 1ull;
+				const LABEL PL = wave_read(prev_lab[kp], b);
+				const uint32_t pzz = __builtin_amdgcn_readlane(prev_zz[kp], b);
 #pragma unroll
-						for (int j = 0; j < K; j++) if (n_cur == static_cast<uint32_t>(j) * 64u + lane) { cur_lab[j] = L; cur_zz[j] = zz; }
-						n_cur++;
-					}
-				}
-				if (keep && lane == 0) v.mark[col + v.sxy * z_s] = static_cast<uint16_t>(z_e - z_s + 1u);
-				z_s = z_e + 1u;
+				for (int k = 0; k < K; k++) found[k] = lab[k] == PL ? pzz : found[k];
 			}
 		}
+		// decisions as lane masks (uniform): kept runs, runs that take their neighbour's place
+		unsigned long long keepm[K], replm[K];
+		bool maybe_dup = false;
 #pragma unroll
-		for (int k = 0; k < K; k++) { prev_lab[k] = cur_lab[k]; prev_zz[k] = cur_zz[k]; }
-		n_prev = n_cur;
+		for (int k = 0; k < K; k++) {
+			const uint32_t z_s = zz[k] & 0xFFFFu, z_e = zz[k] >> 16, lz_s = found[k] & 0xFFFFu, lz_e = found[k] >> 16;
+			const bool has = found[k] != kPinNoRun;
+			const bool covered = has && lz_s <= z_s && lz_e >= z_e;                   // covered by the neighbour: dropped
+			keepm[k] = __ballot(ends[k] && !covered);
+			replm[k] = __ballot(ends[k] && !covered && has && lz_s >= z_s && lz_e <= z_e);      // covers the neighbour: takes its place
+			// does a label have several runs in this column?  Every run leaves its place in a hashed table and
+			// looks at what stays there: two runs of one label meet in one slot, and one of them sees the other
+			if (ends[k]) dup_table[pin_hash(static_cast<uint64_t>(lab[k])) >> (32 - kPinDupBits)] = static_cast<uint16_t>(k * 64 + lane);
+		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			const bool other = ends[k] && dup_table[pin_hash(static_cast<uint64_t>(lab[k])) >> (32 - kPinDupBits)] != static_cast<uint16_t>(k * 64 + lane);
+			maybe_dup = maybe_dup || __ballot(other) != 0ull;
+		}
+		__builtin_amdgcn_wave_barrier();
+		// a label with several runs in this column (or two labels that met in the table): once one of the label's runs
+		// is kept it is the label's last pin, in THIS column, and the later ones are appended without a look at the neighbour
+		if (maybe_dup) {
+#pragma unroll
+			for (int kq = 0; kq < K; kq++) {
+				unsigned long long qm = ends_m[kq];
+				while (qm) {
+					const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(qm))) - 1u;
+					qm &= qm - 1ull;
+					if (!((keepm[kq] >> b) & 1ull)) continue;
+					const LABEL QL = wave_read(lab[kq], b);
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						if (k < kq) continue;
+						const unsigned long long later = k > kq ? ~0ull : (b == 63u ? 0ull : ~0ull << (b + 1u));
+						const unsigned long long same = __ballot(lab[k] == QL) & ends_m[k] & later;
+						keepm[k] |= same;
+						replm[k] &= ~same;
+					}
+				}
+			}
+		}
+		bool keep[K], repl[K];
+#pragma unroll
+		for (int k = 0; k < K; k++) { keep[k] = (keepm[k] >> lane) & 1ull; repl[k] = (replm[k] >> lane) & 1ull; }
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			const uint32_t z_s = zz[k] & 0xFFFFu, z_e = zz[k] >> 16;
+			if (repl[k]) v.mark[col - 1u + v.sxy * (found[k] & 0xFFFFu)] = 0;
+			if (keep[k]) v.mark[col + v.sxy * z_s] = static_cast<uint16_t>(z_e - z_s + 1u);
+			prev_kept[k] = keepm[k];
+			prev_lab[k] = lab[k];
+			prev_zz[k] = zz[k];
+		}
+		}
 	}
 }
 

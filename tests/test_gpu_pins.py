@@ -60,6 +60,8 @@ CASES = {
   "one_x": lambda: _blocks((1, 64, 12), (1, 5, 2), 3, 9),
   "tall_k4": lambda: _blocks((9, 7, 200), (2, 2, 3), 3, 12),             # label registers per lane: 4, 8, 16
   "tall_k8": lambda: _blocks((6, 5, 400), (2, 1, 2), 3, 13, np.uint64, offset=1 << 50),
+  "tall_k8_groups": lambda: _blocks((8, 5, 400), (2, 1, 2), 3, 16, np.uint64, offset=1 << 50),      # sx a multiple of 4: four columns per load
+  "wide_groups_u8": lambda: _blocks((64, 9, 70), (3, 2, 4), 5, 17, np.uint8),
   "tall_k16": lambda: _blocks((6, 6, 900), (2, 2, 5), 4, 14, np.uint8),
   "tall_thread_rows": lambda: _blocks((4, 3, 1100), (2, 1, 3), 3, 15),    # above 1024 slices: the thread-per-row kernel
   "voronoi_deep": lambda: synth.as_numpy_f(synth.voronoi_labels((96, 64, 80), np.uint32, seed=10, cell=(24, 24, 12))),
@@ -96,6 +98,18 @@ def test_thread_per_row_dedup_equals_oracle(name, checker, monkeypatch):
   monkeypatch.setenv("CKL_PINS_ROW_THREADS", "1")
   arr = CASES[name]()
   assert crackle_amd.compress(arr, allow_pins=1) == checker.compress(arr, allow_pins=True)
+
+
+@pytest.mark.parametrize("name", ["voronoi_deep", "voronoi_modulus", "tall_k8"])
+def test_dedup_one_column_per_load_equals_oracle(name, checker, monkeypatch):
+  """k_pin_dedup_wave fetches four columns per load when sx is a multiple of four; the one-column form
+  on the same volumes (and the host-side bookkeeping of the chosen runs instead of the device's)."""
+  monkeypatch.setenv("CKL_PINS_COLUMN_LOADS", "1")
+  arr = CASES[name]()
+  want = checker.compress(arr, allow_pins=True)
+  assert crackle_amd.compress(arr, allow_pins=1) == want
+  monkeypatch.setenv("CKL_PINS_HOST_BOOKKEEPING", "1")
+  assert crackle_amd.compress(arr, allow_pins=1) == want
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
