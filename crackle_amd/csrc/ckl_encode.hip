@@ -2012,40 +2012,49 @@ std::vector<uint8_t> pins_section_from_device(
 	const uint64_t total = download(d_offsets + N, 1, s)[0];
 	auto up64 = [](uint64_t b) { return (b + 63) & ~static_cast<uint64_t>(63); };
 	const uint64_t o_label = 0, o_choice = o_label + up64(N * 8), o_off = o_choice + up64(N * 8), o_ze = o_off + up64((N + 1) * 8), o_ids = o_ze + up64(N * 4);
-	const uint64_t bytes = o_ids + up64(std::max<uint64_t>(total, 1) * 4);
-	struct Block { uint8_t* p = nullptr; ~Block() { if (p) host_out_free(p); } } blk;
+	const uint64_t o_pins = o_ids + up64(std::max<uint64_t>(total, 1) * 4);      // comp_pin, pin_x, pin_y, pin_zs, pin_ze: written by the host, in the same cached block (no page faults, no zero fill)
+	const uint64_t bytes = o_pins + 5 * up64(N * 4);
+	struct Block { uint8_t* p = nullptr; hipStream_t s = nullptr; ~Block() { if (p) { (void)hipStreamSynchronize(s); host_out_free(p); } } } blk;      // (copies may still be on their way when an error unwinds)
+	blk.s = s;
 	blk.p = static_cast<uint8_t*>(host_out_alloc(bytes));
 	CKL_HIP(hipMemcpyAsync(blk.p + o_label, d_comp_label, N * 8, hipMemcpyDeviceToHost, s));
 	CKL_HIP(hipMemcpyAsync(blk.p + o_choice, d_choice, N * 8, hipMemcpyDeviceToHost, s));
 	CKL_HIP(hipMemcpyAsync(blk.p + o_off, d_offsets, (N + 1) * 8, hipMemcpyDeviceToHost, s));
 	CKL_HIP(hipMemcpyAsync(blk.p + o_ze, d_ze_plus1, N * 4, hipMemcpyDeviceToHost, s));
 	if (total) CKL_HIP(hipMemcpyAsync(blk.p + o_ids, d_ids, total * 4, hipMemcpyDeviceToHost, s));
-	pc.comp_pin.resize(N); pc.pin_x.resize(N); pc.pin_y.resize(N); pc.pin_zs.resize(N); pc.pin_ze.resize(N);      // (first touched by the threads below)
-	CKL_HIP(hipStreamSynchronize(s));
-	HT_MARK("p:d2h");
-	const uint64_t* chosen = reinterpret_cast<const uint64_t*>(blk.p + o_choice);
-	const uint32_t* ze_plus1 = reinterpret_cast<const uint32_t*>(blk.p + o_ze);
-	const uint64_t usx = static_cast<uint64_t>(sx), usz = static_cast<uint64_t>(sz);
-	host_parallel_for(N, 65536, [&](size_t lo, size_t hi) {
-		for (size_t c = lo; c < hi; c++) {
-			if (chosen[c] == kPinNoKey) { pc.comp_pin[c] = kPinNone; pc.pin_x[c] = pc.pin_y[c] = pc.pin_zs[c] = pc.pin_ze[c] = 0; continue; }
-			if (ze_plus1[c] == 0) throw Error(CKL_ERR_RUNTIME, "crackle_amd: a chosen pin lies in no rank's rows");
-			pc.comp_pin[c] = static_cast<uint32_t>(c);
-			const uint64_t col = chosen[c] / usz;
-			pc.pin_zs[c] = static_cast<uint32_t>(chosen[c] % usz);
-			pc.pin_ze[c] = ze_plus1[c] - 1u;
-			pc.pin_x[c] = static_cast<uint32_t>(col % usx);
-			pc.pin_y[c] = static_cast<uint32_t>(col / usx);
-		}
-	});
+	uint32_t* const h_comp_pin = reinterpret_cast<uint32_t*>(blk.p + o_pins);
+	uint32_t* const h_x = reinterpret_cast<uint32_t*>(blk.p + o_pins + up64(N * 4));
+	uint32_t* const h_y = reinterpret_cast<uint32_t*>(blk.p + o_pins + 2 * up64(N * 4));
+	uint32_t* const h_zs = reinterpret_cast<uint32_t*>(blk.p + o_pins + 3 * up64(N * 4));
+	uint32_t* const h_ze = reinterpret_cast<uint32_t*>(blk.p + o_pins + 4 * up64(N * 4));
+	pc.view_comp_pin = h_comp_pin; pc.view_pin_x = h_x; pc.view_pin_y = h_y; pc.view_pin_zs = h_zs; pc.view_pin_ze = h_ze;
 	pc.view_components = N;
 	pc.view_comp_label = reinterpret_cast<const uint64_t*>(blk.p + o_label);
 	pc.view_pin_ids_off = reinterpret_cast<const uint64_t*>(blk.p + o_off);
 	pc.view_pin_ids = reinterpret_cast<const uint32_t*>(blk.p + o_ids);
-	HT_MARK("p:keys");
+	HT_MARK("p:enqueue");
+	const uint64_t* chosen = reinterpret_cast<const uint64_t*>(blk.p + o_choice);
+	const uint32_t* ze_plus1 = reinterpret_cast<const uint32_t*>(blk.p + o_ze);
+	const uint64_t usx = static_cast<uint64_t>(sx), usz = static_cast<uint64_t>(sz);
+	// the copies travel while the cover builds its table of the labels; it calls back when it needs the arrays
+	auto arrays_ready = [&]() {
+	CKL_HIP(hipStreamSynchronize(s));
+	host_parallel_for(N, 65536, [&](size_t lo, size_t hi) {
+		for (size_t c = lo; c < hi; c++) {
+			if (chosen[c] == kPinNoKey) { h_comp_pin[c] = kPinNone; h_x[c] = h_y[c] = h_zs[c] = h_ze[c] = 0; continue; }
+			if (ze_plus1[c] == 0) throw Error(CKL_ERR_RUNTIME, "crackle_amd: a chosen pin lies in no rank's rows");
+			h_comp_pin[c] = static_cast<uint32_t>(c);
+			const uint64_t col = chosen[c] / usz;
+			h_zs[c] = static_cast<uint32_t>(chosen[c] % usz);
+			h_ze[c] = ze_plus1[c] - 1u;
+			h_x[c] = static_cast<uint32_t>(col % usx);
+			h_y[c] = static_cast<uint32_t>(col / usx);
+		}
+	});
+	};
 	Header h;
 	h.sx = static_cast<uint32_t>(sx); h.sy = static_cast<uint32_t>(sy); h.sz = static_cast<uint32_t>(sz);
-	return pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
+	return pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor, arrays_ready);
 }
 
 // The whole pin stage of a volume that one device holds: the passes of pin_candidates_device, then the chosen

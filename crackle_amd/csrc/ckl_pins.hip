@@ -288,7 +288,7 @@ public:
 	}
 private:
 	HostPool() : pid(getpid()) {
-		n_workers = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 32);
+		n_workers = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
 		for (size_t t = 0; t < n_workers; t++) std::thread([this, t] { work(t); }).detach();
 	}
 	void work(size_t t) {
@@ -339,15 +339,22 @@ void host_parallel_for(size_t n, size_t grain, const std::function<void(size_t, 
 std::vector<uint8_t> pins_cover_host(
 	const PinCandidates& pc, int64_t sx, int64_t sy, int64_t sz,
 	const std::vector<uint32_t>& ncomp, uint64_t n_total,
-	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor
+	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor,
+	const std::function<void()>& components_ready
 ) {
 	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
 	const bool viewed = pc.view_components != 0;
 	const uint64_t N = viewed ? pc.view_components : pc.comp_label.size();
-	const size_t P = pc.pin_x.size();
+	const bool pins_viewed = viewed && pc.view_comp_pin;
+	const size_t P = pins_viewed ? static_cast<size_t>(N) : pc.pin_x.size();
 	const uint64_t* const comp_label = viewed ? pc.view_comp_label : pc.comp_label.data();
 	const uint64_t* const ids_off = viewed ? pc.view_pin_ids_off : pc.pin_ids_off.data();
 	const uint32_t* const ids = viewed ? pc.view_pin_ids : pc.pin_ids.data();
+	const uint32_t* const comp_pin = pins_viewed ? pc.view_comp_pin : pc.comp_pin.data();
+	const uint32_t* const pin_x = pins_viewed ? pc.view_pin_x : pc.pin_x.data();
+	const uint32_t* const pin_y = pins_viewed ? pc.view_pin_y : pc.pin_y.data();
+	const uint32_t* const pin_zs = pins_viewed ? pc.view_pin_zs : pc.pin_zs.data();
+	const uint32_t* const pin_ze = pins_viewed ? pc.view_pin_ze : pc.pin_ze.data();
 	const bool prof = getenv("CKL_PROFILE") != nullptr;
 	auto t_last = std::chrono::steady_clock::now();
 	std::string marks;
@@ -359,13 +366,13 @@ std::vector<uint8_t> pins_cover_host(
 		marks += buf;
 		t_last = now;
 	};
-	if (pc.comp_pin.size() != N || (!viewed && pc.pin_ids_off.size() != P + 1) || (viewed && (!comp_label || !ids_off || !ids))) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
+	if ((!pins_viewed && pc.comp_pin.size() != N) || (pins_viewed && (!pin_x || !pin_y || !pin_zs || !pin_ze)) || (!viewed && pc.pin_ids_off.size() != P + 1) || (viewed && (!comp_label || !ids_off || !ids))) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
 	if (pc.label_value.empty() && pc.comp_first.size() != N) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
 
 	// worker threads for the per-label phases (labels are independent of each other)
-	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 32);
+	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
 	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
-	auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) { host_parallel_for(n, grain, body, 32); };
+	auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) { host_parallel_for(n, grain, body, 64); };
 
 	// sort in pieces on the worker threads, then merge the pieces pairwise
 	auto parallel_sort = [&](auto first, auto last, auto less) {
@@ -406,6 +413,7 @@ std::vector<uint8_t> pins_cover_host(
 		}
 	}
 	mark("pinsets");
+	if (components_ready) { components_ready(); mark("arrays"); }
 
 	// ---- components by label (ascending id within a label = linear voxel order, the insertion
 	// order of compute_multiverse, src/pins.hpp:165-198) ----
@@ -417,20 +425,43 @@ std::vector<uint8_t> pins_cover_host(
 			comp_li[c] = pinsets.vals[s];
 		}
 	});
+	// (a counting sort by label, stable in the component id; in T pieces of the components, each with its own counts)
 	std::vector<uint64_t> li_at(n_labels + 1, 0);
-	for (uint64_t c = 0; c < N; c++) li_at[comp_li[c] + 1]++;
-	for (size_t l = 0; l < n_labels; l++) li_at[l + 1] += li_at[l];
 	std::vector<uint32_t> li_comp(N);
 	{
-		std::vector<uint64_t> fill(li_at.begin(), li_at.end() - 1);
-		for (uint64_t c = 0; c < N; c++) li_comp[fill[comp_li[c]]++] = static_cast<uint32_t>(c);
+		const size_t T = (N >= (1u << 14) && n_labels <= (1u << 22)) ? std::min<size_t>(nthreads, 8) : 1;
+		std::vector<uint32_t> cnt(T * n_labels, 0);      // then: where piece t puts its next component of label l
+		parallel_for(T, 1, [&](size_t lo, size_t hi) {
+			for (size_t t = lo; t < hi; t++) {
+				uint32_t* mine = cnt.data() + t * n_labels;
+				for (uint64_t c = N * t / T; c < N * (t + 1) / T; c++) mine[comp_li[c]]++;
+			}
+		});
+		for (size_t l = 0; l < n_labels; l++) {
+			uint64_t tot = 0;
+			for (size_t t = 0; t < T; t++) tot += cnt[t * n_labels + l];
+			li_at[l + 1] = li_at[l] + tot;
+		}
+		if (li_at[n_labels] != N || N > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: internal: component counts by label");
+		parallel_for(n_labels, 4096, [&](size_t lo, size_t hi) {
+			for (size_t l = lo; l < hi; l++) {
+				uint32_t at = static_cast<uint32_t>(li_at[l]);
+				for (size_t t = 0; t < T; t++) { const uint32_t n = cnt[t * n_labels + l]; cnt[t * n_labels + l] = at; at += n; }
+			}
+		});
+		parallel_for(T, 1, [&](size_t lo, size_t hi) {
+			for (size_t t = lo; t < hi; t++) {
+				uint32_t* mine = cnt.data() + t * n_labels;
+				for (uint64_t c = N * t / T; c < N * (t + 1) / T; c++) li_comp[mine[comp_li[c]]++] = static_cast<uint32_t>(c);
+			}
+		});
 	}
 	mark("universe");
 
 	// ---- per label: the universe (a robin-hood flat set, filled in ascending id) and
 	// find_suboptimal_pins (src/pins.hpp:300-346).  A label takes at most one pin per component: its
 	// pins, in the order taken, go to chosen[li_at[li] ...] (no vector per label: 143 k labels at C4) ----
-	auto depth_of = [&](uint32_t p) { return static_cast<uint64_t>(pc.pin_ze[p] - pc.pin_zs[p]); };
+	auto depth_of = [&](uint32_t p) { return static_cast<uint64_t>(pin_ze[p] - pin_zs[p]); };
 	std::vector<uint32_t> chosen(N);
 	std::vector<uint32_t> n_chosen(n_labels, 0);
 	std::vector<uint64_t> depth_sum(n_labels, 0), depth_max(n_labels, 0);
@@ -449,7 +480,7 @@ std::vector<uint8_t> pins_cover_host(
 				size_t us;
 				if (!uni.first(us, cursor)) break;
 				const uint64_t picked = uni.keys[us];
-				const uint32_t p = pc.comp_pin[picked];
+				const uint32_t p = comp_pin[picked];
 				if (p == kPinNone) { uni.erase(picked); continue; }   // cannot happen: every component lies on a kept column run
 				const size_t before = uni.num;
 				for (uint64_t k = ids_off[p]; k < ids_off[p + 1]; k++) uni.erase(ids[k]);
@@ -559,7 +590,7 @@ std::vector<uint8_t> pins_cover_host(
 			sp.clear();
 			for (uint32_t k = 0; k < n_chosen[li]; k++) {
 				const uint32_t p = v[k];
-				sp.push_back({ static_cast<uint64_t>(pc.pin_x[p]) + static_cast<uint64_t>(sx) * (static_cast<uint64_t>(pc.pin_y[p]) + static_cast<uint64_t>(sy) * pc.pin_zs[p]), depth_of(p), p });
+				sp.push_back({ static_cast<uint64_t>(pin_x[p]) + static_cast<uint64_t>(sx) * (static_cast<uint64_t>(pin_y[p]) + static_cast<uint64_t>(sy) * pin_zs[p]), depth_of(p), p });
 			}
 			std::sort(sp.begin(), sp.end(), [](const Sorted& a, const Sorted& b) { return a.idx < b.idx; });
 			uint64_t n_pin_repr = 0;

@@ -44,16 +44,27 @@ struct PinCandidates {
 	const uint64_t* view_comp_label = nullptr;
 	const uint64_t* view_pin_ids_off = nullptr;
 	const uint32_t* view_pin_ids = nullptr;
+	// likewise the per-pin arrays of a caller whose pins are the components' own choices (P = N): comp_pin, pin_x,
+	// pin_y, pin_zs, pin_ze, each view_components entries
+	const uint32_t* view_comp_pin = nullptr;
+	const uint32_t* view_pin_x = nullptr;
+	const uint32_t* view_pin_y = nullptr;
+	const uint32_t* view_pin_zs = nullptr;
+	const uint32_t* view_pin_ze = nullptr;
 };
 
 // worker threads for host loops over components / labels: body(lo, hi) on disjoint ranges, errors rethrown
-void host_parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& body, size_t max_threads = 32);
+void host_parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& body, size_t max_threads = 64);
 
 // The order-sensitive part (cover, background colour, section bytes) on the host.
 std::vector<uint8_t> pins_cover_host(
 	const PinCandidates& pc, int64_t sx, int64_t sy, int64_t sz,
 	const std::vector<uint32_t>& ncomp, uint64_t n_total,
-	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor);
+	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor,
+	const std::function<void()>& components_ready = std::function<void()>());
+// components_ready: called once the labels' table (`pinsets`, from label_value / label_first alone) is built and
+// before anything per component or per pin is read — a caller whose large arrays are still on their way from the
+// device waits for them there (and fills comp_pin, pin_x ... pin_ze, whose sizes must be final beforehand).
 
 // PinCandidates from host volumes with the reference's own loops (add_pin vectors): the
 // CPU statement the device passes are tested against, and the sharded codec's whole-volume
