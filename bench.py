@@ -441,6 +441,10 @@ def main():
       binary = codec.compress(vol, (sx, sy, sz), markov_model_order=args.markov, allow_pins=bool(args.pins))   # merged stream on rank 0
       barrier()
     t1 = time.perf_counter()
+    if os.environ.get("CKL_BENCH_PENDING"):      # measuring: device work still pending when the encoder returns (shifts it into encode_ms)
+      torch.cuda.synchronize()
+      print(f"[bench] device work pending after the encode: {(time.perf_counter() - t1) * 1e3:.2f} ms", file=sys.stderr)
+      t1 = time.perf_counter()
     # decode leg: compressed bytes resident in HBM -> labels resident in HBM,
     # ckl_decoder_create_device (header / z-index / label-section head read back, descriptors, scratch)
     # + ckl_decoder_run

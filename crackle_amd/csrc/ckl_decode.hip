@@ -35,6 +35,7 @@
 #include "ckl_runs.hpp"
 #include "ckl_strips.hpp"
 #include "ckl_contours.hpp"
+#include "ckl_pins.hpp"
 
 #include <algorithm>
 #include <deque>
@@ -2585,6 +2586,8 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	d.d_crc_acc.ensure(d.nslices);
 
 	// label section layout (labels.hpp:424-451, 453-617), parsed once
+	struct PinBlock { uint8_t* p = nullptr; hipStream_t s = nullptr; ~PinBlock() { if (p) { (void)hipStreamSynchronize(s); host_out_free(p); } } } pin_block;      // the pin tables on their way to the device
+	pin_block.s = s;
 	const uint8_t* lb = buf + hb + gib;
 	const uint64_t nlb = h.num_label_bytes;
 	const int sw = h.stored_data_width;
@@ -2664,44 +2667,90 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 		const uint8_t combined = lb[offset++];
 		const int npw = 1 << (combined & 3), dw = 1 << ((combined >> 2) & 3), ccw = 1 << ((combined >> 4) & 3);
 		const int iw = h.pin_index_width();
-		std::vector<uint64_t> pin_index, pin_depth, pin_label, pin_work_off, ccl_id, ccl_label;
-		const uint64_t comp_right = comp_prefix[ze];
-		uint64_t i = offset, work = 0;
-		for (uint64_t label = 0; label < d.num_unique; label++) {
-			if (i + npw > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
-			const uint64_t lv = read_stored(h, lb, d.uniq_offset + label * sw);
-			const uint64_t num_pins = rd_le(lb + i, npw); i += npw;
-			if (num_pins > nlb || i + num_pins * static_cast<uint64_t>(iw + dw) + npw > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
-			uint64_t idx = 0;
-			for (uint64_t j = 0; j < num_pins; j++) {
-				idx += rd_le(lb + i + j * iw, iw);
-				const uint64_t depth = rd_le(lb + i + num_pins * iw + j * dw, dw);
-				const int64_t pin_z = static_cast<int64_t>(idx / d.sxy);
-				const int64_t a = std::max<int64_t>(pin_z, zs);
-				const int64_t b = std::min<int64_t>(pin_z + static_cast<int64_t>(depth) + 1, ze);
-				if (idx >= d.sxy * h.sz || b <= a) continue;   // pin does not touch the decoded range
-				pin_index.push_back(idx); pin_depth.push_back(depth); pin_label.push_back(lv);
-				pin_work_off.push_back(work);
-				work += static_cast<uint64_t>(b - a);
-			}
-			i += num_pins * static_cast<uint64_t>(iw + dw);
-			const uint64_t num_cc = rd_le(lb + i, npw); i += npw;
-			if (num_cc > nlb || i + num_cc * static_cast<uint64_t>(ccw) > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
-			uint64_t id = 0;
-			for (uint64_t j = 0; j < num_cc; j++) {
-				id = (id + rd_le(lb + i, ccw)) & 0xFFFFFFFFull; i += ccw;
-				if (id >= d.comp_left && id < comp_right) { ccl_id.push_back(id); ccl_label.push_back(lv); }
+		// The records are of variable length: one sequential pass finds where each label's record starts (two reads
+		// per label), then the labels are decoded side by side on the worker threads into one pinned block
+		// (host_out_alloc: cached) that is uploaded as it stands.  Nothing is filtered out on the host: a pin that
+		// does not touch the decoded slices gets no work items (k_label_map_pins' search for the pin of a work item
+		// takes the LAST pin that starts at or before it, so pins without work are never found), and
+		// k_label_map_ccids checks the ids' range itself.  (C4, 1.6 M pins + ids: 42 ms -> a few, serial with six
+		// growing vectors and pageable uploads before.)
+		struct PinRec { uint64_t at, num_pins, num_cc; };
+		const uint64_t nu = d.num_unique;
+		std::vector<PinRec> recs(nu);
+		std::vector<uint64_t> pin_base(nu + 1, 0), cc_base(nu + 1, 0), work_base(nu + 1, 0);
+		{
+			uint64_t i = offset;
+			for (uint64_t label = 0; label < nu; label++) {
+				if (i + npw > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+				const uint64_t num_pins = rd_le(lb + i, npw);
+				if (num_pins > nlb || i + npw + num_pins * static_cast<uint64_t>(iw + dw) + npw > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+				const uint64_t j = i + npw + num_pins * static_cast<uint64_t>(iw + dw);
+				const uint64_t num_cc = rd_le(lb + j, npw);
+				if (num_cc > nlb || j + npw + num_cc * static_cast<uint64_t>(ccw) > nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted.");
+				recs[label] = { i, num_pins, num_cc };
+				pin_base[label + 1] = pin_base[label] + num_pins;
+				cc_base[label + 1] = cc_base[label] + num_cc;
+				i = j + npw + num_cc * static_cast<uint64_t>(ccw);
 			}
 		}
-		d.n_pins = pin_index.size();
-		d.pin_total_work = work;
-		d.n_ccl = ccl_id.size();
-		upload(d.d_pin_index, pin_index, s);
-		upload(d.d_pin_depth, pin_depth, s);
-		upload(d.d_pin_label, pin_label, s);
-		upload(d.d_pin_work_off, pin_work_off, s);
-		upload(d.d_ccl_id, ccl_id, s);
-		upload(d.d_ccl_label, ccl_label, s);
+		const uint64_t P = pin_base[nu], C = cc_base[nu];
+		pin_block.p = static_cast<uint8_t*>(host_out_alloc((4 * std::max<uint64_t>(P, 1) + 2 * std::max<uint64_t>(C, 1)) * 8));
+		uint64_t* const pin_index = reinterpret_cast<uint64_t*>(pin_block.p);
+		uint64_t* const pin_depth = pin_index + std::max<uint64_t>(P, 1);
+		uint64_t* const pin_label = pin_depth + std::max<uint64_t>(P, 1);
+		uint64_t* const pin_work_off = pin_label + std::max<uint64_t>(P, 1);
+		uint64_t* const ccl_id = pin_work_off + std::max<uint64_t>(P, 1);
+		uint64_t* const ccl_label = ccl_id + std::max<uint64_t>(C, 1);
+		const uint64_t volume = d.sxy * h.sz;
+		host_parallel_for(nu, 512, [&](size_t lo, size_t hi) {
+			for (size_t label = lo; label < hi; label++) {
+				const PinRec& r = recs[label];
+				const uint64_t lv = read_stored(h, lb, d.uniq_offset + label * sw);
+				const uint8_t* at = lb + r.at + npw;
+				uint64_t idx = 0, work = 0;
+				for (uint64_t j = 0; j < r.num_pins; j++) {
+					idx += rd_le(at + j * iw, iw);
+					const uint64_t depth = rd_le(at + r.num_pins * iw + j * dw, dw);
+					const int64_t pin_z = static_cast<int64_t>(idx / d.sxy);
+					const int64_t a = std::max<int64_t>(pin_z, zs);
+					const int64_t b = std::min<int64_t>(pin_z + static_cast<int64_t>(depth) + 1, ze);
+					const bool touches = idx < volume && b > a;      // else: the pin does not touch the decoded range
+					const uint64_t o = pin_base[label] + j;
+					pin_index[o] = touches ? idx : 0; pin_depth[o] = touches ? depth : 0; pin_label[o] = lv;
+					pin_work_off[o] = touches ? static_cast<uint64_t>(b - a) : 0;      // its work items for now, their offset below
+					work += pin_work_off[o];
+				}
+				work_base[label + 1] = work;
+				const uint8_t* ids = at + r.num_pins * static_cast<uint64_t>(iw + dw) + npw;
+				uint64_t id = 0;
+				for (uint64_t j = 0; j < r.num_cc; j++) {
+					id = (id + rd_le(ids + j * ccw, ccw)) & 0xFFFFFFFFull;
+					ccl_id[cc_base[label] + j] = id; ccl_label[cc_base[label] + j] = lv;
+				}
+			}
+		});
+		for (uint64_t label = 0; label < nu; label++) work_base[label + 1] += work_base[label];
+		host_parallel_for(nu, 2048, [&](size_t lo, size_t hi) {
+			for (size_t label = lo; label < hi; label++) {
+				uint64_t run = work_base[label];
+				for (uint64_t o = pin_base[label]; o < pin_base[label + 1]; o++) { const uint64_t w = pin_work_off[o]; pin_work_off[o] = run; run += w; }
+			}
+		});
+		d.n_pins = P;
+		d.pin_total_work = work_base[nu];
+		d.n_ccl = C;
+		d.d_pin_index.ensure(std::max<uint64_t>(P, 1)); d.d_pin_depth.ensure(std::max<uint64_t>(P, 1)); d.d_pin_label.ensure(std::max<uint64_t>(P, 1));
+		d.d_pin_work_off.ensure(std::max<uint64_t>(P, 1)); d.d_ccl_id.ensure(std::max<uint64_t>(C, 1)); d.d_ccl_label.ensure(std::max<uint64_t>(C, 1));
+		if (P) {
+			CKL_HIP(hipMemcpyAsync(d.d_pin_index.p, pin_index, P * 8, hipMemcpyHostToDevice, s));
+			CKL_HIP(hipMemcpyAsync(d.d_pin_depth.p, pin_depth, P * 8, hipMemcpyHostToDevice, s));
+			CKL_HIP(hipMemcpyAsync(d.d_pin_label.p, pin_label, P * 8, hipMemcpyHostToDevice, s));
+			CKL_HIP(hipMemcpyAsync(d.d_pin_work_off.p, pin_work_off, P * 8, hipMemcpyHostToDevice, s));
+		}
+		if (C) {
+			CKL_HIP(hipMemcpyAsync(d.d_ccl_id.p, ccl_id, C * 8, hipMemcpyHostToDevice, s));
+			CKL_HIP(hipMemcpyAsync(d.d_ccl_label.p, ccl_label, C * 8, hipMemcpyHostToDevice, s));
+		}
 	}
 	pack.commit(d, s);
 	// the caller's host stream and the pin tables above are copied from memory that is not ours to keep
@@ -3781,6 +3830,7 @@ int ckl_decoder_create_device(const uint8_t* stream_device, uint64_t n, int64_t 
 			else CKL_HIP(hipMemcpyAsync(img.p + off, stream_device + off, len, hipMemcpyDeviceToHost, s));
 		};
 		mark("image");
+		if (prof) { CKL_HIP(hipStreamSynchronize(s)); mark("presync"); }
 		// first round, sized for the common case: the front of the stream (header, z-index and label section
 		// head of up to ~16 K slices) and its end (the crc tail); what a stream needs beyond that follows
 		const uint64_t kFront = 64u << 10;

@@ -18,6 +18,12 @@ def main():
   vol = synth.as_numpy_f(synth.voronoi_labels((256, 192, 4), np.uint32, seed=71, cell=(16, 16, 4)))
   streams += [chk.compress(vol, markov_model_order=m) for m in (0, 3)]
   streams += [chk.compress(synth.random_labels((96, 96, 2), np.uint8, seed=72, high=2), markov_model_order=2)]
+  pin_vol = synth.as_numpy_f(synth.voronoi_labels((128, 96, 24), np.uint32, seed=73, cell=(8, 8, 4)))
+  pin_streams = [chk.compress(pin_vol, allow_pins=True, markov_model_order=m) for m in (0, 2)]
+  assert all(crackle_amd.header(b).label_format == 2 for b in pin_streams)
+  streams += pin_streams
+  if len(sys.argv) > 2 and sys.argv[2] == "pins":      # only pin streams, damaged inside their label section (the decoder's parallel parse)
+    streams = pin_streams
   ok = err = ok2 = err2 = 0
   wide = len(sys.argv) > 2 and sys.argv[2] == "wide"
   for t in range(trials):
@@ -26,6 +32,10 @@ def main():
     for _ in range(int(rng.integers(1, 4))):
       # keep the header intact (its crc8 rejects damage early): hit index, labels, codes, crcs
       pos = int(rng.integers(29, n))
+      if len(sys.argv) > 2 and sys.argv[2] == "pins":
+        h = crackle_amd.header(bytes(streams[t % len(streams)]))
+        lo = 29 + 4 * (h.sz + 1)
+        pos = int(rng.integers(lo, lo + h.num_label_bytes))
       b[pos] ^= 1 << int(rng.integers(0, 8))
     try:
       crackle_amd.decompress(bytes(b))
