@@ -971,6 +971,7 @@ struct ckl_encoder {
 	bool async_host_copy = false;       // ckl_encoder_async_host_copy: a run returns when the stream is complete in HBM; its crack codes reach the host buffer on stream_copy
 	bool host_copy_pending = false;     // ... until ckl_encoder_host_wait
 	hipStream_t stream_copy = nullptr;
+	hipStream_t stream_tab = nullptr;   // the pin stage's label lists come to the host beside the passes of the label stream
 	hipEvent_t ev_codes = nullptr;
 	DevBuf<uint8_t> d_stream_out;       // ... here (valid until the next run)
 	uint64_t device_stream_bytes = 0;
@@ -1049,6 +1050,7 @@ struct ckl_encoder {
 		if (stream) (void)hipStreamDestroy(stream);
 		if (stream2) (void)hipStreamDestroy(stream2);
 		if (stream_copy) { (void)hipStreamSynchronize(stream_copy); (void)hipStreamDestroy(stream_copy); }
+		if (stream_tab) { (void)hipStreamSynchronize(stream_tab); (void)hipStreamDestroy(stream_tab); }
 		if (ev_codes) (void)hipEventDestroy(ev_codes);
 	}
 };
@@ -1700,30 +1702,48 @@ void flat_collect(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, i
 
 // the labels with the key of their first column run (the order they enter `pinsets`, src/pins.hpp:126-163), from the
 // components' labels and first runs on the device
-void pin_label_table(ckl_encoder& e, const uint64_t* comp_label, const uint64_t* first_any_dev, uint64_t N, PinCandidates& pc) {
+// The labels with their first column runs (k_pin_label_first / _list) in two steps: the kernels, enqueued as soon as
+// first_any is final (behind the first column pass), and the collection of the two short lists — on a stream of its
+// own, so that it does not queue behind the passes that follow on the label stream.
+struct PinLabelLists {
+	DevBuf<uint64_t> d_tab;
+	DevBuf<uint32_t> d_count;
+	uint32_t slots = 0;
+	hipEvent_t ready = nullptr;
+	~PinLabelLists() { if (ready) (void)hipEventDestroy(ready); }
+};
+void pin_label_table_enqueue(ckl_encoder& e, const uint64_t* comp_label, const uint64_t* first_any_dev, uint64_t N, PinLabelLists& t) {
 	hipStream_t s = e.stream2;
-	struct { const unsigned long long* first_any; } a = { reinterpret_cast<const unsigned long long*>(first_any_dev) };
-	{
-		if (N > (1ull << 30)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components for pin labels");
-		uint32_t slots = 1024;
-		while (slots < 2 * N) slots <<= 1;
-		DevBuf<uint64_t> d_tab;
-		DevBuf<uint32_t> d_count;
-		d_tab.ensure(4ull * slots + 1);      // keys | values | label list | first list, + the all-ones label's minimum
-		d_count.ensure(1);
-		CKL_HIP(hipMemsetAsync(d_tab.p, 0xFF, (2ull * slots) * sizeof(uint64_t), s));
-		CKL_HIP(hipMemsetAsync(d_tab.p + 4ull * slots, 0xFF, sizeof(uint64_t), s));
-		CKL_HIP(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t), s));
-		unsigned long long* t = reinterpret_cast<unsigned long long*>(d_tab.p);
-		hipLaunchKernelGGL(k_pin_label_first, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s,
-			reinterpret_cast<const unsigned long long*>(comp_label), a.first_any, N, t, t + slots, slots - 1u, t + 4ull * slots);
-		hipLaunchKernelGGL(k_pin_label_list, dim3((slots + kPinBlock - 1) / kPinBlock), dim3(kPinBlock), 0, s, t, t + slots, slots, d_count.p, t + 2ull * slots, t + 3ull * slots);
-		const uint32_t nl = download(d_count.p, 1, s)[0];
-		pc.label_value = download(d_tab.p + 2ull * slots, nl, s);
-		pc.label_first = download(d_tab.p + 3ull * slots, nl, s);
-		const uint64_t max_first = download(d_tab.p + 4ull * slots, 1, s)[0];
-		if (max_first != kPinNoKey) { pc.label_value.push_back(kPinNoKey); pc.label_first.push_back(max_first); }
-	}
+	if (N > (1ull << 30)) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components for pin labels");
+	uint32_t slots = 1024;
+	while (slots < 2 * N) slots <<= 1;
+	t.slots = slots;
+	t.d_tab.ensure(4ull * slots + 1);      // keys | values | label list | first list, + the all-ones label's minimum
+	t.d_count.ensure(1);
+	CKL_HIP(hipMemsetAsync(t.d_tab.p, 0xFF, (2ull * slots) * sizeof(uint64_t), s));
+	CKL_HIP(hipMemsetAsync(t.d_tab.p + 4ull * slots, 0xFF, sizeof(uint64_t), s));
+	CKL_HIP(hipMemsetAsync(t.d_count.p, 0, sizeof(uint32_t), s));
+	unsigned long long* tab = reinterpret_cast<unsigned long long*>(t.d_tab.p);
+	hipLaunchKernelGGL(k_pin_label_first, dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s,
+		reinterpret_cast<const unsigned long long*>(comp_label), reinterpret_cast<const unsigned long long*>(first_any_dev), N, tab, tab + slots, slots - 1u, tab + 4ull * slots);
+	hipLaunchKernelGGL(k_pin_label_list, dim3((slots + kPinBlock - 1) / kPinBlock), dim3(kPinBlock), 0, s, tab, tab + slots, slots, t.d_count.p, tab + 2ull * slots, tab + 3ull * slots);
+	if (!t.ready) CKL_HIP(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+	CKL_HIP(hipEventRecord(t.ready, s));
+}
+void pin_label_table_collect(ckl_encoder& e, PinLabelLists& t, PinCandidates& pc) {
+	if (!e.stream_tab) CKL_HIP(hipStreamCreateWithFlags(&e.stream_tab, hipStreamNonBlocking));
+	hipStream_t s = e.stream_tab;
+	CKL_HIP(hipStreamWaitEvent(s, t.ready, 0));
+	const uint32_t nl = download(t.d_count.p, 1, s)[0];
+	pc.label_value = download(t.d_tab.p + 2ull * t.slots, nl, s);
+	pc.label_first = download(t.d_tab.p + 3ull * t.slots, nl, s);
+	const uint64_t max_first = download(t.d_tab.p + 4ull * t.slots, 1, s)[0];
+	if (max_first != kPinNoKey) { pc.label_value.push_back(kPinNoKey); pc.label_first.push_back(max_first); }
+}
+void pin_label_table(ckl_encoder& e, const uint64_t* comp_label, const uint64_t* first_any_dev, uint64_t N, PinCandidates& pc) {
+	PinLabelLists t;
+	pin_label_table_enqueue(e, comp_label, first_any_dev, N, t);
+	pin_label_table_collect(e, t, pc);
 }
 
 // extract_columns + add_pin (src/pins.hpp:95-163) over the rows of `v`: the kept runs marked in v.mark
@@ -1767,7 +1787,8 @@ void pin_dedup_pass(ckl_encoder& e, const LABEL* labels, const PinVolume& v) {
 template <typename LABEL>
 void pin_passes_device(
 	ckl_encoder& e, const LABEL* labels, const uint32_t* cc /* device: component id of every voxel */,
-	int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N, PinVolume& v, unsigned long long*& choice, const uint64_t*& first_any
+	int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N, PinVolume& v, unsigned long long*& choice, const uint64_t*& first_any,
+	const std::function<void(const uint64_t*)>& first_any_final = std::function<void(const uint64_t*)>()      // called (with first_any) once the pass that completes it is enqueued
 ) {
 	hipStream_t s = e.stream2;
 	v = PinVolume();
@@ -1796,6 +1817,7 @@ void pin_passes_device(
 	CKL_HIP(hipMemsetAsync(a.first_depth, 0, N * sizeof(uint32_t), s));
 	const dim3 cgrid((v.sx + kPinBlock - 1) / kPinBlock, v.sy);
 	hipLaunchKernelGGL((k_pin_columns<LABEL, 0>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
+	if (first_any_final) first_any_final(first_any);
 	hipLaunchKernelGGL((k_pin_extent<LABEL, true>), dim3(static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock)), dim3(kPinBlock), 0, s,
 		labels, v, a.first_kept, static_cast<uint32_t>(N), a.first_depth);
 	hipLaunchKernelGGL((k_pin_columns<LABEL, 2>), cgrid, dim3(kPinBlock), 0, s, labels, v, a);
@@ -2004,11 +2026,11 @@ void pins_rows_extent(ckl_encoder& e, const LABEL* labels, const uint32_t* cc, i
 std::vector<uint8_t> pins_section_from_device(
 	ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, uint64_t N, const std::vector<uint32_t>& nc,
 	const uint64_t* d_comp_label, const uint64_t* d_first_any, const uint64_t* d_choice, const uint32_t* d_ze_plus1, const uint64_t* d_offsets, const uint32_t* d_ids,
-	int stored_width, bool auto_bgcolor, int64_t manual_bgcolor
+	int stored_width, bool auto_bgcolor, int64_t manual_bgcolor, const PinLabelTable* table = nullptr
 ) {
 	hipStream_t s = e.stream2;
 	PinCandidates pc;
-	pin_label_table(e, d_comp_label, d_first_any, N, pc);      // the labels with their first runs: a few downloads of its own
+	if (!table) pin_label_table(e, d_comp_label, d_first_any, N, pc);      // the labels with their first runs: a few downloads of its own
 	const uint64_t total = download(d_offsets + N, 1, s)[0];
 	auto up64 = [](uint64_t b) { return (b + 63) & ~static_cast<uint64_t>(63); };
 	const uint64_t o_label = 0, o_choice = o_label + up64(N * 8), o_off = o_choice + up64(N * 8), o_ze = o_off + up64((N + 1) * 8), o_ids = o_ze + up64(N * 4);
@@ -2054,7 +2076,7 @@ std::vector<uint8_t> pins_section_from_device(
 	};
 	Header h;
 	h.sx = static_cast<uint32_t>(sx); h.sy = static_cast<uint32_t>(sy); h.sz = static_cast<uint32_t>(sz);
-	return pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor, arrays_ready);
+	return pins_cover_host(pc, sx, sy, sz, nc, N, h.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor, arrays_ready, table);
 }
 
 // The whole pin stage of a volume that one device holds: the passes of pin_candidates_device, then the chosen
@@ -2072,7 +2094,12 @@ std::vector<uint8_t> pins_section_plain(
 	const uint64_t* first_any = nullptr;
 	PinVolume v;
 	if (getenv("CKL_PINS_ALONE")) CKL_HIP(hipStreamSynchronize(e.stream));      // measuring: the pin kernels without the trail's beside them
-	pin_passes_device<LABEL>(e, labels, cc, sx, sy, sz, N, v, choice, first_any);
+	// The labels' first runs are final after the first column pass: their lists are made there and come to the host
+	// on a stream of their own, and the host builds the label table (7 ms at C4) while the later passes still run.
+	PinLabelLists lists;
+	const bool early_table = !getenv("CKL_PINS_LATE_TABLE");
+	pin_passes_device<LABEL>(e, labels, cc, sx, sy, sz, N, v, choice, first_any,
+		early_table ? std::function<void(const uint64_t*)>([&](const uint64_t* fa) { pin_label_table_enqueue(e, comp_label, fa, N, lists); }) : std::function<void(const uint64_t*)>());
 	const uint32_t nb = static_cast<uint32_t>((N + kPinBlock - 1) / kPinBlock);
 	const uint32_t pieces = static_cast<uint32_t>((N + kPinScanPiece - 1) / kPinScanPiece);
 	DevBuf<uint32_t> d_zep, d_count, d_ze, d_ids;
@@ -2084,6 +2111,14 @@ std::vector<uint8_t> pins_section_plain(
 	hipLaunchKernelGGL(k_pin_scan_pieces, dim3(pieces), dim3(kPinBlock), 0, s, d_count.p, N, d_piece.p);
 	hipLaunchKernelGGL(k_pin_scan_tops, dim3(1), dim3(kPinBlock), 0, s, d_piece.p, pieces);
 	hipLaunchKernelGGL(k_pin_scan_offsets, dim3(pieces), dim3(kPinBlock), 0, s, d_count.p, N, d_piece.p, pieces, d_off.p);
+	std::shared_ptr<const PinLabelTable> table;
+	if (early_table) {
+		PinCandidates lc;
+		pin_label_table_collect(e, lists, lc);
+		HT_MARK("p:lists");
+		table = pins_label_table_host(lc.label_value, lc.label_first);
+		HT_MARK("p:table");
+	}
 	const uint64_t total = download(d_off.p + N, 1, s)[0];
 	HT_MARK("p:passes");
 	uint64_t id_budget = 1ull << 26;      // 256 MiB of ids
@@ -2097,7 +2132,7 @@ std::vector<uint8_t> pins_section_plain(
 	hipLaunchKernelGGL(k_pin_minus1, dim3(nb), dim3(kPinBlock), 0, s, d_zep.p, N, d_ze.p);
 	hipLaunchKernelGGL(k_pin_ids, dim3(nb), dim3(kPinBlock), 0, s, v, choice, d_ze.p, reinterpret_cast<const uint64_t*>(d_off.p), static_cast<uint32_t>(N), d_ids.p);
 	std::vector<uint8_t> bin = pins_section_from_device(e, sx, sy, sz, N, nc, comp_label, first_any, reinterpret_cast<const uint64_t*>(choice), d_zep.p,
-		reinterpret_cast<const uint64_t*>(d_off.p), d_ids.p, stored_width, auto_bgcolor, manual_bgcolor);
+		reinterpret_cast<const uint64_t*>(d_off.p), d_ids.p, stored_width, auto_bgcolor, manual_bgcolor, table.get());
 	HT_MARK("pins_host");
 	return bin;
 }

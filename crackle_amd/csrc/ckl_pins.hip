@@ -175,6 +175,8 @@ private:
 
 }  // namespace
 
+struct PinLabelTable { RhTable pinsets; size_t n_labels = 0; };
+
 // ---- host statement of the device passes (src/pins.hpp:95-163 with the choice rule of 325-340) ----
 template <typename LABEL>
 PinCandidates pin_candidates_host(const LABEL* labels, const uint32_t* cc, int64_t sx_, int64_t sy_, int64_t sz_, uint64_t N) {
@@ -336,11 +338,52 @@ void host_parallel_for(size_t n, size_t grain, const std::function<void(size_t, 
 	for (auto& e : errors) if (!e.empty()) throw Error(CKL_ERR_RUNTIME, e);
 }
 
+namespace {
+// sort in pieces on the worker threads, then merge the pieces pairwise
+template <typename It, typename Less>
+void host_parallel_sort(It first, It last, Less less) {
+	const size_t n = static_cast<size_t>(last - first);
+	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
+	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
+	size_t pieces = 1;
+	while (pieces < nthreads && pieces < 16 && n / (2 * pieces) >= 4096) pieces *= 2;
+	if (pieces == 1) { std::sort(first, last, less); return; }
+	auto bound = [&](size_t i) { return first + static_cast<std::ptrdiff_t>(n * i / pieces); };
+	host_parallel_for(pieces, 1, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) std::sort(bound(i), bound(i + 1), less); });
+	for (size_t w = 1; w < pieces; w *= 2) {
+		const size_t pairs = pieces / (2 * w);
+		host_parallel_for(pairs, 1, [&](size_t lo, size_t hi) {
+			for (size_t i = lo; i < hi; i++) std::inplace_merge(bound(2 * w * i), bound(2 * w * i + w), bound(2 * w * (i + 1)), less);
+		});
+	}
+}
+
+// the labels enter the table in the order of their first column run
+void pinsets_insert_ordered(std::vector<std::pair<uint64_t, uint64_t>>& order /* (first key, label) */, RhTable& pinsets, size_t& n_labels) {
+	host_parallel_sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a < b; });
+	for (const auto& o : order) {
+		bool found;
+		pinsets.insert(o.second, static_cast<uint32_t>(n_labels), found);
+		if (!found) n_labels++;
+	}
+}
+}  // namespace
+
+std::shared_ptr<const PinLabelTable> pins_label_table_host(const std::vector<uint64_t>& label_value, const std::vector<uint64_t>& label_first) {
+	if (label_first.size() != label_value.size()) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
+	auto t = std::make_shared<PinLabelTable>();
+	std::vector<std::pair<uint64_t, uint64_t>> order;
+	order.reserve(label_value.size());
+	for (size_t i = 0; i < label_value.size(); i++) if (label_first[i] != kPinNoKey) order.emplace_back(label_first[i], label_value[i]);
+	pinsets_insert_ordered(order, t->pinsets, t->n_labels);
+	return t;
+}
+
 std::vector<uint8_t> pins_cover_host(
 	const PinCandidates& pc, int64_t sx, int64_t sy, int64_t sz,
 	const std::vector<uint32_t>& ncomp, uint64_t n_total,
 	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor,
-	const std::function<void()>& components_ready
+	const std::function<void()>& components_ready, const PinLabelTable* table
 ) {
 	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
 	const bool viewed = pc.view_components != 0;
@@ -367,34 +410,19 @@ std::vector<uint8_t> pins_cover_host(
 		t_last = now;
 	};
 	if ((!pins_viewed && pc.comp_pin.size() != N) || (pins_viewed && (!pin_x || !pin_y || !pin_zs || !pin_ze)) || (!viewed && pc.pin_ids_off.size() != P + 1) || (viewed && (!comp_label || !ids_off || !ids))) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
-	if (pc.label_value.empty() && pc.comp_first.size() != N) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
+	if (!table && pc.label_value.empty() && pc.comp_first.size() != N) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
 
 	// worker threads for the per-label phases (labels are independent of each other)
 	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
 	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
 	auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) { host_parallel_for(n, grain, body, 64); };
 
-	// sort in pieces on the worker threads, then merge the pieces pairwise
-	auto parallel_sort = [&](auto first, auto last, auto less) {
-		const size_t n = static_cast<size_t>(last - first);
-		size_t pieces = 1;
-		while (pieces < nthreads && pieces < 16 && n / (2 * pieces) >= 4096) pieces *= 2;
-		if (pieces == 1) { std::sort(first, last, less); return; }
-		auto bound = [&](size_t i) { return first + static_cast<std::ptrdiff_t>(n * i / pieces); };
-		parallel_for(pieces, 1, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) std::sort(bound(i), bound(i + 1), less); });
-		for (size_t w = 1; w < pieces; w *= 2) {
-			const size_t pairs = pieces / (2 * w);
-			parallel_for(pairs, 1, [&](size_t lo, size_t hi) {
-				for (size_t i = lo; i < hi; i++) std::inplace_merge(bound(2 * w * i), bound(2 * w * i + w), bound(2 * w * (i + 1)), less);
-			});
-		}
-	};
+	auto parallel_sort = [&](auto first, auto last, auto less) { host_parallel_sort(first, last, less); };
 
 	// ---- pinsets (src/pins.hpp:126-163): a robin-hood node map keyed by label; its slot order
 	// depends on the order the labels were first seen, i.e. on their first column run ----
-	RhTable pinsets;                                  // label -> label index
-	size_t n_labels = 0;
-	{
+	PinLabelTable own;
+	if (!table) {
 		std::vector<std::pair<uint64_t, uint64_t>> order;      // (first key, label)
 		if (!pc.label_value.empty()) {
 			if (pc.label_first.size() != pc.label_value.size()) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
@@ -405,13 +433,10 @@ std::vector<uint8_t> pins_cover_host(
 			order.reserve(N);
 			for (uint64_t c = 0; c < N; c++) if (pc.comp_first[c] != kPinNoKey) order.emplace_back(pc.comp_first[c], comp_label[c]);
 		}
-		parallel_sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a < b; });
-		for (const auto& o : order) {
-			bool found;
-			pinsets.insert(o.second, static_cast<uint32_t>(n_labels), found);
-			if (!found) n_labels++;
-		}
+		pinsets_insert_ordered(order, own.pinsets, own.n_labels);
 	}
+	const RhTable& pinsets = table ? table->pinsets : own.pinsets;
+	const size_t n_labels = table ? table->n_labels : own.n_labels;
 	mark("pinsets");
 	if (components_ready) { components_ready(); mark("arrays"); }
 

@@ -19,6 +19,7 @@
 #include "ckl_common.hpp"
 
 #include <functional>
+#include <memory>
 #include <vector>
 
 namespace ckl {
@@ -61,7 +62,11 @@ std::vector<uint8_t> pins_cover_host(
 	const PinCandidates& pc, int64_t sx, int64_t sy, int64_t sz,
 	const std::vector<uint32_t>& ncomp, uint64_t n_total,
 	int index_width, int stored_width, bool auto_bgcolor, int64_t manual_bgcolor,
-	const std::function<void()>& components_ready = std::function<void()>());
+	const std::function<void()>& components_ready = std::function<void()>(), const struct PinLabelTable* table = nullptr);
+// `pinsets` of pins::compute (src/pins.hpp:126-163) from label_value / label_first alone: a caller that has these
+// before the rest builds the table while its device passes still run and hands it to pins_cover_host.
+struct PinLabelTable;
+std::shared_ptr<const PinLabelTable> pins_label_table_host(const std::vector<uint64_t>& label_value, const std::vector<uint64_t>& label_first);
 // components_ready: called once the labels' table (`pinsets`, from label_value / label_first alone) is built and
 // before anything per component or per pin is read — a caller whose large arrays are still on their way from the
 // device waits for them there (and fills comp_pin, pin_x ... pin_ze, whose sizes must be final beforehand).
