@@ -283,6 +283,7 @@ struct PinComponentArrays {
 template <bool LAST>
 __device__ __forceinline__ bool pin_wave_leader(bool want, uint32_t c) {
 	const unsigned long long m = __ballot(want);
+	if (m == 0ull) return false;      // (uniform: most voxels update nothing, and the exchange below goes through the LDS crossbar)
 	const uint32_t lane = threadIdx.x & 63u;
 	const unsigned long long others = LAST ? (lane == 63u ? 0ull : m & (~0ull << (lane + 1u))) : m & ((1ull << lane) - 1ull);
 	// the nearest wanting lane on that side (any lane when there is none: its answer is not used)
