@@ -651,6 +651,42 @@ __global__ void __launch_bounds__(kBlock) k_paint_components(
 	out[zi * sxy + px] = run_cc[rbase[zi] + run] + static_cast<uint32_t>(comp_off[zi]) + id_base;
 }
 
+// The same with four pixels (16 bytes of ids) per thread: rows whose length is a multiple of four, where the four
+// share a break word.  (4.1 ms -> for 2048 x 2048 x 256: one 4-byte store per lane moved 1 TB/s.)
+__global__ void __launch_bounds__(kBlock) k_paint_components4(
+	const uint32_t* __restrict__ planeV, uint32_t row_words, uint64_t plane_words, uint32_t sx, uint64_t sxy,
+	const uint32_t* __restrict__ word_base, const uint64_t* __restrict__ rbase, const uint32_t* __restrict__ run_cc,
+	const uint64_t* __restrict__ comp_off, uint32_t id_base, uint32_t* __restrict__ out
+) {
+	const uint32_t zi = blockIdx.y;
+	const uint32_t px = (blockIdx.x * kBlock + threadIdx.x) * 4u;
+	if (px >= sxy) return;
+	const uint32_t y = px / sx, x = px - y * sx;
+	const uint32_t w = x >> 5, bit = x & 31u;
+	const uint64_t wi = zi * plane_words + static_cast<uint64_t>(y) * row_words + w;
+	uint32_t b = planeV[wi];
+	if (w == 0) b |= 1u;
+	const uint32_t* cc = run_cc + rbase[zi];
+	const uint32_t add = static_cast<uint32_t>(comp_off[zi]) + id_base;
+	uint32_t run = word_base[wi] - 1u + __popc(b & (0xFFFFFFFFu >> (31u - bit)));
+	uint4 o;
+	o.x = cc[run] + add;
+	run += (b >> (bit + 1u)) & 1u; o.y = cc[run] + add;
+	run += (b >> (bit + 2u)) & 1u; o.z = cc[run] + add;
+	run += (b >> (bit + 3u)) & 1u; o.w = cc[run] + add;
+	*reinterpret_cast<uint4*>(out + zi * sxy + px) = o;
+}
+
+inline void launch_paint_components(hipStream_t s, const uint32_t* planeV, uint32_t row_words, uint64_t plane_words, int64_t sx, int64_t sy, int64_t sz,
+	const uint32_t* word_base, const uint64_t* rbase, const uint32_t* run_cc, const uint64_t* comp_off, uint32_t id_base, uint32_t* out) {
+	const uint64_t sxy = static_cast<uint64_t>(sx) * sy;
+	const bool four = sx % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && !getenv("CKL_PAINT_COMPONENTS_1");
+	const uint64_t threads = four ? sxy / 4 : sxy;
+	const dim3 grid(static_cast<uint32_t>((threads + kBlock - 1) / kBlock), static_cast<uint32_t>(sz));
+	if (four) hipLaunchKernelGGL(k_paint_components4, grid, dim3(kBlock), 0, s, planeV, row_words, plane_words, static_cast<uint32_t>(sx), sxy, word_base, rbase, run_cc, comp_off, id_base, out);
+	else hipLaunchKernelGGL(k_paint_components, grid, dim3(kBlock), 0, s, planeV, row_words, plane_words, static_cast<uint32_t>(sx), sxy, word_base, rbase, run_cc, comp_off, id_base, out);
+}
+
 // ------------------------------------------------------------------------------
 // label table (labels.hpp:92-152): sorted unique labels and the key of every component.
 // The component -> label list is sorted on device (bitonic network over a power-of-two
@@ -2382,9 +2418,7 @@ void encode_typed(
 			// device passes above; the order-sensitive cover runs on the host (ckl_pins.hip)
 			if (N > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
 			e.d_cc_volume.ensure(voxels);
-			hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((static_cast<uint64_t>(sx) * sy + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
-				e.d_planes.p, e.row_words, e.plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
-				e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, 0u, e.d_cc_volume.p);
+			launch_paint_components(s2, e.d_planes.p, e.row_words, e.plane_words, sx, sy, sz, e.d_word_base.p, e.d_rbase.p, e.d_run_cc.p, e.d_comp_off.p, 0u, e.d_cc_volume.p);
 			pins_binary = pins_section_plain<LABEL>(e, labels, e.d_cc_volume.p, e.d_mapping.p, sx, sy, sz, N, fr.ncomp, head.pin_index_width(), stored_width, auto_bgcolor, manual_bgcolor);
 			label_bytes = pins_binary.size();
 		}
@@ -2851,9 +2885,7 @@ static uint32_t* encoder_components(ckl_encoder* e, const void* labels_device, i
 	if (fr.total + id_base > 0xFFFFFFFFull) throw Error(CKL_ERR_RUNTIME, "crackle_amd: too many components");
 	hipStream_t s2 = e->stream2;
 	if (!cc_device) { e->d_cc_volume.ensure(voxels); cc_device = e->d_cc_volume.p; }
-	hipLaunchKernelGGL(k_paint_components, dim3(static_cast<uint32_t>((static_cast<uint64_t>(sx) * sy + kBlock - 1) / kBlock), static_cast<uint32_t>(sz)), dim3(kBlock), 0, s2,
-		e->d_planes.p, e->row_words, e->plane_words, static_cast<uint32_t>(sx), static_cast<uint64_t>(sx) * sy,
-		e->d_word_base.p, e->d_rbase.p, e->d_run_cc.p, e->d_comp_off.p, id_base, cc_device);
+	launch_paint_components(s2, e->d_planes.p, e->row_words, e->plane_words, sx, sy, sz, e->d_word_base.p, e->d_rbase.p, e->d_run_cc.p, e->d_comp_off.p, id_base, cc_device);
 	for (int64_t z = 0; z < sz; z++) ncomp_host[z] = fr.ncomp[z];
 	return cc_device;
 }
