@@ -550,6 +550,7 @@ def main():
       "encode_ms": float(np.mean(enc_ms)),
       "decode_ms": float(np.mean(dec_ms)),
       "decoder_create_ms": float(np.mean(open_ms)),
+      "per_step_ms": {"encode": [round(v, 3) for v in enc_ms], "decoder_create": [round(v, 3) for v in open_ms], "decode": [round(v, 3) for v in dec_ms]},
       "decode_total_ms": float(np.mean(open_ms)) + float(np.mean(dec_ms)),
       "decode_setup_in_value": bool(resident),
       # encode_ms ends when the stream is complete in HBM and the call has returned; with the overlapped
