@@ -2803,15 +2803,17 @@ int ckl_encoder_stats(
 		e->planes_for = nullptr;
 		if (voxels > 0) {
 			// the label-plane pass yields max / pairs from the same read and leaves the planes for
-			// the ckl_encoder_run that follows
+			// the ckl_encoder_run that follows; the slab's first and last voxel come back with its counts
+			// (they were two blocking copies behind it)
+			uint64_t f = 0, l = 0;
+			const uint8_t* base = static_cast<const uint8_t*>(labels_device);
+			CKL_HIP(hipMemcpyAsync(&f, base, e->dtype_bytes, hipMemcpyDeviceToHost, e->stream));
+			CKL_HIP(hipMemcpyAsync(&l, base + (voxels - 1) * e->dtype_bytes, e->dtype_bytes, hipMemcpyDeviceToHost, e->stream));
 			if (e->dtype_bytes == 1) planes_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz, &st);
 			else if (e->dtype_bytes == 2) planes_pass<uint16_t>(*e, reinterpret_cast<const uint16_t*>(labels_device), sx, sy, sz, &st);
 			else if (e->dtype_bytes == 4) planes_pass<uint32_t>(*e, reinterpret_cast<const uint32_t*>(labels_device), sx, sy, sz, &st);
 			else planes_pass<uint64_t>(*e, reinterpret_cast<const uint64_t*>(labels_device), sx, sy, sz, &st);
-			uint64_t f = 0, l = 0;
-			const uint8_t* base = static_cast<const uint8_t*>(labels_device);
-			CKL_HIP(hipMemcpy(&f, base, e->dtype_bytes, hipMemcpyDeviceToHost));
-			CKL_HIP(hipMemcpy(&l, base + (voxels - 1) * e->dtype_bytes, e->dtype_bytes, hipMemcpyDeviceToHost));
+			CKL_HIP(hipStreamSynchronize(e->stream));      // (planes_pass has waited for the stream already: this returns at once)
 			st.first = f; st.last = l;
 			e->planes_for = labels_device;
 			e->planes_stats = st;

@@ -553,6 +553,19 @@ class ShardedCodec:
     self._shared_vol = None # node-local labels + component ids of the whole volume (pin encoding)
 
   # -- encode -------------------------------------------------------------------
+  def _gather_rows(self, mine: np.ndarray) -> np.ndarray:
+    """Every rank's short int64 vector as the rows of one array: one collective into ONE tensor where the backend
+    has it (RCCL), one transfer back to the host."""
+    t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(self.device)
+    import os
+    if dist.get_backend() == "nccl" and not os.environ.get("CKL_SHARDED_LIST_GATHER"):
+      out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=self.device)
+      dist.all_gather_into_tensor(out, t)
+      return out.cpu().numpy().reshape(self.world, t.numel())
+    parts = [torch.empty_like(t) for _ in range(self.world)]
+    dist.all_gather(parts, t)
+    return torch.stack(parts).cpu().numpy()
+
   def compress(self, vol, slab_shape, markov_model_order: int = 0, allow_pins: bool = False, fortran_order: bool = True, defer: bool = False):
     """Every rank passes its own z-slab (slab_shape = (sx, sy, sz_local)).  Returns the
     stream of the whole volume on rank 0, None elsewhere.
@@ -584,10 +597,7 @@ class ShardedCodec:
     mx, pairs, first, last = be.stats(vol, slab_shape)
     # uint64 labels travel as their int64 bit patterns (labels >= 2^63 do not fit torch.int64 as values)
     mine_np = np.array([pairs, mx, first, last, voxels_local], dtype=np.uint64).view(np.int64)
-    mine = torch.from_numpy(mine_np).to(self.device)
-    everyone = [torch.empty_like(mine) for _ in range(self.world)]
-    dist.all_gather(everyone, mine)
-    table = torch.stack(everyone).cpu().numpy().view(np.uint64)
+    table = self._gather_rows(mine_np).view(np.uint64)
     tot_pairs = int(table[:, 0].sum())
     nonempty = [r for r in range(self.world) if table[r, 4] > 0]
     for a, b in zip(nonempty[:-1], nonempty[1:]):
@@ -689,10 +699,7 @@ class ShardedCodec:
     sec = _SlabSections(slab)
     mark("sections")
     dev = self.device
-    meta = torch.tensor([len(sec.uniq), sec.n_keys, len(sec.cracks), sec.sz], dtype=torch.int64, device=dev)
-    metas = [torch.empty_like(meta) for _ in range(self.world)]
-    dist.all_gather(metas, meta)
-    table = torch.stack(metas).cpu().numpy()
+    table = self._gather_rows(np.array([len(sec.uniq), sec.n_keys, len(sec.cracks), sec.sz], dtype=np.int64))
     packed_dev = None
     cdev = self.compute_device
     if early_merge:
