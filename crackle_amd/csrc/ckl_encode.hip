@@ -1361,6 +1361,11 @@ void crack_pass(
 		max_special = std::max<uint32_t>(max_special, e.count_special[zi]);
 	}
 	if (result) result->any_chain = any;
+	if (g_ht && g_ht->on) {
+		uint32_t over = 0;
+		for (uint32_t zi = 0; zi < ns; zi++) over += e.count_special[zi] > 3584u;
+		fprintf(stderr, "[ckl trail nodes] max special %u, slices above 3584: %u of %u\n", max_special, over, ns);
+	}
 	HT_MARK("c:caps");
 	UploadPacker tables;
 	tables.add(e.d_cbase, cbase); tables.add(e.d_ccap, ccap);
@@ -1452,7 +1457,7 @@ void crack_pass(
 		e.last_trail_slices = ns;
 		ta.events = e.t_events.p; ta.n_events = e.t_counters.p + 5 * ns; ta.seg_len_sum = e.t_counters.p + 6 * ns; ta.chain_ev0 = e.t_chain_ev0.p; ta.ev_lnd = e.t_ev_lnd.p; ta.ev_item = e.t_ev_item.p;
 		ta.dbg = nullptr;
-		{ const char* env = getenv("CKL_TRAIL_WALK"); ta.walk_plain = (env && !strcmp(env, "plain")) ? 1u : 0u; }
+		{ const char* env = getenv("CKL_TRAIL_WALK"); ta.walk_plain = (env && !strcmp(env, "plain")) ? 1u : 0u; ta.walk_no_regs = (env && !strcmp(env, "lds")) ? 1u : 0u; }
 		{ const char* env = getenv("CKL_TRAIL_WALK_STACK"); ta.walk_stack_cap = env ? static_cast<uint32_t>(std::max(1, atoi(env))) : 0xFFFFFFFFu; }
 		if (kTuning && getenv("CKL_TRAIL_DIAG")) { d_tdbg.ensure(16); CKL_HIP(hipMemsetAsync(d_tdbg.p, 0, 128, s)); ta.dbg = d_tdbg.p; ta_dbg = d_tdbg.p; }
 		ta.graph_blocks = e.graph_blocks; ta.blk_special = e.t_blk_special.p; ta.blk_corner = e.t_blk_corner.p;

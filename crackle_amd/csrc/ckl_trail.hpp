@@ -137,6 +137,7 @@ struct TrailArgs {
 	uint32_t* ev_item;
 	uint32_t walk_plain;         // testing (CKL_TRAIL_WALK=plain): trail_walk_slice for every slice
 	uint32_t walk_stack_cap;     // testing (CKL_TRAIL_WALK_STACK=n): branch stack of the hand-scheduled walk capped at n entries
+	uint32_t walk_no_regs;       // testing (CKL_TRAIL_WALK=lds): the hand-scheduled walks on LDS tables only, not the one on register tables
 	unsigned long long* dbg;     // diagnostics (nullable): [0] wave iterations, [1] max per wave, [2] cycles, [3] max cycles, [4] waves, [5] lane-steps
 };
 
@@ -1120,6 +1121,178 @@ __device__ __forceinline__ bool trail_walk_slice_wide(const TrailArgs& a, uint32
 	return true;
 }
 
+// The walk with the node tables in the wavefront's own REGISTERS: node j's record {remaining edges, ends 0|1, ends 2|3}
+// lives in lane j & 63 of registers v[64 + b], v[120 + b], v[176 + b], b = j >> 6 (56 blocks: 3584 nodes), fetched with
+// v_readlane under VGPR indexing (s_set_gpr_idx_on: M0 = b) and updated by a one-lane v_mov into the indexed register.
+// An LDS round trip (~64 cycles of a step's ~330, tools/micro/wave_latency.hip) leaves the step; the branch stack stays
+// in LDS, its top is requested at the start of every step and waited for at dead ends only.  The whole slice — tables
+// from LDS into the registers, every chain from its start node — is ONE asm block: between two blocks the compiler
+// would be free to use the table registers.  Ends are in the plain format (node << 2 | arrival edge), events too
+// (kEvWalkWide); stack entries event index << 14 | node.
+//   LDS at address 0: [records of 12 bytes, 64 * nblk of them][start node of every chain][branch stack]
+// Called by the whole wavefront.  Returns 0 (all chains walked), 1 (events full), 2 (branch stack full).
+constexpr uint32_t kWalkRegBlocks = 56, kWalkRegNodes = 64u * kWalkRegBlocks;
+__device__ __forceinline__ uint32_t trail_walk_slice_regs_asm(
+	uint32_t nblk, uint32_t list_base, uint32_t n_starts, uint32_t stack_base, uint32_t max_depth, uint32_t* ev, uint32_t* chain_ev0, uint32_t& ev_off, uint32_t& ev_left
+) {
+	uint32_t status, off = 0, left = ev_left;
+	const uint32_t top0 = stack_base - 4u;        // "top entry" of the empty stack: never used
+	const uint32_t ev_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ev)));
+	const uint32_t ev_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ev) >> 32));
+	const uint32_t c0_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(chain_ev0)));
+	const uint32_t c0_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(chain_ev0) >> 32));
+	nblk = __builtin_amdgcn_readfirstlane(nblk);
+	list_base = __builtin_amdgcn_readfirstlane(list_base);
+	n_starts = __builtin_amdgcn_readfirstlane(n_starts);
+	max_depth = __builtin_amdgcn_readfirstlane(max_depth);
+	asm volatile(
+		"s_mov_b32 s61, m0\n"
+		"s_mov_b64 s[62:63], exec\n"
+		// ---- the tables: LDS -> registers, lane l takes node 64 b + l
+		"s_mov_b64 exec, -1\n"
+		"v_mbcnt_lo_u32_b32 v20, -1, 0\n"
+		"v_mbcnt_hi_u32_b32 v20, -1, v20\n"
+		"v_mul_u32_u24 v20, 12, v20\n"
+		"s_mov_b32 s50, 0\n"
+		"10:\n"
+		"ds_read2_b32 v[32:33], v20 offset1:1\n"
+		"ds_read_b32 v34, v20 offset:8\n"
+		"s_waitcnt lgkmcnt(0)\n"
+		"s_set_gpr_idx_on s50, gpr_idx(DST)\n"
+		"s_nop 0\n"
+		"v_mov_b32 v64, v32\n"
+		"v_mov_b32 v120, v33\n"
+		"v_mov_b32 v176, v34\n"
+		"s_set_gpr_idx_off\n"
+		"v_add_u32 v20, 0x300, v20\n"
+		"s_add_u32 s50, s50, 1\n"
+		"s_cmp_lt_u32 s50, %[nblk]\n"
+		"s_cbranch_scc1 10b\n"
+		"s_mov_b64 exec, 1\n"                       // lane 0 from here on (the table registers are read with v_readlane)
+		"s_setprio 3\n"
+		"v_readfirstlane_b32 s43, %[left]\n"
+		"s_mov_b32 s52, %[evlo]\n"
+		"s_mov_b32 s53, %[evhi]\n"
+		"s_mov_b32 s54, %[maxd]\n"
+		"s_mov_b32 s58, %[c0lo]\n"
+		"s_mov_b32 s59, %[c0hi]\n"
+		"s_mov_b32 s56, %[nst]\n"
+		"s_mov_b32 s57, %[list]\n"
+		"s_mov_b32 s55, 0\n"                        // chain
+		"v_mov_b32 v29, 0\n"                        // byte offset of the next event
+		"20:\n"                                     // ---- next chain
+		"s_cmp_ge_u32 s55, s56\n"
+		"s_cbranch_scc1 30f\n"
+		"s_lshl_b32 s48, s55, 2\n"
+		"s_add_u32 s49, s48, s57\n"
+		"v_mov_b32 v21, s49\n"
+		"ds_read_b32 v21, v21\n"                    // its start node
+		"v_lshrrev_b32 v22, 2, v29\n"
+		"v_mov_b32 v24, s48\n"
+		"global_store_dword v24, v22, s[58:59]\n"   // chain_ev0[chain] = index of its first event
+		"s_mov_b32 s41, 0\n"                        // pend
+		"s_mov_b32 s42, 0\n"                        // stack depth
+		"v_mov_b32 v25, %[top]\n"
+		"s_waitcnt lgkmcnt(0)\n"
+		"v_readfirstlane_b32 s40, v21\n"
+		"1:\n"                                      // ---- a step
+		"s_lshr_b32 s50, s40, 6\n"
+		"s_and_b32 s51, s40, 63\n"
+		"ds_read_b32 v26, v25\n"                    // top of the branch stack: wanted at a dead end only
+		"s_set_gpr_idx_on s50, gpr_idx(SRC0)\n"
+		"s_nop 0\n"
+		"v_readlane_b32 s46, v64, s51\n"            // remaining edges
+		"v_readlane_b32 s44, v120, s51\n"           // ends 0|1
+		"v_readlane_b32 s45, v176, s51\n"           // ends 2|3
+		"s_set_gpr_idx_off\n"
+		"s_sub_u32 s43, s43, 1\n"
+		"s_cbranch_scc1 8f\n"                       // no room for another event
+		"s_andn2_b32 s46, s46, s41\n"               // remaining edges without the one we came by
+		"s_cbranch_scc0 4f\n"
+		"s_ff1_i32_b32 s47, s46\n"                  // lowest-numbered edge: right, left, down, up
+		"s_bitset0_b32 s46, s47\n"
+		"s_lshl_b64 exec, 1, s51\n"                 // the node's lane
+		"s_set_gpr_idx_on s50, gpr_idx(DST)\n"
+		"s_nop 0\n"
+		"v_mov_b32 v64, s46\n"
+		"s_set_gpr_idx_off\n"
+		"s_mov_b64 exec, 1\n"
+		"s_lshl_b32 s48, s47, 4\n"
+		"s_lshr_b64 s[44:45], s[44:45], s48\n"      // the edge's end in the low 16 bits
+		"s_lshl_b32 s49, s40, 2\n"
+		"s_or_b32 s49, s49, s47\n"                  // node * 4 + edge
+		"s_cmp_eq_u32 s46, 0\n"
+		"s_cbranch_scc1 3f\n"
+		"s_cmp_ge_u32 s42, s54\n"                   // ---- more edges left: the node goes on the branch stack
+		"s_cbranch_scc1 9f\n"
+		"s_bitset1_b32 s49, 30\n"                   // kEvBseg
+		"v_add_u32 v25, 4, v25\n"
+		"v_lshl_or_b32 v28, v29, 12, s40\n"         // this event's index << 14 | node
+		"s_add_u32 s42, s42, 1\n"
+		"ds_write_b32 v25, v28\n"
+		"3:\n"
+		"v_mov_b32 v30, s49\n"
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"s_and_b32 s48, s44, 3\n"
+		"s_lshl_b32 s41, 1, s48\n"                  // the edge consumed at the far end
+		"s_bfe_u32 s40, s44, 0xe0002\n"             // its node: bits 2 .. 15
+		"s_branch 1b\n"
+		"4:\n"                                      // ---- dead end
+		"s_lshl_b64 exec, 1, s51\n"
+		"s_set_gpr_idx_on s50, gpr_idx(DST)\n"
+		"s_nop 0\n"
+		"v_mov_b32 v64, 0\n"
+		"s_set_gpr_idx_off\n"
+		"s_mov_b64 exec, 1\n"
+		"s_cmp_eq_u32 s42, 0\n"
+		"s_cbranch_scc1 7f\n"
+		"s_waitcnt lgkmcnt(0)\n"
+		"v_readfirstlane_b32 s49, v26\n"            // back to the most recent branch node
+		"s_and_b32 s40, s49, 0x3fff\n"
+		"s_lshr_b32 s49, s49, 14\n"
+		"s_bitset1_b32 s49, 31\n"                   // kEvDead | its kEvBseg
+		"v_mov_b32 v30, s49\n"
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"v_add_u32 v25, -4, v25\n"
+		"s_sub_u32 s42, s42, 1\n"
+		"s_mov_b32 s41, 0\n"
+		"s_branch 1b\n"
+		"7:\n"                                      // ---- the chain is complete
+		"v_mov_b32 v30, 0xc0000000\n"               // kEvEnd
+		"global_store_dword v29, v30, s[52:53]\n"
+		"v_add_u32 v29, 4, v29\n"
+		"s_add_u32 s55, s55, 1\n"
+		"s_branch 20b\n"
+		"30:\n"
+		"s_mov_b32 s48, 0\n"
+		"s_branch 6f\n"
+		"8:\n"
+		"s_mov_b32 s43, 0\n"
+		"s_mov_b32 s48, 1\n"
+		"s_branch 6f\n"
+		"9:\n"
+		"s_mov_b32 s48, 2\n"
+		"6:\n"
+		"s_setprio 0\n"
+		"s_waitcnt lgkmcnt(0)\n"
+		"s_mov_b64 exec, s[62:63]\n"
+		"s_mov_b32 m0, s61\n"
+		"v_readfirstlane_b32 s49, v29\n"
+		"v_mov_b32 %[off], s49\n"
+		"v_mov_b32 %[left], s43\n"
+		"v_mov_b32 %[st], s48\n"
+		: [off] "+v"(off), [left] "+v"(left), [st] "=v"(status)
+		: [nblk] "s"(nblk), [list] "s"(list_base), [nst] "s"(n_starts), [top] "v"(top0), [evlo] "s"(ev_lo), [evhi] "s"(ev_hi), [c0lo] "s"(c0_lo), [c0hi] "s"(c0_hi), [maxd] "s"(max_depth)
+		: "memory", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s61", "s62", "s63",
+		  "v20", "v21", "v22", "v24", "v25", "v26", "v28", "v29", "v30", "v32", "v33", "v34",
+		  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231");
+	ev_off = __builtin_amdgcn_readfirstlane(off);
+	ev_left = __builtin_amdgcn_readfirstlane(left);
+	return __builtin_amdgcn_readfirstlane(status);
+}
+
 // grid = nslices, block = one wavefront; dynamic LDS = lds_bytes
 static __global__ void __launch_bounds__(kWave) k_trail_walk(TrailArgs a, uint32_t lds_bytes) {
 	extern __shared__ uint32_t s_trail[];
@@ -1131,6 +1304,52 @@ static __global__ void __launch_bounds__(kWave) k_trail_walk(TrailArgs a, uint32
 		return;
 	}
 	const unsigned long long dbg_k0 = (kTuning && a.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
+	// hand-scheduled walk with the node tables in registers (slices of up to 3584 nodes)
+	if (!a.walk_plain && !a.walk_no_regs && nn <= kWalkRegNodes && __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s_trail))) == 0u) {
+		const uint32_t nblk = (nn + 63u) / 64u;
+		const uint32_t recs = nblk * 64u * 12u;
+		const uint32_t n_starts = a.n_starts[zi];
+		const uint32_t list_bytes = ((n_starts * 4u + 15u) / 16u) * 16u;
+		const uint32_t kcap = a.kcap[zi];
+		const uint32_t ecap = a.icap[zi];
+		if (nblk > 0u && n_starts <= kcap && recs + list_bytes + 2048u <= lds_bytes) {
+			for (uint32_t j = threadIdx.x; j < nblk * 64u; j += kWave) {
+				uint32_t e[4] = { 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu };
+				if (j < nn) {
+#pragma unroll
+					for (uint32_t k = 0; k < 4; k++) {
+						const uint32_t d = a.dart_end[(nb + j) * 4u + k];
+						e[k] = d == kDartNone ? 0xFFFFu : d;
+					}
+				}
+				s_trail[j * 3u] = j < nn ? a.node_adj[nb + j] : 0u;
+				s_trail[j * 3u + 1u] = e[0] | (e[1] << 16);
+				s_trail[j * 3u + 2u] = e[2] | (e[3] << 16);
+			}
+			const uint32_t* starts = a.starts + nb;
+			const uint32_t* vert2node = a.vert2node + static_cast<uint64_t>(zi) * a.nverts;
+			uint32_t* ch_node = a.chain_node + a.kbase[zi];
+			for (uint32_t si = threadIdx.x; si < n_starts; si += kWave) {
+				const uint32_t sv = starts[si];
+				s_trail[recs / 4u + si] = vert2node[sv];
+				ch_node[si] = sv;
+			}
+			__syncthreads();
+			const uint32_t stack_base = recs + list_bytes;
+			const uint32_t max_depth = min((lds_bytes - stack_base) / 4u, a.walk_stack_cap);
+			uint32_t off = 0, left = min(ecap, 262143u);
+			const uint32_t st = trail_walk_slice_regs_asm(nblk, recs, n_starts, stack_base, max_depth, a.events + a.ibase[zi], a.chain_ev0 + a.kbase[zi], off, left);
+			if (st == 0u || (st == 1u && ecap <= 262143u)) {
+				if (threadIdx.x == 0) {
+					a.n_events[zi] = (off >> 2) | kEvWalkWide;
+					a.n_chains[zi] = n_starts;
+					if (st) atomicOr(a.slice_err + zi, TRAIL_ERR_CAPACITY);
+				}
+				return;
+			}
+			__syncthreads();      // (branch stack beyond its LDS part, or more events than a stack entry can name: the walks below)
+		}
+	}
 	// hand-scheduled walk: [node records of 12 bytes][branch stack: 4 bytes per entry]
 	const uint32_t rec_bytes = nn * 12u + 16u;
 	if (!a.walk_plain && nn < 5461u && rec_bytes + 2048u <= lds_bytes && __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s_trail))) == 0u) {
