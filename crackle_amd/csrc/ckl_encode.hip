@@ -705,6 +705,22 @@ __global__ void __launch_bounds__(kBlock) k_bitonic_step(uint64_t* __restrict__ 
 }
 // all steps with j < 2048 of one k-stage inside LDS (2048 elements per workgroup)
 // every stage k = 2 .. 2048 of the network inside blocks of 2048 keys: one launch instead of eleven
+// two steps of the network (distances j and j / 2) in one launch: a thread takes the four elements that the two
+// steps exchange among themselves (the launches of the sort are what it costs: ~6 us each on the label stream)
+__global__ void __launch_bounds__(kBlock) k_bitonic_step2(uint64_t* __restrict__ a, uint32_t j, uint32_t k, uint32_t n) {
+	const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+	if (t >= n / 4u) return;
+	const uint32_t h = j >> 1;
+	const uint32_t lb = static_cast<uint32_t>(__ffs(h)) - 1u;
+	const uint32_t i = (t & (h - 1u)) | ((t >> lb) << (lb + 2u));      // bits h and j clear
+	uint64_t v0 = a[i], v1 = a[i | h], v2 = a[i | j], v3 = a[i | j | h];
+	const bool up = (i & k) == 0;
+	auto cx = [&](uint64_t& x, uint64_t& y) { if ((x > y) == up) { const uint64_t z = x; x = y; y = z; } };
+	cx(v0, v2); cx(v1, v3);
+	cx(v0, v1); cx(v2, v3);
+	a[i] = v0; a[i | h] = v1; a[i | j] = v2; a[i | j | h] = v3;
+}
+
 __global__ void __launch_bounds__(kBlock) k_bitonic_first(uint64_t* __restrict__ a, uint32_t n) {
 	__shared__ uint64_t s[2048];
 	const uint32_t base = blockIdx.x * 2048u;
@@ -2222,6 +2238,7 @@ uint64_t flat_section(ckl_encoder& e, uint64_t N, int stored_width, int componen
 	hipLaunchKernelGGL(k_bitonic_first, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, n_pad);
 	for (uint32_t k = 4096; k <= n_pad; k <<= 1) {
 		uint32_t j = k >> 1;
+		for (; j >= 4096 && !getenv("CKL_BITONIC_SINGLE_STEPS"); j >>= 2) hipLaunchKernelGGL(k_bitonic_step2, dim3((n_pad / 4 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 		for (; j >= 2048; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3(blocks), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 		hipLaunchKernelGGL(k_bitonic_local, dim3(n_pad / 2048), dim3(kBlock), 0, s, e.d_sorted.p, j, k, n_pad);
 	}
