@@ -164,6 +164,87 @@ __global__ void __launch_bounds__(64) k_vmem_chase(unsigned long long* out, cons
 	T1(x)
 }
 
+// ---- pieces of the register-table walk (trail_walk_slice_regs_asm)
+// a chase through a table held in registers: index -> s_set_gpr_idx_on, v_readlane, off -> next index
+__global__ void __launch_bounds__(64) k_gpridx_chase(unsigned long long* out, uint32_t seed) {
+	uint32_t x = __builtin_amdgcn_readfirstlane(seed & 1023u);
+	const uint32_t lane = threadIdx.x;
+	T0
+	asm volatile(
+		// 16 table registers v64..v79: entry of node n (lane n & 63 of register n >> 6) = (n * 37 + 11) & 1023
+		"s_mov_b32 s50, 0\n"
+		"10:\n"
+		"s_lshl_b32 s51, s50, 6\n"
+		"v_add_u32 v20, s51, %[lane]\n"
+		"v_mul_u32_u24 v20, 37, v20\n"
+		"v_add_u32 v20, 11, v20\n"
+		"v_and_b32 v20, 1023, v20\n"
+		"s_set_gpr_idx_on s50, gpr_idx(DST)\n"
+		"v_mov_b32 v64, v20\n"
+		"s_set_gpr_idx_off\n"
+		"s_add_u32 s50, s50, 1\n"
+		"s_cmp_lt_u32 s50, 16\n"
+		"s_cbranch_scc1 10b\n"
+		"s_mov_b32 s52, 0\n"
+		"1:\n"
+		"s_lshr_b32 s50, %[x], 6\n"
+		"s_and_b32 s51, %[x], 63\n"
+		"s_set_gpr_idx_on s50, gpr_idx(SRC0)\n"
+		"v_readlane_b32 %[x], v64, s51\n"
+		"s_set_gpr_idx_off\n"
+		"s_add_u32 s52, s52, 1\n"
+		"s_cmp_lt_u32 s52, 4096\n"
+		"s_cbranch_scc1 1b\n"
+		: [x] "+s"(x) : [lane] "v"(lane)
+		: "scc", "s50", "s51", "s52", "v20", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
+	T1(x)
+}
+// the mode switch alone: on / off pairs in a dependent SALU chain
+__global__ void __launch_bounds__(64) k_gpridx_onoff(unsigned long long* out, uint32_t seed) {
+	uint32_t x = __builtin_amdgcn_readfirstlane(seed & 7u);
+	T0
+	for (int i = 0; i < N / 4; i++) {
+		asm volatile(
+			"s_set_gpr_idx_on %0, gpr_idx(SRC0)\n s_set_gpr_idx_off\n s_add_u32 %0, %0, 1\n s_and_b32 %0, %0, 7\n"
+			"s_set_gpr_idx_on %0, gpr_idx(SRC0)\n s_set_gpr_idx_off\n s_add_u32 %0, %0, 1\n s_and_b32 %0, %0, 7\n"
+			"s_set_gpr_idx_on %0, gpr_idx(SRC0)\n s_set_gpr_idx_off\n s_add_u32 %0, %0, 1\n s_and_b32 %0, %0, 7\n"
+			"s_set_gpr_idx_on %0, gpr_idx(SRC0)\n s_set_gpr_idx_off\n s_add_u32 %0, %0, 1\n s_and_b32 %0, %0, 7\n"
+			: "+s"(x) : : "scc", "m0");
+	}
+	T1(x)
+}
+// EXEC narrowed to one lane for one VALU write, then back
+__global__ void __launch_bounds__(64) k_exec_one_lane(unsigned long long* out, uint32_t seed) {
+	uint32_t x = __builtin_amdgcn_readfirstlane(seed & 63u);
+	uint32_t v = threadIdx.x;
+	T0
+	for (int i = 0; i < N / 4; i++) {
+		asm volatile(
+			"s_mov_b64 s[62:63], exec\n"
+			"s_lshl_b64 exec, 1, %0\n v_mov_b32 %1, %0\n s_mov_b64 exec, s[62:63]\n s_add_u32 %0, %0, 1\n s_and_b32 %0, %0, 63\n"
+			"s_lshl_b64 exec, 1, %0\n v_mov_b32 %1, %0\n s_mov_b64 exec, s[62:63]\n s_add_u32 %0, %0, 1\n s_and_b32 %0, %0, 63\n"
+			"s_lshl_b64 exec, 1, %0\n v_mov_b32 %1, %0\n s_mov_b64 exec, s[62:63]\n s_add_u32 %0, %0, 1\n s_and_b32 %0, %0, 63\n"
+			"s_lshl_b64 exec, 1, %0\n v_mov_b32 %1, %0\n s_mov_b64 exec, s[62:63]\n s_add_u32 %0, %0, 1\n s_and_b32 %0, %0, 63\n"
+			: "+s"(x), "+v"(v) : : "scc", "s62", "s63");
+	}
+	T1(x + v)
+}
+// a fire-and-forget store per step beside a dependent SALU chain
+__global__ void __launch_bounds__(64) k_store_per_step(unsigned long long* out, uint32_t* sink, uint32_t seed) {
+	uint32_t x = __builtin_amdgcn_readfirstlane(seed);
+	uint32_t off = 0;
+	T0
+	for (int i = 0; i < N / 4; i++) {
+		asm volatile(
+			"v_mov_b32 v30, %0\n global_store_dword %1, v30, %2\n v_add_u32 %1, 4, %1\n s_add_u32 %0, %0, 1\n"
+			"v_mov_b32 v30, %0\n global_store_dword %1, v30, %2\n v_add_u32 %1, 4, %1\n s_add_u32 %0, %0, 1\n"
+			"v_mov_b32 v30, %0\n global_store_dword %1, v30, %2\n v_add_u32 %1, 4, %1\n s_add_u32 %0, %0, 1\n"
+			"v_mov_b32 v30, %0\n global_store_dword %1, v30, %2\n v_add_u32 %1, 4, %1\n s_add_u32 %0, %0, 1\n"
+			: "+s"(x), "+v"(off) : "s"(sink) : "scc", "v30", "memory");
+	}
+	T1(x)
+}
+
 int main() {
 	unsigned long long* out; uint32_t* tab;
 	CK(hipMalloc(&out, 64)); CK(hipMalloc(&tab, 16384));
@@ -190,6 +271,15 @@ int main() {
 		hipLaunchKernelGGL(k_smem_chase, dim3(1), dim3(64), 0, 0, out, tab, 1u); report("scalar-cache chase (s_load_dword)", N);
 		hipLaunchKernelGGL(k_vmem_chase<false>, dim3(1), dim3(64), 0, 0, out, tab, 1u); report("vector L1 chase (global_load_dword)", N);
 		hipLaunchKernelGGL(k_vmem_chase<true>, dim3(1), dim3(64), 0, 0, out, tab, 1u); report("L2 chase (global_load_dword sc1)", N);
+	}
+	{
+		uint32_t* sink; CK(hipMalloc(&sink, 65536 * 4));
+		for (int rep = 0; rep < 2; rep++) {
+			hipLaunchKernelGGL(k_gpridx_chase, dim3(1), dim3(64), 0, 0, out, 1u); report("register-table chase (idx on, v_readlane, idx off)", 4096);
+			hipLaunchKernelGGL(k_gpridx_onoff, dim3(1), dim3(64), 0, 0, out, 1u); report("s_set_gpr_idx_on + off + 2 SALU", N);
+			hipLaunchKernelGGL(k_exec_one_lane, dim3(1), dim3(64), 0, 0, out, 1u); report("exec = 1 << lane, v_mov, exec back, 2 SALU", N);
+			hipLaunchKernelGGL(k_store_per_step, dim3(1), dim3(64), 0, 0, out, sink, 1u); report("v_mov, global_store_dword, v_add, s_add", N);
+		}
 	}
 	// the same with 512 wavefronts in flight, one per workgroup (how the walk runs)
 	hipLaunchKernelGGL(k_lds_chase, dim3(512), dim3(64), 0, 0, out, 1u, 1); report("LDS chase via SGPR, lane 0 only, 512 workgroups", N);
