@@ -261,7 +261,7 @@ def test_large_slices_and_dense_graphs(checker):
   assert np.array_equal(crackle_amd.decompress(want), bits)
 
 
-@pytest.mark.parametrize("env", [{"CKL_TRAIL_LDS": "4096"}, {"CKL_TRAIL_WALK": "plain"}, {"CKL_TRAIL_WALK_STACK": "8"}, {"CKL_LABELS_AT_WALK": "0"}, {"CKL_PLANES_GENERIC": "1"}, {"CKL_NO_OVERLAP": "1"}, {"CKL_SMALL_ESTIMATE": "1"}, {"CKL_STRIP_RUNS": "64"}])
+@pytest.mark.parametrize("env", [{"CKL_TRAIL_LDS": "4096"}, {"CKL_TRAIL_WALK": "plain"}, {"CKL_TRAIL_WALK": "lds"}, {"CKL_TRAIL_WALK": "lds", "CKL_TRAIL_WALK_STACK": "8"}, {"CKL_BITONIC_SINGLE_STEPS": "1"}, {"CKL_TRAIL_WALK_STACK": "8"}, {"CKL_LABELS_AT_WALK": "0"}, {"CKL_PLANES_GENERIC": "1"}, {"CKL_NO_OVERLAP": "1"}, {"CKL_SMALL_ESTIMATE": "1"}, {"CKL_STRIP_RUNS": "64"}])
 def test_encoder_fallback_paths(env, checker, monkeypatch):
   """The encoder's alternate code paths (node tables / union-find in global memory instead
   of LDS, the compiled walk instead of the hand-scheduled one, a walk that starts over because its
