@@ -270,6 +270,26 @@ __device__ __forceinline__ void rec_match_global(
 	if (rerr) atomicOr(rerr_out, rerr);
 }
 
+// Do the moves of a stretch — the positions of `part` (spread mask, bit 2k = position k emits) of a word whose
+// moves are `prevs` — from vertex `start` (y << 16 | x, inside the grid) stay inside the vertex grid?  The strip
+// kernel rasterises without looking (k_strip_ccl2 clamps what leaves its strip), so a stream whose trail walks
+// off the image is caught here: the counts of the four directions settle it for every stretch that is not next
+// to a border, the others are stepped through (crackcodes.hpp:706-862 indexes its edge vector with such a vertex).
+__device__ __forceinline__ bool stretch_in_grid(uint32_t start, uint32_t prevs, uint32_t part, uint32_t sx, uint32_t sy) {
+	const uint32_t x = start & 0xFFFFu, y = start >> 16;
+	const uint32_t hz = part & prevs, vt = part & ~prevs;
+	const uint32_t nr = __popc(hz & ~(prevs >> 1)), nl = __popc(hz & (prevs >> 1)), nd = __popc(vt & (prevs >> 1)), nu = __popc(vt & ~(prevs >> 1));
+	if (nl <= x && x + nr <= sx && nu <= y && y + nd <= sy) return true;
+	uint32_t p = start;
+	for (uint32_t m = part; m; m &= m - 1u) {
+		const uint32_t kind = (prevs >> (__ffs(m) - 1u)) & 3u;
+		const uint32_t unit = (kind & 1u) ? 1u : 0x10000u;
+		p = ((kind ^ (kind >> 1)) & 1u) ? p + unit : p - unit;      // right (1) and down (2) add
+		if ((p & 0xFFFFu) > sx || (p >> 16) > sy) return false;
+	}
+	return true;
+}
+
 // The records of one parked word: the stretches between its 't's, two per record ([A] t [B] | t [A] t [B]
 // | ...; the record carries the jump between its two), each record into the list of every strip its
 // moves can touch.  seg: the segments' offsets (LDS or global), cursor: the slice's list lengths in LDS.
@@ -300,7 +320,7 @@ __device__ __forceinline__ void word_to_records(
 	// that of their own); false when the vertex is outside the grid
 	auto strips_of = [&](uint32_t start, uint32_t part, uint32_t& k0, uint32_t& k1) -> bool {
 		const uint32_t y = start >> 16, x = start & 0xFFFFu;
-		if (x > sx || y > sy) { rerr |= ERR_RANGE; return false; }
+		if (x > sx || y > sy || !stretch_in_grid(start, prevs, part, sx, sy)) { rerr |= ERR_RANGE; return false; }
 		const uint32_t nu = __popc(mU & part), nd = __popc(mD & part);
 		const uint32_t ya = y > nu ? y - nu : 0u, yb = min(y + nd, sy);
 		k0 = L.strip_of(ya); k1 = min(L.strip_of(yb), nstrips - 1u);
@@ -586,7 +606,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 					const uint32_t prevs = wr[q].x, ms = flags;
 					const uint32_t start = seg[o_t] + wr[q].z;
 					const uint32_t y = start >> 16, x = start & 0xFFFFu;
-					if (x > sx || y > sy) { rerr |= ERR_RANGE; continue; }
+					if (x > sx || y > sy || !stretch_in_grid(start, prevs, ms, sx, sy)) { rerr |= ERR_RANGE; continue; }
 					const uint32_t nu = __popc(ms & ~(prevs >> 1) & ~prevs), nd = __popc(ms & (prevs >> 1) & ~prevs);
 					const uint32_t k0 = L.strip_of(y > nu ? y - nu : 0u), k1 = min(L.strip_of(min(y + nd, sy)), nstrips - 1u);
 					const uint4 rec = make_uint4(start, prevs, ms, 0u);

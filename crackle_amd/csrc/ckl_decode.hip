@@ -34,6 +34,7 @@
 #include "ckl_common.hpp"
 #include "ckl_runs.hpp"
 #include "ckl_strips.hpp"
+#include "ckl_strips2.hpp"
 #include "ckl_contours.hpp"
 #include "ckl_pins.hpp"
 
@@ -2956,8 +2957,52 @@ void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p,
 	const uint32_t npx = static_cast<uint32_t>(d.sxy);
 	const RecordLists rl = record_lists(d);
 	bool launched = false;
+	// k_strip_ccl2 (ckl_strips2.hpp): rows of 4 .. 512 plane words, a power of two; CKL_STRIP_V1 keeps k_strip_ccl
+	uint32_t rsh = 0;
+	while ((1u << rsh) < d.row_words) rsh++;
+	const bool v2 = records && (1u << rsh) == d.row_words && rsh >= 2 && rsh <= 9 && !getenv("CKL_STRIP_V1");
+	if (v2) {
+		Strip2Args a2;
+		a2.rsh = rsh; a2.variant = 0;
+		if (const char* env = getenv("CKL_STRIP_VARIANT")) a2.variant = static_cast<uint32_t>(atoi(env));
+		const bool edgelist = (a2.variant & 1u) != 0u;
+		if constexpr (kTuning) {
+			if (diag) {
+				// per-workgroup stamps: raw s_memtime at the phase boundaries
+				const size_t nwg = static_cast<size_t>(d.nstrips) * n;
+				DevBuf<unsigned long long> stamps;
+				stamps.ensure(nwg * kStrip2Stamps);
+				CKL_HIP(hipMemsetAsync(stamps.p, 0, nwg * kStrip2Stamps * sizeof(unsigned long long), s));
+				if (edgelist) hipLaunchKernelGGL((k_strip_ccl2<true, true>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, a2, stamps.p);
+				else hipLaunchKernelGGL((k_strip_ccl2<true, false>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, a2, stamps.p);
+				std::vector<unsigned long long> hs(nwg * kStrip2Stamps);
+				CKL_HIP(hipMemcpyAsync(hs.data(), stamps.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+				CKL_HIP(hipStreamSynchronize(s));
+				double ph[kStrip2Stamps] = {};
+				size_t cnt = 0;
+				unsigned long long t_first = ~0ull, t_last = 0;
+				for (size_t w = 0; w < nwg; w++) {
+					const unsigned long long* q = hs.data() + w * kStrip2Stamps;
+					if (!q[0] || !q[6]) continue;      // overflowed strip
+					for (uint32_t i = 1; i <= 6; i++) ph[i] += static_cast<double>(q[i] - q[i - 1]);
+					t_first = std::min(t_first, q[0]); t_last = std::max(t_last, q[6]);
+					cnt++;
+				}
+				const double c = cnt ? static_cast<double>(cnt) : 1.0;
+				fprintf(stderr, "[ckl strip2 diag, mean cycles per workgroup, %zu workgroups] raster=%.0f read+scan=%.0f starts=%.0f unions=%.0f roots+ids=%.0f weights=%.0f | lifetime=%.0f span(raw)=%.0f\n",
+					cnt, ph[1] / c, ph[2] / c, ph[3] / c, ph[4] / c, ph[5] / c, ph[6] / c, (ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]) / c, static_cast<double>(t_last - t_first));
+				launched = true;
+			}
+		}
+		if (!launched) {
+			if (kTuning && edgelist) hipLaunchKernelGGL((k_strip_ccl2<false, true>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, a2, static_cast<unsigned long long*>(nullptr));
+			else hipLaunchKernelGGL((k_strip_ccl2<false, false>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, a2, static_cast<unsigned long long*>(nullptr));
+			launched = true;
+		}
+		diag = nullptr;      // (the other strip kernels' stamps are k_strip_ccl's scheme)
+	}
 	if constexpr (kTuning) {
-		if (diag) {
+		if (diag && !launched) {
 			if (records) hipLaunchKernelGGL((k_strip_ccl<true, true>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, diag);
 			else hipLaunchKernelGGL((k_strip_ccl<true, false>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, diag);
 			launched = true;
@@ -2967,7 +3012,7 @@ void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p,
 		if (records) hipLaunchKernelGGL((k_strip_ccl<false, true>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, static_cast<unsigned long long*>(nullptr));
 		else hipLaunchKernelGGL((k_strip_ccl<false, false>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, static_cast<unsigned long long*>(nullptr));
 	}
-	if (st) st->done("k_strip_ccl");
+	if (st) st->done(v2 ? "k_strip_ccl2" : "k_strip_ccl");
 	const size_t tab_bytes = static_cast<size_t>(p.ra.cap) * sizeof(uint32_t);      // k_slice_resolve's table
 	if (flat) {
 		bool done = false;

@@ -1,6 +1,6 @@
 """Which kernels answered: every BASELINE.json configuration (one GPU's slab, full slice size) must be
-decoded by the strip path's kernels (k_crack_match -> k_strip_ccl -> k_slice_resolve -> k_paint_strips,
-crackle_amd/csrc/ckl_strips.hpp, ckl_crack_records.hpp) and not by a hand-over to the rasterising kernel or to
+decoded by the strip path's kernels (k_crack_match -> k_strip_ccl2 -> k_slice_resolve -> k_paint_strips,
+crackle_amd/csrc/ckl_strips.hpp, ckl_strips2.hpp, ckl_crack_records.hpp) and not by a hand-over to the rasterising kernel or to
 the general run pipeline — those are silent and session-sticky (ckl_decode.hip: decoder_run), which is how C4
 once ran at 2 % of the roofline without a test noticing.  The stage names come from ckl_decoder_stage_timing,
 the encoder's walk from ckl_encoder_walk_paths.  Outputs are checked as well (round trip on the device)."""
@@ -13,8 +13,9 @@ from crackle_amd import distributed as ckd
 
 pytestmark = pytest.mark.gpu
 
-FAST_FLAT = ["k_crack_match", "k_strip_ccl", "k_slice_resolve", "k_paint_strips"]
-FAST_PINS = ["k_crack_match", "k_strip_ccl", "k_slice_resolve", "k_label_map_pins", "k_strip_labels", "k_paint_strips"]
+# k_strip_ccl2 (ckl_strips2.hpp) is the strip kernel for rows of a power of two of plane words: every shape below
+FAST_FLAT = ["k_crack_match", "k_strip_ccl2", "k_slice_resolve", "k_paint_strips"]
+FAST_PINS = ["k_crack_match", "k_strip_ccl2", "k_slice_resolve", "k_label_map_pins", "k_strip_labels", "k_paint_strips"]
 SLOW = {"k_decode_cracks", "k_run_index", "k_run_union_strips", "k_run_assign", "k_paint_runs"}
 
 # name, slab shape, dtype, encoder options, offset added to the labels
