@@ -2995,11 +2995,12 @@ void launch_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, StripPlan p,
 			}
 		}
 		if (!launched) {
-			if (kTuning && edgelist) hipLaunchKernelGGL((k_strip_ccl2<false, true>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, a2, static_cast<unsigned long long*>(nullptr));
-			else hipLaunchKernelGGL((k_strip_ccl2<false, false>), dim3(d.nstrips, n), dim3(kBlock), 0, s, g, p.sa, rl, d.G->p, npx, a2, static_cast<unsigned long long*>(nullptr));
+			size_t pad = 0;      // tuning: dynamic LDS nobody uses, to see what fewer workgroups per CU cost (CKL_STRIP_PAD bytes)
+			if (kTuning) if (const char* env = getenv("CKL_STRIP_PAD")) pad = static_cast<size_t>(atoi(env));
+			if (kTuning && edgelist) hipLaunchKernelGGL((k_strip_ccl2<false, true>), dim3(d.nstrips, n), dim3(kBlock), pad, s, g, p.sa, rl, d.G->p, npx, a2, static_cast<unsigned long long*>(nullptr));
+			else hipLaunchKernelGGL((k_strip_ccl2<false, false>), dim3(d.nstrips, n), dim3(kBlock), pad, s, g, p.sa, rl, d.G->p, npx, a2, static_cast<unsigned long long*>(nullptr));
 			launched = true;
 		}
-		diag = nullptr;      // (the other strip kernels' stamps are k_strip_ccl's scheme)
 	}
 	if constexpr (kTuning) {
 		if (diag && !launched) {

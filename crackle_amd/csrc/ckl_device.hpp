@@ -30,7 +30,7 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
 	return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(v), CTRL, ROW_MASK, 0xF, false));
 }
-constexpr int kDppRowShr = 0x110, kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138;
+constexpr int kDppRowShr = 0x110, kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;      // wave_shl:1 = every lane takes the value of the lane above it
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
 	v += dpp_u32<kDppRowShr + 1, 0xF>(0u, v);
 	v += dpp_u32<kDppRowShr + 2, 0xF>(0u, v);

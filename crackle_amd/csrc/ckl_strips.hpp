@@ -505,6 +505,27 @@ struct ResolveArgs {
 	uint32_t cap;                    // strip components the LDS table holds (<= kResolveCap)
 };
 
+// little-endian integer of W bytes at any address (global memory takes unaligned accesses: one load, not W)
+template <int W>
+__device__ __forceinline__ uint64_t ld_le(const uint8_t* p) {
+	if constexpr (W == 1) return *p;
+	else if constexpr (W == 2) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+	else if constexpr (W == 4) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+	else { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+}
+// f(integral_constant<int, width>) for the widths the format stores (1, 2, 4, 8: lib.hpp compute_byte_width);
+// the switch sits OUTSIDE the loops over entries, so that the loads of all entries are issued side by side — a
+// byte loop with a run-time bound made every byte a trip to memory of its own (k_slice_resolve: 28 of its 48 us)
+template <typename F>
+__device__ __forceinline__ void with_width(uint32_t w, F&& f) {
+	switch (w) {
+		case 1: f(std::integral_constant<int, 1>{}); break;
+		case 2: f(std::integral_constant<int, 2>{}); break;
+		case 4: f(std::integral_constant<int, 4>{}); break;
+		default: f(std::integral_constant<int, 8>{}); break;
+	}
+}
+
 // grid = slices of the launch, block = kResolveBlock
 // LABELS: flat labels (label_map is ready): the label of every strip component is written here.
 // Otherwise its component id goes to sc_cc (pins: the label table needs the ids first).
@@ -658,9 +679,22 @@ __device__ __forceinline__ bool slice_resolve_body(
 			cc[q] = s_tab[s_tab[ii] & 0xFFFFu] >> 16;
 			wgt[q] = hand_ld<HANDOFF>(sa.sc_w + gi[q]);
 			key[q] = 0;
-			if (LABELS) {
-				const uint8_t* kp = ra.keys + (coff + (cc[q] < nexp ? cc[q] : 0u)) * ra.key_width;
-				for (uint32_t bt = 0; bt < ra.key_width; bt++) key[q] |= static_cast<uint64_t>(kp[bt]) << (8u * bt);
+		}
+		uint64_t lab[kPer];
+		if (LABELS) {
+			// keys of the four entries in one trip to memory, their labels in a second one (entries past the
+			// end and ids outside the label section read entry 0 and are set right afterwards)
+			with_width(ra.key_width, [&](auto W) {
+#pragma unroll
+				for (uint32_t q = 0; q < kPer; q++) key[q] = ld_le<decltype(W)::value>(ra.keys + (coff + (cc[q] < nexp ? cc[q] : 0u)) * static_cast<uint64_t>(decltype(W)::value));
+			});
+#pragma unroll
+			for (uint32_t q = 0; q < kPer; q++) lab[q] = 0;
+			if (ra.num_unique) {
+				with_width(ra.stored_width, [&](auto W) {
+#pragma unroll
+					for (uint32_t q = 0; q < kPer; q++) lab[q] = ld_le<decltype(W)::value>(ra.uniq + (key[q] < ra.num_unique ? key[q] : 0ull) * static_cast<uint64_t>(decltype(W)::value));
+				});
 			}
 		}
 #pragma unroll
@@ -669,8 +703,7 @@ __device__ __forceinline__ bool slice_resolve_body(
 			if (LABELS) {
 				uint64_t val = 0;
 				if (cc[q] < nexp && key[q] < ra.num_unique) {
-					const uint8_t* up = ra.uniq + key[q] * ra.stored_width;
-					for (uint32_t bt = 0; bt < ra.stored_width; bt++) val |= static_cast<uint64_t>(up[bt]) << (8u * bt);
+					val = lab[q];
 					if (ra.is_signed && ra.stored_width < 8u && (val >> (8u * ra.stored_width - 1u))) val |= ~0ull << (8u * ra.stored_width);
 				}
 				if (ra.has_label) val = (val == ra.label);

@@ -84,7 +84,6 @@ __device__ __forceinline__ void strip_ccl2_body(
 	uint32_t* s_bm = s_mem + kStripEdgeCap + kStripWords / 2;
 	uint32_t* s_bmbase = s_bm + kStripBitmapWords;
 	uint32_t* s_scan = s_bmbase + kStripBitmapWords;
-	uint32_t* s_misc = s_scan + kWaves;
 	const uint32_t t = threadIdx.x;
 	unsigned long long* my_diag = DIAG ? diag + (static_cast<uint64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * kStrip2Stamps : nullptr;
 	auto stamp = [&](int slot) { if (DIAG && t == 0) my_diag[slot] = __builtin_amdgcn_s_memtime(); };
@@ -100,6 +99,7 @@ __device__ __forceinline__ void strip_ccl2_body(
 		const uint32_t n_rec = min(rl.count[si], rl.cap);
 		const uint4* list = rl.rec + static_cast<uint64_t>(si) * rl.cap;
 		const uint4 first = list[(t >> 1) < rl.cap ? (t >> 1) : 0u];      // requested with the count, not behind it
+		const uint4 second = list[(t >> 1) + kBlock / 2u < rl.cap ? (t >> 1) + kBlock / 2u : 0u];      // (most strips of a 1024-wide slice hold 130 - 300 records)
 		*reinterpret_cast<uint4*>(s_par + t * 4u) = make_uint4(0u, 0u, 0u, 0u);
 		*reinterpret_cast<uint4*>(s_mem + t * 4u) = make_uint4(0u, 0u, 0u, 0u);
 		__syncthreads();
@@ -107,7 +107,8 @@ __device__ __forceinline__ void strip_ccl2_body(
 		const unsigned long long table = static_cast<unsigned long long>((0u - S) & 0xFFFFu) | (1ull << 16) | (static_cast<unsigned long long>(S) << 32) | (0xFFFFull << 48);
 		const uint32_t half = t & 1u;
 		if ((t >> 1) < n_rec) raster2_half(first, half, y0, sh, nw, table, s_par);
-		for (uint32_t r = (t >> 1) + kBlock / 2u; r < n_rec; r += kBlock / 2u) raster2_half(list[r], half, y0, sh, nw, table, s_par);
+		if ((t >> 1) + kBlock / 2u < n_rec) raster2_half(second, half, y0, sh, nw, table, s_par);
+		for (uint32_t r = (t >> 1) + kBlock; r < n_rec; r += kBlock / 2u) raster2_half(list[r], half, y0, sh, nw, table, s_par);
 		__syncthreads();
 	}
 	stamp(1);
@@ -243,6 +244,9 @@ __device__ __forceinline__ void strip_ccl2_body(
 	__syncthreads();      // the pool now takes the strip components
 	stamp(4);
 	// ---- roots -> strip-local component ids in run order; the roots of 64 consecutive runs are one ballot
+	// (all finds of a thread advancing together, one hop per round, were slower: 0.169 against 0.148 ms — every slot
+	// reads the table every round until the slowest lane of the wavefront is through, and LDS traffic is what this
+	// kernel is short of)
 	uint32_t root[kStripRunsPerThread];
 #pragma unroll
 	for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
@@ -250,50 +254,69 @@ __device__ __forceinline__ void strip_ccl2_body(
 		const uint32_t j = t + i * kBlock;
 		root[i] = j < nloc ? sm_find(s_par, j) : 0xFFFFFFFFu;
 		const unsigned long long roots = __ballot(root[i] == j);
-		if ((t & 63u) == 0u) *reinterpret_cast<uint2*>(s_bm + (j >> 5)) = make_uint2(static_cast<uint32_t>(roots), static_cast<uint32_t>(roots >> 32));
+		if ((t & 31u) == 0u) s_bm[(j >> 5) * 2u] = (t & 32u) ? static_cast<uint32_t>(roots >> 32) : static_cast<uint32_t>(roots);      // (bits, base) pairs: s_bm2 below
 	}
 	__syncthreads();
-	if (t < kWave) {
+	// root bitmap -> (bits, roots before the word) pairs: a run's strip component is one 8-byte LDS read away
+	uint2* s_bm2 = reinterpret_cast<uint2*>(s_bm);      // [kStripBitmapWords] over s_bm | s_bmbase
+	// every wavefront scans the whole bitmap for itself and writes all the bases (the same values four times over:
+	// a wavefront then reads what it wrote itself, and the barrier behind a scan by one wavefront goes)
+	uint32_t nsc;
+	{
 		static_assert(kStripBitmapWords <= 2 * kWave, "two bitmap words per lane");
+		const uint32_t ln = t & 63u;
 		const uint32_t nbw = (nloc + 31u) >> 5;
-		const uint32_t c0 = t < nbw ? __popc(s_bm[t]) : 0u;
-		const uint32_t c1 = t + kWave < nbw ? __popc(s_bm[t + kWave]) : 0u;
+		const uint32_t c0 = ln < nbw ? __popc(s_bm2[ln].x) : 0u;
+		const uint32_t c1 = ln + kWave < nbw ? __popc(s_bm2[ln + kWave < kStripBitmapWords ? ln + kWave : 0u].x) : 0u;
 		const uint32_t i0 = wave_incl_add(c0);
-		const uint32_t tot0 = __shfl(i0, kWave - 1, kWave);
+		const uint32_t tot0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(i0), kWave - 1));
 		const uint32_t i1 = wave_incl_add(c1);
-		if (t < kStripBitmapWords) s_bmbase[t] = i0 - c0;
-		if (t + kWave < kStripBitmapWords) s_bmbase[t + kWave] = tot0 + i1 - c1;
-		if (t == kWave - 1) s_misc[1] = tot0 + i1;
+		if (ln < nbw) s_bm2[ln].y = i0 - c0;
+		if (ln + kWave < nbw) s_bm2[ln + kWave].y = tot0 + i1 - c1;
+		nsc = tot0 + static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(i1), kWave - 1));
 	}
-	__syncthreads();
-	const uint32_t nsc = s_misc[1];
-	// one byte per run while the strip has at most 256 components (strip_lid)
-	uint16_t* lid_out = sa.run_lid + slot;
-	const bool narrow = nsc <= 256u;
+	uint32_t lid[kStripRunsPerThread];
 #pragma unroll
 	for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 		if (i * kBlock >= nloc) break;      // uniform
 		const uint32_t j = t + i * kBlock;
-		if (j >= nloc) continue;
-		const uint32_t r = root[i];
-		const uint32_t lid = s_bmbase[r >> 5] + __popc(s_bm[r >> 5] & ((1u << (r & 31u)) - 1u));
-		s_pool[j] = static_cast<uint16_t>(lid);
-		if (narrow) reinterpret_cast<uint8_t*>(lid_out)[j] = static_cast<uint8_t>(lid);
-		else lid_out[j] = static_cast<uint16_t>(lid);
+		const uint32_t r = j < nloc ? root[i] : 0u;
+		const uint2 e = s_bm2[r >> 5];
+		lid[i] = e.y + __popc(e.x & ((1u << (r & 31u)) - 1u));
+		if (j < nloc) s_pool[j] = static_cast<uint16_t>(lid[i]);
 	}
 	for (uint32_t j = t; j < nsc; j += kBlock) s_par[j] = 0u;      // every find is done (the barriers of the bitmap scan): the table becomes the weights
 	__syncthreads();
 	stamp(5);
-	// ---- crc weights: run j covering [a_j, a_j+1) adds G[n - a_j] ^ G[n - a_j+1] to its component
-#pragma unroll
-	for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
-		if (i * kBlock >= nloc) break;      // uniform
-		const uint32_t j = t + i * kBlock;
-		if (j >= nloc) continue;
-		atomicXor(s_par + s_pool[j], gv[i]);
-		if (j) atomicXor(s_par + s_pool[j - 1], gv[i]);
+	// the runs' strip components to HBM, four per thread and store: one byte per run while the strip has at most 256
+	// components (strip_lid: the paint kernel reads them beside its stores, where every byte read costs several
+	// bytes' worth of store time)
+	if (nsc <= 256u) {
+		uint32_t* out4 = reinterpret_cast<uint32_t*>(sa.run_lid + slot);
+		for (uint32_t j4 = t * 4u; j4 < nloc; j4 += kBlock * 4u) {
+			const uint2 q = *reinterpret_cast<const uint2*>(s_pool + j4);
+			out4[j4 >> 2] = (q.x & 0xFFu) | ((q.x >> 8) & 0xFF00u) | ((q.y & 0xFFu) << 16) | ((q.y >> 16) << 24);
+		}
 	}
-	if (t == 0 && nloc) atomicXor(s_par + s_pool[nloc - 1], G[n_pixels - y1 * g.sx]);
+	else {
+		uint2* out8 = reinterpret_cast<uint2*>(sa.run_lid + slot);
+		for (uint32_t j4 = t * 4u; j4 < nloc; j4 += kBlock * 4u) out8[j4 >> 2] = *reinterpret_cast<const uint2*>(s_pool + j4);
+	}
+	// ---- crc weights: run j covering [a_j, a_j+1) adds G[n - a_j] ^ G[n - a_j+1] to its component; the start
+	// weight of run j + 1 comes from the lane above (the wavefront's last lane leaves it to that run's own thread)
+	{
+		const uint32_t g_end = G[n_pixels - y1 * g.sx];
+#pragma unroll
+		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
+			if (i * kBlock >= nloc) break;      // uniform
+			const uint32_t j = t + i * kBlock;
+			const uint32_t mine = j < nloc ? gv[i] : 0u;
+			uint32_t x = mine ^ dpp_u32<kDppWaveShl1, 0xF>(0u, mine);
+			if (j + 1u == nloc) x ^= g_end;
+			if (j < nloc) atomicXor(s_par + lid[i], x);
+			if ((t & 63u) == 0u && j && j < nloc) atomicXor(s_par + s_pool[j - 1u], mine);
+		}
+	}
 	__syncthreads();
 	uint32_t* w_out = sa.sc_w + slot;
 	for (uint32_t j = t; j < nsc; j += kBlock) w_out[j] = s_par[j];
