@@ -1672,19 +1672,26 @@ __device__ __forceinline__ void paint_tile_groups(
 // `units` groups of PX pixels of a strip from its tables in LDS; each wave-store is one contiguous stretch
 // (16 bytes per lane for 4- and 8-byte labels).  SX32: rows are whole plane words (pixel p = bit p & 31 of word p >> 5).
 template <typename OUT, uint32_t PX, bool SX32, typename F>
-__device__ __forceinline__ void paint_units_from_lds(const uint32_t* s_b, const uint16_t* s_wb, F label_of, OUT* __restrict__ oz, uint32_t units, uint32_t sx, uint32_t rw) {
+__device__ __forceinline__ void paint_units_from_lds(const uint32_t* s_b, const uint16_t* s_wb, F label_of, OUT* __restrict__ oz, uint32_t units, uint32_t sx, uint32_t rw, bool waveq = false) {
 	constexpr uint32_t U = 4;
 	struct alignas(PX * sizeof(OUT)) VX { OUT v[PX]; };
 	const uint32_t t = threadIdx.x;
 	const uint32_t inv_sx = SX32 ? 0u : 0xFFFFFFFFu / sx + 1u;      // p / sx = umulhi(p, inv) for p * sx < 2^32 (a strip has at most 2^15 pixels)
-	for (uint32_t g0 = 0; g0 < units; g0 += kBlock * U) {
+	// WAVEQ: every wavefront streams its own contiguous quarter of the strip (a multiple of 64 groups, so that
+	// every wave-store stays one aligned stretch) instead of the four taking turns KiB by KiB
+	const uint32_t lanes = waveq ? static_cast<uint32_t>(kWave) : static_cast<uint32_t>(kBlock);
+	const uint32_t quarter = ((units + 3u) / 4u + 63u) & ~63u;
+	const uint32_t first = waveq ? (t >> 6) * quarter : 0u;
+	const uint32_t end = waveq ? min(units, first + quarter) : units;
+	const uint32_t tl = waveq ? (t & 63u) : t;
+	for (uint32_t g0 = first; g0 < end; g0 += lanes * U) {
 		VX val[U];
 		uint32_t at[U];
 #pragma unroll
 		for (uint32_t u = 0; u < U; u++) {
-			const uint32_t gi = g0 + u * kBlock + t;
+			const uint32_t gi = g0 + u * lanes + tl;
 			at[u] = 0xFFFFFFFFu;
-			if (gi >= units) continue;
+			if (gi >= end) continue;
 			const uint32_t p = gi * PX;
 			uint32_t wl, sh;
 			if constexpr (SX32) { wl = p >> 5; sh = p & 31u; }
@@ -1708,16 +1715,20 @@ __device__ __forceinline__ void paint_units_from_lds(const uint32_t* s_b, const 
 
 template <typename OUT>
 constexpr uint32_t paint_strips_words() {
-	return (((kStripCap + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u + kStripWords + kStripWords / 2u + kWaves + 7u) & ~7u;
+	return (((kStripCap + 8u + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u + kStripWords + kStripWords / 2u + kWaves + 7u) & ~7u;      // (8 entries of slack behind s_lab: its last vector)
 }
-template <typename OUT, bool DIAG>
+// VEC (rows of a multiple of four plane words: a thread's four words and every strip start are 16-byte aligned):
+// the thread's plane words are ONE 16-byte load and the runs' strip components come eight (four: 16-bit) to a
+// thread in 8-byte loads — 5 vector-memory loads per thread in front of its 32 stores instead of 16: a third of
+// the kernel's memory instructions were loads of 1 - 4 bytes per lane.
+template <typename OUT, bool DIAG, bool VEC>
 __device__ __forceinline__ void paint_strips_body(
 	const RunGeom& g, const StripArrays& sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag,
 	uint32_t zi, uint32_t k, uint32_t* lds
 ) {
-	OUT* s_lab = reinterpret_cast<OUT*>(lds);                // [kStripCap] label of every run
-	OUT* s_tab = s_lab + kStripCap;                          // [kPaintTable] labels of the strip's components (a strip with more reads them from memory)
-	uint32_t* s_b = lds + ((kStripCap + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u;
+	OUT* s_lab = reinterpret_cast<OUT*>(lds);                // [kStripCap + 8] label of every run
+	OUT* s_tab = s_lab + kStripCap + 8u;                     // [kPaintTable] labels of the strip's components (a strip with more reads them from memory)
+	uint32_t* s_b = lds + ((kStripCap + 8u + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u;
 	uint16_t* s_wb = reinterpret_cast<uint16_t*>(s_b + kStripWords);
 	uint32_t* s_scan = s_b + kStripWords + kStripWords / 2u;
 	unsigned long long d_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1734,6 +1745,19 @@ __device__ __forceinline__ void paint_strips_body(
 	const uint32_t rw = g.row_words, sx = g.sx;
 	const uint32_t nw = (y1 - y0) * rw;
 	const uint32_t t = threadIdx.x;
+	if (ablated(sa, 0x10000u)) {      // tuning: the stores alone, same pattern (what the box's write path gives this grid)
+		OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(y0) * sx;
+		constexpr uint32_t PX = sizeof(OUT) == 8 ? 2u : 4u;
+		auto label_of = [&](uint32_t) -> OUT { return static_cast<OUT>(k); };
+		const uint32_t units = (y1 - y0) * sx / PX;
+		struct alignas(PX * sizeof(OUT)) VX { OUT v[PX]; };
+		if (sa.layout & 2u) {
+			const uint32_t quarter = ((units + 3u) / 4u + 63u) & ~63u, first = (t >> 6) * quarter, end = min(units, first + quarter);
+			for (uint32_t gi = first + (t & 63u); gi < end; gi += kWave) { VX val; for (uint32_t q = 0; q < PX; q++) val.v[q] = label_of(gi); store_stream(oz + gi * PX, val); }
+		}
+		else for (uint32_t gi = t; gi < units; gi += kBlock) { VX val; for (uint32_t q = 0; q < PX; q++) val.v[q] = label_of(gi); store_stream(oz + gi * PX, val); }
+		return;
+	}
 	const uint64_t slot = ablated(sa, 0x2000u) ? 0ull : static_cast<uint64_t>(si) * sa.cap;
 	// Two trips to memory in front of the stores, and as few bytes as possible: beside the stores
 	// every byte read costs several bytes' worth of store time (C2: 0.41 ms with every load of the
@@ -1744,20 +1768,39 @@ __device__ __forceinline__ void paint_strips_body(
 	uint32_t b[4];
 	{
 		const uint32_t* pv = ablated(sa, 0x6000u) ? g.planeV : g.planeV + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+		if constexpr (VEC) {
+			const uint4 v4 = *reinterpret_cast<const uint4*>(pv + (t * 4u < nw ? t * 4u : 0u));
+			b[0] = v4.x; b[1] = v4.y; b[2] = v4.z; b[3] = v4.w;
+		}
+		else {
 #pragma unroll
-		for (uint32_t j = 0; j < 4; j++) { const uint32_t wl = t * 4u + j; b[j] = pv[wl < nw ? wl : 0u]; }
+			for (uint32_t j = 0; j < 4; j++) { const uint32_t wl = t * 4u + j; b[j] = pv[wl < nw ? wl : 0u]; }
+		}
 	}
 	const uint32_t nr = sa.strip_nruns[si];
 	const uint32_t nsc = min(sa.strip_nsc[si], sa.cap);
 	if (nr > sa.cap) return;      // uniform (kStripOverflow): flagged by k_strip_ccl, the general pipeline repaints
-	uint32_t lid[kStripRunsPerThread];
+	constexpr uint32_t kLidRounds = (kStripCap + 1023u) / 1024u;      // VEC: 8-byte loads of 8 (one byte each) or 4 strip components
+	uint32_t lid[VEC ? 1 : kStripRunsPerThread];
+	uint2 lid8[VEC ? kLidRounds : 1];
+	const bool narrow = nsc <= 256u;
 	const OUT* lab = static_cast<const OUT*>(sa.sc_label) + slot;
 	{
 		const uint16_t* lp = sa.run_lid + (ablated(sa, 0x8000u) ? 0ull : slot);
+		if constexpr (VEC) {
+			const uint32_t per = narrow ? 2048u : 1024u;      // runs of a round
 #pragma unroll
-		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
-			const uint32_t j = t + i * kBlock;
-			if (i * kBlock < nr) lid[i] = strip_lid(lp, nsc, j < nr ? j : 0u);      // uniform condition
+			for (uint32_t r = 0; r < kLidRounds; r++) {
+				const uint32_t first = r * per + t * (per / kBlock);      // my first run of the round
+				if (r * per < nr) lid8[r] = reinterpret_cast<const uint2*>(lp)[first < nr ? r * kBlock + t : 0u];      // uniform condition
+			}
+		}
+		else {
+#pragma unroll
+			for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
+				const uint32_t j = t + i * kBlock;
+				if (i * kBlock < nr) lid[i] = strip_lid(lp, nsc, j < nr ? j : 0u);      // uniform condition
+			}
 		}
 		if (nsc <= kPaintTable) for (uint32_t j = t; j < nsc; j += kBlock) s_tab[j] = lab[j];
 	}
@@ -1774,7 +1817,7 @@ __device__ __forceinline__ void paint_strips_body(
 	}
 	uint32_t v[1] = { cnt }, tot[1];
 	block_excl_add<1>(v, tot, s_scan);      // its barriers also publish the component labels
-	if (tot[0] != nr) return;      // uniform; cannot happen: the same plane words gave k_strip_ccl its count
+	if (tot[0] != nr && !(kTuning && sa.ablate)) return;      // uniform; cannot happen: the same plane words gave k_strip_ccl its count
 	{
 		uint32_t local = v[0];
 #pragma unroll
@@ -1786,7 +1829,33 @@ __device__ __forceinline__ void paint_strips_body(
 	}
 	stamp(0);
 	// the labels of my runs through their strip components
-	if (nsc <= kPaintTable) {      // uniform
+	if constexpr (VEC) {
+		// my runs of a round are consecutive: their labels leave in vectors
+		const bool tab = nsc <= kPaintTable;
+		auto label_of_lid = [&](uint32_t l) -> OUT { l = l < nsc ? l : 0u; return tab ? s_tab[l] : lab[l]; };
+#pragma unroll
+		for (uint32_t r = 0; r < kLidRounds; r++) {
+			if (narrow) {
+				const uint32_t first = r * 2048u + t * 8u;
+				if (r * 2048u >= nr) break;      // uniform
+				if (first >= nr) continue;
+				struct alignas(8 * sizeof(OUT) > 16 ? 16 : 8 * sizeof(OUT)) V8 { OUT v[8]; } v8;
+#pragma unroll
+				for (uint32_t q = 0; q < 8; q++) v8.v[q] = label_of_lid(((q < 4 ? lid8[r].x : lid8[r].y) >> (8u * (q & 3u))) & 0xFFu);
+				*reinterpret_cast<V8*>(s_lab + first) = v8;
+			}
+			else {
+				const uint32_t first = r * 1024u + t * 4u;
+				if (r * 1024u >= nr) break;      // uniform
+				if (first >= nr) continue;
+				struct alignas(4 * sizeof(OUT) > 16 ? 16 : 4 * sizeof(OUT)) V4 { OUT v[4]; } v4;
+#pragma unroll
+				for (uint32_t q = 0; q < 4; q++) v4.v[q] = label_of_lid(((q < 2 ? lid8[r].x : lid8[r].y) >> (16u * (q & 1u))) & 0xFFFFu);
+				*reinterpret_cast<V4*>(s_lab + first) = v4;
+			}
+		}
+	}
+	else if (nsc <= kPaintTable) {      // uniform
 #pragma unroll
 		for (uint32_t i = 0; i < kStripRunsPerThread; i++) {
 			const uint32_t j = t + i * kBlock;
@@ -1809,10 +1878,11 @@ __device__ __forceinline__ void paint_strips_body(
 	// 32 bytes per lane left C3's paint at 2.0 TB/s); non-temporal stores: 0.39 against 0.41 ms at C2
 	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(y0) * sx;
 	const uint32_t npix = (y1 - y0) * sx;
-	auto label_of = [&](uint32_t run) -> OUT { return s_lab[run]; };
+	auto label_of = [&](uint32_t run) -> OUT { return ablated(sa, 0x20000u) ? static_cast<OUT>(run) : s_lab[run]; };      // (tuning: without the label look-ups)
 	constexpr uint32_t PX = sizeof(OUT) == 8 ? 2u : 4u;
-	if (sx == rw * 32u) paint_units_from_lds<OUT, PX, true>(s_b, s_wb, label_of, oz, npix / PX, sx, rw);
-	else paint_units_from_lds<OUT, PX, false>(s_b, s_wb, label_of, oz, npix / PX, sx, rw);
+	const bool waveq = (sa.layout & 2u) != 0u;
+	if (sx == rw * 32u) paint_units_from_lds<OUT, PX, true>(s_b, s_wb, label_of, oz, npix / PX, sx, rw, waveq);
+	else paint_units_from_lds<OUT, PX, false>(s_b, s_wb, label_of, oz, npix / PX, sx, rw, waveq);
 	stamp(2);
 }
 
@@ -1821,7 +1891,10 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	RunGeom g, StripArrays sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag
 ) {
 	__shared__ __attribute__((aligned(16))) uint32_t s_lds[paint_strips_words<OUT>()];
-	paint_strips_body<OUT, DIAG>(g, sa, out, sxy, diag, blockIdx.y + sa.zbase, blockIdx.x, s_lds);
+	uint32_t zl, k;
+	strip_of_block(sa, zl, k);
+	if ((g.row_words & 3u) == 0u) paint_strips_body<OUT, DIAG, true>(g, sa, out, sxy, diag, zl + sa.zbase, k, s_lds);
+	else paint_strips_body<OUT, DIAG, false>(g, sa, out, sxy, diag, zl + sa.zbase, k, s_lds);
 }
 
 // ---- k_strip_fused: strips -> labels in ONE launch ------------------------------------------------------
@@ -2543,7 +2616,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 			d.d_row_run.ensure(static_cast<size_t>(h.sy) * d.nslices);
 			d.d_strip_nruns.ensure(nst); d.d_strip_nsc.ensure(nst);
 			d.d_seam_first.ensure(nst * d.row_words); d.d_seam_last.ensure(nst * d.row_words);
-			d.d_run_lid.ensure(nst * d.strip_cap); d.d_sc_w.ensure(nst * d.strip_cap);
+			d.d_run_lid.ensure(nst * d.strip_cap + 16); d.d_sc_w.ensure(nst * d.strip_cap);      // (+16: the paint's 8-byte loads of the last strip's last components)
 			d.d_sc_label.ensure(nst * d.strip_cap);
 			if (h.label_format != FLAT) d.d_sc_cc.ensure(nst * d.strip_cap);
 			d.d_overflow.ensure(1);
@@ -2881,6 +2954,8 @@ StripPlan strip_plan(ckl_decoder& d, int has_label, uint64_t label) {
 	sa.nstrips = d.nstrips; sa.strip_rows = d.strip_rows; sa.cap = d.strip_cap; sa.zbase = 0;
 	sa.ablate = 0;
 	if (kTuning) if (const char* env = getenv("CKL_ABLATE")) sa.ablate = static_cast<uint32_t>(strtoul(env, nullptr, 0));
+	sa.layout = 3u;      // XCD-contiguous strips, a quarter of the strip per wavefront in the paint (CKL_STRIP_LAYOUT=0: launch order, KiB by KiB)
+	if (const char* env = getenv("CKL_STRIP_LAYOUT")) sa.layout = static_cast<uint32_t>(strtoul(env, nullptr, 0));
 	ResolveArgs& ra = p.ra;
 	ra.idbits = d.idbits; ra.crc_fix = d.crc_fix; ra.check_crc = d.check_crc ? 1u : 0u;
 	ra.crc_expect = d.d_crc_expect.p; ra.ncomp_expect = d.d_ncomp_expect.p; ra.comp_off = d.d_comp_off.p;

@@ -327,7 +327,10 @@ __device__ __forceinline__ void strip_ccl2_body(
 template <bool DIAG, bool EDGELIST>
 static __global__ void __launch_bounds__(kBlock, 7) k_strip_ccl2(RunGeom g, StripArrays sa, RecordLists rl, const uint32_t* __restrict__ G, uint32_t n_pixels, Strip2Args a2, unsigned long long* __restrict__ diag) {
 	__shared__ __attribute__((aligned(16))) uint32_t s_lds[kStrip2Words];
-	strip_ccl2_body<DIAG, EDGELIST>(g, sa, rl, G, n_pixels, a2.rsh, diag, blockIdx.y + sa.zbase, blockIdx.x, s_lds);
+	uint32_t zl, k;
+	if (sa.layout & 4u) strip_of_block(sa, zl, k);
+	else { zl = blockIdx.y; k = blockIdx.x; }
+	strip_ccl2_body<DIAG, EDGELIST>(g, sa, rl, G, n_pixels, a2.rsh, diag, zl + sa.zbase, k, s_lds);
 }
 
 }  // namespace dev

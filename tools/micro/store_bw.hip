@@ -39,6 +39,45 @@ __global__ void __launch_bounds__(256) k_chunk2(u32x4* out, uint32_t chunk) {
 	for (uint32_t i = threadIdx.x * 2; i < chunk; i += 512) { st<NT>(o + i, v); st<NT>(o + i + 1, v); }
 }
 
+// one workgroup per chunk, every wavefront streams its own contiguous quarter of it
+template <bool NT>
+__global__ void __launch_bounds__(256) k_chunk_wave(u32x4* out, uint32_t chunk) {
+	u32x4 v = { threadIdx.x, 1, 2, 3 };
+	const uint32_t per = chunk / 4;
+	u32x4* o = out + static_cast<uint64_t>(blockIdx.x) * chunk + (threadIdx.x >> 6) * per;
+	for (uint32_t i = threadIdx.x & 63; i < per; i += 64) st<NT>(o + i, v);
+}
+// workgroups of 1024 threads per chunk
+template <bool NT>
+__global__ void __launch_bounds__(1024) k_chunk1024(u32x4* out, uint32_t chunk) {
+	u32x4 v = { threadIdx.x, 1, 2, 3 };
+	u32x4* o = out + static_cast<uint64_t>(blockIdx.x) * chunk;
+	for (uint32_t i = threadIdx.x; i < chunk; i += 1024) st<NT>(o + i, v);
+}
+// the chunk of workgroup b is chunk (b % 8) * (g / 8) + b / 8: the workgroups an XCD gets (b % 8) write one contiguous eighth of the buffer
+template <bool NT>
+__global__ void __launch_bounds__(256) k_chunk_xcd(u32x4* out, uint32_t chunk) {
+	u32x4 v = { threadIdx.x, 1, 2, 3 };
+	const uint32_t b = blockIdx.x, g = gridDim.x;
+	const uint32_t c = (b & 7u) * (g >> 3) + (b >> 3);
+	u32x4* o = out + static_cast<uint64_t>(c) * chunk;
+	for (uint32_t i = threadIdx.x; i < chunk; i += 256) st<NT>(o + i, v);
+}
+
+// general form: workgroup b writes chunk c(b) (XCD: see k_chunk_xcd); inside the chunk every wavefront streams contiguous
+// pieces of `piece` vectors, the wavefronts' pieces interleaved (piece = chunk / 4: a quarter per wavefront; piece = 64:
+// k_chunk's order)
+template <bool NT, bool XCD>
+__global__ void __launch_bounds__(256) k_piece(u32x4* out, uint32_t chunk, uint32_t piece) {
+	u32x4 v = { threadIdx.x, 1, 2, 3 };
+	const uint32_t b = blockIdx.x, g = gridDim.x;
+	const uint32_t c = XCD ? (b & 7u) * (g >> 3) + (b >> 3) : b;
+	u32x4* o = out + static_cast<uint64_t>(c) * chunk;
+	const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+	for (uint32_t p0 = w * piece; p0 < chunk; p0 += 4 * piece)
+		for (uint32_t i = l; i < piece; i += 64) st<NT>(o + p0 + i, v);
+}
+
 int main() {
 	const uint64_t bytes = 1ull << 31, n = bytes / 16;
 	u32x4* out; uint32_t* src;
@@ -63,6 +102,26 @@ int main() {
 		snprintf(nm, 64, "chunk %u KiB plain + 1 load prologue", kb); run(nm, [&] { hipLaunchKernelGGL((k_chunk<false, 1>), dim3(g), dim3(256), 0, 0, out, chunk, src); });
 		snprintf(nm, 64, "chunk %u KiB nt + 2 load prologue", kb); run(nm, [&] { hipLaunchKernelGGL((k_chunk<true, 2>), dim3(g), dim3(256), 0, 0, out, chunk, src); });
 		snprintf(nm, 64, "chunk %u KiB plain 2 vec/thread", kb); run(nm, [&] { hipLaunchKernelGGL(k_chunk2<false>, dim3(g), dim3(256), 0, 0, out, chunk); });
+	}
+	{
+		const uint32_t chunk = 128 * 1024 / 16, g = static_cast<uint32_t>(n / chunk);
+		run("chunk 128 KiB, a quarter per wavefront, plain", [&] { hipLaunchKernelGGL(k_chunk_wave<false>, dim3(g), dim3(256), 0, 0, out, chunk); });
+		run("chunk 128 KiB, a quarter per wavefront, nt", [&] { hipLaunchKernelGGL(k_chunk_wave<true>, dim3(g), dim3(256), 0, 0, out, chunk); });
+		run("chunk 128 KiB, 1024 threads, plain", [&] { hipLaunchKernelGGL(k_chunk1024<false>, dim3(g), dim3(1024), 0, 0, out, chunk); });
+		run("chunk 128 KiB, 1024 threads, nt", [&] { hipLaunchKernelGGL(k_chunk1024<true>, dim3(g), dim3(1024), 0, 0, out, chunk); });
+		run("chunk 128 KiB, XCD-contiguous, plain", [&] { hipLaunchKernelGGL(k_chunk_xcd<false>, dim3(g), dim3(256), 0, 0, out, chunk); });
+		run("chunk 128 KiB, XCD-contiguous, nt", [&] { hipLaunchKernelGGL(k_chunk_xcd<true>, dim3(g), dim3(256), 0, 0, out, chunk); });
+		for (uint32_t pk : { 1u, 4u, 8u, 16u, 32u }) {
+			char nm[96];
+			const uint32_t piece = pk * 1024 / 16;
+			snprintf(nm, 96, "chunk 128 KiB, pieces of %u KiB per wavefront, plain", pk); run(nm, [&] { hipLaunchKernelGGL((k_piece<false, false>), dim3(g), dim3(256), 0, 0, out, chunk, piece); });
+			snprintf(nm, 96, "chunk 128 KiB, pieces of %u KiB per wavefront, nt", pk); run(nm, [&] { hipLaunchKernelGGL((k_piece<true, false>), dim3(g), dim3(256), 0, 0, out, chunk, piece); });
+			snprintf(nm, 96, "chunk 128 KiB, pieces of %u KiB, XCD-contiguous, plain", pk); run(nm, [&] { hipLaunchKernelGGL((k_piece<false, true>), dim3(g), dim3(256), 0, 0, out, chunk, piece); });
+			snprintf(nm, 96, "chunk 128 KiB, pieces of %u KiB, XCD-contiguous, nt", pk); run(nm, [&] { hipLaunchKernelGGL((k_piece<true, true>), dim3(g), dim3(256), 0, 0, out, chunk, piece); });
+		}
+		const uint32_t chunk16 = 16 * 1024 / 16, g16 = static_cast<uint32_t>(n / chunk16);
+		run("chunk 16 KiB, XCD-contiguous, plain", [&] { hipLaunchKernelGGL(k_chunk_xcd<false>, dim3(g16), dim3(256), 0, 0, out, chunk16); });
+		run("chunk 16 KiB, XCD-contiguous, nt", [&] { hipLaunchKernelGGL(k_chunk_xcd<true>, dim3(g16), dim3(256), 0, 0, out, chunk16); });
 	}
 	return 0;
 }
