@@ -1886,6 +1886,122 @@ __device__ __forceinline__ void paint_strips_body(
 	stamp(2);
 }
 
+// The same strip painted by four INDEPENDENT wavefronts, a quarter of its rows each (rows of whole plane words, a
+// multiple of four of them per row, a multiple of four rows): every wavefront loads its own plane words (16 bytes
+// per lane), takes the run number of its first row from row_run (k_strip_ccl / k_strip_ccl2), scans inside the
+// wavefront (DPP), stages the labels of its own runs and streams its own contiguous quarter of the strip.  One
+// barrier (the strip's label table) instead of five, and none between a wavefront's loads and its stores: the
+// 2048 workgroups of a round no longer load, scan and store in step with each other (0.376 -> see DESIGN.md).
+template <typename OUT>
+__device__ __forceinline__ void paint_strips_waves_body(
+	const RunGeom& g, const StripArrays& sa, OUT* __restrict__ out, uint32_t sxy, uint32_t zi, uint32_t k, uint32_t* lds
+) {
+	OUT* s_lab = reinterpret_cast<OUT*>(lds);                // [kStripCap + 8] label of every run
+	OUT* s_tab = s_lab + kStripCap + 8u;                     // [kPaintTable] labels of the strip's components
+	uint32_t* s_b = lds + ((kStripCap + 8u + kPaintTable) * static_cast<uint32_t>(sizeof(OUT)) + 3u) / 4u;
+	uint16_t* s_wb = reinterpret_cast<uint16_t*>(s_b + kStripWords);
+	const uint32_t t = threadIdx.x, wv = t >> 6, ln = t & 63u;
+	const uint32_t si = zi * sa.nstrips + k;
+	const uint32_t y0 = k * sa.strip_rows;
+	const uint32_t y1 = min(y0 + sa.strip_rows, g.sy);
+	const uint32_t rw = g.row_words, sx = g.sx;
+	const uint32_t rq = (y1 - y0) >> 2;             // rows of a wavefront
+	const uint32_t wwords = rq * rw;                // its plane words (<= 256: a strip has <= 1024)
+	const uint32_t wbase = wv * wwords;             // its first word, relative to the strip
+	const uint64_t slot = static_cast<uint64_t>(si) * sa.cap;
+	// ---- first trip: my plane words, the strip's counts, the run numbers of my first row and of the next wavefront's
+	const uint32_t* pv = g.planeV + zi * g.plane_words + static_cast<uint64_t>(y0) * rw;
+	const bool have = ln * 4u < wwords;
+	const uint4 v4 = *reinterpret_cast<const uint4*>(pv + wbase + (have ? ln * 4u : 0u));
+	const uint32_t nr = sa.strip_nruns[si];
+	const uint32_t nsc = min(sa.strip_nsc[si], sa.cap);
+	const uint16_t* rr = sa.row_run + static_cast<uint64_t>(zi) * g.sy + y0;
+	const uint32_t r0 = rr[wv * rq];
+	const uint32_t r1_raw = rr[wv < 3u ? (wv + 1u) * rq : 0u];
+	if (nr > sa.cap) return;      // uniform (kStripOverflow): flagged by the strip kernel, the general pipeline repaints
+	const uint32_t r1 = wv < 3u ? r1_raw : nr;
+	const OUT* lab = static_cast<const OUT*>(sa.sc_label) + slot;
+	const bool tab = nsc <= kPaintTable;
+	if (tab) for (uint32_t j = t; j < nsc; j += kBlock) s_tab[j] = lab[j];
+	// ---- second trip: the strip components of my runs [r0, r1), 8 bytes per lane from an aligned start
+	const bool narrow = nsc <= 256u;
+	const uint32_t per8 = narrow ? 8u : 4u;              // runs per 8-byte piece
+	const uint32_t a0 = r0 & ~(per8 - 1u);
+	const uint2* lp8 = reinterpret_cast<const uint2*>(sa.run_lid + slot);
+	uint32_t first = a0 + ln * per8;
+	uint2 piece = lp8[first < r1 ? first / per8 : 0u];
+	// ---- breaks of my words, run numbers inside the wavefront
+	{
+		const uint32_t w0 = (wbase + ln * 4u) & (rw - 1u);      // (rw is a multiple of 4, not necessarily a power of two)
+		const uint32_t wrow = (wbase + ln * 4u) % rw;
+		(void)w0;
+		const uint32_t fm = g.flip ? 0u : 0xFFFFFFFFu;
+		const uint32_t on = have ? 0xFFFFFFFFu : 0u;
+		uint32_t b[4];
+		b[0] = ((v4.x ^ fm) | (wrow == 0u ? 1u : 0u)) & on;
+		b[1] = (v4.y ^ fm) & on;
+		b[2] = (v4.z ^ fm) & on;
+		b[3] = (v4.w ^ fm) & on;
+		const uint32_t c0 = __popc(b[0]), c1 = __popc(b[1]), c2 = __popc(b[2]), c3 = __popc(b[3]);
+		const uint32_t tot = c0 + c1 + c2 + c3;
+		const uint32_t l0 = r0 + wave_incl_add(tot) - tot, l1 = l0 + c0, l2 = l1 + c1, l3 = l2 + c2;
+		if (have) {
+			*reinterpret_cast<uint4*>(s_b + wbase + ln * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
+			*reinterpret_cast<uint2*>(s_wb + wbase + ln * 4u) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+		}
+	}
+	__syncthreads();      // the label table (the only thing the wavefronts share)
+	// ---- labels of my runs, in vectors (a piece that starts below r0 repeats what the wavefront before me writes)
+	auto label_of_lid = [&](uint32_t l) -> OUT { l = l < nsc ? l : 0u; return tab ? s_tab[l] : lab[l]; };
+	for (;;) {
+		if (first < r1) {
+			if (narrow) {
+				struct alignas(8 * sizeof(OUT) > 16 ? 16 : 8 * sizeof(OUT)) V8 { OUT v[8]; } v8;
+#pragma unroll
+				for (uint32_t q = 0; q < 8; q++) v8.v[q] = label_of_lid(((q < 4 ? piece.x : piece.y) >> (8u * (q & 3u))) & 0xFFu);
+				*reinterpret_cast<V8*>(s_lab + first) = v8;
+			}
+			else {
+				struct alignas(4 * sizeof(OUT) > 16 ? 16 : 4 * sizeof(OUT)) V4 { OUT v[4]; } v4l;
+#pragma unroll
+				for (uint32_t q = 0; q < 4; q++) v4l.v[q] = label_of_lid(((q < 2 ? piece.x : piece.y) >> (16u * (q & 1u))) & 0xFFFFu);
+				*reinterpret_cast<V4*>(s_lab + first) = v4l;
+			}
+		}
+		first += kWave * per8;
+		if (__ballot(first < r1) == 0ull) break;      // wave-uniform (a0 + 64 * per8 covers the runs of 8 rows of every BASELINE shape: one round)
+		piece = lp8[first < r1 ? first / per8 : 0u];
+	}
+	// ---- my quarter of the strip: groups of 4 pixels (2 for 8-byte labels), 16 bytes per lane and store
+	constexpr uint32_t PX = sizeof(OUT) == 8 ? 2u : 4u;
+	constexpr uint32_t U = 4;
+	struct alignas(PX * sizeof(OUT)) VX { OUT v[PX]; };
+	OUT* oz = out + static_cast<uint64_t>(zi) * sxy + static_cast<uint64_t>(y0) * sx;
+	const uint32_t q_units = rq * sx / PX;
+	const uint32_t u_first = wv * q_units, u_end = u_first + q_units;
+	for (uint32_t g0 = u_first; g0 < u_end; g0 += kWave * U) {
+		VX val[U];
+		uint32_t at[U];
+#pragma unroll
+		for (uint32_t u = 0; u < U; u++) {
+			const uint32_t gi = g0 + u * kWave + ln;
+			at[u] = 0xFFFFFFFFu;
+			if (gi >= u_end) continue;
+			const uint32_t p = gi * PX;
+			const uint32_t wl = p >> 5, sh = p & 31u;
+			const uint32_t bw = s_b[wl];
+			uint32_t run = s_wb[wl] + __popc(bw & mask_le(sh)) - 1u;
+			const uint32_t nib = (bw >> sh) >> 1;
+			at[u] = p;
+			val[u].v[0] = s_lab[run];
+#pragma unroll
+			for (uint32_t q = 1; q < PX; q++) { run += (nib >> (q - 1u)) & 1u; val[u].v[q] = s_lab[run]; }
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < U; u++) if (at[u] != 0xFFFFFFFFu) store_stream(oz + at[u], val[u]);
+	}
+}
+
 template <typename OUT, bool DIAG>
 __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	RunGeom g, StripArrays sa, OUT* __restrict__ out, uint32_t sxy, unsigned long long* __restrict__ diag
@@ -1893,6 +2009,10 @@ __global__ void __launch_bounds__(kBlock) k_paint_strips(
 	__shared__ __attribute__((aligned(16))) uint32_t s_lds[paint_strips_words<OUT>()];
 	uint32_t zl, k;
 	strip_of_block(sa, zl, k);
+	if (!DIAG && (sa.layout & 2u) && (g.row_words & 3u) == 0u && g.sx == g.row_words * 32u) {
+		const uint32_t y0 = k * sa.strip_rows, rows = min(y0 + sa.strip_rows, g.sy) - y0;
+		if ((rows & 3u) == 0u && !(kTuning && sa.ablate)) { paint_strips_waves_body<OUT>(g, sa, out, sxy, zl + sa.zbase, k, s_lds); return; }
+	}
 	if ((g.row_words & 3u) == 0u) paint_strips_body<OUT, DIAG, true>(g, sa, out, sxy, diag, zl + sa.zbase, k, s_lds);
 	else paint_strips_body<OUT, DIAG, false>(g, sa, out, sxy, diag, zl + sa.zbase, k, s_lds);
 }
