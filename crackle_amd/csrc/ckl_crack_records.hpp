@@ -388,6 +388,21 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 	const uint32_t nstrips = ra.lists.nstrips;
 	for (uint32_t k = tid; k < nstrips; k += kRecBlock) s_cursor[k] = 0u;
 
+	// the head of the slice's code (its beginning-of-chain index, usually under a hundred bytes) is staged in LDS by
+	// all threads: the one thread that parses it would otherwise make a trip to memory per field
+	constexpr uint32_t kIndexStage = 2048;
+	uint8_t* s_idx = reinterpret_cast<uint8_t*>(s_dyn);
+	const uint32_t stage_n = min(min(code_len, kIndexStage), ra.lds_bytes);
+	for (uint32_t i = tid; i < stage_n; i += kRecBlock) s_idx[i] = code[i];
+	__syncthreads();
+	auto rd_idx = [&](const uint8_t* p, int w) -> uint32_t {      // (the staged bytes are only valid until the markov expansion takes the LDS)
+		const uint32_t at = static_cast<uint32_t>(p - code);
+		uint32_t v = 0;
+		if (at + static_cast<uint32_t>(w) <= stage_n) for (int i = 0; i < w; i++) v |= static_cast<uint32_t>(s_idx[at + i]) << (8 * i);
+		else for (int i = 0; i < w; i++) v |= static_cast<uint32_t>(p[i]) << (8 * i);
+		return v;
+	};
+
 	// ---- beginning-of-chain index (crackcodes.hpp:283-316), one thread ----
 	if (tid == 0) {
 		s_mk_parallel = 0;
@@ -397,7 +412,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			err |= ERR_BOC;
 		}
 		else {
-			const uint32_t index_size = rd_le_dev(code, 4);
+			const uint32_t index_size = rd_idx(code, 4);
 			index_end = 4u + index_size;
 			if (index_size < static_cast<uint32_t>(a.yw) || index_end > code_len || index_end < 4u) {
 				err |= ERR_BOC;
@@ -405,17 +420,17 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			}
 			else {
 				uint32_t idx = 4;
-				const uint32_t num_y = rd_le_dev(code + idx, a.yw);
+				const uint32_t num_y = rd_idx(code + idx, a.yw);
 				idx += a.yw;
 				uint32_t y = 0;
 				for (uint32_t yi = 0; yi < num_y && !err; yi++) {
 					if (idx + a.yw + a.xw > index_end) { err |= ERR_BOC; break; }
-					y += rd_le_dev(code + idx, a.yw); idx += a.yw;
-					const uint32_t num_x = rd_le_dev(code + idx, a.xw); idx += a.xw;
+					y += rd_idx(code + idx, a.yw); idx += a.yw;
+					const uint32_t num_x = rd_idx(code + idx, a.xw); idx += a.xw;
 					uint32_t x = 0;
 					for (uint32_t xi = 0; xi < num_x; xi++) {
 						if (idx + a.xw > index_end) { err |= ERR_BOC; break; }
-						x += rd_le_dev(code + idx, a.xw); idx += a.xw;
+						x += rd_idx(code + idx, a.xw); idx += a.xw;
 						if (x >= sxe || y >= sye || nn >= ncap) { err |= ERR_BOC; break; }
 						nodes[nn++] = x + sxe * y;
 					}
@@ -571,8 +586,8 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			const RecordLists& L = ra.lists;
 			uint4* lists = L.rec + static_cast<uint64_t>(zi) * nstrips * L.cap;
 			const uint4* wsrc = reinterpret_cast<const uint4*>(wout);
-			uint32_t* queue = reinterpret_cast<uint32_t*>(lt.link);      // word indices
-			const uint32_t queue_cap = lcap * 2u;
+			uint4* queue = reinterpret_cast<uint4*>(lt.link);      // the words themselves (16 bytes each: the link table holds 8 per control symbol)
+			const uint32_t queue_cap = lcap / 2u;
 			uint32_t* s_qn = &s_mk_total;      // (the markov expansion is long done)
 			if (tid == 0) *s_qn = 0u;
 			__syncthreads();
@@ -581,7 +596,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 				const u32x4_t raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wsrc + w));      // written by other threads of the workgroup: not through L1
 				return make_uint4(raw.x, raw.y, raw.z, raw.w);
 			};
-			constexpr uint32_t kBatch = 4;      // words of a thread in flight
+			constexpr uint32_t kBatch = 8;      // words of a thread in flight (a slice of C2 gives a thread 14: two trips to memory)
 			for (uint32_t w0 = 0; w0 < n_words; w0 += kBatch * kRecBlock) {
 				uint4 wr[kBatch];
 #pragma unroll
@@ -596,7 +611,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 					if (flags == 0u) continue;
 					if (flags & 0xAAAAAAAAu) {      // a 't' in the word: later, with its like
 						const uint32_t at = atomicAdd(s_qn, 1u);
-						if (at < queue_cap) queue[at] = w0 + q * kRecBlock + tid;
+						if (at < queue_cap) queue[at] = wr[q];
 						else word_to_records(wr[q], seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
 						continue;
 					}
@@ -618,7 +633,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			}
 			__syncthreads();
 			const uint32_t qn = min(*s_qn, queue_cap);
-			for (uint32_t i = tid; i < qn; i += kRecBlock) word_to_records(load_word(queue[i]), seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
+			for (uint32_t i = tid; i < qn; i += kRecBlock) word_to_records(queue[i], seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
 		}
 	}
 	__syncthreads();
