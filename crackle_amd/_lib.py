@@ -61,6 +61,7 @@ EXPORTS = {
   "ckl_decoder_label_stats": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
   "ckl_decoder_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
   "ckl_decoder_stage_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+  "ckl_decoder_set_stage_events": (C.c_int, [C.c_void_p, C.c_int]),
   "ckl_decoder_destroy": (None, [C.c_void_p]),
   "ckl_encoder_create": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
   "ckl_encoder_run": (C.c_int, [

@@ -2401,6 +2401,9 @@ struct ckl_decoder {
 	void* desc_staging = nullptr;        // pinned host image of d_desc (host_out_alloc), kept until the session dies
 	uint32_t* host_flags = nullptr;      // pinned: the runs' per-slice error words + overflow word land here
 	bool host_flags_pinned = false;
+	bool flags_by_resolve = false;       // this run: k_slice_resolve wrote them there itself (ResolveArgs::host_flags)
+	bool stage_events = true;            // HIP events between the kernels (ckl_decoder_stage_timing); off: only around the pipeline
+	bool pending_upload = false;         // decoder_build left copies in flight that no run has waited for yet (ckl_decoder_destroy waits)
 	bool stream_resident = false;        // the stream was in HBM already: capacities come from the z-index alone
 	DevBuf<uint64_t> d_code_off, d_cbase, d_nbase, d_comp_off, d_rbase;
 	DevBuf<uint32_t> d_code_len, d_ccap, d_ncap, d_rcap;
@@ -2949,6 +2952,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	pack.commit(d, s);
 	// the caller's host stream and the pin tables above are copied from memory that is not ours to keep
 	if (!stream_device || h.label_format != FLAT) CKL_HIP(hipStreamSynchronize(s));
+	else d.pending_upload = true;      // (the descriptors' packed copy is still on its way: the first run orders itself behind it, ckl_decoder_destroy waits for it)
 }
 
 struct StageTimer {
@@ -2956,7 +2960,7 @@ struct StageTimer {
 	hipStream_t s;
 	int i = 0;
 	bool on = true;      // off: z-chunks overlap on several streams, only the whole pipeline is timed
-	StageTimer(ckl_decoder& dec, hipStream_t st) : d(dec), s(st) { CKL_HIP(hipEventRecord(d.ev[0], s)); }
+	StageTimer(ckl_decoder& dec, hipStream_t st) : d(dec), s(st) { on = dec.stage_events; CKL_HIP(hipEventRecord(d.ev[0], s)); }
 	void done(const char* name) {
 		if (!on || i >= kMaxStages) return;
 		d.stage_name[i] = name;
@@ -3087,6 +3091,7 @@ StripPlan strip_plan(ckl_decoder& d, int has_label, uint64_t label) {
 		ra.key_width = static_cast<uint32_t>(d.key_width); ra.stored_width = static_cast<uint32_t>(h.stored_data_width);
 		ra.is_signed = h.is_signed ? 1u : 0u; ra.num_unique = d.num_unique;
 	}
+	ra.host_flags = nullptr; ra.host_flags_n = d.nslices;
 	ra.cap = d.resolve_cap;
 	if (const char* env = getenv("CKL_RESOLVE_CAP")) ra.cap = std::min<uint32_t>(d.resolve_cap, static_cast<uint32_t>(std::max(1, atoi(env))));   // testing: forces the overflow path
 	return p;
@@ -3253,6 +3258,13 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 	const bool flat = h.label_format == FLAT;
 	StripPlan p = strip_plan(d, has_label, label);
 	const uint32_t chunks = decode_chunks(d);
+	// flat labels in one chunk: k_slice_resolve settles every slice's error word and the overflow word, and writes them
+	// to the host's mapped memory itself (no k_flags_to_host launch behind the paint)
+	d.flags_by_resolve = flat && chunks <= 1 && d.host_flags_pinned && !(d.use_records && d.use_fused) && !(kTuning && getenv("CKL_STRIP_DIAG")) && !getenv("CKL_FLAGS_KERNEL");
+	if (d.flags_by_resolve) {
+		d.host_flags[ns] = 0u; d.host_flags[ns + 1] = 0u;
+		p.ra.host_flags = d.host_flags;
+	}
 	if (chunks > 1) CKL_HIP(hipMemsetAsync(d.d_overflow.p, 0, sizeof(uint32_t), s));      // one chunk: the crack kernel clears it
 	unsigned long long* diag = nullptr;
 	if (kTuning && getenv("CKL_STRIP_DIAG")) {      // tuning builds: cycle stamps of the strip kernels (adds a sync and a print)
@@ -3388,6 +3400,13 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	const bool prof = getenv("CKL_PROFILE") != nullptr;
 	auto h0 = std::chrono::steady_clock::now();
 
+	// the verdicts come back through the host's pinned memory (a kernel's stores: a copy-engine transfer of
+	// two KiB costs tens of microseconds before it starts)
+	if (!d.host_flags) {
+		d.host_flags = static_cast<uint32_t*>(host_out_alloc(std::max<size_t>(64u << 10, (static_cast<size_t>(ns) + 4) * sizeof(uint32_t))));
+		d.host_flags_pinned = host_out_is_pinned(d.host_flags);
+	}
+	d.flags_by_resolve = false;
 	StageTimer st(d, s);
 	// k_decode_cracks builds the planes band by band in LDS when at least one row of both
 	// planes fits behind the segment tables; otherwise it ORs bits into zeroed planes in HBM
@@ -3479,13 +3498,12 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	uint32_t overflow = 0, timeout = 0;
 	const bool fused_ran = d.ran_fused;
 	d.ran_fused = false;
-	// the verdicts come back through the host's pinned memory (a kernel's stores: a copy-engine transfer of
-	// two KiB costs tens of microseconds before it starts)
-	if (!d.host_flags) {
-		d.host_flags = static_cast<uint32_t*>(host_out_alloc(std::max<size_t>(64u << 10, (static_cast<size_t>(ns) + 4) * sizeof(uint32_t))));
-		d.host_flags_pinned = host_out_is_pinned(d.host_flags);
+	if (d.flags_by_resolve) {
+		CKL_HIP(hipStreamSynchronize(s));
+		memcpy(errs.data(), d.host_flags, ns * sizeof(uint32_t));
+		overflow = d.host_flags[ns];
 	}
-	if (d.host_flags_pinned) {
+	else if (d.host_flags_pinned) {
 		hipLaunchKernelGGL(k_flags_to_host, dim3((ns + kBlock) / kBlock), dim3(kBlock), 0, s, d.d_slice_err.p, ns, strips ? d.d_overflow.p : nullptr, fused_ran ? d.d_fused_ctl.p + kFusedMaxHeads * kFusedHeadStride : nullptr, d.host_flags);
 		CKL_HIP(hipStreamSynchronize(s));
 		memcpy(errs.data(), d.host_flags, ns * sizeof(uint32_t));
@@ -3499,6 +3517,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 		CKL_HIP(hipStreamSynchronize(s));
 	}
 	CKL_HIP(hipGetLastError());
+	d.pending_upload = false;
 	if (fused_ran && (timeout || overflow)) {
 		// a wait inside k_strip_fused gave up (it never should), or a strip / slice did not fit its tables (the fused
 		// launch leaves no planes in HBM for the general pipeline): this and all later runs of the session take the three launches
@@ -4044,6 +4063,44 @@ int ckl_decoder_create(const uint8_t* buf, uint64_t n, int64_t z_start, int64_t 
 // the device): nothing is uploaded.  What the host has to see — header, z-index, the head of the label
 // section (the whole section of a pin stream), markov model, crc tail — comes back in three small
 // copies, each sized by the one before; the crack codes are never touched by the host.
+// The per-slice component counts of a FLAT label section (labels.hpp:424-451) lie behind its unique labels, i.e.
+// at an offset the host only knows once it has read the header and the section's first eight bytes: a second round
+// trip of ckl_decoder_create_device.  This kernel reads those fields on the device (the host validates its own copy
+// of them afterwards) and sends the counts along with the first round.  grid = ceil(max_len / 4096), block = kBlock
+__global__ void __launch_bounds__(kBlock) k_fetch_flat_counts(const uint8_t* __restrict__ src, uint64_t n, uint8_t* __restrict__ dst_host, uint64_t max_len) {
+	__shared__ uint64_t s_off, s_len;
+	if (threadIdx.x == 0) {
+		uint64_t off = 0, len = 0;
+		auto rd = [&](uint64_t at, int w) -> uint64_t { uint64_t v = 0; for (int i = 0; i < w; i++) v |= static_cast<uint64_t>(src[at + i]) << (8 * i); return v; };
+		if (n >= Header::kBytesV0 && src[0] == 'c' && src[1] == 'r' && src[2] == 'k' && src[3] == 'l' && src[4] <= 1 && (src[4] == 0 || n >= Header::kBytes)) {
+			const uint32_t ver = src[4];
+			const uint32_t fmt = static_cast<uint32_t>(rd(5, 2));
+			const uint64_t sx = rd(7, 4), sy = rd(11, 4), sz = rd(15, 4);
+			const uint64_t nlb = ver == 0 ? rd(20, 4) : rd(20, 8);
+			const uint64_t sw = 1ull << ((fmt >> 2) & 3u);
+			const uint64_t hb = ver == 0 ? Header::kBytesV0 : Header::kBytes, gib = (sz + (ver ? 1u : 0u)) * 4u;
+			if (((fmt >> 5) & 3u) == FLAT && nlb >= 8 && hb + gib + 8 <= n && sx * sy) {
+				const uint64_t nu = rd(hb + gib, 8);
+				const uint64_t px = sx * sy, cw = px <= 0xFFull ? 1 : px <= 0xFFFFull ? 2 : px <= 0xFFFFFFFFull ? 4 : 8;
+				if (nu <= (nlb - 8) / sw) {
+					const uint64_t o = 8 + sw * nu;
+					off = hb + gib + o;
+					len = cw * sz < nlb - o ? cw * sz : nlb - o;
+				}
+			}
+		}
+		if (off >= n) len = 0;
+		if (len > n - off) len = n - off;
+		if (len > max_len) len = max_len;
+		s_off = off; s_len = len;
+	}
+	__syncthreads();
+	const uint64_t off = s_off, len = s_len;
+	const uint64_t i = (static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x) * 16u;
+	if (i >= len) return;
+	for (uint64_t b = i; b < len && b < i + 16u; b++) dst_host[off + b] = src[off + b];
+}
+
 int ckl_decoder_create_device(const uint8_t* stream_device, uint64_t n, int64_t z_start, int64_t z_end, int device, ckl_decoder** out) {
 	try {
 		if (!stream_device || !out) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
@@ -4081,6 +4138,8 @@ int ckl_decoder_create_device(const uint8_t* stream_device, uint64_t n, int64_t 
 			hipLaunchKernelGGL(k_fetch_to_host, dim3(static_cast<uint32_t>((longest + 16u * kBlock - 1) / (16u * kBlock)), 2), dim3(kBlock), 0, s, stream_device, img.p, 0ull, front, back0, n - back0);
 		}
 		else { fetch(0, front); fetch(back0, n - back0); }
+		const uint64_t kCountsAhead = 256u << 10;      // bytes of component counts the first round brings along (k_fetch_flat_counts)
+		if (mapped) hipLaunchKernelGGL(k_fetch_flat_counts, dim3(static_cast<uint32_t>(kCountsAhead / (16u * kBlock))), dim3(kBlock), 0, s, stream_device, n, img.p, kCountsAhead);
 		CKL_HIP(hipStreamSynchronize(s));
 		mark("header");
 		const Header h = Header::parse(img.p, n);
@@ -4107,8 +4166,11 @@ int ckl_decoder_create_device(const uint8_t* stream_device, uint64_t n, int64_t 
 			const uint64_t cw = static_cast<uint64_t>(byte_width(static_cast<uint64_t>(h.sx) * h.sy));
 			if (nu <= (h.num_label_bytes - 8) / static_cast<uint64_t>(sw)) {
 				const uint64_t off = 8 + static_cast<uint64_t>(sw) * nu;
-				fetch(hb + gib + off, std::min<uint64_t>(cw * h.sz, h.num_label_bytes - std::min(off, h.num_label_bytes)));
-				CKL_HIP(hipStreamSynchronize(s));
+				const uint64_t len = std::min<uint64_t>(cw * h.sz, h.num_label_bytes - std::min(off, h.num_label_bytes));
+				if (!(mapped && len <= kCountsAhead)) {      // (else k_fetch_flat_counts sent exactly this range with the first round)
+					fetch(hb + gib + off, len);
+					CKL_HIP(hipStreamSynchronize(s));
+				}
 			}
 		}
 		mark("tables");
@@ -4269,8 +4331,17 @@ int ckl_decoder_stage_timing(const ckl_decoder* d, int index, const char** name,
 	return CKL_OK;
 }
 
+int ckl_decoder_set_stage_events(ckl_decoder* d, int on) {
+	if (!d) { set_last_error("crackle_amd: null decoder"); return CKL_ERR_ARG; }
+	d->stage_events = on != 0;
+	return CKL_OK;
+}
+
 void ckl_decoder_destroy(ckl_decoder* d) {
 	if (!d) return;
+	// a session that was built and never run still has its descriptor upload in flight: the staging block and the
+	// stream must not go back to their caches under it
+	if (d->pending_upload && d->stream) (void)hipStreamSynchronize(d->stream);
 	// stream and events go to the cache (at most four sets are kept), idle: every run waits for its own work
 	if (d->stream) {
 		std::lock_guard<std::mutex> lock(g_session_mutex);

@@ -519,6 +519,9 @@ struct ResolveArgs {
 	uint32_t has_label;
 	uint64_t label;
 	uint32_t cap;                    // strip components the LDS table holds (<= kResolveCap)
+	uint32_t* host_flags;            // mapped pinned host memory or null: [slices of the session] final error words, then the overflow word —
+	                                 // the run's verdicts reach the host with the kernel that settles them, no launch of their own behind the paint
+	uint32_t host_flags_n;           // slices of the session (index of the overflow word)
 };
 
 // little-endian integer of W bytes at any address (global memory takes unaligned accesses: one load, not W)
@@ -618,7 +621,10 @@ __device__ __forceinline__ bool slice_resolve_body(
 	const uint32_t total = tot[0];
 	__syncthreads();
 	if (s_flag || total > ra.cap) {      // uniform
-		if (t == 0) atomicOr(sa.overflow, 1u);
+		if (t == 0) {
+			atomicOr(sa.overflow, 1u);
+			if (ra.host_flags) { ra.host_flags[ra.host_flags_n] = 1u; ra.host_flags[zi] = sa.slice_err[zi]; }
+		}
 		return false;
 	}
 	for (uint32_t i = t; i < total; i += kResolveBlock) s_tab[i] = i;
@@ -749,6 +755,7 @@ __device__ __forceinline__ bool slice_resolve_body(
 		else if (ra.check_crc && gf_mul(x, ra.crc_fix) != ra.crc_expect[zi]) e |= ERR_CRC;
 		if (e) atomicOr(sa.slice_err + zi, e);
 		ncomp_out[zi] = ncomp;
+		if (ra.host_flags) ra.host_flags[zi] = sa.slice_err[zi] | e;      // (the bits of the kernels in front crossed a kernel boundary)
 	}
 	stamp(3);
 	return true;

@@ -279,6 +279,11 @@ class HipDecodeSession:
     self._L.ckl_decoder_last_timing(self._h, C.byref(p), C.byref(k))
     return p.value, k.value
 
+  def stage_events(self, on: bool):
+    """HIP events between the kernels of the following runs (the per-stage table of stages()) on or off; the
+    events around the whole pipeline (timing()) are always recorded."""
+    self._L.ckl_decoder_set_stage_events(self._h, int(bool(on)))
+
   def stages(self):
     """[(stage name, ms)] of the last run, in launch order."""
     out = []

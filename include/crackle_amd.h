@@ -197,6 +197,11 @@ int ckl_decoder_last_timing(const ckl_decoder* d, float* pipeline_ms, float* dom
 /* Name and elapsed milliseconds of stage `index` (0-based, in launch order) of the last
  * run; CKL_ERR_ARG past the last stage.  `*name` points to a static string. */
 int ckl_decoder_stage_timing(const ckl_decoder* d, int index, const char** name, float* ms);
+/* on = 0: the following runs record HIP events only around the whole pipeline (ckl_decoder_last_timing's
+ * pipeline_ms stays valid, the per-stage table is empty); on = 1 (the default): also between the kernels.
+ * The events between the kernels cost a few microseconds of device time per run.  (No reference counterpart:
+ * the reference has no device.) */
+int ckl_decoder_set_stage_events(ckl_decoder* d, int on);
 void ckl_decoder_destroy(ckl_decoder* d);
 
 typedef struct ckl_encoder ckl_encoder;

@@ -81,3 +81,33 @@ def test_fused_strip_kernel_is_bit_exact(monkeypatch):
   assert "k_strip_fused" not in [n for n, _ in sess.stages()]
   sess.close()
   assert torch.equal(out, vol)
+
+
+def test_stage_events_can_be_switched_off():
+  """ckl_decoder_set_stage_events(0): the run records events around the pipeline only (bench.py's timed runs: the
+  events between the kernels cost device time); the labels and the pipeline time are there, the stage table is empty,
+  and a corrupted stream is still refused (the error words reach the host through k_slice_resolve)."""
+  dev = torch.device("cuda:0")
+  shape = (1024, 1024, 4)
+  vol = synth.voronoi_labels(shape, np.uint32, seed=3, device=dev)
+  be = ckd.HipBackend(0)
+  codec = ckd.ShardedCodec(be, device=dev)
+  binary = codec.compress(vol, shape)
+  out = torch.empty_like(vol)
+  sess = codec.open_decoder(binary, shape)
+  sess.stage_events(False)
+  sess.run(out)
+  assert sess.stages() == []
+  assert sess.timing()[0] > 0
+  assert torch.equal(out, vol)
+  sess.stage_events(True)
+  sess.run(out)
+  assert [n for n, _ in sess.stages()] == FAST_FLAT
+  sess.close()
+  bad = bytearray(bytes(binary))
+  bad[len(bad) // 2] ^= 0x5A      # inside the crack codes of a middle slice
+  sess = codec.open_decoder(bytes(bad), shape)
+  sess.stage_events(False)
+  with pytest.raises(RuntimeError):
+    sess.run(out)
+  sess.close()
