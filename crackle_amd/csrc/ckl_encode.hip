@@ -2840,6 +2840,9 @@ int ckl_encoder_stats(
 			// (they were two blocking copies behind it)
 			uint64_t f = 0, l = 0;
 			const uint8_t* base = static_cast<const uint8_t*>(labels_device);
+			// the two copies land in this frame: whatever leaves it early (planes_pass throws on an allocation or a HIP
+			// error) waits for them first
+			struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{ e->stream };
 			CKL_HIP(hipMemcpyAsync(&f, base, e->dtype_bytes, hipMemcpyDeviceToHost, e->stream));
 			CKL_HIP(hipMemcpyAsync(&l, base + (voxels - 1) * e->dtype_bytes, e->dtype_bytes, hipMemcpyDeviceToHost, e->stream));
 			if (e->dtype_bytes == 1) planes_pass<uint8_t>(*e, reinterpret_cast<const uint8_t*>(labels_device), sx, sy, sz, &st);

@@ -24,6 +24,7 @@
 #include <unistd.h>
 #include <functional>
 #include <thread>
+#include <sched.h>
 #include <unordered_map>
 
 namespace ckl {
@@ -266,6 +267,18 @@ template PinCandidates pin_candidates_host<uint64_t>(const uint64_t*, const uint
 
 namespace {
 
+// Host threads this process may keep busy: the CPUs of its affinity mask (not the machine's: a rank of a node-wide
+// job is usually pinned to its share), divided by the ranks of the node when the launcher says how many there are
+// (LOCAL_WORLD_SIZE), at most 64; CKL_PINS_THREADS bounds it further (the pool itself, not only the regions).
+static size_t host_cpu_budget() {
+	size_t n = std::max<size_t>(1, std::thread::hardware_concurrency());
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min<size_t>(n, static_cast<size_t>(c)); }
+	if (const char* env = getenv("LOCAL_WORLD_SIZE")) { const int w = atoi(env); if (w > 1) n = std::max<size_t>(1, n / static_cast<size_t>(w)); }
+	if (const char* env = getenv("CKL_PINS_THREADS")) n = std::min<size_t>(n, static_cast<size_t>(std::max(1, atoi(env))));
+	return std::min<size_t>(n, 64);
+}
+
 // Worker threads that stay: starting 32 threads costs 0.5-0.8 ms, and the pin stage runs some twenty parallel
 // regions per volume.  One region at a time; a caller that finds the pool taken (another encoder's region), or
 // that runs in a process forked after the pool was made, starts threads of its own as before.
@@ -290,7 +303,7 @@ public:
 	}
 private:
 	HostPool() : pid(getpid()) {
-		n_workers = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
+		n_workers = host_cpu_budget();
 		for (size_t t = 0; t < n_workers; t++) std::thread([this, t] { work(t); }).detach();
 	}
 	void work(size_t t) {
@@ -320,8 +333,7 @@ private:
 }  // namespace
 
 void host_parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& body, size_t max_threads) {
-	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), max_threads);
-	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
+	size_t nthreads = std::min<size_t>(host_cpu_budget(), max_threads);
 	const size_t want = std::min(nthreads, std::max<size_t>(1, n / std::max<size_t>(grain, 1)));
 	if (want <= 1) { body(0, n); return; }
 	std::vector<std::string> errors(want);
@@ -343,7 +355,7 @@ namespace {
 template <typename It, typename Less>
 void host_parallel_sort(It first, It last, Less less) {
 	const size_t n = static_cast<size_t>(last - first);
-	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
+	size_t nthreads = host_cpu_budget();
 	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
 	size_t pieces = 1;
 	while (pieces < nthreads && pieces < 16 && n / (2 * pieces) >= 4096) pieces *= 2;
@@ -413,7 +425,7 @@ std::vector<uint8_t> pins_cover_host(
 	if (!table && pc.label_value.empty() && pc.comp_first.size() != N) throw Error(CKL_ERR_RUNTIME, "crackle_amd: inconsistent pin candidates");
 
 	// worker threads for the per-label phases (labels are independent of each other)
-	size_t nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64);
+	size_t nthreads = host_cpu_budget();
 	if (const char* env = getenv("CKL_PINS_THREADS")) nthreads = static_cast<size_t>(std::max(1, atoi(env)));
 	auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) { host_parallel_for(n, grain, body, 64); };
 

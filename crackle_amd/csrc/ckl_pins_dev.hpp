@@ -224,14 +224,20 @@ __global__ void __launch_bounds__(64 * kPinWaves) k_pin_dedup_wave(const LABEL* 
 			replm[k] = __ballot(ends[k] && !covered && has && lz_s >= z_s && lz_e <= z_e);      // covers the neighbour: takes its place
 			// does a label have several runs in this column?  Every run leaves its place in a hashed table and
 			// looks at what stays there: two runs of one label meet in one slot, and one of them sees the other
-			if (ends[k]) dup_table[pin_hash(static_cast<uint64_t>(lab[k])) >> (32 - kPinDupBits)] = static_cast<uint16_t>(k * 64 + lane);
+			// (atomic accesses + fences: the exchange is between LANES of the wavefront; with plain accesses and a
+			// wave barrier — which the compiler models as touching no memory — a lane's own store may be forwarded to
+			// its own load below and `other` folds to false)
+			if (ends[k]) __hip_atomic_store(dup_table + (pin_hash(static_cast<uint64_t>(lab[k])) >> (32 - kPinDupBits)), static_cast<uint16_t>(k * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
 		for (int k = 0; k < K; k++) {
-			const bool other = ends[k] && dup_table[pin_hash(static_cast<uint64_t>(lab[k])) >> (32 - kPinDupBits)] != static_cast<uint16_t>(k * 64 + lane);
+			const bool other = ends[k] && __hip_atomic_load(dup_table + (pin_hash(static_cast<uint64_t>(lab[k])) >> (32 - kPinDupBits)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != static_cast<uint16_t>(k * 64 + lane);
 			maybe_dup = maybe_dup || __ballot(other) != 0ull;
 		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// a label with several runs in this column (or two labels that met in the table): once one of the label's runs
 		// is kept it is the label's last pin, in THIS column, and the later ones are appended without a look at the neighbour

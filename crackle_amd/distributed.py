@@ -747,7 +747,7 @@ class ShardedCodec:
     pins_section = None
     import os as _os3
     rows_done = False
-    if use_pins and hasattr(be, "pins_rows_first") and not _os3.environ.get("CKL_PINS_ON_ROOT") and not getattr(self, "_pins_rows_fallback", False):
+    if use_pins and hasattr(be, "pins_rows_first") and not _os3.environ.get("CKL_PINS_ON_ROOT"):
       # every rank works on its own rows of the whole volume; rank 0 only writes the section
       got = self._pins_by_rows(be, vol, slab_shape, table, sec, cw, sw, mark)
       if got is not None:
@@ -960,6 +960,26 @@ class ShardedCodec:
     if unsigned:
       t ^= sign
 
+  def _agree(self, exc):
+    """Do all ranks get past their rank-local step?  One word, all-reduced: if any rank failed, EVERY rank raises here
+    (its own error, or a note that another rank failed) instead of the healthy ones blocking in the next collective."""
+    if self.world > 1:
+      flag = torch.tensor([1 if exc is not None else 0], dtype=torch.int32, device=self.device)
+      dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+      if int(flag.item()) and exc is None:
+        raise RuntimeError("sharded pin stage: another rank failed in its local pass")
+    if exc is not None:
+      raise exc
+
+  @staticmethod
+  def _local(fn):
+    """Runs a rank-local step; returns the exception it raised (for _agree) or None."""
+    try:
+      fn()
+      return None
+    except Exception as exc:      # noqa: BLE001 (whatever it is, the other ranks must hear of it)
+      return exc
+
   def _pins_by_rows(self, be, vol, slab_shape, table, sec, cw, sw, mark):
     """The pin label section with every rank working on its own ROWS of the whole volume (ckl_pins_rows_*,
     include/crackle_amd.h): labels and component ids are transposed from z-slabs to row slabs, the per-component
@@ -976,9 +996,13 @@ class ShardedCodec:
     ncomp_mine = _unpack(sec.comp, cw, sec.sz)
     id_base = int(table[:self.rank, 1].sum())
     cc_mine = torch.empty(max(sxy * sec.sz, 1), dtype=torch.int32, device=dev)
-    nc_mine = be.components_device(vol, slab_shape, id_base, cc_mine)
-    if not np.array_equal(nc_mine.astype(np.int64), ncomp_mine):
-      raise RuntimeError("component counts of the slab stream and of the component pass differ")
+    got = {}
+    def _components():
+      got["nc"] = be.components_device(vol, slab_shape, id_base, cc_mine)
+      if not np.array_equal(got["nc"].astype(np.int64), ncomp_mine):
+        raise RuntimeError("component counts of the slab stream and of the component pass differ")
+    self._agree(self._local(_components))      # before the transposes: a rank that raised would leave the others in all_to_all_single
+    nc_mine = got["nc"]
     rows = self._rows_of(sy)
     y0, nrows = rows[self.rank]
     lab_rows = self._to_row_slabs(vol.reshape(sec.sz, sy, sx), sz_list, rows)
@@ -988,19 +1012,16 @@ class ShardedCodec:
     first_any = torch.full((N,), -1, **i64)
     first_kept = torch.full((N,), -1, **i64)
     comp_label = torch.zeros(N, **i64)
-    if nrows:
-      be.pins_rows_first(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_any, first_kept, comp_label)
+    self._agree(self._local(lambda: be.pins_rows_first(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_any, first_kept, comp_label)) if nrows else None)
     self._reduce(first_any, "min", True)
     self._reduce(first_kept, "min", True)
     self._reduce(comp_label, "max", True)
     best = torch.zeros(N, **i64)
-    if nrows:
-      be.pins_rows_best(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_kept, best)
+    self._agree(self._local(lambda: be.pins_rows_best(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_kept, best)) if nrows else None)
     self._reduce(best, "max", False)
     choice = torch.full((N,), -1, **i64)
     ze = torch.zeros(N, dtype=torch.int32, device=dev)
-    if nrows:
-      be.pins_rows_extent(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_kept, best, choice, ze)
+    self._agree(self._local(lambda: be.pins_rows_extent(lab_rows, cc_rows, sx, nrows, sz_tot, y0, N, first_kept, best, choice, ze)) if nrows else None)
     self._reduce(ze, "max", False)
     if not nrows:      # (a rank without rows: the choice is a function of the reduced arrays alone)
       choice = torch.where(best != 0, best - 1, torch.where(first_kept == -1, first_kept, first_kept >> 16))
@@ -1010,11 +1031,14 @@ class ShardedCodec:
     total = int(offsets[-1].item())
     budget = int(os.environ.get("CKL_PIN_IDS_BUDGET", str(1 << 26)))
     if total > budget:      # volumes with long z-runs: the whole-volume stage makes the chosen pins distinct first
-      self._pins_rows_fallback = True
+      # (decided per call — `total` is the same on every rank, they all take this branch together — and said aloud:
+      # it puts the whole volume on rank 0 again)
+      if self.rank == 0:
+        import sys
+        print(f"[crackle_amd] sharded pin stage: id lists of {total} entries exceed CKL_PIN_IDS_BUDGET={budget}; this volume's pin stage runs on rank 0", file=sys.stderr)
       return None
     ids = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
-    if nrows and total:
-      be.pins_rows_ids(cc_rows, sx, nrows, sz_tot, y0, N, choice, ze, offsets, ids)
+    self._agree(self._local(lambda: be.pins_rows_ids(cc_rows, sx, nrows, sz_tot, y0, N, choice, ze, offsets, ids)) if (nrows and total) else None)
     self._reduce(ids, "sum", False)      # one rank holds each run: the others add zeros
     mark("pins:passes")
     # component counts of every slice

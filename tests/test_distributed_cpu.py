@@ -161,3 +161,48 @@ def test_sharded_compress_at_world_4_and_8(port, kind, order, pins, world):
   the label merge, the per-rank crc parts and the placement of the sections with more than two
   slabs; pins through the whole-volume stage on rank 0."""
   _run_world(port, kind, order, pins, world)
+
+
+def _agree_worker(rank, port, q):
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from oracle_backend import OracleBackend
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+  try:
+    codec = ckd.ShardedCodec(OracleBackend(), rank=rank, world=WORLD, device="cpu")
+    seen = []
+    codec._agree(None)      # nobody failed: nobody raises
+    seen.append("ok")
+    # rank 1 fails its local step: BOTH ranks must raise, the healthy one too (it would otherwise sit in the next collective)
+    exc = codec._local(lambda: (_ for _ in ()).throw(ValueError("rank-local failure"))) if rank == 1 else codec._local(lambda: None)
+    try:
+      codec._agree(exc)
+      seen.append("passed")
+    except ValueError as e:
+      seen.append("own:" + str(e))
+    except RuntimeError as e:
+      seen.append("other:" + str(e))
+    # and the group is still usable afterwards
+    t = torch.tensor([rank + 1])
+    dist.all_reduce(t)
+    seen.append(int(t.item()))
+    q.put((rank, seen))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_a_rank_local_failure():
+  """ShardedCodec._agree (the row-sharded pin stage): a rank whose local pass raised takes every rank with it."""
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_agree_worker, args=(r, port, q)) for r in range(WORLD)]
+  for p in procs:
+    p.start()
+  got = dict(q.get(timeout=120) for _ in range(WORLD))
+  for p in procs:
+    p.join(timeout=60)
+  assert got[0] == ["ok", "other:sharded pin stage: another rank failed in its local pass", 3]
+  assert got[1] == ["ok", "own:rank-local failure", 3]
