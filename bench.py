@@ -50,6 +50,7 @@ def parse_args(argv=None):
   ap.add_argument("--data", type=str, default="voronoi", choices=("voronoi", "noise2000", "binary"),
                   help="voronoi: the connectomics-style volume the metric is quoted on; noise2000 / binary: the reference's adversarial "
                        "inputs (uniform-random labels in [0, 2000) / in {0, 1}: benchmarks/README.md:108-114, 193-227), reported for honesty")
+  ap.add_argument("--cell", type=str, default="32x32x8", help="cell of the jittered-Voronoi generator (8x8x4: severely over-segmented, the reference's watershed benchmark, benchmarks/README.md:284-318)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--sync-host-copy", action="store_true", help="the encoder call returns only when its host bytes are complete (default at N = 1: the codes' PCIe copy overlaps the decode leg and is waited for inside the step)")
   ap.add_argument("--cpu-sample-slices", type=int, default=0, help="slices of the CPU baseline's sample (0: the whole slab)")
@@ -388,10 +389,11 @@ def main():
   # synthetic connectomics-style labels, generated on device;
   # rank r holds slices [r*sz, (r+1)*sz) of one global volume
   offset = (1 << 40) if np_dtype.itemsize == 8 else 0
+  cell = tuple(int(v) for v in args.cell.lower().split("x"))
   if args.data == "voronoi":
-    vol = synth.voronoi_labels((sx, sy, sz_total), np_dtype, seed=2, device=dev, offset=offset,
+    vol = synth.voronoi_labels((sx, sy, sz_total), np_dtype, seed=2, device=dev, offset=offset, cell=cell,
                                z_range=(rank * sz, (rank + 1) * sz)) if world > 1 else \
-          synth.voronoi_labels((sx, sy, sz), np_dtype, seed=2, device=dev, offset=offset)
+          synth.voronoi_labels((sx, sy, sz), np_dtype, seed=2, device=dev, offset=offset, cell=cell)
   else:
     vol = synth.random_labels_device((sx, sy, sz_total), np_dtype, seed=2, high=2000 if args.data == "noise2000" else 2,
                                      device=dev, z_range=(rank * sz, (rank + 1) * sz))
@@ -540,7 +542,7 @@ def main():
       "dtype": {1: "u8", 2: "u16", 4: "u32", 8: "u64"}[item],
       "data": "synthetic",
       "config": {
-        "workload": f"{sx}x{sy}x{sz_total} {np_dtype.name} " + {"voronoi": "jittered-Voronoi labels (cell 32x32x8)", "noise2000": "uniform-random labels in [0, 2000)", "binary": "uniform-random labels in {0, 1}"}[args.data] + f", encode+decode, {'pin' if args.pins else 'flat'} labels, markov {args.markov}",
+        "workload": f"{sx}x{sy}x{sz_total} {np_dtype.name} " + {"voronoi": f"jittered-Voronoi labels (cell {args.cell})", "noise2000": "uniform-random labels in [0, 2000)", "binary": "uniform-random labels in {0, 1}"}[args.data] + f", encode+decode, {'pin' if args.pins else 'flat'} labels, markov {args.markov}",
         "per_gpu_slab": f"{sx}x{sy}x{sz}",
         "parallelism": f"z-slab x{world}",
       },
@@ -604,7 +606,7 @@ def main():
       }
     # bytes against the reference encoder's own output at full size (sha256 of the whole stream)
     if world == 1 and not args.pins:
-      name = f"c2_{sx}x{sy}x{sz}_u32" if (np_dtype.itemsize == 4 and args.markov == 0 and args.data == "voronoi") else None
+      name = f"c2_{sx}x{sy}x{sz}_u32" if (np_dtype.itemsize == 4 and args.markov == 0 and args.data == "voronoi" and args.cell == "32x32x8") else None
       ref = reference_manifest(name) if name else None
       if ref is not None:
         sha = hashlib.sha256(bytes(binary.view()) if hasattr(binary, "view") else bytes(binary)).hexdigest()

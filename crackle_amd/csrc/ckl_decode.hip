@@ -2439,6 +2439,7 @@ struct ckl_decoder {
 	// crack records (ckl_crack_records.hpp): the strip path's front end
 	bool use_records = false;           // k_crack_records + rasterising strip kernel instead of k_decode_cracks
 	uint32_t resolve_cap = 12288;       // strip components of a slice k_slice_resolve's table holds (dynamic LDS)
+	uint32_t resolve_cap_max = 12288;   // with a CU's LDS to itself: a run whose slices overflow resolve_cap is repeated with this one before the general pipeline is asked
 	bool ran_fused = false;             // the last run went through k_strip_fused
 	bool use_fused = false;             // k_strip_fused (flat labels on the record path): strips, resolve and paint in one launch
 	DevBuf<uint32_t> d_fused_ctl;       // heads[8], timeout, pad to kFusedCtlWords, arrive[nslices], ready[nslices]
@@ -2725,6 +2726,8 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 			const bool few = d.nslices <= static_cast<uint32_t>(std::max(1, d.n_cus));
 			const size_t lds_share = few ? static_cast<size_t>(d.max_lds) - 8192u : static_cast<size_t>(d.max_lds) / 2u - 6144u;
 			d.resolve_cap = static_cast<uint32_t>(std::min<size_t>(kResolveCap, (lds_share - (kMaxStrips + 64u) * 4u) / 4u));
+			// (a workgroup alone on its CU: what an over-segmented slice gets, whatever the slice count — see below the label section)
+			d.resolve_cap_max = static_cast<uint32_t>(std::min<size_t>(kResolveCap, (static_cast<size_t>(d.max_lds) - 8192u - (kMaxStrips + 64u) * 4u) / 4u));
 			if (few && !getenv("CKL_LDS_CONTROLS")) {
 				uint32_t nctl = 16384;
 				while (nctl > 64 && rec_lds_bytes(nctl) > lds_share) nctl -= 64;
@@ -2829,6 +2832,15 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 	pack.add(d.d_comp_off, comp_off);
 	pack.add(d.d_ncomp_expect, ncomp_expect);
 	d.ncomp_expect_host = ncomp_expect;
+	if (d.strip_ok && d.resolve_cap < d.resolve_cap_max) {
+		// Over-segmented slices (the reference's watershed benchmark: 16 k segments per 1024 x 1024 slice): a component
+		// meets one to two strips, so a slice has up to ~2 strip components per component.  Where that passes what two
+		// workgroups per CU can hold, k_slice_resolve gets a CU's LDS to itself (two rounds of workgroups for more
+		// slices than CUs) instead of overflowing into the general run pipeline at a tenth of the speed.
+		uint32_t most = 0;
+		for (uint32_t c : ncomp_expect) most = std::max(most, c);
+		if (2ull * most > d.resolve_cap) d.resolve_cap = d.resolve_cap_max;
+	}
 	d.d_label_map.ensure(d.total_comp + 1);
 
 	// crc machinery: geometric-sum table G[m] = x^32 + ... + x^(32 m), component ids are
@@ -3262,7 +3274,7 @@ void strip_pipeline(ckl_decoder& d, const CrackArgs& ca, size_t crack_lds, const
 	// to the host's mapped memory itself (no k_flags_to_host launch behind the paint)
 	d.flags_by_resolve = flat && chunks <= 1 && d.host_flags_pinned && !(d.use_records && d.use_fused) && !(kTuning && getenv("CKL_STRIP_DIAG")) && !getenv("CKL_FLAGS_KERNEL");
 	if (d.flags_by_resolve) {
-		d.host_flags[ns] = 0u; d.host_flags[ns + 1] = 0u;
+		d.host_flags[ns] = 0u; d.host_flags[ns + 1] = 0u; d.host_flags[ns + 2] = 0u;
 		p.ra.host_flags = d.host_flags;
 	}
 	if (chunks > 1) CKL_HIP(hipMemsetAsync(d.d_overflow.p, 0, sizeof(uint32_t), s));      // one chunk: the crack kernel clears it
@@ -3501,7 +3513,7 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 	if (d.flags_by_resolve) {
 		CKL_HIP(hipStreamSynchronize(s));
 		memcpy(errs.data(), d.host_flags, ns * sizeof(uint32_t));
-		overflow = d.host_flags[ns];
+		overflow = (d.host_flags[ns] ? 1u : 0u) | (d.host_flags[ns + 2] ? 2u : 0u);      // (two words: each is only ever written with one constant)
 	}
 	else if (d.host_flags_pinned) {
 		hipLaunchKernelGGL(k_flags_to_host, dim3((ns + kBlock) / kBlock), dim3(kBlock), 0, s, d.d_slice_err.p, ns, strips ? d.d_overflow.p : nullptr, fused_ran ? d.d_fused_ctl.p + kFusedMaxHeads * kFusedHeadStride : nullptr, d.host_flags);
@@ -3533,6 +3545,11 @@ void decoder_run(ckl_decoder& d, void* out_device, uint64_t out_capacity_bytes, 
 			d.use_records = false;
 			return decoder_run(d, out_device, out_capacity_bytes, has_label, label, stats, planes_only, errs_out);
 		}
+	}
+	if (strips && overflow == 2u && d.resolve_cap < d.resolve_cap_max && !getenv("CKL_RESOLVE_CAP")) {
+		// only k_slice_resolve's table was too small (bit 1), and it can be larger: once more with a CU's LDS per slice
+		d.resolve_cap = d.resolve_cap_max;
+		return decoder_run(d, out_device, out_capacity_bytes, has_label, label, stats, planes_only, errs_out);
 	}
 	if (strips && overflow) {
 		// a strip or a slice has more runs / strip components than the LDS tables of the strip path

@@ -622,8 +622,9 @@ __device__ __forceinline__ bool slice_resolve_body(
 	__syncthreads();
 	if (s_flag || total > ra.cap) {      // uniform
 		if (t == 0) {
-			atomicOr(sa.overflow, 1u);
-			if (ra.host_flags) { ra.host_flags[ra.host_flags_n] = 1u; ra.host_flags[zi] = sa.slice_err[zi]; }
+			// bit 0: a strip had more runs than its tables (the strip kernel said so already); bit 1: this table is too small
+			atomicOr(sa.overflow, s_flag ? 1u : 2u);
+			if (ra.host_flags) { ra.host_flags[ra.host_flags_n + (s_flag ? 0u : 2u)] = 1u; ra.host_flags[zi] = sa.slice_err[zi]; }
 		}
 		return false;
 	}

@@ -111,3 +111,26 @@ def test_stage_events_can_be_switched_off():
   with pytest.raises(RuntimeError):
     sess.run(out)
   sess.close()
+
+
+@pytest.mark.parametrize("cell,dt,offset", [((8, 8, 4), np.uint64, 1 << 40), ((12, 12, 4), np.uint32, 0)], ids=["cell8x8x4-u64", "cell12x12x4-u32"])
+def test_over_segmented_slices_stay_on_the_strip_kernels(cell, dt, offset):
+  """The reference's second benchmark is a severely over-segmented uint64 watershed (benchmarks/README.md:284-318):
+  cells of 8 x 8 give a 1024 x 1024 slice ~16 k segments and ~30 k strip components.  The decoder must keep such
+  slices on k_crack_match -> k_strip_ccl2 -> k_slice_resolve -> k_paint_strips (k_slice_resolve with a CU's LDS to
+  itself: ckl_decoder::resolve_cap_max), also when the resolver's table was sized too small at first (forced here
+  with a decode whose first attempt overflows), instead of handing the session to the general run pipeline."""
+  dev = torch.device("cuda:0")
+  shape = (1024, 1024, 6)
+  vol = synth.voronoi_labels(shape, dt, seed=11, device=dev, offset=offset, cell=cell)
+  be = ckd.HipBackend(0)
+  codec = ckd.ShardedCodec(be, device=dev)
+  binary = codec.compress(vol, shape)
+  out = torch.empty_like(vol)
+  sess = codec.open_decoder(binary, shape)
+  for _ in range(2):
+    sess.run(out)
+    names = [n for n, _ in sess.stages()]
+    assert names == FAST_FLAT, f"cell {cell}: decoded by {names}"
+  sess.close()
+  assert torch.equal(out, vol)
