@@ -37,6 +37,17 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+# BASELINE.json's configurations by name (bench.py --config): c2 is the metric's line (one slab per GPU, weak); the others
+# are FIXED volumes, so that N ranks share them (strong scaling) — C3 and C4 are the 8-GPU configurations of BASELINE.json
+CONFIG_PRESETS = {
+  "c1": dict(shape="512x512x128", dtype="uint32", scaling="strong"),
+  "c2": dict(shape="1024x1024x512", dtype="uint32", scaling="weak"),
+  "c3": dict(shape="1024x1024x1024", dtype="uint64", scaling="strong"),
+  "c4": dict(shape="2048x2048x256", dtype="uint32", markov=5, scaling="strong"),
+  "c4pins": dict(shape="2048x2048x256", dtype="uint32", markov=5, pins=1, scaling="strong"),
+}
+
+
 def parse_args(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -54,7 +65,17 @@ def parse_args(argv=None):
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--sync-host-copy", action="store_true", help="the encoder call returns only when its host bytes are complete (default at N = 1: the codes' PCIe copy overlaps the decode leg and is waited for inside the step)")
   ap.add_argument("--cpu-sample-slices", type=int, default=0, help="slices of the CPU baseline's sample (0: the whole slab)")
-  return ap.parse_args(argv)
+  ap.add_argument("--config", type=str, default=None, choices=sorted(CONFIG_PRESETS),
+                  help="a BASELINE.json configuration by name: c2 = the default (1024x1024x512 uint32 per GPU, weak scaling: the metric's line); "
+                       "c1, c3, c4, c4pins = the fixed volumes BASELINE.json names, dealt out over --gpus ranks (strong scaling: what an 8-GPU run "
+                       "of those configurations measures); explicit --shape / --dtype / --markov / --pins / --scaling still win")
+  args = ap.parse_args(argv)
+  if args.config:
+    given = {a.split("=")[0] for a in (argv if argv is not None else sys.argv[1:]) if a.startswith("--")}
+    for key, val in CONFIG_PRESETS[args.config].items():
+      if "--" + key not in given:
+        setattr(args, key, val)
+  return args
 
 
 # ------------------------------------------------------------------------------------
@@ -543,6 +564,8 @@ def main():
       "data": "synthetic",
       "config": {
         "workload": f"{sx}x{sy}x{sz_total} {np_dtype.name} " + {"voronoi": f"jittered-Voronoi labels (cell {args.cell})", "noise2000": "uniform-random labels in [0, 2000)", "binary": "uniform-random labels in {0, 1}"}[args.data] + f", encode+decode, {'pin' if args.pins else 'flat'} labels, markov {args.markov}",
+        "preset": args.config or "c2 (default)" if (args.shape, args.dtype, args.markov, args.pins, args.data, args.cell) == ("1024x1024x512", "uint32", 0, 0, "voronoi", "32x32x8") or args.config else "custom",
+        "scaling_mode": "weak: every rank holds one --shape slab of a volume N times as deep" if args.scaling == "weak" else "strong: the slices of the one --shape volume are dealt out over the ranks",
         "per_gpu_slab": f"{sx}x{sy}x{sz}",
         "parallelism": f"z-slab x{world}",
       },

@@ -3120,7 +3120,22 @@ void launch_paint_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, const 
 	if constexpr (kTuning) {
 		if (diag) { hipLaunchKernelGGL((k_paint_strips<OUT, true>), grid, dim3(kBlock), 0, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), diag + 16); return; }
 	}
-	hipLaunchKernelGGL((k_paint_strips<OUT, false>), grid, dim3(kBlock), 0, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), static_cast<unsigned long long*>(nullptr));
+	// Two workgroups per CU, not eight: the write path is saturated by 8 wavefronts per CU (a pure fill takes its 0.334 ms
+	// at C2 with 12 or with 32), and every further workgroup in flight only lengthens the queues its siblings' loads wait
+	// in (0.370 ms at 8 per CU, 0.346 at 2, 0.352 at 1).  The limit is dynamic LDS nobody uses: just over a third of a
+	// CU's LDS per workgroup.  Grids too small to fill the chip that way keep the full occupancy.  CKL_PAINT_WGS=n (0: no limit).
+	size_t pad = 0;
+	uint32_t wgs = 2;
+	if (const char* env = getenv("CKL_PAINT_WGS")) wgs = static_cast<uint32_t>(std::max(0, atoi(env)));
+	if (wgs && static_cast<uint64_t>(d.nstrips) * n >= 4096u) {
+		const size_t own = paint_strips_words<OUT>() * sizeof(uint32_t);
+		const size_t want = static_cast<size_t>(d.max_lds) / (wgs + 1u) + 1024u;
+		if (want > own && want <= static_cast<size_t>(d.max_lds)) {
+			pad = (want - own + 15u) & ~static_cast<size_t>(15);
+			allow_dynamic_lds(reinterpret_cast<const void*>(&k_paint_strips<OUT, false>), d.device, pad);
+		}
+	}
+	hipLaunchKernelGGL((k_paint_strips<OUT, false>), grid, dim3(kBlock), pad, s, g, p.sa, reinterpret_cast<OUT*>(out_device), static_cast<uint32_t>(d.sxy), static_cast<unsigned long long*>(nullptr));
 }
 
 // strips + resolve of slices [z0, z0 + n); flat labels also paint

@@ -53,3 +53,23 @@ def test_a_failed_rank_ends_the_others():
   p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"CKL_BENCH_REHEARSAL": "dry", "CKL_BENCH_TEST_FAIL_RANK": "1"})
   assert p.returncode != 0 and "exit codes" in p.stderr, p.stderr
   assert time.time() - t0 < 120
+
+
+def test_config_presets_select_the_baseline_shapes_and_strong_scaling():
+  """bench.py --config c3 | c4 | c4pins: the fixed volumes of BASELINE.json dealt out over the ranks (strong scaling: what
+  an 8-GPU run of those configurations measures); c2 / no preset: the metric's line, one slab per GPU (weak); explicit
+  flags win over the preset."""
+  import importlib
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  bench = importlib.import_module("bench")
+  a = bench.parse_args([])
+  assert (a.shape, a.dtype, a.scaling, a.markov, a.pins) == ("1024x1024x512", "uint32", "weak", 0, 0)
+  a = bench.parse_args(["--config", "c3", "--gpus", "8"])
+  assert (a.shape, a.dtype, a.scaling, a.gpus) == ("1024x1024x1024", "uint64", "strong", 8)
+  a = bench.parse_args(["--config", "c4"])
+  assert (a.shape, a.dtype, a.scaling, a.markov, a.pins) == ("2048x2048x256", "uint32", "strong", 5, 0)
+  a = bench.parse_args(["--config", "c4pins"])
+  assert (a.markov, a.pins, a.scaling) == (5, 1, "strong")
+  a = bench.parse_args(["--config", "c4", "--scaling", "weak", "--markov", "0"])
+  assert (a.shape, a.scaling, a.markov) == ("2048x2048x256", "weak", 0)
