@@ -243,7 +243,7 @@ def pmc_traffic(kernels, workload_key):
   separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the guide prescribes for gfx950).
   None when no counters were collected for this workload, a kernel is missing from them, or the
   profile was taken from another build of the library (its recorded lib_sha16 differs)."""
-  for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+  for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
     path = os.path.join(ROOT, "profiles", fn)
     try:
       with open(path) as f:
