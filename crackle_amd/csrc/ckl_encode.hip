@@ -3142,6 +3142,47 @@ int ckl_encoder_walk_paths(ckl_encoder* e, uint32_t* fast_slices, uint32_t* comp
 	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
 }
 
+// grid = slices, block = kBlock: the walk's events of a slice by kind, and the longest run of events that take no decision
+// (a node with one remaining edge is left by it, a dead end returns: kEvSeg / kEvDead / kEvEnd; only kEvBseg picks an edge
+// AND leaves one behind).  counts: [slices][5] = seg, bseg, dead, end, longest run without a kEvBseg
+__global__ void __launch_bounds__(kBlock) k_trail_step_kinds(const uint32_t* __restrict__ events, const uint64_t* __restrict__ ibase, const uint32_t* __restrict__ n_events, uint32_t* __restrict__ counts) {
+	__shared__ uint32_t s_c[5];
+	const uint32_t zi = blockIdx.x;
+	if (threadIdx.x < 5) s_c[threadIdx.x] = 0u;
+	__syncthreads();
+	const uint32_t n = n_events[zi] & ~(dev::kEvFormatAddr12 | dev::kEvWalkWide);
+	const uint32_t* ev = events + ibase[zi];
+	uint32_t c[4] = { 0, 0, 0, 0 };
+	for (uint32_t i = threadIdx.x; i < n; i += kBlock) c[ev[i] >> 30]++;
+	for (int k = 0; k < 4; k++) if (c[k]) atomicAdd(&s_c[k], c[k]);
+	if (threadIdx.x == 0) {      // (one thread: a diagnostic, not a product path)
+		uint32_t run = 0, longest = 0;
+		for (uint32_t i = 0; i < n; i++) { if ((ev[i] >> 30) == 1u) run = 0; else { run++; longest = run > longest ? run : longest; } }
+		s_c[4] = longest;
+	}
+	__syncthreads();
+	if (threadIdx.x < 5) counts[zi * 5u + threadIdx.x] = s_c[threadIdx.x];
+}
+
+int ckl_encoder_walk_step_kinds(ckl_encoder* e, uint32_t* counts, uint32_t max_slices, uint32_t* n_slices) {
+	try {
+		if (!e || !counts || !n_slices) throw Error(CKL_ERR_ARG, "crackle_amd: null argument");
+		const size_t ns = e->last_trail_slices;
+		*n_slices = static_cast<uint32_t>(ns);
+		if (!ns || !e->t_counters.p || !e->t_events.p) { *n_slices = 0; return CKL_OK; }
+		if (ns > max_slices) throw Error(CKL_ERR_ARG, "crackle_amd: counts holds fewer slices than the last run had");
+		select_device(e->device);
+		DevBuf<uint32_t> d_counts;
+		d_counts.ensure(ns * 5);
+		hipLaunchKernelGGL(k_trail_step_kinds, dim3(static_cast<uint32_t>(ns)), dim3(kBlock), 0, e->stream, e->t_events.p, e->t_ibase.p, e->t_counters.p + 5 * ns, d_counts.p);
+		CKL_HIP(hipMemcpyAsync(counts, d_counts.p, ns * 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+		CKL_HIP(hipStreamSynchronize(e->stream));
+		return CKL_OK;
+	}
+	catch (const Error& err) { set_last_error(err.what()); return err.status; }
+	catch (const std::exception& err) { set_last_error(err.what()); return CKL_ERR_RUNTIME; }
+}
+
 void ckl_encoder_destroy(ckl_encoder* e) { delete e; }
 
 int ckl_compress(

@@ -530,6 +530,17 @@ class HipBackend:
       raise RuntimeError(_lib.last_error())
     return f.value, c.value
 
+  def walk_step_kinds(self, max_slices: int = 1 << 16):
+    """(slices, 5) array of the last encode's serial trail by kind of step: along the only remaining edge, branch +
+    lowest edge, dead end, chain end, longest run without a branch (ckl_encoder_walk_step_kinds)."""
+    buf = (C.c_uint32 * (5 * max_slices))()
+    n = C.c_uint32()
+    if not self._enc:
+      return np.zeros((0, 5), np.uint32)
+    if self._L.ckl_encoder_walk_step_kinds(self._enc, buf, max_slices, C.byref(n)) != _lib.CKL_OK:
+      raise RuntimeError(_lib.last_error())
+    return np.frombuffer(buf, dtype=np.uint32, count=5 * n.value).reshape(n.value, 5).copy()
+
   def open_decoder(self, binary: bytes, z_start: int, z_end: int):
     return HipDecodeSession(binary, z_start, z_end, self.device_index)
 

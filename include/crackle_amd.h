@@ -342,6 +342,11 @@ int ckl_encoder_last_timing(const ckl_encoder* e, float* pipeline_ms, float* dom
  * 16-bit fields, or a branch stack beyond its LDS part).  Tests assert the path with it; no reference
  * counterpart. */
 int ckl_encoder_walk_paths(ckl_encoder* e, uint32_t* fast_slices, uint32_t* compiled_slices);
+/* Diagnostic: the serial crack trail of the last ckl_encoder_run, by kind of step.  counts[5 * z + k] for slice z:
+ * k = 0 steps along the only remaining edge of a node, 1 steps that push a branch and pick the lowest edge
+ * (create_crack_codes' one real decision, src/crackcodes.hpp:399-433), 2 dead ends (returns to the branch
+ * stack), 3 chain ends, 4 the longest run of steps that take no decision.  max_slices: capacity of counts / 5. */
+int ckl_encoder_walk_step_kinds(ckl_encoder* e, uint32_t* counts, uint32_t max_slices, uint32_t* n_slices);
 void ckl_encoder_destroy(ckl_encoder* e);
 
 /* ---- host-side stream surgery used by the sharded encoder ------------------ */
