@@ -3127,7 +3127,11 @@ void launch_paint_strips(ckl_decoder& d, hipStream_t s, const RunGeom& g, const 
 	size_t pad = 0;
 	uint32_t wgs = 2;
 	if (const char* env = getenv("CKL_PAINT_WGS")) wgs = static_cast<uint32_t>(std::max(0, atoi(env)));
-	if (wgs && static_cast<uint64_t>(d.nstrips) * n >= 4096u) {
+	// (only where the strips are painted by four independent wavefronts — paint_strips_waves_body: rows of whole plane
+	// words, four of them per lane load, strips of a multiple of four rows —: the one-barrier-per-phase body of other
+	// shapes wants its eight workgroups: 0.42 against 0.67 ms on 13-row strips of an over-segmented volume)
+	const bool waves_body = (p.sa.layout & 2u) && (d.row_words & 3u) == 0u && d.head.sx == d.row_words * 32u && (d.strip_rows & 3u) == 0u;
+	if (wgs && waves_body && static_cast<uint64_t>(d.nstrips) * n >= 4096u) {
 		const size_t own = paint_strips_words<OUT>() * sizeof(uint32_t);
 		const size_t want = static_cast<size_t>(d.max_lds) / (wgs + 1u) + 1024u;
 		if (want > own && want <= static_cast<size_t>(d.max_lds)) {
