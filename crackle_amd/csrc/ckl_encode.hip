@@ -251,6 +251,163 @@ __global__ void __launch_bounds__(kBlock) k_label_planes_fast(
 	}
 }
 
+// The same pass with nothing but label loads in the wavefront's memory queue (round 5).  k_label_planes_fast stores two
+// plane words per row from inside its row loop; loads and stores retire on ONE counter on this architecture and
+// "mixed" means "wait for all": every group of four rows drained its stores before the next loads went out, and the
+// kernel read 2.15 GB in 0.42 - 0.46 ms where a plain read takes 0.31.  Here a row's plane words go to LDS (2 KiB per
+// wavefront for a strip of 32 rows) and leave in two 16-byte stores per lane after the loop; the label of the pixel left
+// of the strip is a SCALAR load (its own counter); and the rows sit in a window of kRowsAhead registers that is
+// refilled as it is consumed, so that kRowsAhead - 1 row loads are always in flight.
+// (or_over_lane_group / wave_shift_up1_label: DPP instead of ds_bpermute.)  Same grid, same outputs.
+template <typename T>
+__device__ __forceinline__ T wave_shift_up1_label(T v) {
+	if constexpr (sizeof(T) == 8) {
+		const uint32_t lo = dev::wave_shift_up1(static_cast<uint32_t>(v), 0u), hi = dev::wave_shift_up1(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32), 0u);
+		return static_cast<T>((static_cast<uint64_t>(hi) << 32) | lo);
+	}
+	else return static_cast<T>(dev::wave_shift_up1(static_cast<uint32_t>(v), 0u));
+}
+// OR of a value over every aligned group of G lanes (2, 4, 8, 16), the result in all lanes of the group: quad permutes,
+// then mirrors of half a row / a row of 16 lanes (a mirror pairs every lane with one of the other half: all an OR needs)
+template <uint32_t G>
+__device__ __forceinline__ uint32_t or_over_lane_group(uint32_t v) {
+	static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lane groups inside a row of 16");
+	if constexpr (G >= 2) v |= dev::dpp_u32<0xB1, 0xF>(0u, v);      // quad_perm [1, 0, 3, 2]
+	if constexpr (G >= 4) v |= dev::dpp_u32<0x4E, 0xF>(0u, v);      // quad_perm [2, 3, 0, 1]
+	if constexpr (G >= 8) v |= dev::dpp_u32<0x141, 0xF>(0u, v);     // row_half_mirror
+	if constexpr (G >= 16) v |= dev::dpp_u32<0x140, 0xF>(0u, v);    // row_mirror
+	return v;
+}
+
+template <typename LABEL>
+__global__ void __launch_bounds__(kBlock) k_label_planes_stream(
+	const LABEL* __restrict__ labels, uint32_t sx, uint32_t sy, uint32_t strips, uint32_t bands,
+	uint32_t* __restrict__ planeV, uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
+	uint32_t* __restrict__ partial, unsigned long long* __restrict__ partial_max, unsigned long long* __restrict__ total_pairs
+) {
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *total_pairs = 0;
+	constexpr uint32_t P = 16 / sizeof(LABEL);        // pixels per lane
+	constexpr uint32_t G = 32 / P;                    // lanes per plane word
+	constexpr uint32_t WPR = 64 / G;                  // plane words of a strip's row
+	struct alignas(16) Vec { LABEL v[P]; };
+	__shared__ uint32_t s_red[3 * kWaves];
+	__shared__ unsigned long long s_max[kWaves];
+	__shared__ __attribute__((aligned(16))) uint32_t s_words[kWaves][2][kBandRows * WPR];      // plane words of the wavefront's strip: V, H
+	const uint32_t zi = blockIdx.y;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t task = blockIdx.x * kWaves + wave;
+	uint32_t nv = 0, nh = 0, pairs = 0;
+	LABEL mxl = 0;
+	if (task < strips * bands) {
+		const uint32_t band = __builtin_amdgcn_readfirstlane(task / strips), strip = __builtin_amdgcn_readfirstlane(task - (task / strips) * strips);
+		const uint32_t x0 = strip * (64u * P);            // the strip's first pixel column (wave-uniform)
+		const uint32_t x = x0 + lane * P;
+		const uint32_t y0 = band * kBandRows, y1 = min(y0 + kBandRows, sy);
+		const bool active = x < sx;
+		const uint64_t slice_off = static_cast<uint64_t>(zi) * sy * sx;
+		const LABEL* col = labels + slice_off + (active ? x : 0u);      // (lanes past the row's end load the row's first vector: every load is unconditional)
+		Vec prev;
+#pragma unroll
+		for (uint32_t i = 0; i < P; i++) prev.v[i] = 0;
+		if (y0 > 0) prev = nt_load_vec<Vec>(col + static_cast<uint64_t>(y0 - 1) * sx);
+		uint32_t* sv = s_words[wave][0];
+		uint32_t* sh = s_words[wave][1];
+		// the pixel before the strip's first one in LINEAR order (the previous row / slice when the strip starts a row):
+		// one label per row, the same for the whole wavefront -> a scalar load of the 4 bytes that hold it
+		auto edge_of = [&](uint32_t y, bool& have) -> LABEL {
+			const uint64_t lin = slice_off + static_cast<uint64_t>(y) * sx + x0;      // wave-uniform
+			have = lin > 0;
+			const uint64_t at = have ? lin - 1 : 0;
+			if constexpr (sizeof(LABEL) >= 4) return labels[at];
+			else {
+				const uint64_t byte = at * sizeof(LABEL);
+				const uint32_t w = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(labels) & ~static_cast<uintptr_t>(3))[(byte + (reinterpret_cast<uintptr_t>(labels) & 3u)) >> 2];
+				return static_cast<LABEL>(w >> (8u * static_cast<uint32_t>((byte + (reinterpret_cast<uintptr_t>(labels) & 3u)) & 3u)));
+			}
+		};
+		constexpr uint32_t kRowsAhead = 4;
+		Vec rows[kRowsAhead];
+		LABEL edges[kRowsAhead];
+		bool have_edges[kRowsAhead];
+		auto request = [&](uint32_t r, uint32_t y) {
+			const uint32_t yl = y < y1 ? y : y1 - 1u;      // (rows past the band re-read its last row: no load in a branch of its own)
+			rows[r] = nt_load_vec<Vec>(col + static_cast<uint64_t>(yl) * sx);
+			edges[r] = edge_of(yl, have_edges[r]);
+		};
+#pragma unroll
+		for (uint32_t r = 0; r < kRowsAhead; r++) request(r, y0 + r);
+		// (a fixed trip count, fully unrolled: straight-line code, so that the compiler waits for exactly the load a row
+		// needs — across a loop's back edge it waits for all of them)
+#pragma unroll
+		for (uint32_t it = 0; it < kBandRows / kRowsAhead; it++) {
+			const uint32_t yb = y0 + it * kRowsAhead;
+#pragma unroll
+			for (uint32_t r = 0; r < kRowsAhead; r++) {
+				const uint32_t y = yb + r;
+				const Vec cur = rows[r];
+				const LABEL edge = edges[r];
+				const bool have_edge = have_edges[r];
+				request(r, y + kRowsAhead);      // the slot is free: its next row goes out before this one is looked at
+				if (y >= y1) continue;
+				LABEL left = wave_shift_up1_label(cur.v[P - 1]);
+				bool have_left = true;
+				if (lane == 0) { left = edge; have_left = have_edge; }
+				uint32_t bv = 0, bh = 0;
+				if (active) {
+#pragma unroll
+					for (uint32_t i = 0; i < P; i++) {
+						const LABEL l = i ? cur.v[i - 1] : left;
+						bv |= (cur.v[i] != l ? 1u : 0u) << i;
+						bh |= (cur.v[i] != prev.v[i] ? 1u : 0u) << i;
+						mxl = cur.v[i] > mxl ? cur.v[i] : mxl;
+					}
+					// lib::pixel_pairs counts equal LINEAR neighbours (lib.hpp:249-256): every pixel but the volume's first has one
+					pairs += P - __popc(bv) - ((have_left || (bv & 1u)) ? 0u : 1u);
+					if (x == 0) bv &= ~1u;      // no crack along the image's left border
+					if (y == 0) bh = 0u;
+				}
+				nv += __popc(bv); nh += __popc(bh);
+				bv <<= (lane % G) * P; bh <<= (lane % G) * P;
+				bv = or_over_lane_group<G>(bv); bh = or_over_lane_group<G>(bh);
+				if ((lane % G) == 0) { sv[(y - y0) * WPR + lane / G] = bv; sh[(y - y0) * WPR + lane / G] = bh; }
+				prev = cur;
+			}
+		}
+		// the strip's plane words out: row r of the band, words word0 .. word0 + WPR - 1 of the row (LDS accesses of one
+		// wavefront are ordered: no barrier)
+		const uint32_t word0 = x0 >> 5;
+		uint32_t* pv = planeV + zi * plane_words;
+		uint32_t* ph = planeH + zi * plane_words;
+		constexpr uint32_t kVecWords = WPR >= 4 ? 4u : WPR;      // words per lane and store
+		constexpr uint32_t kLanesPerRow = WPR / kVecWords;
+		for (uint32_t r0 = 0; r0 < y1 - y0; r0 += 64u / kLanesPerRow) {
+			const uint32_t r = r0 + lane / kLanesPerRow, w = (lane % kLanesPerRow) * kVecWords;
+			if (r >= y1 - y0) continue;
+			const uint64_t at = static_cast<uint64_t>(y0 + r) * row_words + word0 + w;
+			if (word0 + w + kVecWords <= row_words && ((at & (kVecWords - 1u)) == 0u) && kVecWords == 4u) {
+				*reinterpret_cast<uint4*>(pv + at) = *reinterpret_cast<const uint4*>(sv + r * WPR + w);
+				*reinterpret_cast<uint4*>(ph + at) = *reinterpret_cast<const uint4*>(sh + r * WPR + w);
+			}
+			else {
+				for (uint32_t q = 0; q < kVecWords; q++) if (word0 + w + q < row_words) { pv[at + q] = sv[r * WPR + w + q]; ph[at + q] = sh[r * WPR + w + q]; }
+			}
+		}
+	}
+	nv = wave_sum(nv); nh = wave_sum(nh); pairs = wave_sum(pairs);
+	unsigned long long mx = static_cast<unsigned long long>(mxl);
+	for (int d = kWave / 2; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d, kWave); mx = o > mx ? o : mx; }
+	if (lane == 0) { s_red[wave] = nv; s_red[kWaves + wave] = nh; s_red[2 * kWaves + wave] = pairs; s_max[wave] = mx; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tv = 0, th = 0, tp = 0;
+		unsigned long long tm = 0;
+		for (int w = 0; w < kWaves; w++) { tv += s_red[w]; th += s_red[kWaves + w]; tp += s_red[2 * kWaves + w]; tm = s_max[w] > tm ? s_max[w] : tm; }
+		const uint64_t o = static_cast<uint64_t>(zi) * gridDim.x + blockIdx.x;
+		partial[o * 4 + 0] = tv; partial[o * 4 + 1] = th; partial[o * 4 + 2] = tp; partial[o * 4 + 3] = 0;
+		partial_max[o] = tm;
+	}
+}
+
 // ckl_reencode_markov: the decoder's crack planes become the encoder's "differs from the
 // neighbour" planes (a crack is a differing pair for IMPERMISSIBLE streams and an equal pair for
 // PERMISSIBLE ones; image-border pairs carry neither) with their per-slice population counts.
@@ -1261,7 +1418,11 @@ void planes_pass(ckl_encoder& e, const LABEL* labels, int64_t sx, int64_t sy, in
 		e.d_plane_partial_max.ensure(static_cast<size_t>(nblk) * ns);
 		e.d_plane_out.ensure(4ull * ns + 1);
 		if (!getenv("CKL_NO_PREZERO")) trail_prezero(e, sx, sy, sz);
-		hipLaunchKernelGGL(k_label_planes_fast<LABEL>, dim3(nblk, ns), dim3(kBlock), 0, s,
+		if (!getenv("CKL_PLANES_V1")) hipLaunchKernelGGL(k_label_planes_stream<LABEL>, dim3(nblk, ns), dim3(kBlock), 0, s,
+			labels, static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), strips, bands,
+			e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
+			e.d_plane_partial.p, e.d_plane_partial_max.p, e.d_plane_out.p + 4ull * ns);
+		else hipLaunchKernelGGL(k_label_planes_fast<LABEL>, dim3(nblk, ns), dim3(kBlock), 0, s,
 			labels, static_cast<uint32_t>(sx), static_cast<uint32_t>(sy), strips, bands,
 			e.d_planes.p, e.d_planes.p + e.plane_words * ns, e.row_words, e.plane_words,
 			e.d_plane_partial.p, e.d_plane_partial_max.p, e.d_plane_out.p + 4ull * ns);
