@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			else if (nbytes > 0 && !a.markov_serial && markov_lds_need(nbytes, cap, a.markov_order, ra.lds_bytes, mdl_lds, kRecBlock) <= ra.lds_bytes) {
 				s_mk_parallel = 1u + (mdl_lds ? 1u : 0u);
 			}
-			else if (nbytes > 0 && !a.markov_serial && a.mkscratch && ra.lds_bytes >= 2u * kRecBlock * 4u) {
+			else if (nbytes > 0 && !a.markov_serial && a.mkscratch && ra.lds_bytes >= 2u * kRecBlock * 4u + 768u * 4u) {      // (context words + the byte table of markov_expand_parallel)
 				s_mk_parallel = 3u + (markov_model_fits_alone(a.markov_order, ra.lds_bytes, kRecBlock) ? 1u : 0u);
 			}
 			else if (nbytes > 0) ncodes = rec_markov_serial(code + index_end, nbytes, a.markov_order, a.model, cap, upacked, &err);

@@ -688,20 +688,20 @@ __device__ __forceinline__ BitMap3 bitmap3_compose(const BitMap3& f, const BitMa
 	r.c2 = f.c2 + (f2 == 0 ? g.c0 : (f2 == 1 ? g.c1 : g.c2));
 	return r;
 }
-constexpr uint32_t kMarkovWarm = 64;
+constexpr uint32_t kMarkovWarm = 192;      // (64 before round 5: a quarter of C2's chunks then started from a wrong context and 2.1 repair rounds followed; 192: 3 % and 1.4)
 
 // lds: [payload words][rank words][model rows or nothing][2 x kCrackBlock context words]
 __device__ __forceinline__ uint32_t markov_lds_need(uint32_t nbytes, uint32_t cap, int order, uint32_t budget, bool& model_in_lds, uint32_t block = kCrackBlock) {
 	const uint32_t pay = ((nbytes + 3u) / 4u + 2u) * 4u;
 	const uint32_t rnk = (cap / 16u + 2u) * 4u;
-	const uint32_t fix = 2u * block * 4u;
+	const uint32_t fix = 2u * block * 4u + 768u * 4u;      // context words, byte table
 	const uint64_t mdl = 4ull << (2 * order);
 	model_in_lds = order <= 8 && pay + rnk + fix + mdl <= budget;
 	return pay + rnk + fix + (model_in_lds ? static_cast<uint32_t>(mdl) : 0u);
 }
 // the same with payload and ranks in the global scratch: only the model and the context words
 __device__ __forceinline__ bool markov_model_fits_alone(int order, uint32_t budget, uint32_t block = kCrackBlock) {
-	return order <= 8 && (4ull << (2 * order)) + 2ull * block * 4ull <= budget;
+	return order <= 8 && (4ull << (2 * order)) + 2ull * block * 4ull + 768ull * 4ull <= budget;
 }
 
 // GLOBAL: the payload copy and the ranks live in a global scratch area (slices too big for the
@@ -725,10 +725,29 @@ __device__ __forceinline__ void markov_expand_parallel(
 	const uint32_t* rows = model_in_lds ? rows_lds : reinterpret_cast<const uint32_t*>(model_g);
 
 	// ---- stage the payload (zero padded), clear the ranks, stage the model
-	for (uint32_t w = tid; w < pay_words; w += BLOCK) {
-		uint32_t v = 0;
-		for (uint32_t b = 0; b < 4u; b++) { const uint32_t i = w * 4u + b; if (i < nbytes) v |= static_cast<uint32_t>(s[i]) << (8u * b); }
-		pay[w] = v;
+	// (whole words with one unaligned load each, eight of a thread's words requested side by side: byte loads behind a
+	// bounds test of their own made every byte a trip to memory — a third of this function's time at C2)
+	{
+		const uint32_t full = nbytes / 4u;      // words that lie wholly inside the payload
+		constexpr uint32_t kStage = 8;
+		for (uint32_t w0 = tid; w0 < pay_words; w0 += BLOCK * kStage) {
+			uint32_t v[kStage];
+#pragma unroll
+			for (uint32_t q = 0; q < kStage; q++) {
+				const uint32_t w = w0 + q * BLOCK;
+				uint32_t x = 0;
+				if (full) __builtin_memcpy(&x, s + 4ull * (w < full ? w : 0u), 4);      // (uniform: a payload of fewer than four bytes is read byte by byte below)
+				v[q] = w < full ? x : 0u;
+			}
+#pragma unroll
+			for (uint32_t q = 0; q < kStage; q++) {
+				const uint32_t w = w0 + q * BLOCK;
+				if (w >= pay_words) continue;
+				uint32_t x = v[q];
+				if (w == full) for (uint32_t b = 0; b < 4u; b++) { const uint32_t i = w * 4u + b; if (i < nbytes) x |= static_cast<uint32_t>(s[i]) << (8u * b); }      // the tail bytes
+				pay[w] = x;
+			}
+		}
 	}
 	for (uint32_t w = tid; w < rank_words; w += BLOCK) ranks[w] = 0;
 	if (model_in_lds) for (uint32_t r = tid; r < n_rows; r += BLOCK) rows_lds[r] = reinterpret_cast<const uint32_t*>(model_g)[r];
@@ -736,26 +755,58 @@ __device__ __forceinline__ void markov_expand_parallel(
 	__syncthreads();
 	auto ldw = [&](const uint32_t* p) -> uint32_t { return GLOBAL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
 
-	// ---- 1. code boundaries
-	const uint32_t B = nbytes * 8u;
-	const uint32_t Q = (B - 2u + BLOCK - 1u) / BLOCK;
-	const uint32_t lo = min(B, 2u + tid * Q), hi = min(B, lo + Q);
+	// ---- 1. + 2. code boundaries and ranks, a BYTE of the bit stream per step (round 5; a bit per step before: 0.33 of
+	// C2's 0.42 ms with a markov model).  The codes are a prefix code over the bits behind the two-bit start code
+	// (rank 0 = "0", 1 = "10", 2 = "110", 3 = "111", low bit first, markov.hpp:268-313): with the state = ones seen of
+	// the code in progress (0, 1, 2), a byte maps every state to an end state, the number of codes it COMPLETES
+	// (<= 8) and their ranks — one 32-bit table entry (s_tab, built here: 3 x 256).  The stream behind the start code
+	// is read through a two-bit funnel shift, so that bytes are bytes; its last byte holds six bits and is walked bit
+	// by bit by the last thread, which also closes a code left open at the end the way the reference's look-ahead does
+	// (it reads zeros: the open code's rank is its state).
+	uint32_t* s_tab = ctx_end + BLOCK;      // [768]: (state << 8 | byte) -> end state | completed << 2 | ranks << 6
+	for (uint32_t e = tid; e < 768u; e += BLOCK) {
+		uint32_t st = e >> 8, cnt = 0, rk = 0;
+		for (uint32_t i = 0; i < 8u; i++) {
+			const uint32_t b = (e >> i) & 1u;
+			uint32_t rank = 4u;
+			if (st == 2u) { rank = 2u + b; st = 0u; }
+			else if (b) st++;
+			else { rank = st; st = 0u; }
+			if (rank != 4u) { rk |= rank << (2u * cnt); cnt++; }
+		}
+		s_tab[e] = st | (cnt << 2) | (rk << 6);
+	}
+	__syncthreads();
+	const uint32_t nb_full = nbytes - 1u;      // whole bytes of the shifted stream (8 nbytes - 2 bits: the last byte has six)
+	const uint32_t QB = (nb_full + BLOCK - 1u) / BLOCK;
+	const uint32_t b_lo = min(nb_full, tid * QB), b_hi = min(nb_full, b_lo + QB);
+	auto shifted_word = [&](uint32_t w) -> uint32_t { return __funnelshift_r(ldw(pay + w), ldw(pay + w + 1u), 2u); };      // shifted bytes 4 w .. 4 w + 3
 	BitMap3 m;
 	{
-		uint32_t e[3], c[3];
-		// the three start states in one sweep over the bits (one LDS word per 32 bits)
 		uint32_t st0 = 0, st1 = 1, st2 = 2, n0 = 0, n1 = 0, n2 = 0;
-		uint32_t wc = ldw(pay + (lo >> 5));
-		for (uint32_t p = lo; p < hi; p++) {
-			if ((p & 31u) == 0u) wc = ldw(pay + (p >> 5));
-			const uint32_t b = (wc >> (p & 31u)) & 1u;
-			n0 += st0 == 0u ? 1u : 0u; n1 += st1 == 0u ? 1u : 0u; n2 += st2 == 0u ? 1u : 0u;
-			st0 = st0 == 2u ? 0u : (b ? st0 + 1u : 0u);
-			st1 = st1 == 2u ? 0u : (b ? st1 + 1u : 0u);
-			st2 = st2 == 2u ? 0u : (b ? st2 + 1u : 0u);
+		uint32_t wc = b_lo < b_hi ? shifted_word(b_lo >> 2) : 0u;
+		for (uint32_t j = b_lo; j < b_hi; j++) {
+			if ((j & 3u) == 0u && j != b_lo) wc = shifted_word(j >> 2);
+			const uint32_t by = (wc >> (8u * (j & 3u))) & 255u;
+			const uint32_t e0 = s_tab[(st0 << 8) | by], e1 = s_tab[(st1 << 8) | by], e2 = s_tab[(st2 << 8) | by];
+			st0 = e0 & 3u; n0 += (e0 >> 2) & 15u;
+			st1 = e1 & 3u; n1 += (e1 >> 2) & 15u;
+			st2 = e2 & 3u; n2 += (e2 >> 2) & 15u;
 		}
-		e[0] = st0; e[1] = st1; e[2] = st2; c[0] = n0; c[1] = n1; c[2] = n2;
-		m.e = e[0] | (e[1] << 2) | (e[2] << 4); m.c0 = c[0]; m.c1 = c[1]; m.c2 = c[2];
+		if (tid == BLOCK - 1) {      // the six bits of the last byte
+			const uint32_t by = (shifted_word(nb_full >> 2) >> (8u * (nb_full & 3u))) & 63u;
+			uint32_t st[3] = { st0, st1, st2 }, nn[3] = { n0, n1, n2 };
+			for (uint32_t q = 0; q < 3u; q++) {
+				for (uint32_t i = 0; i < 6u; i++) {
+					const uint32_t b = (by >> i) & 1u;
+					if (st[q] == 2u) { nn[q]++; st[q] = 0u; }
+					else if (b) st[q]++;
+					else { nn[q]++; st[q] = 0u; }
+				}
+			}
+			st0 = st[0]; st1 = st[1]; st2 = st[2]; n0 = nn[0]; n1 = nn[1]; n2 = nn[2];
+		}
+		m.e = st0 | (st1 << 2) | (st2 << 4); m.c0 = n0; m.c1 = n1; m.c2 = n2;
 	}
 	// inclusive scan of the maps inside the wavefront, wave totals through LDS
 	const uint32_t lane = tid & (kWave - 1), wave = tid >> 6;
@@ -776,53 +827,52 @@ __device__ __forceinline__ void markov_expand_parallel(
 		pre = bitmap3_compose(pre, t);
 	}
 	const BitMap3 before = bitmap3_compose(pre, exc);
-	if (tid == BLOCK - 1) *s_total = 1u + bitmap3_compose(before, m).c0;      // + the raw start code
-	// ---- 2. ranks by code index (the stream starts at a code start)
+	if (tid == BLOCK - 1) {
+		const BitMap3 all = bitmap3_compose(before, m);
+		*s_total = 1u + all.c0 + ((all.e & 3u) ? 1u : 0u);      // the start code, the completed codes, a code left open at the end
+	}
+	// ---- ranks by code index: the codes a thread's bytes complete are consecutive; only the first and the last rank word
+	// it touches can be shared with a neighbour (atomicOr), the ones between are its own
 	{
 		uint32_t st = before.e & 3u;
-		uint32_t k = 1u + before.c0;          // index of the next code to start
-		uint32_t cur = 0;                      // index of the code in progress (valid when it started in my range)
-		bool mine = false;
-		uint32_t p = lo;
-		// One payload word per 32 bits and one rank word per 16 codes: with the tables in the global scratch (2048 x 2048
-		// slices) a load per bit and an atomic per code made this phase 1.8 ms of C4's decode.  The codes that start
-		// in my range are consecutive; only the first and the last rank word they touch can be shared with a neighbour.
-		uint32_t wcur = ldw(pay + (p >> 5));
-		uint32_t acc = 0, acc_w = 0xFFFFFFFFu;
-		bool acc_shared = true;
-		auto flush = [&](bool last) {
-			if (acc_w == 0xFFFFFFFFu) return;      // nothing assembled yet
-			if (acc) {
-				if (acc_shared || last) atomicOr(ranks + acc_w, acc);
-				else if (GLOBAL) __hip_atomic_store(ranks + acc_w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				else ranks[acc_w] = acc;
-			}
-			acc_shared = false;      // (the words after my first one are mine alone, but for the last)
+		uint32_t k = 1u + before.c0;          // index of the next code to complete
+		unsigned long long acc = 0;           // rank bits from word (k >> 4) on
+		bool first_word = true;
+		auto put = [&](uint32_t wi, uint32_t bits, bool shared) {
+			if (!bits || wi >= rank_words) return;
+			if (shared) atomicOr(ranks + wi, bits);
+			else if (GLOBAL) __hip_atomic_store(ranks + wi, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			else ranks[wi] = bits;
 		};
-		while (p < hi || (mine && st != 0u)) {
-			const uint32_t b = (wcur >> (p & 31u)) & 1u;      // bits past the end read 0
-			if (st == 0u) {
-				if (p >= hi) break;
-				cur = k++; mine = true;
+		auto add = [&](uint32_t cnt, uint32_t rk) {      // cnt codes (ranks rk, two bits each) complete
+			const uint32_t kc = k < cap ? k : cap;        // (codes past the capacity are dropped: the caller reports ERR_CAPACITY)
+			acc |= static_cast<unsigned long long>(k < cap ? rk : 0u) << (2u * (kc & 15u));
+			const uint32_t k2 = k + cnt;
+			if ((k2 >> 4) != (k >> 4)) {
+				put(k >> 4, static_cast<uint32_t>(acc), first_word);
+				first_word = false;
+				acc >>= 32;
 			}
-			uint32_t rank = 4u;
-			if (st == 2u) { rank = 2u + b; st = 0u; }
-			else if (b) st++;
-			else { rank = st; st = 0u; }
-			if (rank != 4u && mine) {
-				if (cur < cap) {
-					if constexpr (GLOBAL) {
-						if ((cur >> 4) != acc_w) { flush(false); acc_w = cur >> 4; acc = 0; }
-						acc |= rank << (2u * (cur & 15u));
-					}
-					else atomicOr(ranks + (cur >> 4), rank << (2u * (cur & 15u)));      // in LDS an atomic per code is the cheaper form (C2, markov 5: 0.39 against 0.45 ms)
-				}
-				mine = false;
-			}
-			p++;
-			if ((p & 31u) == 0u) wcur = ldw(pay + (p >> 5));
+			k = k2;
+		};
+		uint32_t wc = b_lo < b_hi ? shifted_word(b_lo >> 2) : 0u;
+		for (uint32_t j = b_lo; j < b_hi; j++) {
+			if ((j & 3u) == 0u && j != b_lo) wc = shifted_word(j >> 2);
+			const uint32_t e = s_tab[(st << 8) | ((wc >> (8u * (j & 3u))) & 255u)];
+			st = e & 3u;
+			add((e >> 2) & 15u, (e >> 6) & 0xFFFFu);
 		}
-		flush(true);
+		if (tid == BLOCK - 1) {
+			const uint32_t by = (shifted_word(nb_full >> 2) >> (8u * (nb_full & 3u))) & 63u;
+			for (uint32_t i = 0; i < 6u; i++) {
+				const uint32_t b = (by >> i) & 1u;
+				if (st == 2u) { add(1u, 2u + b); st = 0u; }
+				else if (b) st++;
+				else { add(1u, st); st = 0u; }
+			}
+			if (st) add(1u, st);      // the code left open reads zeros behind the payload
+		}
+		put(k >> 4, static_cast<uint32_t>(acc), true);
 	}
 	if (GLOBAL) __threadfence();
 	__syncthreads();
@@ -836,7 +886,7 @@ __device__ __forceinline__ void markov_expand_parallel(
 	const uint32_t* ranks_src = ranks;
 	bool ranks_in_lds = false;
 	if (GLOBAL) {
-		uint32_t* stage = ctx_end + BLOCK;
+		uint32_t* stage = s_tab + 768u;
 		const uint32_t used = static_cast<uint32_t>(stage - lds), need = (n >> 4) + 2u;
 		if (lds_words > used && need <= lds_words - used) {      // uniform
 			for (uint32_t w = tid; w < need; w += BLOCK) stage[w] = ldw(ranks + w);
@@ -854,20 +904,37 @@ __device__ __forceinline__ void markov_expand_parallel(
 	const uint32_t nchunks = (n + C - 1u) / C;
 	const uint32_t k0 = tid * C, k1 = min(n, k0 + C);
 	const bool have = tid < nchunks;
-	auto decode_chunk = [&](uint32_t ctx) -> uint32_t {      // codes max(k0, 1) .. k1-1 from context ctx; writes the words; returns the end context
-		uint32_t word = (k0 == 0u) ? start : 0u;
-		const uint32_t kfirst = max(k0, 1u);
-		uint32_t rw = 0;
-		for (uint32_t k = kfirst; k < k1; k++) {
-			if ((k & 15u) == 0u || k == kfirst) rw = ldr(k >> 4);
-			const uint32_t r = (rw >> (2u * (k & 15u))) & 3u;
-			const uint32_t v = (rows[ctx] >> (8u * r)) & 3u;
-			ctx = (ctx >> 2) + (v << shift);
-			word |= v << (2u * (k & 15u));
-			if ((k & 15u) == 15u) { upacked[k >> 4] = word; word = 0; }
+	// codes max(k0, 1) .. k1 - 1 from context ctx, a WORD of 16 at a time (chunks start on words; only the slice's first
+	// and last word can be partial): writes the words, returns the end context.  REPAIR (a chunk whose start context
+	// turned out different): the context is a shift register of the last `order` (< 16) decoded codes, so once a whole
+	// word comes out as it did before, everything behind it does too — the chunk is left there, kMarkovSame returned
+	// (its end context stands).  A repaired chunk typically rejoins its old trajectory inside one or two words.
+	constexpr uint32_t kMarkovSame = 0xFFFFFFFFu;
+	auto decode_chunk = [&](uint32_t ctx, bool repair) -> uint32_t {
+		const uint32_t w0 = k0 >> 4, w1 = (k1 + 15u) >> 4;
+		for (uint32_t w = w0; w < w1; w++) {
+			const uint32_t rw = ldr(w);
+			const uint32_t lo = w == 0u ? 1u : 0u, hi = min(16u, k1 - 16u * w);      // (code 0 of the slice is the raw start code)
+			uint32_t word = w == 0u ? start : 0u;
+			if (lo == 0u && hi == 16u) {
+#pragma unroll
+				for (uint32_t i = 0; i < 16u; i++) {
+					const uint32_t v = (rows[ctx] >> (8u * ((rw >> (2u * i)) & 3u))) & 3u;
+					ctx = (ctx >> 2) + (v << shift);
+					word |= v << (2u * i);
+				}
+			}
+			else {
+				for (uint32_t i = lo; i < hi; i++) {
+					const uint32_t v = (rows[ctx] >> (8u * ((rw >> (2u * i)) & 3u))) & 3u;
+					ctx = (ctx >> 2) + (v << shift);
+					word |= v << (2u * i);
+				}
+			}
+			if (repair && lo == 0u && hi == 16u && __hip_atomic_load(upacked + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == word) return kMarkovSame;
+			upacked[w] = word;
 		}
-		if (k1 & 15u) upacked[k1 >> 4] = word;
-		else if (k1 == n) upacked[k1 >> 4] = 0u;
+		if ((k1 & 15u) == 0u && k1 == n) upacked[k1 >> 4] = 0u;
 		return ctx;
 	};
 	uint32_t my_in = start << shift;
@@ -885,14 +952,18 @@ __device__ __forceinline__ void markov_expand_parallel(
 			my_in = ctx;
 		}
 		ctx_in[tid] = my_in;
-		ctx_end[tid] = decode_chunk(my_in);
+		ctx_end[tid] = decode_chunk(my_in, false);
 	}
 	for (uint32_t round = 0; round <= nchunks; round++) {
 		__syncthreads();
 		const uint32_t want = (have && tid > 0u) ? ctx_end[tid - 1] : my_in;
 		const bool bad = have && tid > 0u && want != my_in;
 		if (!__syncthreads_or(bad ? 1 : 0)) break;
-		if (bad) { my_in = want; ctx_end[tid] = decode_chunk(my_in); }
+		if (bad) {
+			my_in = want;
+			const uint32_t e = decode_chunk(my_in, true);
+			if (e != kMarkovSame) ctx_end[tid] = e;
+		}
 	}
 	__syncthreads();
 }
@@ -982,7 +1053,7 @@ __global__ void __launch_bounds__(kCrackBlock) k_decode_cracks(CrackArgs a, unsi
 			else if (nbytes > 0 && !a.markov_serial && markov_lds_need(nbytes, cap, a.markov_order, a.lds_words * 4u, mdl_lds) <= a.lds_words * 4u) {
 				s_mk_parallel = 1u + (mdl_lds ? 1u : 0u);
 			}
-			else if (nbytes > 0 && !a.markov_serial && a.mkscratch && a.lds_words * 4u >= 2u * kCrackBlock * 4u) {
+			else if (nbytes > 0 && !a.markov_serial && a.mkscratch && a.lds_words * 4u >= 2u * kCrackBlock * 4u + 768u * 4u) {
 				s_mk_parallel = 3u + (markov_model_fits_alone(a.markov_order, a.lds_words * 4u) ? 1u : 0u);      // payload + ranks in the global scratch
 			}
 			else if (nbytes > 0) {
