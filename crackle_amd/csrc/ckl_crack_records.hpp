@@ -28,10 +28,10 @@
 // the two integers.
 #pragma once
 
-constexpr int kRecBlock = 512;                    // threads per slice
-constexpr int kRecWaves = kRecBlock / kWave;
+constexpr int kRecBlock = 512;                    // threads per slice (two workgroups per CU); kRecBlockWide when a decode has no more slices than the chip has CUs
+constexpr int kRecBlockWide = 1024;               // a slice alone on its CU: twice the threads, half the tiles and half the work per thread in every phase
 constexpr uint32_t kRecWords = 8;                 // words of 16 code positions per thread and tile
-constexpr uint32_t kRecTile = kRecBlock * kRecWords * 16u;      // code positions per tile
+constexpr uint32_t rec_tile(int block) { return static_cast<uint32_t>(block) * kRecWords * 16u; }      // code positions per tile
 constexpr uint32_t kRecMaxStrips = 512;           // strips per slice the LDS cursors cover
 constexpr uint32_t kRecMaxDim = 65534;            // packed vertices: 16 bits per coordinate
 constexpr uint32_t kEmitSegWindow = 2048;         // segment offsets k_crack_emit stages in LDS per workgroup
@@ -220,13 +220,13 @@ struct RecArgs {
 
 // the seldom-taken parts of k_crack_match (as functions of their own, not inlined, they made the kernel
 // slower: 0.131 against 0.101 ms at C2)
-template <bool GLOBAL>
+template <bool GLOBAL, int BLOCK>
 __device__ __forceinline__ void rec_markov_expand(
 	const uint8_t* s, uint32_t nbytes, int order, const uint8_t* model_g, uint32_t cap, uint32_t* upacked, uint32_t* lds, uint32_t* gscratch,
 	bool model_in_lds, uint32_t* s_scan, uint32_t* s_total, uint32_t* out2 /* codes, error bits */, uint32_t lds_words
 ) {
 	uint32_t nc = 0, er = 0;
-	markov_expand_parallel<GLOBAL, kRecBlock>(s, nbytes, order, model_g, cap, upacked, lds, gscratch, model_in_lds, s_scan, s_total, nc, er, lds_words);
+	markov_expand_parallel<GLOBAL, BLOCK>(s, nbytes, order, model_g, cap, upacked, lds, gscratch, model_in_lds, s_scan, s_total, nc, er, lds_words);
 	if (threadIdx.x == 0) { out2[0] = nc; out2[1] = er; }
 }
 // one thread: the markov bitstream -> difference codes, 16 per word (markov.hpp:268-313); returns the codes, *err the error bits
@@ -261,12 +261,13 @@ __device__ __forceinline__ uint32_t rec_markov_serial(const uint8_t* s, uint32_t
 	return m;
 }
 // branch matching with the tables in global memory (a slice with more control symbols than the LDS tables hold)
+template <int BLOCK>
 __device__ __forceinline__ void rec_match_global(
 	const CtlTablesP<uint32_t, int32_t>* gt, uint32_t n, const uint32_t* nodes, uint32_t n_nodes, uint32_t sxe, uint32_t sx, uint32_t sy,
 	uint32_t* s_scan, int32_t* s_scanmax, uint32_t* s_first_dead, uint32_t* s_valid_segs, uint32_t* s_loff, uint32_t* s_lcnt, uint32_t* rerr_out
 ) {
 	uint32_t rerr = 0;
-	match_controls_packed<uint32_t, int32_t, kRecBlock>(*gt, n, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, s_first_dead, s_valid_segs, s_loff, s_lcnt, rerr);
+	match_controls_packed<uint32_t, int32_t, BLOCK>(*gt, n, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, s_first_dead, s_valid_segs, s_loff, s_lcnt, rerr);
 	if (rerr) atomicOr(rerr_out, rerr);
 }
 
@@ -359,13 +360,16 @@ __device__ __forceinline__ void word_to_records(
 	}
 }
 
-// grid = slices of the launch, block = kRecBlock, dynamic LDS = lds_bytes
-__global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
+// grid = slices of the launch, block = BLOCK (BLOCK or BLOCKWide), dynamic LDS = lds_bytes
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
+	constexpr int kRecWaves = BLOCK / kWave;
+	constexpr uint32_t kRecTile = rec_tile(BLOCK);
 	extern __shared__ __attribute__((aligned(16))) unsigned long long s_dyn[];
 	__shared__ uint32_t s_scan[4 * kRecWaves];
 	__shared__ int32_t s_scanmax[kRecWaves];
-	__shared__ uint8_t s_last_move[kRecBlock];
-	__shared__ uint8_t s_last_ctrl[kRecBlock];
+	__shared__ uint8_t s_last_move[BLOCK];
+	__shared__ uint8_t s_last_ctrl[BLOCK];
 	__shared__ uint32_t s_nnodes, s_ncodes, s_valid_segs, s_err, s_first_dead;
 	__shared__ uint32_t s_loff[14], s_lcnt[14];
 	__shared__ uint32_t s_mk_parallel, s_mk_total, s_index_end;
@@ -386,14 +390,14 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 	const uint32_t sx = a.sx, sy = a.sy;
 	uint32_t* upacked = a.upacked ? a.upacked + cb / 16u + 2ull * zi : nullptr;
 	const uint32_t nstrips = ra.lists.nstrips;
-	for (uint32_t k = tid; k < nstrips; k += kRecBlock) s_cursor[k] = 0u;
+	for (uint32_t k = tid; k < nstrips; k += BLOCK) s_cursor[k] = 0u;
 
 	// the head of the slice's code (its beginning-of-chain index, usually under a hundred bytes) is staged in LDS by
 	// all threads: the one thread that parses it would otherwise make a trip to memory per field
 	constexpr uint32_t kIndexStage = 2048;
 	uint8_t* s_idx = reinterpret_cast<uint8_t*>(s_dyn);
 	const uint32_t stage_n = min(min(code_len, kIndexStage), ra.lds_bytes);
-	for (uint32_t i = tid; i < stage_n; i += kRecBlock) s_idx[i] = code[i];
+	for (uint32_t i = tid; i < stage_n; i += BLOCK) s_idx[i] = code[i];
 	__syncthreads();
 	auto rd_idx = [&](const uint8_t* p, int w) -> uint32_t {      // (the staged bytes are only valid until the markov expansion takes the LDS)
 		const uint32_t at = static_cast<uint32_t>(p - code);
@@ -443,11 +447,11 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			if (a.markov_order == 0) {
 				ncodes = nbytes * 4u;
 			}
-			else if (nbytes > 0 && !a.markov_serial && markov_lds_need(nbytes, cap, a.markov_order, ra.lds_bytes, mdl_lds, kRecBlock) <= ra.lds_bytes) {
+			else if (nbytes > 0 && !a.markov_serial && markov_lds_need(nbytes, cap, a.markov_order, ra.lds_bytes, mdl_lds, BLOCK) <= ra.lds_bytes) {
 				s_mk_parallel = 1u + (mdl_lds ? 1u : 0u);
 			}
-			else if (nbytes > 0 && !a.markov_serial && a.mkscratch && ra.lds_bytes >= 2u * kRecBlock * 4u + 768u * 4u) {      // (context words + the byte table of markov_expand_parallel)
-				s_mk_parallel = 3u + (markov_model_fits_alone(a.markov_order, ra.lds_bytes, kRecBlock) ? 1u : 0u);
+			else if (nbytes > 0 && !a.markov_serial && a.mkscratch && ra.lds_bytes >= 2u * BLOCK * 4u + 768u * 4u) {      // (context words + the byte table of markov_expand_parallel)
+				s_mk_parallel = 3u + (markov_model_fits_alone(a.markov_order, ra.lds_bytes, BLOCK) ? 1u : 0u);
 			}
 			else if (nbytes > 0) ncodes = rec_markov_serial(code + index_end, nbytes, a.markov_order, a.model, cap, upacked, &err);
 		}
@@ -465,8 +469,8 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 		const uint32_t mode = s_mk_parallel;
 		uint32_t* gsc = a.mkscratch ? a.mkscratch + a.mkbase[zi] : nullptr;
 		__shared__ uint32_t s_mk_out[2];
-		if (mode <= 2u) rec_markov_expand<false>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 2u, s_scan, &s_mk_total, s_mk_out, ra.lds_bytes / 4u);
-		else rec_markov_expand<true>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 4u, s_scan, &s_mk_total, s_mk_out, ra.lds_bytes / 4u);
+		if (mode <= 2u) rec_markov_expand<false, BLOCK>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 2u, s_scan, &s_mk_total, s_mk_out, ra.lds_bytes / 4u);
+		else rec_markov_expand<true, BLOCK>(code + ie, code_len - ie, a.markov_order, a.model, cap, upacked, reinterpret_cast<uint32_t*>(s_dyn), gsc, mode == 4u, s_scan, &s_mk_total, s_mk_out, ra.lds_bytes / 4u);
 		if (tid == 0) { s_ncodes = s_mk_out[0]; if (s_mk_out[1]) s_err |= s_mk_out[1]; }
 		__syncthreads();
 	}
@@ -474,11 +478,11 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 	stamp(0);
 	const uint32_t n_codes = s_ncodes;
 	const uint32_t n_nodes = s_nnodes;
-	// the code positions 0 .. n_codes are dealt out in tiles of kRecBlock x span, span the same for every
+	// the code positions 0 .. n_codes are dealt out in tiles of BLOCK x span, span the same for every
 	// tile of the slice (a multiple of 16, at most 128): all threads get an even share
 	const uint32_t n_tiles = n_codes / kRecTile + 1u;
-	const uint32_t span = min(kRecWords * 16u, ((n_codes / n_tiles + kRecBlock) / kRecBlock + 15u) / 16u * 16u);
-	const uint32_t tile_step = span * kRecBlock;
+	const uint32_t span = min(kRecWords * 16u, ((n_codes / n_tiles + BLOCK) / BLOCK + 15u) / 16u * 16u);
+	const uint32_t tile_step = span * BLOCK;
 	const uint32_t index_end = 4u + (code_len >= 4u ? rd_le_dev(code, 4) : 0u);
 	const uint8_t* packed = code + index_end;
 	const uint32_t* words;
@@ -522,7 +526,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 		for (uint32_t tile = 0; tile <= n_codes; tile += tile_step) {
 			WordSyms ws[kRecWords];
 			uint32_t o_a, o_dx, o_dy;
-			tile_symbols<false, kRecBlock, kRecWords>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+			tile_symbols<false, BLOCK, kRecWords>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
 			stamp(1);
 			uint32_t o_p = (o_dy << 16) + o_dx;
 			uint32_t nt = 0;
@@ -549,7 +553,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 					else if (o_a + 2u < kcap) { a.g_kind[kb + o_a] = static_cast<uint8_t>(kind); a.g_dx[kb + o_a] = cp; }
 					o_a++;
 				}
-				if (j < words_per) *reinterpret_cast<uint4*>(wout + w0 + j * kRecBlock) = make_uint4(w.prevs, w.ms | (w.isT << 1), o_p, o_t);
+				if (j < words_per) *reinterpret_cast<uint4*>(wout + w0 + j * BLOCK) = make_uint4(w.prevs, w.ms | (w.isT << 1), o_p, o_t);
 				o_t += __popc(w.isT);
 				o_p += __popc(mR) - __popc(mL) + ((__popc(mD) - __popc(mU)) << 16);
 			}
@@ -560,7 +564,7 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 		const uint32_t n_ctl = c.a;
 		const uint32_t* seg = lt.seg;
 		if (n_ctl + 2u <= lcap) {
-			match_controls_packed<uint16_t, int16_t, kRecBlock>(lt, n_ctl, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, rerr, ra.diag);
+			match_controls_packed<uint16_t, int16_t, BLOCK>(lt, n_ctl, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, rerr, ra.diag);
 		}
 		else {
 			// more control symbols than the LDS tables hold: the first of them were recorded in LDS
@@ -569,10 +573,10 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			gt.link = a.g_link + kb; gt.seg = a.g_seg_x + kb; gt.gmin = a.g_gmin + kb;
 			uint32_t n = n_ctl;
 			if (n + 2u >= kcap) { n = kcap - 3u; rerr |= ERR_CAPACITY; }
-			for (uint32_t i = tid; i + 2u < lcap && i < n; i += kRecBlock) { gt.kind[i] = lt.kind[i]; gt.pos[i] = lt.pos[i]; }
+			for (uint32_t i = tid; i + 2u < lcap && i < n; i += BLOCK) { gt.kind[i] = lt.kind[i]; gt.pos[i] = lt.pos[i]; }
 			__syncthreads();
 			__threadfence_block();
-			rec_match_global(&gt, n, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, &s_err);
+			rec_match_global<BLOCK>(&gt, n, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, &s_err);
 			__threadfence_block();
 			seg = gt.seg;
 		}
@@ -597,11 +601,11 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 				return make_uint4(raw.x, raw.y, raw.z, raw.w);
 			};
 			constexpr uint32_t kBatch = 8;      // words of a thread in flight (a slice of C2 gives a thread 14: two trips to memory)
-			for (uint32_t w0 = 0; w0 < n_words; w0 += kBatch * kRecBlock) {
+			for (uint32_t w0 = 0; w0 < n_words; w0 += kBatch * BLOCK) {
 				uint4 wr[kBatch];
 #pragma unroll
 				for (uint32_t q = 0; q < kBatch; q++) {
-					const uint32_t w = w0 + q * kRecBlock + tid;
+					const uint32_t w = w0 + q * BLOCK + tid;
 					wr[q] = load_word(w < n_words ? w : 0u);
 					if (w >= n_words) wr[q].y = 0u;
 				}
@@ -633,13 +637,13 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			}
 			__syncthreads();
 			const uint32_t qn = min(*s_qn, queue_cap);
-			for (uint32_t i = tid; i < qn; i += kRecBlock) word_to_records(queue[i], seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
+			for (uint32_t i = tid; i < qn; i += BLOCK) word_to_records(queue[i], seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
 		}
 	}
 	__syncthreads();
 	{
 		const RecordLists& L = ra.lists;
-		for (uint32_t k = tid; k < nstrips; k += kRecBlock) {
+		for (uint32_t k = tid; k < nstrips; k += BLOCK) {
 			const uint32_t n = s_cursor[k];
 			L.count[static_cast<uint64_t>(zi) * nstrips + k] = min(n, L.cap);
 			if (n > L.cap) rerr |= ERR_LIST;
@@ -656,6 +660,6 @@ __global__ void __launch_bounds__(kRecBlock, 4) k_crack_match(RecArgs ra) {
 			ra.fused_ctl[ra.fused_ctl_words + ra.fused_n + zi] = 0u;
 		}
 	}
-	if (ra.fused_ctl && blockIdx.x == 0) for (uint32_t w = tid; w < ra.fused_ctl_words; w += kRecBlock) ra.fused_ctl[w] = 0u;      // ticket counters, timeout
+	if (ra.fused_ctl && blockIdx.x == 0) for (uint32_t w = tid; w < ra.fused_ctl_words; w += BLOCK) ra.fused_ctl[w] = 0u;      // ticket counters, timeout
 }
 

@@ -2522,6 +2522,7 @@ struct ckl_decoder {
 	DevBuf<uint64_t> d_word_off;
 	uint32_t max_words = 0;             // most words of one slice
 	uint32_t rec_cap = 0, rec_lds_controls = 0;
+	int rec_block = kRecBlock;          // threads of k_crack_match's workgroups
 	size_t rec_lds = 0;
 	const uint64_t* foreign_label_map = nullptr;   // array_equal: component -> label table of ANOTHER stream (same component counts)
 	int paint_width = 0;                // array_equal: bytes per painted voxel when it is not this stream's data width
@@ -2805,7 +2806,9 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 				if (rec_lds_bytes(nctl) <= lds_share && nctl > d.rec_lds_controls) {
 					d.rec_lds_controls = nctl;
 					d.rec_lds = lds_share & ~static_cast<size_t>(15);
-					allow_dynamic_lds(reinterpret_cast<const void*>(&k_crack_match), d.device, d.rec_lds);
+					d.rec_block = getenv("CKL_REC_NARROW") ? kRecBlock : kRecBlockWide;      // a slice has its CU to itself: 16 wavefronts instead of 8
+					if (d.rec_block == kRecBlockWide) allow_dynamic_lds(reinterpret_cast<const void*>(&k_crack_match<kRecBlockWide>), d.device, d.rec_lds);
+					else allow_dynamic_lds(reinterpret_cast<const void*>(&k_crack_match<kRecBlock>), d.device, d.rec_lds);
 				}
 			}
 			const size_t nst = static_cast<size_t>(d.nstrips) * d.nslices;
@@ -2834,7 +2837,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 				uint64_t wtot = 0;
 				d.max_words = 0;
 				for (uint32_t zi = 0; zi < d.nslices; zi++) {
-					const uint32_t nw = (ccap[zi] / kRecTile + 1u) * kRecBlock * kRecWords;
+					const uint32_t nw = (ccap[zi] / rec_tile(d.rec_block) + 1u) * static_cast<uint32_t>(d.rec_block) * kRecWords;
 					word_off[zi] = wtot; wtot += nw;
 					d.max_words = std::max(d.max_words, nw);
 				}
@@ -3242,7 +3245,8 @@ void launch_crack_records(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t 
 		CKL_HIP(hipMemsetAsync(d.d_diag.p + 32, 0, 32 * sizeof(unsigned long long), s));
 		ra.diag = d.d_diag.p + 32;
 	}
-	hipLaunchKernelGGL(k_crack_match, dim3(n), dim3(kRecBlock), d.rec_lds, s, ra);
+	if (d.rec_block == kRecBlockWide) hipLaunchKernelGGL(k_crack_match<kRecBlockWide>, dim3(n), dim3(kRecBlockWide), d.rec_lds, s, ra);
+	else hipLaunchKernelGGL(k_crack_match<kRecBlock>, dim3(n), dim3(kRecBlock), d.rec_lds, s, ra);
 	if (st) st->done("k_crack_match");
 	if (ra.diag) {
 		unsigned long long hd[32];
@@ -4146,7 +4150,7 @@ static std::unique_ptr<ckl_decoder> decoder_new(int device) {
 		d->rec_lds = (rec_lds_bytes(nctl) + 15) & ~static_cast<size_t>(15);
 		// markov streams are expanded in the same LDS: give them all of the half
 		if (!getenv("CKL_LDS_CONTROLS")) d->rec_lds = std::max(d->rec_lds, budget & ~static_cast<size_t>(15));
-		if (nctl && once(1, d->rec_lds)) CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_crack_match), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(d->rec_lds)));
+		if (nctl && once(1, d->rec_lds)) CKL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_crack_match<kRecBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(d->rec_lds)));
 	}
 	return d;
 }
