@@ -9,7 +9,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # CKL_TUNING_LIB=1 (kernel work only): the -DCKL_TUNING build with cycle stamps and ablation switches
-LIB_PATH = os.path.join(HERE, "libcrackle_amd_tuning.so" if os.environ.get("CKL_TUNING_LIB") else "libcrackle_amd.so")
+# CKL_LIB_AB=name (kernel work only): libcrackle_amd_<name>.so, an earlier build kept beside the current one for an A/B inside one GPU call
+LIB_PATH = os.path.join(HERE, "libcrackle_amd_tuning.so" if os.environ.get("CKL_TUNING_LIB") else
+                        ("libcrackle_amd_%s.so" % os.environ["CKL_LIB_AB"]) if os.environ.get("CKL_LIB_AB") else "libcrackle_amd.so")
 
 CKL_OK, CKL_ERR_FORMAT, CKL_ERR_RUNTIME, CKL_ERR_ARG, CKL_ERR_NO_DEVICE, CKL_ERR_CRC = range(6)
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -30,8 +30,11 @@
 
 constexpr int kRecBlock = 512;                    // threads per slice (two workgroups per CU); kRecBlockWide when a decode has no more slices than the chip has CUs
 constexpr int kRecBlockWide = 1024;               // a slice alone on its CU: twice the threads, half the tiles and half the work per thread in every phase
-constexpr uint32_t kRecWords = 8;                 // words of 16 code positions per thread and tile
-constexpr uint32_t rec_tile(int block) { return static_cast<uint32_t>(block) * kRecWords * 16u; }      // code positions per tile
+// words of 16 code positions per thread and tile: with eight of them the 512-thread kernel spilled twelve of a tile's symbol words and — what cost
+// more — threadIdx.x and the wavefront's scan slot, which it then fetched back from scratch memory in front of most barriers; with six it keeps
+// everything in its 128 registers (a slice of C2 takes three tiles either way: its share is 96 positions per thread)
+constexpr uint32_t rec_words(int block) { return block == kRecBlock ? 6u : 8u; }
+constexpr uint32_t rec_tile(int block) { return static_cast<uint32_t>(block) * rec_words(block) * 16u; }      // code positions per tile
 constexpr uint32_t kRecMaxStrips = 512;           // strips per slice the LDS cursors cover
 constexpr uint32_t kRecMaxDim = 65534;            // packed vertices: 16 bits per coordinate
 constexpr uint32_t kEmitSegWindow = 2048;         // segment offsets k_crack_emit stages in LDS per workgroup
@@ -162,7 +165,7 @@ __device__ __forceinline__ void match_controls_packed(
 	}
 	__syncthreads();
 	sub(6);
-	const uint32_t first_dead = *s_first_dead;
+	const uint32_t first_dead = uni(*s_first_dead);
 	const uint32_t n_eff = min(N, first_dead);
 	// ---- pointer jumping: (value, parent) pairs updated in single 8-byte accesses, consistent under races
 	for (uint32_t i = i0; i < i1; i++) {
@@ -365,6 +368,7 @@ template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 	constexpr int kRecWaves = BLOCK / kWave;
 	constexpr uint32_t kRecTile = rec_tile(BLOCK);
+	constexpr uint32_t kRecWords = rec_words(BLOCK);
 	extern __shared__ __attribute__((aligned(16))) unsigned long long s_dyn[];
 	__shared__ uint32_t s_scan[4 * kRecWaves];
 	__shared__ int32_t s_scanmax[kRecWaves];
@@ -476,14 +480,15 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 	}
 	if (a.markov_order) __threadfence_block();
 	stamp(0);
-	const uint32_t n_codes = s_ncodes;
-	const uint32_t n_nodes = s_nnodes;
+	// (values every lane holds alike, read from LDS or memory, are moved to scalar registers: the kernel is short of vector registers)
+	const uint32_t n_codes = uni(s_ncodes);
+	const uint32_t n_nodes = uni(s_nnodes);
 	// the code positions 0 .. n_codes are dealt out in tiles of BLOCK x span, span the same for every
 	// tile of the slice (a multiple of 16, at most 128): all threads get an even share
 	const uint32_t n_tiles = n_codes / kRecTile + 1u;
 	const uint32_t span = min(kRecWords * 16u, ((n_codes / n_tiles + BLOCK) / BLOCK + 15u) / 16u * 16u);
 	const uint32_t tile_step = span * BLOCK;
-	const uint32_t index_end = 4u + (code_len >= 4u ? rd_le_dev(code, 4) : 0u);
+	const uint32_t index_end = uni(4u + (code_len >= 4u ? rd_le_dev(code, 4) : 0u));
 	const uint8_t* packed = code + index_end;
 	const uint32_t* words;
 	uint32_t wshift;
@@ -526,7 +531,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 		for (uint32_t tile = 0; tile <= n_codes; tile += tile_step) {
 			WordSyms ws[kRecWords];
 			uint32_t o_a, o_dx, o_dy;
-			tile_symbols<false, BLOCK, kRecWords>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl);
+			tile_symbols<false, BLOCK, kRecWords>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl, ra.diag);
 			stamp(1);
 			uint32_t o_p = (o_dy << 16) + o_dx;
 			uint32_t nt = 0;
@@ -535,7 +540,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 			uint32_t vt[1] = { nt }, tt[1];
 			block_excl_add<1, kRecWaves>(vt, tt, s_scan);
 			uint32_t o_t = t_before + vt[0];
-			t_before += tt[0];
+			t_before = uni(t_before + tt[0]);
 			// word j of all threads side by side (one contiguous KiB per wavefront and store): the array's
 			// order is [tile][j][thread], not stream order — k_crack_bin does not care
 			const uint32_t w0 = (tile / 16u) + tid;
@@ -561,7 +566,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 			stamp(2);
 		}
 		// ---- branch matching
-		const uint32_t n_ctl = c.a;
+		const uint32_t n_ctl = uni(c.a);
 		const uint32_t* seg = lt.seg;
 		if (n_ctl + 2u <= lcap) {
 			match_controls_packed<uint16_t, int16_t, BLOCK>(lt, n_ctl, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, rerr, ra.diag);
@@ -586,7 +591,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 		// which is free now) and dealt out again, so that the loop over stretches runs with all lanes busy
 		// instead of once per word for the sake of a few lanes.
 		{
-			const uint32_t valid_segs = s_valid_segs;
+			const uint32_t valid_segs = uni(s_valid_segs);
 			const RecordLists& L = ra.lists;
 			uint4* lists = L.rec + static_cast<uint64_t>(zi) * nstrips * L.cap;
 			const uint4* wsrc = reinterpret_cast<const uint4*>(wout);
@@ -636,11 +641,13 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 				}
 			}
 			__syncthreads();
-			const uint32_t qn = min(*s_qn, queue_cap);
+			stamp(15);
+			const uint32_t qn = uni(min(*s_qn, queue_cap));
 			for (uint32_t i = tid; i < qn; i += BLOCK) word_to_records(queue[i], seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
 		}
 	}
 	__syncthreads();
+	stamp(16);
 	{
 		const RecordLists& L = ra.lists;
 		for (uint32_t k = tid; k < nstrips; k += BLOCK) {

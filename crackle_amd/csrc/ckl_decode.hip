@@ -97,6 +97,8 @@ struct CrackArgs {
 	uint32_t* overflow;          // strip path: its overflow word, cleared here as well (or null)
 };
 
+// a value all lanes of the wavefront hold alike, as a scalar
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 __device__ __forceinline__ uint32_t rd_le_dev(const uint8_t* p, int w) {
 	uint32_t v = 0;
 	for (int i = 0; i < w; i++) v |= static_cast<uint32_t>(p[i]) << (8 * i);
@@ -412,10 +414,12 @@ template <bool COUNT_T, int BLOCK = kCrackBlock, uint32_t WORDS = kCrackWords>
 __device__ __forceinline__ void tile_symbols(
 	const uint32_t* __restrict__ words, uint32_t wshift, uint32_t n_codes, uint32_t span, uint32_t tile, TileCarry& c,
 	WordSyms (&ws)[WORDS], uint32_t& o_a, uint32_t& o_dx, uint32_t& o_dy,
-	uint32_t* s_scan, int32_t* s_scanmax, uint8_t* s_last_move, uint8_t* s_last_ctrl
+	uint32_t* s_scan, int32_t* s_scanmax, uint8_t* s_last_move, uint8_t* s_last_ctrl, unsigned long long* dg = nullptr
 ) {
 	constexpr int NW = BLOCK / kWave;
 	const uint32_t tid = threadIdx.x;
+	unsigned long long dg_t = (kTuning && dg) ? __builtin_amdgcn_s_memtime() : 0ull;
+	auto sub = [&](int slot) { if (kTuning && dg && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(dg + slot, now - dg_t); dg_t = now; } };
 	// `span` positions per thread (a multiple of 16, at most WORDS * 16): a slice with fewer codes
 	// than a full tile spreads them over all threads instead of filling the first ones with eight
 	// words each; a thread's words past its span are empty
@@ -446,8 +450,10 @@ __device__ __forceinline__ void tile_symbols(
 			tsum = mv[j] >> 30;
 		}
 	}
+	sub(10);
 	uint32_t v1[1] = { tsum }, t1[1];
 	block_excl_add<1, NW>(v1, t1, s_scan);
+	sub(11);
 	const uint32_t base_sum = ((c.sum + v1[0]) & 3u) * kLo;
 #pragma unroll
 	for (uint32_t j = 0; j < WORDS; j++) mv[j] = add_fields(mv[j], base_sum);
@@ -473,6 +479,7 @@ __device__ __forceinline__ void tile_symbols(
 	}
 	int32_t lf_tot;
 	int32_t lf_in = block_excl_max<NW>(lf, lf_tot, s_scanmax);
+	sub(12);
 	if (lf_in < c.lf) lf_in = c.lf;
 	// -- ctrl: within a run of reverses, the positions at an odd distance from the last non-reverse
 	uint32_t ctrl[WORDS];
@@ -497,6 +504,7 @@ __device__ __forceinline__ void tile_symbols(
 	__syncthreads();
 	const uint32_t prev_ctrl = tid ? s_last_ctrl[tid - 1] : c.ctrl;
 	const uint32_t tile_last_ctrl = s_last_ctrl[BLOCK - 1];
+	sub(13);
 
 	// -- events: position g emits the symbol of code g-1 unless g-1 was a control half
 	uint32_t n_a = 0, ddx = 0, ddy = 0;
@@ -518,13 +526,15 @@ __device__ __forceinline__ void tile_symbols(
 	}
 	uint32_t v3[3] = { n_a, ddx, ddy }, t3[3];
 	block_excl_add<3, NW>(v3, t3, s_scan);
+	sub(14);
 	o_a = c.a + v3[0]; o_dx = c.dx + v3[1]; o_dy = c.dy + v3[2];
 
-	c.sum = (c.sum + t1[0]) & 3u;
-	c.move = tile_last_move;
-	c.ctrl = tile_last_ctrl;
-	if (lf_tot > c.lf) c.lf = lf_tot;
-	c.a += t3[0]; c.dx += t3[1]; c.dy += t3[2];
+	// (the carries are the same in every lane: scalar registers)
+	c.sum = uni((c.sum + t1[0]) & 3u);
+	c.move = uni(tile_last_move);
+	c.ctrl = uni(tile_last_ctrl);
+	c.lf = static_cast<int32_t>(uni(static_cast<uint32_t>(lf_tot > c.lf ? lf_tot : c.lf)));
+	c.a = uni(c.a + t3[0]); c.dx = uni(c.dx + t3[1]); c.dy = uni(c.dy + t3[2]);
 }
 
 // Rasterises the moves of one thread's 128 positions (crackcodes.hpp:706-862) straight into the
@@ -683,9 +693,15 @@ __device__ __forceinline__ BitMap3 bitmap3_compose(const BitMap3& f, const BitMa
 	const uint32_t f0 = f.e & 3u, f1 = (f.e >> 2) & 3u, f2 = (f.e >> 4) & 3u;
 	BitMap3 r;
 	r.e = ((g.e >> (2u * f0)) & 3u) | (((g.e >> (2u * f1)) & 3u) << 2) | (((g.e >> (2u * f2)) & 3u) << 4);
-	r.c0 = f.c0 + (f0 == 0 ? g.c0 : (f0 == 1 ? g.c1 : g.c2));
-	r.c1 = f.c1 + (f1 == 0 ? g.c0 : (f1 == 1 ? g.c1 : g.c2));
-	r.c2 = f.c2 + (f2 == 0 ? g.c0 : (f2 == 1 ? g.c1 : g.c2));
+	// (picked with masks: written as `f0 == 0 ? g.c0 : ...` hipcc turns the choice between fields into an index into a copy of g
+	// in scratch memory — a store and a dependent load, a trip to memory, per composition of the scans below)
+	auto pick = [&](uint32_t st) -> uint32_t {
+		const uint32_t m1 = 0u - static_cast<uint32_t>(st == 1u), m2 = 0u - static_cast<uint32_t>(st >= 2u);
+		return (g.c0 & ~(m1 | m2)) | (g.c1 & m1) | (g.c2 & m2);
+	};
+	r.c0 = f.c0 + pick(f0);
+	r.c1 = f.c1 + pick(f1);
+	r.c2 = f.c2 + pick(f2);
 	return r;
 }
 constexpr uint32_t kMarkovWarm = 192;      // (64 before round 5: a quarter of C2's chunks then started from a wrong context and 2.1 repair rounds followed; 192: 3 % and 1.4)
@@ -796,7 +812,9 @@ __device__ __forceinline__ void markov_expand_parallel(
 		if (tid == BLOCK - 1) {      // the six bits of the last byte
 			const uint32_t by = (shifted_word(nb_full >> 2) >> (8u * (nb_full & 3u))) & 63u;
 			uint32_t st[3] = { st0, st1, st2 }, nn[3] = { n0, n1, n2 };
-			for (uint32_t q = 0; q < 3u; q++) {
+#pragma unroll
+			for (uint32_t q = 0; q < 3u; q++) {      // (unrolled: st[q] under a run-time q is an array in scratch memory)
+#pragma unroll
 				for (uint32_t i = 0; i < 6u; i++) {
 					const uint32_t b = (by >> i) & 1u;
 					if (st[q] == 2u) { nn[q]++; st[q] = 0u; }
@@ -2832,12 +2850,12 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 				d.rec_cap = cap;
 				d.d_rec.ensure(nst * cap);
 				d.d_rec_count.ensure(nst);
-				// words of 16 code positions: k_crack_match deals a slice's codes out in tiles of kRecBlock x <= 8 words
+				// words of 16 code positions: k_crack_match deals a slice's codes out in tiles of rec_block x <= rec_words(rec_block) words
 				std::vector<uint64_t> word_off(d.nslices);
 				uint64_t wtot = 0;
 				d.max_words = 0;
 				for (uint32_t zi = 0; zi < d.nslices; zi++) {
-					const uint32_t nw = (ccap[zi] / rec_tile(d.rec_block) + 1u) * static_cast<uint32_t>(d.rec_block) * kRecWords;
+					const uint32_t nw = (ccap[zi] / rec_tile(d.rec_block) + 1u) * static_cast<uint32_t>(d.rec_block) * rec_words(d.rec_block);
 					word_off[zi] = wtot; wtot += nw;
 					d.max_words = std::max(d.max_words, nw);
 				}
@@ -3254,6 +3272,8 @@ void launch_crack_records(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t 
 		CKL_HIP(hipStreamSynchronize(s));
 		fprintf(stderr, "[ckl crack diag, mean cycles per slice] k_crack_match: boc=%.0f symbols=%.0f record=%.0f match=%.0f (depth=%.0f tree=%.0f links=%.0f jump=%.0f seg=%.0f) records=%.0f\n",
 			hd[0] / double(n), hd[1] / double(n), hd[2] / double(n), hd[3] / double(n), hd[4] / double(n), hd[5] / double(n), hd[6] / double(n), hd[7] / double(n), hd[8] / double(n), hd[9] / double(n));
+		fprintf(stderr, "[ckl crack diag] tile_symbols: load+sums=%.0f scan1=%.0f r+lfscan=%.0f ctrl=%.0f events+scan3=%.0f | records: direct=%.0f queued=%.0f counts=%.0f\n",
+			hd[10] / double(n), hd[11] / double(n), hd[12] / double(n), hd[13] / double(n), hd[14] / double(n), hd[15] / double(n), hd[16] / double(n), hd[9] / double(n));
 	}
 }
 
