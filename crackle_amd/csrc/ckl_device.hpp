@@ -67,6 +67,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // Exclusive block scan (sum) of K values per thread at once.  `lds` must hold
 // K * NW uint32 (NW = wavefronts per workgroup).  Returns exclusive prefixes in v[], block totals in total[].
 // Ends with a barrier so `lds` can be reused immediately.
+// Workgroups of eight and sixteen wavefronts combine the wavefronts' totals with a second DPP scan over lanes 0 .. NW - 1
+// (one LDS read per value and thread; reading all NW totals into registers was 48 live registers for K = 3, NW = 16: the
+// 1 024-thread k_crack_match spilled over it).
 template <int K, int NW = kWaves>
 __device__ __forceinline__ void block_excl_add(uint32_t (&v)[K], uint32_t (&total)[K], uint32_t* lds) {
 	const int lane = threadIdx.x & (kWave - 1);
@@ -78,17 +81,34 @@ __device__ __forceinline__ void block_excl_add(uint32_t (&v)[K], uint32_t (&tota
 		if (lane == kWave - 1) lds[k * NW + wave] = incl[k];
 	}
 	__syncthreads();
+	if constexpr (NW >= 8 && NW <= 16) {
+		const int wsel = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-	for (int k = 0; k < K; k++) {
-		uint32_t base = 0, tot = 0;
-#pragma unroll
-		for (int w = 0; w < NW; w++) {
-			uint32_t s = lds[k * NW + w];
-			if (w < wave) base += s;
-			tot += s;
+		for (int k = 0; k < K; k++) {
+			uint32_t t = lds[k * NW + (lane & (NW - 1))];      // (lanes NW .. 63 repeat the pattern: rows of 16 lanes scan on their own)
+			t += dpp_u32<kDppRowShr + 1, 0xF>(0u, t);
+			t += dpp_u32<kDppRowShr + 2, 0xF>(0u, t);
+			t += dpp_u32<kDppRowShr + 4, 0xF>(0u, t);
+			if constexpr (NW == 16) t += dpp_u32<kDppRowShr + 8, 0xF>(0u, t);
+			const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(t), NW - 1));
+			const uint32_t base = wsel ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(t), wsel - 1)) : 0u;
+			v[k] = base + incl[k] - v[k];
+			total[k] = tot;
 		}
-		v[k] = base + incl[k] - v[k];
-		total[k] = tot;
+	}
+	else {
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			uint32_t base = 0, tot = 0;
+#pragma unroll
+			for (int w = 0; w < NW; w++) {
+				uint32_t s = lds[k * NW + w];
+				if (w < wave) base += s;
+				tot += s;
+			}
+			v[k] = base + incl[k] - v[k];
+			total[k] = tot;
+		}
 	}
 	__syncthreads();
 }
@@ -103,11 +123,25 @@ __device__ __forceinline__ int32_t block_excl_max(int32_t v, int32_t& total, int
 	const int32_t excl = static_cast<int32_t>(wave_shift_up1(static_cast<uint32_t>(incl), 0x80000000u));      // lane 0: INT32_MIN
 	__syncthreads();
 	int32_t base = INT32_MIN, tot = INT32_MIN;
+	if constexpr (NW >= 8 && NW <= 16) {      // (as in block_excl_add)
+		auto mx = [](int32_t a, uint32_t b) { const int32_t c = static_cast<int32_t>(b); return c > a ? c : a; };
+		constexpr uint32_t id = 0x80000000u;
+		const int wsel = __builtin_amdgcn_readfirstlane(wave);
+		int32_t t = lds[lane & (NW - 1)];
+		t = mx(t, dpp_u32<kDppRowShr + 1, 0xF>(id, static_cast<uint32_t>(t)));
+		t = mx(t, dpp_u32<kDppRowShr + 2, 0xF>(id, static_cast<uint32_t>(t)));
+		t = mx(t, dpp_u32<kDppRowShr + 4, 0xF>(id, static_cast<uint32_t>(t)));
+		if constexpr (NW == 16) t = mx(t, dpp_u32<kDppRowShr + 8, 0xF>(id, static_cast<uint32_t>(t)));
+		tot = __builtin_amdgcn_readlane(t, NW - 1);
+		if (wsel) base = __builtin_amdgcn_readlane(t, wsel - 1);
+	}
+	else {
 #pragma unroll
-	for (int w = 0; w < NW; w++) {
-		int32_t s = lds[w];
-		if (w < wave) base = s > base ? s : base;
-		tot = s > tot ? s : tot;
+		for (int w = 0; w < NW; w++) {
+			int32_t s = lds[w];
+			if (w < wave) base = s > base ? s : base;
+			tot = s > tot ? s : tot;
+		}
 	}
 	total = tot;
 	__syncthreads();
