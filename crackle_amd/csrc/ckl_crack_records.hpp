@@ -30,10 +30,10 @@
 
 constexpr int kRecBlock = 512;                    // threads per slice (two workgroups per CU); kRecBlockWide when a decode has no more slices than the chip has CUs
 constexpr int kRecBlockWide = 1024;               // a slice alone on its CU: twice the threads, half the tiles and half the work per thread in every phase
-// words of 16 code positions per thread and tile: with eight of them the 512-thread kernel spilled twelve of a tile's symbol words and — what cost
-// more — threadIdx.x and the wavefront's scan slot, which it then fetched back from scratch memory in front of most barriers; with six it keeps
-// everything in its 128 registers (a slice of C2 takes three tiles either way: its share is 96 positions per thread)
-constexpr uint32_t rec_words(int block) { return block == kRecBlock ? 6u : 8u; }
+// words of 16 code positions per thread and tile.  (Round 5: with the block scans reading all wavefront totals into registers the
+// 512-thread kernel spilled at eight words — threadIdx.x and the wavefront's scan slot among others, fetched back from scratch memory
+// in front of most barriers: 0.120 ms at C2; six words without spills 0.102; eight words with the DPP block scans, no spills: 0.098.)
+constexpr uint32_t rec_words(int /*block*/) { return 8u; }
 constexpr uint32_t rec_tile(int block) { return static_cast<uint32_t>(block) * rec_words(block) * 16u; }      // code positions per tile
 constexpr uint32_t kRecMaxStrips = 512;           // strips per slice the LDS cursors cover
 constexpr uint32_t kRecMaxDim = 65534;            // packed vertices: 16 bits per coordinate
@@ -67,10 +67,10 @@ template <typename IDX, typename DEP, int BLOCK>
 __device__ __forceinline__ void match_controls_packed(
 	const CtlTablesP<IDX, DEP>& t, uint32_t N, const uint32_t* nodes, uint32_t n_nodes, uint32_t sxe, uint32_t sx, uint32_t sy,
 	uint32_t* s_scan, int32_t* s_scanmax, uint32_t* s_first_dead, uint32_t* s_valid_segs, uint32_t* s_loff, uint32_t* s_lcnt, uint32_t& rerr,
-	unsigned long long* dg = nullptr
+	unsigned long long* dg = nullptr, uint32_t* wl = nullptr, uint32_t wl_cap = 0, uint32_t* s_wn = nullptr      // work list of the searches (LDS tables only) and its counter
 ) {
 	unsigned long long dg_t = (kTuning && dg) ? __builtin_amdgcn_s_memtime() : 0ull;
-	auto sub = [&](int slot) { if (kTuning && dg && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(dg + slot, now - dg_t); dg_t = now; } };
+	auto sub = [&](int slot) { if (kTuning && dg && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); dg[slot] += now - dg_t; dg_t = now; } };
 	constexpr int NW = BLOCK / kWave;
 	constexpr IDX NONE = static_cast<IDX>(~static_cast<IDX>(0));
 	const uint32_t tid = threadIdx.x;
@@ -121,6 +121,7 @@ __device__ __forceinline__ void match_controls_packed(
 			off += (c + 7u) & ~7u;
 		}
 		s_lcnt[l + 1u] = 0;      // end marker
+		if (s_wn) *s_wn = 0u;
 	}
 	__syncthreads();
 	for (uint32_t l = 1; s_lcnt[l] != 0; l++) {
@@ -138,29 +139,66 @@ __device__ __forceinline__ void match_controls_packed(
 	// ---- links.  A 't' on the empty stack ends its chain: the next chain starts at the next node of the
 	// BOC index; past the last node the trailing pad codes begin (first_dead).  A 't' that pops returns
 	// to its 'b': the symbol after the previous symbol of smaller depth.
+	// Most 't's return to a 'b' a few symbols back, inside the thread's own stretch: `open` keeps the thread's last 64
+	// symbols, bit h set = symbol i - 1 - h is a 'b' nobody has returned to yet, so the stack's top is its lowest bit.  Only a
+	// 't' that finds the window empty searches the tree, and from the window's far end on (all symbols inside lie deeper).
+	// Those searches (C2: 860 of a slice's 1 570 returns, four steps on average, nine at worst) are not made where they
+	// turn up — a wavefront would walk the longest search of its lanes in every one of its rounds, nine times the steps its
+	// lanes need — but listed and dealt out evenly afterwards.
+	auto link_to = [&](uint32_t i, uint32_t j) {      // the 't' at i returns to the 'b' at j
+		uint32_t val, ptr = kLinkNone;
+		const uint32_t pos_j = t.pos[j];
+		const IDX tp = t.lastT[j];
+		if (tp == NONE) val = pack_vertex(nodes[0], sxe) + pos_j;
+		else { val = pos_j - t.pos[tp]; ptr = static_cast<uint32_t>(tp); }
+		t.link[i] = (static_cast<unsigned long long>(ptr) << 32) | val;
+	};
+	auto search = [&](uint32_t i, uint32_t own0, int32_t before) -> uint32_t {      // own0: where the stretch of i's thread begins
+		const uint32_t known = min(64u, i - own0);
+		uint32_t steps = 0;
+		const uint32_t j = static_cast<uint32_t>(prev_smaller<DEP>(t.depth, t.gmin, s_loff, s_lcnt, static_cast<int32_t>(i - known), before, (kTuning && dg) ? &steps : nullptr) + 1);
+		if (kTuning && dg) { atomicAdd(dg + 17, 1ull); atomicAdd(dg + 18, static_cast<unsigned long long>(steps)); }
+		return j;
+	};
 	{
 		int32_t sr = S0, m = M0;
 		uint32_t c = C0;
+		unsigned long long open = 0;
 		for (uint32_t i = i0; i < i1; i++) {
 			const bool isT = t.kind[i] == SYM_T;
 			const int32_t before = sr - m;
 			sr += isT ? -1 : 1;
 			m = sr < m ? sr : m;
-			if (!isT) continue;
-			uint32_t val = 0, ptr = kLinkNone;
+			if (!isT) { open = (open << 1) | 1ull; continue; }
 			if (before == 0) {
+				uint32_t val = 0;
 				c++;
 				if (c >= n_nodes) atomicMin(s_first_dead, i);
 				else val = pack_vertex(nodes[c], sxe);
+				t.link[i] = (static_cast<unsigned long long>(kLinkNone) << 32) | val;
+				if (kTuning && dg) atomicAdd(dg + 20, 1ull);
+			}
+			else if (open) {
+				link_to(i, i - 1u - static_cast<uint32_t>(__builtin_ctzll(open)));
+				open &= open - 1ull;
+				if (kTuning && dg) atomicAdd(dg + 19, 1ull);
 			}
 			else {
-				const uint32_t j = static_cast<uint32_t>(prev_smaller<DEP>(t.depth, t.gmin, s_loff, s_lcnt, static_cast<int32_t>(i), before) + 1);
-				const uint32_t pos_j = t.pos[j];
-				const IDX tp = t.lastT[j];
-				if (tp == NONE) val = pack_vertex(nodes[0], sxe) + pos_j;
-				else { val = pos_j - t.pos[tp]; ptr = static_cast<uint32_t>(tp); }
+				uint32_t at = wl_cap;
+				if (wl) at = atomicAdd(s_wn, 1u);
+				if (at < wl_cap) wl[at] = i | (static_cast<uint32_t>(before) << 16);
+				else link_to(i, search(i, i0, before));
 			}
-			t.link[i] = (static_cast<unsigned long long>(ptr) << 32) | val;
+			open <<= 1;
+		}
+	}
+	if (wl) {
+		__syncthreads();
+		const uint32_t n_wl = uni(min(*s_wn, wl_cap));
+		for (uint32_t k = tid; k < n_wl; k += BLOCK) {
+			const uint32_t item = wl[k];
+			const uint32_t i = item & 0xFFFFu;
+			link_to(i, search(i, i / per * per, static_cast<int32_t>(item >> 16)));
 		}
 	}
 	__syncthreads();
@@ -379,8 +417,13 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 	__shared__ uint32_t s_mk_parallel, s_mk_total, s_index_end;
 	__shared__ uint32_t s_cursor[kRecMaxStrips];      // lengths of the slice's record lists
 
-	unsigned long long d_t = (kTuning && ra.diag) ? __builtin_amdgcn_s_memtime() : 0ull;
-	auto stamp = [&](int slot) { if (kTuning && ra.diag && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(ra.diag + slot, now - d_t); d_t = now; } };
+	// tuning builds: cycle stamps of thread 0, summed per workgroup in LDS and added to the launch's counters at the end
+	// (512 workgroups adding to the same words after every phase waited for each other's atomics and distorted what they measured)
+	__shared__ unsigned long long s_dg[kTuning ? 32 : 1];
+	unsigned long long* const dgp = (kTuning && ra.diag) ? s_dg : nullptr;
+	if (kTuning && dgp) { if (threadIdx.x < 32) s_dg[threadIdx.x] = 0ull; __syncthreads(); }
+	unsigned long long d_t = (kTuning && dgp) ? __builtin_amdgcn_s_memtime() : 0ull;
+	auto stamp = [&](int slot) { if (kTuning && dgp && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); s_dg[slot] += now - d_t; d_t = now; } };
 	const CrackArgs& a = ra.c;
 	const uint32_t zi = blockIdx.x + a.zbase;
 	const uint32_t tid = threadIdx.x;
@@ -531,7 +574,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 		for (uint32_t tile = 0; tile <= n_codes; tile += tile_step) {
 			WordSyms ws[kRecWords];
 			uint32_t o_a, o_dx, o_dy;
-			tile_symbols<false, BLOCK, kRecWords>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl, ra.diag);
+			tile_symbols<false, BLOCK, kRecWords>(words, wshift, n_codes, span, tile, c, ws, o_a, o_dx, o_dy, s_scan, s_scanmax, s_last_move, s_last_ctrl, dgp);
 			stamp(1);
 			uint32_t o_p = (o_dy << 16) + o_dx;
 			uint32_t nt = 0;
@@ -569,7 +612,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 		const uint32_t n_ctl = uni(c.a);
 		const uint32_t* seg = lt.seg;
 		if (n_ctl + 2u <= lcap) {
-			match_controls_packed<uint16_t, int16_t, BLOCK>(lt, n_ctl, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, rerr, ra.diag);
+			match_controls_packed<uint16_t, int16_t, BLOCK>(lt, n_ctl, nodes, n_nodes, sxe, sx, sy, s_scan, s_scanmax, &s_first_dead, &s_valid_segs, s_loff, s_lcnt, rerr, dgp,
+				reinterpret_cast<uint32_t*>(lt.link + n_ctl), (lcap - n_ctl) * 2u, &s_mk_total);      // (the link table's unused end holds the list of searches)
 		}
 		else {
 			// more control symbols than the LDS tables hold: the first of them were recorded in LDS
@@ -668,5 +712,6 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 		}
 	}
 	if (ra.fused_ctl && blockIdx.x == 0) for (uint32_t w = tid; w < ra.fused_ctl_words; w += BLOCK) ra.fused_ctl[w] = 0u;      // ticket counters, timeout
+	if (kTuning && dgp && tid < 32 && s_dg[tid]) atomicAdd(ra.diag + tid, s_dg[tid]);
 }
 

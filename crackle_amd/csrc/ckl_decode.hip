@@ -419,7 +419,7 @@ __device__ __forceinline__ void tile_symbols(
 	constexpr int NW = BLOCK / kWave;
 	const uint32_t tid = threadIdx.x;
 	unsigned long long dg_t = (kTuning && dg) ? __builtin_amdgcn_s_memtime() : 0ull;
-	auto sub = [&](int slot) { if (kTuning && dg && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(dg + slot, now - dg_t); dg_t = now; } };
+	auto sub = [&](int slot) { if (kTuning && dg && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); dg[slot] += now - dg_t; dg_t = now; } };
 	// `span` positions per thread (a multiple of 16, at most WORDS * 16): a slice with fewer codes
 	// than a full tile spreads them over all threads instead of filling the first ones with eight
 	// words each; a thread's words past its span are empty
@@ -3274,6 +3274,7 @@ void launch_crack_records(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t 
 			hd[0] / double(n), hd[1] / double(n), hd[2] / double(n), hd[3] / double(n), hd[4] / double(n), hd[5] / double(n), hd[6] / double(n), hd[7] / double(n), hd[8] / double(n), hd[9] / double(n));
 		fprintf(stderr, "[ckl crack diag] tile_symbols: load+sums=%.0f scan1=%.0f r+lfscan=%.0f ctrl=%.0f events+scan3=%.0f | records: direct=%.0f queued=%.0f counts=%.0f\n",
 			hd[10] / double(n), hd[11] / double(n), hd[12] / double(n), hd[13] / double(n), hd[14] / double(n), hd[15] / double(n), hd[16] / double(n), hd[9] / double(n));
+		fprintf(stderr, "[ckl crack diag] links per slice: local pops=%.0f searches=%.0f (steps %.0f) chain ends=%.0f\n", hd[19] / double(n), hd[17] / double(n), hd[18] / double(n), hd[20] / double(n));
 	}
 }
 
