@@ -257,6 +257,7 @@ struct RecArgs {
 	uint32_t* fused_ctl;         // k_strip_fused's words (fused_ctl_words of ticket counters and timeout, arrive[fused_n], ready[fused_n]): zeroed here, or null
 	uint32_t fused_n, fused_ctl_words;
 	unsigned long long* diag;    // tuning builds: cycle stamps, summed over the slices
+	uint32_t ablate;             // tuning builds (CKL_ABLATE, results wrong): 0x400000 no parked-word stores, 0x800000 the parked words are loaded and dropped, 0x1000000 they are not loaded
 };
 
 // the seldom-taken parts of k_crack_match (as functions of their own, not inlined, they made the kernel
@@ -601,7 +602,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 					else if (o_a + 2u < kcap) { a.g_kind[kb + o_a] = static_cast<uint8_t>(kind); a.g_dx[kb + o_a] = cp; }
 					o_a++;
 				}
-				if (j < words_per) *reinterpret_cast<uint4*>(wout + w0 + j * BLOCK) = make_uint4(w.prevs, w.ms | (w.isT << 1), o_p, o_t);
+				if (j < words_per && !(kTuning && (ra.ablate & 0x400000u))) *reinterpret_cast<uint4*>(wout + w0 + j * BLOCK) = make_uint4(w.prevs, w.ms | (w.isT << 1), o_p, o_t);
 				o_t += __popc(w.isT);
 				o_p += __popc(mR) - __popc(mL) + ((__popc(mD) - __popc(mU)) << 16);
 			}
@@ -655,30 +656,49 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 #pragma unroll
 				for (uint32_t q = 0; q < kBatch; q++) {
 					const uint32_t w = w0 + q * BLOCK + tid;
+					if (kTuning && (ra.ablate & 0x1000000u)) { wr[q] = make_uint4(0u, 0u, 0u, 0u); continue; }
 					wr[q] = load_word(w < n_words ? w : 0u);
 					if (w >= n_words) wr[q].y = 0u;
+					if (kTuning && (ra.ablate & 0x800000u)) wr[q].y = 0u;
 				}
+				// The batch's words side by side, step by step — segment offset (LDS), start vertex and strips, a slot from the
+				// strip's cursor (LDS atomic), the store: done word by word, each behind its own branches, a thread went
+				// through these latencies once per word, ~1 000 cycles each.
+				uint32_t off[kBatch];
+				bool dir[kBatch];
 #pragma unroll
 				for (uint32_t q = 0; q < kBatch; q++) {
 					const uint32_t flags = wr[q].y;
-					if (flags == 0u) continue;
-					if (flags & 0xAAAAAAAAu) {      // a 't' in the word: later, with its like
-						const uint32_t at = atomicAdd(s_qn, 1u);
-						if (at < queue_cap) queue[at] = wr[q];
-						else word_to_records(wr[q], seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
-						continue;
-					}
-					// one stretch, one record
-					const uint32_t o_t = wr[q].w;
-					if (o_t >= valid_segs) continue;
-					const uint32_t prevs = wr[q].x, ms = flags;
-					const uint32_t start = seg[o_t] + wr[q].z;
+					dir[q] = flags != 0u && (flags & 0xAAAAAAAAu) == 0u && wr[q].w < valid_segs;      // one stretch, one record
+					off[q] = dir[q] ? seg[wr[q].w] : 0u;
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < kBatch; q++) {
+					if ((wr[q].y & 0xAAAAAAAAu) == 0u) continue;      // a 't' in the word: later, with its like
+					const uint32_t at = atomicAdd(s_qn, 1u);
+					if (at < queue_cap) queue[at] = wr[q];
+					else word_to_records(wr[q], seg, valid_segs, L, lists, s_cursor, sx, sy, rerr);
+				}
+				uint32_t k0[kBatch], k1[kBatch], at0[kBatch];
+#pragma unroll
+				for (uint32_t q = 0; q < kBatch; q++) {
+					const uint32_t prevs = wr[q].x, ms = wr[q].y;
+					const uint32_t start = off[q] + wr[q].z;
+					wr[q].z = start;
 					const uint32_t y = start >> 16, x = start & 0xFFFFu;
-					if (x > sx || y > sy || !stretch_in_grid(start, prevs, ms, sx, sy)) { rerr |= ERR_RANGE; continue; }
+					if (dir[q] && (x > sx || y > sy || !stretch_in_grid(start, prevs, ms, sx, sy))) { rerr |= ERR_RANGE; dir[q] = false; }
 					const uint32_t nu = __popc(ms & ~(prevs >> 1) & ~prevs), nd = __popc(ms & (prevs >> 1) & ~prevs);
-					const uint32_t k0 = L.strip_of(y > nu ? y - nu : 0u), k1 = min(L.strip_of(min(y + nd, sy)), nstrips - 1u);
-					const uint4 rec = make_uint4(start, prevs, ms, 0u);
-					for (uint32_t k = k0; k <= k1; k++) {
+					k0[q] = L.strip_of(min(y > nu ? y - nu : 0u, sy));
+					k1[q] = min(L.strip_of(min(y + nd, sy)), nstrips - 1u);
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < kBatch; q++) at0[q] = dir[q] ? atomicAdd(&s_cursor[k0[q]], 1u) : L.cap;
+#pragma unroll
+				for (uint32_t q = 0; q < kBatch; q++) {
+					if (!dir[q]) continue;
+					const uint4 rec = make_uint4(wr[q].z, wr[q].x, wr[q].y, 0u);
+					if (at0[q] < L.cap) lists[static_cast<uint64_t>(k0[q]) * L.cap + at0[q]] = rec;
+					for (uint32_t k = k0[q] + 1u; k <= k1[q]; k++) {
 						const uint32_t at = atomicAdd(&s_cursor[k], 1u);
 						if (at < L.cap) lists[static_cast<uint64_t>(k) * L.cap + at] = rec;
 					}

@@ -3241,6 +3241,7 @@ RecordLists record_lists(ckl_decoder& d) {
 	rl.nstrips = d.nstrips; rl.strip_rows = d.strip_rows;
 	rl.strip_shift = 0xFFFFFFFFu;
 	for (uint32_t b = 0; b < 32; b++) if ((1u << b) == d.strip_rows) rl.strip_shift = b;
+	rl.strip_magic = static_cast<uint32_t>((1ull << 32) / std::max<uint32_t>(2u, d.strip_rows)) + 1u;      // (rows = 1 is a power of two: the shift)
 	return rl;
 }
 
@@ -3258,6 +3259,8 @@ void launch_crack_records(ckl_decoder& d, hipStream_t s, CrackArgs ca, uint32_t 
 	ra.fused_n = d.nslices;
 	ra.fused_ctl_words = kFusedCtlWords;
 	ra.diag = nullptr;
+	ra.ablate = 0;
+	if (kTuning) if (const char* env = getenv("CKL_ABLATE")) ra.ablate = static_cast<uint32_t>(strtoul(env, nullptr, 0));
 	if (kTuning && getenv("CKL_CRACK_DIAG")) {
 		d.d_diag.ensure(64);
 		CKL_HIP(hipMemsetAsync(d.d_diag.p + 32, 0, 32 * sizeof(unsigned long long), s));

@@ -123,7 +123,9 @@ struct RecordLists {
 	uint32_t cap;                // records per list
 	uint32_t nstrips, strip_rows;
 	uint32_t strip_shift;        // log2(strip_rows) when it is a power of two, else 0xFFFFFFFF
-	__device__ __forceinline__ uint32_t strip_of(uint32_t y) const { return strip_shift != 0xFFFFFFFFu ? y >> strip_shift : y / strip_rows; }
+	uint32_t strip_magic;        // floor(2^32 / strip_rows) + 1: y / strip_rows = high word of y * magic for y < 65536 (the error term y * (magic * rows - 2^32) stays below 2^32)
+	// (two of these per record: as a division by a run-time number it was ~20 instructions each, a tenth of k_crack_match's vector work)
+	__device__ __forceinline__ uint32_t strip_of(uint32_t y) const { return strip_shift != 0xFFFFFFFFu ? y >> strip_shift : __umulhi(y, strip_magic); }
 };
 
 // Walks one record — x: the vertex before its first move, packed y << 16 | x; y: the 16 moves of its
