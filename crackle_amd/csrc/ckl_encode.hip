@@ -1455,13 +1455,13 @@ void graph_pass(ckl_encoder& e, int64_t sx, int64_t sy, int64_t sz, int perm_mod
 	hipStream_t s = e.stream;
 	const uint32_t ns = static_cast<uint32_t>(sz);
 	e.tiles_x = static_cast<uint32_t>((sx + 1 + kTrailTileDim - 1) / kTrailTileDim);
-	e.tiles_y = static_cast<uint32_t>((sy + 1 + kTrailTileDim - 1) / kTrailTileDim);
+	e.tiles_y = static_cast<uint32_t>((sy + 1 + 7) / 8);      // rows of 32 x 8 pieces
 	// micro-tiles of 8 x 8 vertices, 32 bytes (2 uint4) each, 2 x 2 of them per 128-byte line
 	const uint32_t mtx = static_cast<uint32_t>((sx + 1 + 7) / 8), mty = static_cast<uint32_t>((sy + 1 + 7) / 8);
 	e.mtx2 = (mtx + 1) / 2;
 	e.adjm_stride = static_cast<uint64_t>(e.mtx2) * ((mty + 1) / 2) * 4 * 2;      // uint4 per slice
 	e.d_adjm.ensure(e.adjm_stride * ns);
-	e.graph_blocks = (e.tiles_x * e.tiles_y + kGraphTiles - 1) / kGraphTiles;
+	e.graph_blocks = (e.tiles_x * e.tiles_y + kBlock - 1) / kBlock;
 	e.t_blk_special.ensure(static_cast<size_t>(e.graph_blocks) * ns);
 	e.t_blk_corner.ensure(static_cast<size_t>(e.graph_blocks) * ns);
 	e.d_count_vh.ensure(4 * static_cast<size_t>(ns));

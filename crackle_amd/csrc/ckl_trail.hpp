@@ -41,7 +41,7 @@ namespace dev {
 // of the row.  Four micro-tiles (2 x 2) share one 128-byte line.  A walking lane keeps the
 // micro-tile it is in in registers and only goes to memory when it leaves it: the walks are
 // bound by cache-line traffic, not arithmetic, and this serves ~6 steps per fetch.
-constexpr uint32_t kTrailTileShift = 5, kTrailTileDim = 32;        // thread mapping of k_trail_graph / k_trail_nodes: one thread per 32-vertex row piece
+constexpr uint32_t kTrailTileShift = 5, kTrailTileDim = 32;        // thread mapping of k_trail_graph / k_trail_nodes: one thread per piece of 32 x 8 vertices
 __device__ __forceinline__ uint32_t mt_index(uint32_t mx, uint32_t my, uint32_t mtx2) {
 	return (((my >> 1) * mtx2 + (mx >> 1)) << 2) | ((my & 1u) << 1) | (mx & 1u);
 }
@@ -66,7 +66,7 @@ struct TrailArgs {
 	const uint4* adjm;           // micro-tiles (2 x uint4 each), see mt_index
 	uint64_t adjm_stride;        // uint4 per slice
 	uint32_t mtx2;               // micro-tile column pairs per row
-	uint32_t tiles_x, tiles_y;   // 32 x 32 vertex tiles: thread mapping of k_trail_graph / k_trail_nodes
+	uint32_t tiles_x, tiles_y;   // pieces of 32 x 8 vertices per row of pieces / rows of pieces: thread mapping of k_trail_graph / k_trail_nodes
 	const uint32_t* planeV;      // crack planes (k_trail_nodes recomputes the vertex nibbles from them)
 	const uint32_t* planeH;
 	uint32_t row_words;
@@ -198,9 +198,51 @@ __device__ __forceinline__ uint32_t spread8(uint32_t m) {
 	return x;
 }
 
-constexpr uint32_t kGraphTiles = kBlock / kTrailTileDim;     // 32 x 32 vertex tiles per workgroup
+// The edge bits of the eight vertex rows y0 .. y0 + 7 (y0 a multiple of 8) of the 32 vertices x = 32 tx + i: what
+// trail_row_bits gives row by row, with all 25 plane words requested up front — from addresses clamped into the slice, the
+// words masked afterwards (a load behind a test of its own is waited for there).  Rows past sy come out empty.
+__device__ __forceinline__ void trail_rows8(
+	const uint32_t* __restrict__ pv, const uint32_t* __restrict__ ph, uint32_t row_words,
+	uint32_t sx, uint32_t sy, uint32_t tx, uint32_t y0, uint32_t inv, TileRowBits (&b)[8]
+) {
+#pragma unroll
+	for (int k = 0; k < 8; k++) b[k] = TileRowBits{ 0, 0, 0, 0 };
+	if (row_words == 0 || sy == 0) return;
+	const uint32_t x0 = tx << 5;
+	const uint32_t lt_sx = x0 >= sx ? 0u : (sx - x0 >= 32u ? 0xFFFFFFFFu : ((1u << (sx - x0)) - 1u));        // x < sx
+	const uint32_t le_sx = x0 > sx ? 0u : (sx - x0 >= 31u ? 0xFFFFFFFFu : ((2u << (sx - x0)) - 1u));        // x <= sx
+	const uint32_t ge_1 = tx == 0 ? 0xFFFFFFFEu : 0xFFFFFFFFu;                                                // x >= 1
+	const bool have_w = tx < row_words;
+	const uint32_t txc = have_w ? tx : row_words - 1u, txp = tx > 0 ? min(tx - 1u, row_words - 1u) : 0u;
+	uint32_t hw[8], hpw[8], vw[9];
+#pragma unroll
+	for (uint32_t k = 0; k < 8; k++) {
+		const uint64_t row = static_cast<uint64_t>(min(y0 + k, sy - 1u)) * row_words;
+		hw[k] = ph[row + txc];
+		hpw[k] = ph[row + txp];
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < 9; k++) {      // plane V rows y0 - 1 .. y0 + 7
+		const uint32_t y = y0 + k;           // (row + 1)
+		vw[k] = pv[static_cast<uint64_t>(min(y > 0 ? y - 1u : 0u, sy - 1u)) * row_words + txc];
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < 8; k++) {
+		const uint32_t y = y0 + k;
+		const uint32_t h = have_w ? hw[k] : 0u, hp = tx > 0 ? hpw[k] : 0u;
+		if (y >= 1 && y < sy) {
+			b[k].R = (h ^ inv) & lt_sx;
+			b[k].L = (((h << 1) | (hp >> 31)) ^ inv) & ge_1 & le_sx;
+		}
+		if (y < sy) b[k].D = ((have_w ? vw[k + 1] : 0u) ^ inv) & ge_1 & lt_sx;
+		if (y >= 1 && y <= sy) b[k].U = ((have_w ? vw[k] : 0u) ^ inv) & ge_1 & lt_sx;
+	}
+}
 
-// grid = (graph_blocks, nslices)
+// grid = (graph_blocks, nslices).  One thread per piece of 32 x 8 vertices = one row of four micro-tiles, the pieces of a
+// slice numbered row by row (tiles_x per row of pieces, tiles_y = rows of pieces): neighbouring lanes read neighbouring
+// plane words, and a thread writes whole micro-tiles (2 x 16 bytes each).  (Until round 5: one thread per 32 x 1 vertices,
+// four loads, four 4-byte stores — 70 000 workgroups of C2 that lived for one trip to memory each: 0.18 ms for 0.4 GB.)
 static __global__ void __launch_bounds__(kBlock) k_trail_graph(
 	const uint32_t* __restrict__ planeV, const uint32_t* __restrict__ planeH, uint32_t row_words, uint64_t plane_words,
 	uint32_t sx, uint32_t sy, uint32_t perm_mode, const unsigned long long* __restrict__ total_pairs, unsigned long long half_voxels,
@@ -211,32 +253,29 @@ static __global__ void __launch_bounds__(kBlock) k_trail_graph(
 	const uint32_t zi = blockIdx.y;
 	// perm_mode 2: the crack format follows from the volume's equal pixel pairs (crackle.hpp:50-55), counted by the kernels in front
 	const bool permissible = perm_mode == 2u ? static_cast<long long>(*total_pairs) < static_cast<long long>(half_voxels) : perm_mode != 0u;
-	// thread -> (tile of the workgroup, row of the tile): neighbouring lanes take the SAME row of
-	// neighbouring tiles, so that a wavefront's plane loads are 8 stretches of 32 bytes instead of
-	// 64 different lines (the tiles of a workgroup lie side by side)
-	const uint32_t tile = blockIdx.x * kGraphTiles + (threadIdx.x & (kGraphTiles - 1u));
-	const uint32_t r = threadIdx.x / kGraphTiles;
-	const uint32_t mtx = (sx + 1u + 7u) >> 3, mty = (sy + 1u + 7u) >> 3;
+	const uint32_t item = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t mtx = (sx + 1u + 7u) >> 3;
 	uint32_t ns = 0, nc = 0;
-	if (tile < tiles_x * tiles_y) {
-		const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-		const uint32_t y = (ty << kTrailTileShift) + r;
-		TileRowBits b = { 0, 0, 0, 0 };
-		if (y <= sy) b = trail_row_bits(planeV + zi * plane_words, planeH + zi * plane_words, row_words, sx, sy, tx, y, permissible ? 0xFFFFFFFFu : 0u);
+	if (item < tiles_x * tiles_y) {
+		const uint32_t ty = item / tiles_x, tx = item - ty * tiles_x;
+		TileRowBits b[8];
+		trail_rows8(planeV + zi * plane_words, planeH + zi * plane_words, row_words, sx, sy, tx, ty << 3, permissible ? 0xFFFFFFFFu : 0u, b);
 		uint32_t* dst = adjm_words + zi * adjm_stride_words;
-		const uint32_t my = y >> 3;
-		if (my < mty) {
 #pragma unroll
-			for (uint32_t q = 0; q < 4; q++) {
-				const uint32_t mx = tx * 4u + q;
-				if (mx >= mtx) break;
-				const uint32_t w = spread8((b.R >> (8 * q)) & 255u) | (spread8((b.L >> (8 * q)) & 255u) << 1)
-					| (spread8((b.D >> (8 * q)) & 255u) << 2) | (spread8((b.U >> (8 * q)) & 255u) << 3);
-				dst[static_cast<uint64_t>(mt_index(mx, my, mtx2)) * 8u + (y & 7u)] = w;
-			}
+		for (uint32_t q = 0; q < 4; q++) {
+			const uint32_t mx = tx * 4u + q;
+			if (mx >= mtx) break;
+			uint32_t w[8];
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++)
+				w[k] = spread8((b[k].R >> (8 * q)) & 255u) | (spread8((b[k].L >> (8 * q)) & 255u) << 1)
+					| (spread8((b[k].D >> (8 * q)) & 255u) << 2) | (spread8((b[k].U >> (8 * q)) & 255u) << 3);
+			uint4* mt = reinterpret_cast<uint4*>(dst + static_cast<uint64_t>(mt_index(mx, ty, mtx2)) * 8u);
+			mt[0] = make_uint4(w[0], w[1], w[2], w[3]);
+			mt[1] = make_uint4(w[4], w[5], w[6], w[7]);
 		}
-		ns = __popc(trail_special_mask(b));
-		nc = __popc(trail_corner_mask(b));
+#pragma unroll
+		for (uint32_t k = 0; k < 8; k++) { ns += __popc(trail_special_mask(b[k])); nc += __popc(trail_corner_mask(b[k])); }
 	}
 	ns = wave_sum(ns); nc = wave_sum(nc);
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -270,44 +309,53 @@ static __global__ void __launch_bounds__(kBlock) k_trail_count_scan(
 	if (threadIdx.x == 0) { tot_special[zi] = cs; tot_corner[zi] = cc; }
 }
 
-// grid = (graph_blocks, nslices), same thread -> tile row mapping as k_trail_graph:
-// nodes are numbered in (workgroup, row, tile, x) order, no atomics
+// grid = (graph_blocks, nslices), same thread -> piece mapping as k_trail_graph:
+// nodes are numbered in (workgroup, piece, row, x) order, no atomics
 static __global__ void __launch_bounds__(kBlock) k_trail_nodes(TrailArgs a) {
 	__shared__ uint32_t s_scan[2 * kWaves];
 	const uint32_t zi = blockIdx.y + a.z0;
-	const uint32_t tile = blockIdx.x * kGraphTiles + (threadIdx.x & (kGraphTiles - 1u));
-	const uint32_t r = threadIdx.x / kGraphTiles;
-	TileRowBits b = { 0, 0, 0, 0 };
-	uint32_t x0 = 0, y = 0;
-	if (tile < a.tiles_x * a.tiles_y) {
-		const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-		x0 = tx << kTrailTileShift; y = (ty << kTrailTileShift) + r;
-		if (y <= a.sy) b = trail_row_bits(a.planeV + zi * a.plane_words, a.planeH + zi * a.plane_words, a.row_words, a.sx, a.sy, tx, y, a.inv);
+	const uint32_t item = blockIdx.x * kBlock + threadIdx.x;
+	TileRowBits b[8];
+	uint32_t x0 = 0, y0 = 0;
+	if (item < a.tiles_x * a.tiles_y) {
+		const uint32_t ty = item / a.tiles_x, tx = item - ty * a.tiles_x;
+		x0 = tx << kTrailTileShift; y0 = ty << 3;
+		trail_rows8(a.planeV + zi * a.plane_words, a.planeH + zi * a.plane_words, a.row_words, a.sx, a.sy, tx, y0, a.inv, b);
 	}
-	const uint32_t ms = trail_special_mask(b), mc = trail_corner_mask(b);
-	uint32_t v[2] = { static_cast<uint32_t>(__popc(ms)), static_cast<uint32_t>(__popc(mc)) }, tot[2];
+	else {
+#pragma unroll
+		for (int k = 0; k < 8; k++) b[k] = TileRowBits{ 0, 0, 0, 0 };
+	}
+	uint32_t v[2] = { 0, 0 }, tot[2];
+#pragma unroll
+	for (uint32_t k = 0; k < 8; k++) { v[0] += __popc(trail_special_mask(b[k])); v[1] += __popc(trail_corner_mask(b[k])); }
 	block_excl_add<2>(v, tot, s_scan);
 	uint32_t j = a.blk_special[static_cast<uint64_t>(zi) * a.graph_blocks + blockIdx.x] + v[0];
 	uint32_t c = a.blk_corner[static_cast<uint64_t>(zi) * a.graph_blocks + blockIdx.x] + v[1];
 	const uint64_t nb = a.nbase[zi];
 	const uint32_t ncap = a.ncap[zi], cocap = a.cocap[zi];
 	uint32_t err = 0;
-	for (uint32_t m = ms; m; m &= m - 1u) {
-		const uint32_t i = __ffs(m) - 1;
-		const uint32_t vtx = y * a.sxe + x0 + i;
-		if (j < ncap) {
-			a.node_vertex[nb + j] = vtx;
-			a.node_adj[nb + j] = static_cast<uint8_t>(((b.R >> i) & 1u) | (((b.L >> i) & 1u) << 1) | (((b.D >> i) & 1u) << 2) | (((b.U >> i) & 1u) << 3));
-			a.vert2node[static_cast<uint64_t>(zi) * a.nverts + vtx] = j;
+#pragma unroll
+	for (uint32_t k = 0; k < 8; k++) {
+		const uint32_t y = y0 + k;
+		const TileRowBits& r = b[k];
+		for (uint32_t m = trail_special_mask(r); m; m &= m - 1u) {
+			const uint32_t i = __ffs(m) - 1;
+			const uint32_t vtx = y * a.sxe + x0 + i;
+			if (j < ncap) {
+				a.node_vertex[nb + j] = vtx;
+				a.node_adj[nb + j] = static_cast<uint8_t>(((r.R >> i) & 1u) | (((r.L >> i) & 1u) << 1) | (((r.D >> i) & 1u) << 2) | (((r.U >> i) & 1u) << 3));
+				a.vert2node[static_cast<uint64_t>(zi) * a.nverts + vtx] = j;
+			}
+			else err = TRAIL_ERR_CAPACITY;
+			j++;
 		}
-		else err = TRAIL_ERR_CAPACITY;
-		j++;
-	}
-	for (uint32_t m = mc; m; m &= m - 1u) {
-		const uint32_t i = __ffs(m) - 1;
-		if (c < cocap) a.corner_vertex[a.cobase[zi] + c] = y * a.sxe + x0 + i;
-		else err = TRAIL_ERR_CAPACITY;
-		c++;
+		for (uint32_t m = trail_corner_mask(r); m; m &= m - 1u) {
+			const uint32_t i = __ffs(m) - 1;
+			if (c < cocap) a.corner_vertex[a.cobase[zi] + c] = y * a.sxe + x0 + i;
+			else err = TRAIL_ERR_CAPACITY;
+			c++;
+		}
 	}
 	if (err) atomicOr(a.slice_err + zi, err);
 	// node / corner totals of the slice (k_trail_loops and k_trail_components append to n_nodes)
