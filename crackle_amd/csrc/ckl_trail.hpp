@@ -250,35 +250,51 @@ static __global__ void __launch_bounds__(kBlock) k_trail_graph(
 	uint32_t mtx2, uint32_t tiles_x, uint32_t tiles_y, uint32_t* __restrict__ blk_special, uint32_t* __restrict__ blk_corner
 ) {
 	__shared__ uint32_t s_red[2 * kWaves];
+	// A thread's four micro-tiles are eight 16-byte pieces in two stretches of 64 bytes; stored by their owner, a store instruction
+	// is 64 pieces of 16 bytes in 64 different lines (16.8 M write requests at C2: the L2s' request rate, 0.09 of the kernel's
+	// 0.16 ms).  They go through LDS instead, so that four neighbouring lanes store one stretch of 64 bytes.
+	__shared__ uint4 s_out[kWaves][kWave * 8];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t zi = blockIdx.y;
 	// perm_mode 2: the crack format follows from the volume's equal pixel pairs (crackle.hpp:50-55), counted by the kernels in front
 	const bool permissible = perm_mode == 2u ? static_cast<long long>(*total_pairs) < static_cast<long long>(half_voxels) : perm_mode != 0u;
 	const uint32_t item = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t mtx = (sx + 1u + 7u) >> 3;
 	uint32_t ns = 0, nc = 0;
+	uint32_t my_base = 0, my_tiles = 0;      // byte offset of my first micro-tile in the slice's graph, how many of my four exist
 	if (item < tiles_x * tiles_y) {
 		const uint32_t ty = item / tiles_x, tx = item - ty * tiles_x;
 		TileRowBits b[8];
 		trail_rows8(planeV + zi * plane_words, planeH + zi * plane_words, row_words, sx, sy, tx, ty << 3, permissible ? 0xFFFFFFFFu : 0u, b);
-		uint32_t* dst = adjm_words + zi * adjm_stride_words;
+		my_base = mt_index(tx * 4u, ty, mtx2) * 32u;
+		my_tiles = min(4u, mtx - min(mtx, tx * 4u));
 #pragma unroll
 		for (uint32_t q = 0; q < 4; q++) {
-			const uint32_t mx = tx * 4u + q;
-			if (mx >= mtx) break;
 			uint32_t w[8];
 #pragma unroll
 			for (uint32_t k = 0; k < 8; k++)
 				w[k] = spread8((b[k].R >> (8 * q)) & 255u) | (spread8((b[k].L >> (8 * q)) & 255u) << 1)
 					| (spread8((b[k].D >> (8 * q)) & 255u) << 2) | (spread8((b[k].U >> (8 * q)) & 255u) << 3);
-			uint4* mt = reinterpret_cast<uint4*>(dst + static_cast<uint64_t>(mt_index(mx, ty, mtx2)) * 8u);
-			mt[0] = make_uint4(w[0], w[1], w[2], w[3]);
-			mt[1] = make_uint4(w[4], w[5], w[6], w[7]);
+			// piece p = 2 q + half of lane l sits at 8 l + (p ^ (l & 7)): eight neighbouring lanes hit eight different bank groups
+			s_out[wave][lane * 8 + ((2u * q) ^ (lane & 7))] = make_uint4(w[0], w[1], w[2], w[3]);
+			s_out[wave][lane * 8 + ((2u * q + 1u) ^ (lane & 7))] = make_uint4(w[4], w[5], w[6], w[7]);
 		}
 #pragma unroll
 		for (uint32_t k = 0; k < 8; k++) { ns += __popc(trail_special_mask(b[k])); nc += __popc(trail_corner_mask(b[k])); }
 	}
+	{
+		// (a wavefront's own pieces: no barrier, LDS operations of a wavefront complete in order)
+		uint8_t* dst = reinterpret_cast<uint8_t*>(adjm_words + zi * adjm_stride_words);
+#pragma unroll
+		for (uint32_t i = 0; i < 8; i++) {
+			const uint32_t owner = i * 8u + (lane >> 3), p = lane & 7u;
+			const uint32_t base = __shfl(my_base, owner, kWave), have = __shfl(my_tiles, owner, kWave);
+			const uint4 v = s_out[wave][owner * 8u + (p ^ (owner & 7u))];
+			const uint32_t q = p >> 1;
+			if (q < have) *reinterpret_cast<uint4*>(dst + base + (q >> 1) * 128u + (q & 1u) * 32u + (p & 1u) * 16u) = v;
+		}
+	}
 	ns = wave_sum(ns); nc = wave_sum(nc);
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	if (lane == 0) { s_red[wave] = ns; s_red[kWaves + wave] = nc; }
 	__syncthreads();
 	if (threadIdx.x == 0) {

@@ -60,7 +60,7 @@ def main():
     res[k] = row
   with open(out, "w") as fh:
     json.dump({"source": "rocprofv3 --kernel-trace --pmc <SQ group> of bench.py --steps 1 --warmup 1 (tools/sq_profile.sh)", "kernels": res}, fh, indent=1, sort_keys=True)
-  want = ("k_decode_cracks", "k_crack", "k_strip", "k_slice_resolve", "k_paint_strips", "k_trail_walk", "k_trail_items", "k_trail_segments", "k_trail_expand")
+  want = ("k_decode_cracks", "k_crack", "k_strip", "k_slice_resolve", "k_paint_strips", "k_trail_walk", "k_trail_items", "k_trail_segments", "k_trail_expand", "k_trail_graph", "k_trail_nodes", "k_label_planes", "k_trail_components", "k_finish")
   for k in sorted(res):
     if not k.startswith(want):
       continue
