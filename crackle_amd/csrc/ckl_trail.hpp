@@ -1762,6 +1762,14 @@ static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	uint32_t* longs = s_long[wv];
 	struct __attribute__((packed)) U64 { unsigned long long v; };
+	struct __attribute__((packed)) U32 { uint32_t v; };
+	struct __attribute__((packed)) U16 { uint16_t v; };
+	// the low n (< 8) bytes of v: at most three stores (4 + 2 + 1 bytes) instead of one per byte
+	auto store_tail = [](uint8_t* o, unsigned long long v, uint32_t n) {
+		if (n & 4u) { reinterpret_cast<U32*>(o)->v = static_cast<uint32_t>(v); o += 4; v >>= 32; }
+		if (n & 2u) { reinterpret_cast<U16*>(o)->v = static_cast<uint16_t>(v); o += 2; v >>= 16; }
+		if (n & 1u) o[0] = static_cast<uint8_t>(v);
+	};
 
 	// ---- the copies
 	uint32_t n_long = 0;
@@ -1771,7 +1779,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
 		if (i < range_end) {
 			const uint32_t it = items[i], kind = it & kItemMask;
 			uint8_t* o = cp0 + item_off[i];
-			if (kind == kItemCtl) { o[0] = static_cast<uint8_t>(it & 3u); o[1] = static_cast<uint8_t>((it >> 2) & 3u); }
+			if (kind == kItemCtl) reinterpret_cast<U16*>(o)->v = static_cast<uint16_t>((it & 3u) | (((it >> 2) & 3u) << 8));
 			else if (kind == kItemSeg) {
 				const uint32_t d = it & ~kItemMask;
 				const uint32_t len = a.dart_len[nb * 4u + d];
@@ -1788,7 +1796,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
 							hi = (hi | (hi << 12)) & 0x000F000Fu; hi = (hi | (hi << 6)) & 0x03030303u;
 							const unsigned long long v = (static_cast<unsigned long long>(hi) << 32) | lo;
 							if (g * 8u + 8u <= len) reinterpret_cast<U64*>(o + g * 8u)->v = v;
-							else for (uint32_t t = 0; t < len - g * 8u; t++) o[g * 8u + t] = static_cast<uint8_t>(v >> (8u * t));
+							else store_tail(o + g * 8u, v, len - g * 8u);
 						}
 					}
 				}
@@ -1829,7 +1837,7 @@ static __global__ void __launch_bounds__(kBlock) k_trail_expand(TrailArgs a) {
 				--left;
 				if (nacc == 8u || left == 0) {
 					if (nacc == 8u) reinterpret_cast<U64*>(cp)->v = acc;
-					else for (uint32_t q = 0; q < nacc; q++) cp[q] = static_cast<uint8_t>(acc >> (8u * q));
+					else store_tail(cp, acc, nacc);
 					cp += nacc; acc = 0; nacc = 0;
 				}
 				if (left == 0) active = false;
