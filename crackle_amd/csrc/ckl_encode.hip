@@ -1121,6 +1121,53 @@ __global__ void __launch_bounds__(kBlock) k_gather_codes(
 
 // n bytes from src to dst, any alignment on either side: the device-resident copy of the assembled stream
 // (ckl_encoder_keep_device_stream) takes its two bulky sections from buffers of this session.  A device-to-device
+// ---- crc32c of a device buffer (the flat label section: header.hpp / crackle.hpp:171-216 store it behind the crack codes) ----
+// The register's journey is linear over GF(2): state(c, M) = c * x^bits(M) + state(0, M).  The n bytes are laid right-aligned
+// into a frame of G * 256 * P bytes (G a power of two; zeros in front leave a zero register where it is), every thread
+// runs its P bytes from a zero register through the byte table, and the pieces are folded pairwise with x^(bits of the
+// right half) — inside the workgroups here, over the workgroups in k_crc32c_fold.
+struct CrcShifts { uint32_t x[8]; };      // x[k] = x^(8 * piece * 2^k) mod P, reflected representation (ckl_common.hpp: gf_xpow)
+__global__ void __launch_bounds__(kBlock) k_crc32c_pieces(const uint8_t* __restrict__ data, uint64_t n, uint64_t pad, uint32_t P, CrcShifts sh, uint32_t* __restrict__ parts) {
+	__shared__ uint32_t s_tab[256];
+	__shared__ uint32_t s_st[kBlock];
+	{
+		uint32_t c = threadIdx.x;
+		for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ dev::kCrcPoly : (c >> 1);
+		s_tab[threadIdx.x] = c;
+	}
+	__syncthreads();
+	const uint64_t f0 = (static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x) * P;      // my piece's place in the frame
+	uint32_t c = 0;
+	for (uint32_t g = 0; g < P; g += 16) {
+		const int64_t m0 = static_cast<int64_t>(f0 + g) - static_cast<int64_t>(pad);           // ... and in the message
+		uint32_t w[4] = { 0, 0, 0, 0 };
+		if (m0 >= 0 && static_cast<uint64_t>(m0) + 16u <= n) __builtin_memcpy(w, data + m0, 16);      // (unaligned 16-byte load)
+		else if (m0 + 16 > 0) for (int b = 0; b < 16; b++) { const int64_t i = m0 + b; if (i >= 0 && static_cast<uint64_t>(i) < n) w[b >> 2] |= static_cast<uint32_t>(data[i]) << (8 * (b & 3)); }
+#pragma unroll
+		for (int b = 0; b < 16; b++) c = s_tab[(c ^ (w[b >> 2] >> (8 * (b & 3)))) & 0xFFu] ^ (c >> 8);
+	}
+	s_st[threadIdx.x] = c;
+	__syncthreads();
+	for (int k = 0; k < 8; k++) {
+		const uint32_t stride = 1u << k;
+		if ((threadIdx.x & (2u * stride - 1u)) == 0u) s_st[threadIdx.x] = gf_mul(s_st[threadIdx.x], sh.x[k]) ^ s_st[threadIdx.x + stride];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) parts[blockIdx.x] = s_st[0];
+}
+// one workgroup: the G (a power of two, <= kBlock) workgroup states -> the finished crc32c (register preset to all ones, inverted at the end)
+__global__ void __launch_bounds__(kBlock) k_crc32c_fold(const uint32_t* __restrict__ parts, uint32_t G, CrcShifts sh, uint32_t init_term, uint32_t* __restrict__ out) {
+	__shared__ uint32_t s_st[kBlock];
+	s_st[threadIdx.x] = threadIdx.x < G ? parts[threadIdx.x] : 0u;
+	__syncthreads();
+	for (int k = 0; (1u << k) < G; k++) {
+		const uint32_t stride = 1u << k;
+		if ((threadIdx.x & (2u * stride - 1u)) == 0u && threadIdx.x + stride < G) s_st[threadIdx.x] = gf_mul(s_st[threadIdx.x], sh.x[k]) ^ s_st[threadIdx.x + stride];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) out[0] = ~(s_st[0] ^ init_term);
+}
+
 // hipMemcpyAsync moved the 13 MB of C2's crack codes at 115 GB/s (113 us on the encode's tail); this is a plain
 // streaming kernel.  Destination words are written aligned; a source word is two aligned loads and a funnel shift.
 // grid-stride, block = kBlock.
@@ -1151,6 +1198,21 @@ __global__ void __launch_bounds__(kBlock) k_copy_bytes(const uint8_t* __restrict
 // host orchestration
 // ------------------------------------------------------------------------------
 using namespace ckl;
+
+// crc32c of n > 0 device bytes into out[0], on stream s (parts: scratch of kBlock words)
+static void crc32c_device(const uint8_t* data, uint64_t n, uint32_t* parts, uint32_t* out, hipStream_t s) {
+	uint32_t P = 128, G = 1;
+	while (G < static_cast<uint32_t>(kBlock) && static_cast<uint64_t>(G) * kBlock * P < n) G <<= 1;
+	if (static_cast<uint64_t>(G) * kBlock * P < n) P = static_cast<uint32_t>(((n + static_cast<uint64_t>(G) * kBlock - 1) / (static_cast<uint64_t>(G) * kBlock) + 15) / 16 * 16);
+	const uint64_t frame = static_cast<uint64_t>(G) * kBlock * P;
+	CrcShifts in_wg, over_wg;
+	for (int k = 0; k < 8; k++) {
+		in_wg.x[k] = gf_xpow(8ull * P << k);
+		over_wg.x[k] = gf_xpow(8ull * P * kBlock << k);
+	}
+	hipLaunchKernelGGL(k_crc32c_pieces, dim3(G), dim3(kBlock), 0, s, data, n, frame - n, P, in_wg, parts);
+	hipLaunchKernelGGL(k_crc32c_fold, dim3(1), dim3(kBlock), 0, s, parts, G, over_wg, gf_mul(0xFFFFFFFFu, gf_xpow(8ull * n)), out);
+}
 
 // k_copy_bytes on stream s
 static void copy_bytes_device(const uint8_t* src, uint8_t* dst, uint64_t n, hipStream_t s) {
@@ -1193,6 +1255,8 @@ struct ckl_encoder {
 	hipStream_t stream_copy = nullptr;
 	hipStream_t stream_tab = nullptr;   // the pin stage's label lists come to the host beside the passes of the label stream
 	hipEvent_t ev_codes = nullptr;
+	hipEvent_t ev_labels_crc = nullptr;          // the label section's crc32c stands in d_labels_crc (device-resident streams: ckl_encoder_run)
+	DevBuf<uint32_t> d_labels_crc;               // [0]: the crc, [1 ..]: the workgroups' states
 	DevBuf<uint8_t> d_stream_out;       // ... here (valid until the next run)
 	uint64_t device_stream_bytes = 0;
 	uint64_t last_codes_total = 0;      // bytes of the last run's crack codes
@@ -1272,6 +1336,7 @@ struct ckl_encoder {
 		if (stream_copy) { (void)hipStreamSynchronize(stream_copy); (void)hipStreamDestroy(stream_copy); }
 		if (stream_tab) { (void)hipStreamSynchronize(stream_tab); (void)hipStreamDestroy(stream_tab); }
 		if (ev_codes) (void)hipEventDestroy(ev_codes);
+		if (ev_labels_crc) (void)hipEventDestroy(ev_labels_crc);
 	}
 };
 
@@ -2599,6 +2664,7 @@ void encode_typed(
 	uint32_t labels_crc = 0;
 	const int component_width = byte_width(static_cast<uint64_t>(sx) * sy);
 	hipStream_t s2 = e.stream2;
+	bool labels_stay = false;      // set by label_side: the label section and its crc stay on the device until the background copy
 	auto label_side = [&]() {
 		if (labels_at_walk) {
 			CKL_HIP(hipStreamWaitEvent(s2, e.evd0, 0));      // (starting one kernel earlier, beside k_trail_components, cost 0.2 ms)
@@ -2619,6 +2685,7 @@ void encode_typed(
 		else {
 			label_bytes = flat_section(e, N, stored_width, component_width, static_cast<uint32_t>(sz), ov);
 			HT_MARK("label_table");
+			labels_stay = e.async_host_copy && e.keep_device_stream && !e.defer_codes && label_bytes > 0 && !getenv("CKL_LABELS_CRC_HOST");
 			// The output buffer is taken now, sized with an estimate of the crack code bytes, so that
 			// the label section is copied out and checksummed while the trail still runs; a stream
 			// that outgrows the estimate is moved to a larger buffer at assembly.
@@ -2628,9 +2695,20 @@ void encode_typed(
 			uint8_t* eo = static_cast<uint8_t*>(early.p);
 			// (one copy: four pieces with an event each, checksummed while the next was on the link, saved 0.04 ms
 			// and now and then stalled the enqueueing thread for milliseconds)
-			if (label_bytes) CKL_HIP(hipMemcpyAsync(eo + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToHost, s2));
-			CKL_HIP(hipStreamSynchronize(s2));
-			labels_crc = crc32c(eo + off_labels, label_bytes);
+			if (labels_stay) {
+				// the caller goes on from the stream in HBM: the section's crc32c is taken on the device and the section itself travels
+				// to the host with the crack codes, in the background (until round 5 both sat on the encode's tail: 8 MB over the link,
+				// then the host's crc over them, 0.25 ms at C2)
+				e.d_labels_crc.ensure(1 + kBlock);
+				if (!e.ev_labels_crc) CKL_HIP(hipEventCreateWithFlags(&e.ev_labels_crc, hipEventDisableTiming));
+				crc32c_device(e.d_labels_bin.p, label_bytes, e.d_labels_crc.p + 1, e.d_labels_crc.p, s2);
+				CKL_HIP(hipEventRecord(e.ev_labels_crc, s2));
+			}
+			else {
+				if (label_bytes) CKL_HIP(hipMemcpyAsync(eo + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToHost, s2));
+				CKL_HIP(hipStreamSynchronize(s2));
+				labels_crc = crc32c(eo + off_labels, label_bytes);
+			}
 			HT_MARK("labels_d2h");
 		}
 	};
@@ -2688,6 +2766,10 @@ void encode_typed(
 			if (!stored_model.empty()) CKL_HIP(hipMemcpyAsync(ds + off_model, o + off_model, stored_model.size(), hipMemcpyHostToDevice, s));
 			if (cr.total) copy_bytes_device(e.d_codes_out.p, ds + off_codes, cr.total, s);
 			CKL_HIP(hipMemcpyAsync(ds + off_tail, o + off_tail, 4ull * (sz + 1), hipMemcpyHostToDevice, s));
+			if (labels_stay) {
+				CKL_HIP(hipStreamWaitEvent(s, e.ev_labels_crc, 0));
+				CKL_HIP(hipMemcpyAsync(ds + off_tail, e.d_labels_crc.p, 4, hipMemcpyDeviceToDevice, s));
+			}
 			e.device_stream_bytes = total;
 		}
 		// the crack codes' copy to the host goes LAST: started first, its 13 MB kept the link busy and the 2 KB header
@@ -2701,6 +2783,10 @@ void encode_typed(
 				CKL_HIP(hipEventRecord(e.ev_codes, s));
 				CKL_HIP(hipStreamWaitEvent(e.stream_copy, e.ev_codes, 0));
 				CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, e.stream_copy));
+				if (labels_stay) {
+					CKL_HIP(hipMemcpyAsync(o + off_labels, e.d_labels_bin.p, label_bytes, hipMemcpyDeviceToHost, e.stream_copy));
+					CKL_HIP(hipMemcpyAsync(o + off_tail, e.d_labels_crc.p, 4, hipMemcpyDeviceToHost, e.stream_copy));
+				}
 				e.host_copy_pending = true;
 			}
 			else CKL_HIP(hipMemcpyAsync(o + off_codes, e.d_codes_out.p, cr.total, hipMemcpyDeviceToHost, s));
