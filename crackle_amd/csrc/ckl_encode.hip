@@ -620,13 +620,42 @@ __global__ void __launch_bounds__(kFinishBlock) k_finish(FinishArgs a) {
 			}
 			uint32_t chain = lo;
 			uint32_t next_off = (chain + 1 < nch) ? ch_off[chain + 1] : 0xFFFFFFFFu;
+			if (i0 + kPer <= next_off) {
+				// all sixteen in one chain (a slice has ~100 chains in 128 k codes): the surviving codes go out together — one
+				// unaligned 16-byte store when none is a tombstone, else 8 + 4 + 2 + 1 — instead of a store per byte (67 M one-byte
+				// requests at C2 ran at the L2s' request rate)
+				struct __attribute__((packed)) U128 { uint4 v; };
+				struct __attribute__((packed)) U64 { unsigned long long v; };
+				struct __attribute__((packed)) U32 { uint32_t v; };
+				struct __attribute__((packed)) U16 { uint16_t v; };
+				uint8_t* d = fcode + dst[chain] + (g - vstart[chain]);
+				unsigned long long w0 = 0, w1 = 0;
+				uint32_t m = 0;
 #pragma unroll
-			for (uint32_t k = 0; k < kPer; k++) {
-				const uint32_t i = i0 + k;
-				while (i >= next_off) { chain++; next_off = (chain + 1 < nch) ? ch_off[chain + 1] : 0xFFFFFFFFu; }
-				if (c[k] != CODE_TOMB) {
-					fcode[dst[chain] + (g - vstart[chain])] = c[k];
-					g++;
+				for (uint32_t k = 0; k < kPer; k++) {
+					if (c[k] != CODE_TOMB) {
+						if (m < 8u) w0 |= static_cast<unsigned long long>(c[k]) << (8u * m);
+						else w1 |= static_cast<unsigned long long>(c[k]) << (8u * (m - 8u));
+						m++;
+					}
+				}
+				if (m == 16u) reinterpret_cast<U128*>(d)->v = make_uint4(static_cast<uint32_t>(w0), static_cast<uint32_t>(w0 >> 32), static_cast<uint32_t>(w1), static_cast<uint32_t>(w1 >> 32));
+				else {
+					if (m & 8u) { reinterpret_cast<U64*>(d)->v = w0; d += 8; w0 = w1; }
+					if (m & 4u) { reinterpret_cast<U32*>(d)->v = static_cast<uint32_t>(w0); d += 4; w0 >>= 32; }
+					if (m & 2u) { reinterpret_cast<U16*>(d)->v = static_cast<uint16_t>(w0); d += 2; w0 >>= 16; }
+					if (m & 1u) d[0] = static_cast<uint8_t>(w0);
+				}
+			}
+			else {
+#pragma unroll
+				for (uint32_t k = 0; k < kPer; k++) {
+					const uint32_t i = i0 + k;
+					while (i >= next_off) { chain++; next_off = (chain + 1 < nch) ? ch_off[chain + 1] : 0xFFFFFFFFu; }
+					if (c[k] != CODE_TOMB) {
+						fcode[dst[chain] + (g - vstart[chain])] = c[k];
+						g++;
+					}
 				}
 			}
 		}
