@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_crack_match(RecArgs ra) {
 	const uint32_t n_tiles = n_codes / kRecTile + 1u;
 	const uint32_t span = min(kRecWords * 16u, ((n_codes / n_tiles + BLOCK) / BLOCK + 15u) / 16u * 16u);
 	const uint32_t tile_step = span * BLOCK;
-	const uint32_t index_end = uni(4u + (code_len >= 4u ? rd_le_dev(code, 4) : 0u));
+	const uint32_t index_end = uni(s_index_end);      // (what the index parse found: 4 + its size, or the end of the code when it is broken — no second trip to memory for it)
 	const uint8_t* packed = code + index_end;
 	const uint32_t* words;
 	uint32_t wshift;

@@ -155,6 +155,35 @@ def test_device_resident_sessions_full_size_properties():
   L.ckl_decoder_destroy(dec)
 
 
+@pytest.mark.parametrize("shape,dtype,cell,markov", [
+  ((8, 8, 2), np.uint8, (4, 4, 1), 0),            # a label section of a few bytes: one workgroup, most of the frame is padding
+  ((36, 20, 3), np.uint16, (6, 6, 2), 0),
+  ((100, 60, 5), np.uint64, (5, 5, 2), 0),        # wide labels, a section whose length is no multiple of anything
+  ((256, 256, 8), np.uint32, (8, 8, 2), 3),       # with a markov model between the label section and the codes
+  ((512, 512, 16), np.uint32, (4, 4, 2), 0),      # 130 k labels: several workgroups of pieces
+])
+def test_label_section_crc_on_device(checker, shape, dtype, cell, markov):
+  """Streams that stay in HBM take the label section's crc32c on the device (k_crc32c_pieces / k_crc32c_fold) and bring the
+  section to the host in the background: the host bytes after the wait are the reference's, for sections from a few bytes on."""
+  import torch
+  from crackle_amd import distributed as ckd
+  dev = torch.device("cuda:0")
+  be = ckd.HipBackend(0, zero_copy=True)
+  vol = synth.voronoi_labels(shape, dtype, seed=91, device=dev, cell=cell)
+  want = checker.compress(synth.as_numpy_f(vol), markov_model_order=markov)
+  item = vol.element_size()
+  be.keep_device_stream(shape, item, True)
+  be.async_host_copy(shape, item, True)
+  try:
+    for _ in range(2):
+      stream = be.encode(vol, shape, False, True, markov, None)
+      be.host_wait()
+      assert bytes(stream) == want
+  finally:
+    be.async_host_copy(shape, item, False)
+    be.keep_device_stream(shape, item, False)
+
+
 def test_encoder_async_host_copy(checker):
   """ckl_encoder_async_host_copy / ckl_encoder_host_wait: the call returns with the stream complete in HBM
   (a decoder runs from it at once), the host buffer is complete after the wait, and the next run waits for
