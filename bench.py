@@ -266,6 +266,34 @@ def pmc_traffic(kernels, workload_key):
   return None, {}
 
 
+DECODE_SIDE_KERNELS = ("k_crack_match", "k_strip_ccl", "k_strip_ccl2", "k_slice_resolve", "k_paint_strips", "k_fetch_to_host", "k_fetch_flat_counts",
+                       "k_build_geom_table", "k_decode_cracks", "k_flags_to_host", "k_strip_labels", "k_label_map", "k_label_map_pins", "k_paint_runs")
+
+
+def pmc_traffic_encode(workload_key):
+  """HBM bytes of ONE encode: every kernel of the committed PMC passes that is not one of the decoder's, its bytes per launch
+  times its launches per encode (launches over those of the label-plane kernel, which runs once per encode).  None under the
+  conditions of pmc_traffic()."""
+  path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+  try:
+    with open(path) as f:
+      t = json.load(f)
+  except (OSError, ValueError):
+    return None
+  if t.get("workload") != workload_key or t.get("lib_sha16") != lib_sha16():
+    return None
+  rows = t.get("kernels", {})
+  encodes = sum(float(r.get("launches", 0)) for n, r in rows.items() if n.split("<")[0].startswith("k_label_planes"))
+  if encodes <= 0:
+    return None
+  total = 0.0
+  for name, r in rows.items():
+    if name.split("<")[0] in DECODE_SIDE_KERNELS:
+      continue
+    total += float(r.get("hbm_bytes_per_launch", 0.0)) * float(r.get("launches", 0)) / encodes
+  return total
+
+
 def cpu_model():
   try:
     with open("/proc/cpuinfo") as f:
@@ -623,7 +651,7 @@ def main():
         "bound": "hbm", "kernel": "encode pipeline (planes, trail, label stream: two streams)",
         "achieved": alg_bytes / (enc_p * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": alg_bytes / (enc_p * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": pmc_traffic_encode(workload_key) if (args.pins == 0 and args.data == "voronoi" and args.cell == "32x32x8") else None,
         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": enc_p,
         "longest_kernel": {"kernel": "k_trail_walk", "kernel_ms": enc_k, "share_of_pipeline": (enc_k / enc_p) if enc_p > 0 else None},
       }
