@@ -487,9 +487,9 @@ class HipBackend:
     self._L.ckl_encoder_keep_device_stream(self._encoder(shape, itemsize), int(bool(keep)))
 
   def async_host_copy(self, shape, itemsize: int, on: bool = True):
-    """Following encodes of this shape return when their stream is complete in HBM; the crack codes reach
-    the returned host buffer in the background (needs keep_device_stream): host_wait() before its bytes are
-    read or released."""
+    """Following encodes of this shape return when their stream is complete in HBM; the crack codes and the
+    flat label section (with its crc32c, computed on the device) reach the returned host buffer in the
+    background (needs keep_device_stream): host_wait() before its bytes are read or released."""
     self._L.ckl_encoder_async_host_copy(self._encoder(shape, itemsize), int(bool(on)))
 
   def host_wait(self):

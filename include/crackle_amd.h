@@ -250,8 +250,9 @@ int ckl_encoder_defer_codes(ckl_encoder* e, int defer);
  * buffer is the session's and valid until its next run or its destruction. */
 int ckl_encoder_keep_device_stream(ckl_encoder* e, int keep);
 /* With on != 0 (and ckl_encoder_keep_device_stream), ckl_encoder_run returns as soon as the stream is complete
- * in HBM: header, z-index, labels and crcs are in the returned host buffer, its crack codes (the bulk) are
- * still crossing PCIe on a stream of their own.  ckl_encoder_host_wait blocks until they have arrived; the
+ * in HBM: header, z-index and the slices' crcs are in the returned host buffer, its crack codes (the bulk) and —
+ * for flat labels — the label section with its crc32c (taken on the device) are still crossing PCIe on a stream
+ * of their own.  ckl_encoder_host_wait blocks until they have arrived; the
  * host bytes must not be read, and the buffer not be freed, before.  In between the caller may decode from
  * ckl_encoder_device_stream or do anything else on the device; the encoder's next run waits by itself.
  * With ckl_encoder_defer_codes the same holds for ckl_encoder_codes_to_host: it starts the copy and returns.
