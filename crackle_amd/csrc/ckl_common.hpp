@@ -124,6 +124,11 @@ struct Header {
 void* host_out_alloc(size_t bytes);        // pinned (cached) host buffer for results; release with ckl_free / host_out_free
 void host_out_free(void* p);               // also accepts plain malloc'd pointers
 bool host_out_is_pinned(const void* p);    // a block of host_out_alloc that is page-locked and mapped into the device's address space
+// Small host -> device copies on the hot paths (descriptor tables, headers, crc tails: a few KiB to a few hundred): when
+// the source lies in a pinned, device-mapped block of host_out_alloc (`block`: that block's base pointer) a one-workgroup-
+// per-4-KiB kernel reads it over the link; else hipMemcpyAsync.  (hipMemcpyAsync of 40 KiB from pinned memory was seen to
+// block its caller for 5 - 8 ms once in a few dozen calls on this stack — 9 % of a bench run's value when it happened.)
+void upload_small(void* dst_device, const void* src_host, size_t bytes, hipStream_t s, const void* block);
 void* pool_alloc(size_t bytes, int* device = nullptr);      // throws Error on failure; *device: the device the block lives on (the current one)
 void pool_free(void* p, size_t bytes, int device = -1);     // returns the block to the pool of its device (-1: the current device)
 void pool_trim();                          // hipFree everything that is pooled

@@ -2609,7 +2609,7 @@ struct DescPacker {
 		if (d.desc_staging) host_out_free(d.desc_staging);
 		d.desc_staging = host_out_alloc(std::max<size_t>(image.size(), 64u << 10));      // >= 64 KiB: pinned
 		memcpy(d.desc_staging, image.data(), image.size());
-		CKL_HIP(hipMemcpyAsync(d.d_desc.p, d.desc_staging, image.size(), hipMemcpyHostToDevice, s));
+		upload_small(d.d_desc.p, d.desc_staging, image.size(), s, d.desc_staging);
 		for (const Item& it : items) it.bind(it.buf, d.d_desc.p + it.off, it.count);
 	}
 };

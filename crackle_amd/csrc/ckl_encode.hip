@@ -20,6 +20,7 @@
 #include <chrono>
 #include <functional>
 #include <memory>
+#include <mutex>
 
 namespace ckl {
 
@@ -1234,10 +1235,22 @@ static void crc32c_device(const uint8_t* data, uint64_t n, uint32_t* parts, uint
 	while (G < static_cast<uint32_t>(kBlock) && static_cast<uint64_t>(G) * kBlock * P < n) G <<= 1;
 	if (static_cast<uint64_t>(G) * kBlock * P < n) P = static_cast<uint32_t>(((n + static_cast<uint64_t>(G) * kBlock - 1) / (static_cast<uint64_t>(G) * kBlock) + 15) / 16 * 16);
 	const uint64_t frame = static_cast<uint64_t>(G) * kBlock * P;
+	// (the sixteen powers depend on the piece length only — 128 bytes for every section up to 8 MB — and cost the host ~40 us,
+	// on the encode's tail: kept from call to call)
+	static std::mutex shifts_mutex;
+	static uint32_t shifts_for = 0;
+	static CrcShifts shifts_in, shifts_over;
 	CrcShifts in_wg, over_wg;
-	for (int k = 0; k < 8; k++) {
-		in_wg.x[k] = gf_xpow(8ull * P << k);
-		over_wg.x[k] = gf_xpow(8ull * P * kBlock << k);
+	{
+		std::lock_guard<std::mutex> lock(shifts_mutex);
+		if (shifts_for != P) {
+			for (int k = 0; k < 8; k++) {
+				shifts_in.x[k] = gf_xpow(8ull * P << k);
+				shifts_over.x[k] = gf_xpow(8ull * P * kBlock << k);
+			}
+			shifts_for = P;
+		}
+		in_wg = shifts_in; over_wg = shifts_over;
 	}
 	hipLaunchKernelGGL(k_crc32c_pieces, dim3(G), dim3(kBlock), 0, s, data, n, frame - n, P, in_wg, parts);
 	hipLaunchKernelGGL(k_crc32c_fold, dim3(1), dim3(kBlock), 0, s, parts, G, over_wg, gf_mul(0xFFFFFFFFu, gf_xpow(8ull * n)), out);
@@ -1284,6 +1297,7 @@ struct ckl_encoder {
 	hipStream_t stream_copy = nullptr;
 	hipStream_t stream_tab = nullptr;   // the pin stage's label lists come to the host beside the passes of the label stream
 	hipEvent_t ev_codes = nullptr;
+	void* tables_staging = nullptr;              // pinned host image of d_crack_tables (crack_pass: UploadPacker::commit)
 	hipEvent_t ev_labels_crc = nullptr;          // the label section's crc32c stands in d_labels_crc (device-resident streams: ckl_encoder_run)
 	DevBuf<uint32_t> d_labels_crc;               // [0]: the crc, [1 ..]: the workgroups' states
 	DevBuf<uint8_t> d_stream_out;       // ... here (valid until the next run)
@@ -1365,6 +1379,7 @@ struct ckl_encoder {
 		if (stream_copy) { (void)hipStreamSynchronize(stream_copy); (void)hipStreamDestroy(stream_copy); }
 		if (stream_tab) { (void)hipStreamSynchronize(stream_tab); (void)hipStreamDestroy(stream_tab); }
 		if (ev_codes) (void)hipEventDestroy(ev_codes);
+		if (tables_staging) host_out_free(tables_staging);
 		if (ev_labels_crc) (void)hipEventDestroy(ev_labels_crc);
 	}
 };
@@ -1390,11 +1405,18 @@ struct UploadPacker {
 		items.push_back({ &dst, off, src.size(), [](void* b, uint8_t* base, size_t n) { static_cast<DevBuf<T>*>(b)->borrow(reinterpret_cast<T*>(base), n); } });
 	}
 	// `block` must not be in use by kernels of another stream; the copy is ordered on `s`
-	void commit(DevBuf<uint8_t>& block, hipStream_t s) {
+	// staging: the session's pinned host block for this image (kept until its next commit: the copy kernel reads it), or null
+	void commit(DevBuf<uint8_t>& block, hipStream_t s, void** staging = nullptr) {
 		if (image.empty()) return;
 		for (const Item& it : items) it.bind(it.buf, nullptr, 0);        // views of the old block go first: ensure() may free it
 		block.ensure(image.size());
-		CKL_HIP(hipMemcpyAsync(block.p, image.data(), image.size(), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
+		if (staging) {
+			if (*staging) host_out_free(*staging);
+			*staging = host_out_alloc(std::max<size_t>(image.size(), 64u << 10));      // >= 64 KiB: pinned
+			memcpy(*staging, image.data(), image.size());
+			upload_small(block.p, *staging, image.size(), s, *staging);
+		}
+		else CKL_HIP(hipMemcpyAsync(block.p, image.data(), image.size(), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
 		for (const Item& it : items) it.bind(it.buf, block.p + it.off, it.count);
 	}
 };
@@ -1678,7 +1700,7 @@ void crack_pass(
 	tables.add(e.t_cobase, cobase); tables.add(e.t_cocap, cocap);
 	tables.add(e.t_ibase, ibase); tables.add(e.t_icap, icap);
 	tables.add(e.t_max_steps, max_steps);
-	tables.commit(e.d_crack_tables, s);
+	tables.commit(e.d_crack_tables, s, &e.tables_staging);
 	HT_MARK("c:tables");
 	e.d_payload.ensure(ptot + 8); e.d_boc.ensure(btot + 8);
 	e.codes_capacity = ptot + btot;
@@ -2787,14 +2809,14 @@ void encode_typed(
 			// ones go up from the host buffer
 			e.d_stream_out.ensure(total + 16);
 			uint8_t* ds = e.d_stream_out.p;
-			CKL_HIP(hipMemcpyAsync(ds, o, off_labels, hipMemcpyHostToDevice, s));
+			upload_small(ds, o, off_labels, s, o);      // (o: a pinned, device-mapped block when the stream is 64 KiB or more)
 			if (label_bytes) {
 				if (head.label_format == FLAT) copy_bytes_device(e.d_labels_bin.p, ds + off_labels, label_bytes, s);
 				else CKL_HIP(hipMemcpyAsync(ds + off_labels, o + off_labels, label_bytes, hipMemcpyHostToDevice, s));
 			}
-			if (!stored_model.empty()) CKL_HIP(hipMemcpyAsync(ds + off_model, o + off_model, stored_model.size(), hipMemcpyHostToDevice, s));
+			if (!stored_model.empty()) upload_small(ds + off_model, o + off_model, stored_model.size(), s, o);
 			if (cr.total) copy_bytes_device(e.d_codes_out.p, ds + off_codes, cr.total, s);
-			CKL_HIP(hipMemcpyAsync(ds + off_tail, o + off_tail, 4ull * (sz + 1), hipMemcpyHostToDevice, s));
+			upload_small(ds + off_tail, o + off_tail, 4ull * (sz + 1), s, o);
 			if (labels_stay) {
 				CKL_HIP(hipStreamWaitEvent(s, e.ev_labels_crc, 0));
 				CKL_HIP(hipMemcpyAsync(ds + off_tail, e.d_labels_crc.p, 4, hipMemcpyDeviceToDevice, s));
