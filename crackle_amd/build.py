@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrackle_amd.so")
-SOURCES = ["ckl_common.hip", "ckl_decode.hip", "ckl_encode.hip", "ckl_pins.hip", "ckl_zstack.hip"]
+SOURCES = ["ckl_common.hip", "ckl_decode.hip", "ckl_encode.hip", "ckl_pins.hip", "ckl_zstack.hip", "ckl_upload.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + [os.path.join("..", "..", "include", "crackle_amd.h")]
 ARCH = os.environ.get("CKL_OFFLOAD_ARCH", "gfx950")
 

@@ -139,6 +139,8 @@ void* host_out_alloc(size_t bytes) {
 	}
 	const size_t cap = bytes < (1u << 20) ? bytes : bytes + bytes / 4;
 	void* p = nullptr;
+	static const bool trace = getenv("CKL_POOL_TRACE") != nullptr;      // diagnostic: allocations that miss the cache, on stderr
+	if (trace) fprintf(stderr, "[ckl pool] new host block of %zu bytes (%zu cached blocks)\n", bytes, g_host_free.size());
 	if (bytes >= (64u << 10) && hipHostMalloc(&p, cap, hipHostMallocDefault) == hipSuccess && p) {
 		std::lock_guard<std::mutex> lock(g_host_mutex);
 		g_host_live.push_back({ p, cap });
@@ -177,7 +179,10 @@ void host_out_free(void* p) {
 		}
 	}
 	if (!b.p) free(p);                       // a plain malloc'd buffer
-	else if (drop) (void)hipHostFree(b.p);
+	else if (drop) {
+		if (getenv("CKL_POOL_TRACE")) fprintf(stderr, "[ckl pool] host block of %zu bytes dropped from the cache\n", b.bytes);
+		(void)hipHostFree(b.p);
+	}
 }
 
 // ---- checksums -------------------------------------------------------------------

@@ -128,6 +128,8 @@ bool host_out_is_pinned(const void* p);    // a block of host_out_alloc that is 
 // the source lies in a pinned, device-mapped block of host_out_alloc (`block`: that block's base pointer) a one-workgroup-
 // per-4-KiB kernel reads it over the link; else hipMemcpyAsync.  (hipMemcpyAsync of 40 KiB from pinned memory was seen to
 // block its caller for 5 - 8 ms once in a few dozen calls on this stack — 9 % of a bench run's value when it happened.)
+// (Defined in ckl_upload.hip, a translation unit of its own — see there.  Callers pass a null `block` for pin-label streams, whose
+// set-up and assembly move tens of megabytes with the copy engines anyway: they keep hipMemcpyAsync.)
 void upload_small(void* dst_device, const void* src_host, size_t bytes, hipStream_t s, const void* block);
 void* pool_alloc(size_t bytes, int* device = nullptr);      // throws Error on failure; *device: the device the block lives on (the current one)
 void pool_free(void* p, size_t bytes, int device = -1);     // returns the block to the pool of its device (-1: the current device)

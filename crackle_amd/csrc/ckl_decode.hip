@@ -97,29 +97,6 @@ struct CrackArgs {
 	uint32_t* overflow;          // strip path: its overflow word, cleared here as well (or null)
 };
 
-// (defined here and not in ckl_common.hip: that file is also compiled as plain C++ by the sanitizer tests)
-namespace {
-__global__ void __launch_bounds__(256) k_upload_small(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes) {
-	const size_t i = (static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x) * 16;
-	if (i >= bytes) return;
-	if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && i + 16 <= bytes) {
-		*reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
-		return;
-	}
-	for (size_t k = i; k < bytes && k < i + 16; k++) dst[k] = src[k];
-}
-}
-
-void upload_small(void* dst_device, const void* src_host, size_t bytes, hipStream_t s, const void* block) {
-	if (bytes == 0) return;
-	if (block && host_out_is_pinned(block) && !getenv("CKL_UPLOAD_MEMCPY")) {
-		hipLaunchKernelGGL(k_upload_small, dim3(static_cast<uint32_t>((bytes + 4095) / 4096)), dim3(256), 0, s,
-			static_cast<const uint8_t*>(src_host), static_cast<uint8_t*>(dst_device), bytes);
-		return;
-	}
-	CKL_HIP(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, s));
-}
-
 // a value all lanes of the wavefront hold alike, as a scalar
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 __device__ __forceinline__ uint32_t rd_le_dev(const uint8_t* p, int w) {
@@ -2626,13 +2603,14 @@ struct DescPacker {
 		items.push_back({ &dst, off, src.size() * sizeof(T), src.size(),
 			[](void* b, uint8_t* base, size_t n) { static_cast<DevBuf<T>*>(b)->borrow(reinterpret_cast<T*>(base), n); } });
 	}
-	void commit(ckl_decoder& d, hipStream_t s) {
+	// by_kernel: see upload_small (flat label streams; pin streams upload their tables with the copy engines anyway)
+	void commit(ckl_decoder& d, hipStream_t s, bool by_kernel) {
 		if (image.empty()) return;
 		d.d_desc.ensure(image.size());
 		if (d.desc_staging) host_out_free(d.desc_staging);
 		d.desc_staging = host_out_alloc(std::max<size_t>(image.size(), 64u << 10));      // >= 64 KiB: pinned
 		memcpy(d.desc_staging, image.data(), image.size());
-		upload_small(d.d_desc.p, d.desc_staging, image.size(), s, d.desc_staging);
+		upload_small(d.d_desc.p, d.desc_staging, image.size(), s, by_kernel ? d.desc_staging : nullptr);
 		for (const Item& it : items) it.bind(it.buf, d.d_desc.p + it.off, it.count);
 	}
 };
@@ -3076,7 +3054,7 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 			CKL_HIP(hipMemcpyAsync(d.d_ccl_label.p, ccl_label, C * 8, hipMemcpyHostToDevice, s));
 		}
 	}
-	pack.commit(d, s);
+	pack.commit(d, s, h.label_format == FLAT);
 	// the caller's host stream and the pin tables above are copied from memory that is not ours to keep
 	if (!stream_device || h.label_format != FLAT) CKL_HIP(hipStreamSynchronize(s));
 	else d.pending_upload = true;      // (the descriptors' packed copy is still on its way: the first run orders itself behind it, ckl_decoder_destroy waits for it)

@@ -1298,6 +1298,7 @@ struct ckl_encoder {
 	hipStream_t stream_tab = nullptr;   // the pin stage's label lists come to the host beside the passes of the label stream
 	hipEvent_t ev_codes = nullptr;
 	void* tables_staging = nullptr;              // pinned host image of d_crack_tables (crack_pass: UploadPacker::commit)
+	bool uploads_by_kernel = false;              // this run's small uploads go by upload_small's kernel (flat label streams)
 	hipEvent_t ev_labels_crc = nullptr;          // the label section's crc32c stands in d_labels_crc (device-resident streams: ckl_encoder_run)
 	DevBuf<uint32_t> d_labels_crc;               // [0]: the crc, [1 ..]: the workgroups' states
 	DevBuf<uint8_t> d_stream_out;       // ... here (valid until the next run)
@@ -1700,7 +1701,7 @@ void crack_pass(
 	tables.add(e.t_cobase, cobase); tables.add(e.t_cocap, cocap);
 	tables.add(e.t_ibase, ibase); tables.add(e.t_icap, icap);
 	tables.add(e.t_max_steps, max_steps);
-	tables.commit(e.d_crack_tables, s, &e.tables_staging);
+	tables.commit(e.d_crack_tables, s, e.uploads_by_kernel ? &e.tables_staging : nullptr);
 	HT_MARK("c:tables");
 	e.d_payload.ensure(ptot + 8); e.d_boc.ensure(btot + 8);
 	e.codes_capacity = ptot + btot;
@@ -2622,6 +2623,7 @@ void encode_typed(
 	}
 	if (sz == 1 || !allow_pins) head.label_format = FLAT;           // crackle.hpp:62-64
 	if (ov && ov->force_label_format >= 0) head.label_format = ov->force_label_format;
+	e.uploads_by_kernel = head.label_format == FLAT;
 	head.is_signed = false;
 	head.data_width = static_cast<int>(sizeof(LABEL));
 	head.stored_data_width = stored_width;
@@ -2809,14 +2811,15 @@ void encode_typed(
 			// ones go up from the host buffer
 			e.d_stream_out.ensure(total + 16);
 			uint8_t* ds = e.d_stream_out.p;
-			upload_small(ds, o, off_labels, s, o);      // (o: a pinned, device-mapped block when the stream is 64 KiB or more)
+			const void* up = head.label_format == FLAT ? o : nullptr;      // (by kernel for flat label streams only, see upload_small; o: a pinned, device-mapped block when the stream is 64 KiB or more)
+			upload_small(ds, o, off_labels, s, up);
 			if (label_bytes) {
 				if (head.label_format == FLAT) copy_bytes_device(e.d_labels_bin.p, ds + off_labels, label_bytes, s);
 				else CKL_HIP(hipMemcpyAsync(ds + off_labels, o + off_labels, label_bytes, hipMemcpyHostToDevice, s));
 			}
-			if (!stored_model.empty()) upload_small(ds + off_model, o + off_model, stored_model.size(), s, o);
+			if (!stored_model.empty()) upload_small(ds + off_model, o + off_model, stored_model.size(), s, up);
 			if (cr.total) copy_bytes_device(e.d_codes_out.p, ds + off_codes, cr.total, s);
-			upload_small(ds + off_tail, o + off_tail, 4ull * (sz + 1), s, o);
+			upload_small(ds + off_tail, o + off_tail, 4ull * (sz + 1), s, up);
 			if (labels_stay) {
 				CKL_HIP(hipStreamWaitEvent(s, e.ev_labels_crc, 0));
 				CKL_HIP(hipMemcpyAsync(ds + off_tail, e.d_labels_crc.p, 4, hipMemcpyDeviceToDevice, s));
