@@ -2994,6 +2994,11 @@ void decoder_build(ckl_decoder& d, const uint8_t* buf, uint64_t n, int64_t z_sta
 				cc_base[label + 1] = cc_base[label] + num_cc;
 				i = j + npw + num_cc * static_cast<uint64_t>(ccw);
 			}
+			// The records must end where the section does.  They do not for the sections the reference's encoder writes when a
+			// label has more than 255 single-component ids while no label has 256 pins (the count shares the pins' field width
+			// and overflows it: labels.hpp:209-229, tools/repro_pins_u8.py): the reference then returns labels read out of
+			// step; this decoder refuses.
+			if (i != nlb) throw Error(CKL_ERR_RUNTIME, "crackle: pin section is malformed or corrupted (its records do not end with the section: a count field overflowed?).");
 		}
 		const uint64_t P = pin_base[nu], C = cc_base[nu];
 		pin_block.p = static_cast<uint8_t*>(host_out_alloc((4 * std::max<uint64_t>(P, 1) + 2 * std::max<uint64_t>(C, 1)) * 8));

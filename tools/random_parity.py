@@ -63,7 +63,12 @@ def main():
     want = chk.compress(arr, **kw)
     got = crackle_amd.compress(arr, **{k: (1 if k == "allow_pins" else v) for k, v in kw.items()})
     ok = got == want
-    back = crackle_amd.decompress(want)
+    try:
+      back = crackle_amd.decompress(want)
+    except RuntimeError as exc:      # (the reference's own pin-section overflow is refused: tools/repro_pins_u8.py)
+      print("REFUSED", tag, str(exc)[:100], flush=True)
+      bad += 1
+      continue
     ok = ok and back.shape == arr.shape and np.array_equal(back, arr)
     if i % 3 == 0 and arr.size:
       u, c = np.unique(arr, return_counts=True)
