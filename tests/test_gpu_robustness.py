@@ -69,3 +69,22 @@ def test_overrides_that_force_nothing_use_the_cached_volume_statistics(checker):
     L.ckl_free(out)
     L.ckl_encoder_destroy(enc)
     assert got == want, np.dtype(dt).name
+
+
+@pytest.mark.gpu
+def test_the_references_overflowed_pin_section_is_refused(checker):
+  """The reference's pin encoder writes the count of a label's single-component ids in a field sized from the labels' pin
+  counts (src/labels.hpp:209-229): 1024 x 248 x 4 uint8 voxels of 4 x 4 x 2 cells give a label 261 such ids beside fewer
+  than 256 pins per label, the one-byte count overflows and the reference decodes its own stream to wrong labels
+  (tools/repro_pins_u8.py).  The encoder here writes the same bytes (bit-exact); the decoder refuses them."""
+  shape = (1024, 248, 4)
+  arr = synth.as_numpy_f(synth.voronoi_labels(shape, np.uint8, seed=11, cell=(4, 4, 2)))
+  want = checker.compress(arr, allow_pins=True)
+  assert crackle_amd.compress(arr, allow_pins=True) == want
+  with pytest.raises(RuntimeError, match="pin section is malformed"):
+    crackle_amd.decompress(want)
+  # one slice less and every count fits: the same geometry round-trips
+  arr3 = np.asfortranarray(arr[:, :, :3])
+  want3 = checker.compress(arr3, allow_pins=True)
+  assert crackle_amd.compress(arr3, allow_pins=True) == want3
+  assert np.array_equal(crackle_amd.decompress(want3), arr3)
